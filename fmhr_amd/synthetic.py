@@ -1,0 +1,138 @@
+"""Deterministic synthetic HAM workloads: MANO-like open-wrist blob mesh, Fibonacci-sphere cameras with the
+reference's projection convention (/root/reference/get_data.py:64-73,96-97), and hyper-parameters of conf/demo_sfs.conf.
+
+Host-side numpy only (no rendering here): targets are rendered by whoever owns a renderer (the HIP path in bench/tests,
+the CPU oracle in CPU tests) through `make_targets`.
+"""
+import math
+
+import numpy as np
+import torch
+
+# /root/reference/conf/demo_sfs.conf:16-29
+DEMO_WEIGHTS = dict(sfs=50.0, albedo=1.0, lap=2000.0, mask=1000.0, edge=500000.0, delta=50000.0)
+DEMO_LR = dict(lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
+# half extents of the MANO template bounding box
+SEMI_AXES = (0.0965, 0.0306, 0.0838)
+
+CONFIGS = {
+    # name: (views, H, W, rings, segments)
+    "C1": (1, 256, 256, 24, 32),
+    "C2": (8, 512, 334, 24, 32),
+    "C3": (16, 512, 512, 192, 256),
+    "metric": (48, 512, 512, 192, 256),
+    "C4": (48, 1024, 1024, 192, 256),
+}
+
+
+def blob_mesh(rings, segs, seed=0, bump=0.10):
+    """Open-wrist UV blob: closed top pole, open bottom => disc topology like MANO.  V = rings*segs+1,
+    F = segs + 2*segs*(rings-1).  rings=192, segs=256 -> V=49153, F=98048 (MANO sub3: 49281 / 98432)."""
+    rng = np.random.default_rng(seed)
+    th_max = 0.86 * math.pi
+    i = np.arange(1, rings + 1, dtype=np.float64)[:, None]
+    j = np.arange(segs, dtype=np.float64)[None, :]
+    th = th_max * i / rings
+    ph = 2 * math.pi * j / segs
+    # seeded low-frequency radial displacement (concavities / self-occlusion)
+    disp = np.zeros_like(th * ph)
+    for _ in range(6):
+        kt, kp = rng.integers(1, 4), rng.integers(1, 5)
+        a, p0, p1 = rng.uniform(0.3, 1.0), rng.uniform(0, 2 * math.pi), rng.uniform(0, 2 * math.pi)
+        disp = disp + a * np.sin(kt * th + p0) * np.cos(kp * ph + p1) * np.sin(th)
+    disp = 1.0 + bump * disp / max(1e-9, np.abs(disp).max())
+    # pole on the long axis (finger tips), opening at the wrist end
+    d = np.stack([np.cos(th) * np.ones_like(ph), np.sin(th) * np.sin(ph), np.sin(th) * np.cos(ph)], -1) * disp[..., None]
+    verts = np.concatenate([np.array([[1.0, 0.0, 0.0]]), d.reshape(-1, 3)], 0) * np.array(SEMI_AXES)
+    faces = []
+    ring0 = 1 + np.arange(segs)
+    nxt = 1 + (np.arange(segs) + 1) % segs
+    faces.append(np.stack([np.zeros(segs, dtype=np.int64), ring0, nxt], 1))
+    for r in range(1, rings):
+        a0, b0 = (r - 1) * segs, r * segs
+        faces.append(np.stack([a0 + ring0, b0 + ring0, b0 + nxt], 1))
+        faces.append(np.stack([a0 + ring0, b0 + nxt, a0 + nxt], 1))
+    faces = np.concatenate(faces, 0)
+    return verts.astype(np.float32), faces.astype(np.int32)
+
+
+def fibonacci_dirs(n):
+    k = np.arange(n) + 0.5
+    z = 1 - 2 * k / n
+    r = np.sqrt(np.maximum(0, 1 - z * z))
+    ph = k * math.pi * (3 - math.sqrt(5))
+    return np.stack([r * np.cos(ph), r * np.sin(ph), z], 1)
+
+
+def cameras(verts, n, H, W, coverage=0.25, dist=0.6):
+    """n OpenCV-convention cameras on a Fibonacci sphere looking at the centroid.  Returns (w2c, proj) float32 [n,4,4]
+    stored TRANSPOSED for the reference's row-vector convention (get_data.py:96-97), focal chosen per view so the
+    projected mesh covers ~`coverage` of the image."""
+    c = verts.mean(0).astype(np.float64)
+    w2cs, projs = [], []
+    for d in fibonacci_dirs(n):
+        eye = c + dist * d
+        fwd = (c - eye) / np.linalg.norm(c - eye)
+        up = np.array([0.0, 0.0, 1.0]) if abs(fwd[2]) < 0.95 else np.array([0.0, 1.0, 0.0])
+        right = np.cross(fwd, up)
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        R = np.stack([right, down, fwd], 0)          # world -> camera rows (x right, y down, z forward)
+        t = -R @ eye
+        w2c = np.eye(4)
+        w2c[:3, :3], w2c[:3, 3] = R, t
+        pc = (verts.astype(np.float64) @ R.T + t)
+        xy = pc[:, :2] / pc[:, 2:3]
+        ev = np.linalg.eigvalsh(np.cov(xy.T))
+        area_unit = math.pi * 4.0 * math.sqrt(max(ev[0], 1e-12) * max(ev[1], 1e-12))   # ellipse with radii 2 sigma
+        f = math.sqrt(coverage * H * W / area_unit)
+        ctr = xy.mean(0)
+        cx, cy = W / 2.0 - f * ctr[0], H / 2.0 - f * ctr[1]
+        proj = np.zeros((4, 4))
+        proj[0, 0], proj[0, 2] = f / (W / 2.0), cx / (W / 2.0) - 1.0
+        proj[1, 1], proj[1, 2] = f / (H / 2.0), cy / (H / 2.0) - 1.0
+        proj[2, 3] = -0.1
+        proj[3, 2] = 1.0
+        w2cs.append(w2c.T)
+        projs.append(proj.T)
+    return np.stack(w2cs).astype(np.float32), np.stack(projs).astype(np.float32)
+
+
+def make_scene(views, H, W, rings, segs, seed=0, coverage=0.25):
+    """Everything the stage-2 loop needs except the rendered targets (see make_targets)."""
+    rng = np.random.default_rng(seed)
+    verts, faces = blob_mesh(rings, segs, seed)
+    w2c, proj = cameras(verts, views, H, W, coverage)
+    V = verts.shape[0]
+    sh_true = np.concatenate([np.full((views, 1), 0.8), 0.1 * rng.standard_normal((views, 8))], 1).astype(np.float32)
+    albedo_true = rng.uniform(0.3, 0.9, (V, 3)).astype(np.float32)
+    verts_true = (verts + 0.0005 * rng.standard_normal(verts.shape)).astype(np.float32)
+    sh0 = (sh_true + 0.02 * rng.standard_normal(sh_true.shape)).astype(np.float32)
+    albedo0 = np.full((V, 3), 0.6, dtype=np.float32)
+    t = torch.from_numpy
+    return dict(views=views, H=H, W=W, V=V, F=faces.shape[0],
+                vertices=t(verts), faces=t(faces), w2c=t(w2c), proj=t(proj),
+                vertices_true=t(verts_true), albedo_true=t(albedo_true), sh_true=t(sh_true),
+                albedo0=t(albedo0), sh0=t(sh0), weights=dict(DEMO_WEIGHTS), lr=dict(DEMO_LR))
+
+
+def scene_from_config(name, seed=0, views=None):
+    v, H, W, r, c = CONFIGS[name]
+    return make_scene(views or v, H, W, r, c, seed)
+
+
+def make_targets(scene, forward_fn, device=None):
+    """Render the targets with the caller's renderer.  forward_fn(vertices[V,3], albedo[V,3], sh[n,9], mask[n,H,W]) must
+    return dict(tmp_img [n,H,W,3], pred_mask [n,H,W], rast [n,H,W,4]) — the stage-2 forward of the reference.
+    img = shaded render of the perturbed copy; mask = its coverage; valid_mask = AA silhouette of the START mesh
+    (mesh_sfs_optim.py:146,158)."""
+    n, H, W = scene["views"], scene["H"], scene["W"]
+    dev = device or scene["vertices"].device
+    ones = torch.ones(n, H, W, dtype=torch.float32, device=dev)
+    tgt = forward_fn(scene["vertices_true"].to(dev), scene["albedo_true"].to(dev), scene["sh_true"].to(dev), ones)
+    img = tgt["tmp_img"].detach().clone()
+    mask = (tgt["rast"][..., 3] > 0).to(torch.float32)
+    start = forward_fn(scene["vertices"].to(dev), scene["albedo0"].to(dev), scene["sh0"].to(dev), ones)
+    valid_mask = start["pred_mask"].detach().clone()
+    cov = float((start["rast"][..., 3] > 0).to(torch.float32).mean())
+    return dict(img=img, mask=mask, valid_mask=valid_mask, coverage=cov)

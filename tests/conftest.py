@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_helpers.npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ham_oracle
+    ham_oracle.lib()
+    return ham_oracle
