@@ -1,0 +1,515 @@
+// fmhr_amd/csrc/antialias.hip — mesh topology tables and silhouette antialiasing, forward + backward, for gfx950.
+// Replaces dr.antialias of nvdiffrast as called at /root/reference/mesh_sfs_optim.py:274,287 (and its per-call edge hash).
+//
+// Forward: one lane per pixel looks at its right and lower neighbour; a pair with different triangle ids is analysed on the
+// spot and, if a silhouette edge crosses between the two centres, blended with float atomics and
+// appended to the work queue by wave64 ballot + popcount prefix (one queue atomic per wave).  Only pairs that actually
+// blend are queued, so the queue length is proportional to the silhouette length, not to the number of triangle seams.
+#include "common.h"
+#include <float.h>
+
+namespace fmhr {
+
+// ------------------------------------------------------------------------------------------------ edge hash (topology)
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr int kNoCode = 0x7fffffff;
+
+struct EdgeSlot { unsigned long long key; int c0; int c1; };
+
+__device__ __forceinline__ unsigned hash_u64(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return (unsigned)k;
+}
+
+__device__ __forceinline__ unsigned long long edge_key(const int32_t* tri, int code)
+{
+    int f = code / 3, k = code - f * 3;
+    int a = tri[f * 3 + (k + 1) % 3], b = tri[f * 3 + (k + 2) % 3];
+    unsigned lo = (unsigned)min(a, b), hi = (unsigned)max(a, b);
+    return ((unsigned long long)lo << 32) | hi;
+}
+
+__global__ void k_hash_clear(EdgeSlot* tab, unsigned T)
+{
+    unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < T) { tab[i].key = kEmptyKey; tab[i].c0 = kNoCode; tab[i].c1 = kNoCode; }
+}
+
+__global__ void k_hash_insert(const int32_t* __restrict__ tri, int F, EdgeSlot* tab, unsigned mask)
+{
+    int code = blockIdx.x * kBlock + threadIdx.x;
+    if (code >= 3 * F) return;
+    unsigned long long key = edge_key(tri, code);
+    unsigned h = hash_u64(key) & mask;
+    for (unsigned probe = 0; probe <= mask; probe++) {
+        unsigned long long old = atomicCAS(&tab[h].key, kEmptyKey, key);
+        if (old == kEmptyKey || old == key) { atomicMin(&tab[h].c0, code); return; }
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int hash_find(const EdgeSlot* tab, unsigned mask, unsigned long long key)
+{
+    unsigned h = hash_u64(key) & mask;
+    for (unsigned probe = 0; probe <= mask; probe++) {
+        unsigned long long k = tab[h].key;
+        if (k == key) return (int)h;
+        if (k == kEmptyKey) return -1;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+__global__ void k_hash_second(const int32_t* __restrict__ tri, int F, EdgeSlot* tab, unsigned mask)
+{
+    int code = blockIdx.x * kBlock + threadIdx.x;
+    if (code >= 3 * F) return;
+    int s = hash_find(tab, mask, edge_key(tri, code));
+    if (s >= 0 && tab[s].c0 != code) atomicMin(&tab[s].c1, code);
+}
+
+__global__ void k_hash_opp(const int32_t* __restrict__ tri, int F, const EdgeSlot* tab, unsigned mask, int32_t* __restrict__ opp)
+{
+    int code = blockIdx.x * kBlock + threadIdx.x;
+    if (code >= 3 * F) return;
+    int s = hash_find(tab, mask, edge_key(tri, code));
+    int r = -1;
+    if (s >= 0) {
+        int a = tab[s].c0, b = tab[s].c1;
+        int oa = tri[a], ob = (b == kNoCode) ? -1 : tri[b];
+        r = (oa == tri[code]) ? ob : oa;
+    }
+    opp[code] = r;
+}
+
+// ------------------------------------------------------------------------------------------------ adjacency CSR
+__global__ void k_adj_degree(const EdgeSlot* tab, unsigned T, int V, int* deg)
+{
+    unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T || tab[i].key == kEmptyKey) return;
+    int lo = (int)(tab[i].key >> 32), hi = (int)(tab[i].key & 0xffffffffu);
+    if (lo == hi || lo >= V || hi >= V) return;
+    atomicAdd(&deg[lo], 1);
+    atomicAdd(&deg[hi], 1);
+}
+
+// single-workgroup exclusive scan (V is at most a few 1e5; runs once per mesh)
+__global__ void __launch_bounds__(1024) k_scan_exclusive(const int* __restrict__ in, int n, int* __restrict__ out)
+{
+    __shared__ int sm[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = (i < n) ? in[i] : 0;
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int t = (threadIdx.x >= o) ? sm[threadIdx.x - o] : 0;
+            __syncthreads();
+            sm[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) out[i] = carry + sm[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += sm[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+__global__ void k_adj_fill(const EdgeSlot* tab, unsigned T, int V, const int* __restrict__ row_ptr, int* cursor, int* col)
+{
+    unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T || tab[i].key == kEmptyKey) return;
+    int lo = (int)(tab[i].key >> 32), hi = (int)(tab[i].key & 0xffffffffu);
+    if (lo == hi || lo >= V || hi >= V) return;
+    col[row_ptr[lo] + atomicAdd(&cursor[lo], 1)] = hi;
+    col[row_ptr[hi] + atomicAdd(&cursor[hi], 1)] = lo;
+}
+
+__global__ void k_adj_sort_rows(int V, const int* __restrict__ row_ptr, int* col)
+{
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= V) return;
+    int a = row_ptr[v], b = row_ptr[v + 1];
+    for (int i = a + 1; i < b; i++) {
+        int x = col[i], j = i - 1;
+        while (j >= a && col[j] > x) { col[j + 1] = col[j]; j--; }
+        col[j + 1] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ antialias analysis
+constexpr int AA_DOWN = 4, AA_TRI1 = 8, AA_FOUND = 16, AA_CLAMPED = 32;
+
+__device__ __forceinline__ bool same_sign(float a, float b) { return (int)(__float_as_uint(a) ^ __float_as_uint(b)) >= 0; }
+
+__device__ __forceinline__ bool rational_gt(float n0, float n1, float d0, float d1)
+{
+    float dd = d0 * d1;
+    float l = n0 * d1;
+    float r = n1 * d0;
+    if (dd < 0.0f) return l < r;
+    return l > r;
+}
+
+__device__ __forceinline__ int max_idx3(float n0, float n1, float n2, float d0, float d1, float d2)
+{
+    bool g10 = rational_gt(n1, n0, d1, d0);
+    bool g20 = rational_gt(n2, n0, d2, d0);
+    bool g21 = rational_gt(n2, n1, d2, d1);
+    if (g20 && g21) return 2;
+    if (g10) return 1;
+    return 0;
+}
+
+// Analyse the pixel pair ((px,py), (px+1-d, py+d)) of view b.  z0/id0 and z1/id1 are rast.z / rast.w of the two pixels.
+// Returns the work-item code (0 = no blend) and alpha.  Statement-for-statement fp32 (no contraction).
+__device__ __forceinline__ int aa_analyse(const float* __restrict__ posv, const int32_t* __restrict__ tri,
+                                          const int32_t* __restrict__ opp, int V, int F, int H, int W,
+                                          int px, int py, int d, float z0, float id0, float z1, float id1, float& alpha_out)
+{
+    int tri0 = (int)id0 - 1, tri1 = (int)id1 - 1;
+    int t = (tri0 >= 0) ? tri0 : tri1;
+    if (tri0 >= 0 && tri1 >= 0) t = (z0 < z1) ? tri0 : tri1;
+    int qx = px, qy = py;
+    if (t == tri1) { qx += 1 - d; qy += d; }
+    if (t < 0 || t >= F) return 0;
+    int vi0 = tri[t * 3], vi1 = tri[t * 3 + 1], vi2 = tri[t * 3 + 2];
+    if ((unsigned)vi0 >= (unsigned)V || (unsigned)vi1 >= (unsigned)V || (unsigned)vi2 >= (unsigned)V) return 0;
+    int op0 = opp[t * 3], op1 = opp[t * 3 + 1], op2 = opp[t * 3 + 2];
+    const float4 p0 = ldg4(posv + (size_t)vi0 * 4), p1 = ldg4(posv + (size_t)vi1 * 4), p2 = ldg4(posv + (size_t)vi2 * 4);
+    const float4 o0 = (op0 < 0) ? p0 : ldg4(posv + (size_t)op0 * 4);
+    const float4 o1 = (op1 < 0) ? p1 : ldg4(posv + (size_t)op1 * 4);
+    const float4 o2 = (op2 < 0) ? p2 : ldg4(posv + (size_t)op2 * 4);
+    float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
+    float w0 = 1.0f / p0.w, w1 = 1.0f / p1.w, w2 = 1.0f / p2.w;
+    float ow0 = 1.0f / o0.w, ow1 = 1.0f / o1.w, ow2 = 1.0f / o2.w;
+    float fx = (float)qx + 0.5f; fx = fx - xh;
+    float fy = (float)qy + 0.5f; fy = fy - yh;
+    float m;
+    m = p0.x * w0; m = m * xh; float x0 = m - fx;    m = p0.y * w0; m = m * yh; float y0 = m - fy;
+    m = p1.x * w1; m = m * xh; float x1 = m - fx;    m = p1.y * w1; m = m * yh; float y1 = m - fy;
+    m = p2.x * w2; m = m * xh; float x2 = m - fx;    m = p2.y * w2; m = m * yh; float y2 = m - fy;
+    m = o0.x * ow0; m = m * xh; float ox0 = m - fx;  m = o0.y * ow0; m = m * yh; float oy0 = m - fy;
+    m = o1.x * ow1; m = m * xh; float ox1 = m - fx;  m = o1.y * ow1; m = m * yh; float oy1 = m - fy;
+    m = o2.x * ow2; m = m * xh; float ox2 = m - fx;  m = o2.y * ow2; m = m * yh; float oy2 = m - fy;
+    float e0, e1, e2, e3, l, r;
+    e0 = x1 - x0;  e1 = y2 - y0;  e2 = x2 - x0;  e3 = y1 - y0;  l = e0 * e1; r = e2 * e3; float bb = l - r;
+    e0 = x1 - ox0; e1 = y2 - oy0; e2 = x2 - ox0; e3 = y1 - oy0; l = e0 * e1; r = e2 * e3; float a0 = l - r;
+    e0 = x2 - ox1; e1 = y0 - oy1; e2 = x0 - ox1; e3 = y2 - oy1; l = e0 * e1; r = e2 * e3; float a1 = l - r;
+    e0 = x0 - ox2; e1 = y1 - oy2; e2 = x1 - ox2; e3 = y0 - oy2; l = e0 * e1; r = e2 * e3; float a2 = l - r;
+    bool s0 = same_sign(a0, bb), s1 = same_sign(a1, bb), s2 = same_sign(a2, bb);
+    if (!(s0 || s1 || s2)) return 0;
+    if (d) { float tt; tt = x0; x0 = y0; y0 = tt; tt = x1; x1 = y1; y1 = tt; tt = x2; x2 = y2; y2 = tt; }
+    float dx0 = x2 - x1, dx1 = x0 - x2, dx2 = x1 - x0;
+    float dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;
+    float ds = (t == tri0) ? 1.0f : -1.0f;
+    l = x1 * dy0; r = y1 * dx0; float d0 = l - r; d0 = ds * d0;
+    l = x2 * dy1; r = y2 * dx1; float d1 = l - r; d1 = ds * d1;
+    l = x0 * dy2; r = y0 * dx2; float d2 = l - r; d2 = ds * d2;
+    const float NEG = -FLT_MAX;
+    if (same_sign(y1, y2)) { d0 = NEG; dy0 = 1.0f; }
+    if (same_sign(y2, y0)) { d1 = NEG; dy1 = 1.0f; }
+    if (same_sign(y0, y1)) { d2 = NEG; dy2 = 1.0f; }
+    int di = max_idx3(d0, d1, d2, dy0, dy1, dy2);
+    float dc = NEG;
+    if (di == 0 && s0 && fabsf(dy0) >= fabsf(dx0)) dc = d0 / dy0;
+    if (di == 1 && s1 && fabsf(dy1) >= fabsf(dx1)) dc = d1 / dy1;
+    if (di == 2 && s2 && fabsf(dy2) >= fabsf(dx2)) dc = d2 / dy2;
+    const float eps = 0.0625f;
+    if (!(dc > -eps && dc < 1.0f + eps)) return 0;
+    int code = di | (d ? AA_DOWN : 0) | ((t == tri0) ? 0 : AA_TRI1) | AA_FOUND;
+    if (dc < 0.0f) { dc = 0.0f; code |= AA_CLAMPED; }
+    if (dc > 1.0f) { dc = 1.0f; code |= AA_CLAMPED; }
+    float al = 0.5f - dc;
+    al = ds * al;
+    alpha_out = al;
+    return code;
+}
+
+// append one item per flagged lane with a single queue atomic per wave
+__device__ __forceinline__ void queue_push(bool has, int4 item, float alpha, int32_t* counter, int cap,
+                                           int4* __restrict__ items, float* __restrict__ alphas)
+{
+    unsigned long long bal = __ballot(has);
+    if (bal == 0) return;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)bal) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(bal));
+    base = __shfl(base, leader, 64);
+    if (has) {
+        int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (slot < cap) { items[slot] = item; alphas[slot] = alpha; }
+        else counter[1] = 1;
+    }
+}
+
+template <int CA, int CB>
+__global__ void __launch_bounds__(kBlock)
+k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, const float4* __restrict__ rast,
+         const float* __restrict__ pos, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
+         int n, int V, int F, int H, int W, int Cdyn, float* __restrict__ outA, float* __restrict__ outB,
+         int4* __restrict__ items, float* __restrict__ alphas, int32_t* counter, int cap)
+{
+    long long P = (long long)H * W;
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    bool live = gid < (long long)n * P;
+    int b = 0, px = 0, py = 0;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        b = (int)(gid / P);
+        int rem = (int)(gid - (long long)b * P);
+        py = rem / W; px = rem - py * W;
+        r0 = rast[gid];
+    }
+    const float* posv = pos + (size_t)b * V * 4;
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        bool has = false;
+        float alpha = 0.f;
+        int code = 0;
+        long long gid1 = gid + (d ? W : 1);
+        if (live && (d ? (py + 1 < H) : (px + 1 < W))) {
+            float4 r1 = rast[gid1];
+            if (r1.w != r0.w) {
+                code = aa_analyse(posv, tri, opp, V, F, H, W, px, py, d, r0.z, r0.w, r1.z, r1.w, alpha);
+                has = code != 0;
+            }
+        }
+        if (has) {
+            long long tgt = (alpha > 0.f) ? gid : gid1;
+            const int C = (CA > 0) ? CA : Cdyn;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                float dcol = colorA[gid1 * C + c] - colorA[gid * C + c];
+                if (dcol != 0.f) atomicAdd(outA + tgt * C + c, alpha * dcol);
+            }
+            if (CB > 0) {
+#pragma unroll
+                for (int c = 0; c < CB; c++) {
+                    float dcol = colorB[gid1 * CB + c] - colorB[gid * CB + c];
+                    if (dcol != 0.f) atomicAdd(outB + tgt * CB + c, alpha * dcol);
+                }
+            }
+        }
+        queue_push(has, make_int4(px, py, b, code), alpha, counter, cap, items, alphas);
+    }
+}
+
+// backward over the queue: colour gradients (+-alpha * dy[target]) and the position gradient of the crossing point
+template <int CA, int CB>
+__global__ void __launch_bounds__(kBlock)
+k_aa_bwd(const float* __restrict__ colorA, const float* __restrict__ colorB, const float4* __restrict__ rast,
+         const float* __restrict__ pos, const int32_t* __restrict__ tri, const float* __restrict__ dyA,
+         const float* __restrict__ dyB, const int4* __restrict__ items, const float* __restrict__ alphas,
+         const int32_t* __restrict__ counter, int cap, int n, int V, int H, int W, int Cdyn,
+         float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos)
+{
+    int cnt = min(counter[0], cap);
+    const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < cnt; k += gridDim.x * kBlock) {
+        int4 it = items[k];
+        int px = it.x, py = it.y, b = it.z, code = it.w;
+        int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
+        float alpha = alphas[k];
+        long long pix0 = ((long long)b * H + py) * W + px;
+        long long pix1 = pix0 + (d ? W : 1);
+        long long tgt = (alpha > 0.f) ? pix0 : pix1;
+        float galpha = 0.f;
+        const int C = (CA > 0) ? CA : Cdyn;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            float g = dyA[tgt * C + c];
+            galpha += g * (colorA[pix1 * C + c] - colorA[pix0 * C + c]);
+            if (gcolorA != nullptr && g != 0.f) {
+                atomicAdd(gcolorA + pix1 * C + c, alpha * g);
+                atomicAdd(gcolorA + pix0 * C + c, -alpha * g);
+            }
+        }
+        if (CB > 0) {
+#pragma unroll
+            for (int c = 0; c < CB; c++) {
+                float g = dyB[tgt * CB + c];
+                galpha += g * (colorB[pix1 * CB + c] - colorB[pix0 * CB + c]);
+                if (gcolorB != nullptr && g != 0.f) {
+                    atomicAdd(gcolorB + pix1 * CB + c, alpha * g);
+                    atomicAdd(gcolorB + pix0 * CB + c, -alpha * g);
+                }
+            }
+        }
+        if ((code & AA_CLAMPED) || galpha == 0.f) continue;
+        int t = (int)rast[(code & AA_TRI1) ? pix1 : pix0].w - 1;
+        int qx = px, qy = py;
+        if (code & AA_TRI1) { qx += 1 - d; qy += d; }
+        int e1 = di + 1; if (e1 >= 3) e1 -= 3;
+        int e2 = di + 2; if (e2 >= 3) e2 -= 3;
+        int va = tri[t * 3 + e1], vb = tri[t * 3 + e2];
+        const float4 pa = ldg4(pos + ((size_t)b * V + va) * 4), pb = ldg4(pos + ((size_t)b * V + vb) * 4);
+        float fx = (float)qx + 0.5f - xh, fy = (float)qy + 0.5f - yh;
+        float wa = 1.0f / pa.w, wb = 1.0f / pb.w;
+        float xa = pa.x * wa * xh - fx, ya = pa.y * wa * yh - fy;
+        float xb = pb.x * wb * xh - fx, yb = pb.y * wb * yh - fy;
+        if (d) { float tt; tt = xa; xa = ya; ya = tt; tt = xb; xb = yb; yb = tt; }
+        float gxc = -galpha;
+        float iden = 1.0f / (ya - yb);
+        float tpar = ya * iden;
+        float g_xa = gxc * (1.0f - tpar), g_xb = gxc * tpar;
+        float g_t = gxc * (xb - xa);
+        float g_ya = g_t * (-yb * iden * iden), g_yb = g_t * (ya * iden * iden);
+        if (d) { float tt; tt = g_xa; g_xa = g_ya; g_ya = tt; tt = g_xb; g_xb = g_yb; g_yb = tt; }
+        float* qa = gpos + ((size_t)b * V + va) * 4;
+        float* qb = gpos + ((size_t)b * V + vb) * 4;
+        atomicAdd(qa + 0, g_xa * xh * wa); atomicAdd(qa + 1, g_ya * yh * wa);
+        atomicAdd(qa + 3, -(g_xa * pa.x * xh + g_ya * pa.y * yh) * wa * wa);
+        atomicAdd(qb + 0, g_xb * xh * wb); atomicAdd(qb + 1, g_yb * yh * wb);
+        atomicAdd(qb + 3, -(g_xb * pb.x * xh + g_yb * pb.y * yh) * wb * wb);
+    }
+}
+
+static unsigned table_size(int F)
+{
+    unsigned T = 64;
+    while ((long long)T < 6ll * F) T <<= 1;
+    return T;
+}
+
+static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipStream_t st)
+{
+    k_hash_clear<<<cdiv(T, kBlock), kBlock, 0, st>>>(tab, T);
+    FMHR_CHECK_LAUNCH("k_hash_clear");
+    if (F > 0) {
+        k_hash_insert<<<cdiv(3ll * F, kBlock), kBlock, 0, st>>>(tri, F, tab, T - 1);
+        FMHR_CHECK_LAUNCH("k_hash_insert");
+        k_hash_second<<<cdiv(3ll * F, kBlock), kBlock, 0, st>>>(tri, F, tab, T - 1);
+        FMHR_CHECK_LAUNCH("k_hash_second");
+    }
+    return FMHR_OK;
+}
+
+// fused-step entry points (ham_step.hip)
+int aa_fwd_dual(const float* mask_col, const float* img_col, const float* rast, const float* pos, const int32_t* tri,
+                const int32_t* opp, int n, int V, int F, int H, int W, float* out_mask, float* out_img, int32_t* items,
+                float* alphas, int32_t* counter, int cap, hipStream_t st)
+{
+    long long nP = (long long)n * H * W;
+    k_aa_fwd<1, 3><<<cdiv(nP, kBlock), kBlock, 0, st>>>(mask_col, img_col, (const float4*)rast, pos, tri, opp, n, V, F, H, W, 1,
+                                                       out_mask, out_img, (int4*)items, alphas, counter, cap);
+    FMHR_CHECK_LAUNCH("k_aa_fwd<1,3>");
+    return FMHR_OK;
+}
+
+int aa_bwd_dual(const float* mask_col, const float* img_col, const float* rast, const float* pos, const int32_t* tri,
+                const float* dy_mask, const float* dy_img, const int32_t* items, const float* alphas, const int32_t* counter,
+                int cap, int n, int V, int H, int W, float* gimg, float* gpos, hipStream_t st)
+{
+    int grid = min(max(cdiv(cap, kBlock), 1), 2048);
+    k_aa_bwd<1, 3><<<grid, kBlock, 0, st>>>(mask_col, img_col, (const float4*)rast, pos, tri, dy_mask, dy_img,
+                                            (const int4*)items, alphas, counter, cap, n, V, H, W, 1, nullptr, gimg, gpos);
+    FMHR_CHECK_LAUNCH("k_aa_bwd<1,3>");
+    return FMHR_OK;
+}
+
+}  // namespace fmhr
+
+using namespace fmhr;
+
+extern "C" size_t fmhr_topology_workspace_bytes(int F) { return (size_t)table_size(F) * sizeof(EdgeSlot); }
+
+extern "C" int fmhr_topology_build(const int32_t* tri, int F, int V, int32_t* opp, void* ws, size_t ws_bytes, void* stream)
+{
+    FMHR_CHECK_ARG(F >= 0 && V >= 0, "topology_build: bad dims");
+    if (F == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(tri && opp && ws, "topology_build: null pointer");
+    FMHR_CHECK_ARG(ws_bytes >= fmhr_topology_workspace_bytes(F), "topology_build: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned T = table_size(F);
+    EdgeSlot* tab = (EdgeSlot*)ws;
+    int rc = build_hash(tri, F, tab, T, st);
+    if (rc) return rc;
+    k_hash_opp<<<cdiv(3ll * F, kBlock), kBlock, 0, st>>>(tri, F, tab, T - 1, opp);
+    FMHR_CHECK_LAUNCH("k_hash_opp");
+    return FMHR_OK;
+}
+
+extern "C" size_t fmhr_adjacency_workspace_bytes(int V, int F)
+{
+    return (size_t)table_size(F) * sizeof(EdgeSlot) + (size_t)(V + 1) * 4 * 2;
+}
+
+extern "C" int fmhr_adjacency_build(const int32_t* tri, int F, int V, int32_t* row_ptr, int32_t* col_idx, void* ws,
+                                    size_t ws_bytes, void* stream)
+{
+    FMHR_CHECK_ARG(F >= 0 && V >= 0, "adjacency_build: bad dims");
+    FMHR_CHECK_ARG(row_ptr && ws && (tri || F == 0) && (col_idx || F == 0), "adjacency_build: null pointer");
+    FMHR_CHECK_ARG(ws_bytes >= fmhr_adjacency_workspace_bytes(V, F), "adjacency_build: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned T = table_size(F);
+    EdgeSlot* tab = (EdgeSlot*)ws;
+    int* deg = (int*)((char*)ws + (size_t)T * sizeof(EdgeSlot));
+    int* cursor = deg + (V + 1);
+    hipError_t e = hipMemsetAsync(deg, 0, (size_t)(V + 1) * 8, st);
+    if (e != hipSuccess) return hip_fail(e, "memset deg");
+    int rc = build_hash(tri, F, tab, T, st);
+    if (rc) return rc;
+    k_adj_degree<<<cdiv(T, kBlock), kBlock, 0, st>>>(tab, T, V, deg);
+    FMHR_CHECK_LAUNCH("k_adj_degree");
+    k_scan_exclusive<<<1, 1024, 0, st>>>(deg, V, row_ptr);
+    FMHR_CHECK_LAUNCH("k_scan_exclusive");
+    k_adj_fill<<<cdiv(T, kBlock), kBlock, 0, st>>>(tab, T, V, row_ptr, cursor, col_idx);
+    FMHR_CHECK_LAUNCH("k_adj_fill");
+    if (V > 0) {
+        k_adj_sort_rows<<<cdiv(V, kBlock), kBlock, 0, st>>>(V, row_ptr, col_idx);
+        FMHR_CHECK_LAUNCH("k_adj_sort_rows");
+    }
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
+                                  const int32_t* opp, int n, int V, int F, int H, int W, int C, float* out, int32_t* items,
+                                  float* alphas, int32_t* counter, int cap, void* stream)
+{
+    FMHR_CHECK_ARG(n >= 0 && V >= 0 && F >= 0 && H > 0 && W > 0 && C > 0 && cap >= 0, "antialias_fwd: bad dims");
+    long long nP = (long long)n * H * W;
+    if (nP == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(color && rast && out && items && alphas && counter && (pos || V == 0) && ((tri && opp) || F == 0),
+                   "antialias_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(out, color, (size_t)nP * C * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return hip_fail(e, "antialias_fwd copy");
+    if (F == 0) return FMHR_OK;
+    int grid = cdiv(nP, kBlock);
+    int4* it = (int4*)items;
+    const float4* r4 = (const float4*)rast;
+    if (C == 1) k_aa_fwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    else if (C == 3) k_aa_fwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    else k_aa_fwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    FMHR_CHECK_LAUNCH("k_aa_fwd");
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_antialias_bwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
+                                  const float* dy, const int32_t* items, const float* alphas, const int32_t* counter,
+                                  int cap, int n, int V, int F, int H, int W, int C, float* gcolor, float* gpos, void* stream)
+{
+    FMHR_CHECK_ARG(n >= 0 && V >= 0 && F >= 0 && H > 0 && W > 0 && C > 0 && cap >= 0, "antialias_bwd: bad dims");
+    long long nP = (long long)n * H * W;
+    if (nP == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(color && rast && dy && items && alphas && counter && gcolor && (gpos || V == 0), "antialias_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(gcolor, dy, (size_t)nP * C * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return hip_fail(e, "antialias_bwd copy");
+    if (F == 0 || cap == 0) return FMHR_OK;
+    int grid = min(max(cdiv(cap, kBlock), 1), 2048);
+    const int4* it = (const int4*)items;
+    const float4* r4 = (const float4*)rast;
+    if (C == 1) k_aa_bwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, dy, nullptr, it, alphas, counter, cap, n, V, H, W, C, gcolor, nullptr, gpos);
+    else if (C == 3) k_aa_bwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, dy, nullptr, it, alphas, counter, cap, n, V, H, W, C, gcolor, nullptr, gpos);
+    else k_aa_bwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, dy, nullptr, it, alphas, counter, cap, n, V, H, W, C, gcolor, nullptr, gpos);
+    FMHR_CHECK_LAUNCH("k_aa_bwd");
+    return FMHR_OK;
+}

@@ -1,0 +1,26 @@
+#!/bin/bash
+# fmhr_amd/csrc/build.sh — builds fmhr_amd/libfmhr_ham.so for gfx950 (no GPU needed: hipcc cross-compiles).
+# -ffp-contract=off is part of the numerical contract: do not remove it.
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libfmhr_ham.so
+SRCS="abi.cpp raster.hip antialias.hip mesh.hip shade.hip ham_step.hip"
+NEW=0
+for f in $SRCS common.h ../../include/fmhr_ham.h build.sh; do
+  if [ ! -f "$OUT" ] || [ "$f" -nt "$OUT" ]; then NEW=1; fi
+done
+if [ "$NEW" = "0" ] && [ "${FMHR_FORCE_BUILD:-0}" = "0" ]; then echo "libfmhr_ham.so up to date"; exit 0; fi
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result"
+mkdir -p ../../build/obj
+OBJS=""
+pids=""
+for f in $SRCS; do
+  o=../../build/obj/${f%.*}.o
+  OBJS="$OBJS $o"
+  ( $HIPCC $FLAGS -x hip -c $f -o $o ) &
+  pids="$pids $!"
+done
+for p in $pids; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+echo "built $(realpath $OUT)"

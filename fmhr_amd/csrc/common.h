@@ -1,0 +1,133 @@
+// fmhr_amd/csrc/common.h — shared device helpers for the gfx950 HAM kernels.
+// The whole library is compiled with -ffp-contract=off: every statement below is one IEEE fp32 operation, so the discrete
+// decisions (snap, coverage, depth order, antialias edge selection) are bit-identical on every launch and can be
+// re-stated exactly by a CPU checker.  Where a fused multiply-add is wanted for speed it is written as fmaf().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fmhr_ham.h"
+
+namespace fmhr {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define FMHR_CHECK_ARG(cond, ...)                     \
+    do {                                              \
+        if (!(cond)) {                                \
+            ::fmhr::set_error(__VA_ARGS__);           \
+            return FMHR_E_ARG;                        \
+        }                                             \
+    } while (0)
+
+#define FMHR_CHECK_LAUNCH(what)                                   \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) return ::fmhr::hip_fail(e__, what); \
+    } while (0)
+
+constexpr int kBlock = 256;
+constexpr int kSub = 256;        // sub-pixel units per pixel (8 bits)
+constexpr int kHalf = 128;
+constexpr float kSnapLim = 4194304.0f;   // 2^22 sub-pixel guard band
+
+static inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
+
+struct Frag { float u, v, zw; };
+
+// DESIGN.md §3 R1+R2: whole-triangle near/far reject and snap to 1/256 px.
+__device__ __forceinline__ bool snap_vertex(const float4 p, float kx, float ky, int& ox, int& oy)
+{
+    if (!(p.w > 0.0f) || !(p.z >= -p.w) || !(p.z <= p.w)) return false;
+    float rw = 1.0f / p.w;
+    float sx = p.x * rw;
+    float sy = p.y * rw;
+    float qx = sx * kx;
+    qx = qx + kx;
+    float qy = sy * ky;
+    qy = qy + ky;
+    if (!(qx == qx) || !(qy == qy)) return false;
+    if (qx > kSnapLim) qx = kSnapLim;
+    if (qx < -kSnapLim) qx = -kSnapLim;
+    if (qy > kSnapLim) qy = kSnapLim;
+    if (qy < -kSnapLim) qy = -kSnapLim;
+    ox = (int)rintf(qx);
+    oy = (int)rintf(qy);
+    return true;
+}
+
+// edge test with the owner rule for pixel centres exactly on an edge (CCW-normalised triangle).
+__device__ __forceinline__ bool edge_in(int ax, int ay, int bx, int by, int cx, int cy)
+{
+    long long dx = bx - ax, dy = by - ay;
+    long long e = dx * (long long)(cy - ay) - dy * (long long)(cx - ax);
+    if (e > 0) return true;
+    if (e < 0) return false;
+    return (dy > 0) || (dy == 0 && dx > 0);
+}
+
+// fragment (u, v, z/w) of a triangle at a pixel; false when degenerate.
+__device__ __forceinline__ bool fragment(const float4 p0, const float4 p1, const float4 p2, int px, int py,
+                                         float xs, float xo, float ys, float yo, Frag& o)
+{
+    float fx = xs * (float)px; fx = fx + xo;
+    float fy = ys * (float)py; fy = fy + yo;
+    float t;
+    t = fx * p0.w; float p0x = p0.x - t;  t = fy * p0.w; float p0y = p0.y - t;
+    t = fx * p1.w; float p1x = p1.x - t;  t = fy * p1.w; float p1y = p1.y - t;
+    t = fx * p2.w; float p2x = p2.x - t;  t = fy * p2.w; float p2y = p2.y - t;
+    float m0, m1;
+    m0 = p1x * p2y; m1 = p1y * p2x; float a0 = m0 - m1;
+    m0 = p2x * p0y; m1 = p2y * p0x; float a1 = m0 - m1;
+    m0 = p0x * p1y; m1 = p0y * p1x; float a2 = m0 - m1;
+    float at = a0 + a1; at = at + a2;
+    if (!(fabsf(at) > 0.0f)) return false;
+    float iw = 1.0f / at;
+    float b0 = a0 * iw;
+    float b1 = a1 * iw;
+    float zn = p0.z * a0; t = p1.z * a1; zn = zn + t; t = p2.z * a2; zn = zn + t;
+    float wn = p0.w * a0; t = p1.w * a1; wn = wn + t; t = p2.w * a2; wn = wn + t;
+    float q = zn / wn;
+    if (!(q == q)) return false;
+    if (b0 < 0.0f) b0 = 0.0f;
+    if (b0 > 1.0f) b0 = 1.0f;
+    if (b1 < 0.0f) b1 = 0.0f;
+    if (b1 > 1.0f) b1 = 1.0f;
+    if (q < -1.0f) q = -1.0f;
+    if (q > 1.0f) q = 1.0f;
+    q = q + 0.0f;
+    o.u = b0; o.v = b1; o.zw = q;
+    return true;
+}
+
+// order-preserving map float -> uint32 (smaller float => smaller key)
+__device__ __forceinline__ uint32_t mono_key(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// wave64 sum reduction (all lanes get lane-0-valid result in lane 0)
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block (256 threads = 4 waves) sum; result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* sm4)
+{
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm4[wv] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = sm4[0] + sm4[1] + sm4[2] + sm4[3];
+    __syncthreads();
+    return r;
+}
+
+}  // namespace fmhr

@@ -1,0 +1,495 @@
+// fmhr_amd/csrc/mesh.hip — view-independent mesh kernels for gfx950: vertex normals, SH radiance, uniform Laplacian,
+// clip transform, edge-length hinge and delta term (forward + backward).
+// Replaces get_normals / get_radiance / laplacian_smoothing("uniform") of /root/reference/models/utils.py:508-548,
+// 208-226, 696-722 and the inline code of /root/reference/mesh_sfs_optim.py:262-264, 296-304.
+#include "common.h"
+
+namespace fmhr {
+
+__device__ __forceinline__ float3 ld3(const float* p) { return make_float3(p[0], p[1], p[2]); }
+__device__ __forceinline__ float3 sub3(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b)
+{
+    return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ void atomic_add3(float* p, float3 v) { atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); }
+
+// ------------------------------------------------------------------------------------------------ vertex normals
+// one lane per (batch, face): corner k adds cross(v[k+1]-v[k], v[k+2]-v[k]) to vertex k (models/utils.py:517-543)
+__global__ void __launch_bounds__(kBlock)
+k_normals_faces(const float* __restrict__ verts, const int32_t* __restrict__ tri, int nb, int V, int F, float* __restrict__ nsum)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (long long)nb * F) return;
+    int b = (int)(gid / F), f = (int)(gid - (long long)b * F);
+    int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
+    if ((unsigned)i[0] >= (unsigned)V || (unsigned)i[1] >= (unsigned)V || (unsigned)i[2] >= (unsigned)V) return;
+    const float* vb = verts + (size_t)b * V * 3;
+    float3 v[3] = {ld3(vb + (size_t)i[0] * 3), ld3(vb + (size_t)i[1] * 3), ld3(vb + (size_t)i[2] * 3)};
+    float* nb_ = nsum + (size_t)b * V * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float3 c = cross3(sub3(v[(k + 1) % 3], v[k]), sub3(v[(k + 2) % 3], v[k]));
+        atomic_add3(nb_ + (size_t)i[k] * 3, c);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_normals_normalize(const float* __restrict__ nsum, long long N, float* __restrict__ normals)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= N) return;
+    float3 s = ld3(nsum + gid * 3);
+    float len = sqrtf(s.x * s.x + s.y * s.y + s.z * s.z);
+    float inv = 1.0f / fmaxf(len, 1e-6f);
+    normals[gid * 3] = s.x * inv; normals[gid * 3 + 1] = s.y * inv; normals[gid * 3 + 2] = s.z * inv;
+}
+
+// g_s = d L / d nsum from d L / d normals (normalise backward with the eps clamp); gstride lets the caller pass [V,8] rows
+__global__ void __launch_bounds__(kBlock)
+k_normals_bwd_vertex(const float* __restrict__ nsum, const float* __restrict__ gn, int gstride, long long N, float* __restrict__ gs)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= N) return;
+    float3 s = ld3(nsum + gid * 3);
+    float3 g = ld3(gn + gid * gstride);
+    float len = sqrtf(s.x * s.x + s.y * s.y + s.z * s.z);
+    float3 o;
+    if (len > 1e-6f) {
+        float inv = 1.0f / len;
+        float3 nh = make_float3(s.x * inv, s.y * inv, s.z * inv);
+        float dt = nh.x * g.x + nh.y * g.y + nh.z * g.z;
+        o = make_float3((g.x - nh.x * dt) * inv, (g.y - nh.y * dt) * inv, (g.z - nh.z * dt) * inv);
+    } else {
+        o = make_float3(g.x * 1e6f, g.y * 1e6f, g.z * 1e6f);
+    }
+    gs[gid * 3] = o.x; gs[gid * 3 + 1] = o.y; gs[gid * 3 + 2] = o.z;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_normals_bwd_faces(const float* __restrict__ verts, const int32_t* __restrict__ tri, const float* __restrict__ gs,
+                    int nb, int V, int F, float* __restrict__ gverts)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (long long)nb * F) return;
+    int b = (int)(gid / F), f = (int)(gid - (long long)b * F);
+    int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
+    if ((unsigned)i[0] >= (unsigned)V || (unsigned)i[1] >= (unsigned)V || (unsigned)i[2] >= (unsigned)V) return;
+    const float* vb = verts + (size_t)b * V * 3;
+    const float* gb = gs + (size_t)b * V * 3;
+    float3 v[3] = {ld3(vb + (size_t)i[0] * 3), ld3(vb + (size_t)i[1] * 3), ld3(vb + (size_t)i[2] * 3)};
+    float3 acc[3] = {make_float3(0, 0, 0), make_float3(0, 0, 0), make_float3(0, 0, 0)};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        float3 e1 = sub3(v[k1], v[k]), e2 = sub3(v[k2], v[k]);
+        float3 gc = ld3(gb + (size_t)i[k] * 3);
+        float3 ge1 = cross3(e2, gc), ge2 = cross3(gc, e1);
+        acc[k1].x += ge1.x; acc[k1].y += ge1.y; acc[k1].z += ge1.z;
+        acc[k2].x += ge2.x; acc[k2].y += ge2.y; acc[k2].z += ge2.z;
+        acc[k].x -= ge1.x + ge2.x; acc[k].y -= ge1.y + ge2.y; acc[k].z -= ge1.z + ge2.z;
+    }
+    float* go = gverts + (size_t)b * V * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) atomic_add3(go + (size_t)i[k] * 3, acc[k]);
+}
+
+// ------------------------------------------------------------------------------------------------ SH radiance (order 3, 9 terms)
+__device__ __forceinline__ float sh9(const float* c, float x, float y, float z)
+{
+    float r = c[0];
+    r = r + c[1] * y;
+    r = r + c[2] * z;
+    r = r + c[3] * x;
+    r = r + c[4] * x * y;
+    r = r + c[5] * y * z;
+    r = r + c[6] * (2.0f * z * z - x * x - y * y);
+    r = r + c[7] * z * x;
+    r = r + c[8] * (x * x - y * y);
+    return r;
+}
+__device__ __forceinline__ float3 sh9_dn(const float* c, float x, float y, float z)
+{
+    return make_float3(c[3] + c[4] * y - 2.0f * c[6] * x + c[7] * z + 2.0f * c[8] * x,
+                       c[1] + c[4] * x + c[5] * z - 2.0f * c[6] * y - 2.0f * c[8] * y,
+                       c[2] + c[5] * y + 4.0f * c[6] * z + c[7] * x);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_sh_fwd(const float* __restrict__ coeff, const float* __restrict__ normal, int P, int per_pixel, float* __restrict__ out)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const float* c = coeff + (per_pixel ? (size_t)i * 9 : 0);
+    float cc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) cc[k] = c[k];
+    out[i] = sh9(cc, normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_sh_bwd(const float* __restrict__ coeff, const float* __restrict__ normal, const float* __restrict__ dy, int P, int per_pixel,
+         float* __restrict__ gcoeff, float* __restrict__ gnormal)
+{
+    __shared__ float sm[4];
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    bool live = i < P;
+    float x = 0, y = 0, z = 0, g = 0;
+    float cc[9];
+    const float* c = coeff + ((per_pixel && live) ? (size_t)i * 9 : 0);
+#pragma unroll
+    for (int k = 0; k < 9; k++) cc[k] = c[k];
+    if (live) { x = normal[i * 3]; y = normal[i * 3 + 1]; z = normal[i * 3 + 2]; g = dy[i]; }
+    float basis[9] = {1.0f, y, z, x, x * y, y * z, 2.0f * z * z - x * x - y * y, z * x, x * x - y * y};
+    if (live) {
+        float3 dn = sh9_dn(cc, x, y, z);
+        gnormal[i * 3] = g * dn.x; gnormal[i * 3 + 1] = g * dn.y; gnormal[i * 3 + 2] = g * dn.z;
+    }
+    if (per_pixel) {
+        if (live)
+#pragma unroll
+            for (int k = 0; k < 9; k++) gcoeff[(size_t)i * 9 + k] = g * basis[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            float s = block_sum(g * basis[k], sm);
+            if (threadIdx.x == 0) atomicAdd(gcoeff + k, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ uniform Laplacian on a CSR
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+k_lap_fwd(const float* __restrict__ x, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col, int V,
+          float scale, float* __restrict__ lx, float* __restrict__ loss)
+{
+    __shared__ float sm[4];
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    float nrm = 0.f;
+    if (i < V) {
+        int a = row_ptr[i], b = row_ptr[i + 1];
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) acc[c] = 0.f;
+        for (int j = a; j < b; j++) {
+            const float* xj = x + (size_t)col[j] * C;
+#pragma unroll
+            for (int c = 0; c < C; c++) acc[c] += xj[c];
+        }
+        float inv = (b > a) ? 1.0f / (float)(b - a) : 0.0f;
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            float v = acc[c] * inv - x[(size_t)i * C + c];
+            lx[(size_t)i * C + c] = v;
+            s2 += v * v;
+        }
+        nrm = sqrtf(s2);
+    }
+    float s = block_sum(nrm, sm);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s * scale);
+}
+
+// rowg_i = gscale * lx_i / |lx_i|  (0 where the row norm is 0, as torch's norm backward)
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+k_lap_bwd_rows(const float* __restrict__ lx, int V, float gscale, float* __restrict__ rowg)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= V) return;
+    float v[C], s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; c++) { v[c] = lx[(size_t)i * C + c]; s2 += v[c] * v[c]; }
+    float nrm = sqrtf(s2);
+    float k = (nrm > 0.f) ? gscale / nrm : 0.f;
+#pragma unroll
+    for (int c = 0; c < C; c++) rowg[(size_t)i * C + c] = v[c] * k;
+}
+
+// gx_j += sum_{i in N(j)} rowg_i / deg_i - rowg_j   (L^T r by gather: the adjacency is symmetric)
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+k_lap_bwd_gather(const float* __restrict__ rowg, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col, int V,
+                 float* __restrict__ gx)
+{
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= V) return;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = -rowg[(size_t)j * C + c];
+    for (int e = row_ptr[j]; e < row_ptr[j + 1]; e++) {
+        int i = col[e];
+        float inv = 1.0f / (float)(row_ptr[i + 1] - row_ptr[i]);
+#pragma unroll
+        for (int c = 0; c < C; c++) acc[c] += rowg[(size_t)i * C + c] * inv;
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) gx[(size_t)j * C + c] += acc[c];
+}
+
+// ------------------------------------------------------------------------------------------------ fused-step mesh kernels
+// vertices = vertices_tmp + delta (mesh_sfs_optim.py:253)
+__global__ void __launch_bounds__(kBlock)
+k_add_delta(const float* __restrict__ a, const float* __restrict__ b, int N, float* __restrict__ o)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < N) o[i] = a[i] + b[i];
+}
+
+// pos[b,v,:] = ([v,1] @ w2c[b]) @ proj[b]  — row-vector convention, two steps like the reference's two einsums
+__global__ void __launch_bounds__(kBlock)
+k_transform_fwd(const float* __restrict__ verts, const float* __restrict__ w2c, const float* __restrict__ proj, int V,
+                float4* __restrict__ pos)
+{
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    int b = blockIdx.y;
+    if (v >= V) return;
+    const float* A = w2c + (size_t)b * 16;
+    const float* B = proj + (size_t)b * 16;
+    float x = verts[(size_t)v * 3], y = verts[(size_t)v * 3 + 1], z = verts[(size_t)v * 3 + 2];
+    float r[4], o[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) r[l] = x * A[l] + y * A[4 + l] + z * A[8 + l] + A[12 + l];
+#pragma unroll
+    for (int l = 0; l < 4; l++) o[l] = r[0] * B[l] + r[1] * B[4 + l] + r[2] * B[8 + l] + r[3] * B[12 + l];
+    pos[(size_t)b * V + v] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// gverts[v] += sum_b ((gpos[b,v] @ proj[b]^T) @ w2c[b]^T)[:3]   (one lane per vertex, no atomics)
+__global__ void __launch_bounds__(kBlock)
+k_transform_bwd(const float4* __restrict__ gpos, const float* __restrict__ w2c, const float* __restrict__ proj, int n, int V,
+                float* __restrict__ gverts)
+{
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= V) return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int b = 0; b < n; b++) {
+        const float* A = w2c + (size_t)b * 16;
+        const float* B = proj + (size_t)b * 16;
+        float4 g = gpos[(size_t)b * V + v];
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = g.x * B[k * 4] + g.y * B[k * 4 + 1] + g.z * B[k * 4 + 2] + g.w * B[k * 4 + 3];
+        ax += r[0] * A[0] + r[1] * A[1] + r[2] * A[2] + r[3] * A[3];
+        ay += r[0] * A[4] + r[1] * A[5] + r[2] * A[6] + r[3] * A[7];
+        az += r[0] * A[8] + r[1] * A[9] + r[2] * A[10] + r[3] * A[11];
+    }
+    gverts[(size_t)v * 3] += ax; gverts[(size_t)v * 3 + 1] += ay; gverts[(size_t)v * 3 + 2] += az;
+}
+
+// edge hinge: mean over the 3F directed face edges of clip(|e|^2 - m, 0, 1) (mesh_sfs_optim.py:296-302)
+__global__ void __launch_bounds__(kBlock)
+k_edge_hinge(const float* __restrict__ verts, const int32_t* __restrict__ tri, int V, int F, float mean_len, float wscale,
+             float gscale, float* __restrict__ loss, float* __restrict__ gverts)
+{
+    __shared__ float sm[4];
+    int f = blockIdx.x * kBlock + threadIdx.x;
+    float part = 0.f;
+    if (f < F) {
+        int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+        if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+            float3 a = ld3(verts + (size_t)i0 * 3), b = ld3(verts + (size_t)i1 * 3), c = ld3(verts + (size_t)i2 * 3);
+            float3 e[3] = {sub3(a, b), sub3(c, b), sub3(a, c)};
+            int hi[3] = {i0, i2, i0}, lo[3] = {i1, i1, i2};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float l2 = e[k].x * e[k].x + e[k].y * e[k].y + e[k].z * e[k].z;
+                float d = l2 - mean_len;
+                part += fminf(fmaxf(d, 0.f), 1.f);
+                if (gscale != 0.f && d > 0.f && d < 1.f) {
+                    float3 g = make_float3(2.f * e[k].x * gscale, 2.f * e[k].y * gscale, 2.f * e[k].z * gscale);
+                    atomic_add3(gverts + (size_t)hi[k] * 3, g);
+                    atomic_add3(gverts + (size_t)lo[k] * 3, make_float3(-g.x, -g.y, -g.z));
+                }
+            }
+        }
+    }
+    float s = block_sum(part, sm);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s * wscale);
+}
+
+// delta term: mean_v |delta_v|^2 (mesh_sfs_optim.py:304); gdelta += gscale * 2 delta
+__global__ void __launch_bounds__(kBlock)
+k_delta_term(const float* __restrict__ delta, int V, float wscale, float gscale, float* __restrict__ loss, float* __restrict__ gdelta)
+{
+    __shared__ float sm[4];
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    float part = 0.f;
+    if (v < V) {
+        float3 d = ld3(delta + (size_t)v * 3);
+        part = d.x * d.x + d.y * d.y + d.z * d.z;
+        if (gscale != 0.f) {
+            gdelta[(size_t)v * 3] += 2.f * d.x * gscale;
+            gdelta[(size_t)v * 3 + 1] += 2.f * d.y * gscale;
+            gdelta[(size_t)v * 3 + 2] += 2.f * d.z * gscale;
+        }
+    }
+    float s = block_sum(part, sm);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s * wscale);
+}
+
+// ---- internal launchers used by ham_step.hip
+int normals_fwd_impl(const float* verts, const int32_t* tri, int nb, int V, int F, float* nsum, float* normals, hipStream_t st)
+{
+    long long N = (long long)nb * V;
+    if (N == 0) return FMHR_OK;
+    hipError_t e = hipMemsetAsync(nsum, 0, (size_t)N * 12, st);
+    if (e != hipSuccess) return hip_fail(e, "memset nsum");
+    if (F > 0) {
+        k_normals_faces<<<cdiv((long long)nb * F, kBlock), kBlock, 0, st>>>(verts, tri, nb, V, F, nsum);
+        FMHR_CHECK_LAUNCH("k_normals_faces");
+    }
+    k_normals_normalize<<<cdiv(N, kBlock), kBlock, 0, st>>>(nsum, N, normals);
+    FMHR_CHECK_LAUNCH("k_normals_normalize");
+    return FMHR_OK;
+}
+
+int normals_bwd_impl(const float* verts, const int32_t* tri, const float* nsum, const float* gn, int gstride, int nb, int V,
+                     int F, float* gtmp, float* gverts, hipStream_t st)
+{
+    long long N = (long long)nb * V;
+    if (N == 0 || F == 0) return FMHR_OK;
+    k_normals_bwd_vertex<<<cdiv(N, kBlock), kBlock, 0, st>>>(nsum, gn, gstride, N, gtmp);
+    FMHR_CHECK_LAUNCH("k_normals_bwd_vertex");
+    k_normals_bwd_faces<<<cdiv((long long)nb * F, kBlock), kBlock, 0, st>>>(verts, tri, gtmp, nb, V, F, gverts);
+    FMHR_CHECK_LAUNCH("k_normals_bwd_faces");
+    return FMHR_OK;
+}
+
+int lap_fwd_impl(const float* x, const int32_t* row_ptr, const int32_t* col, int V, int C, float weight, float* lx,
+                 float* loss, hipStream_t st)
+{
+    if (V == 0) return FMHR_OK;
+    float scale = weight / (float)V;
+    int grid = cdiv(V, kBlock);
+    switch (C) {
+        case 1: k_lap_fwd<1><<<grid, kBlock, 0, st>>>(x, row_ptr, col, V, scale, lx, loss); break;
+        case 2: k_lap_fwd<2><<<grid, kBlock, 0, st>>>(x, row_ptr, col, V, scale, lx, loss); break;
+        case 3: k_lap_fwd<3><<<grid, kBlock, 0, st>>>(x, row_ptr, col, V, scale, lx, loss); break;
+        case 4: k_lap_fwd<4><<<grid, kBlock, 0, st>>>(x, row_ptr, col, V, scale, lx, loss); break;
+        default: set_error("laplacian: C must be 1..4 (got %d)", C); return FMHR_E_ARG;
+    }
+    FMHR_CHECK_LAUNCH("k_lap_fwd");
+    return FMHR_OK;
+}
+
+int lap_bwd_impl(const float* lx, const int32_t* row_ptr, const int32_t* col, int V, int C, float gscale, float* rowg,
+                 float* gx, hipStream_t st)
+{
+    if (V == 0) return FMHR_OK;
+    float gs = gscale / (float)V;
+    int grid = cdiv(V, kBlock);
+    switch (C) {
+        case 1: k_lap_bwd_rows<1><<<grid, kBlock, 0, st>>>(lx, V, gs, rowg); k_lap_bwd_gather<1><<<grid, kBlock, 0, st>>>(rowg, row_ptr, col, V, gx); break;
+        case 2: k_lap_bwd_rows<2><<<grid, kBlock, 0, st>>>(lx, V, gs, rowg); k_lap_bwd_gather<2><<<grid, kBlock, 0, st>>>(rowg, row_ptr, col, V, gx); break;
+        case 3: k_lap_bwd_rows<3><<<grid, kBlock, 0, st>>>(lx, V, gs, rowg); k_lap_bwd_gather<3><<<grid, kBlock, 0, st>>>(rowg, row_ptr, col, V, gx); break;
+        case 4: k_lap_bwd_rows<4><<<grid, kBlock, 0, st>>>(lx, V, gs, rowg); k_lap_bwd_gather<4><<<grid, kBlock, 0, st>>>(rowg, row_ptr, col, V, gx); break;
+        default: set_error("laplacian: C must be 1..4 (got %d)", C); return FMHR_E_ARG;
+    }
+    FMHR_CHECK_LAUNCH("k_lap_bwd");
+    return FMHR_OK;
+}
+
+int add_delta_impl(const float* a, const float* b, int N, float* o, hipStream_t st)
+{
+    if (N == 0) return FMHR_OK;
+    k_add_delta<<<cdiv(N, kBlock), kBlock, 0, st>>>(a, b, N, o);
+    FMHR_CHECK_LAUNCH("k_add_delta");
+    return FMHR_OK;
+}
+
+int transform_fwd_impl(const float* verts, const float* w2c, const float* proj, int n, int V, float* pos, hipStream_t st)
+{
+    if (n == 0 || V == 0) return FMHR_OK;
+    k_transform_fwd<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>(verts, w2c, proj, V, (float4*)pos);
+    FMHR_CHECK_LAUNCH("k_transform_fwd");
+    return FMHR_OK;
+}
+
+int transform_bwd_impl(const float* gpos, const float* w2c, const float* proj, int n, int V, float* gverts, hipStream_t st)
+{
+    if (n == 0 || V == 0) return FMHR_OK;
+    k_transform_bwd<<<cdiv(V, kBlock), kBlock, 0, st>>>((const float4*)gpos, w2c, proj, n, V, gverts);
+    FMHR_CHECK_LAUNCH("k_transform_bwd");
+    return FMHR_OK;
+}
+
+int edge_hinge_impl(const float* verts, const int32_t* tri, int V, int F, float mean_len, float weight, float gscale,
+                    float* loss, float* gverts, hipStream_t st)
+{
+    if (F == 0) return FMHR_OK;
+    k_edge_hinge<<<cdiv(F, kBlock), kBlock, 0, st>>>(verts, tri, V, F, mean_len, weight / (3.0f * (float)F),
+                                                      gscale / (3.0f * (float)F), loss, gverts);
+    FMHR_CHECK_LAUNCH("k_edge_hinge");
+    return FMHR_OK;
+}
+
+int delta_term_impl(const float* delta, int V, float weight, float gscale, float* loss, float* gdelta, hipStream_t st)
+{
+    if (V == 0) return FMHR_OK;
+    k_delta_term<<<cdiv(V, kBlock), kBlock, 0, st>>>(delta, V, weight / (float)V, gscale / (float)V, loss, gdelta);
+    FMHR_CHECK_LAUNCH("k_delta_term");
+    return FMHR_OK;
+}
+
+}  // namespace fmhr
+
+using namespace fmhr;
+
+extern "C" int fmhr_vertex_normals_fwd(const float* verts, const int32_t* tri, int b, int V, int F, float* nsum, float* normals,
+                                       void* stream)
+{
+    FMHR_CHECK_ARG(b >= 0 && V >= 0 && F >= 0, "vertex_normals_fwd: bad dims");
+    if ((long long)b * V == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(verts && nsum && normals && (tri || F == 0), "vertex_normals_fwd: null pointer");
+    return normals_fwd_impl(verts, tri, b, V, F, nsum, normals, (hipStream_t)stream);
+}
+
+extern "C" int fmhr_vertex_normals_bwd(const float* verts, const int32_t* tri, const float* nsum, const float* gnormals, int b,
+                                       int V, int F, float* gtmp, float* gverts, void* stream)
+{
+    FMHR_CHECK_ARG(b >= 0 && V >= 0 && F >= 0, "vertex_normals_bwd: bad dims");
+    if ((long long)b * V == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(verts && nsum && gnormals && gtmp && gverts && (tri || F == 0), "vertex_normals_bwd: null pointer");
+    return normals_bwd_impl(verts, tri, nsum, gnormals, 3, b, V, F, gtmp, gverts, (hipStream_t)stream);
+}
+
+extern "C" int fmhr_sh_radiance_fwd(const float* coeff, const float* normal, int P, int per_pixel, float* out, void* stream)
+{
+    FMHR_CHECK_ARG(P >= 0, "sh_radiance_fwd: bad dims");
+    if (P == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(coeff && normal && out, "sh_radiance_fwd: null pointer");
+    k_sh_fwd<<<cdiv(P, kBlock), kBlock, 0, (hipStream_t)stream>>>(coeff, normal, P, per_pixel, out);
+    FMHR_CHECK_LAUNCH("k_sh_fwd");
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_sh_radiance_bwd(const float* coeff, const float* normal, const float* dy, int P, int per_pixel,
+                                    float* gcoeff, float* gnormal, void* stream)
+{
+    FMHR_CHECK_ARG(P >= 0, "sh_radiance_bwd: bad dims");
+    if (P == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(coeff && normal && dy && gcoeff && gnormal, "sh_radiance_bwd: null pointer");
+    k_sh_bwd<<<cdiv(P, kBlock), kBlock, 0, (hipStream_t)stream>>>(coeff, normal, dy, P, per_pixel, gcoeff, gnormal);
+    FMHR_CHECK_LAUNCH("k_sh_bwd");
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_laplacian_uniform_fwd(const float* x, const int32_t* row_ptr, const int32_t* col_idx, int V, int C,
+                                          float weight, float* lx, float* loss, void* stream)
+{
+    FMHR_CHECK_ARG(V >= 0 && C >= 1 && C <= 4, "laplacian_uniform_fwd: bad dims (C must be 1..4)");
+    if (V == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(x && row_ptr && lx && loss, "laplacian_uniform_fwd: null pointer");
+    return lap_fwd_impl(x, row_ptr, col_idx, V, C, weight, lx, loss, (hipStream_t)stream);
+}
+
+extern "C" int fmhr_laplacian_uniform_bwd(const float* lx, const int32_t* row_ptr, const int32_t* col_idx, int V, int C,
+                                          float gscale, float* rowg, float* gx, void* stream)
+{
+    FMHR_CHECK_ARG(V >= 0 && C >= 1 && C <= 4, "laplacian_uniform_bwd: bad dims (C must be 1..4)");
+    if (V == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(lx && row_ptr && rowg && gx, "laplacian_uniform_bwd: null pointer");
+    return lap_bwd_impl(lx, row_ptr, col_idx, V, C, gscale, rowg, gx, (hipStream_t)stream);
+}

@@ -1,0 +1,314 @@
+// fmhr_amd/csrc/raster.hip — rasterize / interpolate, forward + backward, for gfx950.
+// Replaces dr.rasterize / dr.interpolate of nvdiffrast as called at /root/reference/mesh_sfs_optim.py:267,269.
+//
+// Forward = triangle-parallel scan conversion into a 64-bit (depth | triangle) key buffer with atomicMin, then a
+// per-pixel resolve that recomputes the winner's fragment.  The HAM meshes are micro-triangle meshes (~1.3 px per visible
+// triangle at 512^2): the work is per triangle, not per pixel, so one lane owns one triangle and walks its
+// (tiny) bounding box; triangles with a large box are queued and swept by a whole workgroup each.
+#include "common.h"
+
+namespace fmhr {
+
+constexpr int kSmallBox = 64;   // boxes up to this many pixel centres are walked by the owning lane
+
+struct TriSetup {
+    int x0, y0, x1, y1, x2, y2;     // CCW-normalised snapped coordinates
+    int pxa, pxb, pya, pyb;         // inclusive pixel range
+};
+
+__device__ __forceinline__ bool setup_triangle(const float4 p0, const float4 p1, const float4 p2, int H, int W, TriSetup& s)
+{
+    const float kx = (float)W * 128.0f, ky = (float)H * 128.0f;
+    if (!snap_vertex(p0, kx, ky, s.x0, s.y0)) return false;
+    if (!snap_vertex(p1, kx, ky, s.x1, s.y1)) return false;
+    if (!snap_vertex(p2, kx, ky, s.x2, s.y2)) return false;
+    long long area2 = (long long)(s.x1 - s.x0) * (s.y2 - s.y0) - (long long)(s.y1 - s.y0) * (s.x2 - s.x0);
+    if (area2 == 0) return false;
+    if (area2 < 0) { int t; t = s.x1; s.x1 = s.x2; s.x2 = t; t = s.y1; s.y1 = s.y2; s.y2 = t; }
+    int mnx = min(s.x0, min(s.x1, s.x2)), mxx = max(s.x0, max(s.x1, s.x2));
+    int mny = min(s.y0, min(s.y1, s.y2)), mxy = max(s.y0, max(s.y1, s.y2));
+    s.pxa = max((mnx - kHalf + kSub - 1) >> 8, 0);       // ceil((mn-128)/256), arithmetic shift floors
+    s.pxb = min((mxx - kHalf) >> 8, W - 1);
+    s.pya = max((mny - kHalf + kSub - 1) >> 8, 0);
+    s.pyb = min((mxy - kHalf) >> 8, H - 1);
+    return s.pxa <= s.pxb && s.pya <= s.pyb;
+}
+
+__device__ __forceinline__ void shade_pixel(const TriSetup& s, const float4 p0, const float4 p1, const float4 p2,
+                                            int px, int py, int f, float xs, float xo, float ys, float yo,
+                                            unsigned long long* keys_view, int W)
+{
+    int cx = px * kSub + kHalf, cy = py * kSub + kHalf;
+    if (!edge_in(s.x0, s.y0, s.x1, s.y1, cx, cy)) return;
+    if (!edge_in(s.x1, s.y1, s.x2, s.y2, cx, cy)) return;
+    if (!edge_in(s.x2, s.y2, s.x0, s.y0, cx, cy)) return;
+    Frag fr;
+    if (!fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) return;
+    unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | (unsigned)f;
+    atomicMin(&keys_view[(size_t)py * W + px], key);
+}
+
+// one lane per (view, triangle)
+__global__ void __launch_bounds__(kBlock)
+k_raster_tris(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
+              unsigned long long* __restrict__ keys, int* __restrict__ large_cnt, int2* __restrict__ large_q)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (long long)n * F) return;
+    int b = (int)(gid / F), f = (int)(gid - (long long)b * F);
+    int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+    if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return;
+    const float* vp = pos + (size_t)b * V * 4;
+    const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+    TriSetup s;
+    if (!setup_triangle(p0, p1, p2, H, W, s)) return;
+    int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
+    if (bw * (long long)bh > kSmallBox) {
+        int slot = atomicAdd(large_cnt, 1);
+        large_q[slot] = make_int2(b, f);
+        return;
+    }
+    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
+    float xo = 1.0f / (float)W; xo = xo - 1.0f;
+    float yo = 1.0f / (float)H; yo = yo - 1.0f;
+    unsigned long long* kv = keys + (size_t)b * H * W;
+    for (int py = s.pya; py <= s.pyb; py++)
+        for (int px = s.pxa; px <= s.pxb; px++)
+            shade_pixel(s, p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W);
+}
+
+// one workgroup per queued large triangle (grid-stride over the queue; the count lives on the device)
+__global__ void __launch_bounds__(kBlock)
+k_raster_large(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
+               unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt, const int2* __restrict__ large_q)
+{
+    const int cnt = *large_cnt;
+    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
+    float xo = 1.0f / (float)W; xo = xo - 1.0f;
+    float yo = 1.0f / (float)H; yo = yo - 1.0f;
+    for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
+        int2 bf = large_q[it];
+        int b = bf.x, f = bf.y;
+        int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+        const float* vp = pos + (size_t)b * V * 4;
+        const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+        TriSetup s;
+        if (!setup_triangle(p0, p1, p2, H, W, s)) continue;
+        int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
+        unsigned long long* kv = keys + (size_t)b * H * W;
+        for (int i = threadIdx.x; i < bw * bh; i += kBlock) {
+            int py = s.pya + i / bw, px = s.pxa + i % bw;
+            shade_pixel(s, p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W);
+        }
+    }
+}
+
+// per pixel: decode the winning key, recompute its fragment, write (u, v, z/w, id+1) as one 16-B store
+__global__ void __launch_bounds__(kBlock)
+k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int H, int W,
+                 const unsigned long long* __restrict__ keys, float4* __restrict__ rast)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    long long P = (long long)H * W;
+    if (gid >= (long long)n * P) return;
+    unsigned long long key = keys[gid];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (key != ~0ull) {
+        int b = (int)(gid / P);
+        int rem = (int)(gid - (long long)b * P);
+        int py = rem / W, px = rem - py * W;
+        int f = (int)(key & 0xffffffffu);
+        const float* vp = pos + (size_t)b * V * 4;
+        const float4 p0 = ldg4(vp + (size_t)tri[f * 3] * 4), p1 = ldg4(vp + (size_t)tri[f * 3 + 1] * 4),
+                     p2 = ldg4(vp + (size_t)tri[f * 3 + 2] * 4);
+        const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
+        float xo = 1.0f / (float)W; xo = xo - 1.0f;
+        float yo = 1.0f / (float)H; yo = yo - 1.0f;
+        Frag fr;
+        if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
+    }
+    rast[gid] = o;
+}
+
+// ------------------------------------------------------------------------------------------------ rasterize backward
+__global__ void __launch_bounds__(kBlock)
+k_raster_bwd(const float* __restrict__ pos, const int32_t* __restrict__ tri, const float4* __restrict__ rast,
+             const float4* __restrict__ dy, int n, int V, int F, int H, int W, float* __restrict__ gpos)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    long long P = (long long)H * W;
+    if (gid >= (long long)n * P) return;
+    float4 r = rast[gid];
+    int t = (int)r.w - 1;
+    if (t < 0 || t >= F) return;
+    float4 g = dy[gid];
+    if (g.x == 0.f && g.y == 0.f) return;
+    int b = (int)(gid / P);
+    int rem = (int)(gid - (long long)b * P);
+    int py = rem / W, px = rem - py * W;
+    int i0 = tri[t * 3], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
+    const float* vp = pos + (size_t)b * V * 4;
+    const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+    float fx = (2.0f / (float)W) * (float)px + (1.0f / (float)W - 1.0f);
+    float fy = (2.0f / (float)H) * (float)py + (1.0f / (float)H - 1.0f);
+    float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+    float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+    float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+    float iw = 1.0f / (a0 + a1 + a2);
+    float b0 = a0 * iw, b1 = a1 * iw;
+    float gb0 = g.x * iw, gb1 = g.y * iw, gbb = gb0 * b0 + gb1 * b1;
+    float g0x = gbb * (p2y - p1y) - gb1 * p2y;
+    float g1x = gbb * (p0y - p2y) + gb0 * p2y;
+    float g2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
+    float g0y = gbb * (p1x - p2x) + gb1 * p2x;
+    float g1y = gbb * (p2x - p0x) - gb0 * p2x;
+    float g2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
+    float* q0 = gpos + ((size_t)b * V + i0) * 4;
+    float* q1 = gpos + ((size_t)b * V + i1) * 4;
+    float* q2 = gpos + ((size_t)b * V + i2) * 4;
+    atomicAdd(q0 + 0, g0x); atomicAdd(q0 + 1, g0y); atomicAdd(q0 + 3, -fx * g0x - fy * g0y);
+    atomicAdd(q1 + 0, g1x); atomicAdd(q1 + 1, g1y); atomicAdd(q1 + 3, -fx * g1x - fy * g1y);
+    atomicAdd(q2 + 0, g2x); atomicAdd(q2 + 1, g2y); atomicAdd(q2 + 3, -fx * g2x - fy * g2y);
+}
+
+// ------------------------------------------------------------------------------------------------ interpolate
+__global__ void __launch_bounds__(kBlock)
+k_interp_fwd(const float* __restrict__ attr, const float4* __restrict__ rast, const int32_t* __restrict__ tri,
+             int n, int an, int V, int F, long long P, int C, float* __restrict__ out)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (long long)n * P) return;
+    float4 r = rast[gid];
+    int t = (int)r.w - 1;
+    float* o = out + gid * C;
+    if (t < 0 || t >= F) {
+        for (int c = 0; c < C; c++) o[c] = 0.f;
+        return;
+    }
+    int b = (int)(gid / P);
+    const float* A = attr + (an == 1 ? 0 : (size_t)b * V * C);
+    const float* a0 = A + (size_t)tri[t * 3] * C;
+    const float* a1 = A + (size_t)tri[t * 3 + 1] * C;
+    const float* a2 = A + (size_t)tri[t * 3 + 2] * C;
+    float w2 = 1.0f - r.x - r.y;
+    for (int c = 0; c < C; c++) o[c] = r.x * a0[c] + r.y * a1[c] + w2 * a2[c];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_interp_bwd(const float* __restrict__ attr, const float4* __restrict__ rast, const int32_t* __restrict__ tri,
+             const float* __restrict__ dy, int n, int an, int V, int F, long long P, int C,
+             float* __restrict__ gattr, float4* __restrict__ grast)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (long long)n * P) return;
+    float4 r = rast[gid];
+    int t = (int)r.w - 1;
+    if (t < 0 || t >= F) { grast[gid] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    int b = (int)(gid / P);
+    size_t off = (an == 1 ? 0 : (size_t)b * V * C);
+    size_t i0 = (size_t)tri[t * 3] * C, i1 = (size_t)tri[t * 3 + 1] * C, i2 = (size_t)tri[t * 3 + 2] * C;
+    const float* A = attr + off;
+    float* G = gattr + off;
+    const float* d = dy + gid * C;
+    float w2 = 1.0f - r.x - r.y, gu = 0.f, gv = 0.f;
+    for (int c = 0; c < C; c++) {
+        float dc = d[c];
+        if (dc != 0.f) {
+            atomicAdd(G + i0 + c, r.x * dc);
+            atomicAdd(G + i1 + c, r.y * dc);
+            atomicAdd(G + i2 + c, w2 * dc);
+        }
+        float a2 = A[i2 + c];
+        gu += dc * (A[i0 + c] - a2);
+        gv += dc * (A[i1 + c] - a2);
+    }
+    grast[gid] = make_float4(gu, gv, 0.f, 0.f);
+}
+
+}  // namespace fmhr
+
+using namespace fmhr;
+
+extern "C" size_t fmhr_rasterize_workspace_bytes(int n, int F, int H, int W)
+{
+    // [keys: n*H*W u64][large counter: 16 B][large queue: n*F int2]
+    return (size_t)n * H * W * 8 + 16 + (size_t)n * F * 8;
+}
+
+namespace fmhr {
+int rasterize_fwd_impl(const float* pos, const int32_t* tri, int n, int V, int F, int H, int W, float* rast, void* ws,
+                       hipStream_t st)
+{
+    size_t nP = (size_t)n * H * W;
+    unsigned long long* keys = (unsigned long long*)ws;
+    int* large_cnt = (int*)((char*)ws + nP * 8);
+    int2* large_q = (int2*)((char*)ws + nP * 8 + 16);
+    if (nP == 0) return FMHR_OK;
+    hipError_t e = hipMemsetAsync(keys, 0xFF, nP * 8, st);
+    if (e != hipSuccess) return hip_fail(e, "memset keys");
+    e = hipMemsetAsync(large_cnt, 0, 16, st);
+    if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
+    if ((long long)n * F > 0) {
+        k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, large_cnt, large_q);
+        FMHR_CHECK_LAUNCH("k_raster_tris");
+        k_raster_large<<<1024, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, large_cnt, large_q);
+        FMHR_CHECK_LAUNCH("k_raster_large");
+    }
+    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, H, W, keys, (float4*)rast);
+    FMHR_CHECK_LAUNCH("k_raster_resolve");
+    return FMHR_OK;
+}
+}  // namespace fmhr
+
+extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, int V, int F, int H, int W, float* rast,
+                                  void* ws, size_t ws_bytes, void* stream)
+{
+    FMHR_CHECK_ARG(n >= 0 && V >= 0 && F >= 0 && H > 0 && W > 0, "rasterize_fwd: bad dims n=%d V=%d F=%d H=%d W=%d", n, V, F, H, W);
+    FMHR_CHECK_ARG(H <= 8192 && W <= 8192, "rasterize_fwd: resolution above 8192 not supported");
+    FMHR_CHECK_ARG(F < (1 << 24), "rasterize_fwd: F must be < 2^24 (triangle id is stored as fp32)");
+    FMHR_CHECK_ARG(n == 0 || (rast && ws && (pos || V == 0) && (tri || F == 0)), "rasterize_fwd: null pointer");
+    FMHR_CHECK_ARG(ws_bytes >= fmhr_rasterize_workspace_bytes(n, F, H, W), "rasterize_fwd: workspace too small");
+    return rasterize_fwd_impl(pos, tri, n, V, F, H, W, rast, ws, (hipStream_t)stream);
+}
+
+extern "C" int fmhr_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int n, int V,
+                                  int F, int H, int W, float* gpos, void* stream)
+{
+    FMHR_CHECK_ARG(n >= 0 && V >= 0 && F >= 0 && H > 0 && W > 0, "rasterize_bwd: bad dims");
+    size_t nP = (size_t)n * H * W;
+    if (nP == 0 || F == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(pos && tri && rast && dy && gpos, "rasterize_bwd: null pointer");
+    k_raster_bwd<<<cdiv((long long)nP, kBlock), kBlock, 0, (hipStream_t)stream>>>(pos, tri, (const float4*)rast,
+                                                                                  (const float4*)dy, n, V, F, H, W, gpos);
+    FMHR_CHECK_LAUNCH("k_raster_bwd");
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri, int n, int an, int V, int F,
+                                    int H, int W, int C, float* out, void* stream)
+{
+    FMHR_CHECK_ARG(n >= 0 && V >= 0 && F >= 0 && H > 0 && W > 0 && C > 0, "interpolate_fwd: bad dims");
+    FMHR_CHECK_ARG(an == 1 || an == n, "interpolate_fwd: attr batch must be 1 or n (got %d, n=%d)", an, n);
+    size_t nP = (size_t)n * H * W;
+    if (nP == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(rast && out && (attr || V == 0) && (tri || F == 0), "interpolate_fwd: null pointer");
+    k_interp_fwd<<<cdiv((long long)nP, kBlock), kBlock, 0, (hipStream_t)stream>>>(attr, (const float4*)rast, tri, n, an, V, F,
+                                                                                  (long long)H * W, C, out);
+    FMHR_CHECK_LAUNCH("k_interp_fwd");
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_interpolate_bwd(const float* attr, const float* rast, const int32_t* tri, const float* dy, int n,
+                                    int an, int V, int F, int H, int W, int C, float* gattr, float* grast, void* stream)
+{
+    FMHR_CHECK_ARG(n >= 0 && V >= 0 && F >= 0 && H > 0 && W > 0 && C > 0, "interpolate_bwd: bad dims");
+    FMHR_CHECK_ARG(an == 1 || an == n, "interpolate_bwd: attr batch must be 1 or n");
+    size_t nP = (size_t)n * H * W;
+    if (nP == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(rast && dy && grast && (attr || V == 0) && (gattr || V == 0) && (tri || F == 0), "interpolate_bwd: null pointer");
+    k_interp_bwd<<<cdiv((long long)nP, kBlock), kBlock, 0, (hipStream_t)stream>>>(attr, (const float4*)rast, tri, dy, n, an, V,
+                                                                                  F, (long long)H * W, C, gattr, (float4*)grast);
+    FMHR_CHECK_LAUNCH("k_interp_bwd");
+    return FMHR_OK;
+}

@@ -1,0 +1,71 @@
+"""fmhr_amd.dist — view sharding of the HAM step over ranks (one process per GPU, torch.distributed; backend "nccl" is RCCL
+on ROCm) — SURVEY.md §8e.  The reference has no multi-GPU code; this is the build's data-parallel axis:
+
+* the n views of a step are split contiguously over G ranks; every rank holds the whole mesh;
+* exchange 1: all-reduce(SUM) of the valid-pixel count (F.l1_loss divides by the batch-global 3*Pv, mesh_sfs_optim.py:289);
+* exchange 2: ONE all-reduce(SUM) per step of the packed per-vertex gradients [gdelta | galbedo] = [2,V,3] fp32
+  (1.18 MB at V = 49k: latency-bound on xGMI); regulariser gradients are view-independent and added by rank 0 only.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_views(n_views, rank, world):
+    """Contiguous, balanced partition: returns (start, stop) of this rank's views."""
+    base, rem = divmod(n_views, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class ShardedStep:
+    """Wraps a per-rank step function `local_step(n_valid_reduce, reg_grads) -> (losses[8], gdelta[V,3], galbedo[V,3])`
+    and performs the gradient exchange.  `local_step` must call `n_valid_reduce(t)` on its valid-pixel count tensor between
+    its forward and backward phases (HamStage2.step does, via `group`)."""
+
+    def __init__(self, V, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # one packed bucket: [gdelta | galbedo | 8 loss slots]
+        self.bucket = torch.zeros(2 * V * 3 + 8, dtype=torch.float32, device=device)
+        self.V = V
+
+    def reduce(self, losses, gdelta, galbedo):
+        """Pack, all-reduce once, unpack into views of the bucket.  View-independent loss slots (lap, albedo, edge, delta)
+        are identical on all ranks and are averaged back; sfs / mask are partial sums over views and add up."""
+        V = self.V
+        b = self.bucket
+        b[: V * 3].copy_(gdelta.reshape(-1))
+        b[V * 3: 2 * V * 3].copy_(galbedo.reshape(-1))
+        b[2 * V * 3:].copy_(losses)
+        if self.world > 1:
+            dist.all_reduce(b, group=self.group)
+        gd = b[: V * 3].view(V, 3)
+        ga = b[V * 3: 2 * V * 3].view(V, 3)
+        ls = b[2 * V * 3:].clone()
+        if self.world > 1:
+            for i in (1, 2, 4, 5):                 # lap, albedo, edge, delta: replicated values
+                ls[i] = ls[i] / self.world
+            ls[7] = ls[7] / self.world             # n_valid_global was already global on every rank
+            ls[6] = ls[0] + ls[1] + ls[2] + ls[3] + ls[4] + ls[5]
+        return ls, gd, ga

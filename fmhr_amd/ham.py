@@ -1,0 +1,137 @@
+"""fmhr_amd.ham — the fused stage-2 HAM iteration (render + six losses + backward) and the optimisation loop.
+
+Replaces the loop body of /root/reference/mesh_sfs_optim.py:253-310.  One `HamStage2.step()` issues two C-ABI calls
+(fmhr_ham_forward / fmhr_ham_backward, include/fmhr_ham.h) on the current stream; the only thing in between is the
+valid-pixel count hand-over (an all-reduce when views are sharded over ranks).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import HamDims, HamViews, HamWeights, call, ptr, stream_ptr
+
+LOSS_NAMES = ("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid")
+
+
+def edge_length_mean(vertices, faces):
+    """mean squared length of the 3F directed face edges of the initial mesh (mesh_sfs_optim.py:184-188); one-off."""
+    fl = faces.long()
+    a, b, c = vertices[fl[:, 0]], vertices[fl[:, 1]], vertices[fl[:, 2]]
+    return float(torch.cat([((a - b) ** 2).sum(1), ((c - b) ** 2).sum(1), ((a - c) ** 2).sum(1)]).mean())
+
+
+class HamStage2:
+    """Owns the per-mesh tables (edge/opposite-vertex table, adjacency CSR) and the step workspace for `n` local views.
+
+    faces: int32 [F,3] on the GPU.  `n_global` = number of views in the whole batch (== n unless views are sharded)."""
+
+    def __init__(self, faces, V, n, H, W, weights, edge_len_mean, n_global=None, aa_cap=None):
+        if not faces.is_cuda or faces.dtype != torch.int32:
+            raise RuntimeError("HamStage2: faces must be an int32 GPU tensor")
+        self.lib = _lib.load()
+        self.dev = faces.device
+        self.faces = faces.contiguous()
+        self.V, self.F, self.n, self.H, self.W = int(V), int(faces.shape[0]), int(n), int(H), int(W)
+        self.n_global = int(n_global or n)
+        self.weights = dict(weights)
+        self.edge_len_mean = float(edge_len_mean)
+        st = stream_ptr(self.dev)
+        # per-mesh tables, built once (the reference rebuilds both twice per step)
+        self.opp = torch.full((self.F, 3), -1, dtype=torch.int32, device=self.dev)
+        nb = self.lib.fmhr_topology_workspace_bytes(self.F)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.dev)
+        call("fmhr_topology_build", ptr(self.faces), self.F, self.V, ptr(self.opp), ptr(ws), nb, st)
+        self.row_ptr = torch.zeros(self.V + 1, dtype=torch.int32, device=self.dev)
+        self.col_idx = torch.zeros(6 * self.F, dtype=torch.int32, device=self.dev)
+        nb = self.lib.fmhr_adjacency_workspace_bytes(self.V, self.F)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.dev)
+        call("fmhr_adjacency_build", ptr(self.faces), self.F, self.V, ptr(self.row_ptr), ptr(self.col_idx), ptr(ws), nb, st)
+        self.nnz = int(self.row_ptr[-1])
+        # antialias queue: only pairs that blend are queued (∝ silhouette length); 1/4 of the pixels is a generous bound
+        cap = int(aa_cap or max(65536, self.n * self.H * self.W // 4))
+        self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap, 0)
+        self.ws_bytes = self.lib.fmhr_ham_workspace_bytes(ctypes.byref(self.dims))
+        if self.ws_bytes == 0:
+            raise RuntimeError("fmhr_ham_workspace_bytes failed: " + self.lib.fmhr_last_error().decode())
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
+        self.n_valid_local = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.n_valid_global = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.losses = torch.zeros(8, dtype=torch.float32, device=self.dev)
+        self.gdelta = torch.zeros(self.V, 3, dtype=torch.float32, device=self.dev)
+        self.galbedo = torch.zeros(self.V, 3, dtype=torch.float32, device=self.dev)
+        self._views = None
+
+    # -- the two phases -------------------------------------------------------------------------------------------------
+    def forward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask):
+        call("fmhr_ham_forward", ctypes.byref(self.dims), ptr(vertices_tmp), ptr(delta), ptr(albedo), ptr(sh), ptr(w2c),
+             ptr(proj), ptr(img), ptr(mask), ptr(self.faces), ptr(self.opp), ptr(self.n_valid_local), ptr(self.ws),
+             self.ws_bytes, stream_ptr(self.dev))
+
+    def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True):
+        w = self.weights
+        wt = HamWeights(w["sfs"], w["lap"], w["albedo"], w["mask"], w["edge"], w["delta"], self.edge_len_mean,
+                        float(self.n_global * self.H * self.W), 1.0 if reg_grads else 0.0)
+        call("fmhr_ham_backward", ctypes.byref(self.dims), ctypes.byref(wt), ptr(vertices_tmp), ptr(delta), ptr(albedo),
+             ptr(sh), ptr(w2c), ptr(proj), ptr(img), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp),
+             ptr(self.row_ptr), ptr(self.col_idx), ptr(self.n_valid_global), ptr(self.losses), ptr(self.gdelta),
+             ptr(self.galbedo), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
+
+    def step(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group=None, reg_grads=True):
+        """Full forward + backward.  Returns (losses[8] device tensor, gdelta [V,3], galbedo [V,3]) — buffers owned by this
+        object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded."""
+        self._check(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask)
+        self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask)
+        self.n_valid_global.copy_(self.n_valid_local)        # int32 -> float32, on the stream
+        if group is not None:
+            torch.distributed.all_reduce(self.n_valid_global, group=group)
+        self.backward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=reg_grads)
+        return self.losses, self.gdelta, self.galbedo
+
+    def _check(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask):
+        n, V, H, W = self.n, self.V, self.H, self.W
+        exp = dict(vertices_tmp=(V, 3), delta=(V, 3), albedo=(V, 3), sh=(n, 9), w2c=(n, 4, 4), proj=(n, 4, 4),
+                   img=(n, H, W, 3), mask=(n, H, W), valid_mask=(n, H, W))
+        got = dict(vertices_tmp=vertices_tmp, delta=delta, albedo=albedo, sh=sh, w2c=w2c, proj=proj, img=img, mask=mask,
+                   valid_mask=valid_mask)
+        for k, shp in exp.items():
+            t = got[k]
+            if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError(f"HamStage2.step: {k} must be a contiguous float32 GPU tensor of shape {shp}, "
+                                   f"got {tuple(t.shape)} {t.dtype} {t.device}")
+
+    # -- intermediates (views into the workspace; valid until the next step) ----------------------------------------------
+    def views(self):
+        if self._views is None:
+            hv = HamViews()
+            call("fmhr_ham_workspace_views", ctypes.byref(self.dims), ptr(self.ws), self.ws_bytes, ctypes.byref(hv))
+            base = self.ws.data_ptr()
+            n, V, H, W = self.n, self.V, self.H, self.W
+
+            def view(p, shape, dtype=torch.float32):
+                numel = 1
+                for s in shape:
+                    numel *= s
+                off = p - base
+                return self.ws[off: off + numel * 4].view(dtype).view(*shape)
+
+            self._views = dict(pos=view(hv.pos, (n, V, 4)), normals=view(hv.normals, (V, 3)), rast=view(hv.rast, (n, H, W, 4)),
+                               tmp_img_pre_aa=view(hv.tmp_img, (n, H, W, 3)), tmp_img=view(hv.aa_img, (n, H, W, 3)),
+                               pred_mask=view(hv.aa_mask, (n, H, W)), aa_counter=view(hv.aa_counter, (2,), torch.int32))
+        return self._views
+
+    def loss_dict(self):
+        vals = self.losses.tolist()
+        return dict(zip(LOSS_NAMES, vals))
+
+
+def render_forward(faces, vertices, albedo, sh, w2c, proj, mask, H, W):
+    """Stage-2 forward only (for target generation / re-rendering): returns dict(tmp_img, pred_mask, rast) clones."""
+    n, V = w2c.shape[0], vertices.shape[0]
+    hs = HamStage2(faces, V, n, H, W, dict(sfs=0, lap=0, albedo=0, mask=0, edge=0, delta=0), 0.0)
+    zero = torch.zeros_like(vertices)
+    img = torch.zeros(n, H, W, 3, device=vertices.device)
+    hs.forward(vertices.contiguous(), zero, albedo.contiguous(), sh.contiguous(), w2c.contiguous(), proj.contiguous(), img,
+               mask.contiguous())
+    v = hs.views()
+    return dict(tmp_img=v["tmp_img"].clone(), pred_mask=v["pred_mask"].clone(), rast=v["rast"].clone())

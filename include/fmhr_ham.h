@@ -1,0 +1,161 @@
+/*
+ * include/fmhr_ham.h — C ABI of the MI355X-native HAM renderer (libfmhr_ham.so, gfx950 only).
+ *
+ * This is the drop-in boundary for the one hot path of agnJason/FMHR: the stage-2 "HAM" iteration of
+ * /root/reference/mesh_sfs_optim.py:253-310.  The reference reaches its native code through nvdiffrast's Python ops
+ * (`import nvdiffrast.torch as dr`, mesh_sfs_optim.py:14) and the torch helpers of models/utils.py; each entry point
+ * below names the reference interface it replaces.  Python binding: fmhr_amd/_lib.py (ctypes) — see INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer (hipMalloc'd; PyTorch-ROCm tensors' data_ptr()), fp32 / int32, contiguous;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); nothing synchronises the host,
+ *     nothing allocates, nothing keeps global mutable state: calls are re-entrant across streams and graph-capturable;
+ *   - return 0 on success, <0 on error (FMHR_E_*); fmhr_last_error() gives the thread-local message;
+ *   - gradient outputs documented "+=" are ACCUMULATED into caller-zeroed buffers, the others are overwritten;
+ *   - scratch memory is caller-allocated: query the size with the matching *_workspace_bytes().
+ * There is no CPU back end: without a GPU every compute call fails with FMHR_E_HIP.
+ */
+#ifndef FMHR_HAM_H
+#define FMHR_HAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMHR_ABI_VERSION 1
+#define FMHR_OK 0
+#define FMHR_E_ARG (-1)   /* bad shape / null pointer / workspace too small */
+#define FMHR_E_HIP (-2)   /* HIP runtime error (message has hipGetErrorString) */
+
+int fmhr_abi_version(void);
+const char* fmhr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ topology (once per mesh)
+ * Replaces nvdiffrast's per-call edge hash (`dr.antialias(..., topology_hash=None)`, mesh_sfs_optim.py:274,287 rebuild it
+ * twice per step).  opp[f*3+k] = the vertex opposite edge k (= edge (tri[f][k+1], tri[f][k+2])) in the neighbouring face,
+ * or -1 on a boundary edge.  An edge shared by >2 faces keeps the two lowest codes 3*f+k. */
+size_t fmhr_topology_workspace_bytes(int F);
+int fmhr_topology_build(const int32_t* tri, int F, int V, int32_t* opp, void* ws, size_t ws_bytes, void* stream);
+
+/* Unique-neighbour adjacency (CSR, rows sorted) for the uniform Laplacian of models/utils.py:661-693 (`compute_laplacian`,
+ * which the reference rebuilds twice per step, mesh_sfs_optim.py:292-293).  Needs `opp` from fmhr_topology_build.
+ * row_ptr [V+1], col_idx [>= 6F] (nnz = row_ptr[V] <= 6F). */
+size_t fmhr_adjacency_workspace_bytes(int V, int F);
+int fmhr_adjacency_build(const int32_t* tri, int F, int V, int32_t* row_ptr, int32_t* col_idx,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ nvdiffrast-shaped primitives
+ * dr.rasterize(glctx, pos, tri, resolution=(H,W))  — mesh_sfs_optim.py:142,212,267; get_data.py:251.
+ * pos [n,V,4] clip space, tri [F,3]; rast [n,H,W,4] = (u, v, z/w, tri_id+1) or zeros.  Rules: DESIGN.md §3. */
+size_t fmhr_rasterize_workspace_bytes(int n, int F, int H, int W);
+int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, int V, int F, int H, int W,
+                       float* rast, void* ws, size_t ws_bytes, void* stream);
+/* backward of rast[...,0:2] w.r.t. pos: dy [n,H,W,4] (only .x,.y read); gpos [n,V,4] += */
+int fmhr_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy,
+                       int n, int V, int F, int H, int W, float* gpos, void* stream);
+
+/* dr.interpolate(attr, rast, tri) — mesh_sfs_optim.py:143,214,269; get_data.py:253.  attr [an,V,C], an in {1,n}. */
+int fmhr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri,
+                         int n, int an, int V, int F, int H, int W, int C, float* out, void* stream);
+/* gattr [an,V,C] +=, grast [n,H,W,4] overwritten (.z,.w = 0) */
+int fmhr_interpolate_bwd(const float* attr, const float* rast, const int32_t* tri, const float* dy,
+                         int n, int an, int V, int F, int H, int W, int C, float* gattr, float* grast, void* stream);
+
+/* dr.antialias(color, rast, pos, tri) — mesh_sfs_optim.py:146,147,217,219,274,287.
+ * items [cap,4] int32 = (px, py, view, code), alphas [cap], counter [2] int32 = (items found, overflow flag): the work queue
+ * the backward replays.  counter must be zeroed by the caller (hipMemsetAsync) before the forward. */
+int fmhr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
+                       int n, int V, int F, int H, int W, int C, float* out,
+                       int32_t* items, float* alphas, int32_t* counter, int cap, void* stream);
+/* gcolor [n,H,W,C] overwritten (= dy + blend terms); gpos [n,V,4] += */
+int fmhr_antialias_bwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
+                       const int32_t* items, const float* alphas, const int32_t* counter, int cap,
+                       int n, int V, int F, int H, int W, int C, float* gcolor, float* gpos, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ models/utils.py helpers
+ * get_normals(vertices, faces) — models/utils.py:508-548.  verts [b,V,3]; nsum [b,V,3] = un-normalised sums (saved for the
+ * backward), normals [b,V,3] = nsum / max(|nsum|, 1e-6). */
+int fmhr_vertex_normals_fwd(const float* verts, const int32_t* tri, int b, int V, int F,
+                            float* nsum, float* normals, void* stream);
+/* gverts [b,V,3] += ; gtmp [b,V,3] scratch */
+int fmhr_vertex_normals_bwd(const float* verts, const int32_t* tri, const float* nsum, const float* gnormals,
+                            int b, int V, int F, float* gtmp, float* gverts, void* stream);
+
+/* get_radiance(coeff, normal, 3) — models/utils.py:208-226.  coeff [P,9] (per_pixel=1) or [9]; normal [P,3]; out [P]. */
+int fmhr_sh_radiance_fwd(const float* coeff, const float* normal, int P, int per_pixel, float* out, void* stream);
+/* gcoeff [P,9] overwritten when per_pixel, else [9] += ; gnormal [P,3] overwritten */
+int fmhr_sh_radiance_bwd(const float* coeff, const float* normal, const float* dy, int P, int per_pixel,
+                         float* gcoeff, float* gnormal, void* stream);
+
+/* laplacian_smoothing(x, faces, "uniform") — models/utils.py:696-722 on a cached CSR.  x [V,C] (C<=4);
+ * loss[0] += weight * (1/V) sum_i |(Lx)_i|;  lx [V,C] scratch/out.  Backward: gx [V,C] += gscale * d loss / d x. */
+int fmhr_laplacian_uniform_fwd(const float* x, const int32_t* row_ptr, const int32_t* col_idx, int V, int C,
+                               float weight, float* lx, float* loss, void* stream);
+int fmhr_laplacian_uniform_bwd(const float* lx, const int32_t* row_ptr, const int32_t* col_idx, int V, int C,
+                               float gscale, float* rowg, float* gx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ fused stage-2 step
+ * One full forward+backward of mesh_sfs_optim.py:253-308 for the n views this rank owns.  See fmhr_ham_forward() / fmhr_ham_backward() below. */
+typedef struct fmhr_ham_dims {
+    int32_t n, V, F, H, W;      /* views on this rank, vertices, faces, image size */
+    int32_t nnz;                /* adjacency nnz (row_ptr[V]) */
+    int32_t aa_cap;             /* capacity of the antialias work queue (items) */
+    int32_t reserved;
+} fmhr_ham_dims;
+
+typedef struct fmhr_ham_weights {
+    float sfs, lap, albedo, mask, edge, delta;   /* conf/demo_sfs.conf:16-22 */
+    float edge_length_mean;                      /* mesh_sfs_optim.py:188 */
+    float mse_denominator;                       /* n_global * H * W  (mesh_sfs_optim.py:295) */
+    float reg_grad_scale;                        /* 1: add the view-independent regulariser gradients (lap, albedo-lap, edge,
+                                                    delta) to gdelta/galbedo; 0: leave them out (all ranks but one in the
+                                                    view-sharded loop, so the all-reduce sums them once) */
+} fmhr_ham_weights;
+
+/* loss vector layout (device, float[8]): sfs, lap, albedo, mask, edge, delta, total, n_valid_global as used */
+#define FMHR_LOSS_SFS 0
+#define FMHR_LOSS_LAP 1
+#define FMHR_LOSS_ALBEDO 2
+#define FMHR_LOSS_MASK 3
+#define FMHR_LOSS_EDGE 4
+#define FMHR_LOSS_DELTA 5
+#define FMHR_LOSS_TOTAL 6
+#define FMHR_LOSS_NVALID 7
+
+size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
+
+/* Phase A: geometry + rasterize + shade + antialias (forward up to the AA images) and the local valid-pixel count.
+ * Phase B: losses + the whole backward.  The split exists because F.l1_loss divides by the batch-GLOBAL 3*Pv
+ * (mesh_sfs_optim.py:289): a view-sharded caller all-reduces n_valid between the two phases.
+ *   vertices_tmp, delta, albedo [V,3]; sh [n,9]; w2c, proj [n,4,4] (row-vector convention, get_data.py:96-97);
+ *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx [nnz].
+ *   n_valid_local: device int32[1] written by phase A.  n_valid_global: device float[1] read by phase B.
+ *   losses: device float[8]; gdelta, galbedo [V,3] overwritten (view-dependent part only when reg_grads=0). */
+int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
+                     const float* sh, const float* w2c, const float* proj, const float* img, const float* mask,
+                     const int32_t* tri, const int32_t* opp, int32_t* n_valid_local,
+                     void* ws, size_t ws_bytes, void* stream);
+int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const float* vertices_tmp, const float* delta,
+                      const float* albedo, const float* sh, const float* w2c, const float* proj, const float* img,
+                      const float* mask, const float* valid_mask, const int32_t* tri, const int32_t* opp,
+                      const int32_t* row_ptr, const int32_t* col_idx, const float* n_valid_global,
+                      float* losses, float* gdelta, float* galbedo, void* ws, size_t ws_bytes, void* stream);
+/* Views of the step's intermediates inside the workspace (for parity tests / rendering): returns device pointers. */
+typedef struct fmhr_ham_views {
+    float* pos;        /* [n,V,4]   */
+    float* normals;    /* [V,3]     */
+    float* rast;       /* [n,H,W,4] */
+    float* tmp_img;    /* [n,H,W,3] shaded image before antialias */
+    float* aa_img;     /* [n,H,W,3] */
+    float* aa_mask;    /* [n,H,W]   */
+    int32_t* aa_counter; /* [2] */
+} fmhr_ham_views;
+int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, fmhr_ham_views* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMHR_HAM_H */

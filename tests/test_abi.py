@@ -1,0 +1,76 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads without a GPU and exports exactly the symbols
+include/fmhr_ham.h declares; argument errors are reported without touching the GPU; the product never imports oracle/."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.check_call([os.path.join(ROOT, "fmhr_amd", "csrc", "build.sh")])
+    from fmhr_amd import _lib
+    return _lib.load()
+
+
+def test_header_and_library_agree(lib):
+    from fmhr_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "fmhr_ham.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fmhr_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (fmhr_[a-z_0-9]+)", out))
+    assert declared <= exported, declared - exported
+    assert lib.fmhr_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from fmhr_amd._lib import HamDims, HamWeights, HamViews
+    assert ctypes.sizeof(HamDims) == 32 and ctypes.sizeof(HamWeights) == 36 and ctypes.sizeof(HamViews) == 56
+
+
+def test_argument_errors_without_gpu(lib):
+    from fmhr_amd._lib import HamDims
+    assert lib.fmhr_rasterize_fwd(None, None, 1, 3, 1, 0, 8, None, None, 0, None) == -1
+    assert b"bad dims" in lib.fmhr_last_error()
+    assert lib.fmhr_rasterize_fwd(None, None, 1, 3, 1, 8, 8, None, None, 0, None) == -1
+    assert lib.fmhr_interpolate_fwd(None, None, None, 2, 3, 3, 1, 8, 8, 4, None, None) == -1
+    assert b"attr batch" in lib.fmhr_last_error()
+    assert lib.fmhr_laplacian_uniform_fwd(None, None, None, 10, 5, 1.0, None, None, None) == -1
+    bad = HamDims(0, 10, 10, 8, 8, 0, 16, 0)
+    assert lib.fmhr_ham_workspace_bytes(ctypes.byref(bad)) == 0
+    ok = HamDims(2, 100, 180, 64, 48, 0, 1024, 0)
+    assert lib.fmhr_ham_workspace_bytes(ctypes.byref(ok)) > 2 * 64 * 48 * 16
+    assert lib.fmhr_rasterize_workspace_bytes(2, 10, 8, 8) == 2 * 64 * 8 + 16 + 2 * 10 * 8
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    import torch
+    from fmhr_amd import dr, utils
+    pos = torch.zeros(1, 3, 4)
+    tri = torch.zeros(1, 3, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="GPU"):
+        dr.rasterize(dr.RasterizeGLContext(), pos, tri, (8, 8))
+    with pytest.raises(RuntimeError, match="GPU"):
+        utils.get_normals(torch.zeros(1, 3, 3), tri)
+    with pytest.raises(RuntimeError):
+        dr.rasterize(None, torch.zeros(3, 4), tri, (8, 8))
+    with pytest.raises(RuntimeError):
+        dr.rasterize(None, pos, tri.long(), (8, 8))
+
+
+def test_product_never_touches_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "fmhr_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".sh")):
+                txt = open(os.path.join(dp, f)).read()
+                # docstrings may CITE /root/reference file:line; nothing may import/open it or anything under oracle/
+                if re.search(r"(import\s+ham_oracle|from\s+oracle|oracle/|raster_oracle|sys\.path[^\n]*reference|open\([^\n]*reference)", txt):
+                    bad.append(f)
+    assert not bad, bad

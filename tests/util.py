@@ -1,0 +1,51 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+import torch
+
+
+def rel_err(a, b):
+    """per-tensor max|a-b| / max|b| (SURVEY.md §7 'Tolerance definition')."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def random_scene(seed, n=2, H=24, W=20, dtype=torch.float32, nv=14, nf=18):
+    """random soup of triangles with perspective w, unique vertex triples (no coplanar duplicates)."""
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(-0.95, 0.95, (n, nv, 2))
+    w = rng.uniform(0.6, 1.6, (n, nv, 1))
+    z = rng.uniform(-0.5, 0.5, (n, nv, 1))
+    pos = torch.tensor(np.concatenate([xy * w, z * w, w], 2), dtype=dtype)
+    faces, seen = [], set()
+    while len(faces) < nf:
+        t = rng.permutation(nv)[:3]
+        if frozenset(t.tolist()) not in seen:
+            seen.add(frozenset(t.tolist()))
+            faces.append(t)
+    tri = torch.tensor(np.stack(faces), dtype=torch.int32)
+    return pos, tri, rng
+
+
+def mesh_scene(name_or_dims, seed=0, views=None):
+    """synthetic HAM scene (fmhr_amd.synthetic) as CPU tensors + clip positions for its start mesh."""
+    from fmhr_amd import synthetic as S
+    if isinstance(name_or_dims, str):
+        sc = S.scene_from_config(name_or_dims, seed, views)
+    else:
+        sc = S.make_scene(*name_or_dims, seed=seed)
+    v4 = torch.cat([sc["vertices"], torch.ones(sc["V"], 1)], 1)
+    sc["pos"] = torch.einsum('nvk,nkl->nvl', torch.einsum('vk,nkl->nvl', v4, sc["w2c"]), sc["proj"]).contiguous()
+    return sc
+
+
+def sort_items(items, alphas):
+    """canonical order of an antialias work queue: by (view, y, x, d)."""
+    it = items.cpu().long()
+    al = alphas.cpu()
+    key = ((it[:, 2] * 100000 + it[:, 1]) * 100000 + it[:, 0]) * 2 + ((it[:, 3] >> 2) & 1)
+    o = torch.argsort(key)
+    return it[o], al[o]
