@@ -21,6 +21,22 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+# "native": fp64 tensors take their discrete decisions in fp64.  "f32": fp64 tensors take the fp32 twin's decisions (the ones
+# the HIP kernels take) and only the VALUES are fp64 — the reference for value tolerances (raster_oracle.c "mix" variants).
+DECISIONS = "native"
+
+
+class f32_decisions:
+    """context manager: with ham_oracle.f32_decisions(): ... (fp64 values on fp32 decisions)"""
+
+    def __enter__(self):
+        global DECISIONS
+        self.prev, DECISIONS = DECISIONS, "f32"
+
+    def __exit__(self, *a):
+        global DECISIONS
+        DECISIONS = self.prev
+
 
 
 def build():
@@ -37,7 +53,7 @@ def lib():
             build()
         _LIB = ctypes.CDLL(so)
         _LIB.orc_topology_build.restype = ctypes.c_int
-        for s in ("f32", "f64"):
+        for s in ("f32", "f64", "mix"):
             getattr(_LIB, "orc_antialias_fwd_" + s).restype = ctypes.c_int
     return _LIB
 
@@ -76,7 +92,8 @@ class _Rasterize(torch.autograd.Function):
         pos = pos.contiguous()
         n, V, _ = pos.shape
         rast = torch.empty(n, H, W, 4, dtype=pos.dtype)
-        getattr(lib(), "orc_rasterize_fwd_" + _sfx(pos))(_p(pos), _p(tri), n, V, tri.shape[0], H, W, _p(rast))
+        sfx = "mix" if (pos.dtype == torch.float64 and DECISIONS == "f32") else _sfx(pos)
+        getattr(lib(), "orc_rasterize_fwd_" + sfx)(_p(pos), _p(tri), n, V, tri.shape[0], H, W, _p(rast))
         ctx.save_for_backward(pos, tri, rast)
         return rast
 
@@ -128,7 +145,8 @@ class _Antialias(torch.autograd.Function):
         max_items = 2 * n * H * W
         items = torch.empty(max_items, 4, dtype=torch.int32)
         alphas = torch.empty(max_items, dtype=color.dtype)
-        cnt = getattr(lib(), "orc_antialias_fwd_" + _sfx(color))(_p(color), _p(rast), _p(pos), _p(tri), _p(opp), n, V, tri.shape[0],
+        sfx = "mix" if (color.dtype == torch.float64 and DECISIONS == "f32") else _sfx(color)
+        cnt = getattr(lib(), "orc_antialias_fwd_" + sfx)(_p(color), _p(rast), _p(pos), _p(tri), _p(opp), n, V, tri.shape[0],
                                                                  H, W, C, _p(out), _p(items), _p(alphas), max_items)
         items = items[:cnt].clone()
         alphas = alphas[:cnt].clone()
@@ -159,8 +177,8 @@ class RasterizeGLContext:
     def opp(self, tri, V):
         key = (tri.data_ptr(), tri._version, tri.shape[0], V)
         if key not in self._topo:
-            self._topo = {key: topology_build(tri, V)}
-        return self._topo[key]
+            self._topo = {key: (topology_build(tri, V), tri)}     # keep `tri` alive: its address is part of the key
+        return self._topo[key][0]
 
 
 _DEFAULT_CTX = RasterizeGLContext()
@@ -291,12 +309,13 @@ def clip_positions(vertices, w2c, proj):
 
 
 def ham_stage2_losses(vertices_tmp, delta, albedo, sh_coeff, w2c, proj, img, mask, valid_mask, faces, resolution,
-                      weights, edge_length_mean, degree=3, sfs_denominator=None, mse_denominator=None, dr=None):
+                      weights, edge_length_mean, degree=3, sfs_denominator=None, mse_denominator=None, dr=None,
+                      pos_value=None):
     """One stage-2 forward of the reference (mesh_sfs_optim.py:253-306) on top of the oracle `dr` ops.
 
     weights: dict(sfs, lap, albedo, mask, edge, delta).  Returns dict with the six losses, `loss`, and the named
     intermediates.  `sfs_denominator` / `mse_denominator` override the batch-local divisors 3*Pv and n*P (used by the
-    view-sharded path)."""
+    view-sharded path).  `pos_value` injects clip positions (values only)."""
     import torch.nn.functional as F
     import sys
     dr = dr or sys.modules[__name__]
@@ -304,6 +323,10 @@ def ham_stage2_losses(vertices_tmp, delta, albedo, sh_coeff, w2c, proj, img, mas
     vertices = vertices_tmp + delta
     n = w2c.shape[0]
     vertsw, proj_verts = clip_positions(vertices, w2c, proj)
+    if pos_value is not None:
+        # evaluate at externally supplied clip positions (e.g. the GPU's, which differ in the last bit from torch's einsum)
+        # while keeping the autograd graph: a + (b - a) == b exactly for nearby floats
+        proj_verts = proj_verts + (pos_value.to(proj_verts.dtype) - proj_verts).detach()
     normals = get_normals(vertsw[:, :, :3], faces.long())
     rast_out, _ = dr.rasterize(glctx, proj_verts, faces, resolution=resolution)
     feat = torch.cat([normals, albedo.expand(n, -1, -1), torch.ones_like(vertsw[:, :, :1])], dim=2)

@@ -66,3 +66,96 @@ int orc_topology_build(const int32_t* tri, int F, int V, int32_t* opp)
 #define FABS fabs
 #define MAXREAL DBL_MAX
 #include "raster_oracle_impl.h"
+#undef SFX
+#undef REAL
+#undef RINT
+#undef FABS
+#undef MAXREAL
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * "mix" variants: every DISCRETE decision (snap, coverage, depth order, antialias pair/edge selection, clamp flag) is taken
+ * by the fp32 twin on float-cast inputs — i.e. exactly the decisions the HIP kernels take — and every VALUE is then
+ * recomputed in fp64.  This is the reference for value tolerances: "the GPU's decisions, exact arithmetic". */
+void orc_rasterize_fwd_mix(const double* pos, const int32_t* tri, int n, int V, int F, int H, int W, double* rast)
+{
+    size_t npos = (size_t)n * V * 4, npix = (size_t)n * H * W;
+    float* posf = (float*)malloc(sizeof(float) * (npos ? npos : 1));
+    float* rastf = (float*)malloc(sizeof(float) * (npix ? npix : 1) * 4);
+    for (size_t i = 0; i < npos; i++) posf[i] = (float)pos[i];
+    orc_rasterize_fwd_f32(posf, tri, n, V, F, H, W, rastf);
+    const double xs = 2.0 / W, ys = 2.0 / H, xo = 1.0 / W - 1.0, yo = 1.0 / H - 1.0;
+    for (int b = 0; b < n; b++)
+        for (int py = 0; py < H; py++)
+            for (int px = 0; px < W; px++) {
+                size_t pix = ((size_t)b * H + py) * W + px;
+                double* o = rast + pix * 4;
+                int t = (int)rastf[pix * 4 + 3] - 1;
+                o[0] = o[1] = o[2] = o[3] = 0.0;
+                if (t < 0) continue;
+                const double* vp = pos + (size_t)b * V * 4;
+                double u, v, zw;
+                if (!fragment_f64(vp + (size_t)tri[t * 3] * 4, vp + (size_t)tri[t * 3 + 1] * 4, vp + (size_t)tri[t * 3 + 2] * 4,
+                                  px, py, xs, xo, ys, yo, &u, &v, &zw)) { u = rastf[pix * 4]; v = rastf[pix * 4 + 1]; zw = rastf[pix * 4 + 2]; }
+                o[0] = u; o[1] = v; o[2] = zw; o[3] = (double)(t + 1);
+            }
+    free(posf); free(rastf);
+}
+
+int orc_antialias_fwd_mix(const double* color, const double* rast, const double* pos, const int32_t* tri, const int32_t* opp,
+                          int n, int V, int F, int H, int W, int C, double* out, int32_t* items, double* alphas, int max_items)
+{
+    size_t npos = (size_t)n * V * 4, npix = (size_t)n * H * W;
+    float* posf = (float*)malloc(sizeof(float) * (npos ? npos : 1));
+    float* rastf = (float*)malloc(sizeof(float) * (npix ? npix : 1) * 4);
+    for (size_t i = 0; i < npos; i++) posf[i] = (float)pos[i];
+    for (size_t i = 0; i < npix * 4; i++) rastf[i] = (float)rast[i];
+    memcpy(out, color, sizeof(double) * npix * C);
+    const double xh = 0.5 * W, yh = 0.5 * H;
+    int cnt = 0;
+    for (int b = 0; b < n; b++)
+        for (int py = 0; py < H; py++)
+            for (int px = 0; px < W; px++)
+                for (int d = 0; d < 2; d++) {
+                    if (d == 0 && px + 1 >= W) continue;
+                    if (d == 1 && py + 1 >= H) continue;
+                    size_t pix0 = ((size_t)b * H + py) * W + px;
+                    size_t pix1 = pix0 + (d ? (size_t)W : 1);
+                    if (rastf[pix0 * 4 + 3] == rastf[pix1 * 4 + 3]) continue;
+                    float alpha_f;
+                    int code = aa_analyse_f32(rastf, posf, tri, opp, V, F, H, W, b, px, py, d, &alpha_f);
+                    if (!code) continue;
+                    double alpha = (double)alpha_f;
+                    if (!(code & AA_CLAMPED)) {
+                        /* recompute the crossing of the selected edge in fp64 */
+                        int t = (int)rastf[((code & AA_TRI1) ? pix1 : pix0) * 4 + 3] - 1;
+                        int qx = px, qy = py;
+                        if (code & AA_TRI1) { qx += 1 - d; qy += d; }
+                        int di = AA_DI(code);
+                        int va = tri[t * 3 + (di + 1) % 3], vb = tri[t * 3 + (di + 2) % 3];
+                        const double* pa = pos + ((size_t)b * V + va) * 4;
+                        const double* pb = pos + ((size_t)b * V + vb) * 4;
+                        double fx = qx + 0.5 - xh, fy = qy + 0.5 - yh;
+                        double xa = pa[0] / pa[3] * xh - fx, ya = pa[1] / pa[3] * yh - fy;
+                        double xb = pb[0] / pb[3] * xh - fx, yb = pb[1] / pb[3] * yh - fy;
+                        if (d) { double tt; tt = xa; xa = ya; ya = tt; tt = xb; xb = yb; yb = tt; }
+                        double ds = (code & AA_TRI1) ? -1.0 : 1.0;
+                        double xc = xa + ya / (ya - yb) * (xb - xa);
+                        double dc = ds * xc;
+                        if (dc < 0.0) dc = 0.0;
+                        if (dc > 1.0) dc = 1.0;
+                        alpha = ds * (0.5 - dc);
+                        if ((alpha > 0.0) != (alpha_f > 0.0f)) alpha = (double)alpha_f;   /* keep the f32 target pixel */
+                    }
+                    const double* c0 = color + pix0 * C;
+                    const double* c1 = color + pix1 * C;
+                    double* o = out + ((alpha > 0.0) ? pix0 : pix1) * C;
+                    for (int c = 0; c < C; c++) o[c] += alpha * (c1[c] - c0[c]);
+                    if (cnt < max_items) {
+                        items[cnt * 4 + 0] = px; items[cnt * 4 + 1] = py; items[cnt * 4 + 2] = b; items[cnt * 4 + 3] = code;
+                        alphas[cnt] = alpha;
+                    }
+                    cnt++;
+                }
+    free(posf); free(rastf);
+    return cnt;
+}

@@ -73,8 +73,10 @@ def test_large_mesh_vs_oracle(U, oracle):
     (nd * w.to(dev)).sum().backward()
     assert rel_err(nd, oracle.get_normals(v[None], f)) < 1e-5
     assert rel_err(vd.grad, vg.grad) < TOL
+    # the reference's L.mm(x) loses ~1e-4 (relative) to cancellation in fp32 on a smooth mesh (measured: its own fp32 vs
+    # fp64 run differ by 1.2e-4), so the truth for the 1e-4 bar is the fp64 oracle; the kernel sums differences instead
     for x in (v, sc["albedo_true"]):
-        a = x.clone().requires_grad_(True)
+        a = x.double().clone().requires_grad_(True)
         la = oracle.laplacian_smoothing(a, f)
         la.backward()
         b = x.to(dev).clone().requires_grad_(True)
