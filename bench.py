@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py — HAM stage-2 iterations/sec on MI355X (BASELINE.json metric).
+
+One "step" = one full stage-2 iteration of /root/reference/mesh_sfs_optim.py:253-310 on the metric workload (48 views,
+512x512, sub3-class mesh V=49153/F=98048): render + six losses + backward + gradient exchange + Adam step.
+`python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under torch.distributed.run, one rank per GPU,
+views sharded contiguously over ranks (strong scaling: the 48-view batch is fixed), ONE packed all-reduce of the per-vertex
+gradients per step plus the valid-pixel count all-reduce.
+
+Prints ONE JSON line on rank 0 with the contract fields plus:
+  roofline     — dominant launch group of the step: algorithmic bytes (SURVEY.md §8d per-primitive table) / its mean HIP-event
+                 duration over the timed region, vs the 8 TB/s HBM peak
+  step_roofline— the same for the whole step: n*B_alg(view)+const bytes / device time of the step
+  kernels      — mean HIP-event milliseconds per launch group (from an untimed profiling pass)
+  cpu_baseline — the CPU oracle restatement ("port") timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from fmhr_amd import _lib, dist as fdist, synthetic  # noqa: E402
+from fmhr_amd.ham import HamStage2, edge_length_mean, render_forward  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+SLOTS = ["geometry", "raster_clear", "raster_tris", "raster_large", "raster_resolve", "shade_fwd", "aa_fwd", "loss_pix",
+         "aa_bwd", "shade_bwd", "transform_bwd", "normals_bwd", "regularisers"]
+
+
+def alg_bytes(slot, n, P, V, F, nnz):
+    """Algorithmic bytes per launch of a launch group = SURVEY.md §8d per-primitive table, regrouped by launch group
+    (the groups sum to n*(508 P + 252 V + 72 F) + the ~34 MB/step view-independent constant)."""
+    per_view = {
+        "geometry": 28 * V,                                   # transform fwd: 12V r + 16V w
+        "raster_tris": 16 * V + 12 * F,                       # rasterize fwd reads
+        "raster_resolve": 16 * P,                             # rasterize fwd write
+        "shade_fwd": 92 * P + 28 * V + 12 * F,                # interpolate C=7 fwd + shade fwd
+        "aa_fwd": 64 * P + 32 * V + 24 * F,                   # antialias mask + image fwd
+        "loss_pix": 88 * P,                                   # losses fwd + bwd
+        "aa_bwd": 80 * P + 32 * V,                            # antialias bwd
+        "shade_bwd": 168 * P + 88 * V + 24 * F,               # shade + interpolate + rasterize bwd
+        "transform_bwd": 28 * V,
+    }
+    const = {
+        "geometry": 24 * V + 12 * F,                          # normals fwd
+        "normals_bwd": 24 * V + 12 * F,
+        "regularisers": 4 * (8 * nnz + 24 * V) + 24 * F + 60 * V,
+    }
+    return n * per_view.get(slot, 0) + const.get(slot, 0)
+
+
+def step_alg_bytes(n, P, V, F, nnz):
+    return n * (508 * P + 252 * V + 72 * F) + (48 * V + 24 * F) + 4 * (8 * nnz + 24 * V) + (24 * F + 60 * V) + 2 * 7 * 12 * V
+
+
+class Timing:
+    """HIP events for the per-launch-group timing hook of the C ABI (fmhr_timing_attach)."""
+
+    def __init__(self, n_sets, stream):
+        import ctypes
+        self.ct = ctypes
+        self.sets = []
+        for _ in range(n_sets):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(2 * len(SLOTS))]
+            for e in evs:
+                e.record(stream)                      # creates the underlying hipEvent_t
+            arr = (ctypes.c_void_p * len(evs))(*[e.cuda_event for e in evs])
+            self.sets.append((evs, arr))
+
+    def attach(self, i, only_slot=-1):
+        _lib.call("fmhr_timing_attach", self.sets[i][1], 2 * len(SLOTS), only_slot)
+
+    @staticmethod
+    def detach():
+        _lib.call("fmhr_timing_detach")
+
+    def ms(self, i, slot):
+        evs = self.sets[i][0]
+        return evs[2 * slot].elapsed_time(evs[2 * slot + 1])
+
+
+def cpu_baseline(scene, views_sample, seed):
+    """Time the CPU oracle (restatement of the reference loop body on CPU torch + the C rasterizer) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ham_oracle as oracle
+    oracle.lib()
+    # the GPU box gives one-GPU jobs a 16-CPU share whatever os.cpu_count() says: over-subscribing 256 threads is 30x slower
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = int(os.environ.get("FMHR_CPU_THREADS", min(avail, 16)))
+    torch.set_num_threads(cores)
+    S = views_sample
+    w2c, proj = scene["w2c"][:S].contiguous(), scene["proj"][:S].contiguous()
+    sh = scene["sh0"][:S].contiguous()
+    H, W = scene["H"], scene["W"]
+    faces = scene["faces"]
+    with torch.no_grad():
+        ones = torch.ones(S, H, W)
+        tg = oracle.ham_stage2_losses(scene["vertices_true"], torch.zeros_like(scene["vertices"]), scene["albedo_true"][None],
+                                      scene["sh_true"][:S], w2c, proj, torch.zeros(S, H, W, 3), ones, ones, faces, (H, W),
+                                      dict(sfs=0, lap=0, albedo=0, mask=0, edge=0, delta=0), 0.0)
+    img, mask = tg["tmp_img"], (tg["rast"][..., 3] > 0).float()
+    valid_mask = tg["pred_mask"]
+    elm = float(oracle.edge_length_mean(scene["vertices"], faces))
+    times = []
+    for it in range(3):
+        d = torch.zeros_like(scene["vertices"]).requires_grad_(True)
+        a = scene["albedo0"][None].clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        out = oracle.ham_stage2_losses(scene["vertices"], d, a, sh, w2c, proj, img, mask, valid_mask, faces, (H, W),
+                                       scene["weights"], elm)
+        out["loss"].backward()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    n = scene["views"]
+    return dict(value=1.0 / (t * n / S), unit="iterations/s", cores=cores, kind="port",
+                sample=f"{S} of {n} views ({H}x{W}, V={scene['V']}), fwd+bwd, median of 3 = {t:.3f}s, scaled x{n / S:.0f}; "
+                       f"C rasterizer is single-threaded, torch ops use {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="metric", choices=list(synthetic.CONFIGS))
+    ap.add_argument("--views", type=int, default=None, help="override the view count of the config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    rank, world, local = fdist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(args.seed)
+
+    scene = synthetic.scene_from_config(args.config, args.seed, args.views)
+    n_total, H, W, V, F = scene["views"], scene["H"], scene["W"], scene["V"], scene["F"]
+    s0, s1 = fdist.shard_views(n_total, rank, world)
+    n = s1 - s0
+    if n == 0:
+        raise SystemExit("more ranks than views")
+    faces = scene["faces"].to(dev)
+    w2c, proj = scene["w2c"][s0:s1].contiguous().to(dev), scene["proj"][s0:s1].contiguous().to(dev)
+    sh = scene["sh0"][s0:s1].contiguous().to(dev)
+    local_scene = dict(scene, views=n, sh_true=scene["sh_true"][s0:s1], sh0=scene["sh0"][s0:s1])
+    tg = synthetic.make_targets(local_scene, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, H, W), device=dev)
+    vtmp = scene["vertices"].to(dev).contiguous()
+    elm = edge_length_mean(vtmp, faces)
+    hs = HamStage2(faces, V, n, H, W, scene["weights"], elm, n_global=n_total)
+
+    delta = torch.zeros(V, 3, device=dev, requires_grad=True)
+    albedo = scene["albedo0"][None].to(dev).clone().requires_grad_(True)           # [1,V,3] as in the reference (:176)
+    lr = scene["lr"]
+    groups = [{'params': delta, 'lr': lr["lr"]}, {'params': albedo, 'lr': lr["albedo_lr"]}]
+    try:
+        opt = torch.optim.Adam(groups, fused=True)
+    except Exception:
+        opt = torch.optim.Adam(groups)
+    sharded = fdist.ShardedStep(V, dev)
+    group = torch.distributed.group.WORLD if world > 1 else None
+
+    def step():
+        losses, gd, ga = hs.step(vtmp, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"],
+                                 group=group, reg_grads=(rank == 0))
+        if world > 1:
+            losses, gd, ga = sharded.reduce(losses, gd, ga)
+        delta.grad, albedo.grad = gd, ga.view(1, V, 3)
+        opt.step()
+        return losses
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    # untimed profiling pass: per-launch-group HIP-event times -> dominant group
+    prof_steps = 3
+    tm = Timing(prof_steps, stream)
+    for i in range(prof_steps):
+        tm.attach(i)
+        step()
+    Timing.detach()
+    torch.cuda.synchronize()
+    kernels = {name: sum(tm.ms(i, k) for i in range(prof_steps)) / prof_steps for k, name in enumerate(SLOTS)}
+    P = H * W
+    dom = max((k for k in range(len(SLOTS)) if alg_bytes(SLOTS[k], n, P, V, F, hs.nnz) > 0), key=lambda k: kernels[SLOTS[k]])
+
+    # timed region: EXACTLY K steps between barrier+synchronize pairs; HIP events on the step's own stream bracket the
+    # dominant launch group (recorded asynchronously by the library) and the whole step
+    K = args.steps
+    tk = Timing(K, stream)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        tk.attach(i, dom)
+        ev0[i].record(stream)
+        losses = step()
+        ev1[i].record(stream)
+    barrier()
+    t1 = time.perf_counter()
+    Timing.detach()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    dom_ms = sum(tk.ms(i, dom) for i in range(K)) / K
+    step_dev_ms = sum(ev0[i].elapsed_time(ev1[i]) for i in range(K)) / K
+    final = hs.loss_dict() if world == 1 else dict(zip(("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid"), losses.tolist()))
+
+    if rank == 0:
+        ms_per_step = elapsed / K * 1e3
+        dom_bytes = alg_bytes(SLOTS[dom], n, P, V, F, hs.nnz)
+        dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
+        sb = step_alg_bytes(n, P, V, F, hs.nnz)
+        step_gbs = sb / (step_dev_ms * 1e-3) / 1e9
+        out = {
+            "metric": "HAM render+backward iters/sec (48 views, 49k verts, 512x512)",
+            "value": K / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n_total} views x {H}x{W}, blob mesh V={V} F={F} (MANO sub3 class), "
+                                   f"stage-2 step = render + 6 losses + backward + grad all-reduce + Adam",
+                       "views": n_total, "views_per_gpu": n, "H": H, "W": W, "V": V, "F": F,
+                       "coverage": round(tg["coverage"], 4), "parallelism": f"views sharded over {world} GPU(s)"},
+            "roofline": {"bound": "hbm", "kernel": SLOTS[dom], "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom_gbs / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": dom_bytes,
+                         "avg_launch_ms": dom_ms},
+            "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": step_gbs / HBM_PEAK_GBS, "alg_bytes_per_step": sb, "device_ms_per_step": step_dev_ms},
+            "kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
+            "losses": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in final.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, max(1, min(args.cpu_views, n_total)), args.seed)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

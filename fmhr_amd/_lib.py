@@ -49,6 +49,8 @@ SIGNATURES = {
     "fmhr_sh_radiance_bwd": (c_int, [P, P, P, c_int, c_int, P, P, P]),
     "fmhr_laplacian_uniform_fwd": (c_int, [P, P, P, c_int, c_int, c_float, P, P, P]),
     "fmhr_laplacian_uniform_bwd": (c_int, [P, P, P, c_int, c_int, c_float, P, P, P]),
+    "fmhr_timing_attach": (c_int, [P, c_int, c_int]),
+    "fmhr_timing_detach": (c_int, []),
     "fmhr_ham_workspace_bytes": (c_size_t, [ctypes.POINTER(HamDims)]),
     "fmhr_ham_workspace_views": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, ctypes.POINTER(HamViews)]),
     "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),

@@ -22,5 +22,34 @@ int hip_fail(hipError_t e, const char* what)
 }
 }  // namespace fmhr
 
+namespace fmhr {
+static thread_local void** g_ev = nullptr;
+static thread_local int g_only = -1;
+
+void prof_mark(int slot, int end, hipStream_t st)
+{
+    if (g_ev == nullptr || (g_only >= 0 && g_only != slot)) return;
+    (void)hipEventRecord((hipEvent_t)g_ev[2 * slot + end], st);
+}
+}  // namespace fmhr
+
+extern "C" int fmhr_timing_attach(void** events, int n_events, int only_slot)
+{
+    if (events == nullptr || n_events < 2 * FMHR_SLOT_COUNT || only_slot >= FMHR_SLOT_COUNT) {
+        fmhr::set_error("timing_attach: need %d events", 2 * FMHR_SLOT_COUNT);
+        return FMHR_E_ARG;
+    }
+    fmhr::g_ev = events;
+    fmhr::g_only = only_slot;
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_timing_detach(void)
+{
+    fmhr::g_ev = nullptr;
+    fmhr::g_only = -1;
+    return FMHR_OK;
+}
+
 extern "C" int fmhr_abi_version(void) { return FMHR_ABI_VERSION; }
 extern "C" const char* fmhr_last_error(void) { return fmhr::g_err; }

@@ -11,6 +11,13 @@ namespace fmhr {
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+void prof_mark(int slot, int end, hipStream_t st);   // abi.cpp: records a timing event when a sink is attached
+
+struct ProfScope {                                   // brackets a launch group with the optional timing events
+    int slot; hipStream_t st;
+    ProfScope(int s, hipStream_t t) : slot(s), st(t) { prof_mark(slot, 0, st); }
+    ~ProfScope() { prof_mark(slot, 1, st); }
+};
 
 #define FMHR_CHECK_ARG(cond, ...)                     \
     do {                                              \

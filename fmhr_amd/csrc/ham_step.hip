@@ -136,13 +136,20 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     float* pos = (float*)(w + L.pos);
     float* rast = (float*)(w + L.rast);
     size_t nP = (size_t)d->n * d->H * d->W;
-    TRY(add_delta_impl(vertices_tmp, delta, d->V * 3, vertices, st));
-    TRY(normals_fwd_impl(vertices, tri, 1, d->V, d->F, (float*)(w + L.nsum), (float*)(w + L.normals), st));
-    TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, st));
+    {
+        ProfScope ps(FMHR_SLOT_GEOMETRY, st);
+        TRY(add_delta_impl(vertices_tmp, delta, d->V * 3, vertices, st));
+        TRY(normals_fwd_impl(vertices, tri, 1, d->V, d->F, (float*)(w + L.nsum), (float*)(w + L.normals), st));
+        TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, st));
+    }
     TRY(rasterize_fwd_impl(pos, tri, d->n, d->V, d->F, d->H, d->W, rast, w + L.raster_ws, st));
-    HIPTRY(hipMemsetAsync(n_valid_local, 0, 4, st), "memset n_valid");
-    TRY(shade_fwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, d->n, d->F, d->H, d->W, (float*)(w + L.tmp_img),
-                       (float*)(w + L.mask_col), n_valid_local, st));
+    {
+        ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
+        HIPTRY(hipMemsetAsync(n_valid_local, 0, 4, st), "memset n_valid");
+        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, d->n, d->F, d->H, d->W, (float*)(w + L.tmp_img),
+                           (float*)(w + L.mask_col), n_valid_local, st));
+    }
+    ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     HIPTRY(hipMemcpyAsync(w + L.aa_img, w + L.tmp_img, nP * 12, hipMemcpyDeviceToDevice, st), "copy tmp_img");
     HIPTRY(hipMemcpyAsync(w + L.aa_mask, w + L.mask_col, nP * 4, hipMemcpyDeviceToDevice, st), "copy mask_col");
     HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, st), "memset aa_counter");
@@ -177,27 +184,43 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     size_t nP = (size_t)d->n * d->H * d->W, V = d->V;
     const float rg = wt->reg_grad_scale;
 
-    HIPTRY(hipMemsetAsync(losses, 0, 32, st), "memset losses");
-    HIPTRY(hipMemsetAsync(gpos, 0, (size_t)d->n * V * 16, st), "memset gpos");
-    HIPTRY(hipMemsetAsync(gattr, 0, V * 32, st), "memset gattr");
-    HIPTRY(hipMemsetAsync(gvert, 0, V * 12, st), "memset gvert");
-    HIPTRY(hipMemsetAsync(galbedo, 0, V * 12, st), "memset galbedo");
-
-    // losses on the antialiased images + their per-pixel gradients
-    TRY(loss_pix_impl(rast, (float*)(w + L.aa_img), img, mask, (float*)(w + L.aa_mask), valid_mask, (long long)nP, n_valid_global,
-                      wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa_img), (float*)(w + L.g_aa_mask), losses, st));
-    // antialias backward (both images share one queue): colour grads of the shaded image, position grads of both
-    HIPTRY(hipMemcpyAsync(w + L.g_tmp_img, w + L.g_aa_img, nP * 12, hipMemcpyDeviceToDevice, st), "copy g_aa_img");
-    TRY(aa_bwd_dual((float*)(w + L.mask_col), (float*)(w + L.tmp_img), rast, pos, tri, (float*)(w + L.g_aa_mask),
-                    (float*)(w + L.g_aa_img), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas), (int32_t*)(w + L.aa_counter),
-                    d->aa_cap, d->n, d->V, d->H, d->W, (float*)(w + L.g_tmp_img), gpos, st));
-    // shade + interpolate + rasterize backward
-    TRY(shade_bwd_impl(rast, tri, pos, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_tmp_img), d->n, d->V, d->F,
-                       d->H, d->W, gattr, gpos, st));
-    // clip transform backward (sum over views) and vertex-normal backward
-    TRY(transform_bwd_impl(gpos, w2c, proj, d->n, d->V, gvert, st));
-    TRY(normals_bwd_impl(vertices, tri, (float*)(w + L.nsum), gattr, 8, 1, d->V, d->F, (float*)(w + L.gtmp), gvert, st));
-    TRY(unpack_albedo_grad_impl(gattr, d->V, galbedo, st));
+    {
+        ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
+        HIPTRY(hipMemsetAsync(losses, 0, 32, st), "memset losses");
+        HIPTRY(hipMemsetAsync(gpos, 0, (size_t)d->n * V * 16, st), "memset gpos");
+        HIPTRY(hipMemsetAsync(gattr, 0, V * 32, st), "memset gattr");
+        HIPTRY(hipMemsetAsync(gvert, 0, V * 12, st), "memset gvert");
+        HIPTRY(hipMemsetAsync(galbedo, 0, V * 12, st), "memset galbedo");
+        // losses on the antialiased images + their per-pixel gradients
+        TRY(loss_pix_impl(rast, (float*)(w + L.aa_img), img, mask, (float*)(w + L.aa_mask), valid_mask, (long long)nP,
+                          n_valid_global, wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa_img),
+                          (float*)(w + L.g_aa_mask), losses, st));
+    }
+    {
+        // antialias backward (both images share one queue): colour grads of the shaded image, position grads of both
+        ProfScope ps(FMHR_SLOT_AA_BWD, st);
+        HIPTRY(hipMemcpyAsync(w + L.g_tmp_img, w + L.g_aa_img, nP * 12, hipMemcpyDeviceToDevice, st), "copy g_aa_img");
+        TRY(aa_bwd_dual((float*)(w + L.mask_col), (float*)(w + L.tmp_img), rast, pos, tri, (float*)(w + L.g_aa_mask),
+                        (float*)(w + L.g_aa_img), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
+                        (int32_t*)(w + L.aa_counter), d->aa_cap, d->n, d->V, d->H, d->W, (float*)(w + L.g_tmp_img), gpos, st));
+    }
+    {
+        // shade + interpolate + rasterize backward
+        ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
+        TRY(shade_bwd_impl(rast, tri, pos, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_tmp_img), d->n, d->V,
+                           d->F, d->H, d->W, gattr, gpos, st));
+    }
+    {
+        // clip transform backward (sum over views)
+        ProfScope ps(FMHR_SLOT_TRANSFORM_BWD, st);
+        TRY(transform_bwd_impl(gpos, w2c, proj, d->n, d->V, gvert, st));
+    }
+    {
+        ProfScope ps(FMHR_SLOT_NORMALS_BWD, st);
+        TRY(normals_bwd_impl(vertices, tri, (float*)(w + L.nsum), gattr, 8, 1, d->V, d->F, (float*)(w + L.gtmp), gvert, st));
+        TRY(unpack_albedo_grad_impl(gattr, d->V, galbedo, st));
+    }
+    ProfScope ps(FMHR_SLOT_REGULARISERS, st);
     // view-independent regularisers (mesh_sfs_optim.py:292-293, 296-304)
     TRY(lap_fwd_impl(vertices, row_ptr, col_idx, d->V, 3, wt->lap, (float*)(w + L.lx_v), losses + FMHR_LOSS_LAP, st));
     TRY(lap_fwd_impl(albedo, row_ptr, col_idx, d->V, 3, wt->albedo, (float*)(w + L.lx_a), losses + FMHR_LOSS_ALBEDO, st));

@@ -245,16 +245,24 @@ int rasterize_fwd_impl(const float* pos, const int32_t* tri, int n, int V, int F
     int* large_cnt = (int*)((char*)ws + nP * 8);
     int2* large_q = (int2*)((char*)ws + nP * 8 + 16);
     if (nP == 0) return FMHR_OK;
-    hipError_t e = hipMemsetAsync(keys, 0xFF, nP * 8, st);
-    if (e != hipSuccess) return hip_fail(e, "memset keys");
-    e = hipMemsetAsync(large_cnt, 0, 16, st);
-    if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
+    {
+        ProfScope ps(FMHR_SLOT_RASTER_CLEAR, st);
+        hipError_t e = hipMemsetAsync(keys, 0xFF, nP * 8, st);
+        if (e != hipSuccess) return hip_fail(e, "memset keys");
+        e = hipMemsetAsync(large_cnt, 0, 16, st);
+        if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
+    }
     if ((long long)n * F > 0) {
-        k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, large_cnt, large_q);
-        FMHR_CHECK_LAUNCH("k_raster_tris");
+        {
+            ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
+            k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, large_cnt, large_q);
+            FMHR_CHECK_LAUNCH("k_raster_tris");
+        }
+        ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);
         k_raster_large<<<1024, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, large_cnt, large_q);
         FMHR_CHECK_LAUNCH("k_raster_large");
     }
+    ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
     k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, H, W, keys, (float4*)rast);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;

@@ -155,6 +155,28 @@ typedef struct fmhr_ham_views {
 } fmhr_ham_views;
 int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, fmhr_ham_views* out);
 
+/* ------------------------------------------------------------------------------------------------ per-kernel timing (optional)
+ * Attach an array of 2*FMHR_SLOT_COUNT hipEvent_t (created by the caller with timing enabled) to the CALLING THREAD: while
+ * attached, fmhr_ham_forward/backward record events[2*slot] / events[2*slot+1] around launch group `slot` on the step's
+ * stream (asynchronously: nothing synchronises).  only_slot >= 0 restricts recording to that group; -1 records all.
+ * The caller reads hipEventElapsedTime after synchronising.  Thread-local: other threads/streams are unaffected. */
+#define FMHR_SLOT_GEOMETRY 0        /* vertices = tmp+delta, vertex normals, clip transform */
+#define FMHR_SLOT_RASTER_CLEAR 1
+#define FMHR_SLOT_RASTER_TRIS 2
+#define FMHR_SLOT_RASTER_LARGE 3
+#define FMHR_SLOT_RASTER_RESOLVE 4
+#define FMHR_SLOT_SHADE_FWD 5
+#define FMHR_SLOT_AA_FWD 6          /* the two image copies + the antialias kernel */
+#define FMHR_SLOT_LOSS_PIX 7        /* + the gradient buffer clears */
+#define FMHR_SLOT_AA_BWD 8
+#define FMHR_SLOT_SHADE_BWD 9
+#define FMHR_SLOT_TRANSFORM_BWD 10
+#define FMHR_SLOT_NORMALS_BWD 11
+#define FMHR_SLOT_REGULARISERS 12
+#define FMHR_SLOT_COUNT 13
+int fmhr_timing_attach(void** events, int n_events, int only_slot);
+int fmhr_timing_detach(void);
+
 #ifdef __cplusplus
 }
 #endif
