@@ -1,0 +1,93 @@
+"""World-size-2 rehearsal of the view-sharded step on CPU (gloo): fmhr_amd.dist's partition + valid-count all-reduce + ONE
+packed gradient all-reduce must reproduce the single-process full-batch result.  The compute is the CPU oracle (the product
+has no CPU path); what is under test is the host-side sharding logic the GPU ranks run unchanged over RCCL."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_step(oracle, sc, s0, s1, n_total, reg_grads, reduce_fn):
+    """what HamStage2.step does on a GPU rank, on the oracle: forward -> n_valid all-reduce -> losses with global divisors."""
+    sl = slice(s0, s1)
+    d = sc["delta"].clone().requires_grad_(True)
+    a = sc["albedo"][None].clone().requires_grad_(True)
+    H, W = sc["H"], sc["W"]
+    with torch.no_grad():
+        _, pos = oracle.clip_positions(sc["vertices"] + sc["delta"], sc["w2c"][sl], sc["proj"][sl])
+        rast, _ = oracle.rasterize(None, pos.contiguous(), sc["faces"], (H, W))
+        n_valid = ((sc["mask"][sl] > 0) & (rast[..., 3] > 0)).sum().to(torch.float32).reshape(1)
+    reduce_fn(n_valid)
+    w = dict(sc["weights"])
+    out = oracle.ham_stage2_losses(sc["vertices"], d, a, sc["sh0"][sl], sc["w2c"][sl], sc["proj"][sl], sc["img"][sl],
+                                   sc["mask"][sl], sc["valid_mask"][sl], sc["faces"], (H, W), w, sc["elm"],
+                                   sfs_denominator=3.0 * float(n_valid), mse_denominator=float(n_total * H * W))
+    view_terms = out["sfs"] + out["mask"]
+    reg_terms = out["lap"] + out["albedo"] + out["edge"] + out["delta"]
+    (view_terms + (reg_terms if reg_grads else 0.0 * reg_terms)).backward()
+    losses = torch.stack([out[k].detach() for k in ("sfs", "lap", "albedo", "mask", "edge", "delta")] +
+                         [out["loss"].detach(), n_valid[0]]).to(torch.float32)
+    return losses, d.grad, a.grad[0]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    import ham_oracle as oracle
+    from fmhr_amd import dist as fdist
+    from test_gpu_ham import prepare
+    r, w, _ = fdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    sc = prepare(oracle, (5, 64, 48, 10, 14), 7)           # 5 views over 2 ranks: ragged 3 + 2 split
+    s0, s1 = fdist.shard_views(sc["views"], rank, world)
+    sh = fdist.ShardedStep(sc["V"], torch.device("cpu"))
+    losses, gd, ga = _oracle_step(oracle, sc, s0, s1, sc["views"], rank == 0, lambda t: dist.all_reduce(t))
+    ls, gd, ga = sh.reduce(losses, gd, ga)
+    if rank == 0:
+        q.put((ls.clone(), gd.clone(), ga.clone(), (s0, s1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_match_single_process(oracle):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fmhr_amd import dist as fdist
+    from test_gpu_ham import prepare
+    from util import rel_err
+    assert [fdist.shard_views(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [fdist.shard_views(48, r, 8) for r in range(8)] == [(6 * r, 6 * r + 6) for r in range(8)]
+    assert fdist.shard_views(3, 3, 4) == (3, 3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ls, gd, ga, shard0 = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert shard0 == (0, 3)
+    sc = prepare(oracle, (5, 64, 48, 10, 14), 7)
+    ref_l, ref_gd, ref_ga = _oracle_step(oracle, sc, 0, 5, 5, True, lambda t: None)
+    assert rel_err(ls[:7], ref_l[:7]) < 1e-5, (ls, ref_l)
+    assert float(ls[7]) == float(ref_l[7])
+    assert rel_err(gd, ref_gd) < 1e-5 and rel_err(ga, ref_ga) < 1e-5
