@@ -23,8 +23,8 @@ class HamWeights(ctypes.Structure):
 
 
 class HamViews(ctypes.Structure):
-    _fields_ = [("pos", c_void_p), ("normals", c_void_p), ("rast", c_void_p), ("tmp_img", c_void_p), ("aa_img", c_void_p),
-                ("aa_mask", c_void_p), ("aa_counter", c_void_p)]
+    _fields_ = [("pos", c_void_p), ("normals", c_void_p), ("rast", c_void_p), ("shaded", c_void_p), ("aa", c_void_p),
+                ("aa_counter", c_void_p)]
 
 
 P = c_void_p
@@ -36,7 +36,7 @@ SIGNATURES = {
     "fmhr_topology_build": (c_int, [P, c_int, c_int, P, P, c_size_t, P]),
     "fmhr_adjacency_workspace_bytes": (c_size_t, [c_int, c_int]),
     "fmhr_adjacency_build": (c_int, [P, c_int, c_int, P, P, P, c_size_t, P]),
-    "fmhr_rasterize_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "fmhr_rasterize_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "fmhr_rasterize_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "fmhr_rasterize_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "fmhr_interpolate_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
@@ -55,7 +55,9 @@ SIGNATURES = {
     "fmhr_ham_workspace_views": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, ctypes.POINTER(HamViews)]),
     "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "fmhr_ham_backward": (c_int, [ctypes.POINTER(HamDims), ctypes.POINTER(HamWeights), P, P, P, P, P, P, P, P, P, P, P, P, P,
-                                  P, P, P, P, P, c_size_t, P]),
+                                  P, P, P, P, P, P, P, c_size_t, P]),
+    "fmhr_vertex_faces_workspace_bytes": (c_size_t, [c_int]),
+    "fmhr_vertex_faces_build": (c_int, [P, c_int, c_int, P, P, P, c_size_t, P]),
 }
 
 _lib = None

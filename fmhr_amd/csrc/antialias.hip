@@ -142,6 +142,23 @@ __global__ void k_adj_sort_rows(int V, const int* __restrict__ row_ptr, int* col
     }
 }
 
+// vertex -> incident face corners (code = 3*face + corner), CSR with sorted rows: the gather-style backward walks it
+__global__ void k_vf_count(const int32_t* __restrict__ tri, int F, int V, int* deg)
+{
+    int code = blockIdx.x * kBlock + threadIdx.x;
+    if (code >= 3 * F) return;
+    int v = tri[code];
+    if ((unsigned)v < (unsigned)V) atomicAdd(&deg[v], 1);
+}
+
+__global__ void k_vf_fill(const int32_t* __restrict__ tri, int F, int V, const int* __restrict__ row_ptr, int* cursor, int* idx)
+{
+    int code = blockIdx.x * kBlock + threadIdx.x;
+    if (code >= 3 * F) return;
+    int v = tri[code];
+    if ((unsigned)v < (unsigned)V) idx[row_ptr[v] + atomicAdd(&cursor[v], 1)] = code;
+}
+
 // ------------------------------------------------------------------------------------------------ antialias analysis
 constexpr int AA_DOWN = 4, AA_TRI1 = 8, AA_FOUND = 16, AA_CLAMPED = 32;
 
@@ -391,26 +408,25 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
     return FMHR_OK;
 }
 
-// fused-step entry points (ham_step.hip)
-int aa_fwd_dual(const float* mask_col, const float* img_col, const float* rast, const float* pos, const int32_t* tri,
-                const int32_t* opp, int n, int V, int F, int H, int W, float* out_mask, float* out_img, int32_t* items,
-                float* alphas, int32_t* counter, int cap, hipStream_t st)
+// fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour)
+int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int n, int V,
+                int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int cap, hipStream_t st)
 {
     long long nP = (long long)n * H * W;
-    k_aa_fwd<1, 3><<<cdiv(nP, kBlock), kBlock, 0, st>>>(mask_col, img_col, (const float4*)rast, pos, tri, opp, n, V, F, H, W, 1,
-                                                       out_mask, out_img, (int4*)items, alphas, counter, cap);
-    FMHR_CHECK_LAUNCH("k_aa_fwd<1,3>");
+    k_aa_fwd<4, 0><<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, opp, n, V, F, H, W, 4, out,
+                                                       nullptr, (int4*)items, alphas, counter, cap);
+    FMHR_CHECK_LAUNCH("k_aa_fwd<4>");
     return FMHR_OK;
 }
 
-int aa_bwd_dual(const float* mask_col, const float* img_col, const float* rast, const float* pos, const int32_t* tri,
-                const float* dy_mask, const float* dy_img, const int32_t* items, const float* alphas, const int32_t* counter,
-                int cap, int n, int V, int H, int W, float* gimg, float* gpos, hipStream_t st)
+int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
+                const int32_t* items, const float* alphas, const int32_t* counter, int cap, int n, int V, int H, int W,
+                float* gcolor, float* gpos, hipStream_t st)
 {
-    int grid = min(max(cdiv(cap, kBlock), 1), 2048);
-    k_aa_bwd<1, 3><<<grid, kBlock, 0, st>>>(mask_col, img_col, (const float4*)rast, pos, tri, dy_mask, dy_img,
-                                            (const int4*)items, alphas, counter, cap, n, V, H, W, 1, nullptr, gimg, gpos);
-    FMHR_CHECK_LAUNCH("k_aa_bwd<1,3>");
+    int grid = min(max(cdiv(cap, kBlock), 1), 1024);
+    k_aa_bwd<4, 0><<<grid, kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, dy, nullptr, (const int4*)items, alphas,
+                                            counter, cap, n, V, H, W, 4, gcolor, nullptr, gpos);
+    FMHR_CHECK_LAUNCH("k_aa_bwd<4>");
     return FMHR_OK;
 }
 
@@ -464,6 +480,36 @@ extern "C" int fmhr_adjacency_build(const int32_t* tri, int F, int V, int32_t* r
     FMHR_CHECK_LAUNCH("k_adj_fill");
     if (V > 0) {
         k_adj_sort_rows<<<cdiv(V, kBlock), kBlock, 0, st>>>(V, row_ptr, col_idx);
+        FMHR_CHECK_LAUNCH("k_adj_sort_rows");
+    }
+    return FMHR_OK;
+}
+
+extern "C" size_t fmhr_vertex_faces_workspace_bytes(int V) { return (size_t)(V + 1) * 4 * 2; }
+
+extern "C" int fmhr_vertex_faces_build(const int32_t* tri, int F, int V, int32_t* vf_ptr, int32_t* vf_idx, void* ws,
+                                       size_t ws_bytes, void* stream)
+{
+    FMHR_CHECK_ARG(F >= 0 && V >= 0, "vertex_faces_build: bad dims");
+    FMHR_CHECK_ARG(vf_ptr && ws && (tri || F == 0) && (vf_idx || F == 0), "vertex_faces_build: null pointer");
+    FMHR_CHECK_ARG(ws_bytes >= fmhr_vertex_faces_workspace_bytes(V), "vertex_faces_build: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int* deg = (int*)ws;
+    int* cursor = deg + (V + 1);
+    hipError_t e = hipMemsetAsync(deg, 0, (size_t)(V + 1) * 8, st);
+    if (e != hipSuccess) return hip_fail(e, "memset deg");
+    if (F > 0) {
+        k_vf_count<<<cdiv(3ll * F, kBlock), kBlock, 0, st>>>(tri, F, V, deg);
+        FMHR_CHECK_LAUNCH("k_vf_count");
+    }
+    k_scan_exclusive<<<1, 1024, 0, st>>>(deg, V, vf_ptr);
+    FMHR_CHECK_LAUNCH("k_scan_exclusive");
+    if (F > 0) {
+        k_vf_fill<<<cdiv(3ll * F, kBlock), kBlock, 0, st>>>(tri, F, V, vf_ptr, cursor, vf_idx);
+        FMHR_CHECK_LAUNCH("k_vf_fill");
+    }
+    if (V > 0) {
+        k_adj_sort_rows<<<cdiv(V, kBlock), kBlock, 0, st>>>(V, vf_ptr, vf_idx);
         FMHR_CHECK_LAUNCH("k_adj_sort_rows");
     }
     return FMHR_OK;

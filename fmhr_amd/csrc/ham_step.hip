@@ -5,33 +5,35 @@
 
 namespace fmhr {
 // raster.hip / antialias.hip / mesh.hip / shade.hip
-int rasterize_fwd_impl(const float*, const int32_t*, int, int, int, int, int, float*, void*, hipStream_t);
-int aa_fwd_dual(const float*, const float*, const float*, const float*, const int32_t*, const int32_t*, int, int, int, int, int,
-                float*, float*, int32_t*, float*, int32_t*, int, hipStream_t);
-int aa_bwd_dual(const float*, const float*, const float*, const float*, const int32_t*, const float*, const float*,
-                const int32_t*, const float*, const int32_t*, int, int, int, int, int, float*, float*, hipStream_t);
+size_t raster_core_ws_bytes(int n, int F, int H, int W);
+int rasterize_fwd_impl(const float*, const int2*, const int32_t*, int, int, int, int, int, float*, void*, int*, int*, hipStream_t);
+int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, int, int, int, int, int, float*,
+                int32_t*, float*, int32_t*, int, hipStream_t);
+int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const int32_t*, const float*,
+                const int32_t*, int, int, int, int, int, float*, float*, hipStream_t);
 int normals_fwd_impl(const float*, const int32_t*, int, int, int, float*, float*, hipStream_t);
 int normals_bwd_impl(const float*, const int32_t*, const float*, const float*, int, int, int, int, float*, float*, hipStream_t);
 int lap_fwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, float*, float*, hipStream_t);
 int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, float*, float*, hipStream_t);
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
-int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, hipStream_t);
-int transform_bwd_impl(const float*, const float*, const float*, int, int, float*, hipStream_t);
+int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, hipStream_t);
 int edge_hinge_impl(const float*, const int32_t*, int, int, float, float, float, float*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
 int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, int, int, int, int,
                    float*, float*, int*, hipStream_t);
-int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, const float*, long long, const float*,
-                  float, float, float, float*, float*, float*, hipStream_t);
-int shade_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*,
-                   const float*, int, int, int, int, int, float*, float*, hipStream_t);
-int unpack_albedo_grad_impl(const float*, int, float*, hipStream_t);
+int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const float*, float, float,
+                  float, float*, float*, float*, hipStream_t);
+int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*, int, int,
+                 int, int, float*, hipStream_t);
+int vertex_gather_impl(const float*, const float*, const int*, const int*, const int32_t*, const int32_t*, const int32_t*,
+                       const float*, int, int, int, int, int, float*, float*, hipStream_t);
+int reduce_views_impl(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
 int finish_losses_impl(float*, const float*, hipStream_t);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, pos, raster_ws, rast, tmp_img, mask_col, aa_img, aa_mask, aa_items, aa_alphas, aa_counter,
-        g_aa_img, g_aa_mask, g_tmp_img, gpos, gattr, gvert, gtmp, lx_v, lx_a, rowg, total;
+    size_t vertices, nsum, normals, pos, snap, raster_ws, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+        g_shaded, rec, gpos, part, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -50,20 +52,22 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.nsum = take(off, V * 12);
     L.normals = take(off, V * 12);
     L.pos = take(off, nV * 16);
-    L.raster_ws = take(off, fmhr_rasterize_workspace_bytes(d->n, d->F, d->H, d->W));
+    L.snap = take(off, nV * 8);
+    L.raster_ws = take(off, raster_core_ws_bytes(d->n, d->F, d->H, d->W));
+    L.head = take(off, (size_t)d->n * d->F * 4);
+    L.next = take(off, nP * 4);
     L.rast = take(off, nP * 16);
-    L.tmp_img = take(off, nP * 12);
-    L.mask_col = take(off, nP * 4);
-    L.aa_img = take(off, nP * 12);
-    L.aa_mask = take(off, nP * 4);
+    L.shaded = take(off, nP * 16);
+    L.aa = take(off, nP * 16);
     L.aa_items = take(off, (size_t)d->aa_cap * 16);
     L.aa_alphas = take(off, (size_t)d->aa_cap * 4);
     L.aa_counter = take(off, 16);
-    L.g_aa_img = take(off, nP * 12);
-    L.g_aa_mask = take(off, nP * 4);
-    L.g_tmp_img = take(off, nP * 12);
+    L.g_aa = take(off, nP * 16);
+    L.g_shaded = take(off, nP * 16);
+    L.rec = take(off, nP * 32);
     L.gpos = take(off, nV * 16);
-    L.gattr = take(off, V * 32);
+    L.part = take(off, nV * 32);
+    L.gnormal = take(off, V * 12);
     L.gvert = take(off, V * 12);
     L.gtmp = take(off, V * 12);
     L.lx_v = take(off, V * 12);
@@ -79,6 +83,7 @@ static int check_dims(const fmhr_ham_dims* d)
     FMHR_CHECK_ARG(d->n >= 1 && d->V >= 1 && d->F >= 1 && d->H >= 1 && d->W >= 1 && d->aa_cap >= 1,
                    "ham: bad dims n=%d V=%d F=%d H=%d W=%d aa_cap=%d", d->n, d->V, d->F, d->H, d->W, d->aa_cap);
     FMHR_CHECK_ARG(d->H <= 8192 && d->W <= 8192 && d->F < (1 << 24), "ham: H,W <= 8192 and F < 2^24 required");
+    FMHR_CHECK_ARG(((long long)d->n * d->H * d->W) % 4 == 0, "ham: n*H*W must be a multiple of 4");
     return FMHR_OK;
 }
 
@@ -112,9 +117,8 @@ extern "C" int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t
     out->pos = (float*)(w + L.pos);
     out->normals = (float*)(w + L.normals);
     out->rast = (float*)(w + L.rast);
-    out->tmp_img = (float*)(w + L.tmp_img);
-    out->aa_img = (float*)(w + L.aa_img);
-    out->aa_mask = (float*)(w + L.aa_mask);
+    out->shaded = (float*)(w + L.shaded);
+    out->aa = (float*)(w + L.aa);
     out->aa_counter = (int32_t*)(w + L.aa_counter);
     return FMHR_OK;
 }
@@ -135,43 +139,40 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     float* vertices = (float*)(w + L.vertices);
     float* pos = (float*)(w + L.pos);
     float* rast = (float*)(w + L.rast);
-    size_t nP = (size_t)d->n * d->H * d->W;
     {
         ProfScope ps(FMHR_SLOT_GEOMETRY, st);
         TRY(add_delta_impl(vertices_tmp, delta, d->V * 3, vertices, st));
         TRY(normals_fwd_impl(vertices, tri, 1, d->V, d->F, (float*)(w + L.nsum), (float*)(w + L.normals), st));
-        TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, st));
+        TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), st));
     }
-    TRY(rasterize_fwd_impl(pos, tri, d->n, d->V, d->F, d->H, d->W, rast, w + L.raster_ws, st));
+    TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, d->n, d->V, d->F, d->H, d->W, rast, w + L.raster_ws,
+                           (int*)(w + L.head), (int*)(w + L.next), st));
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         HIPTRY(hipMemsetAsync(n_valid_local, 0, 4, st), "memset n_valid");
-        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, d->n, d->F, d->H, d->W, (float*)(w + L.tmp_img),
-                           (float*)(w + L.mask_col), n_valid_local, st));
+        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, d->n, d->F, d->H, d->W, (float*)(w + L.shaded),
+                           (float*)(w + L.aa), n_valid_local, st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
-    HIPTRY(hipMemcpyAsync(w + L.aa_img, w + L.tmp_img, nP * 12, hipMemcpyDeviceToDevice, st), "copy tmp_img");
-    HIPTRY(hipMemcpyAsync(w + L.aa_mask, w + L.mask_col, nP * 4, hipMemcpyDeviceToDevice, st), "copy mask_col");
     HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, st), "memset aa_counter");
-    TRY(aa_fwd_dual((float*)(w + L.mask_col), (float*)(w + L.tmp_img), rast, pos, tri, opp, d->n, d->V, d->F, d->H, d->W,
-                    (float*)(w + L.aa_mask), (float*)(w + L.aa_img), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
-                    (int32_t*)(w + L.aa_counter), d->aa_cap, st));
+    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.aa),
+                    (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas), (int32_t*)(w + L.aa_counter), d->aa_cap, st));
     return FMHR_OK;
 }
 
 extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* wt, const float* vertices_tmp,
                                  const float* delta, const float* albedo, const float* sh, const float* w2c, const float* proj,
                                  const float* img, const float* mask, const float* valid_mask, const int32_t* tri,
-                                 const int32_t* opp, const int32_t* row_ptr, const int32_t* col_idx,
-                                 const float* n_valid_global, float* losses, float* gdelta, float* galbedo, void* ws,
-                                 size_t ws_bytes, void* stream)
+                                 const int32_t* opp, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* vf_ptr,
+                                 const int32_t* vf_idx, const float* n_valid_global, float* losses, float* gdelta,
+                                 float* galbedo, void* ws, size_t ws_bytes, void* stream)
 {
     (void)vertices_tmp; (void)opp;
     TRY(check_dims(d));
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_backward: workspace too small (%zu < %zu)", ws_bytes, L.total);
     FMHR_CHECK_ARG(wt && delta && albedo && sh && w2c && proj && img && mask && valid_mask && tri && row_ptr && col_idx &&
-                       n_valid_global && losses && gdelta && galbedo, "ham_backward: null pointer");
+                       vf_ptr && vf_idx && n_valid_global && losses && gdelta && galbedo, "ham_backward: null pointer");
     FMHR_CHECK_ARG(wt->mse_denominator > 0.f, "ham_backward: mse_denominator must be > 0");
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
@@ -179,7 +180,6 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     float* pos = (float*)(w + L.pos);
     float* rast = (float*)(w + L.rast);
     float* gpos = (float*)(w + L.gpos);
-    float* gattr = (float*)(w + L.gattr);
     float* gvert = (float*)(w + L.gvert);
     size_t nP = (size_t)d->n * d->H * d->W, V = d->V;
     const float rg = wt->reg_grad_scale;
@@ -188,37 +188,36 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
         HIPTRY(hipMemsetAsync(losses, 0, 32, st), "memset losses");
         HIPTRY(hipMemsetAsync(gpos, 0, (size_t)d->n * V * 16, st), "memset gpos");
-        HIPTRY(hipMemsetAsync(gattr, 0, V * 32, st), "memset gattr");
         HIPTRY(hipMemsetAsync(gvert, 0, V * 12, st), "memset gvert");
         HIPTRY(hipMemsetAsync(galbedo, 0, V * 12, st), "memset galbedo");
-        // losses on the antialiased images + their per-pixel gradients
-        TRY(loss_pix_impl(rast, (float*)(w + L.aa_img), img, mask, (float*)(w + L.aa_mask), valid_mask, (long long)nP,
-                          n_valid_global, wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa_img),
-                          (float*)(w + L.g_aa_mask), losses, st));
+        // losses on the antialiased rgba + their per-pixel gradients (written twice: g_aa and the AA-backward target)
+        TRY(loss_pix_impl((float*)(w + L.shaded), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP, n_valid_global,
+                          wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa), (float*)(w + L.g_shaded), losses, st));
     }
     {
-        // antialias backward (both images share one queue): colour grads of the shaded image, position grads of both
+        // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads into gpos
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
-        HIPTRY(hipMemcpyAsync(w + L.g_tmp_img, w + L.g_aa_img, nP * 12, hipMemcpyDeviceToDevice, st), "copy g_aa_img");
-        TRY(aa_bwd_dual((float*)(w + L.mask_col), (float*)(w + L.tmp_img), rast, pos, tri, (float*)(w + L.g_aa_mask),
-                        (float*)(w + L.g_aa_img), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
-                        (int32_t*)(w + L.aa_counter), d->aa_cap, d->n, d->V, d->H, d->W, (float*)(w + L.g_tmp_img), gpos, st));
+        TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (float*)(w + L.g_aa), (int32_t*)(w + L.aa_items),
+                        (float*)(w + L.aa_alphas), (int32_t*)(w + L.aa_counter), d->aa_cap, d->n, d->V, d->H, d->W,
+                        (float*)(w + L.g_shaded), gpos, st));
     }
     {
-        // shade + interpolate + rasterize backward
+        // shade + interpolate + rasterize backward, gather style: per-pixel records, then one lane per (view, vertex)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
-        TRY(shade_bwd_impl(rast, tri, pos, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_tmp_img), d->n, d->V,
-                           d->F, d->H, d->W, gattr, gpos, st));
+        TRY(pix_bwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_shaded), d->n, d->F, d->H, d->W,
+                         (float*)(w + L.rec), st));
+        TRY(vertex_gather_impl(rast, (float*)(w + L.rec), (int*)(w + L.head), (int*)(w + L.next), tri, vf_ptr, vf_idx, pos, d->n,
+                               d->V, d->F, d->H, d->W, (float*)(w + L.part), gpos, st));
     }
     {
-        // clip transform backward (sum over views)
+        // sum over views: attribute grads and the clip-transform backward
         ProfScope ps(FMHR_SLOT_TRANSFORM_BWD, st);
-        TRY(transform_bwd_impl(gpos, w2c, proj, d->n, d->V, gvert, st));
+        TRY(reduce_views_impl((float*)(w + L.part), gpos, w2c, proj, d->n, d->V, gvert, (float*)(w + L.gnormal), galbedo, st));
     }
     {
         ProfScope ps(FMHR_SLOT_NORMALS_BWD, st);
-        TRY(normals_bwd_impl(vertices, tri, (float*)(w + L.nsum), gattr, 8, 1, d->V, d->F, (float*)(w + L.gtmp), gvert, st));
-        TRY(unpack_albedo_grad_impl(gattr, d->V, galbedo, st));
+        TRY(normals_bwd_impl(vertices, tri, (float*)(w + L.nsum), (float*)(w + L.gnormal), 3, 1, d->V, d->F, (float*)(w + L.gtmp),
+                             gvert, st));
     }
     ProfScope ps(FMHR_SLOT_REGULARISERS, st);
     // view-independent regularisers (mesh_sfs_optim.py:292-293, 296-304)

@@ -242,7 +242,7 @@ k_add_delta(const float* __restrict__ a, const float* __restrict__ b, int N, flo
 // pos[b,v,:] = ([v,1] @ w2c[b]) @ proj[b]  — row-vector convention, two steps like the reference's two einsums
 __global__ void __launch_bounds__(kBlock)
 k_transform_fwd(const float* __restrict__ verts, const float* __restrict__ w2c, const float* __restrict__ proj, int V,
-                float4* __restrict__ pos)
+                float4* __restrict__ pos, int H, int W, int2* __restrict__ snap)
 {
     int v = blockIdx.x * kBlock + threadIdx.x;
     int b = blockIdx.y;
@@ -255,7 +255,13 @@ k_transform_fwd(const float* __restrict__ verts, const float* __restrict__ w2c, 
     for (int l = 0; l < 4; l++) r[l] = x * A[l] + y * A[4 + l] + z * A[8 + l] + A[12 + l];
 #pragma unroll
     for (int l = 0; l < 4; l++) o[l] = r[0] * B[l] + r[1] * B[4 + l] + r[2] * B[8 + l] + r[3] * B[12 + l];
-    pos[(size_t)b * V + v] = make_float4(o[0], o[1], o[2], o[3]);
+    float4 p = make_float4(o[0], o[1], o[2], o[3]);
+    pos[(size_t)b * V + v] = p;
+    if (snap != nullptr) {          // R1 + R2 of the rasterizer, once per (view, vertex)
+        int x, y;
+        bool ok = snap_vertex(p, (float)W * 128.0f, (float)H * 128.0f, x, y);
+        snap[(size_t)b * V + v] = ok ? make_int2(x, y) : make_int2((int)0x80000000, 0);
+    }
 }
 
 // gverts[v] += sum_b ((gpos[b,v] @ proj[b]^T) @ w2c[b]^T)[:3]   (one lane per vertex, no atomics)
@@ -401,10 +407,11 @@ int add_delta_impl(const float* a, const float* b, int N, float* o, hipStream_t 
     return FMHR_OK;
 }
 
-int transform_fwd_impl(const float* verts, const float* w2c, const float* proj, int n, int V, float* pos, hipStream_t st)
+int transform_fwd_impl(const float* verts, const float* w2c, const float* proj, int n, int V, float* pos, int H, int W,
+                       int2* snap, hipStream_t st)
 {
     if (n == 0 || V == 0) return FMHR_OK;
-    k_transform_fwd<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>(verts, w2c, proj, V, (float4*)pos);
+    k_transform_fwd<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>(verts, w2c, proj, V, (float4*)pos, H, W, snap);
     FMHR_CHECK_LAUNCH("k_transform_fwd");
     return FMHR_OK;
 }

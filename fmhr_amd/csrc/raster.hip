@@ -16,52 +16,67 @@ struct TriSetup {
     int pxa, pxb, pya, pyb;         // inclusive pixel range
 };
 
-__device__ __forceinline__ bool setup_triangle(const float4 p0, const float4 p1, const float4 p2, int H, int W, TriSetup& s)
+constexpr int kRejected = (int)0x80000000;   // snap.x of a vertex that fails R1 (or is NaN)
+
+// one lane per (view, vertex): R1 + R2 once per vertex instead of once per incident triangle corner
+__global__ void __launch_bounds__(kBlock)
+k_snap_vertices(const float4* __restrict__ pos, long long N, int H, int W, int2* __restrict__ snap)
 {
-    const float kx = (float)W * 128.0f, ky = (float)H * 128.0f;
-    if (!snap_vertex(p0, kx, ky, s.x0, s.y0)) return false;
-    if (!snap_vertex(p1, kx, ky, s.x1, s.y1)) return false;
-    if (!snap_vertex(p2, kx, ky, s.x2, s.y2)) return false;
-    long long area2 = (long long)(s.x1 - s.x0) * (s.y2 - s.y0) - (long long)(s.y1 - s.y0) * (s.x2 - s.x0);
-    if (area2 == 0) return false;
-    if (area2 < 0) { int t; t = s.x1; s.x1 = s.x2; s.x2 = t; t = s.y1; s.y1 = s.y2; s.y2 = t; }
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= N) return;
+    int x, y;
+    bool ok = snap_vertex(pos[gid], (float)W * 128.0f, (float)H * 128.0f, x, y);
+    snap[gid] = ok ? make_int2(x, y) : make_int2(kRejected, 0);
+}
+
+__device__ __forceinline__ bool setup_triangle(const int2 s0, const int2 s1, const int2 s2, int H, int W, TriSetup& s)
+{
+    if (s0.x == kRejected || s1.x == kRejected || s2.x == kRejected) return false;
+    s.x0 = s0.x; s.y0 = s0.y; s.x1 = s1.x; s.y1 = s1.y; s.x2 = s2.x; s.y2 = s2.y;
     int mnx = min(s.x0, min(s.x1, s.x2)), mxx = max(s.x0, max(s.x1, s.x2));
     int mny = min(s.y0, min(s.y1, s.y2)), mxy = max(s.y0, max(s.y1, s.y2));
     s.pxa = max((mnx - kHalf + kSub - 1) >> 8, 0);       // ceil((mn-128)/256), arithmetic shift floors
     s.pxb = min((mxx - kHalf) >> 8, W - 1);
     s.pya = max((mny - kHalf + kSub - 1) >> 8, 0);
     s.pyb = min((mxy - kHalf) >> 8, H - 1);
-    return s.pxa <= s.pxb && s.pya <= s.pyb;
+    if (s.pxa > s.pxb || s.pya > s.pyb) return false;    // the box holds no pixel centre (most micro-triangles end here)
+    long long area2 = (long long)(s.x1 - s.x0) * (s.y2 - s.y0) - (long long)(s.y1 - s.y0) * (s.x2 - s.x0);
+    if (area2 == 0) return false;
+    if (area2 < 0) { int t; t = s.x1; s.x1 = s.x2; s.x2 = t; t = s.y1; s.y1 = s.y2; s.y2 = t; }
+    return true;
 }
 
-__device__ __forceinline__ void shade_pixel(const TriSetup& s, const float4 p0, const float4 p1, const float4 p2,
-                                            int px, int py, int f, float xs, float xo, float ys, float yo,
-                                            unsigned long long* keys_view, int W)
+__device__ __forceinline__ bool covers(const TriSetup& s, int px, int py)
 {
     int cx = px * kSub + kHalf, cy = py * kSub + kHalf;
-    if (!edge_in(s.x0, s.y0, s.x1, s.y1, cx, cy)) return;
-    if (!edge_in(s.x1, s.y1, s.x2, s.y2, cx, cy)) return;
-    if (!edge_in(s.x2, s.y2, s.x0, s.y0, cx, cy)) return;
+    return edge_in(s.x0, s.y0, s.x1, s.y1, cx, cy) && edge_in(s.x1, s.y1, s.x2, s.y2, cx, cy) &&
+           edge_in(s.x2, s.y2, s.x0, s.y0, cx, cy);
+}
+
+__device__ __forceinline__ void emit_fragment(const float4 p0, const float4 p1, const float4 p2, int px, int py, int f,
+                                              float xs, float xo, float ys, float yo, unsigned long long* keys_view, int W)
+{
     Frag fr;
     if (!fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) return;
     unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | (unsigned)f;
     atomicMin(&keys_view[(size_t)py * W + px], key);
 }
 
-// one lane per (view, triangle)
+// one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup; clip positions are only fetched by the
+// lanes whose triangle actually covers a pixel centre
 __global__ void __launch_bounds__(kBlock)
-k_raster_tris(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
-              unsigned long long* __restrict__ keys, int* __restrict__ large_cnt, int2* __restrict__ large_q)
+k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
+              int F, int H, int W, unsigned long long* __restrict__ keys, int* __restrict__ large_cnt,
+              int2* __restrict__ large_q)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)n * F) return;
     int b = (int)(gid / F), f = (int)(gid - (long long)b * F);
     int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
     if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return;
-    const float* vp = pos + (size_t)b * V * 4;
-    const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+    const int2* sv = snap + (size_t)b * V;
     TriSetup s;
-    if (!setup_triangle(p0, p1, p2, H, W, s)) return;
+    if (!setup_triangle(sv[i0], sv[i1], sv[i2], H, W, s)) return;
     int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
     if (bw * (long long)bh > kSmallBox) {
         int slot = atomicAdd(large_cnt, 1);
@@ -72,15 +87,22 @@ k_raster_tris(const float* __restrict__ pos, const int32_t* __restrict__ tri, in
     float xo = 1.0f / (float)W; xo = xo - 1.0f;
     float yo = 1.0f / (float)H; yo = yo - 1.0f;
     unsigned long long* kv = keys + (size_t)b * H * W;
+    const float* vp = pos + (size_t)b * V * 4;
+    float4 p0, p1, p2;
+    bool loaded = false;
     for (int py = s.pya; py <= s.pyb; py++)
-        for (int px = s.pxa; px <= s.pxb; px++)
-            shade_pixel(s, p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W);
+        for (int px = s.pxa; px <= s.pxb; px++) {
+            if (!covers(s, px, py)) continue;
+            if (!loaded) { p0 = ldg4(vp + (size_t)i0 * 4); p1 = ldg4(vp + (size_t)i1 * 4); p2 = ldg4(vp + (size_t)i2 * 4); loaded = true; }
+            emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W);
+        }
 }
 
 // one workgroup per queued large triangle (grid-stride over the queue; the count lives on the device)
 __global__ void __launch_bounds__(kBlock)
-k_raster_large(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
-               unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt, const int2* __restrict__ large_q)
+k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
+               int F, int H, int W, unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt,
+               const int2* __restrict__ large_q)
 {
     const int cnt = *large_cnt;
     const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
@@ -90,23 +112,26 @@ k_raster_large(const float* __restrict__ pos, const int32_t* __restrict__ tri, i
         int2 bf = large_q[it];
         int b = bf.x, f = bf.y;
         int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+        const int2* sv = snap + (size_t)b * V;
+        TriSetup s;
+        if (!setup_triangle(sv[i0], sv[i1], sv[i2], H, W, s)) continue;
         const float* vp = pos + (size_t)b * V * 4;
         const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
-        TriSetup s;
-        if (!setup_triangle(p0, p1, p2, H, W, s)) continue;
         int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
         unsigned long long* kv = keys + (size_t)b * H * W;
         for (int i = threadIdx.x; i < bw * bh; i += kBlock) {
             int py = s.pya + i / bw, px = s.pxa + i % bw;
-            shade_pixel(s, p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W);
+            if (covers(s, px, py)) emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W);
         }
     }
 }
 
-// per pixel: decode the winning key, recompute its fragment, write (u, v, z/w, id+1) as one 16-B store
+// per pixel: decode the winning key, recompute its fragment, write (u, v, z/w, id+1) as one 16-B store; optionally thread
+// the pixel onto its triangle's list (head [n,F] / next [n,H,W]) for the gather-style backward
 __global__ void __launch_bounds__(kBlock)
-k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int H, int W,
-                 const unsigned long long* __restrict__ keys, float4* __restrict__ rast)
+k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
+                 const unsigned long long* __restrict__ keys, float4* __restrict__ rast, int* __restrict__ head,
+                 int* __restrict__ next)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     long long P = (long long)H * W;
@@ -125,7 +150,10 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         float xo = 1.0f / (float)W; xo = xo - 1.0f;
         float yo = 1.0f / (float)H; yo = yo - 1.0f;
         Frag fr;
-        if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
+        if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
+            o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
+            if (head != nullptr) next[gid] = atomicExch(&head[(size_t)b * F + f], rem);
+        }
     }
     rast[gid] = o;
 }
@@ -230,15 +258,29 @@ k_interp_bwd(const float* __restrict__ attr, const float4* __restrict__ rast, co
 
 using namespace fmhr;
 
-extern "C" size_t fmhr_rasterize_workspace_bytes(int n, int F, int H, int W)
+namespace fmhr {
+// [keys: n*H*W u64][large counter: 16 B][large queue: n*F int2]
+size_t raster_core_ws_bytes(int n, int F, int H, int W) { return (size_t)n * H * W * 8 + 16 + (size_t)n * F * 8; }
+}  // namespace fmhr
+
+extern "C" size_t fmhr_rasterize_workspace_bytes(int n, int V, int F, int H, int W)
 {
-    // [keys: n*H*W u64][large counter: 16 B][large queue: n*F int2]
-    return (size_t)n * H * W * 8 + 16 + (size_t)n * F * 8;
+    return fmhr::raster_core_ws_bytes(n, F, H, W) + (size_t)n * V * 8;      // + snapped vertices [n,V] int2
 }
 
 namespace fmhr {
-int rasterize_fwd_impl(const float* pos, const int32_t* tri, int n, int V, int F, int H, int W, float* rast, void* ws,
-                       hipStream_t st)
+int snap_vertices_impl(const float* pos, int n, int V, int H, int W, int2* snap, hipStream_t st)
+{
+    long long N = (long long)n * V;
+    if (N == 0) return FMHR_OK;
+    k_snap_vertices<<<cdiv(N, kBlock), kBlock, 0, st>>>((const float4*)pos, N, H, W, snap);
+    FMHR_CHECK_LAUNCH("k_snap_vertices");
+    return FMHR_OK;
+}
+
+// snap [n,V] int2 must already hold the snapped vertices; head/next may be null
+int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, int n, int V, int F, int H, int W, float* rast,
+                       void* ws, int* head, int* next, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
     unsigned long long* keys = (unsigned long long*)ws;
@@ -251,19 +293,23 @@ int rasterize_fwd_impl(const float* pos, const int32_t* tri, int n, int V, int F
         if (e != hipSuccess) return hip_fail(e, "memset keys");
         e = hipMemsetAsync(large_cnt, 0, 16, st);
         if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
+        if (head != nullptr && (size_t)n * F > 0) {
+            e = hipMemsetAsync(head, 0xFF, (size_t)n * F * 4, st);
+            if (e != hipSuccess) return hip_fail(e, "memset head");
+        }
     }
     if ((long long)n * F > 0) {
         {
             ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
-            k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, large_cnt, large_q);
+            k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q);
             FMHR_CHECK_LAUNCH("k_raster_tris");
         }
         ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);
-        k_raster_large<<<1024, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, large_cnt, large_q);
+        k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q);
         FMHR_CHECK_LAUNCH("k_raster_large");
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, H, W, keys, (float4*)rast);
+    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, next);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }
@@ -276,8 +322,11 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     FMHR_CHECK_ARG(H <= 8192 && W <= 8192, "rasterize_fwd: resolution above 8192 not supported");
     FMHR_CHECK_ARG(F < (1 << 24), "rasterize_fwd: F must be < 2^24 (triangle id is stored as fp32)");
     FMHR_CHECK_ARG(n == 0 || (rast && ws && (pos || V == 0) && (tri || F == 0)), "rasterize_fwd: null pointer");
-    FMHR_CHECK_ARG(ws_bytes >= fmhr_rasterize_workspace_bytes(n, F, H, W), "rasterize_fwd: workspace too small");
-    return rasterize_fwd_impl(pos, tri, n, V, F, H, W, rast, ws, (hipStream_t)stream);
+    FMHR_CHECK_ARG(ws_bytes >= fmhr_rasterize_workspace_bytes(n, V, F, H, W), "rasterize_fwd: workspace too small");
+    int2* snap = (int2*)((char*)ws + raster_core_ws_bytes(n, F, H, W));
+    int rc = snap_vertices_impl(pos, n, V, H, W, snap, (hipStream_t)stream);
+    if (rc) return rc;
+    return rasterize_fwd_impl(pos, snap, tri, n, V, F, H, W, rast, ws, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int fmhr_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int n, int V,

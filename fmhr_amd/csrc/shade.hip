@@ -1,7 +1,9 @@
-// fmhr_amd/csrc/shade.hip — fused per-pixel kernels of the stage-2 HAM step for gfx950.
+// fmhr_amd/csrc/shade.hip — fused per-pixel / per-vertex kernels of the stage-2 HAM step for gfx950.
 // One pass replaces the reference's interpolate(C=7) -> slices -> F.normalize -> boolean gather -> get_radiance ->
-// multiply -> scatter chain (/root/reference/mesh_sfs_optim.py:268-286), one pass the two loss reductions (:289,:295),
-// and one pass the backward of all of it down to per-vertex attribute gradients and clip-space position gradients.
+// multiply -> scatter chain (/root/reference/mesh_sfs_optim.py:268-286), one pass the two loss reductions (:289,:295).
+// The backward is GATHER-style: a per-pixel pass writes one 32-B gradient record per covered pixel, then one lane per
+// (view, vertex) walks the pixel lists of its incident faces (threaded by the rasterizer) and sums its own gradient — no
+// float atomics (the scatter form ran at the 0.08 TB/s "64 lanes -> 64 rows" atomic shape: 3.6 ms per step).
 #include "common.h"
 
 namespace fmhr {
@@ -27,7 +29,10 @@ struct PixShade {
     float hx, hy, hz;        // normalised
     float ar, ag, ab;        // interpolated albedo
     float rad;
+    float3 n0, n1, n2, a0, a1, a2;
 };
+
+__device__ __forceinline__ float3 ld3f(const float* p) { return make_float3(p[0], p[1], p[2]); }
 
 __device__ __forceinline__ void shade_eval(const float4 r, const int32_t* __restrict__ tri, const float* __restrict__ normals,
                                            const float* __restrict__ albedo, const float* __restrict__ shc, PixShade& s)
@@ -35,25 +40,26 @@ __device__ __forceinline__ void shade_eval(const float4 r, const int32_t* __rest
     int t = (int)r.w - 1;
     s.i0 = tri[t * 3]; s.i1 = tri[t * 3 + 1]; s.i2 = tri[t * 3 + 2];
     s.b0 = r.x; s.b1 = r.y; s.b2 = 1.0f - r.x - r.y;
-    const float* n0 = normals + (size_t)s.i0 * 3; const float* n1 = normals + (size_t)s.i1 * 3; const float* n2 = normals + (size_t)s.i2 * 3;
-    const float* a0 = albedo + (size_t)s.i0 * 3; const float* a1 = albedo + (size_t)s.i1 * 3; const float* a2 = albedo + (size_t)s.i2 * 3;
-    s.nx = s.b0 * n0[0] + s.b1 * n1[0] + s.b2 * n2[0];
-    s.ny = s.b0 * n0[1] + s.b1 * n1[1] + s.b2 * n2[1];
-    s.nz = s.b0 * n0[2] + s.b1 * n1[2] + s.b2 * n2[2];
-    s.ar = s.b0 * a0[0] + s.b1 * a1[0] + s.b2 * a2[0];
-    s.ag = s.b0 * a0[1] + s.b1 * a1[1] + s.b2 * a2[1];
-    s.ab = s.b0 * a0[2] + s.b1 * a1[2] + s.b2 * a2[2];
+    s.n0 = ld3f(normals + (size_t)s.i0 * 3); s.n1 = ld3f(normals + (size_t)s.i1 * 3); s.n2 = ld3f(normals + (size_t)s.i2 * 3);
+    s.a0 = ld3f(albedo + (size_t)s.i0 * 3); s.a1 = ld3f(albedo + (size_t)s.i1 * 3); s.a2 = ld3f(albedo + (size_t)s.i2 * 3);
+    s.nx = s.b0 * s.n0.x + s.b1 * s.n1.x + s.b2 * s.n2.x;
+    s.ny = s.b0 * s.n0.y + s.b1 * s.n1.y + s.b2 * s.n2.y;
+    s.nz = s.b0 * s.n0.z + s.b1 * s.n1.z + s.b2 * s.n2.z;
+    s.ar = s.b0 * s.a0.x + s.b1 * s.a1.x + s.b2 * s.a2.x;
+    s.ag = s.b0 * s.a0.y + s.b1 * s.a1.y + s.b2 * s.a2.y;
+    s.ab = s.b0 * s.a0.z + s.b1 * s.a1.z + s.b2 * s.a2.z;
     s.len = sqrtf(s.nx * s.nx + s.ny * s.ny + s.nz * s.nz);
     float inv = 1.0f / fmaxf(s.len, 1e-12f);                 // F.normalize(p=2, dim=3), default eps (:273)
     s.hx = s.nx * inv; s.hy = s.ny * inv; s.hz = s.nz * inv;
     s.rad = sh9c(shc, s.hx, s.hy, s.hz);
 }
 
-// forward: rast -> shaded image (zero outside valid = mask>0 & covered), coverage colour, local valid count
+// forward: rast -> rgba (rgb = shaded image, zero outside valid = mask>0 & covered; a = the interpolated ones attribute),
+// written twice (the second copy is the antialias accumulation target); local valid count
 __global__ void __launch_bounds__(kBlock)
 k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ normals,
             const float* __restrict__ albedo, const float* __restrict__ sh, const float* __restrict__ mask,
-            int n, int F, long long P, float* __restrict__ tmp_img, float* __restrict__ mask_col, int* __restrict__ n_valid)
+            int n, int F, long long P, float4* __restrict__ shaded, float4* __restrict__ aa_init, int* __restrict__ n_valid)
 {
     __shared__ float sm[4];
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -61,10 +67,10 @@ k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, co
     if (gid < (long long)n * P) {
         float4 r = rast[gid];
         int t = (int)r.w - 1;
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f, mc = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t >= 0 && t < F) {
             float w2 = 1.0f - r.x - r.y;
-            mc = r.x + r.y + w2;                                 // interpolate of the ones attribute (:268-269)
+            o.w = r.x + r.y + w2;                                // interpolate of the ones attribute (:268-269)
             if (mask[gid] > 0.f) {
                 int b = (int)(gid / P);
                 float shc[9];
@@ -72,44 +78,55 @@ k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, co
                 for (int k = 0; k < 9; k++) shc[k] = sh[(size_t)b * 9 + k];
                 PixShade s;
                 shade_eval(r, tri, normals, albedo, shc, s);
-                o0 = s.rad * s.ar; o1 = s.rad * s.ag; o2 = s.rad * s.ab;
+                o.x = s.rad * s.ar; o.y = s.rad * s.ag; o.z = s.rad * s.ab;
                 cnt = 1.f;
             }
         }
-        tmp_img[gid * 3] = o0; tmp_img[gid * 3 + 1] = o1; tmp_img[gid * 3 + 2] = o2;
-        mask_col[gid] = mc;
+        shaded[gid] = o;
+        aa_init[gid] = o;
     }
     float s = block_sum(cnt, sm);
     if (threadIdx.x == 0 && s != 0.f) atomicAdd(n_valid, (int)s);
 }
 
-// losses + their per-pixel gradients: sfs = w * mean_valid |aa_img - img| (:289), mask = w * mean (aa_mask - valid_mask)^2 (:295)
+// losses + their per-pixel gradients, 4 pixels per lane so every access is a 16-B vector:
+// sfs = w * mean_valid |aa.rgb - img| (:289), mask = w * mean (aa.a - valid_mask)^2 (:295).
+// g_aa [.,4] = d loss / d antialiased rgba, written twice (second copy = antialias-backward accumulation target).
 __global__ void __launch_bounds__(kBlock)
-k_loss_pix(const float4* __restrict__ rast, const float* __restrict__ aa_img, const float* __restrict__ img,
-           const float* __restrict__ mask, const float* __restrict__ aa_mask, const float* __restrict__ valid_mask,
-           long long N, const float* __restrict__ n_valid_global, float w_sfs, float w_mask, float mse_den,
-           float* __restrict__ g_aa_img, float* __restrict__ g_aa_mask, float* __restrict__ losses)
+k_loss_pix4(const float4* __restrict__ shaded, const float4* __restrict__ aa, const float4* __restrict__ img3,
+            const float4* __restrict__ mask, const float4* __restrict__ valid_mask, long long N4,
+            const float* __restrict__ n_valid_global, float w_sfs, float w_mask, float mse_den,
+            float4* __restrict__ g_aa, float4* __restrict__ g_shaded, float* __restrict__ losses)
 {
     __shared__ float sm[4];
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
     float l1 = 0.f, l2 = 0.f;
     float den = 3.0f * n_valid_global[0];
     float k1 = (den > 0.f) ? w_sfs / den : 0.f;
     float k2 = w_mask / mse_den;
-    if (gid < N) {
-        bool valid = (mask[gid] > 0.f) && (rast[gid].w > 0.f);
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        if (valid) {
-            float d0 = aa_img[gid * 3] - img[gid * 3], d1 = aa_img[gid * 3 + 1] - img[gid * 3 + 1], d2 = aa_img[gid * 3 + 2] - img[gid * 3 + 2];
-            l1 = fabsf(d0) + fabsf(d1) + fabsf(d2);
-            g0 = (d0 > 0.f) ? k1 : ((d0 < 0.f) ? -k1 : 0.f);
-            g1 = (d1 > 0.f) ? k1 : ((d1 < 0.f) ? -k1 : 0.f);
-            g2 = (d2 > 0.f) ? k1 : ((d2 < 0.f) ? -k1 : 0.f);
+    if (q < N4) {
+        float4 i0 = img3[q * 3], i1 = img3[q * 3 + 1], i2 = img3[q * 3 + 2];    // 4 pixels x rgb = 12 floats
+        const float im[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
+        float4 mk = mask[q], vm = valid_mask[q];
+        const float mka[4] = {mk.x, mk.y, mk.z, mk.w}, vma[4] = {vm.x, vm.y, vm.z, vm.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float4 a = aa[q * 4 + j];
+            float cov = shaded[q * 4 + j].w;                    // != 0 exactly where the pixel is covered
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mka[j] > 0.f && cov != 0.f) {
+                float d0 = a.x - im[j * 3], d1 = a.y - im[j * 3 + 1], d2 = a.z - im[j * 3 + 2];
+                l1 += fabsf(d0) + fabsf(d1) + fabsf(d2);
+                g.x = (d0 > 0.f) ? k1 : ((d0 < 0.f) ? -k1 : 0.f);
+                g.y = (d1 > 0.f) ? k1 : ((d1 < 0.f) ? -k1 : 0.f);
+                g.z = (d2 > 0.f) ? k1 : ((d2 < 0.f) ? -k1 : 0.f);
+            }
+            float dm = a.w - vma[j];
+            l2 += dm * dm;
+            g.w = 2.0f * dm * k2;
+            g_aa[q * 4 + j] = g;
+            g_shaded[q * 4 + j] = g;
         }
-        g_aa_img[gid * 3] = g0; g_aa_img[gid * 3 + 1] = g1; g_aa_img[gid * 3 + 2] = g2;
-        float dm = aa_mask[gid] - valid_mask[gid];
-        l2 = dm * dm;
-        g_aa_mask[gid] = 2.0f * dm * k2;
     }
     float s1 = block_sum(l1, sm);
     float s2 = block_sum(l2, sm);
@@ -119,99 +136,144 @@ k_loss_pix(const float4* __restrict__ rast, const float* __restrict__ aa_img, co
     }
 }
 
-// backward of shade + interpolate + rasterize for one pixel: attribute grads into gattr[V,8] (0..2 normal, 3..5 albedo),
-// clip-space position grads into gpos[n,V,4]
+// per covered pixel: backward of shade + normalise down to the interpolated attributes, and the barycentric gradients.
+// record = (g_normal_raw.xyz, g_albedo.x | g_albedo.yz, g_u, g_v), zeros for covered pixels outside the photometric mask.
 __global__ void __launch_bounds__(kBlock)
-k_shade_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ pos,
-            const float* __restrict__ normals, const float* __restrict__ albedo, const float* __restrict__ sh,
-            const float* __restrict__ mask, const float* __restrict__ g_img, int n, int V, int F, int H, int W,
-            float* __restrict__ gattr, float* __restrict__ gpos)
+k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ normals,
+          const float* __restrict__ albedo, const float* __restrict__ sh, const float* __restrict__ mask,
+          const float4* __restrict__ g_shaded, int n, int F, long long P, float4* __restrict__ rec)
 {
-    long long P = (long long)H * W;
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)n * P) return;
     float4 r = rast[gid];
     int t = (int)r.w - 1;
-    if (t < 0 || t >= F || !(mask[gid] > 0.f)) return;
-    float g0 = g_img[gid * 3], g1 = g_img[gid * 3 + 1], g2 = g_img[gid * 3 + 2];
-    if (g0 == 0.f && g1 == 0.f && g2 == 0.f) return;
-    int b = (int)(gid / P);
-    int rem = (int)(gid - (long long)b * P);
-    int py = rem / W, px = rem - py * W;
-    float c[9];
+    if (t < 0 || t >= F) return;
+    float4 g = g_shaded[gid];
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    if (mask[gid] > 0.f && (g.x != 0.f || g.y != 0.f || g.z != 0.f)) {
+        int b = (int)(gid / P);
+        float c[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) c[k] = sh[(size_t)b * 9 + k];
-    PixShade s;
-    shade_eval(r, tri, normals, albedo, c, s);
-    // pred = rad * albedo
-    float g_rad = g0 * s.ar + g1 * s.ag + g2 * s.ab;
-    float ga0 = g0 * s.rad, ga1 = g1 * s.rad, ga2 = g2 * s.rad;
-    float x = s.hx, y = s.hy, z = s.hz;
-    float dx = c[3] + c[4] * y - 2.0f * c[6] * x + c[7] * z + 2.0f * c[8] * x;
-    float dy = c[1] + c[4] * x + c[5] * z - 2.0f * c[6] * y - 2.0f * c[8] * y;
-    float dz = c[2] + c[5] * y + 4.0f * c[6] * z + c[7] * x;
-    float ghx = g_rad * dx, ghy = g_rad * dy, ghz = g_rad * dz;
-    float gnx, gny, gnz;
-    if (s.len > 1e-12f) {
-        float inv = 1.0f / s.len;
-        float dt = x * ghx + y * ghy + z * ghz;
-        gnx = (ghx - x * dt) * inv; gny = (ghy - y * dt) * inv; gnz = (ghz - z * dt) * inv;
-    } else {
-        gnx = ghx * 1e12f; gny = ghy * 1e12f; gnz = ghz * 1e12f;
+        for (int k = 0; k < 9; k++) c[k] = sh[(size_t)b * 9 + k];
+        PixShade s;
+        shade_eval(r, tri, normals, albedo, c, s);
+        float g_rad = g.x * s.ar + g.y * s.ag + g.z * s.ab;
+        float ga0 = g.x * s.rad, ga1 = g.y * s.rad, ga2 = g.z * s.rad;
+        float x = s.hx, y = s.hy, z = s.hz;
+        float dx = c[3] + c[4] * y - 2.0f * c[6] * x + c[7] * z + 2.0f * c[8] * x;
+        float dy = c[1] + c[4] * x + c[5] * z - 2.0f * c[6] * y - 2.0f * c[8] * y;
+        float dz = c[2] + c[5] * y + 4.0f * c[6] * z + c[7] * x;
+        float ghx = g_rad * dx, ghy = g_rad * dy, ghz = g_rad * dz;
+        float gnx, gny, gnz;
+        if (s.len > 1e-12f) {
+            float inv = 1.0f / s.len;
+            float dt = x * ghx + y * ghy + z * ghz;
+            gnx = (ghx - x * dt) * inv; gny = (ghy - y * dt) * inv; gnz = (ghz - z * dt) * inv;
+        } else {
+            gnx = ghx * 1e12f; gny = ghy * 1e12f; gnz = ghz * 1e12f;
+        }
+        // interpolate backward w.r.t. the barycentrics; the ones channel contributes exactly 0
+        float gu = gnx * (s.n0.x - s.n2.x) + gny * (s.n0.y - s.n2.y) + gnz * (s.n0.z - s.n2.z) +
+                   ga0 * (s.a0.x - s.a2.x) + ga1 * (s.a0.y - s.a2.y) + ga2 * (s.a0.z - s.a2.z);
+        float gv = gnx * (s.n1.x - s.n2.x) + gny * (s.n1.y - s.n2.y) + gnz * (s.n1.z - s.n2.z) +
+                   ga0 * (s.a1.x - s.a2.x) + ga1 * (s.a1.y - s.a2.y) + ga2 * (s.a1.z - s.a2.z);
+        r0 = make_float4(gnx, gny, gnz, ga0);
+        r1 = make_float4(ga1, ga2, gu, gv);
     }
-    const float gch[6] = {gnx, gny, gnz, ga0, ga1, ga2};
-    const int idx[3] = {s.i0, s.i1, s.i2};
-    const float bw[3] = {s.b0, s.b1, s.b2};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float* q = gattr + (size_t)idx[k] * 8;
-#pragma unroll
-        for (int ch = 0; ch < 6; ch++) atomicAdd(q + ch, bw[k] * gch[ch]);
-    }
-    // barycentric gradients (interpolate backward), then rasterize backward
-    const float* n0 = normals + (size_t)s.i0 * 3; const float* n1 = normals + (size_t)s.i1 * 3; const float* n2 = normals + (size_t)s.i2 * 3;
-    const float* a0 = albedo + (size_t)s.i0 * 3; const float* a1 = albedo + (size_t)s.i1 * 3; const float* a2 = albedo + (size_t)s.i2 * 3;
-    float gu = 0.f, gv = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-        gu += gch[ch] * (n0[ch] - n2[ch]) + gch[3 + ch] * (a0[ch] - a2[ch]);
-        gv += gch[ch] * (n1[ch] - n2[ch]) + gch[3 + ch] * (a1[ch] - a2[ch]);
-    }
-    if (gu == 0.f && gv == 0.f) return;
-    const float* vp = pos + (size_t)b * V * 4;
-    const float4 p0 = ldg4(vp + (size_t)s.i0 * 4), p1 = ldg4(vp + (size_t)s.i1 * 4), p2 = ldg4(vp + (size_t)s.i2 * 4);
-    float fx = (2.0f / (float)W) * (float)px + (1.0f / (float)W - 1.0f);
-    float fy = (2.0f / (float)H) * (float)py + (1.0f / (float)H - 1.0f);
-    float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-    float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-    float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-    float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
-    float iw = 1.0f / (e0 + e1 + e2);
-    float bb0 = e0 * iw, bb1 = e1 * iw;
-    float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * bb0 + gb1 * bb1;
-    float q0x = gbb * (p2y - p1y) - gb1 * p2y;
-    float q1x = gbb * (p0y - p2y) + gb0 * p2y;
-    float q2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
-    float q0y = gbb * (p1x - p2x) + gb1 * p2x;
-    float q1y = gbb * (p2x - p0x) - gb0 * p2x;
-    float q2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
-    float* o0 = gpos + ((size_t)b * V + s.i0) * 4;
-    float* o1 = gpos + ((size_t)b * V + s.i1) * 4;
-    float* o2 = gpos + ((size_t)b * V + s.i2) * 4;
-    atomicAdd(o0 + 0, q0x); atomicAdd(o0 + 1, q0y); atomicAdd(o0 + 3, -fx * q0x - fy * q0y);
-    atomicAdd(o1 + 0, q1x); atomicAdd(o1 + 1, q1y); atomicAdd(o1 + 3, -fx * q1x - fy * q1y);
-    atomicAdd(o2 + 0, q2x); atomicAdd(o2 + 1, q2y); atomicAdd(o2 + 3, -fx * q2x - fy * q2y);
+    rec[gid * 2] = r0;
+    rec[gid * 2 + 1] = r1;
 }
 
-// galbedo[v,:] = gattr[v,3:6] (+ existing), used after the pixel pass
+// one lane per (view, vertex): walk the incident face corners (CSR), each face's pixel list (head/next from the rasterizer),
+// and sum this vertex's share: attribute gradients b_k * record (-> part[b,v,0:6]) and the rasterize-backward position
+// gradient of corner k (-> gpos[b,v] +=, which already holds the antialias-backward atomics).
 __global__ void __launch_bounds__(kBlock)
-k_unpack_albedo_grad(const float* __restrict__ gattr, int V, float* __restrict__ galbedo)
+k_vertex_gather(const float4* __restrict__ rast, const float4* __restrict__ rec, const int* __restrict__ head,
+                const int* __restrict__ next, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
+                const int32_t* __restrict__ vf_idx, const float* __restrict__ pos, int n, int V, int F, int H, int W,
+                float4* __restrict__ part, float4* __restrict__ gpos)
+{
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    int b = blockIdx.y;
+    if (v >= V) return;
+    const long long P = (long long)H * W;
+    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
+    float an0 = 0.f, an1 = 0.f, an2 = 0.f, aa0 = 0.f, aa1 = 0.f, aa2 = 0.f, gx = 0.f, gy = 0.f, gw = 0.f;
+    const int* hb = head + (size_t)b * F;
+    const float* vp = pos + (size_t)b * V * 4;
+    for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
+        int code = vf_idx[e];
+        int f = code / 3, k = code - f * 3;
+        int pix = hb[f];
+        if (pix < 0) continue;
+        int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+        const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+        while (pix >= 0) {
+            long long gid = (long long)b * P + pix;
+            float4 r = rast[gid];
+            float4 r0 = rec[gid * 2], r1 = rec[gid * 2 + 1];
+            float bk = (k == 0) ? r.x : ((k == 1) ? r.y : 1.0f - r.x - r.y);
+            an0 += bk * r0.x; an1 += bk * r0.y; an2 += bk * r0.z;
+            aa0 += bk * r0.w; aa1 += bk * r1.x; aa2 += bk * r1.y;
+            float gu = r1.z, gv = r1.w;
+            if (gu != 0.f || gv != 0.f) {
+                int py = pix / W, px = pix - py * W;
+                float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
+                float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+                float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+                float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+                float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
+                float iw = 1.0f / (e0 + e1 + e2);
+                float bb0 = e0 * iw, bb1 = e1 * iw;
+                float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * bb0 + gb1 * bb1;
+                float qx, qy;
+                if (k == 0) { qx = gbb * (p2y - p1y) - gb1 * p2y; qy = gbb * (p1x - p2x) + gb1 * p2x; }
+                else if (k == 1) { qx = gbb * (p0y - p2y) + gb0 * p2y; qy = gbb * (p2x - p0x) - gb0 * p2x; }
+                else { qx = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y; qy = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x; }
+                gx += qx; gy += qy; gw += -fx * qx - fy * qy;
+            }
+            pix = next[gid];
+        }
+    }
+    size_t o = (size_t)b * V + v;
+    part[o * 2] = make_float4(an0, an1, an2, aa0);
+    part[o * 2 + 1] = make_float4(aa1, aa2, 0.f, 0.f);
+    if (gx != 0.f || gy != 0.f || gw != 0.f) {
+        float4 g = gpos[o];
+        g.x += gx; g.y += gy; g.w += gw;
+        gpos[o] = g;
+    }
+}
+
+// per vertex: sum the per-view partials (attribute grads) and apply the clip-transform backward to gpos (sum over views):
+// gverts[v] += sum_b ((gpos[b,v] @ proj[b]^T) @ w2c[b]^T)[:3];  gnormal[v] = sum_b part.n;  galbedo[v] += sum_b part.a
+__global__ void __launch_bounds__(kBlock)
+k_reduce_views(const float4* __restrict__ part, const float4* __restrict__ gpos, const float* __restrict__ w2c,
+               const float* __restrict__ proj, int n, int V, float* __restrict__ gverts, float* __restrict__ gnormal,
+               float* __restrict__ galbedo)
 {
     int v = blockIdx.x * kBlock + threadIdx.x;
     if (v >= V) return;
-    galbedo[(size_t)v * 3] += gattr[(size_t)v * 8 + 3];
-    galbedo[(size_t)v * 3 + 1] += gattr[(size_t)v * 8 + 4];
-    galbedo[(size_t)v * 3 + 2] += gattr[(size_t)v * 8 + 5];
+    float ax = 0.f, ay = 0.f, az = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int b = 0; b < n; b++) {
+        size_t o = (size_t)b * V + v;
+        float4 q0 = part[o * 2], q1 = part[o * 2 + 1];
+        n0 += q0.x; n1 += q0.y; n2 += q0.z; a0 += q0.w; a1 += q1.x; a2 += q1.y;
+        float4 g = gpos[o];
+        if (g.x != 0.f || g.y != 0.f || g.w != 0.f || g.z != 0.f) {
+            const float* A = w2c + (size_t)b * 16;
+            const float* B = proj + (size_t)b * 16;
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = g.x * B[k * 4] + g.y * B[k * 4 + 1] + g.z * B[k * 4 + 2] + g.w * B[k * 4 + 3];
+            ax += r[0] * A[0] + r[1] * A[1] + r[2] * A[2] + r[3] * A[3];
+            ay += r[0] * A[4] + r[1] * A[5] + r[2] * A[6] + r[3] * A[7];
+            az += r[0] * A[8] + r[1] * A[9] + r[2] * A[10] + r[3] * A[11];
+        }
+    }
+    gverts[(size_t)v * 3] += ax; gverts[(size_t)v * 3 + 1] += ay; gverts[(size_t)v * 3 + 2] += az;
+    gnormal[(size_t)v * 3] = n0; gnormal[(size_t)v * 3 + 1] = n1; gnormal[(size_t)v * 3 + 2] = n2;
+    galbedo[(size_t)v * 3] += a0; galbedo[(size_t)v * 3 + 1] += a1; galbedo[(size_t)v * 3 + 2] += a2;
 }
 
 __global__ void k_finish_losses(float* losses, const float* n_valid)
@@ -224,44 +286,58 @@ __global__ void k_finish_losses(float* losses, const float* n_valid)
 }
 
 int shade_fwd_impl(const float* rast, const int32_t* tri, const float* normals, const float* albedo, const float* sh,
-                   const float* mask, int n, int F, int H, int W, float* tmp_img, float* mask_col, int* n_valid, hipStream_t st)
+                   const float* mask, int n, int F, int H, int W, float* shaded, float* aa_init, int* n_valid, hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0) return FMHR_OK;
-    k_shade_fwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, normals, albedo, sh, mask, n, F, P, tmp_img,
-                                                       mask_col, n_valid);
+    k_shade_fwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, normals, albedo, sh, mask, n, F, P,
+                                                       (float4*)shaded, (float4*)aa_init, n_valid);
     FMHR_CHECK_LAUNCH("k_shade_fwd");
     return FMHR_OK;
 }
 
-int loss_pix_impl(const float* rast, const float* aa_img, const float* img, const float* mask, const float* aa_mask,
-                  const float* valid_mask, long long N, const float* n_valid_global, float w_sfs, float w_mask, float mse_den,
-                  float* g_aa_img, float* g_aa_mask, float* losses, hipStream_t st)
+int loss_pix_impl(const float* shaded, const float* aa, const float* img, const float* mask, const float* valid_mask,
+                  long long N, const float* n_valid_global, float w_sfs, float w_mask, float mse_den, float* g_aa,
+                  float* g_shaded, float* losses, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_loss_pix<<<cdiv(N, kBlock), kBlock, 0, st>>>((const float4*)rast, aa_img, img, mask, aa_mask, valid_mask, N, n_valid_global,
-                                                  w_sfs, w_mask, mse_den, g_aa_img, g_aa_mask, losses);
-    FMHR_CHECK_LAUNCH("k_loss_pix");
+    if (N % 4 != 0) { set_error("ham: n*H*W must be a multiple of 4 (got %lld)", N); return FMHR_E_ARG; }
+    k_loss_pix4<<<cdiv(N / 4, kBlock), kBlock, 0, st>>>((const float4*)shaded, (const float4*)aa, (const float4*)img,
+                                                        (const float4*)mask, (const float4*)valid_mask, N / 4, n_valid_global,
+                                                        w_sfs, w_mask, mse_den, (float4*)g_aa, (float4*)g_shaded, losses);
+    FMHR_CHECK_LAUNCH("k_loss_pix4");
     return FMHR_OK;
 }
 
-int shade_bwd_impl(const float* rast, const int32_t* tri, const float* pos, const float* normals, const float* albedo,
-                   const float* sh, const float* mask, const float* g_img, int n, int V, int F, int H, int W, float* gattr,
-                   float* gpos, hipStream_t st)
+int pix_bwd_impl(const float* rast, const int32_t* tri, const float* normals, const float* albedo, const float* sh,
+                 const float* mask, const float* g_shaded, int n, int F, int H, int W, float* rec, hipStream_t st)
 {
-    long long nP = (long long)n * H * W;
-    if (nP == 0 || F == 0) return FMHR_OK;
-    k_shade_bwd<<<cdiv(nP, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, pos, normals, albedo, sh, mask, g_img, n, V, F, H, W,
-                                                    gattr, gpos);
-    FMHR_CHECK_LAUNCH("k_shade_bwd");
+    long long P = (long long)H * W;
+    if (n * P == 0 || F == 0) return FMHR_OK;
+    k_pix_bwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, normals, albedo, sh, mask, (const float4*)g_shaded,
+                                                     n, F, P, (float4*)rec);
+    FMHR_CHECK_LAUNCH("k_pix_bwd");
     return FMHR_OK;
 }
 
-int unpack_albedo_grad_impl(const float* gattr, int V, float* galbedo, hipStream_t st)
+int vertex_gather_impl(const float* rast, const float* rec, const int* head, const int* next, const int32_t* tri,
+                       const int32_t* vf_ptr, const int32_t* vf_idx, const float* pos, int n, int V, int F, int H, int W,
+                       float* part, float* gpos, hipStream_t st)
+{
+    if (n == 0 || V == 0) return FMHR_OK;
+    k_vertex_gather<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>((const float4*)rast, (const float4*)rec, head, next, tri, vf_ptr,
+                                                                vf_idx, pos, n, V, F, H, W, (float4*)part, (float4*)gpos);
+    FMHR_CHECK_LAUNCH("k_vertex_gather");
+    return FMHR_OK;
+}
+
+int reduce_views_impl(const float* part, const float* gpos, const float* w2c, const float* proj, int n, int V, float* gverts,
+                      float* gnormal, float* galbedo, hipStream_t st)
 {
     if (V == 0) return FMHR_OK;
-    k_unpack_albedo_grad<<<cdiv(V, kBlock), kBlock, 0, st>>>(gattr, V, galbedo);
-    FMHR_CHECK_LAUNCH("k_unpack_albedo_grad");
+    k_reduce_views<<<cdiv(V, kBlock), kBlock, 0, st>>>((const float4*)part, (const float4*)gpos, w2c, proj, n, V, gverts, gnormal,
+                                                      galbedo);
+    FMHR_CHECK_LAUNCH("k_reduce_views");
     return FMHR_OK;
 }
 

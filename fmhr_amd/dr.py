@@ -60,7 +60,7 @@ class _RasterizeFn(torch.autograd.Function):
         n, V, _ = pos.shape
         F = tri.shape[0]
         rast = torch.empty(n, H, W, 4, dtype=torch.float32, device=pos.device)
-        nb = _lib.load().fmhr_rasterize_workspace_bytes(n, F, H, W)
+        nb = _lib.load().fmhr_rasterize_workspace_bytes(n, V, F, H, W)
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=pos.device)
         call("fmhr_rasterize_fwd", ptr(pos), ptr(tri), n, V, F, H, W, ptr(rast), ptr(ws), nb, stream_ptr(pos.device))
         ctx.save_for_backward(pos, tri, rast)

@@ -48,6 +48,11 @@ class HamStage2:
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.dev)
         call("fmhr_adjacency_build", ptr(self.faces), self.F, self.V, ptr(self.row_ptr), ptr(self.col_idx), ptr(ws), nb, st)
         self.nnz = int(self.row_ptr[-1])
+        self.vf_ptr = torch.zeros(self.V + 1, dtype=torch.int32, device=self.dev)
+        self.vf_idx = torch.zeros(3 * self.F, dtype=torch.int32, device=self.dev)
+        nb = self.lib.fmhr_vertex_faces_workspace_bytes(self.V)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.dev)
+        call("fmhr_vertex_faces_build", ptr(self.faces), self.F, self.V, ptr(self.vf_ptr), ptr(self.vf_idx), ptr(ws), nb, st)
         # antialias queue: only pairs that blend are queued (∝ silhouette length); 1/4 of the pixels is a generous bound
         cap = int(aa_cap or max(65536, self.n * self.H * self.W // 4))
         self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap, 0)
@@ -74,7 +79,8 @@ class HamStage2:
                         float(self.n_global * self.H * self.W), 1.0 if reg_grads else 0.0)
         call("fmhr_ham_backward", ctypes.byref(self.dims), ctypes.byref(wt), ptr(vertices_tmp), ptr(delta), ptr(albedo),
              ptr(sh), ptr(w2c), ptr(proj), ptr(img), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp),
-             ptr(self.row_ptr), ptr(self.col_idx), ptr(self.n_valid_global), ptr(self.losses), ptr(self.gdelta),
+             ptr(self.row_ptr), ptr(self.col_idx), ptr(self.vf_ptr), ptr(self.vf_idx), ptr(self.n_valid_global),
+             ptr(self.losses), ptr(self.gdelta),
              ptr(self.galbedo), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
 
     def step(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group=None, reg_grads=True):
@@ -115,9 +121,10 @@ class HamStage2:
                 off = p - base
                 return self.ws[off: off + numel * 4].view(dtype).view(*shape)
 
+            shaded, aa = view(hv.shaded, (n, H, W, 4)), view(hv.aa, (n, H, W, 4))
             self._views = dict(pos=view(hv.pos, (n, V, 4)), normals=view(hv.normals, (V, 3)), rast=view(hv.rast, (n, H, W, 4)),
-                               tmp_img_pre_aa=view(hv.tmp_img, (n, H, W, 3)), tmp_img=view(hv.aa_img, (n, H, W, 3)),
-                               pred_mask=view(hv.aa_mask, (n, H, W)), aa_counter=view(hv.aa_counter, (2,), torch.int32))
+                               tmp_img_pre_aa=shaded[..., :3], tmp_img=aa[..., :3], pred_mask=aa[..., 3],
+                               aa_counter=view(hv.aa_counter, (2,), torch.int32))
         return self._views
 
     def loss_dict(self):

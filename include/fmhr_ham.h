@@ -47,10 +47,16 @@ size_t fmhr_adjacency_workspace_bytes(int V, int F);
 int fmhr_adjacency_build(const int32_t* tri, int F, int V, int32_t* row_ptr, int32_t* col_idx,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* vertex -> incident face corners (CSR, rows sorted; entry = 3*face + corner): the gather-style backward of the fused step walks
+ * it instead of scattering float atomics.  vf_ptr [V+1], vf_idx [3F]. */
+size_t fmhr_vertex_faces_workspace_bytes(int V);
+int fmhr_vertex_faces_build(const int32_t* tri, int F, int V, int32_t* vf_ptr, int32_t* vf_idx,
+                            void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ nvdiffrast-shaped primitives
  * dr.rasterize(glctx, pos, tri, resolution=(H,W))  — mesh_sfs_optim.py:142,212,267; get_data.py:251.
  * pos [n,V,4] clip space, tri [F,3]; rast [n,H,W,4] = (u, v, z/w, tri_id+1) or zeros.  Rules: DESIGN.md §3. */
-size_t fmhr_rasterize_workspace_bytes(int n, int F, int H, int W);
+size_t fmhr_rasterize_workspace_bytes(int n, int V, int F, int H, int W);
 int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, int V, int F, int H, int W,
                        float* rast, void* ws, size_t ws_bytes, void* stream);
 /* backward of rast[...,0:2] w.r.t. pos: dy [n,H,W,4] (only .x,.y read); gpos [n,V,4] += */
@@ -131,7 +137,8 @@ size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
  * Phase B: losses + the whole backward.  The split exists because F.l1_loss divides by the batch-GLOBAL 3*Pv
  * (mesh_sfs_optim.py:289): a view-sharded caller all-reduces n_valid between the two phases.
  *   vertices_tmp, delta, albedo [V,3]; sh [n,9]; w2c, proj [n,4,4] (row-vector convention, get_data.py:96-97);
- *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx [nnz].
+ *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx [nnz]; vf_ptr [V+1]; vf_idx [3F].
+ *   n*H*W must be a multiple of 4.
  *   n_valid_local: device int32[1] written by phase A.  n_valid_global: device float[1] read by phase B.
  *   losses: device float[8]; gdelta, galbedo [V,3] overwritten (view-dependent part only when reg_grads=0). */
 int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
@@ -141,16 +148,16 @@ int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const fl
 int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const float* vertices_tmp, const float* delta,
                       const float* albedo, const float* sh, const float* w2c, const float* proj, const float* img,
                       const float* mask, const float* valid_mask, const int32_t* tri, const int32_t* opp,
-                      const int32_t* row_ptr, const int32_t* col_idx, const float* n_valid_global,
+                      const int32_t* row_ptr, const int32_t* col_idx, const int32_t* vf_ptr, const int32_t* vf_idx,
+                      const float* n_valid_global,
                       float* losses, float* gdelta, float* galbedo, void* ws, size_t ws_bytes, void* stream);
 /* Views of the step's intermediates inside the workspace (for parity tests / rendering): returns device pointers. */
 typedef struct fmhr_ham_views {
     float* pos;        /* [n,V,4]   */
     float* normals;    /* [V,3]     */
     float* rast;       /* [n,H,W,4] */
-    float* tmp_img;    /* [n,H,W,3] shaded image before antialias */
-    float* aa_img;     /* [n,H,W,3] */
-    float* aa_mask;    /* [n,H,W]   */
+    float* shaded;     /* [n,H,W,4] rgb = shaded image before antialias (tmp_img, :285-286), a = coverage colour (:272) */
+    float* aa;         /* [n,H,W,4] the same after antialias: rgb = tmp_img (:287), a = pred_mask (:274) */
     int32_t* aa_counter; /* [2] */
 } fmhr_ham_views;
 int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, fmhr_ham_views* out);
