@@ -2,7 +2,7 @@
 """bench.py — HAM stage-2 iterations/sec on MI355X (BASELINE.json metric).
 
 One "step" = one full stage-2 iteration of /root/reference/mesh_sfs_optim.py:253-310 on the metric workload (48 views,
-512x512, sub3-class mesh V=49153/F=98048): render + six losses + backward + gradient exchange + Adam step.
+512x512, sub3-class mesh V=48693/F=97088): render + six losses + backward + gradient exchange + Adam step.
 `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under torch.distributed.run, one rank per GPU,
 views sharded contiguously over ranks (strong scaling: the 48-view batch is fixed), ONE packed all-reduce of the per-vertex
 gradients per step plus the valid-pixel count all-reduce.

@@ -183,10 +183,41 @@ __device__ __forceinline__ int max_idx3(float n0, float n1, float n2, float d0, 
     return 0;
 }
 
+// rule A3: silhouette edges of a triangle in a view, decided on the snapped integer coordinates.
+// bit k = edge k (opposite vertex k) is a silhouette edge; 0 when a vertex of the triangle itself is rejected.
+__device__ __forceinline__ int silhouette_bits_snapped(int2 s0, int2 s1, int2 s2, int2 o0, int2 o1, int2 o2)
+{
+    const int REJ = (int)0x80000000;
+    if (s0.x == REJ || s1.x == REJ || s2.x == REJ) return 0;
+    if (o0.x == REJ) o0 = s0;
+    if (o1.x == REJ) o1 = s1;
+    if (o2.x == REJ) o2 = s2;
+    long long bb = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s2.x - s0.x) * (s1.y - s0.y);
+    long long a0 = (long long)(s1.x - o0.x) * (s2.y - o0.y) - (long long)(s2.x - o0.x) * (s1.y - o0.y);
+    long long a1 = (long long)(s2.x - o1.x) * (s0.y - o1.y) - (long long)(s0.x - o1.x) * (s2.y - o1.y);
+    long long a2 = (long long)(s0.x - o2.x) * (s1.y - o2.y) - (long long)(s1.x - o2.x) * (s0.y - o2.y);
+    int bits = 0;
+    if ((a0 < 0) == (bb < 0)) bits |= 1;
+    if ((a1 < 0) == (bb < 0)) bits |= 2;
+    if ((a2 < 0) == (bb < 0)) bits |= 4;
+    return bits;
+}
+
+__device__ __forceinline__ int2 snap_or_reject(const float* posv, int v, float kx, float ky)
+{
+    if (v < 0) return make_int2((int)0x80000000, 0);
+    int x, y;
+    bool ok = snap_vertex(ldg4(posv + (size_t)v * 4), kx, ky, x, y);
+    return ok ? make_int2(x, y) : make_int2((int)0x80000000, 0);
+}
+
 // Analyse the pixel pair ((px,py), (px+1-d, py+d)) of view b.  z0/id0 and z1/id1 are rast.z / rast.w of the two pixels.
+// `silh` (nullable) = this view's per-triangle silhouette bits precomputed by the rasterizer: most seams between
+// micro-triangles are not silhouettes and leave here after one byte load.
 // Returns the work-item code (0 = no blend) and alpha.  Statement-for-statement fp32 (no contraction).
 __device__ __forceinline__ int aa_analyse(const float* __restrict__ posv, const int32_t* __restrict__ tri,
-                                          const int32_t* __restrict__ opp, int V, int F, int H, int W,
+                                          const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
+                                          int V, int F, int H, int W,
                                           int px, int py, int d, float z0, float id0, float z1, float id1, float& alpha_out)
 {
     int tri0 = (int)id0 - 1, tri1 = (int)id1 - 1;
@@ -195,32 +226,32 @@ __device__ __forceinline__ int aa_analyse(const float* __restrict__ posv, const 
     int qx = px, qy = py;
     if (t == tri1) { qx += 1 - d; qy += d; }
     if (t < 0 || t >= F) return 0;
+    int sb;
+    if (silh != nullptr) {
+        sb = silh[t];
+        if (!sb) return 0;
+    }
     int vi0 = tri[t * 3], vi1 = tri[t * 3 + 1], vi2 = tri[t * 3 + 2];
     if ((unsigned)vi0 >= (unsigned)V || (unsigned)vi1 >= (unsigned)V || (unsigned)vi2 >= (unsigned)V) return 0;
-    int op0 = opp[t * 3], op1 = opp[t * 3 + 1], op2 = opp[t * 3 + 2];
+    if (silh == nullptr) {
+        const float kx = (float)W * 128.0f, ky = (float)H * 128.0f;
+        int op0 = opp[t * 3], op1 = opp[t * 3 + 1], op2 = opp[t * 3 + 2];
+        sb = silhouette_bits_snapped(snap_or_reject(posv, vi0, kx, ky), snap_or_reject(posv, vi1, kx, ky),
+                                     snap_or_reject(posv, vi2, kx, ky), snap_or_reject(posv, op0, kx, ky),
+                                     snap_or_reject(posv, op1, kx, ky), snap_or_reject(posv, op2, kx, ky));
+        if (!sb) return 0;
+    }
+    bool s0 = sb & 1, s1 = sb & 2, s2 = sb & 4;
     const float4 p0 = ldg4(posv + (size_t)vi0 * 4), p1 = ldg4(posv + (size_t)vi1 * 4), p2 = ldg4(posv + (size_t)vi2 * 4);
-    const float4 o0 = (op0 < 0) ? p0 : ldg4(posv + (size_t)op0 * 4);
-    const float4 o1 = (op1 < 0) ? p1 : ldg4(posv + (size_t)op1 * 4);
-    const float4 o2 = (op2 < 0) ? p2 : ldg4(posv + (size_t)op2 * 4);
     float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     float w0 = 1.0f / p0.w, w1 = 1.0f / p1.w, w2 = 1.0f / p2.w;
-    float ow0 = 1.0f / o0.w, ow1 = 1.0f / o1.w, ow2 = 1.0f / o2.w;
     float fx = (float)qx + 0.5f; fx = fx - xh;
     float fy = (float)qy + 0.5f; fy = fy - yh;
     float m;
     m = p0.x * w0; m = m * xh; float x0 = m - fx;    m = p0.y * w0; m = m * yh; float y0 = m - fy;
     m = p1.x * w1; m = m * xh; float x1 = m - fx;    m = p1.y * w1; m = m * yh; float y1 = m - fy;
     m = p2.x * w2; m = m * xh; float x2 = m - fx;    m = p2.y * w2; m = m * yh; float y2 = m - fy;
-    m = o0.x * ow0; m = m * xh; float ox0 = m - fx;  m = o0.y * ow0; m = m * yh; float oy0 = m - fy;
-    m = o1.x * ow1; m = m * xh; float ox1 = m - fx;  m = o1.y * ow1; m = m * yh; float oy1 = m - fy;
-    m = o2.x * ow2; m = m * xh; float ox2 = m - fx;  m = o2.y * ow2; m = m * yh; float oy2 = m - fy;
-    float e0, e1, e2, e3, l, r;
-    e0 = x1 - x0;  e1 = y2 - y0;  e2 = x2 - x0;  e3 = y1 - y0;  l = e0 * e1; r = e2 * e3; float bb = l - r;
-    e0 = x1 - ox0; e1 = y2 - oy0; e2 = x2 - ox0; e3 = y1 - oy0; l = e0 * e1; r = e2 * e3; float a0 = l - r;
-    e0 = x2 - ox1; e1 = y0 - oy1; e2 = x0 - ox1; e3 = y2 - oy1; l = e0 * e1; r = e2 * e3; float a1 = l - r;
-    e0 = x0 - ox2; e1 = y1 - oy2; e2 = x1 - ox2; e3 = y0 - oy2; l = e0 * e1; r = e2 * e3; float a2 = l - r;
-    bool s0 = same_sign(a0, bb), s1 = same_sign(a1, bb), s2 = same_sign(a2, bb);
-    if (!(s0 || s1 || s2)) return 0;
+    float l, r;
     if (d) { float tt; tt = x0; x0 = y0; y0 = tt; tt = x1; x1 = y1; y1 = tt; tt = x2; x2 = y2; y2 = tt; }
     float dx0 = x2 - x1, dx1 = x0 - x2, dx2 = x1 - x0;
     float dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;
@@ -270,6 +301,7 @@ template <int CA, int CB>
 __global__ void __launch_bounds__(kBlock)
 k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, const float4* __restrict__ rast,
          const float* __restrict__ pos, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
+         const unsigned char* __restrict__ silh,
          int n, int V, int F, int H, int W, int Cdyn, float* __restrict__ outA, float* __restrict__ outB,
          int4* __restrict__ items, float* __restrict__ alphas, int32_t* counter, int cap)
 {
@@ -294,7 +326,7 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
         if (live && (d ? (py + 1 < H) : (px + 1 < W))) {
             float4 r1 = rast[gid1];
             if (r1.w != r0.w) {
-                code = aa_analyse(posv, tri, opp, V, F, H, W, px, py, d, r0.z, r0.w, r1.z, r1.w, alpha);
+                code = aa_analyse(posv, tri, opp, silh ? silh + (size_t)b * F : nullptr, V, F, H, W, px, py, d, r0.z, r0.w, r1.z, r1.w, alpha);
                 has = code != 0;
             }
         }
@@ -409,11 +441,12 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
 }
 
 // fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour)
-int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int n, int V,
-                int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int cap, hipStream_t st)
+int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
+                const unsigned char* silh, int n, int V, int F, int H, int W, float* out, int32_t* items, float* alphas,
+                int32_t* counter, int cap, hipStream_t st)
 {
     long long nP = (long long)n * H * W;
-    k_aa_fwd<4, 0><<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, opp, n, V, F, H, W, 4, out,
+    k_aa_fwd<4, 0><<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, opp, silh, n, V, F, H, W, 4, out,
                                                        nullptr, (int4*)items, alphas, counter, cap);
     FMHR_CHECK_LAUNCH("k_aa_fwd<4>");
     return FMHR_OK;
@@ -531,9 +564,9 @@ extern "C" int fmhr_antialias_fwd(const float* color, const float* rast, const f
     int grid = cdiv(nP, kBlock);
     int4* it = (int4*)items;
     const float4* r4 = (const float4*)rast;
-    if (C == 1) k_aa_fwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
-    else if (C == 3) k_aa_fwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
-    else k_aa_fwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    if (C == 1) k_aa_fwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    else if (C == 3) k_aa_fwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    else k_aa_fwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
     FMHR_CHECK_LAUNCH("k_aa_fwd");
     return FMHR_OK;
 }

@@ -6,9 +6,10 @@
 namespace fmhr {
 // raster.hip / antialias.hip / mesh.hip / shade.hip
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
-int rasterize_fwd_impl(const float*, const int2*, const int32_t*, int, int, int, int, int, float*, void*, int*, int*, hipStream_t);
-int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, int, int, int, int, int, float*,
-                int32_t*, float*, int32_t*, int, hipStream_t);
+int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
+                       void*, int*, int*, hipStream_t);
+int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, int, int, int,
+                int, int, float*, int32_t*, float*, int32_t*, int, hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const int32_t*, const float*,
                 const int32_t*, int, int, int, int, int, float*, float*, hipStream_t);
 int normals_fwd_impl(const float*, const int32_t*, int, int, int, float*, float*, hipStream_t);
@@ -32,7 +33,7 @@ int finish_losses_impl(float*, const float*, hipStream_t);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, pos, snap, raster_ws, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+    size_t vertices, nsum, normals, pos, snap, silh, raster_ws, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
         g_shaded, rec, gpos, part, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
 };
 
@@ -53,6 +54,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.normals = take(off, V * 12);
     L.pos = take(off, nV * 16);
     L.snap = take(off, nV * 8);
+    L.silh = take(off, (size_t)d->n * d->F);
     L.raster_ws = take(off, raster_core_ws_bytes(d->n, d->F, d->H, d->W));
     L.head = take(off, (size_t)d->n * d->F * 4);
     L.next = take(off, nP * 4);
@@ -145,8 +147,8 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         TRY(normals_fwd_impl(vertices, tri, 1, d->V, d->F, (float*)(w + L.nsum), (float*)(w + L.normals), st));
         TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), st));
     }
-    TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, d->n, d->V, d->F, d->H, d->W, rast, w + L.raster_ws,
-                           (int*)(w + L.head), (int*)(w + L.next), st));
+    TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
+                           rast, w + L.raster_ws, (int*)(w + L.head), (int*)(w + L.next), st));
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         HIPTRY(hipMemsetAsync(n_valid_local, 0, 4, st), "memset n_valid");
@@ -155,7 +157,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, st), "memset aa_counter");
-    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.aa),
+    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W, (float*)(w + L.aa),
                     (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas), (int32_t*)(w + L.aa_counter), d->aa_cap, st));
     return FMHR_OK;
 }

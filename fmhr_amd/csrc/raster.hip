@@ -65,7 +65,8 @@ __device__ __forceinline__ void emit_fragment(const float4 p0, const float4 p1, 
 // one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup; clip positions are only fetched by the
 // lanes whose triangle actually covers a pixel centre
 __global__ void __launch_bounds__(kBlock)
-k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
+k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
+              const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, int* __restrict__ large_cnt,
               int2* __restrict__ large_q)
 {
@@ -76,7 +77,24 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return;
     const int2* sv = snap + (size_t)b * V;
     TriSetup s;
-    if (!setup_triangle(sv[i0], sv[i1], sv[i2], H, W, s)) return;
+    const int2 s0 = sv[i0], s1 = sv[i1], s2 = sv[i2];
+    if (!setup_triangle(s0, s1, s2, H, W, s)) return;
+    if (silh != nullptr) {
+        // antialias rule A3 on the snapped coordinates, once per (view, triangle) that can own a pixel
+        const int REJ = (int)0x80000000;
+        int o0 = opp[f * 3], o1 = opp[f * 3 + 1], o2 = opp[f * 3 + 2];
+        int2 q0 = (o0 < 0) ? make_int2(REJ, 0) : sv[o0], q1 = (o1 < 0) ? make_int2(REJ, 0) : sv[o1],
+             q2 = (o2 < 0) ? make_int2(REJ, 0) : sv[o2];
+        if (q0.x == REJ) q0 = s0;
+        if (q1.x == REJ) q1 = s1;
+        if (q2.x == REJ) q2 = s2;
+        long long bb = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s2.x - s0.x) * (s1.y - s0.y);
+        long long a0 = (long long)(s1.x - q0.x) * (s2.y - q0.y) - (long long)(s2.x - q0.x) * (s1.y - q0.y);
+        long long a1 = (long long)(s2.x - q1.x) * (s0.y - q1.y) - (long long)(s0.x - q1.x) * (s2.y - q1.y);
+        long long a2 = (long long)(s0.x - q2.x) * (s1.y - q2.y) - (long long)(s1.x - q2.x) * (s0.y - q2.y);
+        silh[(size_t)b * F + f] = (unsigned char)((((a0 < 0) == (bb < 0)) ? 1 : 0) | (((a1 < 0) == (bb < 0)) ? 2 : 0) |
+                                                  (((a2 < 0) == (bb < 0)) ? 4 : 0));
+    }
     int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
     if (bw * (long long)bh > kSmallBox) {
         int slot = atomicAdd(large_cnt, 1);
@@ -279,8 +297,8 @@ int snap_vertices_impl(const float* pos, int n, int V, int H, int W, int2* snap,
 }
 
 // snap [n,V] int2 must already hold the snapped vertices; head/next may be null
-int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, int n, int V, int F, int H, int W, float* rast,
-                       void* ws, int* head, int* next, hipStream_t st)
+int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, const int32_t* opp, unsigned char* silh, int n, int V,
+                       int F, int H, int W, float* rast, void* ws, int* head, int* next, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
     unsigned long long* keys = (unsigned long long*)ws;
@@ -301,7 +319,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, i
     if ((long long)n * F > 0) {
         {
             ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
-            k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q);
+            k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, large_cnt, large_q);
             FMHR_CHECK_LAUNCH("k_raster_tris");
         }
         ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);
@@ -326,7 +344,7 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     int2* snap = (int2*)((char*)ws + raster_core_ws_bytes(n, F, H, W));
     int rc = snap_vertices_impl(pos, n, V, H, W, snap, (hipStream_t)stream);
     if (rc) return rc;
-    return rasterize_fwd_impl(pos, snap, tri, n, V, F, H, W, rast, ws, nullptr, nullptr, (hipStream_t)stream);
+    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int fmhr_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int n, int V,

@@ -16,34 +16,59 @@ DEMO_LR = dict(lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
 SEMI_AXES = (0.0965, 0.0306, 0.0838)
 
 CONFIGS = {
-    # name: (views, H, W, rings, segments)
-    "C1": (1, 256, 256, 24, 32),
-    "C2": (8, 512, 334, 24, 32),
-    "C3": (16, 512, 512, 192, 256),
-    "metric": (48, 512, 512, 192, 256),
-    "C4": (48, 1024, 1024, 192, 256),
+    # name: (views, H, W, rings, segments, subdivisions).  The base blob 21 x 37 has V=778 / F=1517 (MANO: 778 / 1538); three
+    # 1:4 subdivisions give V=48693 / F=97088 (MANO sub3: 49281 / 98432) with MANO-like bounded valence and the face/vertex
+    # order contract of SURVEY.md Appendix E.
+    "C1": (1, 256, 256, 21, 37, 0),
+    "C2": (8, 512, 334, 21, 37, 0),
+    "C3": (16, 512, 512, 21, 37, 3),
+    "metric": (48, 512, 512, 21, 37, 3),
+    "C4": (48, 1024, 1024, 21, 37, 3),
 }
 
 
-def blob_mesh(rings, segs, seed=0, bump=0.10):
-    """Open-wrist UV blob: closed top pole, open bottom => disc topology like MANO.  V = rings*segs+1,
-    F = segs + 2*segs*(rings-1).  rings=192, segs=256 -> V=49153, F=98048 (MANO sub3: 49281 / 98432)."""
+TH_MAX = 0.86 * math.pi
+
+
+def _blob_surface(th, ph, seed, bump):
+    """points of the bumpy ellipsoid at spherical parameters (th from the pole on the long axis, ph around it)."""
     rng = np.random.default_rng(seed)
-    th_max = 0.86 * math.pi
-    i = np.arange(1, rings + 1, dtype=np.float64)[:, None]
-    j = np.arange(segs, dtype=np.float64)[None, :]
-    th = th_max * i / rings
-    ph = 2 * math.pi * j / segs
-    # seeded low-frequency radial displacement (concavities / self-occlusion)
     disp = np.zeros_like(th * ph)
-    for _ in range(6):
+    for _ in range(6):                     # seeded low-frequency radial displacement (concavities / self-occlusion)
         kt, kp = rng.integers(1, 4), rng.integers(1, 5)
         a, p0, p1 = rng.uniform(0.3, 1.0), rng.uniform(0, 2 * math.pi), rng.uniform(0, 2 * math.pi)
         disp = disp + a * np.sin(kt * th + p0) * np.cos(kp * ph + p1) * np.sin(th)
-    disp = 1.0 + bump * disp / max(1e-9, np.abs(disp).max())
-    # pole on the long axis (finger tips), opening at the wrist end
+    disp = 1.0 + bump * disp / 3.0
     d = np.stack([np.cos(th) * np.ones_like(ph), np.sin(th) * np.sin(ph), np.sin(th) * np.cos(ph)], -1) * disp[..., None]
-    verts = np.concatenate([np.array([[1.0, 0.0, 0.0]]), d.reshape(-1, 3)], 0) * np.array(SEMI_AXES)
+    return d * np.array(SEMI_AXES)
+
+
+def subdivide(faces, V):
+    """1:4 midpoint subdivision with the order contract of SURVEY.md Appendix E (repose.py:14-24 relies on it): original
+    vertices keep their indices, edge midpoints are appended in unique-edge order, each parent [f0,f1,f2] becomes the four
+    consecutive children [f0,m01,m02], [m01,f1,m12], [m02,m12,f2], [m01,m12,m02].  Returns (faces', edges [E,2], V')."""
+    f = faces.astype(np.int64)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    e.sort(axis=1)
+    uniq, inv = np.unique(e[:, 0] * V + e[:, 1], return_inverse=True)
+    edges = np.stack([uniq // V, uniq % V], 1)
+    Fn = f.shape[0]
+    m01, m12, m20 = V + inv[:Fn], V + inv[Fn:2 * Fn], V + inv[2 * Fn:]
+    kids = np.stack([np.stack([f[:, 0], m01, m20], 1), np.stack([m01, f[:, 1], m12], 1),
+                     np.stack([m20, m12, f[:, 2]], 1), np.stack([m01, m12, m20], 1)], 1).reshape(-1, 3)
+    return kids.astype(np.int32), edges, V + edges.shape[0]
+
+
+def blob_mesh(rings, segs, seed=0, bump=0.10, subdiv=0):
+    """Open-wrist UV blob: closed top pole, open bottom => disc topology like MANO.  Base: V = rings*segs+1,
+    F = segs + 2*segs*(rings-1); then `subdiv` 1:4 subdivisions whose new vertices are put on the analytic surface (midpoints in
+    parameter space) — the counts and index layout of a Loop-subdivided MANO without needing trimesh."""
+    i = np.arange(1, rings + 1, dtype=np.float64)[:, None]
+    j = np.arange(segs, dtype=np.float64)[None, :]
+    th = (TH_MAX * i / rings) * np.ones((1, segs))
+    ph = (2 * math.pi * j / segs) * np.ones((rings, 1))
+    th = np.concatenate([[0.0], th.reshape(-1)])
+    ph = np.concatenate([[0.0], ph.reshape(-1)])
     faces = []
     ring0 = 1 + np.arange(segs)
     nxt = 1 + (np.arange(segs) + 1) % segs
@@ -52,7 +77,19 @@ def blob_mesh(rings, segs, seed=0, bump=0.10):
         a0, b0 = (r - 1) * segs, r * segs
         faces.append(np.stack([a0 + ring0, b0 + ring0, b0 + nxt], 1))
         faces.append(np.stack([a0 + ring0, b0 + nxt, a0 + nxt], 1))
-    faces = np.concatenate(faces, 0)
+    faces = np.concatenate(faces, 0).astype(np.int32)
+    for _ in range(subdiv):
+        V = th.shape[0]
+        faces, edges, _ = subdivide(faces, V)
+        a, b = edges[:, 0], edges[:, 1]
+        pa, pb = ph[a], ph[b]
+        # midpoint in parameter space; the pole (index 0, th = 0) has no meaningful ph: take the other end's
+        pa = np.where(th[a] == 0, pb, pa)
+        pb = np.where(th[b] == 0, pa, pb)
+        dphi = (pb - pa + math.pi) % (2 * math.pi) - math.pi
+        th = np.concatenate([th, 0.5 * (th[a] + th[b])])
+        ph = np.concatenate([ph, pa + 0.5 * dphi])
+    verts = _blob_surface(th[:, None], ph[:, None], seed, bump)[:, 0, :]
     return verts.astype(np.float32), faces.astype(np.int32)
 
 
@@ -98,10 +135,10 @@ def cameras(verts, n, H, W, coverage=0.25, dist=0.6):
     return np.stack(w2cs).astype(np.float32), np.stack(projs).astype(np.float32)
 
 
-def make_scene(views, H, W, rings, segs, seed=0, coverage=0.25):
+def make_scene(views, H, W, rings, segs, subdiv=0, seed=0, coverage=0.25):
     """Everything the stage-2 loop needs except the rendered targets (see make_targets)."""
     rng = np.random.default_rng(seed)
-    verts, faces = blob_mesh(rings, segs, seed)
+    verts, faces = blob_mesh(rings, segs, seed, subdiv=subdiv)
     w2c, proj = cameras(verts, views, H, W, coverage)
     V = verts.shape[0]
     sh_true = np.concatenate([np.full((views, 1), 0.8), 0.1 * rng.standard_normal((views, 8))], 1).astype(np.float32)
@@ -117,8 +154,8 @@ def make_scene(views, H, W, rings, segs, seed=0, coverage=0.25):
 
 
 def scene_from_config(name, seed=0, views=None):
-    v, H, W, r, c = CONFIGS[name]
-    return make_scene(views or v, H, W, r, c, seed)
+    v, H, W, r, c, sd = CONFIGS[name]
+    return make_scene(views or v, H, W, r, c, sd, seed)
 
 
 def make_targets(scene, forward_fn, device=None):

@@ -252,6 +252,31 @@ static inline int SFX(max_idx3)(REAL n0, REAL n1, REAL n2, REAL d0, REAL d1, REA
 #define AA_FOUND 16
 #define AA_CLAMPED 32
 
+/* rule A3: which edges of triangle (vi0,vi1,vi2) are silhouette edges in this view — decided on the SNAPPED integer
+ * coordinates (exact, translation invariant, consistent with coverage): edge k (opposite vertex k) is a silhouette edge iff the
+ * neighbouring triangle's opposite vertex lies on the same side of the edge as vertex k (fold) — or there is no neighbour.
+ * bit k set = edge k is silhouette; returns 0 if a vertex of the triangle itself is rejected. */
+static int SFX(silhouette_bits)(const REAL* P, int vi0, int vi1, int vi2, int op0, int op1, int op2, int H, int W)
+{
+    int64_t x0, y0, x1, y1, x2, y2, ox, oy;
+    if (!SFX(snap_vertex)(P + (size_t)vi0 * 4, H, W, &x0, &y0)) return 0;
+    if (!SFX(snap_vertex)(P + (size_t)vi1 * 4, H, W, &x1, &y1)) return 0;
+    if (!SFX(snap_vertex)(P + (size_t)vi2 * 4, H, W, &x2, &y2)) return 0;
+    int64_t bb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    int bits = 0;
+    int64_t a;
+    if (op0 < 0 || !SFX(snap_vertex)(P + (size_t)op0 * 4, H, W, &ox, &oy)) { ox = x0; oy = y0; }
+    a = (x1 - ox) * (y2 - oy) - (x2 - ox) * (y1 - oy);
+    if ((a < 0) == (bb < 0)) bits |= 1;
+    if (op1 < 0 || !SFX(snap_vertex)(P + (size_t)op1 * 4, H, W, &ox, &oy)) { ox = x1; oy = y1; }
+    a = (x2 - ox) * (y0 - oy) - (x0 - ox) * (y2 - oy);
+    if ((a < 0) == (bb < 0)) bits |= 2;
+    if (op2 < 0 || !SFX(snap_vertex)(P + (size_t)op2 * 4, H, W, &ox, &oy)) { ox = x2; oy = y2; }
+    a = (x0 - ox) * (y1 - oy) - (x1 - ox) * (y0 - oy);
+    if ((a < 0) == (bb < 0)) bits |= 4;
+    return bits;
+}
+
 /* Analyse one pixel pair.  Returns code (0 if the pair produces no blend) and alpha. */
 static int SFX(aa_analyse)(const REAL* rast, const REAL* pos, const int32_t* tri, const int32_t* opp,
                            int V, int F, int H, int W, int b, int px, int py, int d, REAL* alpha_out)
@@ -269,30 +294,19 @@ static int SFX(aa_analyse)(const REAL* rast, const REAL* pos, const int32_t* tri
     if (vi0 < 0 || vi0 >= V || vi1 < 0 || vi1 >= V || vi2 < 0 || vi2 >= V) return 0;
     int op0 = opp[t * 3], op1 = opp[t * 3 + 1], op2 = opp[t * 3 + 2];
     const REAL* P = pos + (size_t)b * V * 4;
+    int sb = SFX(silhouette_bits)(P, vi0, vi1, vi2, op0, op1, op2, H, W);
+    if (!sb) return 0;
+    int s0 = sb & 1, s1 = sb & 2, s2 = sb & 4;
     const REAL* p0 = P + (size_t)vi0 * 4; const REAL* p1 = P + (size_t)vi1 * 4; const REAL* p2 = P + (size_t)vi2 * 4;
-    const REAL* o0 = (op0 < 0) ? p0 : P + (size_t)op0 * 4;
-    const REAL* o1 = (op1 < 0) ? p1 : P + (size_t)op1 * 4;
-    const REAL* o2 = (op2 < 0) ? p2 : P + (size_t)op2 * 4;
     REAL xh = R_(0.5) * (REAL)W, yh = R_(0.5) * (REAL)H;
     REAL w0 = R_(1) / p0[3], w1 = R_(1) / p1[3], w2 = R_(1) / p2[3];
-    REAL ow0 = R_(1) / o0[3], ow1 = R_(1) / o1[3], ow2 = R_(1) / o2[3];
     REAL fx = (REAL)qx + R_(0.5); fx = fx - xh;
     REAL fy = (REAL)qy + R_(0.5); fy = fy - yh;
     REAL m;
     m = p0[0] * w0; m = m * xh; REAL x0 = m - fx;   m = p0[1] * w0; m = m * yh; REAL y0 = m - fy;
     m = p1[0] * w1; m = m * xh; REAL x1 = m - fx;   m = p1[1] * w1; m = m * yh; REAL y1 = m - fy;
     m = p2[0] * w2; m = m * xh; REAL x2 = m - fx;   m = p2[1] * w2; m = m * yh; REAL y2 = m - fy;
-    m = o0[0] * ow0; m = m * xh; REAL ox0 = m - fx; m = o0[1] * ow0; m = m * yh; REAL oy0 = m - fy;
-    m = o1[0] * ow1; m = m * xh; REAL ox1 = m - fx; m = o1[1] * ow1; m = m * yh; REAL oy1 = m - fy;
-    m = o2[0] * ow2; m = m * xh; REAL ox2 = m - fx; m = o2[1] * ow2; m = m * yh; REAL oy2 = m - fy;
-    /* signs to kill non-silhouette edges: triangle itself and its three wings */
-    REAL e0, e1, e2, e3, l, r;
-    e0 = x1 - x0;  e1 = y2 - y0;  e2 = x2 - x0;  e3 = y1 - y0;  l = e0 * e1; r = e2 * e3; REAL bb = l - r;
-    e0 = x1 - ox0; e1 = y2 - oy0; e2 = x2 - ox0; e3 = y1 - oy0; l = e0 * e1; r = e2 * e3; REAL a0 = l - r;
-    e0 = x2 - ox1; e1 = y0 - oy1; e2 = x0 - ox1; e3 = y2 - oy1; l = e0 * e1; r = e2 * e3; REAL a1 = l - r;
-    e0 = x0 - ox2; e1 = y1 - oy2; e2 = x1 - ox2; e3 = y0 - oy2; l = e0 * e1; r = e2 * e3; REAL a2 = l - r;
-    int s0 = SFX(same_sign)(a0, bb), s1 = SFX(same_sign)(a1, bb), s2 = SFX(same_sign)(a2, bb);
-    if (!(s0 || s1 || s2)) return 0;
+    REAL l, r;
     if (d) { REAL tt; tt = x0; x0 = y0; y0 = tt; tt = x1; x1 = y1; y1 = tt; tt = x2; x2 = y2; y2 = tt; }
     REAL dx0 = x2 - x1, dx1 = x0 - x2, dx2 = x1 - x0;
     REAL dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;

@@ -158,11 +158,11 @@ def test_unchanged_loop_body_on_dr(oracle):
 
 
 def test_full_size_properties():
-    """sub3-class mesh (V=49153, F=98048) at 512x512, 4 views: size-independent properties (the oracle is too slow here)."""
+    """sub3-class mesh (V=48693, F=97088) at 512x512, 4 views: size-independent properties (the oracle is too slow here)."""
     from fmhr_amd import synthetic as S
     from fmhr_amd.ham import HamStage2, render_forward, edge_length_mean
     dev = torch.device("cuda:0")
-    sc = S.make_scene(4, 512, 512, 192, 256, seed=0)
+    sc = S.make_scene(4, 512, 512, 21, 37, 3, seed=0)
     faces = sc["faces"].to(dev)
     fwd = lambda v, a, s, m: render_forward(faces, v, a, s, sc["w2c"].to(dev), sc["proj"].to(dev), m, 512, 512)
     tg = S.make_targets(sc, fwd, device=dev)

@@ -35,7 +35,7 @@ def test_step_fd_and_precision(oracle):
             continue
         num = float(p["loss"] - m["loss"]) / 2
         ana = float((d.grad * dd).sum() + (a.grad * da).sum())
-        assert abs(num - ana) <= 2e-4 * abs(ana) + 1e-12, (num, ana)
+        assert abs(num - ana) <= 1e-3 * abs(ana) + 5e-9, (num, ana)   # L1 / hinge kinks crossed by the step add O(h) noise
         checked += 1
     assert checked >= 4
     # fp32 twin agrees with fp64 (same decisions on this scene)
