@@ -301,12 +301,15 @@ template <int CA, int CB>
 __global__ void __launch_bounds__(kBlock)
 k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, const float4* __restrict__ rast,
          const float* __restrict__ pos, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
-         const unsigned char* __restrict__ silh,
+         const unsigned char* __restrict__ silh, const unsigned char* __restrict__ act,
+         const unsigned long long* __restrict__ covw,
          int n, int V, int F, int H, int W, int Cdyn, float* __restrict__ outA, float* __restrict__ outB,
          int4* __restrict__ items, float* __restrict__ alphas, int32_t* counter, int cap)
 {
     long long P = (long long)H * W;
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    // sparse mode (fused step): inactive 64-pixel segments hold no covered pixel and no neighbour of one -> no pair can blend
+    if (act != nullptr && (gid - (gid & 63) >= (long long)n * P || __builtin_amdgcn_readfirstlane((int)act[gid >> 6]) == 0)) return;
     bool live = gid < (long long)n * P;
     int b = 0, px = 0, py = 0;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -314,7 +317,8 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
         b = (int)(gid / P);
         int rem = (int)(gid - (long long)b * P);
         py = rem / W; px = rem - py * W;
-        r0 = rast[gid];
+        // in sparse mode rast is only defined on covered pixels: an uncovered pixel is the all-zero fragment
+        if (covw == nullptr || ((covw[gid >> 6] >> (gid & 63)) & 1ull)) r0 = rast[gid];
     }
     const float* posv = pos + (size_t)b * V * 4;
 #pragma unroll
@@ -324,7 +328,8 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
         int code = 0;
         long long gid1 = gid + (d ? W : 1);
         if (live && (d ? (py + 1 < H) : (px + 1 < W))) {
-            float4 r1 = rast[gid1];
+            float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (covw == nullptr || ((covw[gid1 >> 6] >> (gid1 & 63)) & 1ull)) r1 = rast[gid1];
             if (r1.w != r0.w) {
                 code = aa_analyse(posv, tri, opp, silh ? silh + (size_t)b * F : nullptr, V, F, H, W, px, py, d, r0.z, r0.w, r1.z, r1.w, alpha);
                 has = code != 0;
@@ -442,11 +447,11 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
 
 // fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour)
 int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
-                const unsigned char* silh, int n, int V, int F, int H, int W, float* out, int32_t* items, float* alphas,
-                int32_t* counter, int cap, hipStream_t st)
+                const unsigned char* silh, const unsigned char* act, const unsigned long long* covw, int n, int V, int F, int H,
+                int W, float* out, int32_t* items, float* alphas, int32_t* counter, int cap, hipStream_t st)
 {
     long long nP = (long long)n * H * W;
-    k_aa_fwd<4, 0><<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, opp, silh, n, V, F, H, W, 4, out,
+    k_aa_fwd<4, 0><<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, opp, silh, act, covw, n, V, F, H, W, 4, out,
                                                        nullptr, (int4*)items, alphas, counter, cap);
     FMHR_CHECK_LAUNCH("k_aa_fwd<4>");
     return FMHR_OK;
@@ -564,9 +569,9 @@ extern "C" int fmhr_antialias_fwd(const float* color, const float* rast, const f
     int grid = cdiv(nP, kBlock);
     int4* it = (int4*)items;
     const float4* r4 = (const float4*)rast;
-    if (C == 1) k_aa_fwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
-    else if (C == 3) k_aa_fwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
-    else k_aa_fwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    if (C == 1) k_aa_fwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    else if (C == 3) k_aa_fwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    else k_aa_fwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
     FMHR_CHECK_LAUNCH("k_aa_fwd");
     return FMHR_OK;
 }

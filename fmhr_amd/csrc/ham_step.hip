@@ -6,10 +6,14 @@
 namespace fmhr {
 // raster.hip / antialias.hip / mesh.hip / shade.hip
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
+int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
-                       void*, int*, int*, hipStream_t);
-int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, int, int, int,
-                int, int, float*, int32_t*, float*, int32_t*, int, hipStream_t);
+                       void*, int*, int*, unsigned char*, unsigned long long*, hipStream_t);
+int active_segments_impl(const unsigned long long*, const float*, long long, int, unsigned char*, hipStream_t);
+int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
+int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*,
+                const unsigned char*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int,
+                hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const int32_t*, const float*,
                 const int32_t*, int, int, int, int, int, float*, float*, hipStream_t);
 int normals_fwd_impl(const float*, const int32_t*, int, int, int, float*, float*, hipStream_t);
@@ -21,20 +25,20 @@ int transform_fwd_impl(const float*, const float*, const float*, int, int, float
 int edge_hinge_impl(const float*, const int32_t*, int, int, float, float, float, float*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
 int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, int, int, int, int,
-                   float*, float*, int*, hipStream_t);
-int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const float*, float, float,
-                  float, float*, float*, float*, hipStream_t);
+                   const unsigned char*, const unsigned long long*, float*, float*, float*, int*, hipStream_t);
+int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const unsigned char*,
+                  const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*, int, int,
-                 int, int, float*, hipStream_t);
+                 int, int, const unsigned long long*, float*, hipStream_t);
 int vertex_gather_impl(const float*, const float*, const int*, const int*, const int32_t*, const int32_t*, const int32_t*,
                        const float*, int, int, int, int, int, float*, float*, hipStream_t);
 int reduce_views_impl(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
-int finish_losses_impl(float*, const float*, hipStream_t);
+int finish_losses_impl(float*, const float*, const float*, const float*, int, float, float, float, hipStream_t);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, pos, snap, silh, raster_ws, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
-        g_shaded, rec, gpos, part, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
+    size_t vertices, nsum, normals, pos, snap, silh, raster_ws, dirty, covw, act, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+        g_shaded, rec, gpos, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -56,6 +60,9 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.snap = take(off, nV * 8);
     L.silh = take(off, (size_t)d->n * d->F);
     L.raster_ws = take(off, raster_core_ws_bytes(d->n, d->F, d->H, d->W));
+    L.dirty = take(off, (nP + 63) / 64);
+    L.covw = take(off, ((nP + 63) / 64) * 8);
+    L.act = take(off, (nP + 63) / 64);
     L.head = take(off, (size_t)d->n * d->F * 4);
     L.next = take(off, nP * 4);
     L.rast = take(off, nP * 16);
@@ -69,6 +76,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.rec = take(off, nP * 32);
     L.gpos = take(off, nV * 16);
     L.part = take(off, nV * 32);
+    L.partials = take(off, ((nP + 255) / 256) * 4 * 3);
     L.gnormal = take(off, V * 12);
     L.gvert = take(off, V * 12);
     L.gtmp = take(off, V * 12);
@@ -125,22 +133,43 @@ extern "C" int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t
     return FMHR_OK;
 }
 
-extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
-                                const float* sh, const float* w2c, const float* proj, const float* img, const float* mask,
-                                const int32_t* tri, const int32_t* opp, int32_t* n_valid_local, void* ws, size_t ws_bytes,
-                                void* stream)
+extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream)
 {
-    (void)img;
+    TRY(check_dims(d));
+    Layout L = make_layout(d);
+    FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_workspace_init: workspace too small or null");
+    char* w = (char*)ws;
+    return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, d->W, (hipStream_t)stream);
+}
+
+extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream)
+{
+    TRY(check_dims(d));
+    Layout L = make_layout(d);
+    FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_densify: workspace too small or null");
+    char* w = (char*)ws;
+    return densify_impl((const unsigned long long*)(w + L.covw), (const unsigned char*)(w + L.act), (long long)d->n * d->H * d->W,
+                        (float*)(w + L.rast), (float*)(w + L.shaded), (float*)(w + L.aa), (hipStream_t)stream);
+}
+
+extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
+                                const float* sh, const float* w2c, const float* proj, const float* mask,
+                                const float* valid_mask, const int32_t* tri, const int32_t* opp, int32_t* n_valid_local,
+                                void* ws, size_t ws_bytes, void* stream)
+{
     TRY(check_dims(d));
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_forward: workspace too small (%zu < %zu)", ws_bytes, L.total);
-    FMHR_CHECK_ARG(vertices_tmp && delta && albedo && sh && w2c && proj && mask && tri && opp && n_valid_local,
+    FMHR_CHECK_ARG(vertices_tmp && delta && albedo && sh && w2c && proj && mask && valid_mask && tri && opp && n_valid_local,
                    "ham_forward: null pointer");
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
     float* vertices = (float*)(w + L.vertices);
     float* pos = (float*)(w + L.pos);
     float* rast = (float*)(w + L.rast);
+    const long long nP = (long long)d->n * d->H * d->W;
+    unsigned char* act = (unsigned char*)(w + L.act);
+    unsigned long long* covw = (unsigned long long*)(w + L.covw);
     {
         ProfScope ps(FMHR_SLOT_GEOMETRY, st);
         TRY(add_delta_impl(vertices_tmp, delta, d->V * 3, vertices, st));
@@ -148,16 +177,16 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), st));
     }
     TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
-                           rast, w + L.raster_ws, (int*)(w + L.head), (int*)(w + L.next), st));
+                           rast, w + L.raster_ws, (int*)(w + L.head), (int*)(w + L.next), (unsigned char*)(w + L.dirty), covw, st));
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
-        HIPTRY(hipMemsetAsync(n_valid_local, 0, 4, st), "memset n_valid");
-        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, d->n, d->F, d->H, d->W, (float*)(w + L.shaded),
-                           (float*)(w + L.aa), n_valid_local, st));
+        TRY(active_segments_impl(covw, valid_mask, nP, d->W, act, st));
+        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, d->n, d->F, d->H, d->W, act, covw,
+                           (float*)(w + L.shaded), (float*)(w + L.aa), (float*)(w + L.partials), n_valid_local, st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, st), "memset aa_counter");
-    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W, (float*)(w + L.aa),
+    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), act, covw, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.aa),
                     (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas), (int32_t*)(w + L.aa_counter), d->aa_cap, st));
     return FMHR_OK;
 }
@@ -185,6 +214,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     float* gvert = (float*)(w + L.gvert);
     size_t nP = (size_t)d->n * d->H * d->W, V = d->V;
     const float rg = wt->reg_grad_scale;
+    const size_t nB = (nP + 255) / 256;
 
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
@@ -193,8 +223,10 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         HIPTRY(hipMemsetAsync(gvert, 0, V * 12, st), "memset gvert");
         HIPTRY(hipMemsetAsync(galbedo, 0, V * 12, st), "memset galbedo");
         // losses on the antialiased rgba + their per-pixel gradients (written twice: g_aa and the AA-backward target)
-        TRY(loss_pix_impl((float*)(w + L.shaded), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP, n_valid_global,
-                          wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa), (float*)(w + L.g_shaded), losses, st));
+        TRY(loss_pix_impl((float*)(w + L.shaded), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
+                          (const unsigned char*)(w + L.act), n_valid_global,
+                          wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa), (float*)(w + L.g_shaded),
+                          (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, st));
     }
     {
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads into gpos
@@ -207,7 +239,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         // shade + interpolate + rasterize backward, gather style: per-pixel records, then one lane per (view, vertex)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
         TRY(pix_bwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_shaded), d->n, d->F, d->H, d->W,
-                         (float*)(w + L.rec), st));
+                         (const unsigned long long*)(w + L.covw), (float*)(w + L.rec), st));
         TRY(vertex_gather_impl(rast, (float*)(w + L.rec), (int*)(w + L.head), (int*)(w + L.next), tri, vf_ptr, vf_idx, pos, d->n,
                                d->V, d->F, d->H, d->W, (float*)(w + L.part), gpos, st));
     }
@@ -232,6 +264,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     TRY(edge_hinge_impl(vertices, tri, d->V, d->F, wt->edge_length_mean, wt->edge, wt->edge * rg, losses + FMHR_LOSS_EDGE, gvert, st));
     TRY(delta_term_impl(delta, d->V, wt->delta, wt->delta * rg, losses + FMHR_LOSS_DELTA, gvert, st));
     HIPTRY(hipMemcpyAsync(gdelta, gvert, V * 12, hipMemcpyDeviceToDevice, st), "copy gdelta");
-    TRY(finish_losses_impl(losses, n_valid_global, st));
+    TRY(finish_losses_impl(losses, n_valid_global, (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, (int)nB,
+                           wt->sfs, wt->mask, wt->mse_denominator, st));
     return FMHR_OK;
 }

@@ -53,13 +53,18 @@ __device__ __forceinline__ bool covers(const TriSetup& s, int px, int py)
            edge_in(s.x2, s.y2, s.x0, s.y0, cx, cy);
 }
 
+// `dirty` (nullable): one byte per 64-pixel segment of the flattened [n*H*W] pixel index; set when a fragment lands there, so
+// the resolve pass (and everything after it) only touches segments that can hold coverage
 __device__ __forceinline__ void emit_fragment(const float4 p0, const float4 p1, const float4 p2, int px, int py, int f,
-                                              float xs, float xo, float ys, float yo, unsigned long long* keys_view, int W)
+                                              float xs, float xo, float ys, float yo, unsigned long long* keys_view, int W,
+                                              unsigned char* dirty, long long pixbase)
 {
     Frag fr;
     if (!fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) return;
     unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | (unsigned)f;
-    atomicMin(&keys_view[(size_t)py * W + px], key);
+    size_t pix = (size_t)py * W + px;
+    atomicMin(&keys_view[pix], key);
+    if (dirty != nullptr) dirty[(pixbase + (long long)pix) >> 6] = 1;
 }
 
 // one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup; clip positions are only fetched by the
@@ -68,7 +73,7 @@ __global__ void __launch_bounds__(kBlock)
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, int* __restrict__ large_cnt,
-              int2* __restrict__ large_q)
+              int2* __restrict__ large_q, unsigned char* __restrict__ dirty)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)n * F) return;
@@ -112,7 +117,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         for (int px = s.pxa; px <= s.pxb; px++) {
             if (!covers(s, px, py)) continue;
             if (!loaded) { p0 = ldg4(vp + (size_t)i0 * 4); p1 = ldg4(vp + (size_t)i1 * 4); p2 = ldg4(vp + (size_t)i2 * 4); loaded = true; }
-            emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W);
+            emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W, dirty, (long long)b * H * W);
         }
 }
 
@@ -120,7 +125,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
 __global__ void __launch_bounds__(kBlock)
 k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
                int F, int H, int W, unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt,
-               const int2* __restrict__ large_q)
+               const int2* __restrict__ large_q, unsigned char* __restrict__ dirty)
 {
     const int cnt = *large_cnt;
     const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
@@ -139,23 +144,37 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
         unsigned long long* kv = keys + (size_t)b * H * W;
         for (int i = threadIdx.x; i < bw * bh; i += kBlock) {
             int py = s.pya + i / bw, px = s.pxa + i % bw;
-            if (covers(s, px, py)) emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W);
+            if (covers(s, px, py)) emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W, dirty, (long long)b * H * W);
         }
     }
 }
 
 // per pixel: decode the winning key, recompute its fragment, write (u, v, z/w, id+1) as one 16-B store; optionally thread
-// the pixel onto its triangle's list (head [n,F] / next [n,H,W]) for the gather-style backward
+// the pixel onto its triangle's list (head [n,F] / next [n,H,W]) for the gather-style backward.
+// Sparse mode (dirty != null, fused step): a wave owns one 64-pixel segment; a clean segment costs one scalar load; a dirty one
+// is resolved, its keys are reset to "empty" (the key buffer cleans itself: no per-step 100 MB memset), covered lanes get
+// their rast written (uncovered lanes are zero-filled later, only where a consumer will look), and the coverage word is stored.
 __global__ void __launch_bounds__(kBlock)
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
-                 const unsigned long long* __restrict__ keys, float4* __restrict__ rast, int* __restrict__ head,
-                 int* __restrict__ next)
+                 unsigned long long* __restrict__ keys, float4* __restrict__ rast, int* __restrict__ head,
+                 int* __restrict__ next, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     long long P = (long long)H * W;
-    if (gid >= (long long)n * P) return;
-    unsigned long long key = keys[gid];
+    const bool sparse = dirty != nullptr;
+    long long seg = gid >> 6;
+    if (sparse) {
+        if (gid - (gid & 63) >= (long long)n * P) return;            // whole wave out of range
+        int d = __builtin_amdgcn_readfirstlane((int)dirty[seg]);
+        if (!d) {
+            if ((threadIdx.x & 63) == 0) covw[seg] = 0ull;
+            return;
+        }
+    }
+    bool live = gid < (long long)n * P;
+    unsigned long long key = live ? keys[gid] : ~0ull;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool covered = false;
     if (key != ~0ull) {
         int b = (int)(gid / P);
         int rem = (int)(gid - (long long)b * P);
@@ -170,10 +189,20 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         Frag fr;
         if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
             o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
+            covered = true;
             if (head != nullptr) next[gid] = atomicExch(&head[(size_t)b * F + f], rem);
         }
     }
-    rast[gid] = o;
+    if (sparse) {
+        unsigned long long bal = __ballot(covered);
+        if (live) {
+            if (covered) rast[gid] = o;
+            keys[gid] = ~0ull;
+        }
+        if ((threadIdx.x & 63) == 0) { covw[seg] = bal; dirty[seg] = 0; }
+    } else if (live) {
+        rast[gid] = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ rasterize backward
@@ -296,9 +325,22 @@ int snap_vertices_impl(const float* pos, int n, int V, int H, int W, int2* snap,
     return FMHR_OK;
 }
 
-// snap [n,V] int2 must already hold the snapped vertices; head/next may be null
+// One-off initialisation of the self-cleaning sparse state: keys all "empty", no dirty segment.
+int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipStream_t st)
+{
+    size_t nP = (size_t)n * H * W;
+    hipError_t e = hipMemsetAsync(ws, 0xFF, nP * 8, st);
+    if (e != hipSuccess) return hip_fail(e, "init keys");
+    e = hipMemsetAsync(dirty, 0, (nP + 63) / 64, st);
+    if (e != hipSuccess) return hip_fail(e, "init dirty");
+    return FMHR_OK;
+}
+
+// snap [n,V] int2 must already hold the snapped vertices; head/next may be null.  dirty/covw non-null = sparse mode (the key
+// buffer must have been initialised by raster_sparse_init and is left clean again).
 int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, const int32_t* opp, unsigned char* silh, int n, int V,
-                       int F, int H, int W, float* rast, void* ws, int* head, int* next, hipStream_t st)
+                       int F, int H, int W, float* rast, void* ws, int* head, int* next, unsigned char* dirty,
+                       unsigned long long* covw, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
     unsigned long long* keys = (unsigned long long*)ws;
@@ -307,8 +349,11 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     if (nP == 0) return FMHR_OK;
     {
         ProfScope ps(FMHR_SLOT_RASTER_CLEAR, st);
-        hipError_t e = hipMemsetAsync(keys, 0xFF, nP * 8, st);
-        if (e != hipSuccess) return hip_fail(e, "memset keys");
+        hipError_t e;
+        if (dirty == nullptr) {
+            e = hipMemsetAsync(keys, 0xFF, nP * 8, st);
+            if (e != hipSuccess) return hip_fail(e, "memset keys");
+        }
         e = hipMemsetAsync(large_cnt, 0, 16, st);
         if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
         if (head != nullptr && (size_t)n * F > 0) {
@@ -319,15 +364,17 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     if ((long long)n * F > 0) {
         {
             ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
-            k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, large_cnt, large_q);
+            k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, large_cnt,
+                                                                          large_q, dirty);
             FMHR_CHECK_LAUNCH("k_raster_tris");
         }
         ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);
-        k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q);
+        k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty);
         FMHR_CHECK_LAUNCH("k_raster_large");
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, next);
+    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, next, dirty,
+                                                                    covw);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }
@@ -344,7 +391,8 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     int2* snap = (int2*)((char*)ws + raster_core_ws_bytes(n, F, H, W));
     int rc = snap_vertices_impl(pos, n, V, H, W, snap, (hipStream_t)stream);
     if (rc) return rc;
-    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, (hipStream_t)stream);
+    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, nullptr, nullptr,
+                              (hipStream_t)stream);
 }
 
 extern "C" int fmhr_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int n, int V,

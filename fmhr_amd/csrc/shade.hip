@@ -54,18 +54,72 @@ __device__ __forceinline__ void shade_eval(const float4 r, const int32_t* __rest
     s.rad = sh9c(shc, s.hx, s.hy, s.hz);
 }
 
+// ------------------------------------------------------------------------------------------------ segment sparsity
+// The flattened pixel index [n*H*W] is cut into 64-pixel segments = exactly one wave of every per-pixel kernel.  A segment is
+// ACTIVE when it holds a covered pixel, a 4-neighbour of one (antialias pairs and blend targets), or a non-zero valid_mask
+// (silhouette MSE).  Per-pixel kernels return after one scalar load on inactive segments (~2/3 of a 19 %-coverage frame);
+// every buffer is fully (re)written inside active segments each step and never read outside them.
+__device__ __forceinline__ bool cov_range_any(const unsigned long long* __restrict__ covw, long long start, long long nSeg)
+{
+    // any covered pixel with flattened index in [start, start+63]?
+    if (start + 63 < 0) return false;
+    long long w0 = start >> 6;              // arithmetic shift: floor
+    int sh = (int)(start & 63);
+    bool a = false;
+    if (w0 >= 0 && w0 < nSeg) a = (covw[w0] >> sh) != 0ull;
+    if (sh != 0 && w0 + 1 >= 0 && w0 + 1 < nSeg) a = a || ((covw[w0 + 1] << (64 - sh)) != 0ull);
+    return a;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_active_segments(const unsigned long long* __restrict__ covw, const float* __restrict__ valid_mask, long long N, int W,
+                  unsigned char* __restrict__ act)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid - (gid & 63) >= N) return;
+    float vm = (gid < N) ? valid_mask[gid] : 0.f;
+    unsigned long long bal = __ballot(vm != 0.f);
+    if ((threadIdx.x & 63) != 0) return;
+    long long seg = gid >> 6, nSeg = (N + 63) >> 6, s0 = seg << 6;
+    bool a = bal != 0ull || covw[seg] != 0ull;
+    if (!a) a = (seg + 1 < nSeg && (covw[seg + 1] & 1ull)) || (seg > 0 && (covw[seg - 1] >> 63));
+    if (!a) a = cov_range_any(covw, s0 + W, nSeg) || cov_range_any(covw, s0 - W, nSeg);
+    act[seg] = a ? 1 : 0;
+}
+
+__device__ __forceinline__ bool seg_active(const unsigned char* __restrict__ act, long long gid)
+{
+    return __builtin_amdgcn_readfirstlane((int)act[gid >> 6]) != 0;
+}
+
+// test/inspection helper: make the sparse buffers dense (zeros wherever the step did not write)
+__global__ void __launch_bounds__(kBlock)
+k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ act, long long N,
+          float4* __restrict__ rast, float4* __restrict__ shaded, float4* __restrict__ aa)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= N) return;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool covered = (covw[gid >> 6] >> (gid & 63)) & 1ull;
+    if (!covered) rast[gid] = z;
+    if (!act[gid >> 6]) { shaded[gid] = z; aa[gid] = z; }
+}
+
 // forward: rast -> rgba (rgb = shaded image, zero outside valid = mask>0 & covered; a = the interpolated ones attribute),
 // written twice (the second copy is the antialias accumulation target); local valid count
 __global__ void __launch_bounds__(kBlock)
 k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ normals,
             const float* __restrict__ albedo, const float* __restrict__ sh, const float* __restrict__ mask,
-            int n, int F, long long P, float4* __restrict__ shaded, float4* __restrict__ aa_init, int* __restrict__ n_valid)
+            int n, int F, long long P, const unsigned char* __restrict__ act, const unsigned long long* __restrict__ covw,
+            float4* __restrict__ shaded, float4* __restrict__ aa_init, float* __restrict__ part_cnt)
 {
     __shared__ float sm[4];
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     float cnt = 0.f;
-    if (gid < (long long)n * P) {
-        float4 r = rast[gid];
+    if (gid - (gid & 63) < (long long)n * P && seg_active(act, gid) && gid < (long long)n * P) {
+        const bool covered = (covw[gid >> 6] >> (gid & 63)) & 1ull;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (covered) r = rast[gid];
         int t = (int)r.w - 1;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t >= 0 && t < F) {
@@ -86,54 +140,69 @@ k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, co
         aa_init[gid] = o;
     }
     float s = block_sum(cnt, sm);
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(n_valid, (int)s);
+    if (threadIdx.x == 0) part_cnt[blockIdx.x] = s;        // per-block partial: 49k same-address atomics serialise at ~10 ns each
 }
 
-// losses + their per-pixel gradients, 4 pixels per lane so every access is a 16-B vector:
-// sfs = w * mean_valid |aa.rgb - img| (:289), mask = w * mean (aa.a - valid_mask)^2 (:295).
-// g_aa [.,4] = d loss / d antialiased rgba, written twice (second copy = antialias-backward accumulation target).
+// losses + their per-pixel gradients over the active segments:
+// sfs = w * mean_valid |aa.rgb - img| (:289), mask = w * mean (aa.a - valid_mask)^2 (:295) — inactive segments contribute
+// exactly 0 to both.  g [.,4] = d loss / d antialiased rgba, written twice (g_aa = what the antialias backward reads as dy,
+// g_shaded = its accumulation target).
 __global__ void __launch_bounds__(kBlock)
-k_loss_pix4(const float4* __restrict__ shaded, const float4* __restrict__ aa, const float4* __restrict__ img3,
-            const float4* __restrict__ mask, const float4* __restrict__ valid_mask, long long N4,
-            const float* __restrict__ n_valid_global, float w_sfs, float w_mask, float mse_den,
-            float4* __restrict__ g_aa, float4* __restrict__ g_shaded, float* __restrict__ losses)
+k_loss_pix(const float4* __restrict__ shaded, const float4* __restrict__ aa, const float* __restrict__ img,
+           const float* __restrict__ mask, const float* __restrict__ valid_mask, long long N,
+           const unsigned char* __restrict__ act, const float* __restrict__ n_valid_global, float w_sfs, float w_mask,
+           float mse_den, float4* __restrict__ g_aa, float4* __restrict__ g_shaded, float* __restrict__ part_l1,
+           float* __restrict__ part_l2)
 {
     __shared__ float sm[4];
-    long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     float l1 = 0.f, l2 = 0.f;
     float den = 3.0f * n_valid_global[0];
     float k1 = (den > 0.f) ? w_sfs / den : 0.f;
     float k2 = w_mask / mse_den;
-    if (q < N4) {
-        float4 i0 = img3[q * 3], i1 = img3[q * 3 + 1], i2 = img3[q * 3 + 2];    // 4 pixels x rgb = 12 floats
-        const float im[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
-        float4 mk = mask[q], vm = valid_mask[q];
-        const float mka[4] = {mk.x, mk.y, mk.z, mk.w}, vma[4] = {vm.x, vm.y, vm.z, vm.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float4 a = aa[q * 4 + j];
-            float cov = shaded[q * 4 + j].w;                    // != 0 exactly where the pixel is covered
-            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mka[j] > 0.f && cov != 0.f) {
-                float d0 = a.x - im[j * 3], d1 = a.y - im[j * 3 + 1], d2 = a.z - im[j * 3 + 2];
-                l1 += fabsf(d0) + fabsf(d1) + fabsf(d2);
-                g.x = (d0 > 0.f) ? k1 : ((d0 < 0.f) ? -k1 : 0.f);
-                g.y = (d1 > 0.f) ? k1 : ((d1 < 0.f) ? -k1 : 0.f);
-                g.z = (d2 > 0.f) ? k1 : ((d2 < 0.f) ? -k1 : 0.f);
-            }
-            float dm = a.w - vma[j];
-            l2 += dm * dm;
-            g.w = 2.0f * dm * k2;
-            g_aa[q * 4 + j] = g;
-            g_shaded[q * 4 + j] = g;
+    if (gid - (gid & 63) < N && seg_active(act, gid) && gid < N) {
+        float4 a = aa[gid];
+        float cov = shaded[gid].w;                            // != 0 exactly where the pixel is covered
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mask[gid] > 0.f && cov != 0.f) {
+            float d0 = a.x - img[gid * 3], d1 = a.y - img[gid * 3 + 1], d2 = a.z - img[gid * 3 + 2];
+            l1 = fabsf(d0) + fabsf(d1) + fabsf(d2);
+            g.x = (d0 > 0.f) ? k1 : ((d0 < 0.f) ? -k1 : 0.f);
+            g.y = (d1 > 0.f) ? k1 : ((d1 < 0.f) ? -k1 : 0.f);
+            g.z = (d2 > 0.f) ? k1 : ((d2 < 0.f) ? -k1 : 0.f);
         }
+        float dm = a.w - valid_mask[gid];
+        l2 = dm * dm;
+        g.w = 2.0f * dm * k2;
+        g_aa[gid] = g;
+        g_shaded[gid] = g;
     }
     float s1 = block_sum(l1, sm);
     float s2 = block_sum(l2, sm);
-    if (threadIdx.x == 0) {
-        if (s1 != 0.f) atomicAdd(losses + FMHR_LOSS_SFS, s1 * k1);
-        if (s2 != 0.f) atomicAdd(losses + FMHR_LOSS_MASK, s2 * k2);
-    }
+    if (threadIdx.x == 0) { part_l1[blockIdx.x] = s1; part_l2[blockIdx.x] = s2; }
+}
+
+// single-workgroup deterministic sums of per-block partials
+__device__ __forceinline__ float block1024_sum(float v, float* sm16)
+{
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm16[wv] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 16; i++) r += sm16[i];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__ part, int nb, int* __restrict__ n_valid)
+{
+    __shared__ float sm[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 1024) acc += part[i];
+    float r = block1024_sum(acc, sm);
+    if (threadIdx.x == 0) n_valid[0] = (int)(r + 0.5f);
 }
 
 // per covered pixel: backward of shade + normalise down to the interpolated attributes, and the barycentric gradients.
@@ -141,10 +210,12 @@ k_loss_pix4(const float4* __restrict__ shaded, const float4* __restrict__ aa, co
 __global__ void __launch_bounds__(kBlock)
 k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ normals,
           const float* __restrict__ albedo, const float* __restrict__ sh, const float* __restrict__ mask,
-          const float4* __restrict__ g_shaded, int n, int F, long long P, float4* __restrict__ rec)
+          const float4* __restrict__ g_shaded, int n, int F, long long P, const unsigned long long* __restrict__ covw,
+          float4* __restrict__ rec)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)n * P) return;
+    if (!((covw[gid >> 6] >> (gid & 63)) & 1ull)) return;       // one 8-B word per wave: uncovered segments stop here
     float4 r = rast[gid];
     int t = (int)r.w - 1;
     if (t < 0 || t >= F) return;
@@ -276,46 +347,78 @@ k_reduce_views(const float4* __restrict__ part, const float4* __restrict__ gpos,
     galbedo[(size_t)v * 3] += a0; galbedo[(size_t)v * 3 + 1] += a1; galbedo[(size_t)v * 3 + 2] += a2;
 }
 
-__global__ void k_finish_losses(float* losses, const float* n_valid)
+__global__ void __launch_bounds__(1024)
+k_finish_losses(float* losses, const float* n_valid, const float* __restrict__ part_l1, const float* __restrict__ part_l2, int nb,
+                float w_sfs, float w_mask, float mse_den)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __shared__ float sm[16];
+    float a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 1024) { a1 += part_l1[i]; a2 += part_l2[i]; }
+    float s1 = block1024_sum(a1, sm);
+    float s2 = block1024_sum(a2, sm);
+    if (threadIdx.x == 0) {
+        float den = 3.0f * n_valid[0];
+        losses[FMHR_LOSS_SFS] = (den > 0.f) ? s1 * (w_sfs / den) : 0.f;
+        losses[FMHR_LOSS_MASK] = s2 * (w_mask / mse_den);
         losses[FMHR_LOSS_TOTAL] = losses[FMHR_LOSS_SFS] + losses[FMHR_LOSS_LAP] + losses[FMHR_LOSS_ALBEDO] +
                                   losses[FMHR_LOSS_MASK] + losses[FMHR_LOSS_DELTA] + losses[FMHR_LOSS_EDGE];
         losses[FMHR_LOSS_NVALID] = n_valid[0];
     }
 }
 
+int active_segments_impl(const unsigned long long* covw, const float* valid_mask, long long N, int W, unsigned char* act,
+                         hipStream_t st)
+{
+    if (N == 0) return FMHR_OK;
+    k_active_segments<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, valid_mask, N, W, act);
+    FMHR_CHECK_LAUNCH("k_active_segments");
+    return FMHR_OK;
+}
+
+int densify_impl(const unsigned long long* covw, const unsigned char* act, long long N, float* rast, float* shaded, float* aa,
+                 hipStream_t st)
+{
+    if (N == 0) return FMHR_OK;
+    k_densify<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, act, N, (float4*)rast, (float4*)shaded, (float4*)aa);
+    FMHR_CHECK_LAUNCH("k_densify");
+    return FMHR_OK;
+}
+
 int shade_fwd_impl(const float* rast, const int32_t* tri, const float* normals, const float* albedo, const float* sh,
-                   const float* mask, int n, int F, int H, int W, float* shaded, float* aa_init, int* n_valid, hipStream_t st)
+                   const float* mask, int n, int F, int H, int W, const unsigned char* act, const unsigned long long* covw,
+                   float* shaded, float* aa_init, float* part_cnt, int* n_valid, hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0) return FMHR_OK;
-    k_shade_fwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, normals, albedo, sh, mask, n, F, P,
-                                                       (float4*)shaded, (float4*)aa_init, n_valid);
+    int nb = cdiv(n * P, kBlock);
+    k_shade_fwd<<<nb, kBlock, 0, st>>>((const float4*)rast, tri, normals, albedo, sh, mask, n, F, P, act, covw,
+                                       (float4*)shaded, (float4*)aa_init, part_cnt);
     FMHR_CHECK_LAUNCH("k_shade_fwd");
+    k_reduce_count<<<1, 1024, 0, st>>>(part_cnt, nb, n_valid);
+    FMHR_CHECK_LAUNCH("k_reduce_count");
     return FMHR_OK;
 }
 
 int loss_pix_impl(const float* shaded, const float* aa, const float* img, const float* mask, const float* valid_mask,
-                  long long N, const float* n_valid_global, float w_sfs, float w_mask, float mse_den, float* g_aa,
-                  float* g_shaded, float* losses, hipStream_t st)
+                  long long N, const unsigned char* act, const float* n_valid_global, float w_sfs, float w_mask, float mse_den,
+                  float* g_aa, float* g_shaded, float* part_l1, float* part_l2, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    if (N % 4 != 0) { set_error("ham: n*H*W must be a multiple of 4 (got %lld)", N); return FMHR_E_ARG; }
-    k_loss_pix4<<<cdiv(N / 4, kBlock), kBlock, 0, st>>>((const float4*)shaded, (const float4*)aa, (const float4*)img,
-                                                        (const float4*)mask, (const float4*)valid_mask, N / 4, n_valid_global,
-                                                        w_sfs, w_mask, mse_den, (float4*)g_aa, (float4*)g_shaded, losses);
-    FMHR_CHECK_LAUNCH("k_loss_pix4");
+    k_loss_pix<<<cdiv(N, kBlock), kBlock, 0, st>>>((const float4*)shaded, (const float4*)aa, img, mask, valid_mask, N, act,
+                                                  n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_aa, (float4*)g_shaded, part_l1,
+                                                  part_l2);
+    FMHR_CHECK_LAUNCH("k_loss_pix");
     return FMHR_OK;
 }
 
 int pix_bwd_impl(const float* rast, const int32_t* tri, const float* normals, const float* albedo, const float* sh,
-                 const float* mask, const float* g_shaded, int n, int F, int H, int W, float* rec, hipStream_t st)
+                 const float* mask, const float* g_shaded, int n, int F, int H, int W, const unsigned long long* covw,
+                 float* rec, hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0 || F == 0) return FMHR_OK;
     k_pix_bwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, normals, albedo, sh, mask, (const float4*)g_shaded,
-                                                     n, F, P, (float4*)rec);
+                                                     n, F, P, covw, (float4*)rec);
     FMHR_CHECK_LAUNCH("k_pix_bwd");
     return FMHR_OK;
 }
@@ -341,9 +444,10 @@ int reduce_views_impl(const float* part, const float* gpos, const float* w2c, co
     return FMHR_OK;
 }
 
-int finish_losses_impl(float* losses, const float* n_valid, hipStream_t st)
+int finish_losses_impl(float* losses, const float* n_valid, const float* part_l1, const float* part_l2, int nb, float w_sfs,
+                       float w_mask, float mse_den, hipStream_t st)
 {
-    k_finish_losses<<<1, 64, 0, st>>>(losses, n_valid);
+    k_finish_losses<<<1, 1024, 0, st>>>(losses, n_valid, part_l1, part_l2, nb, w_sfs, w_mask, mse_den);
     FMHR_CHECK_LAUNCH("k_finish_losses");
     return FMHR_OK;
 }

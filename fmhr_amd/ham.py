@@ -60,6 +60,7 @@ class HamStage2:
         if self.ws_bytes == 0:
             raise RuntimeError("fmhr_ham_workspace_bytes failed: " + self.lib.fmhr_last_error().decode())
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
+        call("fmhr_ham_workspace_init", ctypes.byref(self.dims), ptr(self.ws), self.ws_bytes, st)
         self.n_valid_local = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.n_valid_global = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.losses = torch.zeros(8, dtype=torch.float32, device=self.dev)
@@ -68,9 +69,9 @@ class HamStage2:
         self._views = None
 
     # -- the two phases -------------------------------------------------------------------------------------------------
-    def forward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask):
+    def forward(self, vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask):
         call("fmhr_ham_forward", ctypes.byref(self.dims), ptr(vertices_tmp), ptr(delta), ptr(albedo), ptr(sh), ptr(w2c),
-             ptr(proj), ptr(img), ptr(mask), ptr(self.faces), ptr(self.opp), ptr(self.n_valid_local), ptr(self.ws),
+             ptr(proj), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp), ptr(self.n_valid_local), ptr(self.ws),
              self.ws_bytes, stream_ptr(self.dev))
 
     def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True):
@@ -87,7 +88,7 @@ class HamStage2:
         """Full forward + backward.  Returns (losses[8] device tensor, gdelta [V,3], galbedo [V,3]) — buffers owned by this
         object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded."""
         self._check(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask)
-        self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask)
+        self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask)
         self.n_valid_global.copy_(self.n_valid_local)        # int32 -> float32, on the stream
         if group is not None:
             torch.distributed.all_reduce(self.n_valid_global, group=group)
@@ -108,6 +109,8 @@ class HamStage2:
 
     # -- intermediates (views into the workspace; valid until the next step) ----------------------------------------------
     def views(self):
+        """dense views of the last step's intermediates (zero-fills what the sparse step did not write)."""
+        call("fmhr_ham_densify", ctypes.byref(self.dims), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
         if self._views is None:
             hv = HamViews()
             call("fmhr_ham_workspace_views", ctypes.byref(self.dims), ptr(self.ws), self.ws_bytes, ctypes.byref(hv))
@@ -137,8 +140,7 @@ def render_forward(faces, vertices, albedo, sh, w2c, proj, mask, H, W):
     n, V = w2c.shape[0], vertices.shape[0]
     hs = HamStage2(faces, V, n, H, W, dict(sfs=0, lap=0, albedo=0, mask=0, edge=0, delta=0), 0.0)
     zero = torch.zeros_like(vertices)
-    img = torch.zeros(n, H, W, 3, device=vertices.device)
-    hs.forward(vertices.contiguous(), zero, albedo.contiguous(), sh.contiguous(), w2c.contiguous(), proj.contiguous(), img,
-               mask.contiguous())
+    hs.forward(vertices.contiguous(), zero, albedo.contiguous(), sh.contiguous(), w2c.contiguous(), proj.contiguous(),
+               mask.contiguous(), torch.zeros_like(mask))
     v = hs.views()
     return dict(tmp_img=v["tmp_img"].clone(), pred_mask=v["pred_mask"].clone(), rast=v["rast"].clone())

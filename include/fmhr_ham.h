@@ -141,8 +141,10 @@ size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
  *   n*H*W must be a multiple of 4.
  *   n_valid_local: device int32[1] written by phase A.  n_valid_global: device float[1] read by phase B.
  *   losses: device float[8]; gdelta, galbedo [V,3] overwritten (view-dependent part only when reg_grads=0). */
+/* Must be called once on a fresh workspace (and after any aborted step): sets up the self-cleaning sparse rasterizer state. */
+int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);
 int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
-                     const float* sh, const float* w2c, const float* proj, const float* img, const float* mask,
+                     const float* sh, const float* w2c, const float* proj, const float* mask, const float* valid_mask,
                      const int32_t* tri, const int32_t* opp, int32_t* n_valid_local,
                      void* ws, size_t ws_bytes, void* stream);
 int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const float* vertices_tmp, const float* delta,
@@ -161,6 +163,9 @@ typedef struct fmhr_ham_views {
     int32_t* aa_counter; /* [2] */
 } fmhr_ham_views;
 int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, fmhr_ham_views* out);
+/* The step only writes rast / shaded / aa inside "active" 64-pixel segments (covered pixels, their 4-neighbours, non-zero
+ * valid_mask); this fills the rest with zeros so the views above can be inspected as dense images. */
+int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ per-kernel timing (optional)
  * Attach an array of 2*FMHR_SLOT_COUNT hipEvent_t (created by the caller with timing enabled) to the CALLING THREAD: while
