@@ -167,10 +167,8 @@ def main():
     albedo = scene["albedo0"][None].to(dev).clone().requires_grad_(True)           # [1,V,3] as in the reference (:176)
     lr = scene["lr"]
     groups = [{'params': delta, 'lr': lr["lr"]}, {'params': albedo, 'lr': lr["albedo_lr"]}]
-    try:
-        opt = torch.optim.Adam(groups, fused=True)
-    except Exception:
-        opt = torch.optim.Adam(groups)
+    from fmhr_amd.optim import Adam          # same update rule as torch.optim.Adam (tests/test_gpu_utils.py::test_adam)
+    opt = Adam(groups)
     sharded = fdist.ShardedStep(V, dev)
     group = torch.distributed.group.WORLD if world > 1 else None
 

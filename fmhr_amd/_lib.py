@@ -51,7 +51,9 @@ SIGNATURES = {
     "fmhr_laplacian_uniform_bwd": (c_int, [P, P, P, c_int, c_int, c_float, P, P, P]),
     "fmhr_timing_attach": (c_int, [P, c_int, c_int]),
     "fmhr_timing_detach": (c_int, []),
+    "fmhr_adam_step": (c_int, [P, P, P, P, ctypes.c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
     "fmhr_ham_workspace_bytes": (c_size_t, [ctypes.POINTER(HamDims)]),
+    "fmhr_ham_workspace_offset": (ctypes.c_longlong, [ctypes.POINTER(HamDims), ctypes.c_char_p]),
     "fmhr_ham_workspace_views": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, ctypes.POINTER(HamViews)]),
     "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "fmhr_ham_workspace_init": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/fmhr_ham.h"
 
 namespace fmhr {
@@ -13,6 +14,13 @@ void set_error(const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+bool debug_sync()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FMHR_DEBUG_SYNC"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
 }
 
 int hip_fail(hipError_t e, const char* what)

@@ -304,7 +304,8 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
          const unsigned char* __restrict__ silh, const unsigned char* __restrict__ act,
          const unsigned long long* __restrict__ covw,
          int n, int V, int F, int H, int W, int Cdyn, float* __restrict__ outA, float* __restrict__ outB,
-         int4* __restrict__ items, float* __restrict__ alphas, int32_t* counter, int cap)
+         int4* __restrict__ items, float* __restrict__ alphas, int32_t* counter, int cap,
+         unsigned char* __restrict__ px_code, float* __restrict__ px_alpha)
 {
     long long P = (long long)H * W;
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -351,11 +352,83 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
                 }
             }
         }
-        queue_push(has, make_int4(px, py, b, code), alpha, counter, cap, items, alphas);
+        if (px_code != nullptr) {
+            // fused step: the work item stays in place (2 slots per pixel), no queue: a global queue costs one RETURNING
+            // same-address atomic per wave with an item, and ~30k of those serialise to ~0.25 ms per step
+            if (live) {
+                px_code[gid * 2 + d] = (unsigned char)code;
+                if (has) px_alpha[gid * 2 + d] = alpha;
+            }
+        } else {
+            queue_push(has, make_int4(px, py, b, code), alpha, counter, cap, items, alphas);
+        }
     }
 }
 
-// backward over the queue: colour gradients (+-alpha * dy[target]) and the position gradient of the crossing point
+// backward of one work item: colour gradients (+-alpha * dy[target]) and the position gradient of the crossing point
+template <int CA, int CB>
+__device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, float alpha,
+         const float* __restrict__ colorA, const float* __restrict__ colorB, const float4* __restrict__ rast,
+         const float* __restrict__ pos, const int32_t* __restrict__ tri, const float* __restrict__ dyA,
+         const float* __restrict__ dyB, int V, int H, int W, int Cdyn,
+         float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos)
+{
+    const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
+    int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
+    long long pix0 = ((long long)b * H + py) * W + px;
+    long long pix1 = pix0 + (d ? W : 1);
+    long long tgt = (alpha > 0.f) ? pix0 : pix1;
+    float galpha = 0.f;
+    const int C = (CA > 0) ? CA : Cdyn;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        float g = dyA[tgt * C + c];
+        galpha += g * (colorA[pix1 * C + c] - colorA[pix0 * C + c]);
+        if (gcolorA != nullptr && g != 0.f) {
+            atomicAdd(gcolorA + pix1 * C + c, alpha * g);
+            atomicAdd(gcolorA + pix0 * C + c, -alpha * g);
+        }
+    }
+    if (CB > 0) {
+#pragma unroll
+        for (int c = 0; c < CB; c++) {
+            float g = dyB[tgt * CB + c];
+            galpha += g * (colorB[pix1 * CB + c] - colorB[pix0 * CB + c]);
+            if (gcolorB != nullptr && g != 0.f) {
+                atomicAdd(gcolorB + pix1 * CB + c, alpha * g);
+                atomicAdd(gcolorB + pix0 * CB + c, -alpha * g);
+            }
+        }
+    }
+    if ((code & AA_CLAMPED) || galpha == 0.f) return;
+    int t = (int)rast[(code & AA_TRI1) ? pix1 : pix0].w - 1;
+    int qx = px, qy = py;
+    if (code & AA_TRI1) { qx += 1 - d; qy += d; }
+    int e1 = di + 1; if (e1 >= 3) e1 -= 3;
+    int e2 = di + 2; if (e2 >= 3) e2 -= 3;
+    int va = tri[t * 3 + e1], vb = tri[t * 3 + e2];
+    const float4 pa = ldg4(pos + ((size_t)b * V + va) * 4), pb = ldg4(pos + ((size_t)b * V + vb) * 4);
+    float fx = (float)qx + 0.5f - xh, fy = (float)qy + 0.5f - yh;
+    float wa = 1.0f / pa.w, wb = 1.0f / pb.w;
+    float xa = pa.x * wa * xh - fx, ya = pa.y * wa * yh - fy;
+    float xb = pb.x * wb * xh - fx, yb = pb.y * wb * yh - fy;
+    if (d) { float tt; tt = xa; xa = ya; ya = tt; tt = xb; xb = yb; yb = tt; }
+    float gxc = -galpha;
+    float iden = 1.0f / (ya - yb);
+    float tpar = ya * iden;
+    float g_xa = gxc * (1.0f - tpar), g_xb = gxc * tpar;
+    float g_t = gxc * (xb - xa);
+    float g_ya = g_t * (-yb * iden * iden), g_yb = g_t * (ya * iden * iden);
+    if (d) { float tt; tt = g_xa; g_xa = g_ya; g_ya = tt; tt = g_xb; g_xb = g_yb; g_yb = tt; }
+    float* qa = gpos + ((size_t)b * V + va) * 4;
+    float* qb = gpos + ((size_t)b * V + vb) * 4;
+    atomicAdd(qa + 0, g_xa * xh * wa); atomicAdd(qa + 1, g_ya * yh * wa);
+    atomicAdd(qa + 3, -(g_xa * pa.x * xh + g_ya * pa.y * yh) * wa * wa);
+    atomicAdd(qb + 0, g_xb * xh * wb); atomicAdd(qb + 1, g_yb * yh * wb);
+    atomicAdd(qb + 3, -(g_xb * pb.x * xh + g_yb * pb.y * yh) * wb * wb);
+}
+
+// backward over the compact queue (generic dr.antialias op)
 template <int CA, int CB>
 __global__ void __launch_bounds__(kBlock)
 k_aa_bwd(const float* __restrict__ colorA, const float* __restrict__ colorB, const float4* __restrict__ rast,
@@ -365,64 +438,31 @@ k_aa_bwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
          float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos)
 {
     int cnt = min(counter[0], cap);
-    const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     for (int k = blockIdx.x * kBlock + threadIdx.x; k < cnt; k += gridDim.x * kBlock) {
         int4 it = items[k];
-        int px = it.x, py = it.y, b = it.z, code = it.w;
-        int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
-        float alpha = alphas[k];
-        long long pix0 = ((long long)b * H + py) * W + px;
-        long long pix1 = pix0 + (d ? W : 1);
-        long long tgt = (alpha > 0.f) ? pix0 : pix1;
-        float galpha = 0.f;
-        const int C = (CA > 0) ? CA : Cdyn;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            float g = dyA[tgt * C + c];
-            galpha += g * (colorA[pix1 * C + c] - colorA[pix0 * C + c]);
-            if (gcolorA != nullptr && g != 0.f) {
-                atomicAdd(gcolorA + pix1 * C + c, alpha * g);
-                atomicAdd(gcolorA + pix0 * C + c, -alpha * g);
-            }
-        }
-        if (CB > 0) {
-#pragma unroll
-            for (int c = 0; c < CB; c++) {
-                float g = dyB[tgt * CB + c];
-                galpha += g * (colorB[pix1 * CB + c] - colorB[pix0 * CB + c]);
-                if (gcolorB != nullptr && g != 0.f) {
-                    atomicAdd(gcolorB + pix1 * CB + c, alpha * g);
-                    atomicAdd(gcolorB + pix0 * CB + c, -alpha * g);
-                }
-            }
-        }
-        if ((code & AA_CLAMPED) || galpha == 0.f) continue;
-        int t = (int)rast[(code & AA_TRI1) ? pix1 : pix0].w - 1;
-        int qx = px, qy = py;
-        if (code & AA_TRI1) { qx += 1 - d; qy += d; }
-        int e1 = di + 1; if (e1 >= 3) e1 -= 3;
-        int e2 = di + 2; if (e2 >= 3) e2 -= 3;
-        int va = tri[t * 3 + e1], vb = tri[t * 3 + e2];
-        const float4 pa = ldg4(pos + ((size_t)b * V + va) * 4), pb = ldg4(pos + ((size_t)b * V + vb) * 4);
-        float fx = (float)qx + 0.5f - xh, fy = (float)qy + 0.5f - yh;
-        float wa = 1.0f / pa.w, wb = 1.0f / pb.w;
-        float xa = pa.x * wa * xh - fx, ya = pa.y * wa * yh - fy;
-        float xb = pb.x * wb * xh - fx, yb = pb.y * wb * yh - fy;
-        if (d) { float tt; tt = xa; xa = ya; ya = tt; tt = xb; xb = yb; yb = tt; }
-        float gxc = -galpha;
-        float iden = 1.0f / (ya - yb);
-        float tpar = ya * iden;
-        float g_xa = gxc * (1.0f - tpar), g_xb = gxc * tpar;
-        float g_t = gxc * (xb - xa);
-        float g_ya = g_t * (-yb * iden * iden), g_yb = g_t * (ya * iden * iden);
-        if (d) { float tt; tt = g_xa; g_xa = g_ya; g_ya = tt; tt = g_xb; g_xb = g_yb; g_yb = tt; }
-        float* qa = gpos + ((size_t)b * V + va) * 4;
-        float* qb = gpos + ((size_t)b * V + vb) * 4;
-        atomicAdd(qa + 0, g_xa * xh * wa); atomicAdd(qa + 1, g_ya * yh * wa);
-        atomicAdd(qa + 3, -(g_xa * pa.x * xh + g_ya * pa.y * yh) * wa * wa);
-        atomicAdd(qb + 0, g_xb * xh * wb); atomicAdd(qb + 1, g_yb * yh * wb);
-        atomicAdd(qb + 3, -(g_xb * pb.x * xh + g_yb * pb.y * yh) * wb * wb);
+        aa_bwd_item<CA, CB>(it.x, it.y, it.z, it.w, alphas[k], colorA, colorB, rast, pos, tri, dyA, dyB, V, H, W, Cdyn, gcolorA,
+                            gcolorB, gpos);
     }
+}
+
+// backward over in-place items (fused step): one lane per pixel of the active segments, two item slots per pixel
+__global__ void __launch_bounds__(kBlock)
+k_aa_bwd_px(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
+            const int32_t* __restrict__ tri, const float* __restrict__ dy, const unsigned char* __restrict__ px_code,
+            const float* __restrict__ px_alpha, const unsigned char* __restrict__ act, int n, int V, int H, int W,
+            float* __restrict__ gcolor, float* __restrict__ gpos)
+{
+    long long P = (long long)H * W;
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid - (gid & 63) >= (long long)n * P || __builtin_amdgcn_readfirstlane((int)act[gid >> 6]) == 0) return;
+    if (gid >= (long long)n * P) return;
+    uchar2 cd = reinterpret_cast<const uchar2*>(px_code)[gid];
+    if ((cd.x | cd.y) == 0) return;
+    int b = (int)(gid / P);
+    int rem = (int)(gid - (long long)b * P);
+    int py = rem / W, px = rem - py * W;
+    if (cd.x) aa_bwd_item<4, 0>(px, py, b, cd.x, px_alpha[gid * 2], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, gpos);
+    if (cd.y) aa_bwd_item<4, 0>(px, py, b, cd.y, px_alpha[gid * 2 + 1], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, gpos);
 }
 
 static unsigned table_size(int F)
@@ -445,26 +485,26 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
     return FMHR_OK;
 }
 
-// fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour)
+// fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour), in-place items
 int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                 const unsigned char* silh, const unsigned char* act, const unsigned long long* covw, int n, int V, int F, int H,
-                int W, float* out, int32_t* items, float* alphas, int32_t* counter, int cap, hipStream_t st)
+                int W, float* out, unsigned char* px_code, float* px_alpha, hipStream_t st)
 {
     long long nP = (long long)n * H * W;
-    k_aa_fwd<4, 0><<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, opp, silh, act, covw, n, V, F, H, W, 4, out,
-                                                       nullptr, (int4*)items, alphas, counter, cap);
+    k_aa_fwd<4, 0><<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, opp, silh, act, covw, n, V, F,
+                                                       H, W, 4, out, nullptr, nullptr, nullptr, nullptr, 0, px_code, px_alpha);
     FMHR_CHECK_LAUNCH("k_aa_fwd<4>");
     return FMHR_OK;
 }
 
 int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
-                const int32_t* items, const float* alphas, const int32_t* counter, int cap, int n, int V, int H, int W,
+                const unsigned char* px_code, const float* px_alpha, const unsigned char* act, int n, int V, int H, int W,
                 float* gcolor, float* gpos, hipStream_t st)
 {
-    int grid = min(max(cdiv(cap, kBlock), 1), 1024);
-    k_aa_bwd<4, 0><<<grid, kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, dy, nullptr, (const int4*)items, alphas,
-                                            counter, cap, n, V, H, W, 4, gcolor, nullptr, gpos);
-    FMHR_CHECK_LAUNCH("k_aa_bwd<4>");
+    long long nP = (long long)n * H * W;
+    k_aa_bwd_px<<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, dy, px_code, px_alpha, act, n, V, H, W,
+                                                    gcolor, gpos);
+    FMHR_CHECK_LAUNCH("k_aa_bwd_px");
     return FMHR_OK;
 }
 
@@ -569,9 +609,9 @@ extern "C" int fmhr_antialias_fwd(const float* color, const float* rast, const f
     int grid = cdiv(nP, kBlock);
     int4* it = (int4*)items;
     const float4* r4 = (const float4*)rast;
-    if (C == 1) k_aa_fwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
-    else if (C == 3) k_aa_fwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
-    else k_aa_fwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    if (C == 1) k_aa_fwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap, nullptr, nullptr);
+    else if (C == 3) k_aa_fwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap, nullptr, nullptr);
+    else k_aa_fwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap, nullptr, nullptr);
     FMHR_CHECK_LAUNCH("k_aa_fwd");
     return FMHR_OK;
 }

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "../../include/fmhr_ham.h"
 
 namespace fmhr {
@@ -27,10 +28,19 @@ struct ProfScope {                                   // brackets a launch group 
         }                                             \
     } while (0)
 
-#define FMHR_CHECK_LAUNCH(what)                                   \
-    do {                                                          \
-        hipError_t e__ = hipGetLastError();                       \
-        if (e__ != hipSuccess) return ::fmhr::hip_fail(e__, what); \
+bool debug_sync();                                   // abi.cpp: FMHR_DEBUG_SYNC=1 -> synchronise + log after every launch
+
+#define FMHR_CHECK_LAUNCH(what)                                    \
+    do {                                                           \
+        hipError_t e__ = hipGetLastError();                        \
+        if (e__ != hipSuccess) return ::fmhr::hip_fail(e__, what);  \
+        if (::fmhr::debug_sync()) {                                \
+            fprintf(stderr, "[fmhr] %s ...", what);                \
+            fflush(stderr);                                        \
+            e__ = hipDeviceSynchronize();                          \
+            fprintf(stderr, " %s\n", hipGetErrorString(e__));      \
+            if (e__ != hipSuccess) return ::fmhr::hip_fail(e__, what); \
+        }                                                          \
     } while (0)
 
 constexpr int kBlock = 256;

@@ -2,6 +2,7 @@
 // Replaces the loop body /root/reference/mesh_sfs_optim.py:253-308 for the views a rank owns; every launch goes to the
 // caller's stream, nothing synchronises, so the pair is hipGraph-capturable.
 #include "common.h"
+#include <string.h>
 
 namespace fmhr {
 // raster.hip / antialias.hip / mesh.hip / shade.hip
@@ -12,10 +13,10 @@ int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*
 int active_segments_impl(const unsigned long long*, const float*, long long, int, unsigned char*, hipStream_t);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*,
-                const unsigned char*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int,
+                const unsigned char*, const unsigned long long*, int, int, int, int, int, float*, unsigned char*, float*,
                 hipStream_t);
-int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const int32_t*, const float*,
-                const int32_t*, int, int, int, int, int, float*, float*, hipStream_t);
+int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const unsigned char*, const float*,
+                const unsigned char*, int, int, int, int, float*, float*, hipStream_t);
 int normals_fwd_impl(const float*, const int32_t*, int, int, int, float*, float*, hipStream_t);
 int normals_bwd_impl(const float*, const int32_t*, const float*, const float*, int, int, int, int, float*, float*, hipStream_t);
 int lap_fwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, float*, float*, hipStream_t);
@@ -28,10 +29,10 @@ int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, con
                    const unsigned char*, const unsigned long long*, float*, float*, float*, int*, hipStream_t);
 int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const unsigned char*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
-int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*, int, int,
-                 int, int, const unsigned long long*, float*, hipStream_t);
-int vertex_gather_impl(const float*, const float*, const int*, const int*, const int32_t*, const int32_t*, const int32_t*,
-                       const float*, int, int, int, int, int, float*, float*, hipStream_t);
+int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*, const float*,
+                 int, int, int, int, int, const unsigned long long*, float*, hipStream_t);
+int vertex_gather_impl(const float*, const int*, const int*, const int32_t*, const int32_t*, int, int, int, int, int, float*,
+                       float*, hipStream_t);
 int reduce_views_impl(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
 int finish_losses_impl(float*, const float*, const float*, const float*, int, float, float, float, hipStream_t);
 
@@ -63,17 +64,17 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.dirty = take(off, (nP + 63) / 64);
     L.covw = take(off, ((nP + 63) / 64) * 8);
     L.act = take(off, (nP + 63) / 64);
-    L.head = take(off, (size_t)d->n * d->F * 4);
+    L.head = take(off, (size_t)d->n * d->F * 4);   // per-(view, face) pixel-list heads
     L.next = take(off, nP * 4);
     L.rast = take(off, nP * 16);
     L.shaded = take(off, nP * 16);
     L.aa = take(off, nP * 16);
-    L.aa_items = take(off, (size_t)d->aa_cap * 16);
-    L.aa_alphas = take(off, (size_t)d->aa_cap * 4);
+    L.aa_items = take(off, nP * 2);           // in-place work-item codes: 2 slots (right / down pair) per pixel
+    L.aa_alphas = take(off, nP * 8);          // and their alphas
     L.aa_counter = take(off, 16);
     L.g_aa = take(off, nP * 16);
     L.g_shaded = take(off, nP * 16);
-    L.rec = take(off, nP * 32);
+    L.rec = take(off, nP * 80);
     L.gpos = take(off, nV * 16);
     L.part = take(off, nV * 32);
     L.partials = take(off, ((nP + 255) / 256) * 4 * 3);
@@ -118,6 +119,20 @@ extern "C" size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d)
     return make_layout(d).total;
 }
 
+extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const char* name)
+{
+    if (check_dims(d) || name == nullptr) return -1;
+    Layout L = make_layout(d);
+#define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
+    FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
+    FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(head); FMHR_OFF(next); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
+    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_aa); FMHR_OFF(g_shaded); FMHR_OFF(rec); FMHR_OFF(gpos); FMHR_OFF(part);
+    FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(total);
+#undef FMHR_OFF
+    set_error("ham_workspace_offset: unknown buffer '%s'", name);
+    return -1;
+}
+
 extern "C" int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, fmhr_ham_views* out)
 {
     TRY(check_dims(d));
@@ -139,6 +154,7 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_workspace_init: workspace too small or null");
     char* w = (char*)ws;
+    HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, (hipStream_t)stream), "init aa_counter");
     return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, d->W, (hipStream_t)stream);
 }
 
@@ -185,9 +201,8 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
                            (float*)(w + L.shaded), (float*)(w + L.aa), (float*)(w + L.partials), n_valid_local, st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
-    HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, st), "memset aa_counter");
-    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), act, covw, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.aa),
-                    (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas), (int32_t*)(w + L.aa_counter), d->aa_cap, st));
+    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), act, covw, d->n, d->V, d->F,
+                    d->H, d->W, (float*)(w + L.aa), (unsigned char*)(w + L.aa_items), (float*)(w + L.aa_alphas), st));
     return FMHR_OK;
 }
 
@@ -231,17 +246,17 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     {
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads into gpos
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
-        TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (float*)(w + L.g_aa), (int32_t*)(w + L.aa_items),
-                        (float*)(w + L.aa_alphas), (int32_t*)(w + L.aa_counter), d->aa_cap, d->n, d->V, d->H, d->W,
+        TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (float*)(w + L.g_aa), (const unsigned char*)(w + L.aa_items),
+                        (const float*)(w + L.aa_alphas), (const unsigned char*)(w + L.act), d->n, d->V, d->H, d->W,
                         (float*)(w + L.g_shaded), gpos, st));
     }
     {
         // shade + interpolate + rasterize backward, gather style: per-pixel records, then one lane per (view, vertex)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
-        TRY(pix_bwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_shaded), d->n, d->F, d->H, d->W,
-                         (const unsigned long long*)(w + L.covw), (float*)(w + L.rec), st));
-        TRY(vertex_gather_impl(rast, (float*)(w + L.rec), (int*)(w + L.head), (int*)(w + L.next), tri, vf_ptr, vf_idx, pos, d->n,
-                               d->V, d->F, d->H, d->W, (float*)(w + L.part), gpos, st));
+        TRY(pix_bwd_impl(rast, tri, pos, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_shaded), d->n, d->V, d->F,
+                         d->H, d->W, (const unsigned long long*)(w + L.covw), (float*)(w + L.rec), st));
+        TRY(vertex_gather_impl((float*)(w + L.rec), (int*)(w + L.head), (int*)(w + L.next), vf_ptr, vf_idx, d->n, d->V, d->F,
+                               d->H, d->W, (float*)(w + L.part), gpos, st));
     }
     {
         // sum over views: attribute grads and the clip-transform backward

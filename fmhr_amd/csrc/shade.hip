@@ -5,6 +5,7 @@
 // (view, vertex) walks the pixel lists of its incident faces (threaded by the rasterizer) and sums its own gradient — no
 // float atomics (the scatter form ran at the 0.08 TB/s "64 lanes -> 64 rows" atomic shape: 3.6 ms per step).
 #include "common.h"
+#include <stdlib.h>
 
 namespace fmhr {
 
@@ -59,16 +60,9 @@ __device__ __forceinline__ void shade_eval(const float4 r, const int32_t* __rest
 // ACTIVE when it holds a covered pixel, a 4-neighbour of one (antialias pairs and blend targets), or a non-zero valid_mask
 // (silhouette MSE).  Per-pixel kernels return after one scalar load on inactive segments (~2/3 of a 19 %-coverage frame);
 // every buffer is fully (re)written inside active segments each step and never read outside them.
-__device__ __forceinline__ bool cov_range_any(const unsigned long long* __restrict__ covw, long long start, long long nSeg)
+__device__ __forceinline__ unsigned long long covw_at(const unsigned long long* __restrict__ covw, long long w, long long nSeg)
 {
-    // any covered pixel with flattened index in [start, start+63]?
-    if (start + 63 < 0) return false;
-    long long w0 = start >> 6;              // arithmetic shift: floor
-    int sh = (int)(start & 63);
-    bool a = false;
-    if (w0 >= 0 && w0 < nSeg) a = (covw[w0] >> sh) != 0ull;
-    if (sh != 0 && w0 + 1 >= 0 && w0 + 1 < nSeg) a = a || ((covw[w0 + 1] << (64 - sh)) != 0ull);
-    return a;
+    return (w >= 0 && w < nSeg) ? covw[w] : 0ull;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -81,10 +75,17 @@ k_active_segments(const unsigned long long* __restrict__ covw, const float* __re
     unsigned long long bal = __ballot(vm != 0.f);
     if ((threadIdx.x & 63) != 0) return;
     long long seg = gid >> 6, nSeg = (N + 63) >> 6, s0 = seg << 6;
-    bool a = bal != 0ull || covw[seg] != 0ull;
-    if (!a) a = (seg + 1 < nSeg && (covw[seg + 1] & 1ull)) || (seg > 0 && (covw[seg - 1] >> 63));
-    if (!a) a = cov_range_any(covw, s0 + W, nSeg) || cov_range_any(covw, s0 - W, nSeg);
-    act[seg] = a ? 1 : 0;
+    // all seven candidate words are fetched up front (independent loads: one latency, not seven)
+    long long up = s0 - W, dn = s0 + W;
+    long long wu = up >> 6, wd = dn >> 6;               // arithmetic shift = floor, also for negative `up`
+    int su = (int)(up & 63), sd = (int)(dn & 63);
+    unsigned long long c0 = covw[seg], cl = covw_at(covw, seg - 1, nSeg), cr = covw_at(covw, seg + 1, nSeg);
+    unsigned long long u0 = covw_at(covw, wu, nSeg), u1 = covw_at(covw, wu + 1, nSeg);
+    unsigned long long d0 = covw_at(covw, wd, nSeg), d1 = covw_at(covw, wd + 1, nSeg);
+    unsigned long long any = bal | c0 | (cl >> 63) | (cr & 1ull);
+    any |= (u0 >> su) | (su ? (u1 << (64 - su)) : 0ull);   // covered pixels among [s0-W, s0-W+63]
+    any |= (d0 >> sd) | (sd ? (d1 << (64 - sd)) : 0ull);   // and among [s0+W, s0+W+63]
+    act[seg] = any != 0ull ? 1 : 0;
 }
 
 __device__ __forceinline__ bool seg_active(const unsigned char* __restrict__ act, long long gid)
@@ -199,114 +200,148 @@ __device__ __forceinline__ float block1024_sum(float v, float* sm16)
 __global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__ part, int nb, int* __restrict__ n_valid)
 {
     __shared__ float sm[16];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < nb; i += 1024) acc += part[i];
-    float r = block1024_sum(acc, sm);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;     // independent chains: the loads overlap
+    int i = threadIdx.x;
+    for (; i + 3072 < nb; i += 4096) { acc0 += part[i]; acc1 += part[i + 1024]; acc2 += part[i + 2048]; acc3 += part[i + 3072]; }
+    for (; i < nb; i += 1024) acc0 += part[i];
+    float r = block1024_sum((acc0 + acc1) + (acc2 + acc3), sm);
     if (threadIdx.x == 0) n_valid[0] = (int)(r + 0.5f);
 }
 
-// per covered pixel: backward of shade + normalise down to the interpolated attributes, and the barycentric gradients.
-// record = (g_normal_raw.xyz, g_albedo.x | g_albedo.yz, g_u, g_v), zeros for covered pixels outside the photometric mask.
+// per covered pixel with a non-zero image gradient: backward of shade + normalise + interpolate + rasterize for all three
+// corners at once, written as an 80-B record (5 x float4):
+//   R0 = (g_normal_raw.xyz, g_albedo.x)  R1 = (g_albedo.yz, u, v)  R2 = (q0x, q0y, q0w, q1x)  R3 = (q1y, q1w, q2x, q2y)  R4 = (q2w,-,-,-)
+// (q_k = clip-space (x, y, w) gradient of corner k).  The gather sums records, it recomputes nothing.
 __global__ void __launch_bounds__(kBlock)
-k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ normals,
-          const float* __restrict__ albedo, const float* __restrict__ sh, const float* __restrict__ mask,
-          const float4* __restrict__ g_shaded, int n, int F, long long P, const unsigned long long* __restrict__ covw,
-          float4* __restrict__ rec)
+k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ pos,
+          const float* __restrict__ normals, const float* __restrict__ albedo, const float* __restrict__ sh,
+          const float* __restrict__ mask, const float4* __restrict__ g_shaded, int n, int V, int F, int H, int W,
+          const unsigned long long* __restrict__ covw, float4* __restrict__ rec)
 {
+    const long long P = (long long)H * W;
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)n * P) return;
     if (!((covw[gid >> 6] >> (gid & 63)) & 1ull)) return;       // one 8-B word per wave: uncovered segments stop here
+    float4 g = g_shaded[gid];
+    float4* o = rec + gid * 5;
+    if (!(mask[gid] > 0.f) || (g.x == 0.f && g.y == 0.f && g.z == 0.f)) {
+        o[0] = make_float4(0.f, 0.f, 0.f, -1.f);       // covered but gradient-free: the gather skips it on this marker
+        return;
+    }
     float4 r = rast[gid];
     int t = (int)r.w - 1;
     if (t < 0 || t >= F) return;
-    float4 g = g_shaded[gid];
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-    if (mask[gid] > 0.f && (g.x != 0.f || g.y != 0.f || g.z != 0.f)) {
-        int b = (int)(gid / P);
-        float c[9];
+    int b = (int)(gid / P);
+    int rem = (int)(gid - (long long)b * P);
+    int py = rem / W, px = rem - py * W;
+    float c[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) c[k] = sh[(size_t)b * 9 + k];
-        PixShade s;
-        shade_eval(r, tri, normals, albedo, c, s);
-        float g_rad = g.x * s.ar + g.y * s.ag + g.z * s.ab;
-        float ga0 = g.x * s.rad, ga1 = g.y * s.rad, ga2 = g.z * s.rad;
-        float x = s.hx, y = s.hy, z = s.hz;
-        float dx = c[3] + c[4] * y - 2.0f * c[6] * x + c[7] * z + 2.0f * c[8] * x;
-        float dy = c[1] + c[4] * x + c[5] * z - 2.0f * c[6] * y - 2.0f * c[8] * y;
-        float dz = c[2] + c[5] * y + 4.0f * c[6] * z + c[7] * x;
-        float ghx = g_rad * dx, ghy = g_rad * dy, ghz = g_rad * dz;
-        float gnx, gny, gnz;
-        if (s.len > 1e-12f) {
-            float inv = 1.0f / s.len;
-            float dt = x * ghx + y * ghy + z * ghz;
-            gnx = (ghx - x * dt) * inv; gny = (ghy - y * dt) * inv; gnz = (ghz - z * dt) * inv;
-        } else {
-            gnx = ghx * 1e12f; gny = ghy * 1e12f; gnz = ghz * 1e12f;
-        }
-        // interpolate backward w.r.t. the barycentrics; the ones channel contributes exactly 0
-        float gu = gnx * (s.n0.x - s.n2.x) + gny * (s.n0.y - s.n2.y) + gnz * (s.n0.z - s.n2.z) +
-                   ga0 * (s.a0.x - s.a2.x) + ga1 * (s.a0.y - s.a2.y) + ga2 * (s.a0.z - s.a2.z);
-        float gv = gnx * (s.n1.x - s.n2.x) + gny * (s.n1.y - s.n2.y) + gnz * (s.n1.z - s.n2.z) +
-                   ga0 * (s.a1.x - s.a2.x) + ga1 * (s.a1.y - s.a2.y) + ga2 * (s.a1.z - s.a2.z);
-        r0 = make_float4(gnx, gny, gnz, ga0);
-        r1 = make_float4(ga1, ga2, gu, gv);
+    for (int k = 0; k < 9; k++) c[k] = sh[(size_t)b * 9 + k];
+    PixShade s;
+    shade_eval(r, tri, normals, albedo, c, s);
+    float g_rad = g.x * s.ar + g.y * s.ag + g.z * s.ab;
+    float ga0 = g.x * s.rad, ga1 = g.y * s.rad, ga2 = g.z * s.rad;
+    float x = s.hx, y = s.hy, z = s.hz;
+    float dx = c[3] + c[4] * y - 2.0f * c[6] * x + c[7] * z + 2.0f * c[8] * x;
+    float dy = c[1] + c[4] * x + c[5] * z - 2.0f * c[6] * y - 2.0f * c[8] * y;
+    float dz = c[2] + c[5] * y + 4.0f * c[6] * z + c[7] * x;
+    float ghx = g_rad * dx, ghy = g_rad * dy, ghz = g_rad * dz;
+    float gnx, gny, gnz;
+    if (s.len > 1e-12f) {
+        float inv = 1.0f / s.len;
+        float dt = x * ghx + y * ghy + z * ghz;
+        gnx = (ghx - x * dt) * inv; gny = (ghy - y * dt) * inv; gnz = (ghz - z * dt) * inv;
+    } else {
+        gnx = ghx * 1e12f; gny = ghy * 1e12f; gnz = ghz * 1e12f;
     }
-    rec[gid * 2] = r0;
-    rec[gid * 2 + 1] = r1;
+    // interpolate backward w.r.t. the barycentrics; the ones channel contributes exactly 0
+    float gu = gnx * (s.n0.x - s.n2.x) + gny * (s.n0.y - s.n2.y) + gnz * (s.n0.z - s.n2.z) +
+               ga0 * (s.a0.x - s.a2.x) + ga1 * (s.a0.y - s.a2.y) + ga2 * (s.a0.z - s.a2.z);
+    float gv = gnx * (s.n1.x - s.n2.x) + gny * (s.n1.y - s.n2.y) + gnz * (s.n1.z - s.n2.z) +
+               ga0 * (s.a1.x - s.a2.x) + ga1 * (s.a1.y - s.a2.y) + ga2 * (s.a1.z - s.a2.z);
+    // rasterize backward (Appendix B.1) for the three corners
+    const float* vp = pos + (size_t)b * V * 4;
+    const float4 p0 = ldg4(vp + (size_t)s.i0 * 4), p1 = ldg4(vp + (size_t)s.i1 * 4), p2 = ldg4(vp + (size_t)s.i2 * 4);
+    float fx = (2.0f / (float)W) * (float)px + (1.0f / (float)W - 1.0f);
+    float fy = (2.0f / (float)H) * (float)py + (1.0f / (float)H - 1.0f);
+    float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+    float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+    float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
+    float iw = 1.0f / (e0 + e1 + e2);
+    float bb0 = e0 * iw, bb1 = e1 * iw;
+    float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * bb0 + gb1 * bb1;
+    float q0x = gbb * (p2y - p1y) - gb1 * p2y;
+    float q1x = gbb * (p0y - p2y) + gb0 * p2y;
+    float q2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
+    float q0y = gbb * (p1x - p2x) + gb1 * p2x;
+    float q1y = gbb * (p2x - p0x) - gb0 * p2x;
+    float q2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
+    o[0] = make_float4(gnx, gny, gnz, ga0);
+    o[1] = make_float4(ga1, ga2, r.x, r.y);
+    o[2] = make_float4(q0x, q0y, -fx * q0x - fy * q0y, q1x);
+    o[3] = make_float4(q1y, -fx * q1x - fy * q1y, q2x, q2y);
+    o[4] = make_float4(-fx * q2x - fy * q2y, 0.f, 0.f, 0.f);
 }
 
-// one lane per (view, vertex): walk the incident face corners (CSR), each face's pixel list (head/next from the rasterizer),
-// and sum this vertex's share: attribute gradients b_k * record (-> part[b,v,0:6]) and the rasterize-backward position
-// gradient of corner k (-> gpos[b,v] +=, which already holds the antialias-backward atomics).
+// one lane per (view, vertex): for each incident face corner (CSR, entry = 3*face + corner) walk the face's pixel list (head /
+// next, threaded by the rasterizer's resolve pass) and sum this corner's share of every record:
+// attribute gradients b_k * (g_normal, g_albedo) -> part[b,v,0:6]; position gradient q_k -> gpos[b,v] += (it already holds the
+// antialias-backward atomics).  The corner codes and list heads of up to 8 corners are fetched with independent loads before
+// any list is walked, so a vertex costs ~3 memory latencies + one per extra pixel instead of ~4 per corner.
 __global__ void __launch_bounds__(kBlock)
-k_vertex_gather(const float4* __restrict__ rast, const float4* __restrict__ rec, const int* __restrict__ head,
-                const int* __restrict__ next, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
-                const int32_t* __restrict__ vf_idx, const float* __restrict__ pos, int n, int V, int F, int H, int W,
+k_vertex_gather(const float4* __restrict__ rec, const int* __restrict__ head, const int* __restrict__ next,
+                const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx, int n, int V, int F, long long P,
                 float4* __restrict__ part, float4* __restrict__ gpos)
 {
     int v = blockIdx.x * kBlock + threadIdx.x;
     int b = blockIdx.y;
     if (v >= V) return;
-    const long long P = (long long)H * W;
-    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
-    float an0 = 0.f, an1 = 0.f, an2 = 0.f, aa0 = 0.f, aa1 = 0.f, aa2 = 0.f, gx = 0.f, gy = 0.f, gw = 0.f;
+    size_t o = (size_t)b * V + v;
     const int* hb = head + (size_t)b * F;
-    const float* vp = pos + (size_t)b * V * 4;
-    for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
-        int code = vf_idx[e];
-        int f = code / 3, k = code - f * 3;
-        int pix = hb[f];
-        if (pix < 0) continue;
-        int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
-        const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+    float an0 = 0.f, an1 = 0.f, an2 = 0.f, aa0 = 0.f, aa1 = 0.f, aa2 = 0.f, gx = 0.f, gy = 0.f, gw = 0.f;
+    const int e0 = vf_ptr[v], e1 = vf_ptr[v + 1];
+    // walk one face's pixel list for corner `code % 3`
+    auto walk = [&](int code, int pix) {
+        const int k = code - (code / 3) * 3;
         while (pix >= 0) {
             long long gid = (long long)b * P + pix;
-            float4 r = rast[gid];
-            float4 r0 = rec[gid * 2], r1 = rec[gid * 2 + 1];
-            float bk = (k == 0) ? r.x : ((k == 1) ? r.y : 1.0f - r.x - r.y);
-            an0 += bk * r0.x; an1 += bk * r0.y; an2 += bk * r0.z;
-            aa0 += bk * r0.w; aa1 += bk * r1.x; aa2 += bk * r1.y;
-            float gu = r1.z, gv = r1.w;
-            if (gu != 0.f || gv != 0.f) {
-                int py = pix / W, px = pix - py * W;
-                float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
-                float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-                float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-                float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-                float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
-                float iw = 1.0f / (e0 + e1 + e2);
-                float bb0 = e0 * iw, bb1 = e1 * iw;
-                float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * bb0 + gb1 * bb1;
-                float qx, qy;
-                if (k == 0) { qx = gbb * (p2y - p1y) - gb1 * p2y; qy = gbb * (p1x - p2x) + gb1 * p2x; }
-                else if (k == 1) { qx = gbb * (p0y - p2y) + gb0 * p2y; qy = gbb * (p2x - p0x) - gb0 * p2x; }
-                else { qx = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y; qy = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x; }
-                gx += qx; gy += qy; gw += -fx * qx - fy * qy;
+            const float4* r = rec + gid * 5;
+            float4 r0 = r[0];
+            float4 r1 = r[1];
+            float4 r2 = r[2];
+            float4 r3 = r[3];
+            float4 r4 = r[4];
+            int pn = next[gid];
+            if (r0.w != -1.f || r0.x != 0.f) {                // (0,0,0,-1) marks a covered pixel without gradient
+                float bk = (k == 0) ? r1.z : ((k == 1) ? r1.w : 1.0f - r1.z - r1.w);
+                float qx = (k == 0) ? r2.x : ((k == 1) ? r2.w : r3.z);
+                float qy = (k == 0) ? r2.y : ((k == 1) ? r3.x : r3.w);
+                float qw = (k == 0) ? r2.z : ((k == 1) ? r3.y : r4.x);
+                an0 += bk * r0.x; an1 += bk * r0.y; an2 += bk * r0.z;
+                aa0 += bk * r0.w; aa1 += bk * r1.x; aa2 += bk * r1.y;
+                gx += qx; gy += qy; gw += qw;
             }
-            pix = next[gid];
+            pix = pn;
         }
+    };
+    // four corners per round: their codes, then their list heads, are fetched with independent loads before any list is
+    // walked, so a vertex without pixels costs ~3 memory latencies instead of 2 per corner
+    for (int base = e0; base < e1; base += 4) {
+        const int m = e1 - base;
+        int c0 = vf_idx[base];
+        int c1 = (m > 1) ? vf_idx[base + 1] : c0;
+        int c2 = (m > 2) ? vf_idx[base + 2] : c0;
+        int c3 = (m > 3) ? vf_idx[base + 3] : c0;
+        int h0 = hb[c0 / 3];
+        int h1 = hb[c1 / 3];
+        int h2 = hb[c2 / 3];
+        int h3 = hb[c3 / 3];
+        walk(c0, h0);
+        if (m > 1) walk(c1, h1);
+        if (m > 2) walk(c2, h2);
+        if (m > 3) walk(c3, h3);
     }
-    size_t o = (size_t)b * V + v;
     part[o * 2] = make_float4(an0, an1, an2, aa0);
     part[o * 2 + 1] = make_float4(aa1, aa2, 0.f, 0.f);
     if (gx != 0.f || gy != 0.f || gw != 0.f) {
@@ -352,10 +387,15 @@ k_finish_losses(float* losses, const float* n_valid, const float* __restrict__ p
                 float w_sfs, float w_mask, float mse_den)
 {
     __shared__ float sm[16];
-    float a1 = 0.f, a2 = 0.f;
-    for (int i = threadIdx.x; i < nb; i += 1024) { a1 += part_l1[i]; a2 += part_l2[i]; }
-    float s1 = block1024_sum(a1, sm);
-    float s2 = block1024_sum(a2, sm);
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f, d1 = 0.f, d2 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 3072 < nb; i += 4096) {
+        a1 += part_l1[i]; a2 += part_l2[i]; b1 += part_l1[i + 1024]; b2 += part_l2[i + 1024];
+        c1 += part_l1[i + 2048]; c2 += part_l2[i + 2048]; d1 += part_l1[i + 3072]; d2 += part_l2[i + 3072];
+    }
+    for (; i < nb; i += 1024) { a1 += part_l1[i]; a2 += part_l2[i]; }
+    float s1 = block1024_sum((a1 + b1) + (c1 + d1), sm);
+    float s2 = block1024_sum((a2 + b2) + (c2 + d2), sm);
     if (threadIdx.x == 0) {
         float den = 3.0f * n_valid[0];
         losses[FMHR_LOSS_SFS] = (den > 0.f) ? s1 * (w_sfs / den) : 0.f;
@@ -411,25 +451,24 @@ int loss_pix_impl(const float* shaded, const float* aa, const float* img, const 
     return FMHR_OK;
 }
 
-int pix_bwd_impl(const float* rast, const int32_t* tri, const float* normals, const float* albedo, const float* sh,
-                 const float* mask, const float* g_shaded, int n, int F, int H, int W, const unsigned long long* covw,
-                 float* rec, hipStream_t st)
+int pix_bwd_impl(const float* rast, const int32_t* tri, const float* pos, const float* normals, const float* albedo,
+                 const float* sh, const float* mask, const float* g_shaded, int n, int V, int F, int H, int W,
+                 const unsigned long long* covw, float* rec, hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0 || F == 0) return FMHR_OK;
-    k_pix_bwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, normals, albedo, sh, mask, (const float4*)g_shaded,
-                                                     n, F, P, covw, (float4*)rec);
+    k_pix_bwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, pos, normals, albedo, sh, mask,
+                                                     (const float4*)g_shaded, n, V, F, H, W, covw, (float4*)rec);
     FMHR_CHECK_LAUNCH("k_pix_bwd");
     return FMHR_OK;
 }
 
-int vertex_gather_impl(const float* rast, const float* rec, const int* head, const int* next, const int32_t* tri,
-                       const int32_t* vf_ptr, const int32_t* vf_idx, const float* pos, int n, int V, int F, int H, int W,
-                       float* part, float* gpos, hipStream_t st)
+int vertex_gather_impl(const float* rec, const int* head, const int* next, const int32_t* vf_ptr, const int32_t* vf_idx, int n,
+                       int V, int F, int H, int W, float* part, float* gpos, hipStream_t st)
 {
     if (n == 0 || V == 0) return FMHR_OK;
-    k_vertex_gather<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>((const float4*)rast, (const float4*)rec, head, next, tri, vf_ptr,
-                                                                vf_idx, pos, n, V, F, H, W, (float4*)part, (float4*)gpos);
+    k_vertex_gather<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>((const float4*)rec, head, next, vf_ptr, vf_idx, n, V, F,
+                                                                (long long)H * W, (float4*)part, (float4*)gpos);
     FMHR_CHECK_LAUNCH("k_vertex_gather");
     return FMHR_OK;
 }

@@ -130,6 +130,14 @@ class HamStage2:
                                aa_counter=view(hv.aa_counter, (2,), torch.int32))
         return self._views
 
+    def raw(self, name, dtype, count):
+        """debug: `count` elements of a named internal workspace buffer as a tensor view."""
+        off = self.lib.fmhr_ham_workspace_offset(ctypes.byref(self.dims), name.encode())
+        if off < 0:
+            raise RuntimeError(self.lib.fmhr_last_error().decode())
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return self.ws[off: off + nbytes].view(dtype)
+
     def loss_dict(self):
         vals = self.losses.tolist()
         return dict(zip(LOSS_NAMES, vals))

@@ -103,6 +103,11 @@ int fmhr_laplacian_uniform_fwd(const float* x, const int32_t* row_ptr, const int
 int fmhr_laplacian_uniform_bwd(const float* lx, const int32_t* row_ptr, const int32_t* col_idx, int V, int C,
                                float gscale, float* rowg, float* gx, void* stream);
 
+/* torch.optim.Adam(params, lr, betas, eps).step() for one parameter tensor (amsgrad=False, weight_decay=0) —
+ * mesh_sfs_optim.py:244,310.  `step` is the 1-based step count; exp_avg / exp_avg_sq are the caller-owned state (zeros at start). */
+int fmhr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                   float beta1, float beta2, float eps, int step, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ fused stage-2 step
  * One full forward+backward of mesh_sfs_optim.py:253-308 for the n views this rank owns.  See fmhr_ham_forward() / fmhr_ham_backward() below. */
 typedef struct fmhr_ham_dims {
@@ -163,6 +168,8 @@ typedef struct fmhr_ham_views {
     int32_t* aa_counter; /* [2] */
 } fmhr_ham_views;
 int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, fmhr_ham_views* out);
+/* byte offset of a named internal buffer inside the workspace (tests / debugging), -1 if unknown */
+long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const char* name);
 /* The step only writes rast / shaded / aa inside "active" 64-pixel segments (covered pixels, their 4-neighbours, non-zero
  * valid_mask); this fills the rest with zeros so the views above can be inspected as dense images. */
 int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);

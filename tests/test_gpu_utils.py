@@ -84,3 +84,22 @@ def test_large_mesh_vs_oracle(U, oracle):
         lb.backward()
         assert abs(float(la) - float(lb)) < 1e-5 * abs(float(la))
         assert rel_err(b.grad, a.grad) < TOL
+
+
+def test_adam_matches_torch():
+    """fmhr_amd.optim.Adam == torch.optim.Adam (per-group lr, default betas/eps) over 25 steps."""
+    from fmhr_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    a0, b0 = torch.randn(1000, 3, device=dev), torch.randn(1, 777, 3, device=dev)
+    pa, pb = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    qa, qb = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    ref = torch.optim.Adam([{'params': pa, 'lr': 1e-4}, {'params': pb, 'lr': 5e-3}])
+    mine = Adam([{'params': qa, 'lr': 1e-4}, {'params': qb, 'lr': 5e-3}])
+    for i in range(25):
+        ga, gb = torch.randn_like(a0) * (1 + i), torch.randn_like(b0) * 0.01
+        pa.grad, pb.grad, qa.grad, qb.grad = ga.clone(), gb.clone(), ga.clone(), gb.clone()
+        ref.step()
+        mine.step()
+    assert rel_err(qa, pa) < 1e-6 and rel_err(qb, pb) < 1e-6
+    assert rel_err(qa - a0, pa - a0) < 1e-4 and rel_err(qb - b0, pb - b0) < 1e-4
