@@ -55,7 +55,7 @@ SIGNATURES = {
     "fmhr_ham_workspace_bytes": (c_size_t, [ctypes.POINTER(HamDims)]),
     "fmhr_ham_workspace_offset": (ctypes.c_longlong, [ctypes.POINTER(HamDims), ctypes.c_char_p]),
     "fmhr_ham_workspace_views": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, ctypes.POINTER(HamViews)]),
-    "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),
     "fmhr_ham_workspace_init": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),
     "fmhr_ham_densify": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),
     "fmhr_ham_backward": (c_int, [ctypes.POINTER(HamDims), ctypes.POINTER(HamWeights), P, P, P, P, P, P, P, P, P, P, P, P, P,

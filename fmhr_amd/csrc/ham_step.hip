@@ -10,25 +10,28 @@ size_t raster_core_ws_bytes(int n, int F, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
                        void*, int*, int*, unsigned char*, unsigned long long*, hipStream_t);
-int active_segments_impl(const unsigned long long*, const float*, long long, int, unsigned char*, hipStream_t);
+int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
+int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, hipStream_t);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*,
                 const unsigned char*, const unsigned long long*, int, int, int, int, int, float*, unsigned char*, float*,
                 hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const unsigned char*, const float*,
                 const unsigned char*, int, int, int, int, float*, float*, hipStream_t);
-int normals_fwd_impl(const float*, const int32_t*, int, int, int, float*, float*, hipStream_t);
-int normals_bwd_impl(const float*, const int32_t*, const float*, const float*, int, int, int, int, float*, float*, hipStream_t);
+int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, hipStream_t);
+int normals_bwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, float*,
+                            float*, hipStream_t);
+int edge_hinge_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, int, float, float, float, float*,
+                           float*, hipStream_t);
 int lap_fwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, float*, float*, hipStream_t);
 int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, float*, float*, hipStream_t);
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, hipStream_t);
-int edge_hinge_impl(const float*, const int32_t*, int, int, float, float, float, float*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
 int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, int, int, int, int,
                    const unsigned char*, const unsigned long long*, float*, float*, float*, int*, hipStream_t);
 int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const unsigned char*,
-                  const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
+                  const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
 int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*, const float*,
                  int, int, int, int, int, const unsigned long long*, float*, hipStream_t);
 int vertex_gather_impl(const float*, const int*, const int*, const int32_t*, const int32_t*, int, int, int, int, int, float*,
@@ -38,7 +41,7 @@ int finish_losses_impl(float*, const float*, const float*, const float*, int, fl
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, pos, snap, silh, raster_ws, dirty, covw, act, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+    size_t vertices, nsum, normals, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
         g_shaded, rec, gpos, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
 };
 
@@ -64,6 +67,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.dirty = take(off, (nP + 63) / 64);
     L.covw = take(off, ((nP + 63) / 64) * 8);
     L.act = take(off, (nP + 63) / 64);
+    L.vmnz = take(off, (nP + 63) / 64);
     L.head = take(off, (size_t)d->n * d->F * 4);   // per-(view, face) pixel-list heads
     L.next = take(off, nP * 4);
     L.rast = take(off, nP * 16);
@@ -170,14 +174,15 @@ extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_byte
 
 extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
                                 const float* sh, const float* w2c, const float* proj, const float* mask,
-                                const float* valid_mask, const int32_t* tri, const int32_t* opp, int32_t* n_valid_local,
-                                void* ws, size_t ws_bytes, void* stream)
+                                const float* valid_mask, const int32_t* tri, const int32_t* opp, const int32_t* vf_ptr,
+                                const int32_t* vf_idx, int valid_mask_changed, int32_t* n_valid_local, void* ws,
+                                size_t ws_bytes, void* stream)
 {
     TRY(check_dims(d));
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_forward: workspace too small (%zu < %zu)", ws_bytes, L.total);
-    FMHR_CHECK_ARG(vertices_tmp && delta && albedo && sh && w2c && proj && mask && valid_mask && tri && opp && n_valid_local,
-                   "ham_forward: null pointer");
+    FMHR_CHECK_ARG(vertices_tmp && delta && albedo && sh && w2c && proj && mask && valid_mask && tri && opp && vf_ptr && vf_idx &&
+                       n_valid_local, "ham_forward: null pointer");
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
     float* vertices = (float*)(w + L.vertices);
@@ -189,14 +194,15 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     {
         ProfScope ps(FMHR_SLOT_GEOMETRY, st);
         TRY(add_delta_impl(vertices_tmp, delta, d->V * 3, vertices, st));
-        TRY(normals_fwd_impl(vertices, tri, 1, d->V, d->F, (float*)(w + L.nsum), (float*)(w + L.normals), st));
+        TRY(normals_fwd_gather_impl(vertices, tri, vf_ptr, vf_idx, d->V, (float*)(w + L.nsum), (float*)(w + L.normals), st));
         TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), st));
     }
     TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
                            rast, w + L.raster_ws, (int*)(w + L.head), (int*)(w + L.next), (unsigned char*)(w + L.dirty), covw, st));
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
-        TRY(active_segments_impl(covw, valid_mask, nP, d->W, act, st));
+        if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
+        TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, st));
         TRY(shade_fwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, d->n, d->F, d->H, d->W, act, covw,
                            (float*)(w + L.shaded), (float*)(w + L.aa), (float*)(w + L.partials), n_valid_local, st));
     }
@@ -233,15 +239,12 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
 
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
-        HIPTRY(hipMemsetAsync(losses, 0, 32, st), "memset losses");
         HIPTRY(hipMemsetAsync(gpos, 0, (size_t)d->n * V * 16, st), "memset gpos");
-        HIPTRY(hipMemsetAsync(gvert, 0, V * 12, st), "memset gvert");
-        HIPTRY(hipMemsetAsync(galbedo, 0, V * 12, st), "memset galbedo");
         // losses on the antialiased rgba + their per-pixel gradients (written twice: g_aa and the AA-backward target)
         TRY(loss_pix_impl((float*)(w + L.shaded), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
                           (const unsigned char*)(w + L.act), n_valid_global,
                           wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa), (float*)(w + L.g_shaded),
-                          (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, st));
+                          (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, losses, st));
     }
     {
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads into gpos
@@ -265,8 +268,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     }
     {
         ProfScope ps(FMHR_SLOT_NORMALS_BWD, st);
-        TRY(normals_bwd_impl(vertices, tri, (float*)(w + L.nsum), (float*)(w + L.gnormal), 3, 1, d->V, d->F, (float*)(w + L.gtmp),
-                             gvert, st));
+        TRY(normals_bwd_gather_impl(vertices, tri, vf_ptr, vf_idx, (float*)(w + L.nsum), (float*)(w + L.gnormal), d->V,
+                                    (float*)(w + L.gtmp), gvert, st));
     }
     ProfScope ps(FMHR_SLOT_REGULARISERS, st);
     // view-independent regularisers (mesh_sfs_optim.py:292-293, 296-304)
@@ -276,7 +279,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         TRY(lap_bwd_impl((float*)(w + L.lx_v), row_ptr, col_idx, d->V, 3, wt->lap * rg, (float*)(w + L.rowg), gvert, st));
         TRY(lap_bwd_impl((float*)(w + L.lx_a), row_ptr, col_idx, d->V, 3, wt->albedo * rg, (float*)(w + L.rowg), galbedo, st));
     }
-    TRY(edge_hinge_impl(vertices, tri, d->V, d->F, wt->edge_length_mean, wt->edge, wt->edge * rg, losses + FMHR_LOSS_EDGE, gvert, st));
+    TRY(edge_hinge_gather_impl(vertices, tri, vf_ptr, vf_idx, d->V, d->F, wt->edge_length_mean, wt->edge, wt->edge * rg,
+                               losses + FMHR_LOSS_EDGE, gvert, st));
     TRY(delta_term_impl(delta, d->V, wt->delta, wt->delta * rg, losses + FMHR_LOSS_DELTA, gvert, st));
     HIPTRY(hipMemcpyAsync(gdelta, gvert, V * 12, hipMemcpyDeviceToDevice, st), "copy gdelta");
     TRY(finish_losses_impl(losses, n_valid_global, (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, (int)nB,

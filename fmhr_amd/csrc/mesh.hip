@@ -356,7 +356,128 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
     p[i] = p[i] - step_size * (mi / denom);
 }
 
+// ------------------------------------------------------------------------------------------------ CSR-gather forms (fused step)
+// One lane per vertex walks its incident face corners (vf CSR, entry = 3*face + corner): no float atomics, deterministic
+// summation order.  The face-scatter forms above took ~40 us each on atomics into a 0.6 MB array; these take a few us.
+__global__ void __launch_bounds__(kBlock)
+k_normals_gather(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
+                 const int32_t* __restrict__ vf_idx, int V, float* __restrict__ nsum, float* __restrict__ normals)
+{
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= V) return;
+    float3 p = ld3(verts + (size_t)v * 3);
+    float3 acc = make_float3(0.f, 0.f, 0.f);
+    for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
+        int code = vf_idx[e];
+        int f = code / 3, k = code - f * 3;
+        int k1 = (k + 1 == 3) ? 0 : k + 1, k2 = (k1 + 1 == 3) ? 0 : k1 + 1;
+        float3 a = ld3(verts + (size_t)tri[f * 3 + k1] * 3), b = ld3(verts + (size_t)tri[f * 3 + k2] * 3);
+        float3 c = cross3(sub3(a, p), sub3(b, p));          // corner k: cross(v[k+1]-v[k], v[k+2]-v[k]) (models/utils.py:517-543)
+        acc.x += c.x; acc.y += c.y; acc.z += c.z;
+    }
+    nsum[(size_t)v * 3] = acc.x; nsum[(size_t)v * 3 + 1] = acc.y; nsum[(size_t)v * 3 + 2] = acc.z;
+    float len = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
+    float inv = 1.0f / fmaxf(len, 1e-6f);
+    normals[(size_t)v * 3] = acc.x * inv; normals[(size_t)v * 3 + 1] = acc.y * inv; normals[(size_t)v * 3 + 2] = acc.z * inv;
+}
+
+// gverts[v] += sum over incident faces of this vertex's share of d(sum_k g_s[i_k] . cross_k)/d verts
+__global__ void __launch_bounds__(kBlock)
+k_normals_bwd_gather(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
+                     const int32_t* __restrict__ vf_idx, const float* __restrict__ gs, int V, float* __restrict__ gverts)
+{
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= V) return;
+    float3 acc = make_float3(0.f, 0.f, 0.f);
+    for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
+        int code = vf_idx[e];
+        int f = code / 3, c = code - f * 3;
+        int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
+        float3 p[3] = {ld3(verts + (size_t)i[0] * 3), ld3(verts + (size_t)i[1] * 3), ld3(verts + (size_t)i[2] * 3)};
+        float3 g[3] = {ld3(gs + (size_t)i[0] * 3), ld3(gs + (size_t)i[1] * 3), ld3(gs + (size_t)i[2] * 3)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+            float3 e1 = sub3(p[k1], p[k]), e2 = sub3(p[k2], p[k]);
+            float3 ge1 = cross3(e2, g[k]), ge2 = cross3(g[k], e1);
+            if (c == k1) { acc.x += ge1.x; acc.y += ge1.y; acc.z += ge1.z; }
+            if (c == k2) { acc.x += ge2.x; acc.y += ge2.y; acc.z += ge2.z; }
+            if (c == k) { acc.x -= ge1.x + ge2.x; acc.y -= ge1.y + ge2.y; acc.z -= ge1.z + ge2.z; }
+        }
+    }
+    gverts[(size_t)v * 3] += acc.x; gverts[(size_t)v * 3 + 1] += acc.y; gverts[(size_t)v * 3 + 2] += acc.z;
+}
+
+// edge hinge by gather: the loss of a face's three directed edges is accounted by its corner 0; gradients by each corner
+__global__ void __launch_bounds__(kBlock)
+k_edge_hinge_gather(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
+                    const int32_t* __restrict__ vf_idx, int V, float mean_len, float wscale, float gscale,
+                    float* __restrict__ loss, float* __restrict__ gverts)
+{
+    __shared__ float sm[4];
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    float part = 0.f;
+    if (v < V) {
+        float3 acc = make_float3(0.f, 0.f, 0.f);
+        for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
+            int code = vf_idx[e];
+            int f = code / 3, c = code - f * 3;
+            float3 a = ld3(verts + (size_t)tri[f * 3] * 3), b = ld3(verts + (size_t)tri[f * 3 + 1] * 3),
+                   cc = ld3(verts + (size_t)tri[f * 3 + 2] * 3);
+            // edges (a-b), (c-b), (a-c) with signs per corner: corner0: +e0 +e2, corner1: -e0 -e1, corner2: +e1 -e2
+            float3 ed[3] = {sub3(a, b), sub3(cc, b), sub3(a, cc)};
+            const float sgn[3][3] = {{1.f, 0.f, 1.f}, {-1.f, -1.f, 0.f}, {0.f, 1.f, -1.f}};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float l2 = ed[k].x * ed[k].x + ed[k].y * ed[k].y + ed[k].z * ed[k].z;
+                float d = l2 - mean_len;
+                if (c == 0) part += fminf(fmaxf(d, 0.f), 1.f);
+                float sg = sgn[c][k];
+                if (d > 0.f && d < 1.f && sg != 0.f) {
+                    float w = 2.f * gscale * sg;
+                    acc.x += w * ed[k].x; acc.y += w * ed[k].y; acc.z += w * ed[k].z;
+                }
+            }
+        }
+        if (gscale != 0.f) {
+            gverts[(size_t)v * 3] += acc.x; gverts[(size_t)v * 3 + 1] += acc.y; gverts[(size_t)v * 3 + 2] += acc.z;
+        }
+    }
+    float s = block_sum(part, sm);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s * wscale);
+}
+
 // ---- internal launchers used by ham_step.hip
+int normals_fwd_gather_impl(const float* verts, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, int V,
+                            float* nsum, float* normals, hipStream_t st)
+{
+    if (V == 0) return FMHR_OK;
+    k_normals_gather<<<cdiv(V, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, nsum, normals);
+    FMHR_CHECK_LAUNCH("k_normals_gather");
+    return FMHR_OK;
+}
+
+int normals_bwd_gather_impl(const float* verts, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx,
+                            const float* nsum, const float* gn, int V, float* gtmp, float* gverts, hipStream_t st)
+{
+    if (V == 0) return FMHR_OK;
+    k_normals_bwd_vertex<<<cdiv(V, kBlock), kBlock, 0, st>>>(nsum, gn, 3, (long long)V, gtmp);
+    FMHR_CHECK_LAUNCH("k_normals_bwd_vertex");
+    k_normals_bwd_gather<<<cdiv(V, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, gtmp, V, gverts);
+    FMHR_CHECK_LAUNCH("k_normals_bwd_gather");
+    return FMHR_OK;
+}
+
+int edge_hinge_gather_impl(const float* verts, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, int V, int F,
+                           float mean_len, float weight, float gscale, float* loss, float* gverts, hipStream_t st)
+{
+    if (F == 0 || V == 0) return FMHR_OK;
+    k_edge_hinge_gather<<<cdiv(V, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, mean_len, weight / (3.0f * (float)F),
+                                                           gscale / (3.0f * (float)F), loss, gverts);
+    FMHR_CHECK_LAUNCH("k_edge_hinge_gather");
+    return FMHR_OK;
+}
+
 int normals_fwd_impl(const float* verts, const int32_t* tri, int nb, int V, int F, float* nsum, float* normals, hipStream_t st)
 {
     long long N = (long long)nb * V;

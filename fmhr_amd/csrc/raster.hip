@@ -157,13 +157,15 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
 __global__ void __launch_bounds__(kBlock)
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, int* __restrict__ head,
-                 int* __restrict__ next, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw)
+                 int* __restrict__ next, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw,
+                 int* __restrict__ large_cnt)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     long long P = (long long)H * W;
     const bool sparse = dirty != nullptr;
     long long seg = gid >> 6;
     if (sparse) {
+        if (gid == 0) *large_cnt = 0;                                // k_raster_large is done: rearm its queue counter
         if (gid - (gid & 63) >= (long long)n * P) return;            // whole wave out of range
         int d = __builtin_amdgcn_readfirstlane((int)dirty[seg]);
         if (!d) {
@@ -333,6 +335,8 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
     if (e != hipSuccess) return hip_fail(e, "init keys");
     e = hipMemsetAsync(dirty, 0, (nP + 63) / 64, st);
     if (e != hipSuccess) return hip_fail(e, "init dirty");
+    e = hipMemsetAsync((char*)ws + nP * 8, 0, 16, st);               // large-triangle queue counter
+    if (e != hipSuccess) return hip_fail(e, "init large_cnt");
     return FMHR_OK;
 }
 
@@ -354,8 +358,10 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
             e = hipMemsetAsync(keys, 0xFF, nP * 8, st);
             if (e != hipSuccess) return hip_fail(e, "memset keys");
         }
-        e = hipMemsetAsync(large_cnt, 0, 16, st);
-        if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
+        if (dirty == nullptr) {          // sparse mode: the resolve pass re-zeroes the counter for the next call
+            e = hipMemsetAsync(large_cnt, 0, 16, st);
+            if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
+        }
         if (head != nullptr && (size_t)n * F > 0) {
             e = hipMemsetAsync(head, 0xFF, (size_t)n * F * 4, st);
             if (e != hipSuccess) return hip_fail(e, "memset head");
@@ -374,7 +380,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
     k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, next, dirty,
-                                                                    covw);
+                                                                    covw, large_cnt);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }

@@ -65,24 +65,32 @@ __device__ __forceinline__ unsigned long long covw_at(const unsigned long long* 
     return (w >= 0 && w < nSeg) ? covw[w] : 0ull;
 }
 
+// per-segment "valid_mask has a non-zero" flags: recomputed only when the caller says the mask changed (it is constant over a
+// HAM run: the AA silhouette of the initial mesh, mesh_sfs_optim.py:158)
 __global__ void __launch_bounds__(kBlock)
-k_active_segments(const unsigned long long* __restrict__ covw, const float* __restrict__ valid_mask, long long N, int W,
-                  unsigned char* __restrict__ act)
+k_valid_mask_segments(const float* __restrict__ valid_mask, long long N, unsigned char* __restrict__ vmnz)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid - (gid & 63) >= N) return;
     float vm = (gid < N) ? valid_mask[gid] : 0.f;
     unsigned long long bal = __ballot(vm != 0.f);
-    if ((threadIdx.x & 63) != 0) return;
-    long long seg = gid >> 6, nSeg = (N + 63) >> 6, s0 = seg << 6;
-    // all seven candidate words are fetched up front (independent loads: one latency, not seven)
-    long long up = s0 - W, dn = s0 + W;
+    if ((threadIdx.x & 63) == 0) vmnz[gid >> 6] = bal != 0ull ? 1 : 0;
+}
+
+// one lane per segment: active = own coverage | 4-neighbour coverage | valid_mask flag (seven independent word loads)
+__global__ void __launch_bounds__(kBlock)
+k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
+                  unsigned char* __restrict__ act)
+{
+    long long seg = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (seg >= nSeg) return;
+    long long s0 = seg << 6, up = s0 - W, dn = s0 + W;
     long long wu = up >> 6, wd = dn >> 6;               // arithmetic shift = floor, also for negative `up`
     int su = (int)(up & 63), sd = (int)(dn & 63);
     unsigned long long c0 = covw[seg], cl = covw_at(covw, seg - 1, nSeg), cr = covw_at(covw, seg + 1, nSeg);
     unsigned long long u0 = covw_at(covw, wu, nSeg), u1 = covw_at(covw, wu + 1, nSeg);
     unsigned long long d0 = covw_at(covw, wd, nSeg), d1 = covw_at(covw, wd + 1, nSeg);
-    unsigned long long any = bal | c0 | (cl >> 63) | (cr & 1ull);
+    unsigned long long any = (unsigned long long)vmnz[seg] | c0 | (cl >> 63) | (cr & 1ull);
     any |= (u0 >> su) | (su ? (u1 << (64 - su)) : 0ull);   // covered pixels among [s0-W, s0-W+63]
     any |= (d0 >> sd) | (sd ? (d1 << (64 - sd)) : 0ull);   // and among [s0+W, s0+W+63]
     act[seg] = any != 0ull ? 1 : 0;
@@ -153,7 +161,7 @@ k_loss_pix(const float4* __restrict__ shaded, const float4* __restrict__ aa, con
            const float* __restrict__ mask, const float* __restrict__ valid_mask, long long N,
            const unsigned char* __restrict__ act, const float* __restrict__ n_valid_global, float w_sfs, float w_mask,
            float mse_den, float4* __restrict__ g_aa, float4* __restrict__ g_shaded, float* __restrict__ part_l1,
-           float* __restrict__ part_l2)
+           float* __restrict__ part_l2, float* __restrict__ losses)
 {
     __shared__ float sm[4];
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -181,6 +189,7 @@ k_loss_pix(const float4* __restrict__ shaded, const float4* __restrict__ aa, con
     float s1 = block_sum(l1, sm);
     float s2 = block_sum(l2, sm);
     if (threadIdx.x == 0) { part_l1[blockIdx.x] = s1; part_l2[blockIdx.x] = s2; }
+    if (blockIdx.x == 0 && threadIdx.x < 8) losses[threadIdx.x] = 0.f;      // the regulariser kernels accumulate into these later
 }
 
 // single-workgroup deterministic sums of per-block partials
@@ -377,9 +386,10 @@ k_reduce_views(const float4* __restrict__ part, const float4* __restrict__ gpos,
             az += r[0] * A[8] + r[1] * A[9] + r[2] * A[10] + r[3] * A[11];
         }
     }
-    gverts[(size_t)v * 3] += ax; gverts[(size_t)v * 3 + 1] += ay; gverts[(size_t)v * 3 + 2] += az;
+    // first writer of gverts / galbedo this step: plain stores (no memset needed), later kernels accumulate
+    gverts[(size_t)v * 3] = ax; gverts[(size_t)v * 3 + 1] = ay; gverts[(size_t)v * 3 + 2] = az;
     gnormal[(size_t)v * 3] = n0; gnormal[(size_t)v * 3 + 1] = n1; gnormal[(size_t)v * 3 + 2] = n2;
-    galbedo[(size_t)v * 3] += a0; galbedo[(size_t)v * 3 + 1] += a1; galbedo[(size_t)v * 3 + 2] += a2;
+    galbedo[(size_t)v * 3] = a0; galbedo[(size_t)v * 3 + 1] = a1; galbedo[(size_t)v * 3 + 2] = a2;
 }
 
 __global__ void __launch_bounds__(1024)
@@ -406,11 +416,20 @@ k_finish_losses(float* losses, const float* n_valid, const float* __restrict__ p
     }
 }
 
-int active_segments_impl(const unsigned long long* covw, const float* valid_mask, long long N, int W, unsigned char* act,
+int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char* vmnz, hipStream_t st)
+{
+    if (N == 0) return FMHR_OK;
+    k_valid_mask_segments<<<cdiv(N, kBlock), kBlock, 0, st>>>(valid_mask, N, vmnz);
+    FMHR_CHECK_LAUNCH("k_valid_mask_segments");
+    return FMHR_OK;
+}
+
+int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
                          hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_active_segments<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, valid_mask, N, W, act);
+    long long nSeg = (N + 63) >> 6;
+    k_active_segments<<<cdiv(nSeg, kBlock), kBlock, 0, st>>>(covw, vmnz, nSeg, W, act);
     FMHR_CHECK_LAUNCH("k_active_segments");
     return FMHR_OK;
 }
@@ -441,12 +460,12 @@ int shade_fwd_impl(const float* rast, const int32_t* tri, const float* normals, 
 
 int loss_pix_impl(const float* shaded, const float* aa, const float* img, const float* mask, const float* valid_mask,
                   long long N, const unsigned char* act, const float* n_valid_global, float w_sfs, float w_mask, float mse_den,
-                  float* g_aa, float* g_shaded, float* part_l1, float* part_l2, hipStream_t st)
+                  float* g_aa, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     k_loss_pix<<<cdiv(N, kBlock), kBlock, 0, st>>>((const float4*)shaded, (const float4*)aa, img, mask, valid_mask, N, act,
                                                   n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_aa, (float4*)g_shaded, part_l1,
-                                                  part_l2);
+                                                  part_l2, losses);
     FMHR_CHECK_LAUNCH("k_loss_pix");
     return FMHR_OK;
 }

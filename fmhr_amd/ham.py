@@ -67,12 +67,16 @@ class HamStage2:
         self.gdelta = torch.zeros(self.V, 3, dtype=torch.float32, device=self.dev)
         self.galbedo = torch.zeros(self.V, 3, dtype=torch.float32, device=self.dev)
         self._views = None
+        self._vm_key, self._vm_ref = None, None
 
     # -- the two phases -------------------------------------------------------------------------------------------------
     def forward(self, vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask):
+        key = (valid_mask.data_ptr(), valid_mask._version)
+        changed = 1 if key != self._vm_key else 0            # the tensor is kept alive below, so its address is not reused
+        self._vm_key, self._vm_ref = key, valid_mask
         call("fmhr_ham_forward", ctypes.byref(self.dims), ptr(vertices_tmp), ptr(delta), ptr(albedo), ptr(sh), ptr(w2c),
-             ptr(proj), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp), ptr(self.n_valid_local), ptr(self.ws),
-             self.ws_bytes, stream_ptr(self.dev))
+             ptr(proj), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp), ptr(self.vf_ptr), ptr(self.vf_idx),
+             changed, ptr(self.n_valid_local), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
 
     def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True):
         w = self.weights

@@ -144,14 +144,16 @@ size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
  *   vertices_tmp, delta, albedo [V,3]; sh [n,9]; w2c, proj [n,4,4] (row-vector convention, get_data.py:96-97);
  *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx [nnz]; vf_ptr [V+1]; vf_idx [3F].
  *   n*H*W must be a multiple of 4.
+ *   valid_mask_changed: pass 1 on the first call on a workspace and whenever valid_mask's CONTENTS may differ from the previous
+ *   call (its per-segment non-zero flags are cached in the workspace; the mask is constant over a HAM run, :158).
  *   n_valid_local: device int32[1] written by phase A.  n_valid_global: device float[1] read by phase B.
  *   losses: device float[8]; gdelta, galbedo [V,3] overwritten (view-dependent part only when reg_grads=0). */
 /* Must be called once on a fresh workspace (and after any aborted step): sets up the self-cleaning sparse rasterizer state. */
 int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);
 int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
                      const float* sh, const float* w2c, const float* proj, const float* mask, const float* valid_mask,
-                     const int32_t* tri, const int32_t* opp, int32_t* n_valid_local,
-                     void* ws, size_t ws_bytes, void* stream);
+                     const int32_t* tri, const int32_t* opp, const int32_t* vf_ptr, const int32_t* vf_idx,
+                     int valid_mask_changed, int32_t* n_valid_local, void* ws, size_t ws_bytes, void* stream);
 int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const float* vertices_tmp, const float* delta,
                       const float* albedo, const float* sh, const float* w2c, const float* proj, const float* img,
                       const float* mask, const float* valid_mask, const int32_t* tri, const int32_t* opp,
