@@ -159,6 +159,22 @@ __global__ void k_vf_fill(const int32_t* __restrict__ tri, int F, int V, const i
     if ((unsigned)v < (unsigned)V) idx[row_ptr[v] + atomicAdd(&cursor[v], 1)] = code;
 }
 
+// split every vertex's CSR row into chunks of <= 4 corners: the gather assigns one lane per (chunk, view group), so a
+// high-valence vertex (valence 37 at the pole of the benchmark mesh; scans can have far more) cannot serialise the kernel
+__global__ void k_chunk_count(const int* __restrict__ vf_ptr, int V, int* cnt)
+{
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v < V) cnt[v] = (vf_ptr[v + 1] - vf_ptr[v] + 3) / 4;
+}
+
+__global__ void k_chunk_fill(const int* __restrict__ vf_ptr, const int* __restrict__ vc_ptr, int V, int2* __restrict__ ck)
+{
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= V) return;
+    int c0 = vc_ptr[v], c1 = vc_ptr[v + 1], e = vf_ptr[v];
+    for (int c = c0; c < c1; c++, e += 4) ck[c] = make_int2(v, e);
+}
+
 // ------------------------------------------------------------------------------------------------ antialias analysis
 constexpr int AA_DOWN = 4, AA_TRI1 = 8, AA_FOUND = 16, AA_CLAMPED = 32;
 
@@ -371,7 +387,8 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          const float* __restrict__ colorA, const float* __restrict__ colorB, const float4* __restrict__ rast,
          const float* __restrict__ pos, const int32_t* __restrict__ tri, const float* __restrict__ dyA,
          const float* __restrict__ dyB, int V, int H, int W, int Cdyn,
-         float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos)
+         float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos,
+         const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr)
 {
     const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
@@ -420,12 +437,25 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
     float g_t = gxc * (xb - xa);
     float g_ya = g_t * (-yb * iden * iden), g_yb = g_t * (ya * iden * iden);
     if (d) { float tt; tt = g_xa; g_xa = g_ya; g_ya = tt; tt = g_xb; g_xb = g_yb; g_yb = tt; }
+    const float ax = g_xa * xh * wa, ay = g_ya * yh * wa, aw = -(g_xa * pa.x * xh + g_ya * pa.y * yh) * wa * wa;
+    const float bx = g_xb * xh * wb, by = g_yb * yh * wb, bw = -(g_xb * pb.x * xh + g_yb * pb.y * yh) * wb * wb;
+    if (cmat != nullptr) {
+        // fused step: apply the clip-transform backward here and accumulate straight into the view-independent [V,3] buffer
+        const float4 c0 = cmat[(size_t)b * 3], c1 = cmat[(size_t)b * 3 + 1], c2 = cmat[(size_t)b * 3 + 2];
+        float* qa = gvert + (size_t)va * 3;
+        float* qb = gvert + (size_t)vb * 3;
+        atomicAdd(qa + 0, ax * c0.x + ay * c0.y + aw * c0.z);
+        atomicAdd(qa + 1, ax * c1.x + ay * c1.y + aw * c1.z);
+        atomicAdd(qa + 2, ax * c2.x + ay * c2.y + aw * c2.z);
+        atomicAdd(qb + 0, bx * c0.x + by * c0.y + bw * c0.z);
+        atomicAdd(qb + 1, bx * c1.x + by * c1.y + bw * c1.z);
+        atomicAdd(qb + 2, bx * c2.x + by * c2.y + bw * c2.z);
+        return;
+    }
     float* qa = gpos + ((size_t)b * V + va) * 4;
     float* qb = gpos + ((size_t)b * V + vb) * 4;
-    atomicAdd(qa + 0, g_xa * xh * wa); atomicAdd(qa + 1, g_ya * yh * wa);
-    atomicAdd(qa + 3, -(g_xa * pa.x * xh + g_ya * pa.y * yh) * wa * wa);
-    atomicAdd(qb + 0, g_xb * xh * wb); atomicAdd(qb + 1, g_yb * yh * wb);
-    atomicAdd(qb + 3, -(g_xb * pb.x * xh + g_yb * pb.y * yh) * wb * wb);
+    atomicAdd(qa + 0, ax); atomicAdd(qa + 1, ay); atomicAdd(qa + 3, aw);
+    atomicAdd(qb + 0, bx); atomicAdd(qb + 1, by); atomicAdd(qb + 3, bw);
 }
 
 // backward over the compact queue (generic dr.antialias op)
@@ -450,7 +480,7 @@ __global__ void __launch_bounds__(kBlock)
 k_aa_bwd_px(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
             const int32_t* __restrict__ tri, const float* __restrict__ dy, const unsigned char* __restrict__ px_code,
             const float* __restrict__ px_alpha, const unsigned char* __restrict__ act, int n, int V, int H, int W,
-            float* __restrict__ gcolor, float* __restrict__ gpos)
+            float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert)
 {
     long long P = (long long)H * W;
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -461,8 +491,8 @@ k_aa_bwd_px(const float* __restrict__ color, const float4* __restrict__ rast, co
     int b = (int)(gid / P);
     int rem = (int)(gid - (long long)b * P);
     int py = rem / W, px = rem - py * W;
-    if (cd.x) aa_bwd_item<4, 0>(px, py, b, cd.x, px_alpha[gid * 2], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, gpos);
-    if (cd.y) aa_bwd_item<4, 0>(px, py, b, cd.y, px_alpha[gid * 2 + 1], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, gpos);
+    if (cd.x) aa_bwd_item<4, 0>(px, py, b, cd.x, px_alpha[gid * 2], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
+    if (cd.y) aa_bwd_item<4, 0>(px, py, b, cd.y, px_alpha[gid * 2 + 1], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
 }
 
 static unsigned table_size(int F)
@@ -499,11 +529,11 @@ int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const i
 
 int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
                 const unsigned char* px_code, const float* px_alpha, const unsigned char* act, int n, int V, int H, int W,
-                float* gcolor, float* gpos, hipStream_t st)
+                float* gcolor, const float* cmat, float* gvert, hipStream_t st)
 {
     long long nP = (long long)n * H * W;
     k_aa_bwd_px<<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, dy, px_code, px_alpha, act, n, V, H, W,
-                                                    gcolor, gpos);
+                                                    gcolor, (const float4*)cmat, gvert);
     FMHR_CHECK_LAUNCH("k_aa_bwd_px");
     return FMHR_OK;
 }
@@ -589,6 +619,26 @@ extern "C" int fmhr_vertex_faces_build(const int32_t* tri, int F, int V, int32_t
     if (V > 0) {
         k_adj_sort_rows<<<cdiv(V, kBlock), kBlock, 0, st>>>(V, vf_ptr, vf_idx);
         FMHR_CHECK_LAUNCH("k_adj_sort_rows");
+    }
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_vertex_chunks_build(const int32_t* vf_ptr, int V, int32_t* vc_ptr, int32_t* ck, void* ws, size_t ws_bytes,
+                                        void* stream)
+{
+    FMHR_CHECK_ARG(V >= 0, "vertex_chunks_build: bad dims");
+    FMHR_CHECK_ARG(vf_ptr && vc_ptr && ck && ws && ws_bytes >= (size_t)(V + 1) * 4, "vertex_chunks_build: null pointer / small workspace");
+    hipStream_t st = (hipStream_t)stream;
+    int* cnt = (int*)ws;
+    if (V > 0) {
+        k_chunk_count<<<cdiv(V, kBlock), kBlock, 0, st>>>(vf_ptr, V, cnt);
+        FMHR_CHECK_LAUNCH("k_chunk_count");
+    }
+    k_scan_exclusive<<<1, 1024, 0, st>>>(cnt, V, vc_ptr);
+    FMHR_CHECK_LAUNCH("k_scan_exclusive");
+    if (V > 0) {
+        k_chunk_fill<<<cdiv(V, kBlock), kBlock, 0, st>>>(vf_ptr, vc_ptr, V, (int2*)ck);
+        FMHR_CHECK_LAUNCH("k_chunk_fill");
     }
     return FMHR_OK;
 }

@@ -9,7 +9,7 @@ namespace fmhr {
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
-                       void*, int*, int*, unsigned char*, unsigned long long*, hipStream_t);
+                       void*, int*, int*, int, unsigned char*, unsigned long long*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, hipStream_t);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
@@ -17,7 +17,7 @@ int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const 
                 const unsigned char*, const unsigned long long*, int, int, int, int, int, float*, unsigned char*, float*,
                 hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const unsigned char*, const float*,
-                const unsigned char*, int, int, int, int, float*, float*, hipStream_t);
+                const unsigned char*, int, int, int, int, float*, const float*, float*, hipStream_t);
 int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, hipStream_t);
 int normals_bwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, float*,
                             float*, hipStream_t);
@@ -26,23 +26,22 @@ int edge_hinge_gather_impl(const float*, const int32_t*, const int32_t*, const i
 int lap_fwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, float*, float*, hipStream_t);
 int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, float*, float*, hipStream_t);
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
-int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, hipStream_t);
+int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
 int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, int, int, int, int,
                    const unsigned char*, const unsigned long long*, float*, float*, float*, int*, hipStream_t);
 int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const unsigned char*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
 int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*, const float*,
-                 int, int, int, int, int, const unsigned long long*, float*, hipStream_t);
-int vertex_gather_impl(const float*, const int*, const int*, const int32_t*, const int32_t*, int, int, int, int, int, float*,
-                       float*, hipStream_t);
-int reduce_views_impl(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
+                 int, int, int, int, int, const unsigned long long*, const int*, float*, hipStream_t);
+int vertex_gather_impl(const float*, const int*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const float*,
+                       const float*, int, int, int, int, int, int, float*, float*, float*, float*, hipStream_t);
 int finish_losses_impl(float*, const float*, const float*, const float*, int, float, float, float, hipStream_t);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
-        g_shaded, rec, gpos, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
+        g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -57,6 +56,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     Layout L;
     size_t off = 0;
     size_t V = d->V, nP = (size_t)d->n * d->H * d->W, nV = (size_t)d->n * d->V;
+    const int npad = (d->n + 7) / 8 * 8;
     L.vertices = take(off, V * 12);
     L.nsum = take(off, V * 12);
     L.normals = take(off, V * 12);
@@ -68,7 +68,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.covw = take(off, ((nP + 63) / 64) * 8);
     L.act = take(off, (nP + 63) / 64);
     L.vmnz = take(off, (nP + 63) / 64);
-    L.head = take(off, (size_t)d->n * d->F * 4);   // per-(view, face) pixel-list heads
+    L.head = take(off, (size_t)npad * d->F * 4);   // pixel-list heads, face-major, views innermost (padded to 8)
     L.next = take(off, nP * 4);
     L.rast = take(off, nP * 16);
     L.shaded = take(off, nP * 16);
@@ -78,9 +78,10 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.aa_counter = take(off, 16);
     L.g_aa = take(off, nP * 16);
     L.g_shaded = take(off, nP * 16);
-    L.rec = take(off, nP * 80);
-    L.gpos = take(off, nV * 16);
-    L.part = take(off, nV * 32);
+    L.rec = take(off, nP * 64);
+    L.cmat = take(off, (size_t)d->n * 48);
+    L.gvert_aa = take(off, V * 12);
+    L.part = take(off, (size_t)(npad / 8) * (size_t)(d->n_chunks > 0 ? d->n_chunks : 1) * 48);
     L.partials = take(off, ((nP + 255) / 256) * 4 * 3);
     L.gnormal = take(off, V * 12);
     L.gvert = take(off, V * 12);
@@ -130,7 +131,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(head); FMHR_OFF(next); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
-    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_aa); FMHR_OFF(g_shaded); FMHR_OFF(rec); FMHR_OFF(gpos); FMHR_OFF(part);
+    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_aa); FMHR_OFF(g_shaded); FMHR_OFF(rec); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(total);
 #undef FMHR_OFF
     set_error("ham_workspace_offset: unknown buffer '%s'", name);
@@ -195,10 +196,10 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         ProfScope ps(FMHR_SLOT_GEOMETRY, st);
         TRY(add_delta_impl(vertices_tmp, delta, d->V * 3, vertices, st));
         TRY(normals_fwd_gather_impl(vertices, tri, vf_ptr, vf_idx, d->V, (float*)(w + L.nsum), (float*)(w + L.normals), st));
-        TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), st));
+        TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), st));
     }
     TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
-                           rast, w + L.raster_ws, (int*)(w + L.head), (int*)(w + L.next), (unsigned char*)(w + L.dirty), covw, st));
+                           rast, w + L.raster_ws, (int*)(w + L.head), (int*)(w + L.next), (d->n + 7) / 8 * 8, (unsigned char*)(w + L.dirty), covw, st));
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
@@ -216,7 +217,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                                  const float* delta, const float* albedo, const float* sh, const float* w2c, const float* proj,
                                  const float* img, const float* mask, const float* valid_mask, const int32_t* tri,
                                  const int32_t* opp, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* vf_ptr,
-                                 const int32_t* vf_idx, const float* n_valid_global, float* losses, float* gdelta,
+                                 const int32_t* vf_idx, const int32_t* vc_ptr, const int32_t* ck,
+                                 const float* n_valid_global, float* losses, float* gdelta,
                                  float* galbedo, void* ws, size_t ws_bytes, void* stream)
 {
     (void)vertices_tmp; (void)opp;
@@ -224,14 +226,16 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_backward: workspace too small (%zu < %zu)", ws_bytes, L.total);
     FMHR_CHECK_ARG(wt && delta && albedo && sh && w2c && proj && img && mask && valid_mask && tri && row_ptr && col_idx &&
-                       vf_ptr && vf_idx && n_valid_global && losses && gdelta && galbedo, "ham_backward: null pointer");
+                       vf_ptr && vf_idx && vc_ptr && ck && n_valid_global && losses && gdelta && galbedo, "ham_backward: null pointer");
+    FMHR_CHECK_ARG(d->n_chunks >= 1, "ham_backward: dims.n_chunks must be vc_ptr[V] from fmhr_vertex_chunks_build");
     FMHR_CHECK_ARG(wt->mse_denominator > 0.f, "ham_backward: mse_denominator must be > 0");
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
     float* vertices = (float*)(w + L.vertices);
     float* pos = (float*)(w + L.pos);
     float* rast = (float*)(w + L.rast);
-    float* gpos = (float*)(w + L.gpos);
+    float* gvert_aa = (float*)(w + L.gvert_aa);
+    const int npad = (d->n + 7) / 8 * 8;
     float* gvert = (float*)(w + L.gvert);
     size_t nP = (size_t)d->n * d->H * d->W, V = d->V;
     const float rg = wt->reg_grad_scale;
@@ -239,7 +243,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
 
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
-        HIPTRY(hipMemsetAsync(gpos, 0, (size_t)d->n * V * 16, st), "memset gpos");
+        HIPTRY(hipMemsetAsync(gvert_aa, 0, V * 12, st), "memset gvert_aa");
         // losses on the antialiased rgba + their per-pixel gradients (written twice: g_aa and the AA-backward target)
         TRY(loss_pix_impl((float*)(w + L.shaded), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
                           (const unsigned char*)(w + L.act), n_valid_global,
@@ -247,24 +251,20 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                           (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, losses, st));
     }
     {
-        // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads into gpos
+        // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads (clip-transformed) into gvert_aa
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
         TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (float*)(w + L.g_aa), (const unsigned char*)(w + L.aa_items),
                         (const float*)(w + L.aa_alphas), (const unsigned char*)(w + L.act), d->n, d->V, d->H, d->W,
-                        (float*)(w + L.g_shaded), gpos, st));
+                        (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, st));
     }
     {
         // shade + interpolate + rasterize backward, gather style: per-pixel records, then one lane per (view, vertex)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
         TRY(pix_bwd_impl(rast, tri, pos, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_shaded), d->n, d->V, d->F,
-                         d->H, d->W, (const unsigned long long*)(w + L.covw), (float*)(w + L.rec), st));
-        TRY(vertex_gather_impl((float*)(w + L.rec), (int*)(w + L.head), (int*)(w + L.next), vf_ptr, vf_idx, d->n, d->V, d->F,
-                               d->H, d->W, (float*)(w + L.part), gpos, st));
-    }
-    {
-        // sum over views: attribute grads and the clip-transform backward
-        ProfScope ps(FMHR_SLOT_TRANSFORM_BWD, st);
-        TRY(reduce_views_impl((float*)(w + L.part), gpos, w2c, proj, d->n, d->V, gvert, (float*)(w + L.gnormal), galbedo, st));
+                         d->H, d->W, (const unsigned long long*)(w + L.covw), (const int*)(w + L.next), (float*)(w + L.rec), st));
+        TRY(vertex_gather_impl((float*)(w + L.rec), (int*)(w + L.head), vf_ptr, vf_idx, vc_ptr, ck, (const float*)(w + L.cmat),
+                               gvert_aa, d->n, npad, d->V, d->n_chunks, d->H, d->W, (float*)(w + L.part), gvert,
+                               (float*)(w + L.gnormal), galbedo, st));
     }
     {
         ProfScope ps(FMHR_SLOT_NORMALS_BWD, st);

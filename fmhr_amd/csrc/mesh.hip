@@ -243,13 +243,20 @@ k_add_delta(const float* __restrict__ a, const float* __restrict__ b, int N, flo
 // pos[b,v,:] = ([v,1] @ w2c[b]) @ proj[b]  — row-vector convention, two steps like the reference's two einsums
 __global__ void __launch_bounds__(kBlock)
 k_transform_fwd(const float* __restrict__ verts, const float* __restrict__ w2c, const float* __restrict__ proj, int V,
-                float4* __restrict__ pos, int H, int W, int2* __restrict__ snap)
+                float4* __restrict__ pos, int H, int W, int2* __restrict__ snap, float4* __restrict__ cmat)
 {
     int v = blockIdx.x * kBlock + threadIdx.x;
     int b = blockIdx.y;
     if (v >= V) return;
     const float* A = w2c + (size_t)b * 16;
     const float* B = proj + (size_t)b * 16;
+    if (cmat != nullptr && v < 3) {
+        // d pos_l / d vertex_v = (w2c @ proj)[v][l]: row v of the combined matrix, columns (x, y, w) — what the backward needs
+        float c[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) c[l] = A[v * 4] * B[l] + A[v * 4 + 1] * B[4 + l] + A[v * 4 + 2] * B[8 + l] + A[v * 4 + 3] * B[12 + l];
+        cmat[(size_t)b * 3 + v] = make_float4(c[0], c[1], c[3], 0.f);
+    }
     float x = verts[(size_t)v * 3], y = verts[(size_t)v * 3 + 1], z = verts[(size_t)v * 3 + 2];
     float r[4], o[4];
 #pragma unroll
@@ -548,10 +555,10 @@ int add_delta_impl(const float* a, const float* b, int N, float* o, hipStream_t 
 }
 
 int transform_fwd_impl(const float* verts, const float* w2c, const float* proj, int n, int V, float* pos, int H, int W,
-                       int2* snap, hipStream_t st)
+                       int2* snap, float* cmat, hipStream_t st)
 {
     if (n == 0 || V == 0) return FMHR_OK;
-    k_transform_fwd<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>(verts, w2c, proj, V, (float4*)pos, H, W, snap);
+    k_transform_fwd<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>(verts, w2c, proj, V, (float4*)pos, H, W, snap, (float4*)cmat);
     FMHR_CHECK_LAUNCH("k_transform_fwd");
     return FMHR_OK;
 }

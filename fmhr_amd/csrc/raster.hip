@@ -150,14 +150,15 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
 }
 
 // per pixel: decode the winning key, recompute its fragment, write (u, v, z/w, id+1) as one 16-B store; optionally thread
-// the pixel onto its triangle's list (head [n,F] / next [n,H,W]) for the gather-style backward.
+// the pixel onto its triangle's list (head [F,npad] face-major with the views innermost / next [n,H,W]) for the gather-style
+// backward.
 // Sparse mode (dirty != null, fused step): a wave owns one 64-pixel segment; a clean segment costs one scalar load; a dirty one
 // is resolved, its keys are reset to "empty" (the key buffer cleans itself: no per-step 100 MB memset), covered lanes get
 // their rast written (uncovered lanes are zero-filled later, only where a consumer will look), and the coverage word is stored.
 __global__ void __launch_bounds__(kBlock)
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, int* __restrict__ head,
-                 int* __restrict__ next, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw,
+                 int* __restrict__ next, int npad, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw,
                  int* __restrict__ large_cnt)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -192,7 +193,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
             o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
             covered = true;
-            if (head != nullptr) next[gid] = atomicExch(&head[(size_t)b * F + f], rem);
+            if (head != nullptr) next[gid] = atomicExch(&head[(size_t)f * npad + b], rem);
         }
     }
     if (sparse) {
@@ -343,7 +344,7 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
 // snap [n,V] int2 must already hold the snapped vertices; head/next may be null.  dirty/covw non-null = sparse mode (the key
 // buffer must have been initialised by raster_sparse_init and is left clean again).
 int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, const int32_t* opp, unsigned char* silh, int n, int V,
-                       int F, int H, int W, float* rast, void* ws, int* head, int* next, unsigned char* dirty,
+                       int F, int H, int W, float* rast, void* ws, int* head, int* next, int npad, unsigned char* dirty,
                        unsigned long long* covw, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
@@ -363,7 +364,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
             if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
         }
         if (head != nullptr && (size_t)n * F > 0) {
-            e = hipMemsetAsync(head, 0xFF, (size_t)n * F * 4, st);
+            e = hipMemsetAsync(head, 0xFF, (size_t)npad * F * 4, st);
             if (e != hipSuccess) return hip_fail(e, "memset head");
         }
     }
@@ -379,8 +380,8 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         FMHR_CHECK_LAUNCH("k_raster_large");
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, next, dirty,
-                                                                    covw, large_cnt);
+    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, next, npad,
+                                                                    dirty, covw, large_cnt);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }
@@ -397,7 +398,7 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     int2* snap = (int2*)((char*)ws + raster_core_ws_bytes(n, F, H, W));
     int rc = snap_vertices_impl(pos, n, V, H, W, snap, (hipStream_t)stream);
     if (rc) return rc;
-    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, nullptr, nullptr,
+    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, 0, nullptr, nullptr,
                               (hipStream_t)stream);
 }
 

@@ -218,23 +218,25 @@ __global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__
 }
 
 // per covered pixel with a non-zero image gradient: backward of shade + normalise + interpolate + rasterize for all three
-// corners at once, written as an 80-B record (5 x float4):
-//   R0 = (g_normal_raw.xyz, g_albedo.x)  R1 = (g_albedo.yz, u, v)  R2 = (q0x, q0y, q0w, q1x)  R3 = (q1y, q1w, q2x, q2y)  R4 = (q2w,-,-,-)
-// (q_k = clip-space (x, y, w) gradient of corner k).  The gather sums records, it recomputes nothing.
+// corners at once, written as ONE 64-B line-aligned record (4 x float4):
+//   R0 = (g_normal_raw.xyz, g_albedo.x)  R1 = (g_albedo.yz, u, v)  R2 = (q0x, q0y, q1x, q1y)  R3 = (q2x, q2y, list link, flag)
+// (q_k = clip-space (x, y) gradient of corner k; its w component is -fx*qx - fy*qy, recomputed by the
+// gather from the pixel index).  The link of the pixel's per-face list rides in the record, so a gather visit is one line.
 __global__ void __launch_bounds__(kBlock)
 k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ pos,
           const float* __restrict__ normals, const float* __restrict__ albedo, const float* __restrict__ sh,
           const float* __restrict__ mask, const float4* __restrict__ g_shaded, int n, int V, int F, int H, int W,
-          const unsigned long long* __restrict__ covw, float4* __restrict__ rec)
+          const unsigned long long* __restrict__ covw, const int* __restrict__ next, float4* __restrict__ rec)
 {
     const long long P = (long long)H * W;
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)n * P) return;
     if (!((covw[gid >> 6] >> (gid & 63)) & 1ull)) return;       // one 8-B word per wave: uncovered segments stop here
     float4 g = g_shaded[gid];
-    float4* o = rec + gid * 5;
+    float4* o = rec + gid * 4;
+    const int link = next[gid];                        // the list link travels inside the record: one 64-B line per visit
     if (!(mask[gid] > 0.f) || (g.x == 0.f && g.y == 0.f && g.z == 0.f)) {
-        o[0] = make_float4(0.f, 0.f, 0.f, -1.f);       // covered but gradient-free: the gather skips it on this marker
+        o[3] = make_float4(0.f, 0.f, __int_as_float(link), 0.f);   // .w = 0: covered but gradient-free, the gather skips it
         return;
     }
     float4 r = rast[gid];
@@ -288,106 +290,97 @@ k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, cons
     float q2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
     o[0] = make_float4(gnx, gny, gnz, ga0);
     o[1] = make_float4(ga1, ga2, r.x, r.y);
-    o[2] = make_float4(q0x, q0y, -fx * q0x - fy * q0y, q1x);
-    o[3] = make_float4(q1y, -fx * q1x - fy * q1y, q2x, q2y);
-    o[4] = make_float4(-fx * q2x - fy * q2y, 0.f, 0.f, 0.f);
+    o[2] = make_float4(q0x, q0y, q1x, q1y);
+    o[3] = make_float4(q2x, q2y, __int_as_float(link), 1.f);       // .w = 1: record carries gradients
 }
 
-// one lane per (view, vertex): for each incident face corner (CSR, entry = 3*face + corner) walk the face's pixel list (head /
-// next, threaded by the rasterizer's resolve pass) and sum this corner's share of every record:
-// attribute gradients b_k * (g_normal, g_albedo) -> part[b,v,0:6]; position gradient q_k -> gpos[b,v] += (it already holds the
-// antialias-backward atomics).  The corner codes and list heads of up to 8 corners are fetched with independent loads before
-// any list is walked, so a vertex costs ~3 memory latencies + one per extra pixel instead of ~4 per corner.
+// Gather: one lane per (chunk of <= 4 face corners of one vertex, group of kGroup views).  The list heads are stored
+// face-major with the views innermost (head [F, npad]), so the kGroup heads of a face corner are ONE 32-B read; each non-empty
+// list is walked (one 64-B record line per pixel) and this corner's share of every record is summed: attribute gradients
+// b_k * (g_normal, g_albedo) and the position gradient q_k pushed through the clip transform of its view (cmat [n,3] = rows of
+// w2c @ proj) — the result is view-independent, no [n,V,4] position-gradient buffer exists.
+// Output: part [G, n_chunks, 3 x float4] partial sums.
+constexpr int kGroup = 8;
+
 __global__ void __launch_bounds__(kBlock)
-k_vertex_gather(const float4* __restrict__ rec, const int* __restrict__ head, const int* __restrict__ next,
-                const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx, int n, int V, int F, long long P,
-                float4* __restrict__ part, float4* __restrict__ gpos)
+k_vertex_gather(const float4* __restrict__ rec, const int* __restrict__ head, const int32_t* __restrict__ vf_ptr,
+                const int32_t* __restrict__ vf_idx, const int2* __restrict__ ck, const float4* __restrict__ cmat,
+                int n, int npad, int NC, int H, int W, float4* __restrict__ part)
 {
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    int b = blockIdx.y;
-    if (v >= V) return;
-    size_t o = (size_t)b * V + v;
-    const int* hb = head + (size_t)b * F;
-    float an0 = 0.f, an1 = 0.f, an2 = 0.f, aa0 = 0.f, aa1 = 0.f, aa2 = 0.f, gx = 0.f, gy = 0.f, gw = 0.f;
-    const int e0 = vf_ptr[v], e1 = vf_ptr[v + 1];
-    // walk one face's pixel list for corner `code % 3`
-    auto walk = [&](int code, int pix) {
-        const int k = code - (code / 3) * 3;
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    int g = blockIdx.y;
+    if (c >= NC) return;
+    const int2 cd = ck[c];
+    const int e0 = cd.y, e1 = min(cd.y + 4, vf_ptr[cd.x + 1]);
+    const int b0 = g * kGroup;
+    const long long P = (long long)H * W;
+    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
+    float an0 = 0.f, an1 = 0.f, an2 = 0.f, aa0 = 0.f, aa1 = 0.f, aa2 = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+    // walk one (face, view) pixel list for corner k
+    auto walk = [&](int k, int b, int pix) {
+        float gx = 0.f, gy = 0.f, gw = 0.f;
         while (pix >= 0) {
-            long long gid = (long long)b * P + pix;
-            const float4* r = rec + gid * 5;
+            const float4* r = rec + ((long long)b * P + pix) * 4;
             float4 r0 = r[0];
             float4 r1 = r[1];
             float4 r2 = r[2];
             float4 r3 = r[3];
-            float4 r4 = r[4];
-            int pn = next[gid];
-            if (r0.w != -1.f || r0.x != 0.f) {                // (0,0,0,-1) marks a covered pixel without gradient
+            if (r3.w != 0.f) {
                 float bk = (k == 0) ? r1.z : ((k == 1) ? r1.w : 1.0f - r1.z - r1.w);
-                float qx = (k == 0) ? r2.x : ((k == 1) ? r2.w : r3.z);
-                float qy = (k == 0) ? r2.y : ((k == 1) ? r3.x : r3.w);
-                float qw = (k == 0) ? r2.z : ((k == 1) ? r3.y : r4.x);
+                float qx = (k == 0) ? r2.x : ((k == 1) ? r2.z : r3.x);
+                float qy = (k == 0) ? r2.y : ((k == 1) ? r2.w : r3.y);
+                int py = pix / W, px = pix - py * W;
+                float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
+                gx += qx; gy += qy; gw += -fx * qx - fy * qy;
                 an0 += bk * r0.x; an1 += bk * r0.y; an2 += bk * r0.z;
                 aa0 += bk * r0.w; aa1 += bk * r1.x; aa2 += bk * r1.y;
-                gx += qx; gy += qy; gw += qw;
             }
-            pix = pn;
+            pix = __float_as_int(r3.z);
         }
+        const float4 c0 = cmat[(size_t)b * 3], c1 = cmat[(size_t)b * 3 + 1], c2 = cmat[(size_t)b * 3 + 2];
+        vx += gx * c0.x + gy * c0.y + gw * c0.z;
+        vy += gx * c1.x + gy * c1.y + gw * c1.z;
+        vz += gx * c2.x + gy * c2.y + gw * c2.z;
     };
-    // four corners per round: their codes, then their list heads, are fetched with independent loads before any list is
-    // walked, so a vertex without pixels costs ~3 memory latencies instead of 2 per corner
-    for (int base = e0; base < e1; base += 4) {
-        const int m = e1 - base;
-        int c0 = vf_idx[base];
-        int c1 = (m > 1) ? vf_idx[base + 1] : c0;
-        int c2 = (m > 2) ? vf_idx[base + 2] : c0;
-        int c3 = (m > 3) ? vf_idx[base + 3] : c0;
-        int h0 = hb[c0 / 3];
-        int h1 = hb[c1 / 3];
-        int h2 = hb[c2 / 3];
-        int h3 = hb[c3 / 3];
-        walk(c0, h0);
-        if (m > 1) walk(c1, h1);
-        if (m > 2) walk(c2, h2);
-        if (m > 3) walk(c3, h3);
+    for (int e = e0; e < e1; e++) {
+        const int code = vf_idx[e];
+        const int f = code / 3, k = code - f * 3;
+        const int4* hp = reinterpret_cast<const int4*>(head + (size_t)f * npad + b0);
+        const int4 h0 = hp[0], h1 = hp[1];                    // the kGroup list heads of this face: one 32-B read
+        if (h0.x >= 0) walk(k, b0 + 0, h0.x);
+        if (h0.y >= 0) walk(k, b0 + 1, h0.y);
+        if (h0.z >= 0) walk(k, b0 + 2, h0.z);
+        if (h0.w >= 0) walk(k, b0 + 3, h0.w);
+        if (h1.x >= 0) walk(k, b0 + 4, h1.x);
+        if (h1.y >= 0) walk(k, b0 + 5, h1.y);
+        if (h1.z >= 0) walk(k, b0 + 6, h1.z);
+        if (h1.w >= 0) walk(k, b0 + 7, h1.w);
     }
-    part[o * 2] = make_float4(an0, an1, an2, aa0);
-    part[o * 2 + 1] = make_float4(aa1, aa2, 0.f, 0.f);
-    if (gx != 0.f || gy != 0.f || gw != 0.f) {
-        float4 g = gpos[o];
-        g.x += gx; g.y += gy; g.w += gw;
-        gpos[o] = g;
-    }
+    float4* o = part + ((size_t)g * NC + c) * 3;
+    o[0] = make_float4(an0, an1, an2, aa0);
+    o[1] = make_float4(aa1, aa2, vx, vy);
+    o[2] = make_float4(vz, 0.f, 0.f, 0.f);
 }
 
-// per vertex: sum the per-view partials (attribute grads) and apply the clip-transform backward to gpos (sum over views):
-// gverts[v] += sum_b ((gpos[b,v] @ proj[b]^T) @ w2c[b]^T)[:3];  gnormal[v] = sum_b part.n;  galbedo[v] += sum_b part.a
+// per vertex: sum the partials of its chunks over all view groups; gverts = position part + the antialias-backward part
+// (gvert_aa), gnormal, galbedo — first writer of gverts / galbedo this step: plain stores, later kernels accumulate
 __global__ void __launch_bounds__(kBlock)
-k_reduce_views(const float4* __restrict__ part, const float4* __restrict__ gpos, const float* __restrict__ w2c,
-               const float* __restrict__ proj, int n, int V, float* __restrict__ gverts, float* __restrict__ gnormal,
-               float* __restrict__ galbedo)
+k_reduce_groups(const float4* __restrict__ part, const float* __restrict__ gvert_aa, const int32_t* __restrict__ vc_ptr, int G,
+                int NC, int V, float* __restrict__ gverts, float* __restrict__ gnormal, float* __restrict__ galbedo)
 {
     int v = blockIdx.x * kBlock + threadIdx.x;
     if (v >= V) return;
-    float ax = 0.f, ay = 0.f, az = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int b = 0; b < n; b++) {
-        size_t o = (size_t)b * V + v;
-        float4 q0 = part[o * 2], q1 = part[o * 2 + 1];
-        n0 += q0.x; n1 += q0.y; n2 += q0.z; a0 += q0.w; a1 += q1.x; a2 += q1.y;
-        float4 g = gpos[o];
-        if (g.x != 0.f || g.y != 0.f || g.w != 0.f || g.z != 0.f) {
-            const float* A = w2c + (size_t)b * 16;
-            const float* B = proj + (size_t)b * 16;
-            float r[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = g.x * B[k * 4] + g.y * B[k * 4 + 1] + g.z * B[k * 4 + 2] + g.w * B[k * 4 + 3];
-            ax += r[0] * A[0] + r[1] * A[1] + r[2] * A[2] + r[3] * A[3];
-            ay += r[0] * A[4] + r[1] * A[5] + r[2] * A[6] + r[3] * A[7];
-            az += r[0] * A[8] + r[1] * A[9] + r[2] * A[10] + r[3] * A[11];
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    float x = gvert_aa[(size_t)v * 3], y = gvert_aa[(size_t)v * 3 + 1], z = gvert_aa[(size_t)v * 3 + 2];
+    const int c0 = vc_ptr[v], c1 = vc_ptr[v + 1];
+    for (int g = 0; g < G; g++)
+        for (int c = c0; c < c1; c++) {
+            const float4* q = part + ((size_t)g * NC + c) * 3;
+            float4 q0 = q[0], q1 = q[1], q2 = q[2];
+            n0 += q0.x; n1 += q0.y; n2 += q0.z; a0 += q0.w; a1 += q1.x; a2 += q1.y;
+            x += q1.z; y += q1.w; z += q2.x;
         }
-    }
-    // first writer of gverts / galbedo this step: plain stores (no memset needed), later kernels accumulate
-    gverts[(size_t)v * 3] = ax; gverts[(size_t)v * 3 + 1] = ay; gverts[(size_t)v * 3 + 2] = az;
+    gverts[(size_t)v * 3] = x; gverts[(size_t)v * 3 + 1] = y; gverts[(size_t)v * 3 + 2] = z;
     gnormal[(size_t)v * 3] = n0; gnormal[(size_t)v * 3 + 1] = n1; gnormal[(size_t)v * 3 + 2] = n2;
     galbedo[(size_t)v * 3] = a0; galbedo[(size_t)v * 3 + 1] = a1; galbedo[(size_t)v * 3 + 2] = a2;
 }
@@ -472,33 +465,29 @@ int loss_pix_impl(const float* shaded, const float* aa, const float* img, const 
 
 int pix_bwd_impl(const float* rast, const int32_t* tri, const float* pos, const float* normals, const float* albedo,
                  const float* sh, const float* mask, const float* g_shaded, int n, int V, int F, int H, int W,
-                 const unsigned long long* covw, float* rec, hipStream_t st)
+                 const unsigned long long* covw, const int* next, float* rec, hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0 || F == 0) return FMHR_OK;
     k_pix_bwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, pos, normals, albedo, sh, mask,
-                                                     (const float4*)g_shaded, n, V, F, H, W, covw, (float4*)rec);
+                                                     (const float4*)g_shaded, n, V, F, H, W, covw, next, (float4*)rec);
     FMHR_CHECK_LAUNCH("k_pix_bwd");
     return FMHR_OK;
 }
 
-int vertex_gather_impl(const float* rec, const int* head, const int* next, const int32_t* vf_ptr, const int32_t* vf_idx, int n,
-                       int V, int F, int H, int W, float* part, float* gpos, hipStream_t st)
+int vertex_gather_impl(const float* rec, const int* head, const int32_t* vf_ptr, const int32_t* vf_idx, const int32_t* vc_ptr,
+                       const int32_t* ck, const float* cmat, const float* gvert_aa, int n, int npad, int V, int NC, int H, int W,
+                       float* part, float* gverts, float* gnormal, float* galbedo, hipStream_t st)
 {
     if (n == 0 || V == 0) return FMHR_OK;
-    k_vertex_gather<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>((const float4*)rec, head, next, vf_ptr, vf_idx, n, V, F,
-                                                                (long long)H * W, (float4*)part, (float4*)gpos);
-    FMHR_CHECK_LAUNCH("k_vertex_gather");
-    return FMHR_OK;
-}
-
-int reduce_views_impl(const float* part, const float* gpos, const float* w2c, const float* proj, int n, int V, float* gverts,
-                      float* gnormal, float* galbedo, hipStream_t st)
-{
-    if (V == 0) return FMHR_OK;
-    k_reduce_views<<<cdiv(V, kBlock), kBlock, 0, st>>>((const float4*)part, (const float4*)gpos, w2c, proj, n, V, gverts, gnormal,
-                                                      galbedo);
-    FMHR_CHECK_LAUNCH("k_reduce_views");
+    const int G = npad / kGroup;
+    if (NC > 0) {
+        k_vertex_gather<<<dim3(cdiv(NC, kBlock), G), kBlock, 0, st>>>((const float4*)rec, head, vf_ptr, vf_idx, (const int2*)ck,
+                                                                     (const float4*)cmat, n, npad, NC, H, W, (float4*)part);
+        FMHR_CHECK_LAUNCH("k_vertex_gather");
+    }
+    k_reduce_groups<<<cdiv(V, kBlock), kBlock, 0, st>>>((const float4*)part, gvert_aa, vc_ptr, G, NC, V, gverts, gnormal, galbedo);
+    FMHR_CHECK_LAUNCH("k_reduce_groups");
     return FMHR_OK;
 }
 

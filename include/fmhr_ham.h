@@ -53,6 +53,10 @@ size_t fmhr_vertex_faces_workspace_bytes(int V);
 int fmhr_vertex_faces_build(const int32_t* tri, int F, int V, int32_t* vf_ptr, int32_t* vf_idx,
                             void* ws, size_t ws_bytes, void* stream);
 
+/* CSR rows cut into chunks of <= 4 corners (load balance of the gather): vc_ptr [V+1] = first chunk of each vertex,
+ * ck [<= 3F/4 + V, 2] = (vertex, first CSR entry) per chunk; the chunk count is vc_ptr[V].  ws: (V+1)*4 bytes. */
+int fmhr_vertex_chunks_build(const int32_t* vf_ptr, int V, int32_t* vc_ptr, int32_t* ck, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ nvdiffrast-shaped primitives
  * dr.rasterize(glctx, pos, tri, resolution=(H,W))  — mesh_sfs_optim.py:142,212,267; get_data.py:251.
  * pos [n,V,4] clip space, tri [F,3]; rast [n,H,W,4] = (u, v, z/w, tri_id+1) or zeros.  Rules: DESIGN.md §3. */
@@ -113,8 +117,8 @@ int fmhr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 typedef struct fmhr_ham_dims {
     int32_t n, V, F, H, W;      /* views on this rank, vertices, faces, image size */
     int32_t nnz;                /* adjacency nnz (row_ptr[V]) */
-    int32_t aa_cap;             /* capacity of the antialias work queue (items) */
-    int32_t reserved;
+    int32_t aa_cap;             /* unused by the fused step since the antialias items live in place; keep >= 1 */
+    int32_t n_chunks;           /* vc_ptr[V] from fmhr_vertex_chunks_build */
 } fmhr_ham_dims;
 
 typedef struct fmhr_ham_weights {
@@ -142,7 +146,8 @@ size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
  * Phase B: losses + the whole backward.  The split exists because F.l1_loss divides by the batch-GLOBAL 3*Pv
  * (mesh_sfs_optim.py:289): a view-sharded caller all-reduces n_valid between the two phases.
  *   vertices_tmp, delta, albedo [V,3]; sh [n,9]; w2c, proj [n,4,4] (row-vector convention, get_data.py:96-97);
- *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx [nnz]; vf_ptr [V+1]; vf_idx [3F].
+ *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx [nnz]; vf_ptr [V+1]; vf_idx [3F];
+ *   vc_ptr [V+1]; ck [n_chunks,2].
  *   n*H*W must be a multiple of 4.
  *   valid_mask_changed: pass 1 on the first call on a workspace and whenever valid_mask's CONTENTS may differ from the previous
  *   call (its per-segment non-zero flags are cached in the workspace; the mask is constant over a HAM run, :158).
@@ -158,7 +163,7 @@ int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const f
                       const float* albedo, const float* sh, const float* w2c, const float* proj, const float* img,
                       const float* mask, const float* valid_mask, const int32_t* tri, const int32_t* opp,
                       const int32_t* row_ptr, const int32_t* col_idx, const int32_t* vf_ptr, const int32_t* vf_idx,
-                      const float* n_valid_global,
+                      const int32_t* vc_ptr, const int32_t* ck, const float* n_valid_global,
                       float* losses, float* gdelta, float* galbedo, void* ws, size_t ws_bytes, void* stream);
 /* Views of the step's intermediates inside the workspace (for parity tests / rendering): returns device pointers. */
 typedef struct fmhr_ham_views {
