@@ -5,6 +5,15 @@
 #include <string.h>
 
 namespace fmhr {
+struct MeshTailArgs {
+    const float4* part; const float* gvert_aa; const int32_t* vc_ptr; int G, NC;
+    const float* verts; const float* delta; const float* albedo; const float* nsum;
+    const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
+    int V, F;
+    float lap_w, alb_w, edge_w, delta_w, edge_mean, rg;
+    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a; float* losses;
+};
+int mesh_tail_impl(const MeshTailArgs&, float*, float*, hipStream_t);
 // raster.hip / antialias.hip / mesh.hip / shade.hip
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
@@ -263,26 +272,23 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         TRY(pix_bwd_impl(rast, tri, pos, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_shaded), d->n, d->V, d->F,
                          d->H, d->W, (const unsigned long long*)(w + L.covw), (const int*)(w + L.next), (float*)(w + L.rec), st));
         TRY(vertex_gather_impl((float*)(w + L.rec), (int*)(w + L.head), vf_ptr, vf_idx, vc_ptr, ck, (const float*)(w + L.cmat),
-                               gvert_aa, d->n, npad, d->V, d->n_chunks, d->H, d->W, (float*)(w + L.part), gvert,
-                               (float*)(w + L.gnormal), galbedo, st));
+                               gvert_aa, d->n, npad, d->V, d->n_chunks, d->H, d->W, (float*)(w + L.part), nullptr, nullptr, nullptr,
+                               st));
     }
     {
-        ProfScope ps(FMHR_SLOT_NORMALS_BWD, st);
-        TRY(normals_bwd_gather_impl(vertices, tri, vf_ptr, vf_idx, (float*)(w + L.nsum), (float*)(w + L.gnormal), d->V,
-                                    (float*)(w + L.gtmp), gvert, st));
+        // everything per-vertex after the gather, in two kernels (mesh.hip: k_mesh_tail_a / _b)
+        ProfScope ps(FMHR_SLOT_REGULARISERS, st);
+        MeshTailArgs A;
+        A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.vc_ptr = vc_ptr; A.G = npad / 8; A.NC = d->n_chunks;
+        A.verts = vertices; A.delta = delta; A.albedo = albedo; A.nsum = (const float*)(w + L.nsum);
+        A.tri = tri; A.vf_ptr = vf_ptr; A.vf_idx = vf_idx; A.row_ptr = row_ptr; A.col = col_idx;
+        A.V = d->V; A.F = d->F;
+        A.lap_w = wt->lap / (float)d->V; A.alb_w = wt->albedo / (float)d->V; A.edge_w = wt->edge / (3.0f * (float)d->F);
+        A.delta_w = wt->delta / (float)d->V; A.edge_mean = wt->edge_length_mean; A.rg = rg;
+        A.gs = (float*)(w + L.gtmp); A.rowg_v = (float*)(w + L.rowg); A.rowg_a = (float*)(w + L.lx_a);
+        A.gacc_v = gvert; A.gacc_a = (float*)(w + L.lx_v); A.losses = losses;
+        TRY(mesh_tail_impl(A, gdelta, galbedo, st));
     }
-    ProfScope ps(FMHR_SLOT_REGULARISERS, st);
-    // view-independent regularisers (mesh_sfs_optim.py:292-293, 296-304)
-    TRY(lap_fwd_impl(vertices, row_ptr, col_idx, d->V, 3, wt->lap, (float*)(w + L.lx_v), losses + FMHR_LOSS_LAP, st));
-    TRY(lap_fwd_impl(albedo, row_ptr, col_idx, d->V, 3, wt->albedo, (float*)(w + L.lx_a), losses + FMHR_LOSS_ALBEDO, st));
-    if (rg != 0.f) {
-        TRY(lap_bwd_impl((float*)(w + L.lx_v), row_ptr, col_idx, d->V, 3, wt->lap * rg, (float*)(w + L.rowg), gvert, st));
-        TRY(lap_bwd_impl((float*)(w + L.lx_a), row_ptr, col_idx, d->V, 3, wt->albedo * rg, (float*)(w + L.rowg), galbedo, st));
-    }
-    TRY(edge_hinge_gather_impl(vertices, tri, vf_ptr, vf_idx, d->V, d->F, wt->edge_length_mean, wt->edge, wt->edge * rg,
-                               losses + FMHR_LOSS_EDGE, gvert, st));
-    TRY(delta_term_impl(delta, d->V, wt->delta, wt->delta * rg, losses + FMHR_LOSS_DELTA, gvert, st));
-    HIPTRY(hipMemcpyAsync(gdelta, gvert, V * 12, hipMemcpyDeviceToDevice, st), "copy gdelta");
     TRY(finish_losses_impl(losses, n_valid_global, (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, (int)nB,
                            wt->sfs, wt->mask, wt->mse_denominator, st));
     return FMHR_OK;

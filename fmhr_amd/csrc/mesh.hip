@@ -454,6 +454,175 @@ k_edge_hinge_gather(const float* __restrict__ verts, const int32_t* __restrict__
     if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s * wscale);
 }
 
+// ------------------------------------------------------------------------------------------------ fused backward tail
+// The stage-2 backward ends in thirteen tiny per-vertex kernels (each >= 4.5 us of launch + dependent-load latency for 49k
+// vertices); they collapse into two, split where a vertex needs its NEIGHBOURS' intermediate results.
+// A (own data only): sum the gather partials -> view-dependent gradients; normal-normalise backward -> gs; both uniform
+//    Laplacians forward -> loss terms and scaled row gradients; delta term; edge hinge (loss + gradient).
+// B (neighbour gathers): vertex-normal backward from gs, L^T r for both Laplacians -> final gdelta / galbedo.
+struct MeshTailArgs {
+    const float4* part; const float* gvert_aa; const int32_t* vc_ptr; int G, NC;      // gather partials
+    const float* verts; const float* delta; const float* albedo; const float* nsum;
+    const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
+    int V, F;
+    float lap_w, alb_w, edge_w, delta_w, edge_mean, rg;                               // weights (already / V or / 3F where due)
+    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a; float* losses;
+};
+
+__device__ __forceinline__ void lap_row(const float* __restrict__ x, const int32_t* __restrict__ row_ptr,
+                                        const int32_t* __restrict__ col, int i, float out[3])
+{
+    int a = row_ptr[i], b = row_ptr[i + 1];
+    float xi[3] = {x[(size_t)i * 3], x[(size_t)i * 3 + 1], x[(size_t)i * 3 + 2]};
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int j = a; j < b; j++) {
+        const float* xj = x + (size_t)col[j] * 3;
+        acc[0] += xj[0] - xi[0]; acc[1] += xj[1] - xi[1]; acc[2] += xj[2] - xi[2];
+    }
+    float inv = (b > a) ? 1.0f / (float)(b - a) : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) out[c] = (b > a) ? acc[c] * inv : -xi[c];
+}
+
+__global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
+{
+    __shared__ float sm[4];
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    float l_lap = 0.f, l_alb = 0.f, l_edge = 0.f, l_delta = 0.f;
+    if (v < A.V) {
+        // (1) partial sums of the pixel gather
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        float gx = A.gvert_aa[(size_t)v * 3], gy = A.gvert_aa[(size_t)v * 3 + 1], gz = A.gvert_aa[(size_t)v * 3 + 2];
+        const int c0 = A.vc_ptr[v], c1 = A.vc_ptr[v + 1];
+        for (int g = 0; g < A.G; g++)
+            for (int c = c0; c < c1; c++) {
+                const float4* q = A.part + ((size_t)g * A.NC + c) * 3;
+                float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                n0 += q0.x; n1 += q0.y; n2 += q0.z; a0 += q0.w; a1 += q1.x; a2 += q1.y;
+                gx += q1.z; gy += q1.w; gz += q2.x;
+            }
+        // (2) d/d nsum of the normalised vertex normal (models/utils.py:545, eps 1e-6)
+        {
+            float3 s = ld3(A.nsum + (size_t)v * 3);
+            float len = sqrtf(s.x * s.x + s.y * s.y + s.z * s.z);
+            float3 o;
+            if (len > 1e-6f) {
+                float inv = 1.0f / len;
+                float3 nh = make_float3(s.x * inv, s.y * inv, s.z * inv);
+                float dt = nh.x * n0 + nh.y * n1 + nh.z * n2;
+                o = make_float3((n0 - nh.x * dt) * inv, (n1 - nh.y * dt) * inv, (n2 - nh.z * dt) * inv);
+            } else {
+                o = make_float3(n0 * 1e6f, n1 * 1e6f, n2 * 1e6f);
+            }
+            A.gs[(size_t)v * 3] = o.x; A.gs[(size_t)v * 3 + 1] = o.y; A.gs[(size_t)v * 3 + 2] = o.z;
+        }
+        // (3) uniform Laplacians of the vertices and of the albedo: row norms -> loss, scaled rows -> backward (part B)
+        {
+            float lv[3], la[3];
+            lap_row(A.verts, A.row_ptr, A.col, v, lv);
+            lap_row(A.albedo, A.row_ptr, A.col, v, la);
+            float nv = sqrtf(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
+            float na = sqrtf(la[0] * la[0] + la[1] * la[1] + la[2] * la[2]);
+            l_lap = nv; l_alb = na;
+            float kv = (nv > 0.f) ? A.lap_w * A.rg / nv : 0.f, ka = (na > 0.f) ? A.alb_w * A.rg / na : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) { A.rowg_v[(size_t)v * 3 + c] = lv[c] * kv; A.rowg_a[(size_t)v * 3 + c] = la[c] * ka; }
+        }
+        // (4) delta term (mesh_sfs_optim.py:304)
+        {
+            float3 d = ld3(A.delta + (size_t)v * 3);
+            l_delta = d.x * d.x + d.y * d.y + d.z * d.z;
+            float k = 2.f * A.delta_w * A.rg;
+            gx += k * d.x; gy += k * d.y; gz += k * d.z;
+        }
+        // (5) edge hinge (mesh_sfs_optim.py:296-302): a face's loss is accounted by its corner 0, gradients by each corner
+        {
+            float3 acc = make_float3(0.f, 0.f, 0.f);
+            const float gk = 2.f * A.edge_w * A.rg;
+            for (int e = A.vf_ptr[v]; e < A.vf_ptr[v + 1]; e++) {
+                int code = A.vf_idx[e];
+                int f = code / 3, c = code - f * 3;
+                float3 a = ld3(A.verts + (size_t)A.tri[f * 3] * 3), b = ld3(A.verts + (size_t)A.tri[f * 3 + 1] * 3),
+                       cc = ld3(A.verts + (size_t)A.tri[f * 3 + 2] * 3);
+                float3 ed[3] = {sub3(a, b), sub3(cc, b), sub3(a, cc)};
+                const float sgn[3][3] = {{1.f, 0.f, 1.f}, {-1.f, -1.f, 0.f}, {0.f, 1.f, -1.f}};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float l2 = ed[k].x * ed[k].x + ed[k].y * ed[k].y + ed[k].z * ed[k].z;
+                    float d = l2 - A.edge_mean;
+                    if (c == 0) l_edge += fminf(fmaxf(d, 0.f), 1.f);
+                    float sg = sgn[c][k];
+                    if (d > 0.f && d < 1.f && sg != 0.f) { acc.x += gk * sg * ed[k].x; acc.y += gk * sg * ed[k].y; acc.z += gk * sg * ed[k].z; }
+                }
+            }
+            gx += acc.x; gy += acc.y; gz += acc.z;
+        }
+        A.gacc_v[(size_t)v * 3] = gx; A.gacc_v[(size_t)v * 3 + 1] = gy; A.gacc_v[(size_t)v * 3 + 2] = gz;
+        A.gacc_a[(size_t)v * 3] = a0; A.gacc_a[(size_t)v * 3 + 1] = a1; A.gacc_a[(size_t)v * 3 + 2] = a2;
+    }
+    float s;
+    s = block_sum(l_lap, sm);   if (threadIdx.x == 0 && s != 0.f) atomicAdd(A.losses + FMHR_LOSS_LAP, s * A.lap_w);
+    s = block_sum(l_alb, sm);   if (threadIdx.x == 0 && s != 0.f) atomicAdd(A.losses + FMHR_LOSS_ALBEDO, s * A.alb_w);
+    s = block_sum(l_edge, sm);  if (threadIdx.x == 0 && s != 0.f) atomicAdd(A.losses + FMHR_LOSS_EDGE, s * A.edge_w);
+    s = block_sum(l_delta, sm); if (threadIdx.x == 0 && s != 0.f) atomicAdd(A.losses + FMHR_LOSS_DELTA, s * A.delta_w);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_mesh_tail_b(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
+              const int32_t* __restrict__ vf_idx, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+              const float* __restrict__ gs, const float* __restrict__ rowg_v, const float* __restrict__ rowg_a,
+              const float* __restrict__ gacc_v, const float* __restrict__ gacc_a, int V, float* __restrict__ gdelta,
+              float* __restrict__ galbedo)
+{
+    int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= V) return;
+    float3 acc = ld3(gacc_v + (size_t)v * 3);
+    float3 aca = ld3(gacc_a + (size_t)v * 3);
+    // vertex-normal backward: this vertex's share of d(sum_k gs[i_k] . cross_k)/d verts over its incident faces
+    for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
+        int code = vf_idx[e];
+        int f = code / 3, c = code - f * 3;
+        int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
+        float3 p[3] = {ld3(verts + (size_t)i[0] * 3), ld3(verts + (size_t)i[1] * 3), ld3(verts + (size_t)i[2] * 3)};
+        float3 g[3] = {ld3(gs + (size_t)i[0] * 3), ld3(gs + (size_t)i[1] * 3), ld3(gs + (size_t)i[2] * 3)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+            float3 e1 = sub3(p[k1], p[k]), e2 = sub3(p[k2], p[k]);
+            float3 ge1 = cross3(e2, g[k]), ge2 = cross3(g[k], e1);
+            if (c == k1) { acc.x += ge1.x; acc.y += ge1.y; acc.z += ge1.z; }
+            if (c == k2) { acc.x += ge2.x; acc.y += ge2.y; acc.z += ge2.z; }
+            if (c == k) { acc.x -= ge1.x + ge2.x; acc.y -= ge1.y + ge2.y; acc.z -= ge1.z + ge2.z; }
+        }
+    }
+    // L^T r for both Laplacians (the adjacency is symmetric): sum_{i in N(v)} r_i / deg_i - r_v
+    {
+        float3 rv = ld3(rowg_v + (size_t)v * 3), ra = ld3(rowg_a + (size_t)v * 3);
+        acc.x -= rv.x; acc.y -= rv.y; acc.z -= rv.z;
+        aca.x -= ra.x; aca.y -= ra.y; aca.z -= ra.z;
+        for (int e = row_ptr[v]; e < row_ptr[v + 1]; e++) {
+            int i = col[e];
+            float inv = 1.0f / (float)(row_ptr[i + 1] - row_ptr[i]);
+            float3 qv = ld3(rowg_v + (size_t)i * 3), qa = ld3(rowg_a + (size_t)i * 3);
+            acc.x += qv.x * inv; acc.y += qv.y * inv; acc.z += qv.z * inv;
+            aca.x += qa.x * inv; aca.y += qa.y * inv; aca.z += qa.z * inv;
+        }
+    }
+    gdelta[(size_t)v * 3] = acc.x; gdelta[(size_t)v * 3 + 1] = acc.y; gdelta[(size_t)v * 3 + 2] = acc.z;
+    galbedo[(size_t)v * 3] = aca.x; galbedo[(size_t)v * 3 + 1] = aca.y; galbedo[(size_t)v * 3 + 2] = aca.z;
+}
+
+int mesh_tail_impl(const MeshTailArgs& A, float* gdelta, float* galbedo, hipStream_t st)
+{
+    if (A.V == 0) return FMHR_OK;
+    k_mesh_tail_a<<<cdiv(A.V, kBlock), kBlock, 0, st>>>(A);
+    FMHR_CHECK_LAUNCH("k_mesh_tail_a");
+    k_mesh_tail_b<<<cdiv(A.V, kBlock), kBlock, 0, st>>>(A.verts, A.tri, A.vf_ptr, A.vf_idx, A.row_ptr, A.col, A.gs, A.rowg_v, A.rowg_a,
+                                                       A.gacc_v, A.gacc_a, A.V, gdelta, galbedo);
+    FMHR_CHECK_LAUNCH("k_mesh_tail_b");
+    return FMHR_OK;
+}
+
 // ---- internal launchers used by ham_step.hip
 int normals_fwd_gather_impl(const float* verts, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, int V,
                             float* nsum, float* normals, hipStream_t st)

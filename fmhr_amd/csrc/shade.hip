@@ -486,8 +486,10 @@ int vertex_gather_impl(const float* rec, const int* head, const int32_t* vf_ptr,
                                                                      (const float4*)cmat, n, npad, NC, H, W, (float4*)part);
         FMHR_CHECK_LAUNCH("k_vertex_gather");
     }
-    k_reduce_groups<<<cdiv(V, kBlock), kBlock, 0, st>>>((const float4*)part, gvert_aa, vc_ptr, G, NC, V, gverts, gnormal, galbedo);
-    FMHR_CHECK_LAUNCH("k_reduce_groups");
+    if (gverts != nullptr) {      // stand-alone reduction; the fused step sums the partials in its mesh-tail kernel instead
+        k_reduce_groups<<<cdiv(V, kBlock), kBlock, 0, st>>>((const float4*)part, gvert_aa, vc_ptr, G, NC, V, gverts, gnormal, galbedo);
+        FMHR_CHECK_LAUNCH("k_reduce_groups");
+    }
     return FMHR_OK;
 }
 
