@@ -111,7 +111,7 @@ def cpu_baseline(scene, views_sample, seed):
     valid_mask = tg["pred_mask"]
     elm = float(oracle.edge_length_mean(scene["vertices"], faces))
     times = []
-    for it in range(3):
+    for it in range(5):
         d = torch.zeros_like(scene["vertices"]).requires_grad_(True)
         a = scene["albedo0"][None].clone().requires_grad_(True)
         t0 = time.perf_counter()
@@ -122,7 +122,7 @@ def cpu_baseline(scene, views_sample, seed):
     t = sorted(times)[len(times) // 2]
     n = scene["views"]
     return dict(value=1.0 / (t * n / S), unit="iterations/s", cores=cores, kind="port",
-                sample=f"{S} of {n} views ({H}x{W}, V={scene['V']}), fwd+bwd, median of 3 = {t:.3f}s, scaled x{n / S:.0f}; "
+                sample=f"{S} of {n} views ({H}x{W}, V={scene['V']}), fwd+bwd, median of 5 = {t:.3f}s, scaled x{n / S:.0f}; "
                        f"C rasterizer is single-threaded, torch ops use {cores} threads")
 
 
@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--config", default="metric", choices=list(synthetic.CONFIGS))
     ap.add_argument("--views", type=int, default=None, help="override the view count of the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=4)
+    ap.add_argument("--cpu-views", type=int, default=16)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -228,6 +228,12 @@ def main():
     final = hs.loss_dict() if world == 1 else dict(zip(("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid"), losses.tolist()))
 
     if rank == 0:
+        # HBM traffic of the launch groups comes from the committed PMC profile of this same command (counters cannot be
+        # collected live next to the timed region); null when the workload differs from the profiled one
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath) and args.config == "metric" and world == 1 and args.views is None:
+            traffic = json.load(open(tpath))
         ms_per_step = elapsed / K * 1e3
         dom_bytes = alg_bytes(SLOTS[dom], n, P, V, F, hs.nnz)
         dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
@@ -243,10 +249,12 @@ def main():
                        "views": n_total, "views_per_gpu": n, "H": H, "W": W, "V": V, "F": F,
                        "coverage": round(tg["coverage"], 4), "parallelism": f"views sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": SLOTS[dom], "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom_gbs / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": dom_bytes,
+                         "frac": dom_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get(SLOTS[dom]),
+                         "traffic_source": (traffic or {}).get("_source"), "alg_bytes_per_launch": dom_bytes,
                          "avg_launch_ms": dom_ms},
             "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": step_gbs / HBM_PEAK_GBS, "alg_bytes_per_step": sb, "device_ms_per_step": step_dev_ms},
+                              "frac": step_gbs / HBM_PEAK_GBS, "alg_bytes_per_step": sb, "device_ms_per_step": step_dev_ms,
+                              "traffic_low_high": [traffic["step_total_low"], traffic["step_total_high"]] if traffic else None},
             "kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
             "losses": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in final.items()},
         }
