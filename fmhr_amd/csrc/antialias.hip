@@ -159,12 +159,12 @@ __global__ void k_vf_fill(const int32_t* __restrict__ tri, int F, int V, const i
     if ((unsigned)v < (unsigned)V) idx[row_ptr[v] + atomicAdd(&cursor[v], 1)] = code;
 }
 
-// split every vertex's CSR row into chunks of <= 4 corners: the gather assigns one lane per (chunk, view group), so a
+// split every vertex's CSR row into chunks of <= kChunk corners: the gather assigns one lane per (chunk, view group), so a
 // high-valence vertex (valence 37 at the pole of the benchmark mesh; scans can have far more) cannot serialise the kernel
 __global__ void k_chunk_count(const int* __restrict__ vf_ptr, int V, int* cnt)
 {
     int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v < V) cnt[v] = (vf_ptr[v + 1] - vf_ptr[v] + 3) / 4;
+    if (v < V) cnt[v] = (vf_ptr[v + 1] - vf_ptr[v] + kChunk - 1) / kChunk;
 }
 
 __global__ void k_chunk_fill(const int* __restrict__ vf_ptr, const int* __restrict__ vc_ptr, int V, int2* __restrict__ ck)
@@ -172,7 +172,7 @@ __global__ void k_chunk_fill(const int* __restrict__ vf_ptr, const int* __restri
     int v = blockIdx.x * kBlock + threadIdx.x;
     if (v >= V) return;
     int c0 = vc_ptr[v], c1 = vc_ptr[v + 1], e = vf_ptr[v];
-    for (int c = c0; c < c1; c++, e += 4) ck[c] = make_int2(v, e);
+    for (int c = c0; c < c1; c++, e += kChunk) ck[c] = make_int2(v, e);
 }
 
 // ------------------------------------------------------------------------------------------------ antialias analysis

@@ -4,7 +4,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libfmhr_ham.so
-SRCS="abi.cpp raster.hip antialias.hip mesh.hip shade.hip ham_step.hip"
+SRCS="abi.cpp raster.hip antialias.hip mesh.hip shade.hip ncc.hip ham_step.hip"
 NEW=0
 for f in $SRCS common.h ../../include/fmhr_ham.h build.sh; do
   if [ ! -f "$OUT" ] || [ "$f" -nt "$OUT" ]; then NEW=1; fi

@@ -54,7 +54,7 @@ class HamStage2:
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.dev)
         call("fmhr_vertex_faces_build", ptr(self.faces), self.F, self.V, ptr(self.vf_ptr), ptr(self.vf_idx), ptr(ws), nb, st)
         self.vc_ptr = torch.zeros(self.V + 1, dtype=torch.int32, device=self.dev)
-        self.ck = torch.zeros((3 * self.F) // 4 + self.V + 1, 2, dtype=torch.int32, device=self.dev)
+        self.ck = torch.zeros(3 * self.F + self.V + 1, 2, dtype=torch.int32, device=self.dev)   # bound for any chunk size >= 1
         ws = torch.empty((self.V + 1) * 4, dtype=torch.uint8, device=self.dev)
         call("fmhr_vertex_chunks_build", ptr(self.vf_ptr), self.V, ptr(self.vc_ptr), ptr(self.ck), ptr(ws), (self.V + 1) * 4, st)
         self.n_chunks = int(self.vc_ptr[-1])

@@ -53,8 +53,8 @@ size_t fmhr_vertex_faces_workspace_bytes(int V);
 int fmhr_vertex_faces_build(const int32_t* tri, int F, int V, int32_t* vf_ptr, int32_t* vf_idx,
                             void* ws, size_t ws_bytes, void* stream);
 
-/* CSR rows cut into chunks of <= 4 corners (load balance of the gather): vc_ptr [V+1] = first chunk of each vertex,
- * ck [<= 3F/4 + V, 2] = (vertex, first CSR entry) per chunk; the chunk count is vc_ptr[V].  ws: (V+1)*4 bytes. */
+/* CSR rows cut into chunks of a few corners (load balance of the gather): vc_ptr [V+1] = first chunk of each vertex,
+ * ck [<= 3F + V, 2] = (vertex, first CSR entry) per chunk; the chunk count is vc_ptr[V].  ws: (V+1)*4 bytes. */
 int fmhr_vertex_chunks_build(const int32_t* vf_ptr, int V, int32_t* vc_ptr, int32_t* ck, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ nvdiffrast-shaped primitives
@@ -106,6 +106,14 @@ int fmhr_laplacian_uniform_fwd(const float* x, const int32_t* row_ptr, const int
                                float weight, float* lx, float* loss, void* stream);
 int fmhr_laplacian_uniform_bwd(const float* lx, const int32_t* row_ptr, const int32_t* col_idx, int V, int C,
                                float gscale, float* rowg, float* gx, void* stream);
+
+/* NCC(ref, src, ref_valid_mask, src_valid_mask) — models/ncc_utils.py:4-35 (never called by the reference; named by the
+ * north star).  ref [1,Np,Npx], src / src_valid_mask [nv,Np,Npx] -> out [nv,Np].  ref_valid_mask is unused there too.
+ * Backward: gref [1,Np,Npx] += (caller-zeroed; summed over views), gsrc [nv,Np,Npx] overwritten; either may be null. */
+int fmhr_ncc_fwd(const float* ref, const float* src, const float* src_valid_mask, int nviews, int npoints, int npixels,
+                 float* out, void* stream);
+int fmhr_ncc_bwd(const float* ref, const float* src, const float* src_valid_mask, const float* dy, int nviews, int npoints,
+                 int npixels, float* gref, float* gsrc, void* stream);
 
 /* torch.optim.Adam(params, lr, betas, eps).step() for one parameter tensor (amsgrad=False, weight_decay=0) —
  * mesh_sfs_optim.py:244,310.  `step` is the 1-based step count; exp_avg / exp_avg_sq are the caller-owned state (zeros at start). */

@@ -103,3 +103,23 @@ def test_adam_matches_torch():
         mine.step()
     assert rel_err(qa, pa) < 1e-6 and rel_err(qb, pb) < 1e-6
     assert rel_err(qa - a0, pa - a0) < 1e-4 and rel_err(qb - b0, pb - b0) < 1e-4
+
+
+def test_ncc_golden_and_grad(golden, oracle):
+    """fmhr_amd.ncc_utils.NCC against the reference-generated goldens (incl. the zero-variance / empty-mask guards of Appendix D
+    KA4) and its backward against fp64 autograd of the oracle restatement."""
+    from fmhr_amd.ncc_utils import NCC
+    g, dev = golden, torch.device("cuda:0")
+    out = NCC(T(g["ka_ncc_ref"]).to(dev), T(g["ka_ncc_src"]).to(dev), None, T(g["ka_ncc_mask"]).to(dev))
+    assert rel_err(out, [[1, 0], [-1, 0]]) < 1e-6
+    out = NCC(T(g["n_ref"]).to(dev), T(g["n_src"]).to(dev), None, T(g["n_mask"]).to(dev))
+    assert rel_err(out, g["n_ncc"]) < 1e-5
+    rng = np.random.default_rng(3)
+    w = torch.tensor(rng.standard_normal(g["n_ncc"].shape), dtype=torch.float32)
+    r64 = T(g["n_ref"]).double().requires_grad_(True)
+    s64 = T(g["n_src"]).double().requires_grad_(True)
+    (oracle.NCC(r64, s64, None, T(g["n_mask"]).double()) * w.double()).sum().backward()
+    rg = T(g["n_ref"]).to(dev).requires_grad_(True)
+    sg = T(g["n_src"]).to(dev).requires_grad_(True)
+    (NCC(rg, sg, None, T(g["n_mask"]).to(dev)) * w.to(dev)).sum().backward()
+    assert rel_err(rg.grad, r64.grad) < TOL and rel_err(sg.grad, s64.grad) < TOL
