@@ -27,7 +27,8 @@ int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const 
                 hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const unsigned char*, const float*,
                 const unsigned char*, int, int, int, int, float*, const float*, float*, hipStream_t);
-int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, hipStream_t);
+int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, const float*,
+                            float*, hipStream_t);
 int normals_bwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, float*,
                             float*, hipStream_t);
 int edge_hinge_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, int, float, float, float, float*,
@@ -37,11 +38,11 @@ int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, 
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
-int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, int, int, int, int,
+int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, int, int, int, int,
                    const unsigned char*, const unsigned long long*, float*, float*, float*, int*, hipStream_t);
 int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const unsigned char*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
-int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*, const float*,
+int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*,
                  int, int, int, int, int, const unsigned long long*, const int*, float*, hipStream_t);
 int vertex_gather_impl(const float*, const int*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const float*,
                        const float*, int, int, int, int, int, int, float*, float*, float*, float*, hipStream_t);
@@ -49,7 +50,7 @@ int finish_losses_impl(float*, const float*, const float*, const float*, int, fl
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
         g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
 };
 
@@ -69,6 +70,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.vertices = take(off, V * 12);
     L.nsum = take(off, V * 12);
     L.normals = take(off, V * 12);
+    L.attr8 = take(off, V * 32);
     L.pos = take(off, nV * 16);
     L.snap = take(off, nV * 8);
     L.silh = take(off, (size_t)d->n * d->F);
@@ -204,7 +206,8 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     {
         ProfScope ps(FMHR_SLOT_GEOMETRY, st);
         TRY(add_delta_impl(vertices_tmp, delta, d->V * 3, vertices, st));
-        TRY(normals_fwd_gather_impl(vertices, tri, vf_ptr, vf_idx, d->V, (float*)(w + L.nsum), (float*)(w + L.normals), st));
+        TRY(normals_fwd_gather_impl(vertices, tri, vf_ptr, vf_idx, d->V, (float*)(w + L.nsum), (float*)(w + L.normals), albedo,
+                                    (float*)(w + L.attr8), st));
         TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), st));
     }
     TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
@@ -213,7 +216,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
         TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, st));
-        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.normals), albedo, sh, mask, d->n, d->F, d->H, d->W, act, covw,
+        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.attr8), sh, mask, d->n, d->F, d->H, d->W, act, covw,
                            (float*)(w + L.shaded), (float*)(w + L.aa), (float*)(w + L.partials), n_valid_local, st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
@@ -269,7 +272,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     {
         // shade + interpolate + rasterize backward, gather style: per-pixel records, then one lane per (view, vertex)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
-        TRY(pix_bwd_impl(rast, tri, pos, (float*)(w + L.normals), albedo, sh, mask, (float*)(w + L.g_shaded), d->n, d->V, d->F,
+        TRY(pix_bwd_impl(rast, tri, pos, (float*)(w + L.attr8), sh, mask, (float*)(w + L.g_shaded), d->n, d->V, d->F,
                          d->H, d->W, (const unsigned long long*)(w + L.covw), (const int*)(w + L.next), (float*)(w + L.rec), st));
         TRY(vertex_gather_impl((float*)(w + L.rec), (int*)(w + L.head), vf_ptr, vf_idx, vc_ptr, ck, (const float*)(w + L.cmat),
                                gvert_aa, d->n, npad, d->V, d->n_chunks, d->H, d->W, (float*)(w + L.part), nullptr, nullptr, nullptr,

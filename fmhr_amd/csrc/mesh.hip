@@ -368,7 +368,8 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
 // summation order.  The face-scatter forms above took ~40 us each on atomics into a 0.6 MB array; these take a few us.
 __global__ void __launch_bounds__(kBlock)
 k_normals_gather(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
-                 const int32_t* __restrict__ vf_idx, int V, float* __restrict__ nsum, float* __restrict__ normals)
+                 const int32_t* __restrict__ vf_idx, int V, float* __restrict__ nsum, float* __restrict__ normals,
+                 const float* __restrict__ albedo, float4* __restrict__ attr8)
 {
     int v = blockIdx.x * kBlock + threadIdx.x;
     if (v >= V) return;
@@ -386,6 +387,10 @@ k_normals_gather(const float* __restrict__ verts, const int32_t* __restrict__ tr
     float len = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
     float inv = 1.0f / fmaxf(len, 1e-6f);
     normals[(size_t)v * 3] = acc.x * inv; normals[(size_t)v * 3 + 1] = acc.y * inv; normals[(size_t)v * 3 + 2] = acc.z * inv;
+    if (attr8 != nullptr) {     // packed per-vertex attributes for the pixel kernels: (normal.xyz, albedo.x | albedo.yz, 0, 0)
+        attr8[(size_t)v * 2] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, albedo[(size_t)v * 3]);
+        attr8[(size_t)v * 2 + 1] = make_float4(albedo[(size_t)v * 3 + 1], albedo[(size_t)v * 3 + 2], 0.f, 0.f);
+    }
 }
 
 // gverts[v] += sum over incident faces of this vertex's share of d(sum_k g_s[i_k] . cross_k)/d verts
@@ -625,10 +630,10 @@ int mesh_tail_impl(const MeshTailArgs& A, float* gdelta, float* galbedo, hipStre
 
 // ---- internal launchers used by ham_step.hip
 int normals_fwd_gather_impl(const float* verts, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, int V,
-                            float* nsum, float* normals, hipStream_t st)
+                            float* nsum, float* normals, const float* albedo, float* attr8, hipStream_t st)
 {
     if (V == 0) return FMHR_OK;
-    k_normals_gather<<<cdiv(V, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, nsum, normals);
+    k_normals_gather<<<cdiv(V, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, (float4*)attr8);
     FMHR_CHECK_LAUNCH("k_normals_gather");
     return FMHR_OK;
 }

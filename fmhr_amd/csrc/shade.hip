@@ -9,6 +9,11 @@
 
 namespace fmhr {
 
+// value-only kernels: hardware reciprocal / square root (1 ulp) instead of the correctly rounded expansions (~10 dependent
+// instructions each) — the per-pixel kernels are bound by dependent ALU latency, and nothing discrete hangs on these values
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 __device__ __forceinline__ float sh9c(const float* c, float x, float y, float z)
 {
     float r = c[0];
@@ -35,22 +40,30 @@ struct PixShade {
 
 __device__ __forceinline__ float3 ld3f(const float* p) { return make_float3(p[0], p[1], p[2]); }
 
-__device__ __forceinline__ void shade_eval(const float4 r, const int32_t* __restrict__ tri, const float* __restrict__ normals,
-                                           const float* __restrict__ albedo, const float* __restrict__ shc, PixShade& s)
+// attr8 [V,2] float4 = (normal.xyz, albedo.x | albedo.yz, 0, 0): two 16-B gathers per vertex instead of six 4-B ones (the pixel
+// kernels were bound by the number of load requests, not by bytes)
+__device__ __forceinline__ void shade_eval(const float4 r, const int32_t* __restrict__ tri, const float4* __restrict__ attr8,
+                                           const float* __restrict__ shc, PixShade& s)
 {
     int t = (int)r.w - 1;
     s.i0 = tri[t * 3]; s.i1 = tri[t * 3 + 1]; s.i2 = tri[t * 3 + 2];
     s.b0 = r.x; s.b1 = r.y; s.b2 = 1.0f - r.x - r.y;
-    s.n0 = ld3f(normals + (size_t)s.i0 * 3); s.n1 = ld3f(normals + (size_t)s.i1 * 3); s.n2 = ld3f(normals + (size_t)s.i2 * 3);
-    s.a0 = ld3f(albedo + (size_t)s.i0 * 3); s.a1 = ld3f(albedo + (size_t)s.i1 * 3); s.a2 = ld3f(albedo + (size_t)s.i2 * 3);
+    {
+        const float4 q0 = attr8[(size_t)s.i0 * 2], q1 = attr8[(size_t)s.i0 * 2 + 1];
+        const float4 u0 = attr8[(size_t)s.i1 * 2], u1 = attr8[(size_t)s.i1 * 2 + 1];
+        const float4 w0 = attr8[(size_t)s.i2 * 2], w1 = attr8[(size_t)s.i2 * 2 + 1];
+        s.n0 = make_float3(q0.x, q0.y, q0.z); s.a0 = make_float3(q0.w, q1.x, q1.y);
+        s.n1 = make_float3(u0.x, u0.y, u0.z); s.a1 = make_float3(u0.w, u1.x, u1.y);
+        s.n2 = make_float3(w0.x, w0.y, w0.z); s.a2 = make_float3(w0.w, w1.x, w1.y);
+    }
     s.nx = s.b0 * s.n0.x + s.b1 * s.n1.x + s.b2 * s.n2.x;
     s.ny = s.b0 * s.n0.y + s.b1 * s.n1.y + s.b2 * s.n2.y;
     s.nz = s.b0 * s.n0.z + s.b1 * s.n1.z + s.b2 * s.n2.z;
     s.ar = s.b0 * s.a0.x + s.b1 * s.a1.x + s.b2 * s.a2.x;
     s.ag = s.b0 * s.a0.y + s.b1 * s.a1.y + s.b2 * s.a2.y;
     s.ab = s.b0 * s.a0.z + s.b1 * s.a1.z + s.b2 * s.a2.z;
-    s.len = sqrtf(s.nx * s.nx + s.ny * s.ny + s.nz * s.nz);
-    float inv = 1.0f / fmaxf(s.len, 1e-12f);                 // F.normalize(p=2, dim=3), default eps (:273)
+    s.len = fsqrt(s.nx * s.nx + s.ny * s.ny + s.nz * s.nz);
+    float inv = frcp(fmaxf(s.len, 1e-12f));                  // F.normalize(p=2, dim=3), default eps (:273)
     s.hx = s.nx * inv; s.hy = s.ny * inv; s.hz = s.nz * inv;
     s.rad = sh9c(shc, s.hx, s.hy, s.hz);
 }
@@ -117,8 +130,8 @@ k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __re
 // forward: rast -> rgba (rgb = shaded image, zero outside valid = mask>0 & covered; a = the interpolated ones attribute),
 // written twice (the second copy is the antialias accumulation target); local valid count
 __global__ void __launch_bounds__(kBlock)
-k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ normals,
-            const float* __restrict__ albedo, const float* __restrict__ sh, const float* __restrict__ mask,
+k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float4* __restrict__ attr8,
+            const float* __restrict__ sh, const float* __restrict__ mask,
             int n, int F, long long P, const unsigned char* __restrict__ act, const unsigned long long* __restrict__ covw,
             float4* __restrict__ shaded, float4* __restrict__ aa_init, float* __restrict__ part_cnt)
 {
@@ -140,7 +153,7 @@ k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, co
 #pragma unroll
                 for (int k = 0; k < 9; k++) shc[k] = sh[(size_t)b * 9 + k];
                 PixShade s;
-                shade_eval(r, tri, normals, albedo, shc, s);
+                shade_eval(r, tri, attr8, shc, s);
                 o.x = s.rad * s.ar; o.y = s.rad * s.ag; o.z = s.rad * s.ab;
                 cnt = 1.f;
             }
@@ -224,7 +237,7 @@ __global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__
 // gather from the pixel index).  The link of the pixel's per-face list rides in the record, so a gather visit is one line.
 __global__ void __launch_bounds__(kBlock)
 k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ pos,
-          const float* __restrict__ normals, const float* __restrict__ albedo, const float* __restrict__ sh,
+          const float4* __restrict__ attr8, const float* __restrict__ sh,
           const float* __restrict__ mask, const float4* __restrict__ g_shaded, int n, int V, int F, int H, int W,
           const unsigned long long* __restrict__ covw, const int* __restrict__ next, float4* __restrict__ rec)
 {
@@ -249,7 +262,7 @@ k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, cons
 #pragma unroll
     for (int k = 0; k < 9; k++) c[k] = sh[(size_t)b * 9 + k];
     PixShade s;
-    shade_eval(r, tri, normals, albedo, c, s);
+    shade_eval(r, tri, attr8, c, s);
     float g_rad = g.x * s.ar + g.y * s.ag + g.z * s.ab;
     float ga0 = g.x * s.rad, ga1 = g.y * s.rad, ga2 = g.z * s.rad;
     float x = s.hx, y = s.hy, z = s.hz;
@@ -259,7 +272,7 @@ k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, cons
     float ghx = g_rad * dx, ghy = g_rad * dy, ghz = g_rad * dz;
     float gnx, gny, gnz;
     if (s.len > 1e-12f) {
-        float inv = 1.0f / s.len;
+        float inv = frcp(s.len);
         float dt = x * ghx + y * ghy + z * ghz;
         gnx = (ghx - x * dt) * inv; gny = (ghy - y * dt) * inv; gnz = (ghz - z * dt) * inv;
     } else {
@@ -279,7 +292,7 @@ k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, cons
     float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
     float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
     float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
-    float iw = 1.0f / (e0 + e1 + e2);
+    float iw = frcp(e0 + e1 + e2);
     float bb0 = e0 * iw, bb1 = e1 * iw;
     float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * bb0 + gb1 * bb1;
     float q0x = gbb * (p2y - p1y) - gb1 * p2y;
@@ -449,14 +462,14 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
     return FMHR_OK;
 }
 
-int shade_fwd_impl(const float* rast, const int32_t* tri, const float* normals, const float* albedo, const float* sh,
+int shade_fwd_impl(const float* rast, const int32_t* tri, const float* attr8, const float* sh,
                    const float* mask, int n, int F, int H, int W, const unsigned char* act, const unsigned long long* covw,
                    float* shaded, float* aa_init, float* part_cnt, int* n_valid, hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0) return FMHR_OK;
     int nb = cdiv(n * P, kBlock);
-    k_shade_fwd<<<nb, kBlock, 0, st>>>((const float4*)rast, tri, normals, albedo, sh, mask, n, F, P, act, covw,
+    k_shade_fwd<<<nb, kBlock, 0, st>>>((const float4*)rast, tri, (const float4*)attr8, sh, mask, n, F, P, act, covw,
                                        (float4*)shaded, (float4*)aa_init, part_cnt);
     FMHR_CHECK_LAUNCH("k_shade_fwd");
     k_reduce_count<<<1, 1024, 0, st>>>(part_cnt, nb, n_valid);
@@ -476,13 +489,13 @@ int loss_pix_impl(const float* shaded, const float* aa, const float* img, const 
     return FMHR_OK;
 }
 
-int pix_bwd_impl(const float* rast, const int32_t* tri, const float* pos, const float* normals, const float* albedo,
+int pix_bwd_impl(const float* rast, const int32_t* tri, const float* pos, const float* attr8,
                  const float* sh, const float* mask, const float* g_shaded, int n, int V, int F, int H, int W,
                  const unsigned long long* covw, const int* next, float* rec, hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0 || F == 0) return FMHR_OK;
-    k_pix_bwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, pos, normals, albedo, sh, mask,
+    k_pix_bwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, pos, (const float4*)attr8, sh, mask,
                                                      (const float4*)g_shaded, n, V, F, H, W, covw, next, (float4*)rec);
     FMHR_CHECK_LAUNCH("k_pix_bwd");
     return FMHR_OK;
