@@ -313,21 +313,17 @@ __device__ __forceinline__ void queue_push(bool has, int4 item, float alpha, int
     }
 }
 
+// forward for one pixel: its right and lower pair.  `live` = the pixel exists (lanes of a partial last wave are not)
 template <int CA, int CB>
-__global__ void __launch_bounds__(kBlock)
-k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, const float4* __restrict__ rast,
+__device__ __forceinline__ void aa_fwd_pixel(long long gid, bool live, const float* __restrict__ colorA,
+         const float* __restrict__ colorB, const float4* __restrict__ rast,
          const float* __restrict__ pos, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
-         const unsigned char* __restrict__ silh, const unsigned char* __restrict__ act,
-         const unsigned long long* __restrict__ covw,
+         const unsigned char* __restrict__ silh, const unsigned long long* __restrict__ covw,
          int n, int V, int F, int H, int W, int Cdyn, float* __restrict__ outA, float* __restrict__ outB,
          int4* __restrict__ items, float* __restrict__ alphas, int32_t* counter, int cap,
          unsigned char* __restrict__ px_code, float* __restrict__ px_alpha)
 {
     long long P = (long long)H * W;
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    // sparse mode (fused step): inactive 64-pixel segments hold no covered pixel and no neighbour of one -> no pair can blend
-    if (act != nullptr && (gid - (gid & 63) >= (long long)n * P || __builtin_amdgcn_readfirstlane((int)act[gid >> 6]) == 0)) return;
-    bool live = gid < (long long)n * P;
     int b = 0, px = 0, py = 0;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
@@ -378,6 +374,36 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
         } else {
             queue_push(has, make_int4(px, py, b, code), alpha, counter, cap, items, alphas);
         }
+    }
+}
+
+// generic op: one lane per pixel of the dense image
+template <int CA, int CB>
+__global__ void __launch_bounds__(kBlock)
+k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, const float4* __restrict__ rast,
+         const float* __restrict__ pos, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
+         int n, int V, int F, int H, int W, int Cdyn, float* __restrict__ outA, float* __restrict__ outB,
+         int4* __restrict__ items, float* __restrict__ alphas, int32_t* counter, int cap)
+{
+    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    aa_fwd_pixel<CA, CB>(gid, gid < (long long)n * H * W, colorA, colorB, rast, pos, tri, opp, nullptr, nullptr, n, V, F, H, W, Cdyn,
+                         outA, outB, items, alphas, counter, cap, nullptr, nullptr);
+}
+
+// fused step: persistent waves over the compacted list of active 64-pixel segments, rgba colour, in-place items
+__global__ void __launch_bounds__(kBlock)
+k_aa_fwd_list(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
+              const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
+              const int* __restrict__ act_list, const int* __restrict__ act_count, const unsigned long long* __restrict__ covw,
+              int n, int V, int F, int H, int W, float* __restrict__ out, unsigned char* __restrict__ px_code,
+              float* __restrict__ px_alpha)
+{
+    const int count = *act_count, lane = threadIdx.x & 63;
+    const long long N = (long long)n * H * W;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
+        const long long gid = ((long long)act_list[i] << 6) + lane;
+        aa_fwd_pixel<4, 0>(gid, gid < N, color, nullptr, rast, pos, tri, opp, silh, covw, n, V, F, H, W, 4, out, nullptr, nullptr,
+                           nullptr, nullptr, 0, px_code, px_alpha);
     }
 }
 
@@ -475,24 +501,26 @@ k_aa_bwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
     }
 }
 
-// backward over in-place items (fused step): one lane per pixel of the active segments, two item slots per pixel
+// backward over in-place items (fused step): persistent waves over the active segments, two item slots per pixel
 __global__ void __launch_bounds__(kBlock)
 k_aa_bwd_px(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
             const int32_t* __restrict__ tri, const float* __restrict__ dy, const unsigned char* __restrict__ px_code,
-            const float* __restrict__ px_alpha, const unsigned char* __restrict__ act, int n, int V, int H, int W,
-            float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert)
+            const float* __restrict__ px_alpha, const int* __restrict__ act_list, const int* __restrict__ act_count, int n, int V,
+            int H, int W, float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert)
 {
     long long P = (long long)H * W;
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (gid - (gid & 63) >= (long long)n * P || __builtin_amdgcn_readfirstlane((int)act[gid >> 6]) == 0) return;
-    if (gid >= (long long)n * P) return;
-    uchar2 cd = reinterpret_cast<const uchar2*>(px_code)[gid];
-    if ((cd.x | cd.y) == 0) return;
-    int b = (int)(gid / P);
-    int rem = (int)(gid - (long long)b * P);
-    int py = rem / W, px = rem - py * W;
-    if (cd.x) aa_bwd_item<4, 0>(px, py, b, cd.x, px_alpha[gid * 2], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
-    if (cd.y) aa_bwd_item<4, 0>(px, py, b, cd.y, px_alpha[gid * 2 + 1], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
+    const int count = *act_count, lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
+        const long long gid = ((long long)act_list[i] << 6) + lane;
+        if (gid >= (long long)n * P) continue;
+        uchar2 cd = reinterpret_cast<const uchar2*>(px_code)[gid];
+        if ((cd.x | cd.y) == 0) continue;
+        int b = (int)(gid / P);
+        int rem = (int)(gid - (long long)b * P);
+        int py = rem / W, px = rem - py * W;
+        if (cd.x) aa_bwd_item<4, 0>(px, py, b, cd.x, px_alpha[gid * 2], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
+        if (cd.y) aa_bwd_item<4, 0>(px, py, b, cd.y, px_alpha[gid * 2 + 1], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
+    }
 }
 
 static unsigned table_size(int F)
@@ -515,25 +543,24 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
     return FMHR_OK;
 }
 
-// fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour), in-place items
+// fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour), in-place items,
+// persistent grids over the active-segment list
 int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
-                const unsigned char* silh, const unsigned char* act, const unsigned long long* covw, int n, int V, int F, int H,
-                int W, float* out, unsigned char* px_code, float* px_alpha, hipStream_t st)
+                const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw, int n,
+                int V, int F, int H, int W, float* out, unsigned char* px_code, float* px_alpha, hipStream_t st)
 {
-    long long nP = (long long)n * H * W;
-    k_aa_fwd<4, 0><<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, nullptr, (const float4*)rast, pos, tri, opp, silh, act, covw, n, V, F,
-                                                       H, W, 4, out, nullptr, nullptr, nullptr, nullptr, 0, px_code, px_alpha);
-    FMHR_CHECK_LAUNCH("k_aa_fwd<4>");
+    k_aa_fwd_list<<<2048, kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
+                                           out, px_code, px_alpha);
+    FMHR_CHECK_LAUNCH("k_aa_fwd_list");
     return FMHR_OK;
 }
 
 int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
-                const unsigned char* px_code, const float* px_alpha, const unsigned char* act, int n, int V, int H, int W,
-                float* gcolor, const float* cmat, float* gvert, hipStream_t st)
+                const unsigned char* px_code, const float* px_alpha, const int* act_list, const int* act_count, int n, int V,
+                int H, int W, float* gcolor, const float* cmat, float* gvert, hipStream_t st)
 {
-    long long nP = (long long)n * H * W;
-    k_aa_bwd_px<<<cdiv(nP, kBlock), kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, dy, px_code, px_alpha, act, n, V, H, W,
-                                                    gcolor, (const float4*)cmat, gvert);
+    k_aa_bwd_px<<<2048, kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, dy, px_code, px_alpha, act_list, act_count, n, V, H, W,
+                                         gcolor, (const float4*)cmat, gvert);
     FMHR_CHECK_LAUNCH("k_aa_bwd_px");
     return FMHR_OK;
 }
@@ -659,9 +686,9 @@ extern "C" int fmhr_antialias_fwd(const float* color, const float* rast, const f
     int grid = cdiv(nP, kBlock);
     int4* it = (int4*)items;
     const float4* r4 = (const float4*)rast;
-    if (C == 1) k_aa_fwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap, nullptr, nullptr);
-    else if (C == 3) k_aa_fwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap, nullptr, nullptr);
-    else k_aa_fwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, nullptr, nullptr, nullptr, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap, nullptr, nullptr);
+    if (C == 1) k_aa_fwd<1, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    else if (C == 3) k_aa_fwd<3, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
+    else k_aa_fwd<0, 0><<<grid, kBlock, 0, st>>>(color, nullptr, r4, pos, tri, opp, n, V, F, H, W, C, out, nullptr, it, alphas, counter, cap);
     FMHR_CHECK_LAUNCH("k_aa_fwd");
     return FMHR_OK;
 }

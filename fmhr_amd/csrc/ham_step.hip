@@ -20,13 +20,13 @@ int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
                        void*, int*, int*, int, unsigned char*, unsigned long long*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
-int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, hipStream_t);
+int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, int*,
+                         hipStream_t);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
-int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*,
-                const unsigned char*, const unsigned long long*, int, int, int, int, int, float*, unsigned char*, float*,
-                hipStream_t);
+int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
+                const int*, const unsigned long long*, int, int, int, int, int, float*, unsigned char*, float*, hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const unsigned char*, const float*,
-                const unsigned char*, int, int, int, int, float*, const float*, float*, hipStream_t);
+                const int*, const int*, int, int, int, int, float*, const float*, float*, hipStream_t);
 int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, const float*,
                             float*, hipStream_t);
 int normals_bwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, float*,
@@ -38,19 +38,19 @@ int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, 
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
-int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, int, int, int, int,
-                   const unsigned char*, const unsigned long long*, float*, float*, float*, int*, hipStream_t);
-int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const unsigned char*,
+int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, int, int, int, int, const int*,
+                   const int*, const unsigned long long*, float*, float*, float*, int*, hipStream_t);
+int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
 int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*,
-                 int, int, int, int, int, const unsigned long long*, const int*, float*, hipStream_t);
+                 int, int, int, int, int, const unsigned long long*, const int*, const int*, const int*, float*, hipStream_t);
 int vertex_gather_impl(const float*, const int*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const float*,
                        const float*, int, int, int, int, int, int, float*, float*, float*, float*, hipStream_t);
 int finish_losses_impl(float*, const float*, const float*, const float*, int, float, float, float, hipStream_t);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
         g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
 };
 
@@ -79,6 +79,9 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.covw = take(off, ((nP + 63) / 64) * 8);
     L.act = take(off, (nP + 63) / 64);
     L.vmnz = take(off, (nP + 63) / 64);
+    L.act_list = take(off, ((nP + 63) / 64) * 4);
+    L.cov_list = take(off, ((nP + 63) / 64) * 4);
+    L.act_count = take(off, 16);
     L.head = take(off, (size_t)npad * d->F * 4);   // pixel-list heads, face-major, views innermost (padded to 8)
     L.next = take(off, nP * 4);
     L.rast = take(off, nP * 16);
@@ -93,7 +96,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.cmat = take(off, (size_t)d->n * 48);
     L.gvert_aa = take(off, V * 12);
     L.part = take(off, (size_t)(npad / 8) * (size_t)(d->n_chunks > 0 ? d->n_chunks : 1) * 48);
-    L.partials = take(off, ((nP + 255) / 256) * 4 * 3);
+    L.partials = take(off, 2048 * 4 * 3);           // per-workgroup partial sums of the persistent pixel kernels
     L.gnormal = take(off, V * 12);
     L.gvert = take(off, V * 12);
     L.gtmp = take(off, V * 12);
@@ -215,12 +218,16 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
-        TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, st));
-        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.attr8), sh, mask, d->n, d->F, d->H, d->W, act, covw,
+        HIPTRY(hipMemsetAsync(w + L.act_count, 0, 8, st), "memset act_count");
+        TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, (int*)(w + L.act_list),
+                                 (int*)(w + L.act_count), (int*)(w + L.cov_list), st));
+        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.attr8), sh, mask, d->n, d->F, d->H, d->W, (const int*)(w + L.act_list),
+                           (const int*)(w + L.act_count), covw,
                            (float*)(w + L.shaded), (float*)(w + L.aa), (float*)(w + L.partials), n_valid_local, st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
-    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), act, covw, d->n, d->V, d->F,
+    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
+                    (const int*)(w + L.act_count), covw, d->n, d->V, d->F,
                     d->H, d->W, (float*)(w + L.aa), (unsigned char*)(w + L.aa_items), (float*)(w + L.aa_alphas), st));
     return FMHR_OK;
 }
@@ -251,14 +258,14 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     float* gvert = (float*)(w + L.gvert);
     size_t nP = (size_t)d->n * d->H * d->W, V = d->V;
     const float rg = wt->reg_grad_scale;
-    const size_t nB = (nP + 255) / 256;
+    const size_t nB = 2048;
 
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
         HIPTRY(hipMemsetAsync(gvert_aa, 0, V * 12, st), "memset gvert_aa");
         // losses on the antialiased rgba + their per-pixel gradients (written twice: g_aa and the AA-backward target)
         TRY(loss_pix_impl((float*)(w + L.shaded), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
-                          (const unsigned char*)(w + L.act), n_valid_global,
+                          (const int*)(w + L.act_list), (const int*)(w + L.act_count), n_valid_global,
                           wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa), (float*)(w + L.g_shaded),
                           (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, losses, st));
     }
@@ -266,14 +273,16 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads (clip-transformed) into gvert_aa
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
         TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (float*)(w + L.g_aa), (const unsigned char*)(w + L.aa_items),
-                        (const float*)(w + L.aa_alphas), (const unsigned char*)(w + L.act), d->n, d->V, d->H, d->W,
+                        (const float*)(w + L.aa_alphas), (const int*)(w + L.act_list), (const int*)(w + L.act_count), d->n, d->V,
+                        d->H, d->W,
                         (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, st));
     }
     {
         // shade + interpolate + rasterize backward, gather style: per-pixel records, then one lane per (view, vertex)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
         TRY(pix_bwd_impl(rast, tri, pos, (float*)(w + L.attr8), sh, mask, (float*)(w + L.g_shaded), d->n, d->V, d->F,
-                         d->H, d->W, (const unsigned long long*)(w + L.covw), (const int*)(w + L.next), (float*)(w + L.rec), st));
+                         d->H, d->W, (const unsigned long long*)(w + L.covw), (const int*)(w + L.next), (const int*)(w + L.cov_list),
+                         (const int*)(w + L.act_count) + 1, (float*)(w + L.rec), st));
         TRY(vertex_gather_impl((float*)(w + L.rec), (int*)(w + L.head), vf_ptr, vf_idx, vc_ptr, ck, (const float*)(w + L.cmat),
                                gvert_aa, d->n, npad, d->V, d->n_chunks, d->H, d->W, (float*)(w + L.part), nullptr, nullptr, nullptr,
                                st));

@@ -90,13 +90,10 @@ k_valid_mask_segments(const float* __restrict__ valid_mask, long long N, unsigne
     if ((threadIdx.x & 63) == 0) vmnz[gid >> 6] = bal != 0ull ? 1 : 0;
 }
 
-// one lane per segment: active = own coverage | 4-neighbour coverage | valid_mask flag (seven independent word loads)
-__global__ void __launch_bounds__(kBlock)
-k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
-                  unsigned char* __restrict__ act)
+// active = own coverage | 4-neighbour coverage | valid_mask flag (seven independent word loads)
+__device__ __forceinline__ bool segment_is_active(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz,
+                                                  long long nSeg, int W, long long seg, unsigned char* __restrict__ act)
 {
-    long long seg = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (seg >= nSeg) return;
     long long s0 = seg << 6, up = s0 - W, dn = s0 + W;
     long long wu = up >> 6, wd = dn >> 6;               // arithmetic shift = floor, also for negative `up`
     int su = (int)(up & 63), sd = (int)(dn & 63);
@@ -107,12 +104,49 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
     any |= (u0 >> su) | (su ? (u1 << (64 - su)) : 0ull);   // covered pixels among [s0-W, s0-W+63]
     any |= (d0 >> sd) | (sd ? (d1 << (64 - sd)) : 0ull);   // and among [s0+W, s0+W+63]
     act[seg] = any != 0ull ? 1 : 0;
+    return any != 0ull;
+}
+
+// one lane per segment; the active ones are also compacted into act_list (order arbitrary) so that the per-pixel kernels
+// run as persistent loops over exactly the active segments: 2/3 of a frame's 197k waves would only be launched to exit
+__global__ void __launch_bounds__(kBlock)
+k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
+                  unsigned char* __restrict__ act, int* __restrict__ act_list, int* __restrict__ act_count,
+                  int* __restrict__ cov_list)
+{
+    // act_count[0] = number of active segments (act_list), act_count[1] = number of COVERED segments (cov_list)
+    __shared__ int wcnt[4], ccnt[4];
+    __shared__ int base, cbase;
+    long long seg = (long long)blockIdx.x * kBlock + threadIdx.x;
+    bool a = (seg < nSeg) && segment_is_active(covw, vmnz, nSeg, W, seg, act);
+    bool cv = a && covw[seg] != 0ull;
+    unsigned long long bal = __ballot(a), cbal = __ballot(cv);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { wcnt[wv] = __popcll(bal); ccnt[wv] = __popcll(cbal); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base = atomicAdd(act_count, wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+        cbase = atomicAdd(act_count + 1, ccnt[0] + ccnt[1] + ccnt[2] + ccnt[3]);
+    }
+    __syncthreads();
+    if (a) {
+        int off = base + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int i = 0; i < wv; i++) off += wcnt[i];
+        act_list[off] = (int)seg;
+    }
+    if (cv) {
+        int off = cbase + __popcll(cbal & ((1ull << lane) - 1ull));
+        for (int i = 0; i < wv; i++) off += ccnt[i];
+        cov_list[off] = (int)seg;
+    }
 }
 
 __device__ __forceinline__ bool seg_active(const unsigned char* __restrict__ act, long long gid)
 {
     return __builtin_amdgcn_readfirstlane((int)act[gid >> 6]) != 0;
 }
+
+constexpr int kPersistBlocks = 2048;      // persistent per-pixel kernels: 8 workgroups per CU, waves loop over act_list
 
 // test/inspection helper: make the sparse buffers dense (zeros wherever the step did not write)
 __global__ void __launch_bounds__(kBlock)
@@ -132,14 +166,18 @@ k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __re
 __global__ void __launch_bounds__(kBlock)
 k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float4* __restrict__ attr8,
             const float* __restrict__ sh, const float* __restrict__ mask,
-            int n, int F, long long P, const unsigned char* __restrict__ act, const unsigned long long* __restrict__ covw,
+            int n, int F, long long P, const int* __restrict__ act_list, const int* __restrict__ act_count,
+            const unsigned long long* __restrict__ covw,
             float4* __restrict__ shaded, float4* __restrict__ aa_init, float* __restrict__ part_cnt)
 {
     __shared__ float sm[4];
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int count = *act_count, lane = threadIdx.x & 63;
     float cnt = 0.f;
-    if (gid - (gid & 63) < (long long)n * P && seg_active(act, gid) && gid < (long long)n * P) {
-        const bool covered = (covw[gid >> 6] >> (gid & 63)) & 1ull;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
+        const long long seg = act_list[i];
+        const long long gid = (seg << 6) + lane;
+        if (gid >= (long long)n * P) continue;
+        const bool covered = (covw[seg] >> lane) & 1ull;
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (covered) r = rast[gid];
         int t = (int)r.w - 1;
@@ -155,14 +193,14 @@ k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, co
                 PixShade s;
                 shade_eval(r, tri, attr8, shc, s);
                 o.x = s.rad * s.ar; o.y = s.rad * s.ag; o.z = s.rad * s.ab;
-                cnt = 1.f;
+                cnt += 1.f;
             }
         }
         shaded[gid] = o;
         aa_init[gid] = o;
     }
     float s = block_sum(cnt, sm);
-    if (threadIdx.x == 0) part_cnt[blockIdx.x] = s;        // per-block partial: 49k same-address atomics serialise at ~10 ns each
+    if (threadIdx.x == 0) part_cnt[blockIdx.x] = s;        // per-block partial: same-address atomics serialise at ~10 ns each
 }
 
 // losses + their per-pixel gradients over the active segments:
@@ -172,29 +210,31 @@ k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, co
 __global__ void __launch_bounds__(kBlock)
 k_loss_pix(const float4* __restrict__ shaded, const float4* __restrict__ aa, const float* __restrict__ img,
            const float* __restrict__ mask, const float* __restrict__ valid_mask, long long N,
-           const unsigned char* __restrict__ act, const float* __restrict__ n_valid_global, float w_sfs, float w_mask,
-           float mse_den, float4* __restrict__ g_aa, float4* __restrict__ g_shaded, float* __restrict__ part_l1,
-           float* __restrict__ part_l2, float* __restrict__ losses)
+           const int* __restrict__ act_list, const int* __restrict__ act_count, const float* __restrict__ n_valid_global,
+           float w_sfs, float w_mask, float mse_den, float4* __restrict__ g_aa, float4* __restrict__ g_shaded,
+           float* __restrict__ part_l1, float* __restrict__ part_l2, float* __restrict__ losses)
 {
     __shared__ float sm[4];
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int count = *act_count, lane = threadIdx.x & 63;
     float l1 = 0.f, l2 = 0.f;
     float den = 3.0f * n_valid_global[0];
     float k1 = (den > 0.f) ? w_sfs / den : 0.f;
     float k2 = w_mask / mse_den;
-    if (gid - (gid & 63) < N && seg_active(act, gid) && gid < N) {
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
+        const long long gid = ((long long)act_list[i] << 6) + lane;
+        if (gid >= N) continue;
         float4 a = aa[gid];
         float cov = shaded[gid].w;                            // != 0 exactly where the pixel is covered
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mask[gid] > 0.f && cov != 0.f) {
             float d0 = a.x - img[gid * 3], d1 = a.y - img[gid * 3 + 1], d2 = a.z - img[gid * 3 + 2];
-            l1 = fabsf(d0) + fabsf(d1) + fabsf(d2);
+            l1 += fabsf(d0) + fabsf(d1) + fabsf(d2);
             g.x = (d0 > 0.f) ? k1 : ((d0 < 0.f) ? -k1 : 0.f);
             g.y = (d1 > 0.f) ? k1 : ((d1 < 0.f) ? -k1 : 0.f);
             g.z = (d2 > 0.f) ? k1 : ((d2 < 0.f) ? -k1 : 0.f);
         }
         float dm = a.w - valid_mask[gid];
-        l2 = dm * dm;
+        l2 += dm * dm;
         g.w = 2.0f * dm * k2;
         g_aa[gid] = g;
         g_shaded[gid] = g;
@@ -239,12 +279,18 @@ __global__ void __launch_bounds__(kBlock)
 k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ pos,
           const float4* __restrict__ attr8, const float* __restrict__ sh,
           const float* __restrict__ mask, const float4* __restrict__ g_shaded, int n, int V, int F, int H, int W,
-          const unsigned long long* __restrict__ covw, const int* __restrict__ next, float4* __restrict__ rec)
+          const unsigned long long* __restrict__ covw, const int* __restrict__ next, const int* __restrict__ act_list,
+          const int* __restrict__ act_count, float4* __restrict__ rec)
 {
+    // dense launch (one wave per 64-pixel segment, uncovered segments leave after one 8-B load): the persistent-loop form of
+    // the other pixel kernels was measured SLOWER here (157 vs 132 us) — this kernel is a long dependent chain per pixel and
+    // wants as many independent waves in flight as possible
     const long long P = (long long)H * W;
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    (void)act_list; (void)act_count;
+    {
     if (gid >= (long long)n * P) return;
-    if (!((covw[gid >> 6] >> (gid & 63)) & 1ull)) return;       // one 8-B word per wave: uncovered segments stop here
+    if (!((covw[gid >> 6] >> (gid & 63)) & 1ull)) return;
     float4 g = g_shaded[gid];
     float4* o = rec + gid * 4;
     const int link = next[gid];                        // the list link travels inside the record: one 64-B line per visit
@@ -305,6 +351,7 @@ k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, cons
     o[1] = make_float4(ga1, ga2, r.x, r.y);
     o[2] = make_float4(q0x, q0y, q1x, q1y);
     o[3] = make_float4(q2x, q2y, __int_as_float(link), 1.f);       // .w = 1: record carries gradients
+    }
 }
 
 // Gather: one lane per (chunk of <= 4 face corners of one vertex, group of kGroup views).  The list heads are stored
@@ -444,11 +491,11 @@ int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char
 }
 
 int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
-                         hipStream_t st)
+                         int* act_list, int* act_count, int* cov_list, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     long long nSeg = (N + 63) >> 6;
-    k_active_segments<<<cdiv(nSeg, kBlock), kBlock, 0, st>>>(covw, vmnz, nSeg, W, act);
+    k_active_segments<<<cdiv(nSeg, kBlock), kBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, cov_list);
     FMHR_CHECK_LAUNCH("k_active_segments");
     return FMHR_OK;
 }
@@ -463,13 +510,13 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
 }
 
 int shade_fwd_impl(const float* rast, const int32_t* tri, const float* attr8, const float* sh,
-                   const float* mask, int n, int F, int H, int W, const unsigned char* act, const unsigned long long* covw,
-                   float* shaded, float* aa_init, float* part_cnt, int* n_valid, hipStream_t st)
+                   const float* mask, int n, int F, int H, int W, const int* act_list, const int* act_count,
+                   const unsigned long long* covw, float* shaded, float* aa_init, float* part_cnt, int* n_valid, hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0) return FMHR_OK;
-    int nb = cdiv(n * P, kBlock);
-    k_shade_fwd<<<nb, kBlock, 0, st>>>((const float4*)rast, tri, (const float4*)attr8, sh, mask, n, F, P, act, covw,
+    int nb = kPersistBlocks;
+    k_shade_fwd<<<nb, kBlock, 0, st>>>((const float4*)rast, tri, (const float4*)attr8, sh, mask, n, F, P, act_list, act_count, covw,
                                        (float4*)shaded, (float4*)aa_init, part_cnt);
     FMHR_CHECK_LAUNCH("k_shade_fwd");
     k_reduce_count<<<1, 1024, 0, st>>>(part_cnt, nb, n_valid);
@@ -478,11 +525,11 @@ int shade_fwd_impl(const float* rast, const int32_t* tri, const float* attr8, co
 }
 
 int loss_pix_impl(const float* shaded, const float* aa, const float* img, const float* mask, const float* valid_mask,
-                  long long N, const unsigned char* act, const float* n_valid_global, float w_sfs, float w_mask, float mse_den,
-                  float* g_aa, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
+                  long long N, const int* act_list, const int* act_count, const float* n_valid_global, float w_sfs, float w_mask,
+                  float mse_den, float* g_aa, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_loss_pix<<<cdiv(N, kBlock), kBlock, 0, st>>>((const float4*)shaded, (const float4*)aa, img, mask, valid_mask, N, act,
+    k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>((const float4*)shaded, (const float4*)aa, img, mask, valid_mask, N, act_list, act_count,
                                                   n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_aa, (float4*)g_shaded, part_l1,
                                                   part_l2, losses);
     FMHR_CHECK_LAUNCH("k_loss_pix");
@@ -491,12 +538,14 @@ int loss_pix_impl(const float* shaded, const float* aa, const float* img, const 
 
 int pix_bwd_impl(const float* rast, const int32_t* tri, const float* pos, const float* attr8,
                  const float* sh, const float* mask, const float* g_shaded, int n, int V, int F, int H, int W,
-                 const unsigned long long* covw, const int* next, float* rec, hipStream_t st)
+                 const unsigned long long* covw, const int* next, const int* act_list, const int* act_count, float* rec,
+                 hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0 || F == 0) return FMHR_OK;
     k_pix_bwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, pos, (const float4*)attr8, sh, mask,
-                                                     (const float4*)g_shaded, n, V, F, H, W, covw, next, (float4*)rec);
+                                                (const float4*)g_shaded, n, V, F, H, W, covw, next, act_list, act_count,
+                                                (float4*)rec);
     FMHR_CHECK_LAUNCH("k_pix_bwd");
     return FMHR_OK;
 }
