@@ -1,0 +1,147 @@
+"""fmhr_amd.pipeline — the whole HAM optimisation of /root/reference/mesh_sfs_optim.py:30-343 on the MI355X library
+(SURVEY.md §8f rows N3 / N4): SH least-squares initialisation (:124-174), stage 1 "albedo" (:193-240, op-by-op on
+fmhr_amd.dr / fmhr_amd.utils with autograd), stage 2 "sfs" (:242-317, the fused HamStage2 step), export (:319-343).
+
+`init_sh` and `stage1_loss` take the operator module as an argument (anything with the nvdiffrast surface + the models/utils.py
+helpers), so the parity tests can run the very same code on the CPU checker; the product passes fmhr_amd.dr / fmhr_amd.utils.
+"""
+import math
+import os
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def product_ops():
+    from . import dr, utils
+    return types.SimpleNamespace(RasterizeGLContext=dr.RasterizeGLContext, rasterize=dr.rasterize, interpolate=dr.interpolate,
+                                 antialias=dr.antialias, get_normals=utils.get_normals, get_radiance=utils.get_radiance,
+                                 get_matrix=utils.get_matrix)
+
+
+def clip_positions(vertices, w2c, proj):
+    """mesh_sfs_optim.py:137-140 / :207-209 / :262-264 (row-vector convention)."""
+    n = w2c.shape[0]
+    vertsw = torch.cat([vertices, torch.ones_like(vertices[:, 0:1])], dim=1).unsqueeze(0).expand(n, -1, -1)
+    rot = torch.einsum('ijk,ikl->ijl', vertsw, w2c)
+    return vertsw, torch.einsum('ijk,ikl->ijl', rot, proj).contiguous()
+
+
+def init_sh(ops, vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, degree=3):
+    """Per-view and global SH least squares + mean albedo + the antialiased start silhouettes (mesh_sfs_optim.py:124-174).
+    Returns dict(sh_coeffs [num,9], sh_global [9], albedo_mean [3], valid_masks [num,H,W])."""
+    glctx = ops.RasterizeGLContext()
+    num = imgs.shape[0]
+    v_normals, v_gray, v_imgs, v_masks, sh_coeffs = [], [], [], [], []
+    with torch.no_grad():
+        for k in range(num):
+            w2c, proj, mask, img, gray = w2cs[k:k + 1], projs[k:k + 1], masks[k:k + 1], imgs[k:k + 1], grayimgs[k:k + 1]
+            vertsw, proj_verts = clip_positions(vertices, w2c, proj)
+            normals = ops.get_normals(vertsw[:, :, :3].contiguous(), faces.long())
+            rast_out, _ = ops.rasterize(glctx, proj_verts, faces, resolution=resolution)
+            feat, _ = ops.interpolate(torch.cat([normals, torch.ones_like(vertsw[:, :, :1])], 2).contiguous(), rast_out, faces)
+            pred_normals = feat[:, :, :, :3].contiguous()
+            pred_mask = ops.antialias(feat[:, :, :, 3:4].contiguous(), rast_out, proj_verts, faces).squeeze(-1)
+            pred_normals = F.normalize(ops.antialias(pred_normals, rast_out, proj_verts, faces), p=2, dim=3)
+            valid = (mask > 0) & (rast_out[:, :, :, 3] > 0)
+            vn = pred_normals[valid].detach().cpu().numpy().astype(np.float64)
+            vg = gray[valid].detach().cpu().numpy().astype(np.float64)
+            matrix = ops.get_matrix(torch.from_numpy(vn), degree).numpy()
+            sh = np.linalg.lstsq(matrix, vg, rcond=None)[0]
+            v_normals.append(vn); v_gray.append(vg); v_imgs.append(img[valid]); v_masks.append(pred_mask)
+            sh_coeffs.append(torch.from_numpy(sh.astype(np.float32)).to(imgs.device).unsqueeze(0))
+    vn = np.concatenate(v_normals, 0)
+    sh_global = np.linalg.lstsq(ops.get_matrix(torch.from_numpy(vn), degree).numpy(), np.concatenate(v_gray, 0), rcond=None)[0]
+    sh_global = torch.from_numpy(sh_global.astype(np.float32)).to(imgs.device)
+    radiance = ops.get_radiance(sh_global, torch.from_numpy(vn.astype(np.float32)).to(imgs.device), degree).unsqueeze(-1)
+    albedo_mean = (torch.cat(v_imgs, 0) / radiance).mean(0).detach()
+    return dict(sh_coeffs=torch.cat(sh_coeffs, 0), sh_global=sh_global, albedo_mean=albedo_mean, valid_masks=torch.cat(v_masks, 0))
+
+
+def stage1_loss(ops, glctx, vertices, faces, albedo, sh_coeff, w2c, proj, img, mask, resolution, sfs_weight, degree=3):
+    """One stage-1 batch (mesh_sfs_optim.py:205-233): vertices are constants, antialias is applied to the interpolated normals
+    and albedo BEFORE shading; loss = sfs_weight * L1 over the valid pixels.  albedo [1,V,3], sh_coeff [n,9] carry the graph."""
+    n = w2c.shape[0]
+    vertsw, proj_verts = clip_positions(vertices, w2c, proj)
+    normals = ops.get_normals(vertsw[:, :, :3].contiguous(), faces.long())
+    rast_out, _ = ops.rasterize(glctx, proj_verts, faces, resolution=resolution)
+    feat, _ = ops.interpolate(torch.cat([normals, albedo.expand(n, -1, -1)], dim=2).contiguous(), rast_out, faces)
+    pred_normals = F.normalize(ops.antialias(feat[:, :, :, :3].contiguous(), rast_out, proj_verts, faces), p=2, dim=3)
+    rast_albedo = ops.antialias(feat[:, :, :, 3:6].contiguous(), rast_out, proj_verts, faces)
+    valid_idx = torch.where((mask > 0) & (rast_out[:, :, :, 3] > 0))
+    radiance = ops.get_radiance(sh_coeff[valid_idx[0]].contiguous(), pred_normals[valid_idx].contiguous(), degree).unsqueeze(-1)
+    pred_img = radiance * rast_albedo[valid_idx]
+    return sfs_weight * F.l1_loss(pred_img, img[valid_idx])
+
+
+def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0):
+    """The HAM optimisation end to end on GPU tensors.  conf: dict with the keys of conf/demo_sfs.conf that the loop reads.
+    Returns dict(vertices, delta, albedo, sh_coeffs, history)."""
+    from . import optim
+    from .ham import HamStage2, edge_length_mean
+    from .data import save_obj, save_obj_mesh_with_color
+    ops = product_ops()
+    dev = vertices.device
+    degree, batch = int(conf.get("degree", 3)), int(conf["batch"])
+    num = imgs.shape[0]
+    H, W = resolution
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    init = init_sh(ops, vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, degree)
+    sh_coeffs = init["sh_coeffs"].clone().requires_grad_(True)                       # :168-170
+    albedo = (torch.zeros_like(vertices) + init["albedo_mean"]).unsqueeze(0).contiguous().requires_grad_(True)   # :175-176
+    delta = torch.zeros_like(vertices).requires_grad_(True)
+    vertices_tmp = vertices.detach().clone()
+    elm = edge_length_mean(vertices_tmp, faces)                                      # :184-188
+    history = []
+    # ---- stage 1: albedo + SH (:193-240)
+    opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
+    glctx = ops.RasterizeGLContext()
+    for ep in range(int(conf["epoch_albedo"])):
+        perm = torch.randperm(num, generator=gen).to(dev)
+        for k in range(0, num, batch):
+            idx = perm[k:k + batch]
+            loss = stage1_loss(ops, glctx, vertices_tmp, faces, albedo, sh_coeffs[idx], w2cs[idx], projs[idx], imgs[idx], masks[idx],
+                               resolution, conf["sfs_weight"], degree)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        if log_every and ep % log_every == 0:
+            history.append(("albedo", ep, float(loss)))
+    # ---- stage 2: vertex offsets + albedo (:242-317), fused step
+    sh_fixed = sh_coeffs.detach()
+    weights = dict(sfs=conf["sfs_weight"], lap=conf["lap_weight"], albedo=conf["albedo_weight"], mask=conf["mask_weight"],
+                   edge=conf["edge_weight"], delta=conf["delta_weight"])
+    opt = optim.Adam([{'params': delta, 'lr': conf["lr"]}, {'params': albedo, 'lr': conf["albedo_lr"]}])
+    steppers = {}
+    epoch_sfs = int(conf["epoch_sfs"])
+    for ep in range(epoch_sfs):
+        perm = torch.randperm(num, generator=gen).to(dev)
+        if ep == epoch_sfs // 2:
+            weights["albedo"] = weights["albedo"] / 10000                            # :250-251
+            steppers.clear()
+        for k in range(0, num, batch):
+            idx = perm[k:k + batch]
+            n = idx.shape[0]
+            if n not in steppers:
+                steppers[n] = HamStage2(faces, vertices.shape[0], n, H, W, weights, elm)
+            hs = steppers[n]
+            losses, gd, ga = hs.step(vertices_tmp, delta.detach(), albedo.detach()[0], sh_fixed[idx].contiguous(),
+                                     w2cs[idx].contiguous(), projs[idx].contiguous(), imgs[idx].contiguous(),
+                                     masks[idx].contiguous(), init["valid_masks"][idx].contiguous())
+            delta.grad, albedo.grad = gd, ga.view(1, -1, 3)
+            opt.step()
+        if log_every and ep % log_every == 0:
+            history.append(("sfs", ep, hs.loss_dict()))
+    out_vertices = (vertices_tmp + delta).detach()
+    result = dict(vertices=out_vertices, delta=delta.detach(), albedo=albedo.detach(), sh_coeffs=sh_coeffs.detach(), history=history,
+                  valid_masks=init["valid_masks"])
+    if out_dir is not None:                                                          # :319-335
+        os.makedirs(out_dir, exist_ok=True)
+        torch.save({'sh_coeff': sh_coeffs.detach().cpu(), 'albedo': albedo.detach().cpu()}, os.path.join(out_dir, 'ham.pt'))
+        nv, nf = out_vertices.cpu().numpy(), faces.cpu().numpy()
+        save_obj(os.path.join(out_dir, 'ham.obj'), nv, nf)
+        color = torch.clamp(0.5 * albedo.detach(), 0, 1)[0].cpu().numpy()
+        save_obj_mesh_with_color(os.path.join(out_dir, 'ham_c.obj'), nv, nf, color[:, 2::-1])
+    return result

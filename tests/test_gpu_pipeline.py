@@ -1,0 +1,71 @@
+"""GPU tests of the end-to-end HAM pipeline (fmhr_amd.pipeline): SH initialisation + stage-1 step on fmhr_amd.dr / utils against
+the same code on the CPU checker, and a short full run (init -> stage 1 -> fused stage 2 -> export)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import rel_err
+from test_next_rows import _tiny_capture
+
+pytestmark = pytest.mark.gpu
+
+
+def test_init_and_stage1_match_checker(oracle):
+    from fmhr_amd import pipeline
+    dev = torch.device("cuda:0")
+    sc = _tiny_capture(oracle)
+    res = (sc["H"], sc["W"])
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "faces", "img", "gray", "mask", "w2c", "proj")}
+    ops = pipeline.product_ops()
+    init_g = pipeline.init_sh(ops, g["vertices"], g["faces"], g["img"], g["gray"], g["mask"], g["w2c"], g["proj"], res)
+    init_c = pipeline.init_sh(oracle, sc["vertices"], sc["faces"], sc["img"], sc["gray"], sc["mask"], sc["w2c"], sc["proj"], res)
+    assert rel_err(init_g["sh_coeffs"], init_c["sh_coeffs"]) < 2e-3
+    assert rel_err(init_g["albedo_mean"], init_c["albedo_mean"]) < 1e-3
+    assert rel_err(init_g["valid_masks"], init_c["valid_masks"]) < 1e-4
+    # one stage-1 batch: loss and gradients w.r.t. albedo and the per-view SH coefficients
+    alb_c = (torch.zeros_like(sc["vertices"]) + init_c["albedo_mean"])[None].clone().requires_grad_(True)
+    sh_c = init_c["sh_coeffs"].clone().requires_grad_(True)
+    lc = pipeline.stage1_loss(oracle, None, sc["vertices"], sc["faces"], alb_c, sh_c, sc["w2c"], sc["proj"], sc["img"], sc["mask"],
+                              res, 50.0)
+    lc.backward()
+    alb_g = alb_c.detach().to(dev).clone().requires_grad_(True)
+    sh_g = sh_c.detach().to(dev).clone().requires_grad_(True)
+    lg = pipeline.stage1_loss(ops, ops.RasterizeGLContext(), g["vertices"], g["faces"], alb_g, sh_g, g["w2c"], g["proj"], g["img"],
+                              g["mask"], res, 50.0)
+    lg.backward()
+    # the clip positions come from torch's einsum on each device and differ in the last bit; a handful of marginal pixels may
+    # take the other side of a rule, hence the looser bound here (the decision-exact comparison is test_gpu_dr / test_gpu_ham)
+    assert abs(float(lg) - float(lc)) < 1e-3 * abs(float(lc))
+    assert rel_err(alb_g.grad, alb_c.grad) < 2e-2 and rel_err(sh_g.grad, sh_c.grad) < 2e-3
+
+
+def test_run_ham_end_to_end(oracle, tmp_path):
+    from fmhr_amd import pipeline, synthetic as S
+    from fmhr_amd.ham import render_forward
+    from fmhr_amd.data import load_obj
+    dev = torch.device("cuda:0")
+    sc = S.make_scene(6, 128, 96, 21, 37, 1, seed=5)
+    faces = sc["faces"].to(dev)
+    w2c, proj = sc["w2c"].to(dev), sc["proj"].to(dev)
+    tg = S.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, 128, 96), device=dev)
+    img = tg["img"]
+    gray = (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).contiguous()
+    conf = dict(S.DEMO_WEIGHTS)
+    conf = dict(batch=4, degree=3, epoch_albedo=6, epoch_sfs=8, sfs_weight=50.0, lap_weight=2000.0, albedo_weight=1.0,
+                mask_weight=1000.0, edge_weight=500000.0, delta_weight=50000.0, lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
+    out = pipeline.run_ham(sc["vertices"].to(dev), faces, img, gray, tg["mask"], w2c, proj, (128, 96), conf, out_dir=str(tmp_path),
+                           log_every=1)
+    hist = out["history"]
+    s1 = [h[2] for h in hist if h[0] == "albedo"]
+    s2 = [h[2]["sfs"] for h in hist if h[0] == "sfs"]
+    assert len(s1) == 6 and len(s2) == 8
+    assert s1[-1] < s1[0], s1                       # stage 1 reduces the photometric error
+    assert all(np.isfinite(v) for v in s1 + s2)
+    assert torch.isfinite(out["vertices"]).all() and float(out["delta"].abs().max()) > 0
+    v, f = load_obj(os.path.join(tmp_path, "ham.obj"))
+    assert v.shape == (sc["V"], 3) and f.shape == (sc["F"], 3)
+    ck = torch.load(os.path.join(tmp_path, "ham.pt"))
+    assert ck["sh_coeff"].shape == (6, 9) and ck["albedo"].shape == (1, sc["V"], 3)
+    assert os.path.exists(os.path.join(tmp_path, "ham_c.obj"))
