@@ -11,9 +11,11 @@ struct MeshTailArgs {
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     int V, F;
     float lap_w, alb_w, edge_w, delta_w, edge_mean, rg;
-    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a; float* losses;
+    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a;
+    float* loss_part;
 };
 int mesh_tail_impl(const MeshTailArgs&, float*, float*, hipStream_t);
+int mesh_tail_blocks(int V);
 // raster.hip / antialias.hip / mesh.hip / shade.hip
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
@@ -46,12 +48,12 @@ int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const
                  int, int, int, int, int, const unsigned long long*, const int*, const int*, const int*, float*, hipStream_t);
 int vertex_gather_impl(const float*, const int*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const float*,
                        const float*, int, int, int, int, int, int, float*, float*, float*, float*, hipStream_t);
-int finish_losses_impl(float*, const float*, const float*, const float*, int, float, float, float, hipStream_t);
+int finish_losses_impl(float*, const float*, const float*, const float*, int, const float*, int, float, float, float, hipStream_t);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
-        g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, total;
+        g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -103,6 +105,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.lx_v = take(off, V * 12);
     L.lx_a = take(off, V * 12);
     L.rowg = take(off, V * 12);
+    L.tail_part = take(off, (size_t)mesh_tail_blocks(d->V) * 16);    // per-workgroup regulariser loss sums [4, blocks]
     L.total = off;
     return L;
 }
@@ -298,10 +301,10 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         A.lap_w = wt->lap / (float)d->V; A.alb_w = wt->albedo / (float)d->V; A.edge_w = wt->edge / (3.0f * (float)d->F);
         A.delta_w = wt->delta / (float)d->V; A.edge_mean = wt->edge_length_mean; A.rg = rg;
         A.gs = (float*)(w + L.gtmp); A.rowg_v = (float*)(w + L.rowg); A.rowg_a = (float*)(w + L.lx_a);
-        A.gacc_v = gvert; A.gacc_a = (float*)(w + L.lx_v); A.losses = losses;
+        A.gacc_v = gvert; A.gacc_a = (float*)(w + L.lx_v); A.loss_part = (float*)(w + L.tail_part);
         TRY(mesh_tail_impl(A, gdelta, galbedo, st));
     }
     TRY(finish_losses_impl(losses, n_valid_global, (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, (int)nB,
-                           wt->sfs, wt->mask, wt->mse_denominator, st));
+                           (const float*)(w + L.tail_part), mesh_tail_blocks(d->V), wt->sfs, wt->mask, wt->mse_denominator, st));
     return FMHR_OK;
 }

@@ -364,25 +364,40 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
 }
 
 // ------------------------------------------------------------------------------------------------ CSR-gather forms (fused step)
-// One lane per vertex walks its incident face corners (vf CSR, entry = 3*face + corner): no float atomics, deterministic
+// kSubLanes lanes per vertex walk its incident face corners (vf CSR, entry = 3*face + corner): no float atomics, deterministic
 // summation order.  The face-scatter forms above took ~40 us each on atomics into a 0.6 MB array; these take a few us.
+constexpr int kSubLanes = 8;     // lanes per vertex in the CSR-walking kernels (49k lane-per-vertex threads cannot fill 1024 SIMDs)
+
+__device__ __forceinline__ float sum_sub(float x)
+{
+    x += __shfl_xor(x, 1);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 4);
+    return x;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_normals_gather(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
                  const int32_t* __restrict__ vf_idx, int V, float* __restrict__ nsum, float* __restrict__ normals,
                  const float* __restrict__ albedo, float4* __restrict__ attr8)
 {
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= V) return;
-    float3 p = ld3(verts + (size_t)v * 3);
+    const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
+    const bool live = v < V;
+    const int vv = live ? v : 0;
     float3 acc = make_float3(0.f, 0.f, 0.f);
-    for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
-        int code = vf_idx[e];
-        int f = code / 3, k = code - f * 3;
-        int k1 = (k + 1 == 3) ? 0 : k + 1, k2 = (k1 + 1 == 3) ? 0 : k1 + 1;
-        float3 a = ld3(verts + (size_t)tri[f * 3 + k1] * 3), b = ld3(verts + (size_t)tri[f * 3 + k2] * 3);
-        float3 c = cross3(sub3(a, p), sub3(b, p));          // corner k: cross(v[k+1]-v[k], v[k+2]-v[k]) (models/utils.py:517-543)
-        acc.x += c.x; acc.y += c.y; acc.z += c.z;
+    if (live) {
+        float3 p = ld3(verts + (size_t)vv * 3);
+        for (int e = vf_ptr[vv] + sub; e < vf_ptr[vv + 1]; e += kSubLanes) {
+            int code = vf_idx[e];
+            int f = code / 3, k = code - f * 3;
+            int k1 = (k + 1 == 3) ? 0 : k + 1, k2 = (k1 + 1 == 3) ? 0 : k1 + 1;
+            float3 a = ld3(verts + (size_t)tri[f * 3 + k1] * 3), b = ld3(verts + (size_t)tri[f * 3 + k2] * 3);
+            float3 c = cross3(sub3(a, p), sub3(b, p));      // corner k: cross(v[k+1]-v[k], v[k+2]-v[k]) (models/utils.py:517-543)
+            acc.x += c.x; acc.y += c.y; acc.z += c.z;
+        }
     }
+    acc.x = sum_sub(acc.x); acc.y = sum_sub(acc.y); acc.z = sum_sub(acc.z);
+    if (!live || sub != 0) return;
     nsum[(size_t)v * 3] = acc.x; nsum[(size_t)v * 3 + 1] = acc.y; nsum[(size_t)v * 3 + 2] = acc.z;
     float len = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
     float inv = 1.0f / fmaxf(len, 1e-6f);
@@ -471,41 +486,81 @@ struct MeshTailArgs {
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     int V, F;
     float lap_w, alb_w, edge_w, delta_w, edge_mean, rg;                               // weights (already / V or / 3F where due)
-    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a; float* losses;
+    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a;
+    float* loss_part;                                                                 // [4, gridDim.x] weighted per-block loss sums
 };
 
-__device__ __forceinline__ void lap_row(const float* __restrict__ x, const int32_t* __restrict__ row_ptr,
-                                        const int32_t* __restrict__ col, int i, float out[3])
-{
-    int a = row_ptr[i], b = row_ptr[i + 1];
-    float xi[3] = {x[(size_t)i * 3], x[(size_t)i * 3 + 1], x[(size_t)i * 3 + 2]};
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int j = a; j < b; j++) {
-        const float* xj = x + (size_t)col[j] * 3;
-        acc[0] += xj[0] - xi[0]; acc[1] += xj[1] - xi[1]; acc[2] += xj[2] - xi[2];
-    }
-    float inv = (b > a) ? 1.0f / (float)(b - a) : 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) out[c] = (b > a) ? acc[c] * inv : -xi[c];
-}
-
+// Both kernels give a vertex kSub lanes: 49k vertices are < 1 wave per SIMD, so a lane-per-vertex launch leaves every dependent
+// gather chain (CSR row -> neighbour -> value) exposed; kSub lanes stride over the vertex's rows and combine with xor-shuffles.
 __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
 {
     __shared__ float sm[4];
-    int v = blockIdx.x * kBlock + threadIdx.x;
+    const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
     float l_lap = 0.f, l_alb = 0.f, l_edge = 0.f, l_delta = 0.f;
-    if (v < A.V) {
-        // (1) partial sums of the pixel gather
-        float n0 = 0.f, n1 = 0.f, n2 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        float gx = A.gvert_aa[(size_t)v * 3], gy = A.gvert_aa[(size_t)v * 3 + 1], gz = A.gvert_aa[(size_t)v * 3 + 2];
-        const int c0 = A.vc_ptr[v], c1 = A.vc_ptr[v + 1];
-        for (int g = 0; g < A.G; g++)
-            for (int c = c0; c < c1; c++) {
-                const float4* q = A.part + ((size_t)g * A.NC + c) * 3;
-                float4 q0 = q[0], q1 = q[1], q2 = q[2];
-                n0 += q0.x; n1 += q0.y; n2 += q0.z; a0 += q0.w; a1 += q1.x; a2 += q1.y;
-                gx += q1.z; gy += q1.w; gz += q2.x;
+    const bool live = v < A.V;                                     // uniform over a vertex's lanes
+    const int vv = live ? v : 0;
+    // (1) partial sums of the pixel gather: a vertex's chunks are 3*nc consecutive float4 per group plane; the lanes stride over
+    //     them (neighbouring vertices continue the same run: coalesced) with the G plane loads of one element independent
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    if (live) {
+        const int c0 = A.vc_ptr[vv], nq = (A.vc_ptr[vv + 1] - c0) * 3;
+        const size_t plane = (size_t)A.NC * 3;
+        for (int j = sub; j < nq; j += kSubLanes) {
+            const float4* q = A.part + (size_t)c0 * 3 + j;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < A.G; g++) {
+                float4 t = q[(size_t)g * plane];
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
             }
+            const int slot = j % 3;
+            if (slot == 0) { n0 += acc.x; n1 += acc.y; n2 += acc.z; a0 += acc.w; }
+            else if (slot == 1) { a1 += acc.x; a2 += acc.y; gx += acc.z; gy += acc.w; }
+            else gz += acc.x;
+        }
+    }
+    // (3) uniform Laplacians of the vertices and of the albedo: differences accumulated per neighbour
+    float lv[3] = {0.f, 0.f, 0.f}, la[3] = {0.f, 0.f, 0.f};
+    int deg = 0;
+    float3 xv = make_float3(0.f, 0.f, 0.f), xa = xv;
+    if (live) {
+        const int ra = A.row_ptr[vv], rb = A.row_ptr[vv + 1];
+        deg = rb - ra;
+        xv = ld3(A.verts + (size_t)vv * 3); xa = ld3(A.albedo + (size_t)vv * 3);
+        for (int j = ra + sub; j < rb; j += kSubLanes) {
+            int i = A.col[j];
+            float3 yv = ld3(A.verts + (size_t)i * 3), ya = ld3(A.albedo + (size_t)i * 3);
+            lv[0] += yv.x - xv.x; lv[1] += yv.y - xv.y; lv[2] += yv.z - xv.z;
+            la[0] += ya.x - xa.x; la[1] += ya.y - xa.y; la[2] += ya.z - xa.z;
+        }
+    }
+    // (5) edge hinge (mesh_sfs_optim.py:296-302): a face's loss is accounted by its corner 0, gradients by each corner
+    float3 eg = make_float3(0.f, 0.f, 0.f);
+    if (live) {
+        const float gk = 2.f * A.edge_w * A.rg;
+        for (int e = A.vf_ptr[vv] + sub; e < A.vf_ptr[vv + 1]; e += kSubLanes) {
+            int code = A.vf_idx[e];
+            int f = code / 3, c = code - f * 3;
+            float3 a = ld3(A.verts + (size_t)A.tri[f * 3] * 3), b = ld3(A.verts + (size_t)A.tri[f * 3 + 1] * 3),
+                   cc = ld3(A.verts + (size_t)A.tri[f * 3 + 2] * 3);
+            float3 ed[3] = {sub3(a, b), sub3(cc, b), sub3(a, cc)};
+            const float sgn[3][3] = {{1.f, 0.f, 1.f}, {-1.f, -1.f, 0.f}, {0.f, 1.f, -1.f}};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float l2 = ed[k].x * ed[k].x + ed[k].y * ed[k].y + ed[k].z * ed[k].z;
+                float d = l2 - A.edge_mean;
+                if (c == 0) l_edge += fminf(fmaxf(d, 0.f), 1.f);
+                float sg = sgn[c][k];
+                if (d > 0.f && d < 1.f && sg != 0.f) { eg.x += gk * sg * ed[k].x; eg.y += gk * sg * ed[k].y; eg.z += gk * sg * ed[k].z; }
+            }
+        }
+    }
+    n0 = sum_sub(n0); n1 = sum_sub(n1); n2 = sum_sub(n2); a0 = sum_sub(a0); a1 = sum_sub(a1); a2 = sum_sub(a2);
+    gx = sum_sub(gx + eg.x); gy = sum_sub(gy + eg.y); gz = sum_sub(gz + eg.z);
+#pragma unroll
+    for (int c = 0; c < 3; c++) { lv[c] = sum_sub(lv[c]); la[c] = sum_sub(la[c]); }
+    if (live && sub == 0) {
+        const float* ga = A.gvert_aa + (size_t)v * 3;
+        gx += ga[0]; gy += ga[1]; gz += ga[2];
         // (2) d/d nsum of the normalised vertex normal (models/utils.py:545, eps 1e-6)
         {
             float3 s = ld3(A.nsum + (size_t)v * 3);
@@ -521,11 +576,12 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
             }
             A.gs[(size_t)v * 3] = o.x; A.gs[(size_t)v * 3 + 1] = o.y; A.gs[(size_t)v * 3 + 2] = o.z;
         }
-        // (3) uniform Laplacians of the vertices and of the albedo: row norms -> loss, scaled rows -> backward (part B)
+        // (3) row norms -> loss, scaled rows -> backward (part B); an isolated vertex has the row -x (models/utils.py:684)
         {
-            float lv[3], la[3];
-            lap_row(A.verts, A.row_ptr, A.col, v, lv);
-            lap_row(A.albedo, A.row_ptr, A.col, v, la);
+            const float inv = (deg > 0) ? 1.0f / (float)deg : 0.0f;
+            const float xs[3] = {xv.x, xv.y, xv.z}, as[3] = {xa.x, xa.y, xa.z};
+#pragma unroll
+            for (int c = 0; c < 3; c++) { lv[c] = (deg > 0) ? lv[c] * inv : -xs[c]; la[c] = (deg > 0) ? la[c] * inv : -as[c]; }
             float nv = sqrtf(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
             float na = sqrtf(la[0] * la[0] + la[1] * la[1] + la[2] * la[2]);
             l_lap = nv; l_alb = na;
@@ -540,36 +596,15 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
             float k = 2.f * A.delta_w * A.rg;
             gx += k * d.x; gy += k * d.y; gz += k * d.z;
         }
-        // (5) edge hinge (mesh_sfs_optim.py:296-302): a face's loss is accounted by its corner 0, gradients by each corner
-        {
-            float3 acc = make_float3(0.f, 0.f, 0.f);
-            const float gk = 2.f * A.edge_w * A.rg;
-            for (int e = A.vf_ptr[v]; e < A.vf_ptr[v + 1]; e++) {
-                int code = A.vf_idx[e];
-                int f = code / 3, c = code - f * 3;
-                float3 a = ld3(A.verts + (size_t)A.tri[f * 3] * 3), b = ld3(A.verts + (size_t)A.tri[f * 3 + 1] * 3),
-                       cc = ld3(A.verts + (size_t)A.tri[f * 3 + 2] * 3);
-                float3 ed[3] = {sub3(a, b), sub3(cc, b), sub3(a, cc)};
-                const float sgn[3][3] = {{1.f, 0.f, 1.f}, {-1.f, -1.f, 0.f}, {0.f, 1.f, -1.f}};
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    float l2 = ed[k].x * ed[k].x + ed[k].y * ed[k].y + ed[k].z * ed[k].z;
-                    float d = l2 - A.edge_mean;
-                    if (c == 0) l_edge += fminf(fmaxf(d, 0.f), 1.f);
-                    float sg = sgn[c][k];
-                    if (d > 0.f && d < 1.f && sg != 0.f) { acc.x += gk * sg * ed[k].x; acc.y += gk * sg * ed[k].y; acc.z += gk * sg * ed[k].z; }
-                }
-            }
-            gx += acc.x; gy += acc.y; gz += acc.z;
-        }
         A.gacc_v[(size_t)v * 3] = gx; A.gacc_v[(size_t)v * 3 + 1] = gy; A.gacc_v[(size_t)v * 3 + 2] = gz;
         A.gacc_a[(size_t)v * 3] = a0; A.gacc_a[(size_t)v * 3 + 1] = a1; A.gacc_a[(size_t)v * 3 + 2] = a2;
     }
+    // per-block partials (k_finish_losses adds them up): 4 x 1.5k same-address atomics would serialise for ~60 us
     float s;
-    s = block_sum(l_lap, sm);   if (threadIdx.x == 0 && s != 0.f) atomicAdd(A.losses + FMHR_LOSS_LAP, s * A.lap_w);
-    s = block_sum(l_alb, sm);   if (threadIdx.x == 0 && s != 0.f) atomicAdd(A.losses + FMHR_LOSS_ALBEDO, s * A.alb_w);
-    s = block_sum(l_edge, sm);  if (threadIdx.x == 0 && s != 0.f) atomicAdd(A.losses + FMHR_LOSS_EDGE, s * A.edge_w);
-    s = block_sum(l_delta, sm); if (threadIdx.x == 0 && s != 0.f) atomicAdd(A.losses + FMHR_LOSS_DELTA, s * A.delta_w);
+    s = block_sum(l_lap, sm);   if (threadIdx.x == 0) A.loss_part[blockIdx.x] = s * A.lap_w;
+    s = block_sum(l_alb, sm);   if (threadIdx.x == 0) A.loss_part[gridDim.x + blockIdx.x] = s * A.alb_w;
+    s = block_sum(l_edge, sm);  if (threadIdx.x == 0) A.loss_part[2 * gridDim.x + blockIdx.x] = s * A.edge_w;
+    s = block_sum(l_delta, sm); if (threadIdx.x == 0) A.loss_part[3 * gridDim.x + blockIdx.x] = s * A.delta_w;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -579,33 +614,30 @@ k_mesh_tail_b(const float* __restrict__ verts, const int32_t* __restrict__ tri, 
               const float* __restrict__ gacc_v, const float* __restrict__ gacc_a, int V, float* __restrict__ gdelta,
               float* __restrict__ galbedo)
 {
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= V) return;
-    float3 acc = ld3(gacc_v + (size_t)v * 3);
-    float3 aca = ld3(gacc_a + (size_t)v * 3);
-    // vertex-normal backward: this vertex's share of d(sum_k gs[i_k] . cross_k)/d verts over its incident faces
-    for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
-        int code = vf_idx[e];
-        int f = code / 3, c = code - f * 3;
-        int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
-        float3 p[3] = {ld3(verts + (size_t)i[0] * 3), ld3(verts + (size_t)i[1] * 3), ld3(verts + (size_t)i[2] * 3)};
-        float3 g[3] = {ld3(gs + (size_t)i[0] * 3), ld3(gs + (size_t)i[1] * 3), ld3(gs + (size_t)i[2] * 3)};
+    const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
+    const bool live = v < V;
+    const int vv = live ? v : 0;
+    float3 acc = make_float3(0.f, 0.f, 0.f), aca = acc;
+    if (live) {
+        // vertex-normal backward: this vertex's share of d(sum_k gs[i_k] . cross_k)/d verts over its incident faces
+        for (int e = vf_ptr[vv] + sub; e < vf_ptr[vv + 1]; e += kSubLanes) {
+            int code = vf_idx[e];
+            int f = code / 3, c = code - f * 3;
+            int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
+            float3 p[3] = {ld3(verts + (size_t)i[0] * 3), ld3(verts + (size_t)i[1] * 3), ld3(verts + (size_t)i[2] * 3)};
+            float3 g[3] = {ld3(gs + (size_t)i[0] * 3), ld3(gs + (size_t)i[1] * 3), ld3(gs + (size_t)i[2] * 3)};
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-            float3 e1 = sub3(p[k1], p[k]), e2 = sub3(p[k2], p[k]);
-            float3 ge1 = cross3(e2, g[k]), ge2 = cross3(g[k], e1);
-            if (c == k1) { acc.x += ge1.x; acc.y += ge1.y; acc.z += ge1.z; }
-            if (c == k2) { acc.x += ge2.x; acc.y += ge2.y; acc.z += ge2.z; }
-            if (c == k) { acc.x -= ge1.x + ge2.x; acc.y -= ge1.y + ge2.y; acc.z -= ge1.z + ge2.z; }
+            for (int k = 0; k < 3; k++) {
+                int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                float3 e1 = sub3(p[k1], p[k]), e2 = sub3(p[k2], p[k]);
+                float3 ge1 = cross3(e2, g[k]), ge2 = cross3(g[k], e1);
+                if (c == k1) { acc.x += ge1.x; acc.y += ge1.y; acc.z += ge1.z; }
+                if (c == k2) { acc.x += ge2.x; acc.y += ge2.y; acc.z += ge2.z; }
+                if (c == k) { acc.x -= ge1.x + ge2.x; acc.y -= ge1.y + ge2.y; acc.z -= ge1.z + ge2.z; }
+            }
         }
-    }
-    // L^T r for both Laplacians (the adjacency is symmetric): sum_{i in N(v)} r_i / deg_i - r_v
-    {
-        float3 rv = ld3(rowg_v + (size_t)v * 3), ra = ld3(rowg_a + (size_t)v * 3);
-        acc.x -= rv.x; acc.y -= rv.y; acc.z -= rv.z;
-        aca.x -= ra.x; aca.y -= ra.y; aca.z -= ra.z;
-        for (int e = row_ptr[v]; e < row_ptr[v + 1]; e++) {
+        // L^T r for both Laplacians (the adjacency is symmetric): sum_{i in N(v)} r_i / deg_i - r_v
+        for (int e = row_ptr[vv] + sub; e < row_ptr[vv + 1]; e += kSubLanes) {
             int i = col[e];
             float inv = 1.0f / (float)(row_ptr[i + 1] - row_ptr[i]);
             float3 qv = ld3(rowg_v + (size_t)i * 3), qa = ld3(rowg_a + (size_t)i * 3);
@@ -613,16 +645,24 @@ k_mesh_tail_b(const float* __restrict__ verts, const int32_t* __restrict__ tri, 
             aca.x += qa.x * inv; aca.y += qa.y * inv; aca.z += qa.z * inv;
         }
     }
-    gdelta[(size_t)v * 3] = acc.x; gdelta[(size_t)v * 3 + 1] = acc.y; gdelta[(size_t)v * 3 + 2] = acc.z;
-    galbedo[(size_t)v * 3] = aca.x; galbedo[(size_t)v * 3 + 1] = aca.y; galbedo[(size_t)v * 3 + 2] = aca.z;
+    acc.x = sum_sub(acc.x); acc.y = sum_sub(acc.y); acc.z = sum_sub(acc.z);
+    aca.x = sum_sub(aca.x); aca.y = sum_sub(aca.y); aca.z = sum_sub(aca.z);
+    if (live && sub == 0) {
+        float3 g0 = ld3(gacc_v + (size_t)v * 3), h0 = ld3(gacc_a + (size_t)v * 3);
+        float3 rv = ld3(rowg_v + (size_t)v * 3), ra = ld3(rowg_a + (size_t)v * 3);
+        gdelta[(size_t)v * 3] = g0.x + acc.x - rv.x; gdelta[(size_t)v * 3 + 1] = g0.y + acc.y - rv.y; gdelta[(size_t)v * 3 + 2] = g0.z + acc.z - rv.z;
+        galbedo[(size_t)v * 3] = h0.x + aca.x - ra.x; galbedo[(size_t)v * 3 + 1] = h0.y + aca.y - ra.y; galbedo[(size_t)v * 3 + 2] = h0.z + aca.z - ra.z;
+    }
 }
+
+int mesh_tail_blocks(int V) { return cdiv((long long)V * kSubLanes, kBlock); }
 
 int mesh_tail_impl(const MeshTailArgs& A, float* gdelta, float* galbedo, hipStream_t st)
 {
     if (A.V == 0) return FMHR_OK;
-    k_mesh_tail_a<<<cdiv(A.V, kBlock), kBlock, 0, st>>>(A);
+    k_mesh_tail_a<<<cdiv((long long)A.V * kSubLanes, kBlock), kBlock, 0, st>>>(A);
     FMHR_CHECK_LAUNCH("k_mesh_tail_a");
-    k_mesh_tail_b<<<cdiv(A.V, kBlock), kBlock, 0, st>>>(A.verts, A.tri, A.vf_ptr, A.vf_idx, A.row_ptr, A.col, A.gs, A.rowg_v, A.rowg_a,
+    k_mesh_tail_b<<<cdiv((long long)A.V * kSubLanes, kBlock), kBlock, 0, st>>>(A.verts, A.tri, A.vf_ptr, A.vf_idx, A.row_ptr, A.col, A.gs, A.rowg_v, A.rowg_a,
                                                        A.gacc_v, A.gacc_a, A.V, gdelta, galbedo);
     FMHR_CHECK_LAUNCH("k_mesh_tail_b");
     return FMHR_OK;
@@ -633,7 +673,7 @@ int normals_fwd_gather_impl(const float* verts, const int32_t* tri, const int32_
                             float* nsum, float* normals, const float* albedo, float* attr8, hipStream_t st)
 {
     if (V == 0) return FMHR_OK;
-    k_normals_gather<<<cdiv(V, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, (float4*)attr8);
+    k_normals_gather<<<cdiv((long long)V * kSubLanes, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, (float4*)attr8);
     FMHR_CHECK_LAUNCH("k_normals_gather");
     return FMHR_OK;
 }

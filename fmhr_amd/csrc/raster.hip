@@ -46,6 +46,24 @@ __device__ __forceinline__ bool setup_triangle(const int2 s0, const int2 s1, con
     return true;
 }
 
+// the same test in 32-bit arithmetic: exact whenever the triangle's snapped extent is below 2^14 sub-pixel units (64 px), which
+// is every triangle of the per-lane small-box path unless it pokes far outside the screen
+__device__ __forceinline__ bool edge_in32(int ax, int ay, int bx, int by, int cx, int cy)
+{
+    int dx = bx - ax, dy = by - ay;
+    int e = dx * (cy - ay) - dy * (cx - ax);
+    if (e > 0) return true;
+    if (e < 0) return false;
+    return (dy > 0) || (dy == 0 && dx > 0);
+}
+
+__device__ __forceinline__ bool covers32(const TriSetup& s, int px, int py)
+{
+    int cx = px * kSub + kHalf, cy = py * kSub + kHalf;
+    return edge_in32(s.x0, s.y0, s.x1, s.y1, cx, cy) && edge_in32(s.x1, s.y1, s.x2, s.y2, cx, cy) &&
+           edge_in32(s.x2, s.y2, s.x0, s.y0, cx, cy);
+}
+
 __device__ __forceinline__ bool covers(const TriSetup& s, int px, int py)
 {
     int cx = px * kSub + kHalf, cy = py * kSub + kHalf;
@@ -113,9 +131,11 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     const float* vp = pos + (size_t)b * V * 4;
     float4 p0, p1, p2;
     bool loaded = false;
+    const int ext = max(max(s.x0, max(s.x1, s.x2)) - min(s.x0, min(s.x1, s.x2)), max(s.y0, max(s.y1, s.y2)) - min(s.y0, min(s.y1, s.y2)));
+    const bool small = ext < 16384;   // pixel centres lie within the bbox +-1 px: every product < 2^29
     for (int py = s.pya; py <= s.pyb; py++)
         for (int px = s.pxa; px <= s.pxb; px++) {
-            if (!covers(s, px, py)) continue;
+            if (!(small ? covers32(s, px, py) : covers(s, px, py))) continue;
             if (!loaded) { p0 = ldg4(vp + (size_t)i0 * 4); p1 = ldg4(vp + (size_t)i1 * 4); p2 = ldg4(vp + (size_t)i2 * 4); loaded = true; }
             emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W, dirty, (long long)b * H * W);
         }

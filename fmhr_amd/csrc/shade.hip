@@ -460,9 +460,16 @@ k_reduce_groups(const float4* __restrict__ part, const float* __restrict__ gvert
 
 __global__ void __launch_bounds__(1024)
 k_finish_losses(float* losses, const float* n_valid, const float* __restrict__ part_l1, const float* __restrict__ part_l2, int nb,
-                float w_sfs, float w_mask, float mse_den)
+                const float* __restrict__ tail_part, int tail_nb, float w_sfs, float w_mask, float mse_den)
 {
     __shared__ float sm[16];
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                 // regulariser sums of k_mesh_tail_a (already weighted): lap, albedo, edge, delta
+        float t = 0.f;
+        for (int j = threadIdx.x; j < tail_nb; j += 1024) t += tail_part[(size_t)k * tail_nb + j];
+        r[k] = block1024_sum(t, sm);
+    }
     float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f, d1 = 0.f, d2 = 0.f;
     int i = threadIdx.x;
     for (; i + 3072 < nb; i += 4096) {
@@ -476,6 +483,7 @@ k_finish_losses(float* losses, const float* n_valid, const float* __restrict__ p
         float den = 3.0f * n_valid[0];
         losses[FMHR_LOSS_SFS] = (den > 0.f) ? s1 * (w_sfs / den) : 0.f;
         losses[FMHR_LOSS_MASK] = s2 * (w_mask / mse_den);
+        losses[FMHR_LOSS_LAP] = r[0]; losses[FMHR_LOSS_ALBEDO] = r[1]; losses[FMHR_LOSS_EDGE] = r[2]; losses[FMHR_LOSS_DELTA] = r[3];
         losses[FMHR_LOSS_TOTAL] = losses[FMHR_LOSS_SFS] + losses[FMHR_LOSS_LAP] + losses[FMHR_LOSS_ALBEDO] +
                                   losses[FMHR_LOSS_MASK] + losses[FMHR_LOSS_DELTA] + losses[FMHR_LOSS_EDGE];
         losses[FMHR_LOSS_NVALID] = n_valid[0];
@@ -568,10 +576,10 @@ int vertex_gather_impl(const float* rec, const int* head, const int32_t* vf_ptr,
     return FMHR_OK;
 }
 
-int finish_losses_impl(float* losses, const float* n_valid, const float* part_l1, const float* part_l2, int nb, float w_sfs,
-                       float w_mask, float mse_den, hipStream_t st)
+int finish_losses_impl(float* losses, const float* n_valid, const float* part_l1, const float* part_l2, int nb,
+                       const float* tail_part, int tail_nb, float w_sfs, float w_mask, float mse_den, hipStream_t st)
 {
-    k_finish_losses<<<1, 1024, 0, st>>>(losses, n_valid, part_l1, part_l2, nb, w_sfs, w_mask, mse_den);
+    k_finish_losses<<<1, 1024, 0, st>>>(losses, n_valid, part_l1, part_l2, nb, tail_part, tail_nb, w_sfs, w_mask, mse_den);
     FMHR_CHECK_LAUNCH("k_finish_losses");
     return FMHR_OK;
 }
