@@ -6,7 +6,7 @@
 
 namespace fmhr {
 struct MeshTailArgs {
-    const float4* part; const float* gvert_aa; const int32_t* vc_ptr; int G, NC;
+    const float4* part; float* gvert_aa; const int32_t* vc_ptr; int G, NC;
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     int V, F;
@@ -20,7 +20,7 @@ int mesh_tail_blocks(int V);
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
-                       void*, int*, int*, int, unsigned char*, unsigned long long*, hipStream_t);
+                       void*, int*, int*, int, unsigned char*, unsigned long long*, int*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, int*,
                          hipStream_t);
@@ -41,7 +41,7 @@ int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
 int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, int, int, int, int, const int*,
-                   const int*, const unsigned long long*, float*, float*, float*, int*, hipStream_t);
+                   const int*, const unsigned long long*, float*, float*, float*, int*, float*, hipStream_t);
 int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
 int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*,
@@ -53,7 +53,7 @@ int finish_losses_impl(float*, const float*, const float*, const float*, int, co
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
-        g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, total;
+        g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -106,6 +106,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.lx_a = take(off, V * 12);
     L.rowg = take(off, V * 12);
     L.tail_part = take(off, (size_t)mesh_tail_blocks(d->V) * 16);    // per-workgroup regulariser loss sums [4, blocks]
+    L.n_valid_f = take(off, 16);                    // float copy of n_valid_local (a ready n_valid_global for the one-rank case)
     L.total = off;
     return L;
 }
@@ -149,7 +150,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(head); FMHR_OFF(next); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
     FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_aa); FMHR_OFF(g_shaded); FMHR_OFF(rec); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
-    FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(total);
+    FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(total);
 #undef FMHR_OFF
     set_error("ham_workspace_offset: unknown buffer '%s'", name);
     return -1;
@@ -177,6 +178,8 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_workspace_init: workspace too small or null");
     char* w = (char*)ws;
     HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, (hipStream_t)stream), "init aa_counter");
+    // self-cleaning accumulator: k_mesh_tail_a zeroes each entry after consuming it
+    HIPTRY(hipMemsetAsync(w + L.gvert_aa, 0, (size_t)d->V * 12, (hipStream_t)stream), "init gvert_aa");
     return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, d->W, (hipStream_t)stream);
 }
 
@@ -217,16 +220,17 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), st));
     }
     TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
-                           rast, w + L.raster_ws, (int*)(w + L.head), (int*)(w + L.next), (d->n + 7) / 8 * 8, (unsigned char*)(w + L.dirty), covw, st));
+                           rast, w + L.raster_ws, (int*)(w + L.head), (int*)(w + L.next), (d->n + 7) / 8 * 8, (unsigned char*)(w + L.dirty), covw,
+                           (int*)(w + L.act_count), st));        // the resolve pass also rearms the two segment-list cursors
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
-        HIPTRY(hipMemsetAsync(w + L.act_count, 0, 8, st), "memset act_count");
         TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, (int*)(w + L.act_list),
                                  (int*)(w + L.act_count), (int*)(w + L.cov_list), st));
         TRY(shade_fwd_impl(rast, tri, (float*)(w + L.attr8), sh, mask, d->n, d->F, d->H, d->W, (const int*)(w + L.act_list),
                            (const int*)(w + L.act_count), covw,
-                           (float*)(w + L.shaded), (float*)(w + L.aa), (float*)(w + L.partials), n_valid_local, st));
+                           (float*)(w + L.shaded), (float*)(w + L.aa), (float*)(w + L.partials), n_valid_local,
+                           (float*)(w + L.n_valid_f), st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
@@ -265,7 +269,6 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
 
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
-        HIPTRY(hipMemsetAsync(gvert_aa, 0, V * 12, st), "memset gvert_aa");
         // losses on the antialiased rgba + their per-pixel gradients (written twice: g_aa and the AA-backward target)
         TRY(loss_pix_impl((float*)(w + L.shaded), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
                           (const int*)(w + L.act_list), (const int*)(w + L.act_count), n_valid_global,

@@ -481,7 +481,7 @@ k_edge_hinge_gather(const float* __restrict__ verts, const int32_t* __restrict__
 //    Laplacians forward -> loss terms and scaled row gradients; delta term; edge hinge (loss + gradient).
 // B (neighbour gathers): vertex-normal backward from gs, L^T r for both Laplacians -> final gdelta / galbedo.
 struct MeshTailArgs {
-    const float4* part; const float* gvert_aa; const int32_t* vc_ptr; int G, NC;      // gather partials
+    const float4* part; float* gvert_aa; const int32_t* vc_ptr; int G, NC;      // gather partials
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     int V, F;
@@ -559,8 +559,9 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
 #pragma unroll
     for (int c = 0; c < 3; c++) { lv[c] = sum_sub(lv[c]); la[c] = sum_sub(la[c]); }
     if (live && sub == 0) {
-        const float* ga = A.gvert_aa + (size_t)v * 3;
+        float* ga = A.gvert_aa + (size_t)v * 3;           // antialias-backward atomics; consumed and re-zeroed for the next step
         gx += ga[0]; gy += ga[1]; gz += ga[2];
+        ga[0] = 0.f; ga[1] = 0.f; ga[2] = 0.f;
         // (2) d/d nsum of the normalised vertex normal (models/utils.py:545, eps 1e-6)
         {
             float3 s = ld3(A.nsum + (size_t)v * 3);

@@ -179,14 +179,17 @@ __global__ void __launch_bounds__(kBlock)
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, int* __restrict__ head,
                  int* __restrict__ next, int npad, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw,
-                 int* __restrict__ large_cnt)
+                 int* __restrict__ large_cnt, int* __restrict__ rearm2)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     long long P = (long long)H * W;
     const bool sparse = dirty != nullptr;
     long long seg = gid >> 6;
     if (sparse) {
-        if (gid == 0) *large_cnt = 0;                                // k_raster_large is done: rearm its queue counter
+        if (gid == 0) {                                              // k_raster_large is done: rearm its queue counter, and the
+            *large_cnt = 0;                                          // caller's pair of list cursors (saves a memset launch)
+            if (rearm2 != nullptr) { rearm2[0] = 0; rearm2[1] = 0; }
+        }
         if (gid - (gid & 63) >= (long long)n * P) return;            // whole wave out of range
         int d = __builtin_amdgcn_readfirstlane((int)dirty[seg]);
         if (!d) {
@@ -365,7 +368,7 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
 // buffer must have been initialised by raster_sparse_init and is left clean again).
 int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, const int32_t* opp, unsigned char* silh, int n, int V,
                        int F, int H, int W, float* rast, void* ws, int* head, int* next, int npad, unsigned char* dirty,
-                       unsigned long long* covw, hipStream_t st)
+                       unsigned long long* covw, int* rearm2, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
     unsigned long long* keys = (unsigned long long*)ws;
@@ -401,7 +404,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
     k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, next, npad,
-                                                                    dirty, covw, large_cnt);
+                                                                    dirty, covw, large_cnt, rearm2);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }
@@ -419,7 +422,7 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     int rc = snap_vertices_impl(pos, n, V, H, W, snap, (hipStream_t)stream);
     if (rc) return rc;
     return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, 0, nullptr, nullptr,
-                              (hipStream_t)stream);
+                              nullptr, (hipStream_t)stream);
 }
 
 extern "C" int fmhr_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int n, int V,

@@ -109,15 +109,19 @@ __device__ __forceinline__ bool segment_is_active(const unsigned long long* __re
 
 // one lane per segment; the active ones are also compacted into act_list (order arbitrary) so that the per-pixel kernels
 // run as persistent loops over exactly the active segments: 2/3 of a frame's 197k waves would only be launched to exit
-__global__ void __launch_bounds__(kBlock)
+constexpr int kActBlock = 1024;   // few, fat workgroups: the list cursors are same-address atomics (~10 ns each, serialised)
+
+__global__ void __launch_bounds__(kActBlock)
 k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
                   unsigned char* __restrict__ act, int* __restrict__ act_list, int* __restrict__ act_count,
                   int* __restrict__ cov_list)
 {
-    // act_count[0] = number of active segments (act_list), act_count[1] = number of COVERED segments (cov_list)
-    __shared__ int wcnt[4], ccnt[4];
+    // act_count[0] = number of active segments (act_list), act_count[1] = number of COVERED segments (cov_list); both cursors
+    // advance with ONE 64-bit atomic per workgroup (low word = active, high word = covered)
+    constexpr int kWaves = kActBlock / 64;
+    __shared__ int wcnt[kWaves], ccnt[kWaves];
     __shared__ int base, cbase;
-    long long seg = (long long)blockIdx.x * kBlock + threadIdx.x;
+    long long seg = (long long)blockIdx.x * kActBlock + threadIdx.x;
     bool a = (seg < nSeg) && segment_is_active(covw, vmnz, nSeg, W, seg, act);
     bool cv = a && covw[seg] != 0ull;
     unsigned long long bal = __ballot(a), cbal = __ballot(cv);
@@ -125,8 +129,11 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
     if (lane == 0) { wcnt[wv] = __popcll(bal); ccnt[wv] = __popcll(cbal); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        base = atomicAdd(act_count, wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
-        cbase = atomicAdd(act_count + 1, ccnt[0] + ccnt[1] + ccnt[2] + ccnt[3]);
+        int na = 0, nc = 0;
+        for (int i = 0; i < kWaves; i++) { na += wcnt[i]; nc += ccnt[i]; }
+        unsigned long long old = atomicAdd((unsigned long long*)act_count, ((unsigned long long)(unsigned)nc << 32) | (unsigned)na);
+        base = (int)(old & 0xffffffffull);
+        cbase = (int)(old >> 32);
     }
     __syncthreads();
     if (a) {
@@ -259,7 +266,7 @@ __device__ __forceinline__ float block1024_sum(float v, float* sm16)
     return r;
 }
 
-__global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__ part, int nb, int* __restrict__ n_valid)
+__global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__ part, int nb, int* __restrict__ n_valid, float* __restrict__ n_valid_f)
 {
     __shared__ float sm[16];
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;     // independent chains: the loads overlap
@@ -267,7 +274,7 @@ __global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__
     for (; i + 3072 < nb; i += 4096) { acc0 += part[i]; acc1 += part[i + 1024]; acc2 += part[i + 2048]; acc3 += part[i + 3072]; }
     for (; i < nb; i += 1024) acc0 += part[i];
     float r = block1024_sum((acc0 + acc1) + (acc2 + acc3), sm);
-    if (threadIdx.x == 0) n_valid[0] = (int)(r + 0.5f);
+    if (threadIdx.x == 0) { n_valid[0] = (int)(r + 0.5f); n_valid_f[0] = (float)(int)(r + 0.5f); }
 }
 
 // per covered pixel with a non-zero image gradient: backward of shade + normalise + interpolate + rasterize for all three
@@ -503,7 +510,7 @@ int active_segments_impl(const unsigned long long* covw, const unsigned char* vm
 {
     if (N == 0) return FMHR_OK;
     long long nSeg = (N + 63) >> 6;
-    k_active_segments<<<cdiv(nSeg, kBlock), kBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, cov_list);
+    k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, cov_list);
     FMHR_CHECK_LAUNCH("k_active_segments");
     return FMHR_OK;
 }
@@ -519,7 +526,8 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
 
 int shade_fwd_impl(const float* rast, const int32_t* tri, const float* attr8, const float* sh,
                    const float* mask, int n, int F, int H, int W, const int* act_list, const int* act_count,
-                   const unsigned long long* covw, float* shaded, float* aa_init, float* part_cnt, int* n_valid, hipStream_t st)
+                   const unsigned long long* covw, float* shaded, float* aa_init, float* part_cnt, int* n_valid, float* n_valid_f,
+                   hipStream_t st)
 {
     long long P = (long long)H * W;
     if (n * P == 0) return FMHR_OK;
@@ -527,7 +535,7 @@ int shade_fwd_impl(const float* rast, const int32_t* tri, const float* attr8, co
     k_shade_fwd<<<nb, kBlock, 0, st>>>((const float4*)rast, tri, (const float4*)attr8, sh, mask, n, F, P, act_list, act_count, covw,
                                        (float4*)shaded, (float4*)aa_init, part_cnt);
     FMHR_CHECK_LAUNCH("k_shade_fwd");
-    k_reduce_count<<<1, 1024, 0, st>>>(part_cnt, nb, n_valid);
+    k_reduce_count<<<1, 1024, 0, st>>>(part_cnt, nb, n_valid, n_valid_f);
     FMHR_CHECK_LAUNCH("k_reduce_count");
     return FMHR_OK;
 }

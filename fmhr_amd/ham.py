@@ -67,7 +67,9 @@ class HamStage2:
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
         call("fmhr_ham_workspace_init", ctypes.byref(self.dims), ptr(self.ws), self.ws_bytes, st)
         self.n_valid_local = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.n_valid_global = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        # fmhr_ham_forward also leaves float(n_valid_local) in the workspace: it IS n_valid_global on one rank, and the
+        # all-reduce target (in place) when the views are sharded
+        self.n_valid_global = self.raw("n_valid_f", torch.float32, 1)
         self.losses = torch.zeros(8, dtype=torch.float32, device=self.dev)
         self.gdelta = torch.zeros(self.V, 3, dtype=torch.float32, device=self.dev)
         self.galbedo = torch.zeros(self.V, 3, dtype=torch.float32, device=self.dev)
@@ -99,7 +101,6 @@ class HamStage2:
         object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded."""
         self._check(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask)
         self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask)
-        self.n_valid_global.copy_(self.n_valid_local)        # int32 -> float32, on the stream
         if group is not None:
             torch.distributed.all_reduce(self.n_valid_global, group=group)
         self.backward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=reg_grads)

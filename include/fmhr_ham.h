@@ -159,9 +159,12 @@ size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
  *   n*H*W must be a multiple of 4.
  *   valid_mask_changed: pass 1 on the first call on a workspace and whenever valid_mask's CONTENTS may differ from the previous
  *   call (its per-segment non-zero flags are cached in the workspace; the mask is constant over a HAM run, :158).
- *   n_valid_local: device int32[1] written by phase A.  n_valid_global: device float[1] read by phase B.
+ *   n_valid_local: device int32[1] written by phase A.  n_valid_global: device float[1] read by phase B.  Phase A also
+ *   leaves float(n_valid_local) in the workspace at fmhr_ham_workspace_offset(d, "n_valid_f"): a one-rank caller passes that
+ *   address as n_valid_global; a sharded caller all-reduces it in place.
  *   losses: device float[8]; gdelta, galbedo [V,3] overwritten (view-dependent part only when reg_grads=0). */
-/* Must be called once on a fresh workspace (and after any aborted step): sets up the self-cleaning sparse rasterizer state. */
+/* Must be called once on a fresh workspace (and after any aborted step): sets up the self-cleaning state (depth keys, dirty
+ * flags, antialias-backward vertex accumulator) that every completed forward+backward pair leaves clean again. */
 int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);
 int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
                      const float* sh, const float* w2c, const float* proj, const float* mask, const float* valid_mask,
