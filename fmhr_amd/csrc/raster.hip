@@ -46,24 +46,6 @@ __device__ __forceinline__ bool setup_triangle(const int2 s0, const int2 s1, con
     return true;
 }
 
-// the same test in 32-bit arithmetic: exact whenever the triangle's snapped extent is below 2^14 sub-pixel units (64 px), which
-// is every triangle of the per-lane small-box path unless it pokes far outside the screen
-__device__ __forceinline__ bool edge_in32(int ax, int ay, int bx, int by, int cx, int cy)
-{
-    int dx = bx - ax, dy = by - ay;
-    int e = dx * (cy - ay) - dy * (cx - ax);
-    if (e > 0) return true;
-    if (e < 0) return false;
-    return (dy > 0) || (dy == 0 && dx > 0);
-}
-
-__device__ __forceinline__ bool covers32(const TriSetup& s, int px, int py)
-{
-    int cx = px * kSub + kHalf, cy = py * kSub + kHalf;
-    return edge_in32(s.x0, s.y0, s.x1, s.y1, cx, cy) && edge_in32(s.x1, s.y1, s.x2, s.y2, cx, cy) &&
-           edge_in32(s.x2, s.y2, s.x0, s.y0, cx, cy);
-}
-
 __device__ __forceinline__ bool covers(const TriSetup& s, int px, int py)
 {
     int cx = px * kSub + kHalf, cy = py * kSub + kHalf;
@@ -85,6 +67,27 @@ __device__ __forceinline__ void emit_fragment(const float4 p0, const float4 p1, 
     if (dirty != nullptr) dirty[(pixbase + (long long)pix) >> 6] = 1;
 }
 
+// antialias rule A3 on the snapped integer coordinates (same decision as antialias.hip: silhouette_bits_snapped): bit k set =
+// the edge opposite vertex k is a silhouette edge in this view (its neighbour is missing, rejected or on the same side)
+__device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, const int32_t* __restrict__ opp, const int2* __restrict__ sv,
+                                           const int2 s0, const int2 s1, const int2 s2, int b, int f, int F)
+{
+    if (silh == nullptr) return;
+    const int REJ = (int)0x80000000;
+    int o0 = opp[f * 3], o1 = opp[f * 3 + 1], o2 = opp[f * 3 + 2];
+    int2 q0 = (o0 < 0) ? make_int2(REJ, 0) : sv[o0], q1 = (o1 < 0) ? make_int2(REJ, 0) : sv[o1],
+         q2 = (o2 < 0) ? make_int2(REJ, 0) : sv[o2];
+    if (q0.x == REJ) q0 = s0;
+    if (q1.x == REJ) q1 = s1;
+    if (q2.x == REJ) q2 = s2;
+    long long bb = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s2.x - s0.x) * (s1.y - s0.y);
+    long long a0 = (long long)(s1.x - q0.x) * (s2.y - q0.y) - (long long)(s2.x - q0.x) * (s1.y - q0.y);
+    long long a1 = (long long)(s2.x - q1.x) * (s0.y - q1.y) - (long long)(s0.x - q1.x) * (s2.y - q1.y);
+    long long a2 = (long long)(s0.x - q2.x) * (s1.y - q2.y) - (long long)(s1.x - q2.x) * (s0.y - q2.y);
+    silh[(size_t)b * F + f] = (unsigned char)((((a0 < 0) == (bb < 0)) ? 1 : 0) | (((a1 < 0) == (bb < 0)) ? 2 : 0) |
+                                              (((a2 < 0) == (bb < 0)) ? 4 : 0));
+}
+
 // one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup; clip positions are only fetched by the
 // lanes whose triangle actually covers a pixel centre
 __global__ void __launch_bounds__(kBlock)
@@ -102,24 +105,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     TriSetup s;
     const int2 s0 = sv[i0], s1 = sv[i1], s2 = sv[i2];
     if (!setup_triangle(s0, s1, s2, H, W, s)) return;
-    if (silh != nullptr) {
-        // antialias rule A3 on the snapped coordinates, once per (view, triangle) that can own a pixel
-        const int REJ = (int)0x80000000;
-        int o0 = opp[f * 3], o1 = opp[f * 3 + 1], o2 = opp[f * 3 + 2];
-        int2 q0 = (o0 < 0) ? make_int2(REJ, 0) : sv[o0], q1 = (o1 < 0) ? make_int2(REJ, 0) : sv[o1],
-             q2 = (o2 < 0) ? make_int2(REJ, 0) : sv[o2];
-        if (q0.x == REJ) q0 = s0;
-        if (q1.x == REJ) q1 = s1;
-        if (q2.x == REJ) q2 = s2;
-        long long bb = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s2.x - s0.x) * (s1.y - s0.y);
-        long long a0 = (long long)(s1.x - q0.x) * (s2.y - q0.y) - (long long)(s2.x - q0.x) * (s1.y - q0.y);
-        long long a1 = (long long)(s2.x - q1.x) * (s0.y - q1.y) - (long long)(s0.x - q1.x) * (s2.y - q1.y);
-        long long a2 = (long long)(s0.x - q2.x) * (s1.y - q2.y) - (long long)(s1.x - q2.x) * (s0.y - q2.y);
-        silh[(size_t)b * F + f] = (unsigned char)((((a0 < 0) == (bb < 0)) ? 1 : 0) | (((a1 < 0) == (bb < 0)) ? 2 : 0) |
-                                                  (((a2 < 0) == (bb < 0)) ? 4 : 0));
-    }
     int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
     if (bw * (long long)bh > kSmallBox) {
+        write_silh(silh, opp, sv, s0, s1, s2, b, f, F);
         int slot = atomicAdd(large_cnt, 1);
         large_q[slot] = make_int2(b, f);
         return;
@@ -129,16 +117,58 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     float yo = 1.0f / (float)H; yo = yo - 1.0f;
     unsigned long long* kv = keys + (size_t)b * H * W;
     const float* vp = pos + (size_t)b * V * 4;
-    float4 p0, p1, p2;
-    bool loaded = false;
     const int ext = max(max(s.x0, max(s.x1, s.x2)) - min(s.x0, min(s.x1, s.x2)), max(s.y0, max(s.y1, s.y2)) - min(s.y0, min(s.y1, s.y2)));
-    const bool small = ext < 16384;   // pixel centres lie within the bbox +-1 px: every product < 2^29
-    for (int py = s.pya; py <= s.pyb; py++)
-        for (int px = s.pxa; px <= s.pxb; px++) {
-            if (!(small ? covers32(s, px, py) : covers(s, px, py))) continue;
-            if (!loaded) { p0 = ldg4(vp + (size_t)i0 * 4); p1 = ldg4(vp + (size_t)i1 * 4); p2 = ldg4(vp + (size_t)i2 * 4); loaded = true; }
-            emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W, dirty, (long long)b * H * W);
+    // 32-bit edge arithmetic is exact when the snapped extent is below 2^14 sub-pixel units (64 px): pixel centres lie within
+    // the box +-1 px, so every product stays below 2^29 (every small-box triangle unless it pokes far outside the screen)
+    const bool small = ext < 16384;
+    // pass 1: integer coverage of the (<= 64-pixel) box into a bit mask, no memory traffic.  Pass 2 then fetches the clip
+    // positions ONCE and walks the set bits: fetching at the first covered pixel inside the loop made a wave wait for memory
+    // once per distinct first-hit iteration among its lanes.
+    unsigned long long cm = 0ull;
+    if (small) {
+        // incremental edge functions: E_k = e_k - (tie rule admits e_k == 0 ? 0 : 1), inside <=> all three E_k >= 0 <=> the OR
+        // of the three has a clear sign bit; a pixel step adds a constant per edge (all values stay below 2^30)
+        const int cx0 = s.pxa * kSub + kHalf, cy0 = s.pya * kSub + kHalf;
+        int E0, E1, E2, sx0, sx1, sx2, sy0, sy1, sy2;
+        {
+            int dx = s.x1 - s.x0, dy = s.y1 - s.y0;
+            E0 = dx * (cy0 - s.y0) - dy * (cx0 - s.x0) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
+            sx0 = -dy * kSub; sy0 = dx * kSub;
+            dx = s.x2 - s.x1; dy = s.y2 - s.y1;
+            E1 = dx * (cy0 - s.y1) - dy * (cx0 - s.x1) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
+            sx1 = -dy * kSub; sy1 = dx * kSub;
+            dx = s.x0 - s.x2; dy = s.y0 - s.y2;
+            E2 = dx * (cy0 - s.y2) - dy * (cx0 - s.x2) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
+            sx2 = -dy * kSub; sy2 = dx * kSub;
         }
+        int bit = 0;
+        for (int r = 0; r < bh; r++) {
+            int e0 = E0, e1 = E1, e2 = E2;
+            for (int c = 0; c < bw; c++, bit++) {
+                if ((e0 | e1 | e2) >= 0) cm |= 1ull << bit;
+                e0 += sx0; e1 += sx1; e2 += sx2;
+            }
+            E0 += sy0; E1 += sy1; E2 += sy2;
+        }
+    } else {
+        int bit = 0;
+        for (int py = s.pya; py <= s.pyb; py++)
+            for (int px = s.pxa; px <= s.pxb; px++, bit++)
+                if (covers(s, px, py)) cm |= 1ull << bit;
+    }
+    if (cm == 0ull) return;
+    const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+    const unsigned long long rowbits = (bw >= 64) ? ~0ull : ((1ull << bw) - 1ull);
+    for (int r = 0; r < bh; r++) {
+        unsigned long long rm = (cm >> (r * bw)) & rowbits;
+        while (rm != 0ull) {
+            int c = __builtin_ctzll(rm);
+            rm &= rm - 1ull;
+            emit_fragment(p0, p1, p2, s.pxa + c, s.pya + r, f, xs, xo, ys, yo, kv, W, dirty, (long long)b * H * W);
+        }
+    }
+    // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
+    write_silh(silh, opp, sv, s0, s1, s2, b, f, F);
 }
 
 // one workgroup per queued large triangle (grid-stride over the queue; the count lives on the device)
