@@ -327,9 +327,9 @@ __device__ __forceinline__ void aa_fwd_pixel(long long gid, bool live, const flo
     int b = 0, px = 0, py = 0;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
-        b = (int)(gid / P);
-        int rem = (int)(gid - (long long)b * P);
-        py = rem / W; px = rem - py * W;
+        int rem;
+        b = fast_divmod(gid, (int)P, rem);
+        py = fast_divmod(rem, W, px);
         // in sparse mode rast is only defined on covered pixels: an uncovered pixel is the all-zero fragment
         if (covw == nullptr || ((covw[gid >> 6] >> (gid & 63)) & 1ull)) r0 = rast[gid];
     }
@@ -515,9 +515,9 @@ k_aa_bwd_px(const float* __restrict__ color, const float4* __restrict__ rast, co
         if (gid >= (long long)n * P) continue;
         uchar2 cd = reinterpret_cast<const uchar2*>(px_code)[gid];
         if ((cd.x | cd.y) == 0) continue;
-        int b = (int)(gid / P);
-        int rem = (int)(gid - (long long)b * P);
-        int py = rem / W, px = rem - py * W;
+        int rem, px;
+        const int b = fast_divmod(gid, (int)P, rem);
+        const int py = fast_divmod(rem, W, px);
         if (cd.x) aa_bwd_item<4, 0>(px, py, b, cd.x, px_alpha[gid * 2], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
         if (cd.y) aa_bwd_item<4, 0>(px, py, b, cd.y, px_alpha[gid * 2 + 1], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
     }

@@ -135,6 +135,19 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Exact g / d and g % d (0 <= g, 1 <= d < 2^31, quotient < 2^22) from a float estimate plus integer correction: the compiler's
+// 64-bit software division costs ~200 VALU instructions per lane, and every per-pixel / per-(view, triangle) kernel splits its
+// flat index this way.  The estimate is off by at most one for the quotients seen here; the loops make it exact regardless.
+__device__ __forceinline__ int fast_divmod(long long g, int d, int& r)
+{
+    int q = (int)((float)g * __builtin_amdgcn_rcpf((float)d));
+    long long rem = g - (long long)q * d;
+    while (rem < 0) { rem += d; q--; }
+    while (rem >= d) { rem -= d; q++; }
+    r = (int)rem;
+    return q;
+}
+
 // block (256 threads = 4 waves) sum; result valid in thread 0
 __device__ __forceinline__ float block_sum(float v, float* sm4)
 {

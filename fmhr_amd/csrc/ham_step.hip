@@ -47,7 +47,7 @@ int loss_pix_impl(const float*, const float*, const float*, const float*, const 
 int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*,
                  int, int, int, int, int, const unsigned long long*, const int*, const int*, const int*, float*, hipStream_t);
 int vertex_gather_impl(const float*, const int*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const float*,
-                       const float*, int, int, int, int, int, int, float*, float*, float*, float*, hipStream_t);
+                       const float*, int, int, int, int, int, int, int, float*, float*, float*, float*, hipStream_t);
 int finish_losses_impl(float*, const float*, const float*, const float*, int, const float*, int, float, float, float, hipStream_t);
 
 // workspace carving: every block 256-B aligned
@@ -84,7 +84,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.act_list = take(off, ((nP + 63) / 64) * 4);
     L.cov_list = take(off, ((nP + 63) / 64) * 4);
     L.act_count = take(off, 16);
-    L.head = take(off, (size_t)npad * d->F * 4);   // pixel-list heads, face-major, views innermost (padded to 8)
+    L.head = take(off, (size_t)npad * d->F * 4);   // pixel-list heads [npad, F], view-major (views padded to 8)
     L.next = take(off, nP * 4);
     L.rast = take(off, nP * 16);
     L.shaded = take(off, nP * 16);
@@ -290,7 +290,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                          d->H, d->W, (const unsigned long long*)(w + L.covw), (const int*)(w + L.next), (const int*)(w + L.cov_list),
                          (const int*)(w + L.act_count) + 1, (float*)(w + L.rec), st));
         TRY(vertex_gather_impl((float*)(w + L.rec), (int*)(w + L.head), vf_ptr, vf_idx, vc_ptr, ck, (const float*)(w + L.cmat),
-                               gvert_aa, d->n, npad, d->V, d->n_chunks, d->H, d->W, (float*)(w + L.part), nullptr, nullptr, nullptr,
+                               gvert_aa, d->n, npad, d->V, d->F, d->n_chunks, d->H, d->W, (float*)(w + L.part), nullptr, nullptr, nullptr,
                                st));
     }
     {

@@ -22,7 +22,8 @@ k_normals_faces(const float* __restrict__ verts, const int32_t* __restrict__ tri
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)nb * F) return;
-    int b = (int)(gid / F), f = (int)(gid - (long long)b * F);
+    int f;
+    const int b = fast_divmod(gid, F, f);
     int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
     if ((unsigned)i[0] >= (unsigned)V || (unsigned)i[1] >= (unsigned)V || (unsigned)i[2] >= (unsigned)V) return;
     const float* vb = verts + (size_t)b * V * 3;
@@ -73,7 +74,8 @@ k_normals_bwd_faces(const float* __restrict__ verts, const int32_t* __restrict__
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)nb * F) return;
-    int b = (int)(gid / F), f = (int)(gid - (long long)b * F);
+    int f;
+    const int b = fast_divmod(gid, F, f);
     int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
     if ((unsigned)i[0] >= (unsigned)V || (unsigned)i[1] >= (unsigned)V || (unsigned)i[2] >= (unsigned)V) return;
     const float* vb = verts + (size_t)b * V * 3;

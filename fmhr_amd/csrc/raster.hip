@@ -98,7 +98,8 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (long long)n * F) return;
-    int b = (int)(gid / F), f = (int)(gid - (long long)b * F);
+    int f;
+    const int b = fast_divmod(gid, F, f);
     int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
     if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return;
     const int2* sv = snap + (size_t)b * V;
@@ -232,9 +233,9 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     bool covered = false;
     if (key != ~0ull) {
-        int b = (int)(gid / P);
-        int rem = (int)(gid - (long long)b * P);
-        int py = rem / W, px = rem - py * W;
+        int rem, px;
+        const int b = fast_divmod(gid, (int)P, rem);
+        const int py = fast_divmod(rem, W, px);
         int f = (int)(key & 0xffffffffu);
         const float* vp = pos + (size_t)b * V * 4;
         const float4 p0 = ldg4(vp + (size_t)tri[f * 3] * 4), p1 = ldg4(vp + (size_t)tri[f * 3 + 1] * 4),
@@ -246,7 +247,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
             o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
             covered = true;
-            if (head != nullptr) next[gid] = atomicExch(&head[(size_t)f * npad + b], rem);
+            if (head != nullptr) next[gid] = atomicExch(&head[(size_t)b * F + f], rem);
         }
     }
     if (sparse) {
@@ -274,9 +275,9 @@ k_raster_bwd(const float* __restrict__ pos, const int32_t* __restrict__ tri, con
     if (t < 0 || t >= F) return;
     float4 g = dy[gid];
     if (g.x == 0.f && g.y == 0.f) return;
-    int b = (int)(gid / P);
-    int rem = (int)(gid - (long long)b * P);
-    int py = rem / W, px = rem - py * W;
+    int rem, px;
+    const int b = fast_divmod(gid, (int)P, rem);
+    const int py = fast_divmod(rem, W, px);
     int i0 = tri[t * 3], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
     const float* vp = pos + (size_t)b * V * 4;
     const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
@@ -317,7 +318,8 @@ k_interp_fwd(const float* __restrict__ attr, const float4* __restrict__ rast, co
         for (int c = 0; c < C; c++) o[c] = 0.f;
         return;
     }
-    int b = (int)(gid / P);
+    int rem_;
+    const int b = fast_divmod(gid, (int)P, rem_);
     const float* A = attr + (an == 1 ? 0 : (size_t)b * V * C);
     const float* a0 = A + (size_t)tri[t * 3] * C;
     const float* a1 = A + (size_t)tri[t * 3 + 1] * C;
@@ -336,7 +338,8 @@ k_interp_bwd(const float* __restrict__ attr, const float4* __restrict__ rast, co
     float4 r = rast[gid];
     int t = (int)r.w - 1;
     if (t < 0 || t >= F) { grast[gid] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
-    int b = (int)(gid / P);
+    int rem_;
+    const int b = fast_divmod(gid, (int)P, rem_);
     size_t off = (an == 1 ? 0 : (size_t)b * V * C);
     size_t i0 = (size_t)tri[t * 3] * C, i1 = (size_t)tri[t * 3 + 1] * C, i2 = (size_t)tri[t * 3 + 2] * C;
     const float* A = attr + off;

@@ -193,7 +193,8 @@ k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, co
             float w2 = 1.0f - r.x - r.y;
             o.w = r.x + r.y + w2;                                // interpolate of the ones attribute (:268-269)
             if (mask[gid] > 0.f) {
-                int b = (int)(gid / P);
+                int rem_;
+                const int b = fast_divmod(gid, (int)P, rem_);
                 float shc[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) shc[k] = sh[(size_t)b * 9 + k];
@@ -308,9 +309,9 @@ k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, cons
     float4 r = rast[gid];
     int t = (int)r.w - 1;
     if (t < 0 || t >= F) return;
-    int b = (int)(gid / P);
-    int rem = (int)(gid - (long long)b * P);
-    int py = rem / W, px = rem - py * W;
+    int rem, px;
+    const int b = fast_divmod(gid, (int)P, rem);
+    const int py = fast_divmod(rem, W, px);
     float c[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) c[k] = sh[(size_t)b * 9 + k];
@@ -361,8 +362,9 @@ k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, cons
     }
 }
 
-// Gather: one lane per (chunk of <= 4 face corners of one vertex, group of kGroup views).  The list heads are stored
-// face-major with the views innermost (head [F, npad]), so the kGroup heads of a face corner are ONE 32-B read; each non-empty
+// Gather: one lane per (chunk of <= kChunk face corners of one vertex, group of kGroup views).  The list heads are stored
+// view-major (head [npad, F]): the resolve pass's atomicExch of neighbouring pixels (neighbouring faces) then share cache lines
+// (108 -> 78 us there), and neighbouring gather lanes (faces) share the lines of each of their kGroup head loads; each non-empty
 // list is walked (one 64-B record line per pixel) and this corner's share of every record is summed: attribute gradients
 // b_k * (g_normal, g_albedo) and the position gradient q_k pushed through the clip transform of its view (cmat [n,3] = rows of
 // w2c @ proj) — the result is view-independent, no [n,V,4] position-gradient buffer exists.
@@ -372,7 +374,7 @@ constexpr int kGroup = 8;
 __global__ void __launch_bounds__(kBlock)
 k_vertex_gather(const float4* __restrict__ rec, const int* __restrict__ head, const int32_t* __restrict__ vf_ptr,
                 const int32_t* __restrict__ vf_idx, const int2* __restrict__ ck, const float4* __restrict__ cmat,
-                int n, int npad, int NC, int H, int W, float4* __restrict__ part)
+                int n, int npad, int F, int NC, int H, int W, float4* __restrict__ part)
 {
     int c = blockIdx.x * kBlock + threadIdx.x;
     int g = blockIdx.y;
@@ -390,7 +392,8 @@ k_vertex_gather(const float4* __restrict__ rec, const int* __restrict__ head, co
             float bk = (k == 0) ? r1.z : ((k == 1) ? r1.w : 1.0f - r1.z - r1.w);
             float qx = (k == 0) ? r2.x : ((k == 1) ? r2.z : r3.x);
             float qy = (k == 0) ? r2.y : ((k == 1) ? r2.w : r3.y);
-            int py = pix / W, px = pix - py * W;
+            int px;
+            const int py = fast_divmod(pix, W, px);
             float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
             gx += qx; gy += qy; gw += -fx * qx - fy * qy;
             an0 += bk * r0.x; an1 += bk * r0.y; an2 += bk * r0.z;
@@ -431,10 +434,11 @@ k_vertex_gather(const float4* __restrict__ rec, const int* __restrict__ head, co
     for (int e = e0; e < e1; e++) {
         const int code = vf_idx[e];
         const int f = code / 3, k = code - f * 3;
-        const int4* hp = reinterpret_cast<const int4*>(head + (size_t)f * npad + b0);
-        const int4 h0 = hp[0], h1 = hp[1];                    // the kGroup list heads of this face: one 32-B read
-        four(k, b0, h0.x, h0.y, h0.z, h0.w);
-        four(k, b0 + 4, h1.x, h1.y, h1.z, h1.w);
+        const int* hp = head + (size_t)b0 * F + f;            // view-major heads: neighbouring lanes (faces) share lines
+        const int h0 = hp[0], h1 = hp[F], h2 = hp[2 * (size_t)F], h3 = hp[3 * (size_t)F], h4 = hp[4 * (size_t)F],
+                  h5 = hp[5 * (size_t)F], h6 = hp[6 * (size_t)F], h7 = hp[7 * (size_t)F];
+        four(k, b0, h0, h1, h2, h3);
+        four(k, b0 + 4, h4, h5, h6, h7);
     }
     float4* o = part + ((size_t)g * NC + c) * 3;
     o[0] = make_float4(an0, an1, an2, aa0);
@@ -567,14 +571,14 @@ int pix_bwd_impl(const float* rast, const int32_t* tri, const float* pos, const 
 }
 
 int vertex_gather_impl(const float* rec, const int* head, const int32_t* vf_ptr, const int32_t* vf_idx, const int32_t* vc_ptr,
-                       const int32_t* ck, const float* cmat, const float* gvert_aa, int n, int npad, int V, int NC, int H, int W,
+                       const int32_t* ck, const float* cmat, const float* gvert_aa, int n, int npad, int V, int F, int NC, int H, int W,
                        float* part, float* gverts, float* gnormal, float* galbedo, hipStream_t st)
 {
     if (n == 0 || V == 0) return FMHR_OK;
     const int G = npad / kGroup;
     if (NC > 0) {
         k_vertex_gather<<<dim3(cdiv(NC, kBlock), G), kBlock, 0, st>>>((const float4*)rec, head, vf_ptr, vf_idx, (const int2*)ck,
-                                                                     (const float4*)cmat, n, npad, NC, H, W, (float4*)part);
+                                                                     (const float4*)cmat, n, npad, F, NC, H, W, (float4*)part);
         FMHR_CHECK_LAUNCH("k_vertex_gather");
     }
     if (gverts != nullptr) {      // stand-alone reduction; the fused step sums the partials in its mesh-tail kernel instead
