@@ -20,7 +20,7 @@ int mesh_tail_blocks(int V);
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
-                       void*, int*, int*, int, unsigned char*, unsigned long long*, int*, hipStream_t);
+                       void*, int*, float*, const float*, int, unsigned char*, unsigned long long*, int*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, int*,
                          hipStream_t);
@@ -48,12 +48,16 @@ int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const
                  int, int, int, int, int, const unsigned long long*, const int*, const int*, const int*, float*, hipStream_t);
 int vertex_gather_impl(const float*, const int*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const float*,
                        const float*, int, int, int, int, int, int, int, float*, float*, float*, float*, hipStream_t);
+int corner_slots_impl(const int32_t*, int, int32_t*, hipStream_t);
+int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const int*,
+                  const int32_t*, const float*, int, int, int, int, int, float*, hipStream_t);
+int face_bwd_groups(int n);
 int finish_losses_impl(float*, const float*, const float*, const float*, int, const float*, int, float, float, float, hipStream_t);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, head, next, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
-        g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, total;
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, head, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+        g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, corner_slot, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -85,7 +89,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.cov_list = take(off, ((nP + 63) / 64) * 4);
     L.act_count = take(off, 16);
     L.head = take(off, (size_t)npad * d->F * 4);   // pixel-list heads [npad, F], view-major (views padded to 8)
-    L.next = take(off, nP * 4);
+    L.bwd16 = take(off, nP * 16);             // per covered pixel: (u, v, link of its face's pixel list, mask > 0) for the backward
     L.rast = take(off, nP * 16);
     L.shaded = take(off, nP * 16);
     L.aa = take(off, nP * 16);
@@ -97,7 +101,8 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.rec = take(off, nP * 64);
     L.cmat = take(off, (size_t)d->n * 48);
     L.gvert_aa = take(off, V * 12);
-    L.part = take(off, (size_t)(npad / 8) * (size_t)(d->n_chunks > 0 ? d->n_chunks : 1) * 48);
+    L.part = take(off, (size_t)face_bwd_groups(d->n) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
+    L.corner_slot = take(off, (size_t)d->F * 12);
     L.partials = take(off, 2048 * 4 * 3);           // per-workgroup partial sums of the persistent pixel kernels
     L.gnormal = take(off, V * 12);
     L.gvert = take(off, V * 12);
@@ -148,7 +153,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
     Layout L = make_layout(d);
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
-    FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(head); FMHR_OFF(next); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
+    FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(head); FMHR_OFF(bwd16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
     FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_aa); FMHR_OFF(g_shaded); FMHR_OFF(rec); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(total);
 #undef FMHR_OFF
@@ -220,7 +225,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), st));
     }
     TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
-                           rast, w + L.raster_ws, (int*)(w + L.head), (int*)(w + L.next), (d->n + 7) / 8 * 8, (unsigned char*)(w + L.dirty), covw,
+                           rast, w + L.raster_ws, (int*)(w + L.head), (float*)(w + L.bwd16), mask, (d->n + 7) / 8 * 8, (unsigned char*)(w + L.dirty), covw,
                            (int*)(w + L.act_count), st));        // the resolve pass also rearms the two segment-list cursors
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
@@ -286,18 +291,16 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     {
         // shade + interpolate + rasterize backward, gather style: per-pixel records, then one lane per (view, vertex)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
-        TRY(pix_bwd_impl(rast, tri, pos, (float*)(w + L.attr8), sh, mask, (float*)(w + L.g_shaded), d->n, d->V, d->F,
-                         d->H, d->W, (const unsigned long long*)(w + L.covw), (const int*)(w + L.next), (const int*)(w + L.cov_list),
-                         (const int*)(w + L.act_count) + 1, (float*)(w + L.rec), st));
-        TRY(vertex_gather_impl((float*)(w + L.rec), (int*)(w + L.head), vf_ptr, vf_idx, vc_ptr, ck, (const float*)(w + L.cmat),
-                               gvert_aa, d->n, npad, d->V, d->F, d->n_chunks, d->H, d->W, (float*)(w + L.part), nullptr, nullptr, nullptr,
-                               st));
+        TRY(corner_slots_impl(vf_idx, d->F, (int32_t*)(w + L.corner_slot), st));
+        TRY(face_bwd_impl((const float*)(w + L.bwd16), tri, pos, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
+                          (const int*)(w + L.head), (const int32_t*)(w + L.corner_slot), (const float*)(w + L.cmat), d->n,
+                          d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
     }
     {
         // everything per-vertex after the gather, in two kernels (mesh.hip: k_mesh_tail_a / _b)
         ProfScope ps(FMHR_SLOT_REGULARISERS, st);
         MeshTailArgs A;
-        A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.vc_ptr = vc_ptr; A.G = npad / 8; A.NC = d->n_chunks;
+        A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.vc_ptr = vf_ptr; A.G = face_bwd_groups(d->n); A.NC = 3 * d->F;
         A.verts = vertices; A.delta = delta; A.albedo = albedo; A.nsum = (const float*)(w + L.nsum);
         A.tri = tri; A.vf_ptr = vf_ptr; A.vf_idx = vf_idx; A.row_ptr = row_ptr; A.col = col_idx;
         A.V = d->V; A.F = d->F;

@@ -209,7 +209,7 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
 __global__ void __launch_bounds__(kBlock)
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, int* __restrict__ head,
-                 int* __restrict__ next, int npad, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw,
+                 float4* __restrict__ bwd16, const float* __restrict__ mask, int npad, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw,
                  int* __restrict__ large_cnt, int* __restrict__ rearm2)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -247,7 +247,11 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
             o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
             covered = true;
-            if (head != nullptr) next[gid] = atomicExch(&head[(size_t)b * F + f], rem);
+            if (head != nullptr) {
+                // thread the pixel onto its face's list and leave everything the backward needs per pixel in ONE 16-B word
+                const int link = atomicExch(&head[(size_t)b * F + f], rem);
+                bwd16[gid] = make_float4(fr.u, fr.v, __int_as_float(link), (mask[gid] > 0.f) ? 1.f : 0.f);
+            }
         }
     }
     if (sparse) {
@@ -400,7 +404,7 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
 // snap [n,V] int2 must already hold the snapped vertices; head/next may be null.  dirty/covw non-null = sparse mode (the key
 // buffer must have been initialised by raster_sparse_init and is left clean again).
 int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, const int32_t* opp, unsigned char* silh, int n, int V,
-                       int F, int H, int W, float* rast, void* ws, int* head, int* next, int npad, unsigned char* dirty,
+                       int F, int H, int W, float* rast, void* ws, int* head, float* bwd16, const float* mask, int npad, unsigned char* dirty,
                        unsigned long long* covw, int* rearm2, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
@@ -436,7 +440,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         FMHR_CHECK_LAUNCH("k_raster_large");
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, next, npad,
+    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, (float4*)bwd16, mask, npad,
                                                                     dirty, covw, large_cnt, rearm2);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
@@ -454,7 +458,7 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     int2* snap = (int2*)((char*)ws + raster_core_ws_bytes(n, F, H, W));
     int rc = snap_vertices_impl(pos, n, V, H, W, snap, (hipStream_t)stream);
     if (rc) return rc;
-    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, 0, nullptr, nullptr,
+    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                               nullptr, (hipStream_t)stream);
 }
 

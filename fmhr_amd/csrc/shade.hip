@@ -446,6 +446,163 @@ k_vertex_gather(const float4* __restrict__ rec, const int* __restrict__ head, co
     o[2] = make_float4(vz, 0.f, 0.f, 0.f);
 }
 
+// ------------------------------------------------------------------------------------------------ face-parallel backward
+// One lane per (face, view); the kGroup lanes of a group are kGroup consecutive views of one face.  A lane whose face owns pixels
+// in its view loads the face ONCE (3 vertex ids, 3 x attr8, 3 clip positions), walks the face's pixel list (raster.hip: head
+// [n, F] and the per-pixel (u, v, link, mask flag) written by the resolve pass) doing the whole per-pixel backward (shade ->
+// normalise -> interpolate -> rasterize -> clip transform) in registers and accumulating the three corners' gradients; the group
+// is summed with DPP and lanes 0..2 store corner 0..2 as 3 x float4 into that corner's slot of its vertex's CSR row (corner_slot
+// = inverse of vf_idx), where the mesh tail sums a vertex's slots with coalesced loads.  No per-pixel record buffer, no float
+// atomics, deterministic.  These kernels are bound by the NUMBER of vector-memory requests (each scattered wave-load occupies
+// the texture-address unit for up to 64 cycles), so the per-lane request count is the budget: 1 head + 1 tri (12 B) + 6 attr8 +
+// 3 pos + 2 per pixel; the view's SH row and clip matrix come from an LDS copy.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float group_sum(float x)
+{
+    x += dpp_mov<0xB1>(x);      // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);      // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);     // row_half_mirror: lane i <-> 7 - i within each 8 lanes
+    if (kGroup == 16) x += dpp_mov<0x140>(x);   // row_mirror: lane i <-> 15 - i within each 16 lanes
+    return x;
+}
+
+struct int3a { int x, y, z; };
+
+__global__ void __launch_bounds__(kBlock)
+k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
+           const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
+           const int* __restrict__ head, const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, int n, int V,
+           int F, int H, int W, float4* __restrict__ part)
+{
+    static_assert(kGroup == 8 || kGroup == 16, "group_sum covers 8 or 16 lanes");
+    __shared__ float view_c[kGroup][24];                           // per view of the group: 9 SH coefficients, 12 clip-matrix entries
+    const long long P = (long long)H * W;
+    const int j = threadIdx.x & (kGroup - 1);
+    const int f = blockIdx.x * (kBlock / kGroup) + threadIdx.x / kGroup;
+    const int g = blockIdx.y, b = g * kGroup + j;
+    if (threadIdx.x < kGroup * 24) {
+        const int vb = threadIdx.x / 24, k = threadIdx.x - vb * 24, bb = g * kGroup + vb;
+        float v = 0.f;
+        if (bb < n) v = (k < 9) ? sh[(size_t)bb * 9 + k] : ((k < 21) ? reinterpret_cast<const float*>(cmat)[(size_t)bb * 12 + (k - 9)] : 0.f);
+        view_c[vb][k] = v;
+    }
+    __syncthreads();
+    const bool facelive = f < F;                                   // uniform over a group
+    float A[3][9];                                                 // per corner: g_normal.xyz, g_albedo.xyz, g_vertex.xyz
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int c = 0; c < 9; c++) A[k][c] = 0.f;
+    int p = (facelive && b < n) ? head[(size_t)b * F + f] : -1;
+    if (p >= 0) {
+        const long long vbase = (long long)b * P;
+        float4 gs = g_shaded[vbase + p];                           // the first pixel does not depend on the face data: issue first
+        float4 r = bwd16[vbase + p];
+        const int3a ti = *reinterpret_cast<const int3a*>(tri + (size_t)f * 3);
+        const float4 q0 = attr8[(size_t)ti.x * 2], q1 = attr8[(size_t)ti.x * 2 + 1];
+        const float4 u0 = attr8[(size_t)ti.y * 2], u1 = attr8[(size_t)ti.y * 2 + 1];
+        const float4 w0 = attr8[(size_t)ti.z * 2], w1 = attr8[(size_t)ti.z * 2 + 1];
+        const float* vp = pos + (size_t)b * V * 4;
+        const float4 p0 = ldg4(vp + (size_t)ti.x * 4), p1 = ldg4(vp + (size_t)ti.y * 4), p2 = ldg4(vp + (size_t)ti.z * 4);
+        float c[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) c[k] = view_c[j][k];
+        const float3 n2 = make_float3(w0.x, w0.y, w0.z), a2 = make_float3(w0.w, w1.x, w1.y);
+        const float3 dn0 = make_float3(q0.x - n2.x, q0.y - n2.y, q0.z - n2.z), da0 = make_float3(q0.w - a2.x, q1.x - a2.y, q1.y - a2.z);
+        const float3 dn1 = make_float3(u0.x - n2.x, u0.y - n2.y, u0.z - n2.z), da1 = make_float3(u0.w - a2.x, u1.x - a2.y, u1.y - a2.z);
+        const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
+        float gx[3] = {0.f, 0.f, 0.f}, gy[3] = {0.f, 0.f, 0.f}, gw[3] = {0.f, 0.f, 0.f};
+        while (true) {
+            const int nx = __float_as_int(r.z);
+            if (r.w != 0.f && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) {
+                const float b0 = r.x, b1 = r.y, b2 = 1.0f - r.x - r.y;
+                // forward recompute (shade_eval, with the corner-2-relative attribute differences)
+                const float nxr = n2.x + b0 * dn0.x + b1 * dn1.x, nyr = n2.y + b0 * dn0.y + b1 * dn1.y,
+                            nzr = n2.z + b0 * dn0.z + b1 * dn1.z;
+                const float ar = a2.x + b0 * da0.x + b1 * da1.x, ag = a2.y + b0 * da0.y + b1 * da1.y,
+                            ab = a2.z + b0 * da0.z + b1 * da1.z;
+                const float len = fsqrt(nxr * nxr + nyr * nyr + nzr * nzr);
+                const float inv = frcp(fmaxf(len, 1e-12f));
+                const float x = nxr * inv, y = nyr * inv, z = nzr * inv;
+                const float rad = sh9c(c, x, y, z);
+                // shade backward (mesh_sfs_optim.py:284-286, models/utils.py:208-226)
+                const float g_rad = gs.x * ar + gs.y * ag + gs.z * ab;
+                const float ga0 = gs.x * rad, ga1 = gs.y * rad, ga2 = gs.z * rad;
+                const float dx = c[3] + c[4] * y - 2.0f * c[6] * x + c[7] * z + 2.0f * c[8] * x;
+                const float dy = c[1] + c[4] * x + c[5] * z - 2.0f * c[6] * y - 2.0f * c[8] * y;
+                const float dz = c[2] + c[5] * y + 4.0f * c[6] * z + c[7] * x;
+                const float ghx = g_rad * dx, ghy = g_rad * dy, ghz = g_rad * dz;
+                float gnx, gny, gnz;
+                if (len > 1e-12f) {
+                    const float dt = x * ghx + y * ghy + z * ghz;
+                    gnx = (ghx - x * dt) * inv; gny = (ghy - y * dt) * inv; gnz = (ghz - z * dt) * inv;
+                } else {
+                    gnx = ghx * 1e12f; gny = ghy * 1e12f; gnz = ghz * 1e12f;
+                }
+                // interpolate backward w.r.t. the barycentrics
+                const float gu = gnx * dn0.x + gny * dn0.y + gnz * dn0.z + ga0 * da0.x + ga1 * da0.y + ga2 * da0.z;
+                const float gv = gnx * dn1.x + gny * dn1.y + gnz * dn1.z + ga0 * da1.x + ga1 * da1.y + ga2 * da1.z;
+                // rasterize backward (Appendix B.1) for the three corners
+                int px;
+                const int py = fast_divmod(p, W, px);
+                const float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
+                const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+                const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+                const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+                const float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
+                const float iw = frcp(e0 + e1 + e2);
+                const float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * (e0 * iw) + gb1 * (e1 * iw);
+                const float qx[3] = {gbb * (p2y - p1y) - gb1 * p2y, gbb * (p0y - p2y) + gb0 * p2y,
+                                     gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y};
+                const float qy[3] = {gbb * (p1x - p2x) + gb1 * p2x, gbb * (p2x - p0x) - gb0 * p2x,
+                                     gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x};
+                const float bk[3] = {b0, b1, b2};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    A[k][0] += bk[k] * gnx; A[k][1] += bk[k] * gny; A[k][2] += bk[k] * gnz;
+                    A[k][3] += bk[k] * ga0; A[k][4] += bk[k] * ga1; A[k][5] += bk[k] * ga2;
+                    gx[k] += qx[k]; gy[k] += qy[k]; gw[k] += -fx * qx[k] - fy * qy[k];
+                }
+            }
+            p = nx;
+            if (p < 0) break;
+            gs = g_shaded[vbase + p];
+            r = bwd16[vbase + p];
+        }
+        // clip-transform backward of this view (cmat rows of w2c @ proj): position gradients become view-independent
+        const float* cm = &view_c[j][9];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            A[k][6] = gx[k] * cm[0] + gy[k] * cm[1] + gw[k] * cm[2];
+            A[k][7] = gx[k] * cm[4] + gy[k] * cm[5] + gw[k] * cm[6];
+            A[k][8] = gx[k] * cm[8] + gy[k] * cm[9] + gw[k] * cm[10];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int c = 0; c < 9; c++) A[k][c] = group_sum(A[k][c]);
+    if (facelive && j < 3) {
+        float o[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) o[c] = (j == 0) ? A[0][c] : ((j == 1) ? A[1][c] : A[2][c]);
+        const int e = corner_slot[f * 3 + j];
+        float4* dst = part + ((size_t)g * 3 * F + e) * 3;
+        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+        dst[2] = make_float4(o[8], 0.f, 0.f, 0.f);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_corner_slots(const int32_t* __restrict__ vf_idx, int n3, int32_t* __restrict__ slot)
+{
+    int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e < n3) slot[vf_idx[e]] = e;
+}
+
 // per vertex: sum the partials of its chunks over all view groups; gverts = position part + the antialias-backward part
 // (gvert_aa), gnormal, galbedo — first writer of gverts / galbedo this step: plain stores, later kernels accumulate
 __global__ void __launch_bounds__(kBlock)
@@ -587,6 +744,28 @@ int vertex_gather_impl(const float* rec, const int* head, const int32_t* vf_ptr,
     }
     return FMHR_OK;
 }
+
+int corner_slots_impl(const int32_t* vf_idx, int F, int32_t* slot, hipStream_t st)
+{
+    if (F == 0) return FMHR_OK;
+    k_corner_slots<<<cdiv(3LL * F, kBlock), kBlock, 0, st>>>(vf_idx, 3 * F, slot);
+    FMHR_CHECK_LAUNCH("k_corner_slots");
+    return FMHR_OK;
+}
+
+int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
+                  const int* head, const int32_t* corner_slot, const float* cmat, int n, int V, int F, int H, int W, float* part,
+                  hipStream_t st)
+{
+    if (n == 0 || F == 0) return FMHR_OK;
+    k_face_bwd<<<dim3(cdiv(F, kBlock / kGroup), cdiv(n, kGroup)), kBlock, 0, st>>>(
+        (const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded, head, corner_slot, (const float4*)cmat,
+        n, V, F, H, W, (float4*)part);
+    FMHR_CHECK_LAUNCH("k_face_bwd");
+    return FMHR_OK;
+}
+
+int face_bwd_groups(int n) { return cdiv(n, kGroup); }
 
 int finish_losses_impl(float* losses, const float* n_valid, const float* part_l1, const float* part_l2, int nb,
                        const float* tail_part, int tail_nb, float w_sfs, float w_mask, float mse_den, hipStream_t st)
