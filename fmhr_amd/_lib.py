@@ -13,7 +13,7 @@ c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size
 
 class HamDims(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("V", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32),
-                ("W", ctypes.c_int32), ("nnz", ctypes.c_int32), ("aa_cap", ctypes.c_int32), ("n_chunks", ctypes.c_int32)]
+                ("W", ctypes.c_int32), ("nnz", ctypes.c_int32), ("aa_cap", ctypes.c_int32)]
 
 
 class HamWeights(ctypes.Structure):
@@ -61,8 +61,8 @@ SIGNATURES = {
     "fmhr_ham_workspace_init": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),
     "fmhr_ham_densify": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),
     "fmhr_ham_backward": (c_int, [ctypes.POINTER(HamDims), ctypes.POINTER(HamWeights), P, P, P, P, P, P, P, P, P, P, P, P, P,
-                                  P, P, P, P, P, P, P, P, P, c_size_t, P]),
-    "fmhr_vertex_chunks_build": (c_int, [P, c_int, P, P, P, c_size_t, P]),
+                                  P, P, P, P, P, P, P, P, c_size_t, P]),
+    "fmhr_corner_slots_build": (c_int, [P, c_int, P, P]),
     "fmhr_vertex_faces_workspace_bytes": (c_size_t, [c_int]),
     "fmhr_vertex_faces_build": (c_int, [P, c_int, c_int, P, P, P, c_size_t, P]),
 }

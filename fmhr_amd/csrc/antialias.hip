@@ -159,20 +159,12 @@ __global__ void k_vf_fill(const int32_t* __restrict__ tri, int F, int V, const i
     if ((unsigned)v < (unsigned)V) idx[row_ptr[v] + atomicAdd(&cursor[v], 1)] = code;
 }
 
-// split every vertex's CSR row into chunks of <= kChunk corners: the gather assigns one lane per (chunk, view group), so a
-// high-valence vertex (valence 37 at the pole of the benchmark mesh; scans can have far more) cannot serialise the kernel
-__global__ void k_chunk_count(const int* __restrict__ vf_ptr, int V, int* cnt)
+// inverse of vf_idx: slot[3*face + corner] = position of that corner in its vertex's CSR row (the face-parallel backward of the
+// fused step stores each corner's gradient at its slot; the mesh tail then sums a vertex's slots with contiguous loads)
+__global__ void __launch_bounds__(kBlock) k_corner_slots(const int32_t* __restrict__ vf_idx, int n3, int32_t* __restrict__ slot)
 {
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v < V) cnt[v] = (vf_ptr[v + 1] - vf_ptr[v] + kChunk - 1) / kChunk;
-}
-
-__global__ void k_chunk_fill(const int* __restrict__ vf_ptr, const int* __restrict__ vc_ptr, int V, int2* __restrict__ ck)
-{
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= V) return;
-    int c0 = vc_ptr[v], c1 = vc_ptr[v + 1], e = vf_ptr[v];
-    for (int c = c0; c < c1; c++, e += kChunk) ck[c] = make_int2(v, e);
+    int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e < n3) slot[vf_idx[e]] = e;
 }
 
 // ------------------------------------------------------------------------------------------------ antialias analysis
@@ -650,23 +642,13 @@ extern "C" int fmhr_vertex_faces_build(const int32_t* tri, int F, int V, int32_t
     return FMHR_OK;
 }
 
-extern "C" int fmhr_vertex_chunks_build(const int32_t* vf_ptr, int V, int32_t* vc_ptr, int32_t* ck, void* ws, size_t ws_bytes,
-                                        void* stream)
+extern "C" int fmhr_corner_slots_build(const int32_t* vf_idx, int F, int32_t* corner_slot, void* stream)
 {
-    FMHR_CHECK_ARG(V >= 0, "vertex_chunks_build: bad dims");
-    FMHR_CHECK_ARG(vf_ptr && vc_ptr && ck && ws && ws_bytes >= (size_t)(V + 1) * 4, "vertex_chunks_build: null pointer / small workspace");
-    hipStream_t st = (hipStream_t)stream;
-    int* cnt = (int*)ws;
-    if (V > 0) {
-        k_chunk_count<<<cdiv(V, kBlock), kBlock, 0, st>>>(vf_ptr, V, cnt);
-        FMHR_CHECK_LAUNCH("k_chunk_count");
-    }
-    k_scan_exclusive<<<1, 1024, 0, st>>>(cnt, V, vc_ptr);
-    FMHR_CHECK_LAUNCH("k_scan_exclusive");
-    if (V > 0) {
-        k_chunk_fill<<<cdiv(V, kBlock), kBlock, 0, st>>>(vf_ptr, vc_ptr, V, (int2*)ck);
-        FMHR_CHECK_LAUNCH("k_chunk_fill");
-    }
+    FMHR_CHECK_ARG(F >= 0, "corner_slots_build: bad F=%d", F);
+    if (F == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(vf_idx && corner_slot, "corner_slots_build: null pointer");
+    k_corner_slots<<<cdiv(3LL * F, kBlock), kBlock, 0, (hipStream_t)stream>>>(vf_idx, 3 * F, corner_slot);
+    FMHR_CHECK_LAUNCH("k_corner_slots");
     return FMHR_OK;
 }
 

@@ -44,7 +44,6 @@ bool debug_sync();                                   // abi.cpp: FMHR_DEBUG_SYNC
     } while (0)
 
 constexpr int kBlock = 256;
-constexpr int kChunk = 2;         // face corners per gather chunk (fmhr_vertex_chunks_build / k_vertex_gather)
 constexpr int kSub = 256;        // sub-pixel units per pixel (8 bits)
 constexpr int kHalf = 128;
 constexpr float kSnapLim = 4194304.0f;   // 2^22 sub-pixel guard band

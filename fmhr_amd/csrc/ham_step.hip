@@ -6,7 +6,7 @@
 
 namespace fmhr {
 struct MeshTailArgs {
-    const float4* part; float* gvert_aa; const int32_t* vc_ptr; int G, NC;
+    const float4* part; float* gvert_aa; int G;
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     int V, F;
@@ -44,11 +44,6 @@ int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, con
                    const int*, const unsigned long long*, float*, float*, float*, int*, float*, hipStream_t);
 int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
-int pix_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const float*,
-                 int, int, int, int, int, const unsigned long long*, const int*, const int*, const int*, float*, hipStream_t);
-int vertex_gather_impl(const float*, const int*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const float*,
-                       const float*, int, int, int, int, int, int, int, float*, float*, float*, float*, hipStream_t);
-int corner_slots_impl(const int32_t*, int, int32_t*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const int*,
                   const int32_t*, const float*, int, int, int, int, int, float*, hipStream_t);
 int face_bwd_groups(int n);
@@ -57,7 +52,7 @@ int finish_losses_impl(float*, const float*, const float*, const float*, int, co
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, head, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
-        g_shaded, rec, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, corner_slot, total;
+        g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -98,11 +93,9 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.aa_counter = take(off, 16);
     L.g_aa = take(off, nP * 16);
     L.g_shaded = take(off, nP * 16);
-    L.rec = take(off, nP * 64);
     L.cmat = take(off, (size_t)d->n * 48);
     L.gvert_aa = take(off, V * 12);
     L.part = take(off, (size_t)face_bwd_groups(d->n) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
-    L.corner_slot = take(off, (size_t)d->F * 12);
     L.partials = take(off, 2048 * 4 * 3);           // per-workgroup partial sums of the persistent pixel kernels
     L.gnormal = take(off, V * 12);
     L.gvert = take(off, V * 12);
@@ -154,7 +147,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(head); FMHR_OFF(bwd16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
-    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_aa); FMHR_OFF(g_shaded); FMHR_OFF(rec); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
+    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_aa); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(total);
 #undef FMHR_OFF
     set_error("ham_workspace_offset: unknown buffer '%s'", name);
@@ -248,7 +241,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                                  const float* delta, const float* albedo, const float* sh, const float* w2c, const float* proj,
                                  const float* img, const float* mask, const float* valid_mask, const int32_t* tri,
                                  const int32_t* opp, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* vf_ptr,
-                                 const int32_t* vf_idx, const int32_t* vc_ptr, const int32_t* ck,
+                                 const int32_t* vf_idx, const int32_t* corner_slot,
                                  const float* n_valid_global, float* losses, float* gdelta,
                                  float* galbedo, void* ws, size_t ws_bytes, void* stream)
 {
@@ -257,8 +250,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_backward: workspace too small (%zu < %zu)", ws_bytes, L.total);
     FMHR_CHECK_ARG(wt && delta && albedo && sh && w2c && proj && img && mask && valid_mask && tri && row_ptr && col_idx &&
-                       vf_ptr && vf_idx && vc_ptr && ck && n_valid_global && losses && gdelta && galbedo, "ham_backward: null pointer");
-    FMHR_CHECK_ARG(d->n_chunks >= 1, "ham_backward: dims.n_chunks must be vc_ptr[V] from fmhr_vertex_chunks_build");
+                       vf_ptr && vf_idx && corner_slot && n_valid_global && losses && gdelta && galbedo, "ham_backward: null pointer");
     FMHR_CHECK_ARG(wt->mse_denominator > 0.f, "ham_backward: mse_denominator must be > 0");
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
@@ -289,18 +281,17 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                         (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, st));
     }
     {
-        // shade + interpolate + rasterize backward, gather style: per-pixel records, then one lane per (view, vertex)
+        // shade + interpolate + rasterize + clip-transform backward, face-parallel (shade.hip: k_face_bwd)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
-        TRY(corner_slots_impl(vf_idx, d->F, (int32_t*)(w + L.corner_slot), st));
         TRY(face_bwd_impl((const float*)(w + L.bwd16), tri, pos, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
-                          (const int*)(w + L.head), (const int32_t*)(w + L.corner_slot), (const float*)(w + L.cmat), d->n,
+                          (const int*)(w + L.head), corner_slot, (const float*)(w + L.cmat), d->n,
                           d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
     }
     {
         // everything per-vertex after the gather, in two kernels (mesh.hip: k_mesh_tail_a / _b)
         ProfScope ps(FMHR_SLOT_REGULARISERS, st);
         MeshTailArgs A;
-        A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.vc_ptr = vf_ptr; A.G = face_bwd_groups(d->n); A.NC = 3 * d->F;
+        A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n);
         A.verts = vertices; A.delta = delta; A.albedo = albedo; A.nsum = (const float*)(w + L.nsum);
         A.tri = tri; A.vf_ptr = vf_ptr; A.vf_idx = vf_idx; A.row_ptr = row_ptr; A.col = col_idx;
         A.V = d->V; A.F = d->F;

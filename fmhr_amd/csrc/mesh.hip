@@ -483,7 +483,7 @@ k_edge_hinge_gather(const float* __restrict__ verts, const int32_t* __restrict__
 //    Laplacians forward -> loss terms and scaled row gradients; delta term; edge hinge (loss + gradient).
 // B (neighbour gathers): vertex-normal backward from gs, L^T r for both Laplacians -> final gdelta / galbedo.
 struct MeshTailArgs {
-    const float4* part; float* gvert_aa; const int32_t* vc_ptr; int G, NC;      // gather partials
+    const float4* part; float* gvert_aa; int G;                                       // face-backward corner sums [G, 3F] x 3 float4
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     int V, F;
@@ -501,12 +501,13 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
     float l_lap = 0.f, l_alb = 0.f, l_edge = 0.f, l_delta = 0.f;
     const bool live = v < A.V;                                     // uniform over a vertex's lanes
     const int vv = live ? v : 0;
-    // (1) partial sums of the pixel gather: a vertex's chunks are 3*nc consecutive float4 per group plane; the lanes stride over
-    //     them (neighbouring vertices continue the same run: coalesced) with the G plane loads of one element independent
+    // (1) corner sums of the face-parallel backward: a vertex's corners are 3*deg consecutive float4 per view-group plane (vf CSR
+    //     order); the lanes stride over them (neighbouring vertices continue the same run: coalesced), the G plane loads of one
+    //     element are independent
     float n0 = 0.f, n1 = 0.f, n2 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
     if (live) {
-        const int c0 = A.vc_ptr[vv], nq = (A.vc_ptr[vv + 1] - c0) * 3;
-        const size_t plane = (size_t)A.NC * 3;
+        const int c0 = A.vf_ptr[vv], nq = (A.vf_ptr[vv + 1] - c0) * 3;
+        const size_t plane = (size_t)A.F * 9;
         for (int j = sub; j < nq; j += kSubLanes) {
             const float4* q = A.part + (size_t)c0 * 3 + j;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);

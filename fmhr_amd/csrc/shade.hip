@@ -1,9 +1,9 @@
 // fmhr_amd/csrc/shade.hip — fused per-pixel / per-vertex kernels of the stage-2 HAM step for gfx950.
 // One pass replaces the reference's interpolate(C=7) -> slices -> F.normalize -> boolean gather -> get_radiance ->
 // multiply -> scatter chain (/root/reference/mesh_sfs_optim.py:268-286), one pass the two loss reductions (:289,:295).
-// The backward is GATHER-style: a per-pixel pass writes one 32-B gradient record per covered pixel, then one lane per
-// (view, vertex) walks the pixel lists of its incident faces (threaded by the rasterizer) and sums its own gradient — no
-// float atomics (the scatter form ran at the 0.08 TB/s "64 lanes -> 64 rows" atomic shape: 3.6 ms per step).
+// The backward is FACE-parallel: one lane per (face, view) walks the face's pixel list (threaded by the rasterizer), does the
+// whole per-pixel backward in registers and stores per-corner sums that the mesh tail adds up per vertex — no float atomics
+// (the scatter form ran at the 0.08 TB/s "64 lanes -> 64 rows" atomic shape: 3.6 ms per step).
 #include "common.h"
 #include <stdlib.h>
 
@@ -278,173 +278,7 @@ __global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__
     if (threadIdx.x == 0) { n_valid[0] = (int)(r + 0.5f); n_valid_f[0] = (float)(int)(r + 0.5f); }
 }
 
-// per covered pixel with a non-zero image gradient: backward of shade + normalise + interpolate + rasterize for all three
-// corners at once, written as ONE 64-B line-aligned record (4 x float4):
-//   R0 = (g_normal_raw.xyz, g_albedo.x)  R1 = (g_albedo.yz, u, v)  R2 = (q0x, q0y, q1x, q1y)  R3 = (q2x, q2y, list link, flag)
-// (q_k = clip-space (x, y) gradient of corner k; its w component is -fx*qx - fy*qy, recomputed by the
-// gather from the pixel index).  The link of the pixel's per-face list rides in the record, so a gather visit is one line.
-__global__ void __launch_bounds__(kBlock)
-k_pix_bwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float* __restrict__ pos,
-          const float4* __restrict__ attr8, const float* __restrict__ sh,
-          const float* __restrict__ mask, const float4* __restrict__ g_shaded, int n, int V, int F, int H, int W,
-          const unsigned long long* __restrict__ covw, const int* __restrict__ next, const int* __restrict__ act_list,
-          const int* __restrict__ act_count, float4* __restrict__ rec)
-{
-    // dense launch (one wave per 64-pixel segment, uncovered segments leave after one 8-B load): the persistent-loop form of
-    // the other pixel kernels was measured SLOWER here (157 vs 132 us) — this kernel is a long dependent chain per pixel and
-    // wants as many independent waves in flight as possible
-    const long long P = (long long)H * W;
-    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    (void)act_list; (void)act_count;
-    {
-    if (gid >= (long long)n * P) return;
-    if (!((covw[gid >> 6] >> (gid & 63)) & 1ull)) return;
-    float4 g = g_shaded[gid];
-    float4* o = rec + gid * 4;
-    const int link = next[gid];                        // the list link travels inside the record: one 64-B line per visit
-    if (!(mask[gid] > 0.f) || (g.x == 0.f && g.y == 0.f && g.z == 0.f)) {
-        o[3] = make_float4(0.f, 0.f, __int_as_float(link), 0.f);   // .w = 0: covered but gradient-free, the gather skips it
-        return;
-    }
-    float4 r = rast[gid];
-    int t = (int)r.w - 1;
-    if (t < 0 || t >= F) return;
-    int rem, px;
-    const int b = fast_divmod(gid, (int)P, rem);
-    const int py = fast_divmod(rem, W, px);
-    float c[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) c[k] = sh[(size_t)b * 9 + k];
-    PixShade s;
-    shade_eval(r, tri, attr8, c, s);
-    float g_rad = g.x * s.ar + g.y * s.ag + g.z * s.ab;
-    float ga0 = g.x * s.rad, ga1 = g.y * s.rad, ga2 = g.z * s.rad;
-    float x = s.hx, y = s.hy, z = s.hz;
-    float dx = c[3] + c[4] * y - 2.0f * c[6] * x + c[7] * z + 2.0f * c[8] * x;
-    float dy = c[1] + c[4] * x + c[5] * z - 2.0f * c[6] * y - 2.0f * c[8] * y;
-    float dz = c[2] + c[5] * y + 4.0f * c[6] * z + c[7] * x;
-    float ghx = g_rad * dx, ghy = g_rad * dy, ghz = g_rad * dz;
-    float gnx, gny, gnz;
-    if (s.len > 1e-12f) {
-        float inv = frcp(s.len);
-        float dt = x * ghx + y * ghy + z * ghz;
-        gnx = (ghx - x * dt) * inv; gny = (ghy - y * dt) * inv; gnz = (ghz - z * dt) * inv;
-    } else {
-        gnx = ghx * 1e12f; gny = ghy * 1e12f; gnz = ghz * 1e12f;
-    }
-    // interpolate backward w.r.t. the barycentrics; the ones channel contributes exactly 0
-    float gu = gnx * (s.n0.x - s.n2.x) + gny * (s.n0.y - s.n2.y) + gnz * (s.n0.z - s.n2.z) +
-               ga0 * (s.a0.x - s.a2.x) + ga1 * (s.a0.y - s.a2.y) + ga2 * (s.a0.z - s.a2.z);
-    float gv = gnx * (s.n1.x - s.n2.x) + gny * (s.n1.y - s.n2.y) + gnz * (s.n1.z - s.n2.z) +
-               ga0 * (s.a1.x - s.a2.x) + ga1 * (s.a1.y - s.a2.y) + ga2 * (s.a1.z - s.a2.z);
-    // rasterize backward (Appendix B.1) for the three corners
-    const float* vp = pos + (size_t)b * V * 4;
-    const float4 p0 = ldg4(vp + (size_t)s.i0 * 4), p1 = ldg4(vp + (size_t)s.i1 * 4), p2 = ldg4(vp + (size_t)s.i2 * 4);
-    float fx = (2.0f / (float)W) * (float)px + (1.0f / (float)W - 1.0f);
-    float fy = (2.0f / (float)H) * (float)py + (1.0f / (float)H - 1.0f);
-    float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-    float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-    float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-    float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
-    float iw = frcp(e0 + e1 + e2);
-    float bb0 = e0 * iw, bb1 = e1 * iw;
-    float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * bb0 + gb1 * bb1;
-    float q0x = gbb * (p2y - p1y) - gb1 * p2y;
-    float q1x = gbb * (p0y - p2y) + gb0 * p2y;
-    float q2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
-    float q0y = gbb * (p1x - p2x) + gb1 * p2x;
-    float q1y = gbb * (p2x - p0x) - gb0 * p2x;
-    float q2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
-    o[0] = make_float4(gnx, gny, gnz, ga0);
-    o[1] = make_float4(ga1, ga2, r.x, r.y);
-    o[2] = make_float4(q0x, q0y, q1x, q1y);
-    o[3] = make_float4(q2x, q2y, __int_as_float(link), 1.f);       // .w = 1: record carries gradients
-    }
-}
-
-// Gather: one lane per (chunk of <= kChunk face corners of one vertex, group of kGroup views).  The list heads are stored
-// view-major (head [npad, F]): the resolve pass's atomicExch of neighbouring pixels (neighbouring faces) then share cache lines
-// (108 -> 78 us there), and neighbouring gather lanes (faces) share the lines of each of their kGroup head loads; each non-empty
-// list is walked (one 64-B record line per pixel) and this corner's share of every record is summed: attribute gradients
-// b_k * (g_normal, g_albedo) and the position gradient q_k pushed through the clip transform of its view (cmat [n,3] = rows of
-// w2c @ proj) — the result is view-independent, no [n,V,4] position-gradient buffer exists.
-// Output: part [G, n_chunks, 3 x float4] partial sums.
-constexpr int kGroup = 8;
-
-__global__ void __launch_bounds__(kBlock)
-k_vertex_gather(const float4* __restrict__ rec, const int* __restrict__ head, const int32_t* __restrict__ vf_ptr,
-                const int32_t* __restrict__ vf_idx, const int2* __restrict__ ck, const float4* __restrict__ cmat,
-                int n, int npad, int F, int NC, int H, int W, float4* __restrict__ part)
-{
-    int c = blockIdx.x * kBlock + threadIdx.x;
-    int g = blockIdx.y;
-    if (c >= NC) return;
-    const int2 cd = ck[c];
-    const int e0 = cd.y, e1 = min(cd.y + kChunk, vf_ptr[cd.x + 1]);
-    const int b0 = g * kGroup;
-    const long long P = (long long)H * W;
-    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
-    float an0 = 0.f, an1 = 0.f, an2 = 0.f, aa0 = 0.f, aa1 = 0.f, aa2 = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
-    // consume one record for corner k; returns the list link
-    auto consume = [&](int k, int pix, const float4 r0, const float4 r1, const float4 r2, const float4 r3, float& gx, float& gy,
-                       float& gw) {
-        if (r3.w != 0.f) {
-            float bk = (k == 0) ? r1.z : ((k == 1) ? r1.w : 1.0f - r1.z - r1.w);
-            float qx = (k == 0) ? r2.x : ((k == 1) ? r2.z : r3.x);
-            float qy = (k == 0) ? r2.y : ((k == 1) ? r2.w : r3.y);
-            int px;
-            const int py = fast_divmod(pix, W, px);
-            float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
-            gx += qx; gy += qy; gw += -fx * qx - fy * qy;
-            an0 += bk * r0.x; an1 += bk * r0.y; an2 += bk * r0.z;
-            aa0 += bk * r0.w; aa1 += bk * r1.x; aa2 += bk * r1.y;
-        }
-        return __float_as_int(r3.z);
-    };
-    // four views at a time: the first record of each non-empty list is fetched with independent loads (one memory round trip
-    // for the four), then consumed; the ~30 % of lists with a second pixel are followed afterwards
-    auto four = [&](int k, int bb, int p0, int p1, int p2, int p3) {
-        const int pv[4] = {p0, p1, p2, p3};
-        float4 R0[4], R1[4], R2[4], R3[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            R3[j] = make_float4(0.f, 0.f, __int_as_float(-1), 0.f);
-            if (pv[j] >= 0) {
-                const float4* r = rec + ((long long)(bb + j) * P + pv[j]) * 4;
-                R0[j] = r[0]; R1[j] = r[1]; R2[j] = r[2]; R3[j] = r[3];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (pv[j] < 0) continue;
-            const int b = bb + j;
-            float gx = 0.f, gy = 0.f, gw = 0.f;
-            int pix = consume(k, pv[j], R0[j], R1[j], R2[j], R3[j], gx, gy, gw);
-            while (pix >= 0) {
-                const float4* r = rec + ((long long)b * P + pix) * 4;
-                float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-                pix = consume(k, pix, r0, r1, r2, r3, gx, gy, gw);
-            }
-            const float4 c0 = cmat[(size_t)b * 3], c1 = cmat[(size_t)b * 3 + 1], c2 = cmat[(size_t)b * 3 + 2];
-            vx += gx * c0.x + gy * c0.y + gw * c0.z;
-            vy += gx * c1.x + gy * c1.y + gw * c1.z;
-            vz += gx * c2.x + gy * c2.y + gw * c2.z;
-        }
-    };
-    for (int e = e0; e < e1; e++) {
-        const int code = vf_idx[e];
-        const int f = code / 3, k = code - f * 3;
-        const int* hp = head + (size_t)b0 * F + f;            // view-major heads: neighbouring lanes (faces) share lines
-        const int h0 = hp[0], h1 = hp[F], h2 = hp[2 * (size_t)F], h3 = hp[3 * (size_t)F], h4 = hp[4 * (size_t)F],
-                  h5 = hp[5 * (size_t)F], h6 = hp[6 * (size_t)F], h7 = hp[7 * (size_t)F];
-        four(k, b0, h0, h1, h2, h3);
-        four(k, b0 + 4, h4, h5, h6, h7);
-    }
-    float4* o = part + ((size_t)g * NC + c) * 3;
-    o[0] = make_float4(an0, an1, an2, aa0);
-    o[1] = make_float4(aa1, aa2, vx, vy);
-    o[2] = make_float4(vz, 0.f, 0.f, 0.f);
-}
+constexpr int kGroup = 8;        // views summed inside one lane group of the face-parallel backward
 
 // ------------------------------------------------------------------------------------------------ face-parallel backward
 // One lane per (face, view); the kGroup lanes of a group are kGroup consecutive views of one face.  A lane whose face owns pixels
@@ -597,35 +431,6 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_corner_slots(const int32_t* __restrict__ vf_idx, int n3, int32_t* __restrict__ slot)
-{
-    int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e < n3) slot[vf_idx[e]] = e;
-}
-
-// per vertex: sum the partials of its chunks over all view groups; gverts = position part + the antialias-backward part
-// (gvert_aa), gnormal, galbedo — first writer of gverts / galbedo this step: plain stores, later kernels accumulate
-__global__ void __launch_bounds__(kBlock)
-k_reduce_groups(const float4* __restrict__ part, const float* __restrict__ gvert_aa, const int32_t* __restrict__ vc_ptr, int G,
-                int NC, int V, float* __restrict__ gverts, float* __restrict__ gnormal, float* __restrict__ galbedo)
-{
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= V) return;
-    float n0 = 0.f, n1 = 0.f, n2 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    float x = gvert_aa[(size_t)v * 3], y = gvert_aa[(size_t)v * 3 + 1], z = gvert_aa[(size_t)v * 3 + 2];
-    const int c0 = vc_ptr[v], c1 = vc_ptr[v + 1];
-    for (int g = 0; g < G; g++)
-        for (int c = c0; c < c1; c++) {
-            const float4* q = part + ((size_t)g * NC + c) * 3;
-            float4 q0 = q[0], q1 = q[1], q2 = q[2];
-            n0 += q0.x; n1 += q0.y; n2 += q0.z; a0 += q0.w; a1 += q1.x; a2 += q1.y;
-            x += q1.z; y += q1.w; z += q2.x;
-        }
-    gverts[(size_t)v * 3] = x; gverts[(size_t)v * 3 + 1] = y; gverts[(size_t)v * 3 + 2] = z;
-    gnormal[(size_t)v * 3] = n0; gnormal[(size_t)v * 3 + 1] = n1; gnormal[(size_t)v * 3 + 2] = n2;
-    galbedo[(size_t)v * 3] = a0; galbedo[(size_t)v * 3 + 1] = a1; galbedo[(size_t)v * 3 + 2] = a2;
-}
-
 __global__ void __launch_bounds__(1024)
 k_finish_losses(float* losses, const float* n_valid, const float* __restrict__ part_l1, const float* __restrict__ part_l2, int nb,
                 const float* __restrict__ tail_part, int tail_nb, float w_sfs, float w_mask, float mse_den)
@@ -710,46 +515,6 @@ int loss_pix_impl(const float* shaded, const float* aa, const float* img, const 
                                                   n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_aa, (float4*)g_shaded, part_l1,
                                                   part_l2, losses);
     FMHR_CHECK_LAUNCH("k_loss_pix");
-    return FMHR_OK;
-}
-
-int pix_bwd_impl(const float* rast, const int32_t* tri, const float* pos, const float* attr8,
-                 const float* sh, const float* mask, const float* g_shaded, int n, int V, int F, int H, int W,
-                 const unsigned long long* covw, const int* next, const int* act_list, const int* act_count, float* rec,
-                 hipStream_t st)
-{
-    long long P = (long long)H * W;
-    if (n * P == 0 || F == 0) return FMHR_OK;
-    k_pix_bwd<<<cdiv(n * P, kBlock), kBlock, 0, st>>>((const float4*)rast, tri, pos, (const float4*)attr8, sh, mask,
-                                                (const float4*)g_shaded, n, V, F, H, W, covw, next, act_list, act_count,
-                                                (float4*)rec);
-    FMHR_CHECK_LAUNCH("k_pix_bwd");
-    return FMHR_OK;
-}
-
-int vertex_gather_impl(const float* rec, const int* head, const int32_t* vf_ptr, const int32_t* vf_idx, const int32_t* vc_ptr,
-                       const int32_t* ck, const float* cmat, const float* gvert_aa, int n, int npad, int V, int F, int NC, int H, int W,
-                       float* part, float* gverts, float* gnormal, float* galbedo, hipStream_t st)
-{
-    if (n == 0 || V == 0) return FMHR_OK;
-    const int G = npad / kGroup;
-    if (NC > 0) {
-        k_vertex_gather<<<dim3(cdiv(NC, kBlock), G), kBlock, 0, st>>>((const float4*)rec, head, vf_ptr, vf_idx, (const int2*)ck,
-                                                                     (const float4*)cmat, n, npad, F, NC, H, W, (float4*)part);
-        FMHR_CHECK_LAUNCH("k_vertex_gather");
-    }
-    if (gverts != nullptr) {      // stand-alone reduction; the fused step sums the partials in its mesh-tail kernel instead
-        k_reduce_groups<<<cdiv(V, kBlock), kBlock, 0, st>>>((const float4*)part, gvert_aa, vc_ptr, G, NC, V, gverts, gnormal, galbedo);
-        FMHR_CHECK_LAUNCH("k_reduce_groups");
-    }
-    return FMHR_OK;
-}
-
-int corner_slots_impl(const int32_t* vf_idx, int F, int32_t* slot, hipStream_t st)
-{
-    if (F == 0) return FMHR_OK;
-    k_corner_slots<<<cdiv(3LL * F, kBlock), kBlock, 0, st>>>(vf_idx, 3 * F, slot);
-    FMHR_CHECK_LAUNCH("k_corner_slots");
     return FMHR_OK;
 }
 

@@ -53,14 +53,11 @@ class HamStage2:
         nb = self.lib.fmhr_vertex_faces_workspace_bytes(self.V)
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.dev)
         call("fmhr_vertex_faces_build", ptr(self.faces), self.F, self.V, ptr(self.vf_ptr), ptr(self.vf_idx), ptr(ws), nb, st)
-        self.vc_ptr = torch.zeros(self.V + 1, dtype=torch.int32, device=self.dev)
-        self.ck = torch.zeros(3 * self.F + self.V + 1, 2, dtype=torch.int32, device=self.dev)   # bound for any chunk size >= 1
-        ws = torch.empty((self.V + 1) * 4, dtype=torch.uint8, device=self.dev)
-        call("fmhr_vertex_chunks_build", ptr(self.vf_ptr), self.V, ptr(self.vc_ptr), ptr(self.ck), ptr(ws), (self.V + 1) * 4, st)
-        self.n_chunks = int(self.vc_ptr[-1])
+        self.corner_slot = torch.zeros(3 * self.F, dtype=torch.int32, device=self.dev)
+        call("fmhr_corner_slots_build", ptr(self.vf_idx), self.F, ptr(self.corner_slot), st)
         # antialias queue: only pairs that blend are queued (∝ silhouette length); 1/4 of the pixels is a generous bound
         cap = int(aa_cap or max(65536, self.n * self.H * self.W // 4))
-        self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap, self.n_chunks)
+        self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap)
         self.ws_bytes = self.lib.fmhr_ham_workspace_bytes(ctypes.byref(self.dims))
         if self.ws_bytes == 0:
             raise RuntimeError("fmhr_ham_workspace_bytes failed: " + self.lib.fmhr_last_error().decode())
@@ -91,7 +88,7 @@ class HamStage2:
                         float(self.n_global * self.H * self.W), 1.0 if reg_grads else 0.0)
         call("fmhr_ham_backward", ctypes.byref(self.dims), ctypes.byref(wt), ptr(vertices_tmp), ptr(delta), ptr(albedo),
              ptr(sh), ptr(w2c), ptr(proj), ptr(img), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp),
-             ptr(self.row_ptr), ptr(self.col_idx), ptr(self.vf_ptr), ptr(self.vf_idx), ptr(self.vc_ptr), ptr(self.ck),
+             ptr(self.row_ptr), ptr(self.col_idx), ptr(self.vf_ptr), ptr(self.vf_idx), ptr(self.corner_slot),
              ptr(self.n_valid_global),
              ptr(self.losses), ptr(self.gdelta),
              ptr(self.galbedo), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))

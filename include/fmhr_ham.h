@@ -47,15 +47,15 @@ size_t fmhr_adjacency_workspace_bytes(int V, int F);
 int fmhr_adjacency_build(const int32_t* tri, int F, int V, int32_t* row_ptr, int32_t* col_idx,
                          void* ws, size_t ws_bytes, void* stream);
 
-/* vertex -> incident face corners (CSR, rows sorted; entry = 3*face + corner): the gather-style backward of the fused step walks
- * it instead of scattering float atomics.  vf_ptr [V+1], vf_idx [3F]. */
+/* vertex -> incident face corners (CSR, rows sorted; entry = 3*face + corner): the per-vertex kernels of the fused step walk it
+ * instead of scattering float atomics.  vf_ptr [V+1], vf_idx [3F]. */
 size_t fmhr_vertex_faces_workspace_bytes(int V);
 int fmhr_vertex_faces_build(const int32_t* tri, int F, int V, int32_t* vf_ptr, int32_t* vf_idx,
                             void* ws, size_t ws_bytes, void* stream);
 
-/* CSR rows cut into chunks of a few corners (load balance of the gather): vc_ptr [V+1] = first chunk of each vertex,
- * ck [<= 3F + V, 2] = (vertex, first CSR entry) per chunk; the chunk count is vc_ptr[V].  ws: (V+1)*4 bytes. */
-int fmhr_vertex_chunks_build(const int32_t* vf_ptr, int V, int32_t* vc_ptr, int32_t* ck, void* ws, size_t ws_bytes, void* stream);
+/* inverse of vf_idx: corner_slot [3F], corner_slot[3*face + corner] = position of that corner in its vertex's CSR row.  The
+ * face-parallel backward of the fused step stores each corner's gradient sums at its slot. */
+int fmhr_corner_slots_build(const int32_t* vf_idx, int F, int32_t* corner_slot, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ nvdiffrast-shaped primitives
  * dr.rasterize(glctx, pos, tri, resolution=(H,W))  — mesh_sfs_optim.py:142,212,267; get_data.py:251.
@@ -126,7 +126,6 @@ typedef struct fmhr_ham_dims {
     int32_t n, V, F, H, W;      /* views on this rank, vertices, faces, image size */
     int32_t nnz;                /* adjacency nnz (row_ptr[V]) */
     int32_t aa_cap;             /* unused by the fused step since the antialias items live in place; keep >= 1 */
-    int32_t n_chunks;           /* vc_ptr[V] from fmhr_vertex_chunks_build */
 } fmhr_ham_dims;
 
 typedef struct fmhr_ham_weights {
@@ -155,7 +154,7 @@ size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
  * (mesh_sfs_optim.py:289): a view-sharded caller all-reduces n_valid between the two phases.
  *   vertices_tmp, delta, albedo [V,3]; sh [n,9]; w2c, proj [n,4,4] (row-vector convention, get_data.py:96-97);
  *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx [nnz]; vf_ptr [V+1]; vf_idx [3F];
- *   vc_ptr [V+1]; ck [n_chunks,2].
+ *   corner_slot [3F] (fmhr_corner_slots_build).
  *   n*H*W must be a multiple of 4.
  *   valid_mask_changed: pass 1 on the first call on a workspace and whenever valid_mask's CONTENTS may differ from the previous
  *   call (its per-segment non-zero flags are cached in the workspace; the mask is constant over a HAM run, :158).
@@ -174,7 +173,7 @@ int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const f
                       const float* albedo, const float* sh, const float* w2c, const float* proj, const float* img,
                       const float* mask, const float* valid_mask, const int32_t* tri, const int32_t* opp,
                       const int32_t* row_ptr, const int32_t* col_idx, const int32_t* vf_ptr, const int32_t* vf_idx,
-                      const int32_t* vc_ptr, const int32_t* ck, const float* n_valid_global,
+                      const int32_t* corner_slot, const float* n_valid_global,
                       float* losses, float* gdelta, float* galbedo, void* ws, size_t ws_bytes, void* stream);
 /* Views of the step's intermediates inside the workspace (for parity tests / rendering): returns device pointers. */
 typedef struct fmhr_ham_views {

@@ -31,7 +31,7 @@ def test_header_and_library_agree(lib):
 
 def test_struct_layouts_match_header():
     from fmhr_amd._lib import HamDims, HamWeights, HamViews
-    assert ctypes.sizeof(HamDims) == 32 and ctypes.sizeof(HamWeights) == 36 and ctypes.sizeof(HamViews) == 48
+    assert ctypes.sizeof(HamDims) == 28 and ctypes.sizeof(HamWeights) == 36 and ctypes.sizeof(HamViews) == 48
 
 
 def test_argument_errors_without_gpu(lib):
@@ -42,9 +42,9 @@ def test_argument_errors_without_gpu(lib):
     assert lib.fmhr_interpolate_fwd(None, None, None, 2, 3, 3, 1, 8, 8, 4, None, None) == -1
     assert b"attr batch" in lib.fmhr_last_error()
     assert lib.fmhr_laplacian_uniform_fwd(None, None, None, 10, 5, 1.0, None, None, None) == -1
-    bad = HamDims(0, 10, 10, 8, 8, 0, 16, 0)
+    bad = HamDims(0, 10, 10, 8, 8, 0, 16)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(bad)) == 0
-    ok = HamDims(2, 100, 180, 64, 48, 0, 1024, 0)
+    ok = HamDims(2, 100, 180, 64, 48, 0, 1024)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(ok)) > 2 * 64 * 48 * 16
     assert lib.fmhr_rasterize_workspace_bytes(2, 7, 10, 8, 8) == 2 * 64 * 8 + 16 + 2 * 10 * 8 + 2 * 7 * 8
 
