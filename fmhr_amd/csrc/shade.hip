@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__
     if (threadIdx.x == 0) { n_valid[0] = (int)(r + 0.5f); n_valid_f[0] = (float)(int)(r + 0.5f); }
 }
 
-constexpr int kGroup = 8;        // views summed inside one lane group of the face-parallel backward
+constexpr int kGroup = 8;  // views summed inside one lane group of the face-parallel backward
 
 // ------------------------------------------------------------------------------------------------ face-parallel backward
 // One lane per (face, view); the kGroup lanes of a group are kGroup consecutive views of one face.  A lane whose face owns pixels
@@ -317,8 +317,8 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     const int j = threadIdx.x & (kGroup - 1);
     const int f = blockIdx.x * (kBlock / kGroup) + threadIdx.x / kGroup;
     const int g = blockIdx.y, b = g * kGroup + j;
-    if (threadIdx.x < kGroup * 24) {
-        const int vb = threadIdx.x / 24, k = threadIdx.x - vb * 24, bb = g * kGroup + vb;
+    for (int i = threadIdx.x; i < kGroup * 24; i += kBlock) {
+        const int vb = i / 24, k = i - vb * 24, bb = g * kGroup + vb;
         float v = 0.f;
         if (bb < n) v = (k < 9) ? sh[(size_t)bb * 9 + k] : ((k < 21) ? reinterpret_cast<const float*>(cmat)[(size_t)bb * 12 + (k - 9)] : 0.f);
         view_c[vb][k] = v;
