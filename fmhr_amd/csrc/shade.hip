@@ -290,6 +290,10 @@ constexpr int kGroup = 8;  // views summed inside one lane group of the face-par
 // atomics, deterministic.  These kernels are bound by the NUMBER of vector-memory requests (each scattered wave-load occupies
 // the texture-address unit for up to 64 cycles), so the per-lane request count is the budget: 1 head + 1 tri (12 B) + 6 attr8 +
 // 3 pos + 2 per pixel; the view's SH row and clip matrix come from an LDS copy.
+// keep a loaded 16-B word whole and its load where it was written: without this the compiler splits a float4 load whose .z is
+// unused into two requests and sinks loads below the first branch that tests another one (an extra dependent round trip)
+__device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
@@ -340,10 +344,12 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         const float4 u0 = attr8[(size_t)ti.y * 2], u1 = attr8[(size_t)ti.y * 2 + 1];
         const float4 w0 = attr8[(size_t)ti.z * 2], w1 = attr8[(size_t)ti.z * 2 + 1];
         const float* vp = pos + (size_t)b * V * 4;
-        const float4 p0 = ldg4(vp + (size_t)ti.x * 4), p1 = ldg4(vp + (size_t)ti.y * 4), p2 = ldg4(vp + (size_t)ti.z * 4);
+        float4 p0 = ldg4(vp + (size_t)ti.x * 4), p1 = ldg4(vp + (size_t)ti.y * 4), p2 = ldg4(vp + (size_t)ti.z * 4);
         float c[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) c[k] = view_c[j][k];
+        pin(p0); pin(p1); pin(p2);
+        pin(gs); pin(r);
         const float3 n2 = make_float3(w0.x, w0.y, w0.z), a2 = make_float3(w0.w, w1.x, w1.y);
         const float3 dn0 = make_float3(q0.x - n2.x, q0.y - n2.y, q0.z - n2.z), da0 = make_float3(q0.w - a2.x, q1.x - a2.y, q1.y - a2.z);
         const float3 dn1 = make_float3(u0.x - n2.x, u0.y - n2.y, u0.z - n2.z), da1 = make_float3(u0.w - a2.x, u1.x - a2.y, u1.y - a2.z);
@@ -405,6 +411,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             if (p < 0) break;
             gs = g_shaded[vbase + p];
             r = bwd16[vbase + p];
+            pin(gs); pin(r);
         }
         // clip-transform backward of this view (cmat rows of w2c @ proj): position gradients become view-independent
         const float* cm = &view_c[j][9];
