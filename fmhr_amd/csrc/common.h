@@ -134,15 +134,22 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// keep a loaded 16-B word whole and its load where it was written: without this the compiler splits a float4 load whose
+// components are used at different times into several requests and sinks part of it below the first branch (an extra dependent
+// round trip); the per-pixel kernels are bound by the NUMBER of vector-memory requests
+__device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 // Exact g / d and g % d (0 <= g, 1 <= d < 2^31, quotient < 2^22) from a float estimate plus integer correction: the compiler's
 // 64-bit software division costs ~200 VALU instructions per lane, and every per-pixel / per-(view, triangle) kernel splits its
-// flat index this way.  The estimate is off by at most one for the quotients seen here; the loops make it exact regardless.
+// flat index this way.  With a relative error below 2^-22 in the float product and a quotient below 2^22 the truncated estimate is
+// within one of the true quotient, so one correction each way makes it exact (correction LOOPS would be turned back into
+// divisions by the loop optimiser).
 __device__ __forceinline__ int fast_divmod(long long g, int d, int& r)
 {
     int q = (int)((float)g * __builtin_amdgcn_rcpf((float)d));
     long long rem = g - (long long)q * d;
-    while (rem < 0) { rem += d; q--; }
-    while (rem >= d) { rem -= d; q++; }
+    if (rem < 0) { rem += d; q--; }
+    if (rem >= d) { rem -= d; q++; }
     r = (int)rem;
     return q;
 }

@@ -69,6 +69,19 @@ __device__ __forceinline__ void emit_fragment(const float4 p0, const float4 p1, 
 
 // antialias rule A3 on the snapped integer coordinates (same decision as antialias.hip: silhouette_bits_snapped): bit k set =
 // the edge opposite vertex k is a silhouette edge in this view (its neighbour is missing, rejected or on the same side)
+__device__ __forceinline__ unsigned char silh_bits(const int2 s0, const int2 s1, const int2 s2, int2 q0, int2 q1, int2 q2)
+{
+    const int REJ = (int)0x80000000;
+    if (q0.x == REJ) q0 = s0;
+    if (q1.x == REJ) q1 = s1;
+    if (q2.x == REJ) q2 = s2;
+    long long bb = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s2.x - s0.x) * (s1.y - s0.y);
+    long long a0 = (long long)(s1.x - q0.x) * (s2.y - q0.y) - (long long)(s2.x - q0.x) * (s1.y - q0.y);
+    long long a1 = (long long)(s2.x - q1.x) * (s0.y - q1.y) - (long long)(s0.x - q1.x) * (s2.y - q1.y);
+    long long a2 = (long long)(s0.x - q2.x) * (s1.y - q2.y) - (long long)(s1.x - q2.x) * (s0.y - q2.y);
+    return (unsigned char)((((a0 < 0) == (bb < 0)) ? 1 : 0) | (((a1 < 0) == (bb < 0)) ? 2 : 0) | (((a2 < 0) == (bb < 0)) ? 4 : 0));
+}
+
 __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, const int32_t* __restrict__ opp, const int2* __restrict__ sv,
                                            const int2 s0, const int2 s1, const int2 s2, int b, int f, int F)
 {
@@ -77,15 +90,7 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
     int o0 = opp[f * 3], o1 = opp[f * 3 + 1], o2 = opp[f * 3 + 2];
     int2 q0 = (o0 < 0) ? make_int2(REJ, 0) : sv[o0], q1 = (o1 < 0) ? make_int2(REJ, 0) : sv[o1],
          q2 = (o2 < 0) ? make_int2(REJ, 0) : sv[o2];
-    if (q0.x == REJ) q0 = s0;
-    if (q1.x == REJ) q1 = s1;
-    if (q2.x == REJ) q2 = s2;
-    long long bb = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s2.x - s0.x) * (s1.y - s0.y);
-    long long a0 = (long long)(s1.x - q0.x) * (s2.y - q0.y) - (long long)(s2.x - q0.x) * (s1.y - q0.y);
-    long long a1 = (long long)(s2.x - q1.x) * (s0.y - q1.y) - (long long)(s0.x - q1.x) * (s2.y - q1.y);
-    long long a2 = (long long)(s0.x - q2.x) * (s1.y - q2.y) - (long long)(s1.x - q2.x) * (s0.y - q2.y);
-    silh[(size_t)b * F + f] = (unsigned char)((((a0 < 0) == (bb < 0)) ? 1 : 0) | (((a1 < 0) == (bb < 0)) ? 2 : 0) |
-                                              (((a2 < 0) == (bb < 0)) ? 4 : 0));
+    silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
 }
 
 // one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup; clip positions are only fetched by the
@@ -113,6 +118,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         large_q[slot] = make_int2(b, f);
         return;
     }
+    // the opposite-vertex ids (antialias rule A3) are requested now and arrive while the coverage mask is computed
+    int o0 = -1, o1 = -1, o2 = -1;
+    if (silh != nullptr) { o0 = opp[f * 3]; o1 = opp[f * 3 + 1]; o2 = opp[f * 3 + 2]; }
     const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
     float xo = 1.0f / (float)W; xo = xo - 1.0f;
     float yo = 1.0f / (float)H; yo = yo - 1.0f;
@@ -158,7 +166,11 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 if (covers(s, px, py)) cm |= 1ull << bit;
     }
     if (cm == 0ull) return;
-    const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+    // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
+    float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+    const int2 rej = make_int2(kRejected, 0);
+    const int2 q0 = (o0 < 0) ? rej : sv[o0], q1 = (o1 < 0) ? rej : sv[o1], q2 = (o2 < 0) ? rej : sv[o2];
+    pin(p0); pin(p1); pin(p2);
     const unsigned long long rowbits = (bw >= 64) ? ~0ull : ((1ull << bw) - 1ull);
     for (int r = 0; r < bh; r++) {
         unsigned long long rm = (cm >> (r * bw)) & rowbits;
@@ -169,7 +181,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         }
     }
     // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
-    write_silh(silh, opp, sv, s0, s1, s2, b, f, F);
+    if (silh != nullptr) silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
 }
 
 // one workgroup per queued large triangle (grid-stride over the queue; the count lives on the device)
@@ -190,7 +202,8 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
         TriSetup s;
         if (!setup_triangle(sv[i0], sv[i1], sv[i2], H, W, s)) continue;
         const float* vp = pos + (size_t)b * V * 4;
-        const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+        float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+        pin(p0); pin(p1); pin(p2);
         int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
         unsigned long long* kv = keys + (size_t)b * H * W;
         for (int i = threadIdx.x; i < bw * bh; i += kBlock) {
@@ -230,6 +243,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
     }
     bool live = gid < (long long)n * P;
     unsigned long long key = live ? keys[gid] : ~0ull;
+    const float mk = (live && head != nullptr) ? mask[gid] : 0.f;      // independent of the key: issued with it
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     bool covered = false;
     if (key != ~0ull) {
@@ -238,8 +252,9 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         const int py = fast_divmod(rem, W, px);
         int f = (int)(key & 0xffffffffu);
         const float* vp = pos + (size_t)b * V * 4;
-        const float4 p0 = ldg4(vp + (size_t)tri[f * 3] * 4), p1 = ldg4(vp + (size_t)tri[f * 3 + 1] * 4),
-                     p2 = ldg4(vp + (size_t)tri[f * 3 + 2] * 4);
+        float4 p0 = ldg4(vp + (size_t)tri[f * 3] * 4), p1 = ldg4(vp + (size_t)tri[f * 3 + 1] * 4),
+               p2 = ldg4(vp + (size_t)tri[f * 3 + 2] * 4);
+        pin(p0); pin(p1); pin(p2);
         const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
         float xo = 1.0f / (float)W; xo = xo - 1.0f;
         float yo = 1.0f / (float)H; yo = yo - 1.0f;
@@ -250,7 +265,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             if (head != nullptr) {
                 // thread the pixel onto its face's list and leave everything the backward needs per pixel in ONE 16-B word
                 const int link = atomicExch(&head[(size_t)b * F + f], rem);
-                bwd16[gid] = make_float4(fr.u, fr.v, __int_as_float(link), (mask[gid] > 0.f) ? 1.f : 0.f);
+                bwd16[gid] = make_float4(fr.u, fr.v, __int_as_float(link), (mk > 0.f) ? 1.f : 0.f);
             }
         }
     }

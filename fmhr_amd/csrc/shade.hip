@@ -290,10 +290,6 @@ constexpr int kGroup = 8;  // views summed inside one lane group of the face-par
 // atomics, deterministic.  These kernels are bound by the NUMBER of vector-memory requests (each scattered wave-load occupies
 // the texture-address unit for up to 64 cycles), so the per-lane request count is the budget: 1 head + 1 tri (12 B) + 6 attr8 +
 // 3 pos + 2 per pixel; the view's SH row and clip matrix come from an LDS copy.
-// keep a loaded 16-B word whole and its load where it was written: without this the compiler splits a float4 load whose .z is
-// unused into two requests and sinks loads below the first branch that tests another one (an extra dependent round trip)
-__device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
-
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
