@@ -93,95 +93,158 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
     silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
 }
 
-// one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup; clip positions are only fetched by the
-// lanes whose triangle actually covers a pixel centre
+// one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup, integer coverage mask of the (<= 64-pixel) box.
+// The fragments are then emitted WAVE-cooperatively: the covering lanes park their triangle (clip positions, box origin) in LDS
+// and expand their coverage bits into a dense per-wave task list; every lane then takes tasks round-robin.  A lane looping over
+// its own bits made the whole wave iterate max(bits) times with ~a quarter of the lanes active (the ~100-instruction fragment
+// evaluation was 69 of this kernel's 127 us).
+constexpr int kTaskCap = 1024;       // tasks expanded per round (a wave can hold 64 x 64; more rounds then)
+
+struct TriPark {
+    float4 p0, p1, p2;
+    int f, b, origin, bw;            // origin = pxa | pya << 16
+};
+
 __global__ void __launch_bounds__(kBlock)
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, int* __restrict__ large_cnt,
               int2* __restrict__ large_q, unsigned char* __restrict__ dirty)
 {
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= (long long)n * F) return;
-    int f;
-    const int b = fast_divmod(gid, F, f);
-    int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
-    if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return;
-    const int2* sv = snap + (size_t)b * V;
+    __shared__ TriPark park[kBlock];
+    __shared__ unsigned short tasks[kBlock / 64][kTaskCap];
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long cm = 0ull;
+    int f = 0, b = 0, i0 = 0, i1 = 0, i2 = 0, o0 = -1, o1 = -1, o2 = -1, bw = 1;
+    int2 s0 = make_int2(0, 0), s1 = s0, s2 = s0;
     TriSetup s;
-    const int2 s0 = sv[i0], s1 = sv[i1], s2 = sv[i2];
-    if (!setup_triangle(s0, s1, s2, H, W, s)) return;
-    int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
-    if (bw * (long long)bh > kSmallBox) {
-        write_silh(silh, opp, sv, s0, s1, s2, b, f, F);
-        int slot = atomicAdd(large_cnt, 1);
-        large_q[slot] = make_int2(b, f);
-        return;
+    s.pxa = s.pya = 0;
+    const int2* sv = snap;
+    bool ok = gid < (long long)n * F;
+    if (ok) {
+        b = fast_divmod(gid, F, f);
+        i0 = tri[f * 3]; i1 = tri[f * 3 + 1]; i2 = tri[f * 3 + 2];
+        ok = (unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V;
     }
-    // the opposite-vertex ids (antialias rule A3) are requested now and arrive while the coverage mask is computed
-    int o0 = -1, o1 = -1, o2 = -1;
-    if (silh != nullptr) { o0 = opp[f * 3]; o1 = opp[f * 3 + 1]; o2 = opp[f * 3 + 2]; }
+    if (ok) {
+        sv = snap + (size_t)b * V;
+        s0 = sv[i0]; s1 = sv[i1]; s2 = sv[i2];
+        ok = setup_triangle(s0, s1, s2, H, W, s);
+    }
+    if (ok) {
+        bw = s.pxb - s.pxa + 1;
+        const int bh = s.pyb - s.pya + 1;
+        if (bw * (long long)bh > kSmallBox) {
+            write_silh(silh, opp, sv, s0, s1, s2, b, f, F);
+            int slot = atomicAdd(large_cnt, 1);
+            large_q[slot] = make_int2(b, f);
+        } else {
+            // the opposite-vertex ids (antialias rule A3) are requested now and arrive while the coverage mask is computed
+            if (silh != nullptr) { o0 = opp[f * 3]; o1 = opp[f * 3 + 1]; o2 = opp[f * 3 + 2]; }
+            const int ext = max(max(s.x0, max(s.x1, s.x2)) - min(s.x0, min(s.x1, s.x2)),
+                                max(s.y0, max(s.y1, s.y2)) - min(s.y0, min(s.y1, s.y2)));
+            // 32-bit edge arithmetic is exact when the snapped extent is below 2^14 sub-pixel units (64 px): pixel centres lie
+            // within the box +-1 px, so every product stays below 2^29 (every small-box triangle unless it pokes far off screen)
+            if (ext < 16384) {
+                // incremental edge functions: E_k = e_k - (tie rule admits e_k == 0 ? 0 : 1), inside <=> all three E_k >= 0 <=>
+                // the OR of the three has a clear sign bit; a pixel step adds a constant per edge (all values stay below 2^30)
+                const int cx0 = s.pxa * kSub + kHalf, cy0 = s.pya * kSub + kHalf;
+                int E0, E1, E2, sx0, sx1, sx2, sy0, sy1, sy2;
+                {
+                    int dx = s.x1 - s.x0, dy = s.y1 - s.y0;
+                    E0 = dx * (cy0 - s.y0) - dy * (cx0 - s.x0) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
+                    sx0 = -dy * kSub; sy0 = dx * kSub;
+                    dx = s.x2 - s.x1; dy = s.y2 - s.y1;
+                    E1 = dx * (cy0 - s.y1) - dy * (cx0 - s.x1) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
+                    sx1 = -dy * kSub; sy1 = dx * kSub;
+                    dx = s.x0 - s.x2; dy = s.y0 - s.y2;
+                    E2 = dx * (cy0 - s.y2) - dy * (cx0 - s.x2) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
+                    sx2 = -dy * kSub; sy2 = dx * kSub;
+                }
+                int bit = 0;
+                for (int r = 0; r < bh; r++) {
+                    int e0 = E0, e1 = E1, e2 = E2;
+                    for (int c = 0; c < bw; c++, bit++) {
+                        if ((e0 | e1 | e2) >= 0) cm |= 1ull << bit;
+                        e0 += sx0; e1 += sx1; e2 += sx2;
+                    }
+                    E0 += sy0; E1 += sy1; E2 += sy2;
+                }
+            } else {
+                int bit = 0;
+                for (int py = s.pya; py <= s.pyb; py++)
+                    for (int px = s.pxa; px <= s.pxb; px++, bit++)
+                        if (covers(s, px, py)) cm |= 1ull << bit;
+            }
+        }
+    }
+    // ---- wave-wide task numbering: exclusive scan of the per-lane fragment counts
+    const int cnt = __popcll(cm);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const int excl = incl - cnt, T = __shfl(incl, 63);
+    if (T == 0) return;                                              // wave-uniform
+    if (cm != 0ull) {
+        // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
+        const float* vp = pos + (size_t)b * V * 4;
+        float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+        const int2 rej = make_int2(kRejected, 0);
+        const int2 q0 = (o0 < 0) ? rej : sv[o0], q1 = (o1 < 0) ? rej : sv[o1], q2 = (o2 < 0) ? rej : sv[o2];
+        pin(p0); pin(p1); pin(p2);
+        // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
+        if (silh != nullptr) silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
+        TriPark& t = park[threadIdx.x];
+        t.p0 = p0; t.p1 = p1; t.p2 = p2; t.f = f; t.b = b; t.origin = s.pxa | (s.pya << 16); t.bw = bw;
+    }
     const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
     float xo = 1.0f / (float)W; xo = xo - 1.0f;
     float yo = 1.0f / (float)H; yo = yo - 1.0f;
-    unsigned long long* kv = keys + (size_t)b * H * W;
-    const float* vp = pos + (size_t)b * V * 4;
-    const int ext = max(max(s.x0, max(s.x1, s.x2)) - min(s.x0, min(s.x1, s.x2)), max(s.y0, max(s.y1, s.y2)) - min(s.y0, min(s.y1, s.y2)));
-    // 32-bit edge arithmetic is exact when the snapped extent is below 2^14 sub-pixel units (64 px): pixel centres lie within
-    // the box +-1 px, so every product stays below 2^29 (every small-box triangle unless it pokes far outside the screen)
-    const bool small = ext < 16384;
-    // pass 1: integer coverage of the (<= 64-pixel) box into a bit mask, no memory traffic.  Pass 2 then fetches the clip
-    // positions ONCE and walks the set bits: fetching at the first covered pixel inside the loop made a wave wait for memory
-    // once per distinct first-hit iteration among its lanes.
-    unsigned long long cm = 0ull;
-    if (small) {
-        // incremental edge functions: E_k = e_k - (tie rule admits e_k == 0 ? 0 : 1), inside <=> all three E_k >= 0 <=> the OR
-        // of the three has a clear sign bit; a pixel step adds a constant per edge (all values stay below 2^30)
-        const int cx0 = s.pxa * kSub + kHalf, cy0 = s.pya * kSub + kHalf;
-        int E0, E1, E2, sx0, sx1, sx2, sy0, sy1, sy2;
-        {
-            int dx = s.x1 - s.x0, dy = s.y1 - s.y0;
-            E0 = dx * (cy0 - s.y0) - dy * (cx0 - s.x0) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
-            sx0 = -dy * kSub; sy0 = dx * kSub;
-            dx = s.x2 - s.x1; dy = s.y2 - s.y1;
-            E1 = dx * (cy0 - s.y1) - dy * (cx0 - s.x1) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
-            sx1 = -dy * kSub; sy1 = dx * kSub;
-            dx = s.x0 - s.x2; dy = s.y0 - s.y2;
-            E2 = dx * (cy0 - s.y2) - dy * (cx0 - s.x2) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
-            sx2 = -dy * kSub; sy2 = dx * kSub;
-        }
-        int bit = 0;
-        for (int r = 0; r < bh; r++) {
-            int e0 = E0, e1 = E1, e2 = E2;
-            for (int c = 0; c < bw; c++, bit++) {
-                if ((e0 | e1 | e2) >= 0) cm |= 1ull << bit;
-                e0 += sx0; e1 += sx1; e2 += sx2;
+    const long long P = (long long)H * W;
+    for (int R = 0; R < T; R += kTaskCap) {
+        if (cm != 0ull && excl < R + kTaskCap && excl + cnt > R) {
+            unsigned long long m = cm;
+            int idx = excl - R;
+            while (m != 0ull) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1ull;
+                if (idx >= 0 && idx < kTaskCap) tasks[wv][idx] = (unsigned short)((lane << 6) | bit);
+                idx++;
             }
-            E0 += sy0; E1 += sy1; E2 += sy2;
         }
-    } else {
-        int bit = 0;
-        for (int py = s.pya; py <= s.pyb; py++)
-            for (int px = s.pxa; px <= s.pxb; px++, bit++)
-                if (covers(s, px, py)) cm |= 1ull << bit;
-    }
-    if (cm == 0ull) return;
-    // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
-    float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
-    const int2 rej = make_int2(kRejected, 0);
-    const int2 q0 = (o0 < 0) ? rej : sv[o0], q1 = (o1 < 0) ? rej : sv[o1], q2 = (o2 < 0) ? rej : sv[o2];
-    pin(p0); pin(p1); pin(p2);
-    const unsigned long long rowbits = (bw >= 64) ? ~0ull : ((1ull << bw) - 1ull);
-    for (int r = 0; r < bh; r++) {
-        unsigned long long rm = (cm >> (r * bw)) & rowbits;
-        while (rm != 0ull) {
-            int c = __builtin_ctzll(rm);
-            rm &= rm - 1ull;
-            emit_fragment(p0, p1, p2, s.pxa + c, s.pya + r, f, xs, xo, ys, yo, kv, W, dirty, (long long)b * H * W);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nt = min(kTaskCap, T - R);
+        for (int t0 = 0; t0 < nt; t0 += 64) {                       // uniform trip count: the shuffles below need every lane
+            const int t = t0 + lane;
+            long long segl = -1;
+            if (t < nt) {
+                const int e = tasks[wv][t], o = e >> 6, bit = e & 63;
+                const TriPark& q = park[wv * 64 + o];
+                int c;
+                const int r = fast_divmod(bit, q.bw, c);
+                const int px = (q.origin & 0xffff) + c, py = (q.origin >> 16) + r;
+                Frag fr;
+                if (fragment(q.p0, q.p1, q.p2, px, py, xs, xo, ys, yo, fr)) {
+                    const unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | (unsigned)q.f;
+                    const long long pix = (long long)q.b * P + (long long)py * W + px;
+                    atomicMin(&keys[pix], key);
+                    segl = pix >> 6;
+                }
+            }
+            if (dirty != nullptr) {
+                // consecutive tasks mostly land in the same 64-pixel segment: one flag store per run
+                const long long prev = __shfl_up(segl, 1);
+                if (segl >= 0 && (lane == 0 || prev != segl)) dirty[segl] = 1;
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
-    if (silh != nullptr) silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
 }
 
 // one workgroup per queued large triangle (grid-stride over the queue; the count lives on the device)
