@@ -20,7 +20,7 @@ int mesh_tail_blocks(int V);
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
-                       void*, int*, float*, const float*, int, unsigned char*, unsigned long long*, int*, hipStream_t);
+                       void*, void*, int*, unsigned char*, float*, const float*, unsigned char*, unsigned long long*, int*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, int*,
                          hipStream_t);
@@ -44,14 +44,14 @@ int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, con
                    const int*, const unsigned long long*, float*, float*, float*, int*, float*, hipStream_t);
 int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
-int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const int*,
-                  const int32_t*, const float*, int, int, int, int, int, float*, hipStream_t);
+int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
+                  const int*, const int32_t*, const float*, int, int, int, int, int, float*, hipStream_t);
 int face_bwd_groups(int n);
 int finish_losses_impl(float*, const float*, const float*, const float*, int, const float*, int, float, float, float, hipStream_t);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, head, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
         g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, total;
 };
 
@@ -83,7 +83,9 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.act_list = take(off, ((nP + 63) / 64) * 4);
     L.cov_list = take(off, ((nP + 63) / 64) * 4);
     L.act_count = take(off, 16);
-    L.head = take(off, (size_t)npad * d->F * 4);   // pixel-list heads [npad, F], view-major (views padded to 8)
+    L.cov16 = take(off, (size_t)d->n * d->F * 16); // coverage entries [n, F]: candidate-pixel mask, box origin, stamp | box width
+    L.own8 = take(off, (size_t)d->n * d->F);      // per (view, face): low byte of the last step in which it owned a pixel
+    L.stamp = take(off, 16);                       // step counter tagging the coverage entries
     L.bwd16 = take(off, nP * 16);             // per covered pixel: (u, v, link of its face's pixel list, mask > 0) for the backward
     L.rast = take(off, nP * 16);
     L.shaded = take(off, nP * 16);
@@ -146,7 +148,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
     Layout L = make_layout(d);
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
-    FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(head); FMHR_OFF(bwd16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
+    FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(stamp); FMHR_OFF(bwd16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
     FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_aa); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(total);
 #undef FMHR_OFF
@@ -178,6 +180,10 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, (hipStream_t)stream), "init aa_counter");
     // self-cleaning accumulator: k_mesh_tail_a zeroes each entry after consuming it
     HIPTRY(hipMemsetAsync(w + L.gvert_aa, 0, (size_t)d->V * 12, (hipStream_t)stream), "init gvert_aa");
+    // coverage entries are recognised by the step stamp: start with no entry valid, counter at 0
+    HIPTRY(hipMemsetAsync(w + L.cov16, 0xFF, (size_t)d->n * d->F * 16, (hipStream_t)stream), "init cov16");
+    HIPTRY(hipMemsetAsync(w + L.stamp, 0, 16, (hipStream_t)stream), "init stamp");
+    HIPTRY(hipMemsetAsync(w + L.own8, 0, (size_t)d->n * d->F, (hipStream_t)stream), "init own8");
     return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, d->W, (hipStream_t)stream);
 }
 
@@ -218,7 +224,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), st));
     }
     TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
-                           rast, w + L.raster_ws, (int*)(w + L.head), (float*)(w + L.bwd16), mask, (d->n + 7) / 8 * 8, (unsigned char*)(w + L.dirty), covw,
+                           rast, w + L.raster_ws, w + L.cov16, (int*)(w + L.stamp), (unsigned char*)(w + L.own8), (float*)(w + L.bwd16), mask, (unsigned char*)(w + L.dirty), covw,
                            (int*)(w + L.act_count), st));        // the resolve pass also rearms the two segment-list cursors
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
@@ -284,7 +290,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         // shade + interpolate + rasterize + clip-transform backward, face-parallel (shade.hip: k_face_bwd)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
         TRY(face_bwd_impl((const float*)(w + L.bwd16), tri, pos, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
-                          (const int*)(w + L.head), corner_slot, (const float*)(w + L.cmat), d->n,
+                          w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot, (const float*)(w + L.cmat), d->n,
                           d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
     }
     {

@@ -61,7 +61,7 @@ __device__ __forceinline__ void emit_fragment(const float4 p0, const float4 p1, 
 {
     Frag fr;
     if (!fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) return;
-    unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | (unsigned)f;
+    unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)f << 1) | 1u;   // bit 0: large-box triangle
     size_t pix = (size_t)py * W + px;
     atomicMin(&keys_view[pix], key);
     if (dirty != nullptr) dirty[(pixbase + (long long)pix) >> 6] = 1;
@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(kBlock)
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, int* __restrict__ large_cnt,
-              int2* __restrict__ large_q, unsigned char* __restrict__ dirty)
+              int2* __restrict__ large_q, unsigned char* __restrict__ dirty, int4* __restrict__ cov16,
+              const int* __restrict__ stamp)
 {
     __shared__ TriPark park[kBlock];
     __shared__ unsigned short tasks[kBlock / 64][kTaskCap];
@@ -139,6 +140,8 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             write_silh(silh, opp, sv, s0, s1, s2, b, f, F);
             int slot = atomicAdd(large_cnt, 1);
             large_q[slot] = make_int2(b, f);
+            // coverage entry of a large-box triangle: head of the pixel list the resolve pass threads (atomicExch on .x)
+            if (cov16 != nullptr) cov16[(size_t)b * F + f] = make_int4(-1, 0, 0, (int)(((unsigned)stamp[0] << 8) | 0xFFu));
         } else {
             // the opposite-vertex ids (antialias rule A3) are requested now and arrive while the coverage mask is computed
             if (silh != nullptr) { o0 = opp[f * 3]; o1 = opp[f * 3 + 1]; o2 = opp[f * 3 + 2]; }
@@ -198,6 +201,10 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         pin(p0); pin(p1); pin(p2);
         // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
         if (silh != nullptr) silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
+        // coverage entry (face-parallel backward): candidate-pixel mask of the box, its origin and width, tagged with the step stamp
+        if (cov16 != nullptr)
+            cov16[(size_t)b * F + f] = make_int4((int)(unsigned)(cm & 0xffffffffull), (int)(unsigned)(cm >> 32), s.pxa | (s.pya << 16),
+                                                 (int)(((unsigned)stamp[0] << 8) | (unsigned)bw));
         TriPark& t = park[threadIdx.x];
         t.p0 = p0; t.p1 = p1; t.p2 = p2; t.f = f; t.b = b; t.origin = s.pxa | (s.pya << 16); t.bw = bw;
     }
@@ -230,7 +237,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 const int px = (q.origin & 0xffff) + c, py = (q.origin >> 16) + r;
                 Frag fr;
                 if (fragment(q.p0, q.p1, q.p2, px, py, xs, xo, ys, yo, fr)) {
-                    const unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | (unsigned)q.f;
+                    const unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)q.f << 1);
                     const long long pix = (long long)q.b * P + (long long)py * W + px;
                     atomicMin(&keys[pix], key);
                     segl = pix >> 6;
@@ -251,8 +258,10 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
 __global__ void __launch_bounds__(kBlock)
 k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
                int F, int H, int W, unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt,
-               const int2* __restrict__ large_q, unsigned char* __restrict__ dirty)
+               const int2* __restrict__ large_q, unsigned char* __restrict__ dirty, int* __restrict__ stamp)
 {
+    // k_raster_tris tagged this step's coverage entries with the old counter value; everything after this kernel sees value + 1
+    if (stamp != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamp[0] = stamp[0] + 1;
     const int cnt = *large_cnt;
     const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
     float xo = 1.0f / (float)W; xo = xo - 1.0f;
@@ -284,8 +293,9 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
 // their rast written (uncovered lanes are zero-filled later, only where a consumer will look), and the coverage word is stored.
 __global__ void __launch_bounds__(kBlock)
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
-                 unsigned long long* __restrict__ keys, float4* __restrict__ rast, int* __restrict__ head,
-                 float4* __restrict__ bwd16, const float* __restrict__ mask, int npad, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw,
+                 unsigned long long* __restrict__ keys, float4* __restrict__ rast, int4* __restrict__ cov16,
+                 const int* __restrict__ stamp, unsigned char* __restrict__ own8, float4* __restrict__ bwd16,
+                 const float* __restrict__ mask, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw,
                  int* __restrict__ large_cnt, int* __restrict__ rearm2)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -306,14 +316,15 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
     }
     bool live = gid < (long long)n * P;
     unsigned long long key = live ? keys[gid] : ~0ull;
-    const float mk = (live && head != nullptr) ? mask[gid] : 0.f;      // independent of the key: issued with it
+    const float mk = (live && bwd16 != nullptr) ? mask[gid] : 0.f;      // independent of the key: issued with it
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     bool covered = false;
     if (key != ~0ull) {
         int rem, px;
         const int b = fast_divmod(gid, (int)P, rem);
         const int py = fast_divmod(rem, W, px);
-        int f = (int)(key & 0xffffffffu);
+        const int f = (int)((unsigned)(key & 0xffffffffu) >> 1);
+        const bool large = (key & 1ull) != 0ull;
         const float* vp = pos + (size_t)b * V * 4;
         float4 p0 = ldg4(vp + (size_t)tri[f * 3] * 4), p1 = ldg4(vp + (size_t)tri[f * 3 + 1] * 4),
                p2 = ldg4(vp + (size_t)tri[f * 3 + 2] * 4);
@@ -325,10 +336,17 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
             o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
             covered = true;
-            if (head != nullptr) {
-                // thread the pixel onto its face's list and leave everything the backward needs per pixel in ONE 16-B word
-                const int link = atomicExch(&head[(size_t)b * F + f], rem);
-                bwd16[gid] = make_float4(fr.u, fr.v, __int_as_float(link), (mk > 0.f) ? 1.f : 0.f);
+            if (bwd16 != nullptr) {
+                // everything the backward needs per pixel in ONE 16-B word: (u, v, owner, flags).  owner = the face id (the
+                // face-parallel backward checks its candidate pixels against it); a large-box face has no candidate mask, its
+                // pixels are threaded onto a list instead (head = .x of its coverage entry) and owner holds the link.
+                // flags = (mask > 0) + 2 * large
+                int owner = f;
+                if (large) owner = atomicExch(reinterpret_cast<int*>(&cov16[(size_t)b * F + f]), rem);
+                // "this (view, face) owns pixels in step <stamp>": lets the backward skip the coverage entries of hidden faces.
+                // Only a hint (8-bit stamp; a stale match costs a wasted entry load, never a wrong result)
+                own8[(size_t)b * F + f] = (unsigned char)(stamp[0] - 1);
+                bwd16[gid] = make_float4(fr.u, fr.v, __int_as_float(owner), ((mk > 0.f) ? 1.f : 0.f) + (large ? 2.f : 0.f));
             }
         }
     }
@@ -482,8 +500,8 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
 // snap [n,V] int2 must already hold the snapped vertices; head/next may be null.  dirty/covw non-null = sparse mode (the key
 // buffer must have been initialised by raster_sparse_init and is left clean again).
 int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, const int32_t* opp, unsigned char* silh, int n, int V,
-                       int F, int H, int W, float* rast, void* ws, int* head, float* bwd16, const float* mask, int npad, unsigned char* dirty,
-                       unsigned long long* covw, int* rearm2, hipStream_t st)
+                       int F, int H, int W, float* rast, void* ws, void* cov16, int* stamp, unsigned char* own8, float* bwd16, const float* mask,
+                       unsigned char* dirty, unsigned long long* covw, int* rearm2, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
     unsigned long long* keys = (unsigned long long*)ws;
@@ -501,24 +519,20 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
             e = hipMemsetAsync(large_cnt, 0, 16, st);
             if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
         }
-        if (head != nullptr && (size_t)n * F > 0) {
-            e = hipMemsetAsync(head, 0xFF, (size_t)npad * F * 4, st);
-            if (e != hipSuccess) return hip_fail(e, "memset head");
-        }
     }
     if ((long long)n * F > 0) {
         {
             ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
             k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, large_cnt,
-                                                                          large_q, dirty);
+                                                                          large_q, dirty, (int4*)cov16, stamp);
             FMHR_CHECK_LAUNCH("k_raster_tris");
         }
         ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);
-        k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty);
+        k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty, stamp);
         FMHR_CHECK_LAUNCH("k_raster_large");
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, head, (float4*)bwd16, mask, npad,
+    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, (int4*)cov16, stamp, own8, (float4*)bwd16, mask,
                                                                     dirty, covw, large_cnt, rearm2);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
@@ -536,7 +550,7 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     int2* snap = (int2*)((char*)ws + raster_core_ws_bytes(n, F, H, W));
     int rc = snap_vertices_impl(pos, n, V, H, W, snap, (hipStream_t)stream);
     if (rc) return rc;
-    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                               nullptr, (hipStream_t)stream);
 }
 

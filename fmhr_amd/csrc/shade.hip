@@ -281,15 +281,19 @@ __global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__
 constexpr int kGroup = 8;  // views summed inside one lane group of the face-parallel backward
 
 // ------------------------------------------------------------------------------------------------ face-parallel backward
-// One lane per (face, view); the kGroup lanes of a group are kGroup consecutive views of one face.  A lane whose face owns pixels
-// in its view loads the face ONCE (3 vertex ids, 3 x attr8, 3 clip positions), walks the face's pixel list (raster.hip: head
-// [n, F] and the per-pixel (u, v, link, mask flag) written by the resolve pass) doing the whole per-pixel backward (shade ->
-// normalise -> interpolate -> rasterize -> clip transform) in registers and accumulating the three corners' gradients; the group
-// is summed with DPP and lanes 0..2 store corner 0..2 as 3 x float4 into that corner's slot of its vertex's CSR row (corner_slot
-// = inverse of vf_idx), where the mesh tail sums a vertex's slots with coalesced loads.  No per-pixel record buffer, no float
-// atomics, deterministic.  These kernels are bound by the NUMBER of vector-memory requests (each scattered wave-load occupies
-// the texture-address unit for up to 64 cycles), so the per-lane request count is the budget: 1 head + 1 tri (12 B) + 6 attr8 +
-// 3 pos + 2 per pixel; the view's SH row and clip matrix come from an LDS copy.
+// One lane per (face, view); the kGroup lanes of a group are kGroup consecutive views of ONE face and end in one DPP sum, so any
+// lane of a group may process any pixel of that face in any of the group's views.  The rasterizer left a coverage entry per
+// (view, face): the candidate-pixel mask of the triangle's box (raster.hip: k_raster_tris).  A group expands the masks of its views
+// into an LDS task list and its lanes take the tasks round-robin: load the pixel's (u, v, owner, flags) word and image gradient,
+// skip it unless this face owns the pixel (hidden candidates), else do the whole per-pixel backward (shade -> normalise ->
+// interpolate -> rasterize -> clip transform) in registers, accumulating the three corners' gradients.  Per-face data (3 x
+// attr8 as corner-2-relative differences) and per-(face, view) data (3 clip positions, box) are loaded once and parked in LDS;
+// the view's SH row and clip matrix come from an LDS copy.  Finally lanes 0..2 of a group store corner 0..2 as 3 x float4 into
+// the corner's slot of its vertex's CSR row (corner_slot = inverse of vf_idx), where the mesh tail sums a vertex's slots with
+// coalesced loads.  No per-pixel record buffer, no pixel lists for box triangles, no float atomics, deterministic.
+// (Large-box triangles have no mask: their pixels are on a list threaded by the resolve pass, walked by the owning lane.)
+// The budget of these kernels is the NUMBER of vector-memory requests (a scattered wave-load occupies the texture-address unit
+// for up to 64 cycles) and the number of wave iterations of the ~250-instruction pixel backward.
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
@@ -299,123 +303,232 @@ __device__ __forceinline__ float group_sum(float x)
     x += dpp_mov<0xB1>(x);      // quad_perm [1,0,3,2]
     x += dpp_mov<0x4E>(x);      // quad_perm [2,3,0,1]
     x += dpp_mov<0x141>(x);     // row_half_mirror: lane i <-> 7 - i within each 8 lanes
-    if (kGroup == 16) x += dpp_mov<0x140>(x);   // row_mirror: lane i <-> 15 - i within each 16 lanes
     return x;
 }
 
 struct int3a { int x, y, z; };
+struct FaceAttr { float3 n2, dn0, dn1, a2, da0, da1; };
 
-__global__ void __launch_bounds__(kBlock)
+// backward of ONE pixel of a face for all three corners; A[k] += (g_normal.xyz, g_albedo.xyz, g_vertex.xyz) of corner k.
+// c = the view's 9 SH coefficients followed by its clip matrix rows (view_c layout).
+__device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr& fa_lds, const float4 p0, const float4 p1, const float4 p2,
+                                               const float* __restrict__ c, float u, float v, const float4 gs, int px, int py,
+                                               float xs, float xo, float ys, float yo)
+{
+    const FaceAttr fa = fa_lds;                 // read at the use: the kernel's occupancy is set by its live registers
+    const float b0 = u, b1 = v, b2 = 1.0f - u - v;
+    // forward recompute (shade_eval, with the corner-2-relative attribute differences)
+    const float nxr = fa.n2.x + b0 * fa.dn0.x + b1 * fa.dn1.x, nyr = fa.n2.y + b0 * fa.dn0.y + b1 * fa.dn1.y,
+                nzr = fa.n2.z + b0 * fa.dn0.z + b1 * fa.dn1.z;
+    const float ar = fa.a2.x + b0 * fa.da0.x + b1 * fa.da1.x, ag = fa.a2.y + b0 * fa.da0.y + b1 * fa.da1.y,
+                ab = fa.a2.z + b0 * fa.da0.z + b1 * fa.da1.z;
+    const float len = fsqrt(nxr * nxr + nyr * nyr + nzr * nzr);
+    const float inv = frcp(fmaxf(len, 1e-12f));
+    const float x = nxr * inv, y = nyr * inv, z = nzr * inv;
+    const float rad = sh9c(c, x, y, z);
+    // shade backward (mesh_sfs_optim.py:284-286, models/utils.py:208-226)
+    const float g_rad = gs.x * ar + gs.y * ag + gs.z * ab;
+    const float ga0 = gs.x * rad, ga1 = gs.y * rad, ga2 = gs.z * rad;
+    const float dx = c[3] + c[4] * y - 2.0f * c[6] * x + c[7] * z + 2.0f * c[8] * x;
+    const float dy = c[1] + c[4] * x + c[5] * z - 2.0f * c[6] * y - 2.0f * c[8] * y;
+    const float dz = c[2] + c[5] * y + 4.0f * c[6] * z + c[7] * x;
+    const float ghx = g_rad * dx, ghy = g_rad * dy, ghz = g_rad * dz;
+    float gnx, gny, gnz;
+    if (len > 1e-12f) {
+        const float dt = x * ghx + y * ghy + z * ghz;
+        gnx = (ghx - x * dt) * inv; gny = (ghy - y * dt) * inv; gnz = (ghz - z * dt) * inv;
+    } else {
+        gnx = ghx * 1e12f; gny = ghy * 1e12f; gnz = ghz * 1e12f;
+    }
+    // interpolate backward w.r.t. the barycentrics
+    const float gu = gnx * fa.dn0.x + gny * fa.dn0.y + gnz * fa.dn0.z + ga0 * fa.da0.x + ga1 * fa.da0.y + ga2 * fa.da0.z;
+    const float gv = gnx * fa.dn1.x + gny * fa.dn1.y + gnz * fa.dn1.z + ga0 * fa.da1.x + ga1 * fa.da1.y + ga2 * fa.da1.z;
+    // rasterize backward (Appendix B.1) for the three corners, pushed through the view's clip transform (c[9..]: rows of
+    // w2c @ proj, mesh.hip k_transform_fwd): the position gradients become view-independent
+    const float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
+    const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+    const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+    const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    const float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
+    const float iw = frcp(e0 + e1 + e2);
+    const float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * (e0 * iw) + gb1 * (e1 * iw);
+    const float qx[3] = {gbb * (p2y - p1y) - gb1 * p2y, gbb * (p0y - p2y) + gb0 * p2y, gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y};
+    const float qy[3] = {gbb * (p1x - p2x) + gb1 * p2x, gbb * (p2x - p0x) - gb0 * p2x, gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x};
+    const float bk[3] = {b0, b1, b2};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        A[k][0] += bk[k] * gnx; A[k][1] += bk[k] * gny; A[k][2] += bk[k] * gnz;
+        A[k][3] += bk[k] * ga0; A[k][4] += bk[k] * ga1; A[k][5] += bk[k] * ga2;
+        const float qw = -fx * qx[k] - fy * qy[k];
+        A[k][6] += qx[k] * c[9] + qy[k] * c[10] + qw * c[11];
+        A[k][7] += qx[k] * c[13] + qy[k] * c[14] + qw * c[15];
+        A[k][8] += qx[k] * c[17] + qy[k] * c[18] + qw * c[19];
+    }
+}
+
+constexpr int kTaskG = 64;                       // candidate pixels a group expands per round
+constexpr int kFacesPerBlock = kBlock / kGroup;
+constexpr int kMaxVPL = 3;                       // views per lane: a group of kGroup lanes covers kGroup * VPL views of one face
+
+// VPL views per lane: the fixed part of a (face, view group) — vertex ids, attributes, output slots, the DPP sum, the output
+// store, the launch — is paid once per kGroup * VPL views, and the partial planes the mesh tail has to add up shrink with it.
+template <int VPL>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
-           const int* __restrict__ head, const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, int n, int V,
-           int F, int H, int W, float4* __restrict__ part)
+           const int4* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
+           const int32_t* __restrict__ corner_slot,
+           const float4* __restrict__ cmat, int n, int V, int F, int H, int W, float4* __restrict__ part)
 {
-    static_assert(kGroup == 8 || kGroup == 16, "group_sum covers 8 or 16 lanes");
-    __shared__ float view_c[kGroup][24];                           // per view of the group: 9 SH coefficients, 12 clip-matrix entries
+    static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
+    constexpr int GV = kGroup * VPL;                               // views per group
+    __shared__ float view_c[GV][24];                               // per view of the group: 9 SH coefficients, 12 clip-matrix entries
+    __shared__ float4 pk_pos[kBlock * VPL][3];                     // per (face, view): the three clip positions
+    __shared__ int2 pk_box[kBlock * VPL];                          // box origin (pxa | pya << 16), box width
+    __shared__ FaceAttr pk_attr[kFacesPerBlock];
+    __shared__ unsigned short tasks[kFacesPerBlock][kTaskG];
     const long long P = (long long)H * W;
-    const int j = threadIdx.x & (kGroup - 1);
-    const int f = blockIdx.x * (kBlock / kGroup) + threadIdx.x / kGroup;
-    const int g = blockIdx.y, b = g * kGroup + j;
-    for (int i = threadIdx.x; i < kGroup * 24; i += kBlock) {
-        const int vb = i / 24, k = i - vb * 24, bb = g * kGroup + vb;
+    const int tid = threadIdx.x, j = tid & (kGroup - 1), gl = tid / kGroup, lane = tid & 63;
+    const int f = blockIdx.x * kFacesPerBlock + gl;
+    const int g = blockIdx.y, b0 = g * GV;                         // view of (lane j, slot v) = b0 + v * kGroup + j
+    for (int i = tid; i < GV * 24; i += kBlock) {
+        const int vb = i / 24, k = i - vb * 24, bb = b0 + vb;
         float v = 0.f;
         if (bb < n) v = (k < 9) ? sh[(size_t)bb * 9 + k] : ((k < 21) ? reinterpret_cast<const float*>(cmat)[(size_t)bb * 12 + (k - 9)] : 0.f);
         view_c[vb][k] = v;
     }
-    __syncthreads();
+    __syncthreads();                                               // the only workgroup barrier: everything below is per wave
     const bool facelive = f < F;                                   // uniform over a group
+    // ---- the coverage entries of this lane's (face, view)s; entries of other steps carry another stamp
+    const unsigned cur = ((unsigned)stamp[0] - 1u) & 0xFFFFFFu;    // k_raster_large advanced the counter after the tagging
+    // everything whose address is known up front is requested together (the kernel's time is #waves / wave slots x the length of
+    // a wave's dependent-load chain): the owner marks, the entries, the face's vertex ids, the output slot
+    int3a ti = {0, 0, 0};
+    int es = 0;
+    if (facelive) {
+        ti = *reinterpret_cast<const int3a*>(tri + (size_t)f * 3);
+        if (j < 3) es = corner_slot[f * 3 + j];
+    }
+    int4 e[VPL];
+    unsigned char mark[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; v++) {
+        const int b = b0 + v * kGroup + j;
+        e[v] = make_int4(0, 0, 0, -1);
+        mark[v] = 0;
+        if (facelive && b < n) {
+            mark[v] = own8[(size_t)b * F + f];
+            e[v] = cov16[(size_t)b * F + f];
+        }
+    }
+    // kind: 0 nothing, 1..64 box width of a candidate mask, 255 pixel list.  Triangles that own no pixel this step (off screen, no
+    // pixel centre, hidden: 2/3 of all) are dropped by the owner mark of the resolve pass; a stale mark only costs candidate checks
+    int kind[VPL], cnt = 0;
+    bool anyv = false;
+#pragma unroll
+    for (int v = 0; v < VPL; v++) {
+        const bool live = facelive && (b0 + v * kGroup + j) < n;
+        kind[v] = (live && mark[v] == (unsigned char)cur && ((unsigned)e[v].w >> 8) == cur) ? (e[v].w & 0xFF) : 0;
+        if (kind[v] >= 1 && kind[v] <= 64) cnt += __popc((unsigned)e[v].x) + __popc((unsigned)e[v].y);
+        anyv = anyv || kind[v] != 0;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < kGroup; d <<= 1) {
+        int t = __shfl_up(incl, d, kGroup);
+        if (j >= d) incl += t;
+    }
+    const int excl = incl - cnt, T = __shfl(incl, kGroup - 1, kGroup);
+    const unsigned long long anyk = __ballot(anyv);
+    const bool group_any = ((anyk >> (lane & ~(kGroup - 1))) & 0xFFull) != 0ull;
     float A[3][9];                                                 // per corner: g_normal.xyz, g_albedo.xyz, g_vertex.xyz
 #pragma unroll
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int c = 0; c < 9; c++) A[k][c] = 0.f;
-    int p = (facelive && b < n) ? head[(size_t)b * F + f] : -1;
-    if (p >= 0) {
-        const long long vbase = (long long)b * P;
-        float4 gs = g_shaded[vbase + p];                           // the first pixel does not depend on the face data: issue first
-        float4 r = bwd16[vbase + p];
-        const int3a ti = *reinterpret_cast<const int3a*>(tri + (size_t)f * 3);
-        const float4 q0 = attr8[(size_t)ti.x * 2], q1 = attr8[(size_t)ti.x * 2 + 1];
-        const float4 u0 = attr8[(size_t)ti.y * 2], u1 = attr8[(size_t)ti.y * 2 + 1];
-        const float4 w0 = attr8[(size_t)ti.z * 2], w1 = attr8[(size_t)ti.z * 2 + 1];
-        const float* vp = pos + (size_t)b * V * 4;
-        float4 p0 = ldg4(vp + (size_t)ti.x * 4), p1 = ldg4(vp + (size_t)ti.y * 4), p2 = ldg4(vp + (size_t)ti.z * 4);
-        float c[9];
+    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
+    if (anyk != 0ull) {                                            // wave-uniform
+        // ---- park: clip positions per covering (face, view), attributes once per face (lane 0 of the group)
 #pragma unroll
-        for (int k = 0; k < 9; k++) c[k] = view_c[j][k];
-        pin(p0); pin(p1); pin(p2);
-        pin(gs); pin(r);
-        const float3 n2 = make_float3(w0.x, w0.y, w0.z), a2 = make_float3(w0.w, w1.x, w1.y);
-        const float3 dn0 = make_float3(q0.x - n2.x, q0.y - n2.y, q0.z - n2.z), da0 = make_float3(q0.w - a2.x, q1.x - a2.y, q1.y - a2.z);
-        const float3 dn1 = make_float3(u0.x - n2.x, u0.y - n2.y, u0.z - n2.z), da1 = make_float3(u0.w - a2.x, u1.x - a2.y, u1.y - a2.z);
-        const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
-        float gx[3] = {0.f, 0.f, 0.f}, gy[3] = {0.f, 0.f, 0.f}, gw[3] = {0.f, 0.f, 0.f};
-        while (true) {
-            const int nx = __float_as_int(r.z);
-            if (r.w != 0.f && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) {
-                const float b0 = r.x, b1 = r.y, b2 = 1.0f - r.x - r.y;
-                // forward recompute (shade_eval, with the corner-2-relative attribute differences)
-                const float nxr = n2.x + b0 * dn0.x + b1 * dn1.x, nyr = n2.y + b0 * dn0.y + b1 * dn1.y,
-                            nzr = n2.z + b0 * dn0.z + b1 * dn1.z;
-                const float ar = a2.x + b0 * da0.x + b1 * da1.x, ag = a2.y + b0 * da0.y + b1 * da1.y,
-                            ab = a2.z + b0 * da0.z + b1 * da1.z;
-                const float len = fsqrt(nxr * nxr + nyr * nyr + nzr * nzr);
-                const float inv = frcp(fmaxf(len, 1e-12f));
-                const float x = nxr * inv, y = nyr * inv, z = nzr * inv;
-                const float rad = sh9c(c, x, y, z);
-                // shade backward (mesh_sfs_optim.py:284-286, models/utils.py:208-226)
-                const float g_rad = gs.x * ar + gs.y * ag + gs.z * ab;
-                const float ga0 = gs.x * rad, ga1 = gs.y * rad, ga2 = gs.z * rad;
-                const float dx = c[3] + c[4] * y - 2.0f * c[6] * x + c[7] * z + 2.0f * c[8] * x;
-                const float dy = c[1] + c[4] * x + c[5] * z - 2.0f * c[6] * y - 2.0f * c[8] * y;
-                const float dz = c[2] + c[5] * y + 4.0f * c[6] * z + c[7] * x;
-                const float ghx = g_rad * dx, ghy = g_rad * dy, ghz = g_rad * dz;
-                float gnx, gny, gnz;
-                if (len > 1e-12f) {
-                    const float dt = x * ghx + y * ghy + z * ghz;
-                    gnx = (ghx - x * dt) * inv; gny = (ghy - y * dt) * inv; gnz = (ghz - z * dt) * inv;
-                } else {
-                    gnx = ghx * 1e12f; gny = ghy * 1e12f; gnz = ghz * 1e12f;
-                }
-                // interpolate backward w.r.t. the barycentrics
-                const float gu = gnx * dn0.x + gny * dn0.y + gnz * dn0.z + ga0 * da0.x + ga1 * da0.y + ga2 * da0.z;
-                const float gv = gnx * dn1.x + gny * dn1.y + gnz * dn1.z + ga0 * da1.x + ga1 * da1.y + ga2 * da1.z;
-                // rasterize backward (Appendix B.1) for the three corners
-                int px;
-                const int py = fast_divmod(p, W, px);
-                const float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
-                const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-                const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-                const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-                const float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
-                const float iw = frcp(e0 + e1 + e2);
-                const float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * (e0 * iw) + gb1 * (e1 * iw);
-                const float qx[3] = {gbb * (p2y - p1y) - gb1 * p2y, gbb * (p0y - p2y) + gb0 * p2y,
-                                     gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y};
-                const float qy[3] = {gbb * (p1x - p2x) + gb1 * p2x, gbb * (p2x - p0x) - gb0 * p2x,
-                                     gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x};
-                const float bk[3] = {b0, b1, b2};
+        for (int v = 0; v < VPL; v++)
+            if (kind[v] != 0) {
+                const float* vp = pos + (size_t)(b0 + v * kGroup + j) * V * 4;
+                float4 p0 = ldg4(vp + (size_t)ti.x * 4), p1 = ldg4(vp + (size_t)ti.y * 4), p2 = ldg4(vp + (size_t)ti.z * 4);
+                pin(p0); pin(p1); pin(p2);
+                const int at = tid * VPL + v;
+                pk_pos[at][0] = p0; pk_pos[at][1] = p1; pk_pos[at][2] = p2;
+                pk_box[at] = make_int2(e[v].z, kind[v]);
+            }
+        if (j == 0 && group_any) {
+            const float4 q0 = attr8[(size_t)ti.x * 2], q1 = attr8[(size_t)ti.x * 2 + 1];
+            const float4 u0 = attr8[(size_t)ti.y * 2], u1 = attr8[(size_t)ti.y * 2 + 1];
+            const float4 w0 = attr8[(size_t)ti.z * 2], w1 = attr8[(size_t)ti.z * 2 + 1];
+            FaceAttr fa;
+            fa.n2 = make_float3(w0.x, w0.y, w0.z); fa.a2 = make_float3(w0.w, w1.x, w1.y);
+            fa.dn0 = make_float3(q0.x - fa.n2.x, q0.y - fa.n2.y, q0.z - fa.n2.z);
+            fa.da0 = make_float3(q0.w - fa.a2.x, q1.x - fa.a2.y, q1.y - fa.a2.z);
+            fa.dn1 = make_float3(u0.x - fa.n2.x, u0.y - fa.n2.y, u0.z - fa.n2.z);
+            fa.da1 = make_float3(u0.w - fa.a2.x, u1.x - fa.a2.y, u1.y - fa.a2.z);
+            pk_attr[gl] = fa;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const FaceAttr& fa = pk_attr[gl];
+        // ---- candidate pixels of the group's box triangles, kTaskG per round; task = (view slot v * kGroup + j) << 6 | bit
+        for (int R = 0; __ballot(R < T) != 0ull; R += kTaskG) {     // wave-uniform trip count
+            if (cnt != 0 && excl < R + kTaskG && excl + cnt > R) {
+                int idx = excl - R;
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    A[k][0] += bk[k] * gnx; A[k][1] += bk[k] * gny; A[k][2] += bk[k] * gnz;
-                    A[k][3] += bk[k] * ga0; A[k][4] += bk[k] * ga1; A[k][5] += bk[k] * ga2;
-                    gx[k] += qx[k]; gy[k] += qy[k]; gw[k] += -fx * qx[k] - fy * qy[k];
+                for (int v = 0; v < VPL; v++) {
+                    if (!(kind[v] >= 1 && kind[v] <= 64)) continue;
+                    unsigned long long m = ((unsigned long long)(unsigned)e[v].y << 32) | (unsigned)e[v].x;
+                    while (m != 0ull) {
+                        const int bit = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        if (idx >= 0 && idx < kTaskG) tasks[gl][idx] = (unsigned short)(((v * kGroup + j) << 6) | bit);
+                        idx++;
+                    }
                 }
             }
-            p = nx;
-            if (p < 0) break;
-            gs = g_shaded[vbase + p];
-            r = bwd16[vbase + p];
-            pin(gs); pin(r);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int nt = min(kTaskG, T - R);
+            for (int t = j; t < nt; t += kGroup) {
+                const int en = tasks[gl][t], vs = en >> 6, bit = en & 63;
+                const int src = ((tid & ~(kGroup - 1)) + (vs & (kGroup - 1))) * VPL + (vs >> 3);
+                const int2 box = pk_box[src];
+                int c;
+                const int r = fast_divmod(bit, box.y, c);
+                const int px = (box.x & 0xffff) + c, py = (box.x >> 16) + r;
+                const long long gid = (long long)(b0 + vs) * P + (long long)py * W + px;
+                float4 w = bwd16[gid];
+                float4 gs = g_shaded[gid];
+                pin(w); pin(gs);
+                // owner == this face, mask > 0 and not a list pixel (flags == 1), non-zero image gradient
+                if (__float_as_int(w.z) == f && w.w == 1.f && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f))
+                    pixel_backward(A, fa, pk_pos[src][0], pk_pos[src][1], pk_pos[src][2], &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        // clip-transform backward of this view (cmat rows of w2c @ proj): position gradients become view-independent
-        const float* cm = &view_c[j][9];
+        // ---- large-box triangles: the owning lane walks the pixel list (head in the entry, links in the owner field)
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            A[k][6] = gx[k] * cm[0] + gy[k] * cm[1] + gw[k] * cm[2];
-            A[k][7] = gx[k] * cm[4] + gy[k] * cm[5] + gw[k] * cm[6];
-            A[k][8] = gx[k] * cm[8] + gy[k] * cm[9] + gw[k] * cm[10];
+        for (int v = 0; v < VPL; v++) {
+            if (kind[v] != 255) continue;
+            const int vs = v * kGroup + j, at = tid * VPL + v;
+            int p = e[v].x;
+            while (p >= 0) {
+                const long long gid = (long long)(b0 + vs) * P + p;
+                float4 w = bwd16[gid];
+                float4 gs = g_shaded[gid];
+                pin(w); pin(gs);
+                if (w.w == 3.f && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) {
+                    int px;
+                    const int py = fast_divmod(p, W, px);
+                    pixel_backward(A, fa, pk_pos[at][0], pk_pos[at][1], pk_pos[at][2], &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
+                }
+                p = __float_as_int(w.z);
+            }
         }
     }
 #pragma unroll
@@ -426,8 +539,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         float o[9];
 #pragma unroll
         for (int c = 0; c < 9; c++) o[c] = (j == 0) ? A[0][c] : ((j == 1) ? A[1][c] : A[2][c]);
-        const int e = corner_slot[f * 3 + j];
-        float4* dst = part + ((size_t)g * 3 * F + e) * 3;
+        float4* dst = part + ((size_t)g * 3 * F + es) * 3;
         dst[0] = make_float4(o[0], o[1], o[2], o[3]);
         dst[1] = make_float4(o[4], o[5], o[6], o[7]);
         dst[2] = make_float4(o[8], 0.f, 0.f, 0.f);
@@ -521,19 +633,30 @@ int loss_pix_impl(const float* shaded, const float* aa, const float* img, const 
     return FMHR_OK;
 }
 
+// views per lane: one group spans the whole batch when it can (n <= 8 -> 1, <= 16 -> 2, else 3 with ceil(n / 24) groups)
+static int face_bwd_vpl(int n) { return n <= kGroup ? 1 : (n <= 2 * kGroup ? 2 : kMaxVPL); }
+
+int face_bwd_groups(int n) { return cdiv(n, kGroup * face_bwd_vpl(n)); }
+
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
-                  const int* head, const int32_t* corner_slot, const float* cmat, int n, int V, int F, int H, int W, float* part,
-                  hipStream_t st)
+                  const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
+                  int n, int V, int F, int H, int W, float* part, hipStream_t st)
 {
     if (n == 0 || F == 0) return FMHR_OK;
-    k_face_bwd<<<dim3(cdiv(F, kBlock / kGroup), cdiv(n, kGroup)), kBlock, 0, st>>>(
-        (const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded, head, corner_slot, (const float4*)cmat,
-        n, V, F, H, W, (float4*)part);
+    const dim3 grid(cdiv(F, kFacesPerBlock), face_bwd_groups(n));
+#define FMHR_FACE_BWD(VPL)                                                                                                          \
+    k_face_bwd<VPL><<<grid, kBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
+                                             (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, n, V, F, H, W,     \
+                                             (float4*)part)
+    switch (face_bwd_vpl(n)) {
+        case 1: FMHR_FACE_BWD(1); break;
+        case 2: FMHR_FACE_BWD(2); break;
+        default: FMHR_FACE_BWD(3); break;
+    }
+#undef FMHR_FACE_BWD
     FMHR_CHECK_LAUNCH("k_face_bwd");
     return FMHR_OK;
 }
-
-int face_bwd_groups(int n) { return cdiv(n, kGroup); }
 
 int finish_losses_impl(float* losses, const float* n_valid, const float* part_l1, const float* part_l2, int nb,
                        const float* tail_part, int tail_nb, float w_sfs, float w_mask, float mse_den, hipStream_t st)
