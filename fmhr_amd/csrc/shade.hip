@@ -633,8 +633,9 @@ int loss_pix_impl(const float* shaded, const float* aa, const float* img, const 
     return FMHR_OK;
 }
 
-// views per lane: one group spans the whole batch when it can (n <= 8 -> 1, <= 16 -> 2, else 3 with ceil(n / 24) groups)
-static int face_bwd_vpl(int n) { return n <= kGroup ? 1 : (n <= 2 * kGroup ? 2 : kMaxVPL); }
+// views per lane: one group spans the whole batch when it can (up to kGroup * kMaxVPL = 24 views; measured at 48 views:
+// 2 / 3 / 4 / 6 views per lane -> 149 / 119 / 149 / 202 us, the LDS parking limits the workgroups per CU beyond 3)
+static int face_bwd_vpl(int n) { return min(kMaxVPL, cdiv(n, kGroup)); }
 
 int face_bwd_groups(int n) { return cdiv(n, kGroup * face_bwd_vpl(n)); }
 
