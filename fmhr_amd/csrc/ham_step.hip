@@ -2,6 +2,7 @@
 // Replaces the loop body /root/reference/mesh_sfs_optim.py:253-308 for the views a rank owns; every launch goes to the
 // caller's stream, nothing synchronises, so the pair is hipGraph-capturable.
 #include "common.h"
+#include "shade_common.h"
 #include <string.h>
 
 namespace fmhr {
@@ -20,7 +21,7 @@ int mesh_tail_blocks(int V);
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
-                       void*, void*, int*, unsigned char*, float*, const float*, unsigned char*, unsigned long long*, int*, hipStream_t);
+                       void*, unsigned char*, unsigned long long*, const RasterFused*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, int*,
                          hipStream_t);
@@ -40,8 +41,8 @@ int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, 
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
-int shade_fwd_impl(const float*, const int32_t*, const float*, const float*, const float*, int, int, int, int, const int*,
-                   const int*, const unsigned long long*, float*, float*, float*, int*, float*, hipStream_t);
+int shade_finish_impl(long long, const int*, const int*, const unsigned long long*, float*, float*, const float*, int, int*,
+                      float*, hipStream_t);
 int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
@@ -52,7 +53,7 @@ int finish_losses_impl(float*, const float*, const float*, const float*, int, co
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
-        g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, total;
+        g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, cnt_part, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -107,6 +108,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.rowg = take(off, V * 12);
     L.tail_part = take(off, (size_t)mesh_tail_blocks(d->V) * 16);    // per-workgroup regulariser loss sums [4, blocks]
     L.n_valid_f = take(off, 16);                    // float copy of n_valid_local (a ready n_valid_global for the one-rank case)
+    L.cnt_part = take(off, ((nP + 255) / 256) * 4);  // per-workgroup valid-pixel counts of the resolve pass
     L.total = off;
     return L;
 }
@@ -223,18 +225,26 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
                                     (float*)(w + L.attr8), st));
         TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), st));
     }
-    TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
-                           rast, w + L.raster_ws, w + L.cov16, (int*)(w + L.stamp), (unsigned char*)(w + L.own8), (float*)(w + L.bwd16), mask, (unsigned char*)(w + L.dirty), covw,
-                           (int*)(w + L.act_count), st));        // the resolve pass also rearms the two segment-list cursors
+    {
+        // rasterize; the resolve pass also shades the covered pixels, leaves the per-pixel backward word, marks the owning
+        // (view, face)s and rearms the two segment-list cursors
+        RasterFused fu;
+        fu.cov16 = (int4*)(w + L.cov16); fu.stamp = (int*)(w + L.stamp); fu.own8 = (unsigned char*)(w + L.own8);
+        fu.bwd16 = (float4*)(w + L.bwd16); fu.mask = mask;
+        fu.attr8 = (const float4*)(w + L.attr8); fu.sh = sh;
+        fu.shaded = (float4*)(w + L.shaded); fu.aa_init = (float4*)(w + L.aa); fu.part_cnt = (float*)(w + L.cnt_part);
+        fu.rearm2 = (int*)(w + L.act_count);
+        TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
+                               rast, w + L.raster_ws, (unsigned char*)(w + L.dirty), covw, &fu, st));
+    }
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
         TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, (int*)(w + L.act_list),
                                  (int*)(w + L.act_count), (int*)(w + L.cov_list), st));
-        TRY(shade_fwd_impl(rast, tri, (float*)(w + L.attr8), sh, mask, d->n, d->F, d->H, d->W, (const int*)(w + L.act_list),
-                           (const int*)(w + L.act_count), covw,
-                           (float*)(w + L.shaded), (float*)(w + L.aa), (float*)(w + L.partials), n_valid_local,
-                           (float*)(w + L.n_valid_f), st));
+        TRY(shade_finish_impl(nP, (const int*)(w + L.act_list), (const int*)(w + L.act_count), covw, (float*)(w + L.shaded),
+                              (float*)(w + L.aa), (const float*)(w + L.cnt_part), (int)((nP + 255) / 256), n_valid_local,
+                              (float*)(w + L.n_valid_f), st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),

@@ -6,6 +6,8 @@
 // triangle at 512^2): the work is per triangle, not per pixel, so one lane owns one triangle and walks its
 // (tiny) bounding box; triangles with a large box are queued and swept by a whole workgroup each.
 #include "common.h"
+#include "shade_common.h"
+#include <string.h>
 
 namespace fmhr {
 
@@ -293,72 +295,103 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
 // their rast written (uncovered lanes are zero-filled later, only where a consumer will look), and the coverage word is stored.
 __global__ void __launch_bounds__(kBlock)
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
-                 unsigned long long* __restrict__ keys, float4* __restrict__ rast, int4* __restrict__ cov16,
-                 const int* __restrict__ stamp, unsigned char* __restrict__ own8, float4* __restrict__ bwd16,
-                 const float* __restrict__ mask, unsigned char* __restrict__ dirty, unsigned long long* __restrict__ covw,
-                 int* __restrict__ large_cnt, int* __restrict__ rearm2)
+                 unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
+                 unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu)
 {
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    long long P = (long long)H * W;
+    __shared__ float sm[4];
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long P = (long long)H * W;
     const bool sparse = dirty != nullptr;
-    long long seg = gid >> 6;
+    const long long seg = gid >> 6;
+    bool work = true;                                                // wave-uniform
     if (sparse) {
         if (gid == 0) {                                              // k_raster_large is done: rearm its queue counter, and the
             *large_cnt = 0;                                          // caller's pair of list cursors (saves a memset launch)
-            if (rearm2 != nullptr) { rearm2[0] = 0; rearm2[1] = 0; }
+            if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
         }
-        if (gid - (gid & 63) >= (long long)n * P) return;            // whole wave out of range
-        int d = __builtin_amdgcn_readfirstlane((int)dirty[seg]);
-        if (!d) {
+        if (gid - (gid & 63) >= (long long)n * P) work = false;      // whole wave out of range
+        else if (!__builtin_amdgcn_readfirstlane((int)dirty[seg])) {
             if ((threadIdx.x & 63) == 0) covw[seg] = 0ull;
-            return;
+            work = false;
         }
     }
-    bool live = gid < (long long)n * P;
-    unsigned long long key = live ? keys[gid] : ~0ull;
-    const float mk = (live && bwd16 != nullptr) ? mask[gid] : 0.f;      // independent of the key: issued with it
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool covered = false;
-    if (key != ~0ull) {
-        int rem, px;
-        const int b = fast_divmod(gid, (int)P, rem);
-        const int py = fast_divmod(rem, W, px);
-        const int f = (int)((unsigned)(key & 0xffffffffu) >> 1);
-        const bool large = (key & 1ull) != 0ull;
-        const float* vp = pos + (size_t)b * V * 4;
-        float4 p0 = ldg4(vp + (size_t)tri[f * 3] * 4), p1 = ldg4(vp + (size_t)tri[f * 3 + 1] * 4),
-               p2 = ldg4(vp + (size_t)tri[f * 3 + 2] * 4);
-        pin(p0); pin(p1); pin(p2);
-        const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
-        float xo = 1.0f / (float)W; xo = xo - 1.0f;
-        float yo = 1.0f / (float)H; yo = yo - 1.0f;
-        Frag fr;
-        if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
-            o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
-            covered = true;
-            if (bwd16 != nullptr) {
-                // everything the backward needs per pixel in ONE 16-B word: (u, v, owner, flags).  owner = the face id (the
-                // face-parallel backward checks its candidate pixels against it); a large-box face has no candidate mask, its
-                // pixels are threaded onto a list instead (head = .x of its coverage entry) and owner holds the link.
-                // flags = (mask > 0) + 2 * large
-                int owner = f;
-                if (large) owner = atomicExch(reinterpret_cast<int*>(&cov16[(size_t)b * F + f]), rem);
-                // "this (view, face) owns pixels in step <stamp>": lets the backward skip the coverage entries of hidden faces.
-                // Only a hint (8-bit stamp; a stale match costs a wasted entry load, never a wrong result)
-                own8[(size_t)b * F + f] = (unsigned char)(stamp[0] - 1);
-                bwd16[gid] = make_float4(fr.u, fr.v, __int_as_float(owner), ((mk > 0.f) ? 1.f : 0.f) + (large ? 2.f : 0.f));
+    float nvalid = 0.f;
+    if (work) {
+        const bool live = gid < (long long)n * P;
+        unsigned long long key = live ? keys[gid] : ~0ull;
+        const float mk = (live && fu.bwd16 != nullptr) ? fu.mask[gid] : 0.f;   // independent of the key: issued with it
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f), col = o;
+        bool covered = false;
+        if (key != ~0ull) {
+            int rem, px;
+            const int b = fast_divmod(gid, (int)P, rem);
+            const int py = fast_divmod(rem, W, px);
+            const int f = (int)((unsigned)(key & 0xffffffffu) >> 1);
+            const bool large = (key & 1ull) != 0ull;
+            const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+            const float* vp = pos + (size_t)b * V * 4;
+            float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+            // fused step: the shading inputs ride in the same memory round trip as the clip positions
+            float4 q0, q1, u0, u1, w0, w1;
+            float shc[9];
+            const bool shade = fu.shaded != nullptr && mk > 0.f;
+            if (shade) {
+                q0 = fu.attr8[(size_t)i0 * 2]; q1 = fu.attr8[(size_t)i0 * 2 + 1];
+                u0 = fu.attr8[(size_t)i1 * 2]; u1 = fu.attr8[(size_t)i1 * 2 + 1];
+                w0 = fu.attr8[(size_t)i2 * 2]; w1 = fu.attr8[(size_t)i2 * 2 + 1];
+#pragma unroll
+                for (int k = 0; k < 9; k++) shc[k] = fu.sh[(size_t)b * 9 + k];
+                pin(q0); pin(q1); pin(u0); pin(u1); pin(w0); pin(w1);
+            }
+            pin(p0); pin(p1); pin(p2);
+            const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
+            float xo = 1.0f / (float)W; xo = xo - 1.0f;
+            float yo = 1.0f / (float)H; yo = yo - 1.0f;
+            Frag fr;
+            if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
+                o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
+                covered = true;
+                if (fu.bwd16 != nullptr) {
+                    // everything the backward needs per pixel in ONE 16-B word: (u, v, owner, flags).  owner = the face id (the
+                    // face-parallel backward checks its candidate pixels against it); a large-box face has no candidate mask,
+                    // its pixels are threaded onto a list instead (head = .x of its coverage entry) and owner holds the link.
+                    // flags = (mask > 0) + 2 * large
+                    int owner = f;
+                    if (large) owner = atomicExch(reinterpret_cast<int*>(&fu.cov16[(size_t)b * F + f]), rem);
+                    // "this (view, face) owns pixels in step <stamp>": lets the backward skip the coverage entries of hidden
+                    // faces.  Only a hint (8-bit stamp; a stale match costs a wasted entry load, never a wrong result)
+                    fu.own8[(size_t)b * F + f] = (unsigned char)(fu.stamp[0] - 1);
+                    fu.bwd16[gid] = make_float4(fr.u, fr.v, __int_as_float(owner), ((mk > 0.f) ? 1.f : 0.f) + (large ? 2.f : 0.f));
+                }
+                if (fu.shaded != nullptr) {
+                    // forward shading of the fused step (mesh_sfs_optim.py:268-286): rgb = SH radiance x albedo where mask > 0,
+                    // a = the interpolated ones attribute
+                    const float w2 = 1.0f - fr.u - fr.v;
+                    col.w = fr.u + fr.v + w2;
+                    if (shade) {
+                        PixShade s;
+                        shade_eval_attr(fr.u, fr.v, q0, q1, u0, u1, w0, w1, shc, s);
+                        col.x = s.rad * s.ar; col.y = s.rad * s.ag; col.z = s.rad * s.ab;
+                        nvalid = 1.f;
+                    }
+                }
             }
         }
-    }
-    if (sparse) {
-        unsigned long long bal = __ballot(covered);
-        if (live) {
-            if (covered) rast[gid] = o;
-            keys[gid] = ~0ull;
+        if (sparse) {
+            unsigned long long bal = __ballot(covered);
+            if (live) {
+                if (covered) rast[gid] = o;
+                keys[gid] = ~0ull;
+                if (fu.shaded != nullptr) { fu.shaded[gid] = col; fu.aa_init[gid] = col; }   // zeros on the uncovered lanes
+            }
+            if ((threadIdx.x & 63) == 0) { covw[seg] = bal; dirty[seg] = 0; }
+        } else if (live) {
+            rast[gid] = o;
         }
-        if ((threadIdx.x & 63) == 0) { covw[seg] = bal; dirty[seg] = 0; }
-    } else if (live) {
-        rast[gid] = o;
+    }
+    if (fu.part_cnt != nullptr) {                                    // local count of valid (mask > 0 and covered) pixels
+        float s = block_sum(nvalid, sm);
+        if (threadIdx.x == 0) fu.part_cnt[blockIdx.x] = s;
     }
 }
 
@@ -500,14 +533,17 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
 // snap [n,V] int2 must already hold the snapped vertices; head/next may be null.  dirty/covw non-null = sparse mode (the key
 // buffer must have been initialised by raster_sparse_init and is left clean again).
 int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, const int32_t* opp, unsigned char* silh, int n, int V,
-                       int F, int H, int W, float* rast, void* ws, void* cov16, int* stamp, unsigned char* own8, float* bwd16, const float* mask,
-                       unsigned char* dirty, unsigned long long* covw, int* rearm2, hipStream_t st)
+                       int F, int H, int W, float* rast, void* ws, unsigned char* dirty, unsigned long long* covw,
+                       const RasterFused* fused, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
     unsigned long long* keys = (unsigned long long*)ws;
     int* large_cnt = (int*)((char*)ws + nP * 8);
     int2* large_q = (int2*)((char*)ws + nP * 8 + 16);
     if (nP == 0) return FMHR_OK;
+    RasterFused fu;
+    memset(&fu, 0, sizeof(fu));
+    if (fused != nullptr) fu = *fused;
     {
         ProfScope ps(FMHR_SLOT_RASTER_CLEAR, st);
         hipError_t e;
@@ -524,16 +560,15 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         {
             ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
             k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, large_cnt,
-                                                                          large_q, dirty, (int4*)cov16, stamp);
+                                                                          large_q, dirty, fu.cov16, fu.stamp);
             FMHR_CHECK_LAUNCH("k_raster_tris");
         }
         ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);
-        k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty, stamp);
+        k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty, fu.stamp);
         FMHR_CHECK_LAUNCH("k_raster_large");
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, (int4*)cov16, stamp, own8, (float4*)bwd16, mask,
-                                                                    dirty, covw, large_cnt, rearm2);
+    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }
@@ -550,8 +585,8 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     int2* snap = (int2*)((char*)ws + raster_core_ws_bytes(n, F, H, W));
     int rc = snap_vertices_impl(pos, n, V, H, W, snap, (hipStream_t)stream);
     if (rc) return rc;
-    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                              nullptr, (hipStream_t)stream);
+    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, nullptr,
+                              (hipStream_t)stream);
 }
 
 extern "C" int fmhr_rasterize_bwd(const float* pos, const int32_t* tri, const float* rast, const float* dy, int n, int V,

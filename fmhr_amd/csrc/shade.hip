@@ -5,68 +5,10 @@
 // whole per-pixel backward in registers and stores per-corner sums that the mesh tail adds up per vertex — no float atomics
 // (the scatter form ran at the 0.08 TB/s "64 lanes -> 64 rows" atomic shape: 3.6 ms per step).
 #include "common.h"
+#include "shade_common.h"
 #include <stdlib.h>
 
 namespace fmhr {
-
-// value-only kernels: hardware reciprocal / square root (1 ulp) instead of the correctly rounded expansions (~10 dependent
-// instructions each) — the per-pixel kernels are bound by dependent ALU latency, and nothing discrete hangs on these values
-__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-
-__device__ __forceinline__ float sh9c(const float* c, float x, float y, float z)
-{
-    float r = c[0];
-    r = r + c[1] * y;
-    r = r + c[2] * z;
-    r = r + c[3] * x;
-    r = r + c[4] * x * y;
-    r = r + c[5] * y * z;
-    r = r + c[6] * (2.0f * z * z - x * x - y * y);
-    r = r + c[7] * z * x;
-    r = r + c[8] * (x * x - y * y);
-    return r;
-}
-
-struct PixShade {
-    float b0, b1, b2;        // barycentrics
-    int i0, i1, i2;
-    float nx, ny, nz, len;   // interpolated normal (raw) and its length
-    float hx, hy, hz;        // normalised
-    float ar, ag, ab;        // interpolated albedo
-    float rad;
-    float3 n0, n1, n2, a0, a1, a2;
-};
-
-__device__ __forceinline__ float3 ld3f(const float* p) { return make_float3(p[0], p[1], p[2]); }
-
-// attr8 [V,2] float4 = (normal.xyz, albedo.x | albedo.yz, 0, 0): two 16-B gathers per vertex instead of six 4-B ones (the pixel
-// kernels were bound by the number of load requests, not by bytes)
-__device__ __forceinline__ void shade_eval(const float4 r, const int32_t* __restrict__ tri, const float4* __restrict__ attr8,
-                                           const float* __restrict__ shc, PixShade& s)
-{
-    int t = (int)r.w - 1;
-    s.i0 = tri[t * 3]; s.i1 = tri[t * 3 + 1]; s.i2 = tri[t * 3 + 2];
-    s.b0 = r.x; s.b1 = r.y; s.b2 = 1.0f - r.x - r.y;
-    {
-        const float4 q0 = attr8[(size_t)s.i0 * 2], q1 = attr8[(size_t)s.i0 * 2 + 1];
-        const float4 u0 = attr8[(size_t)s.i1 * 2], u1 = attr8[(size_t)s.i1 * 2 + 1];
-        const float4 w0 = attr8[(size_t)s.i2 * 2], w1 = attr8[(size_t)s.i2 * 2 + 1];
-        s.n0 = make_float3(q0.x, q0.y, q0.z); s.a0 = make_float3(q0.w, q1.x, q1.y);
-        s.n1 = make_float3(u0.x, u0.y, u0.z); s.a1 = make_float3(u0.w, u1.x, u1.y);
-        s.n2 = make_float3(w0.x, w0.y, w0.z); s.a2 = make_float3(w0.w, w1.x, w1.y);
-    }
-    s.nx = s.b0 * s.n0.x + s.b1 * s.n1.x + s.b2 * s.n2.x;
-    s.ny = s.b0 * s.n0.y + s.b1 * s.n1.y + s.b2 * s.n2.y;
-    s.nz = s.b0 * s.n0.z + s.b1 * s.n1.z + s.b2 * s.n2.z;
-    s.ar = s.b0 * s.a0.x + s.b1 * s.a1.x + s.b2 * s.a2.x;
-    s.ag = s.b0 * s.a0.y + s.b1 * s.a1.y + s.b2 * s.a2.y;
-    s.ab = s.b0 * s.a0.z + s.b1 * s.a1.z + s.b2 * s.a2.z;
-    s.len = fsqrt(s.nx * s.nx + s.ny * s.ny + s.nz * s.nz);
-    float inv = frcp(fmaxf(s.len, 1e-12f));                  // F.normalize(p=2, dim=3), default eps (:273)
-    s.hx = s.nx * inv; s.hy = s.ny * inv; s.hz = s.nz * inv;
-    s.rad = sh9c(shc, s.hx, s.hy, s.hz);
-}
 
 // ------------------------------------------------------------------------------------------------ segment sparsity
 // The flattened pixel index [n*H*W] is cut into 64-pixel segments = exactly one wave of every per-pixel kernel.  A segment is
@@ -168,47 +110,21 @@ k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __re
     if (!act[gid >> 6]) { shaded[gid] = z; aa[gid] = z; }
 }
 
-// forward: rast -> rgba (rgb = shaded image, zero outside valid = mask>0 & covered; a = the interpolated ones attribute),
-// written twice (the second copy is the antialias accumulation target); local valid count
+// The forward shading itself is fused into the rasterizer's resolve pass (raster.hip), which writes the rgba pair for every
+// pixel of a segment that received fragments.  Active segments WITHOUT coverage (neighbours of covered ones, valid_mask-only
+// ones) get their zeros here.
 __global__ void __launch_bounds__(kBlock)
-k_shade_fwd(const float4* __restrict__ rast, const int32_t* __restrict__ tri, const float4* __restrict__ attr8,
-            const float* __restrict__ sh, const float* __restrict__ mask,
-            int n, int F, long long P, const int* __restrict__ act_list, const int* __restrict__ act_count,
-            const unsigned long long* __restrict__ covw,
-            float4* __restrict__ shaded, float4* __restrict__ aa_init, float* __restrict__ part_cnt)
+k_fill_uncovered(long long N, const int* __restrict__ act_list, const int* __restrict__ act_count,
+                 const unsigned long long* __restrict__ covw, float4* __restrict__ shaded, float4* __restrict__ aa_init)
 {
-    __shared__ float sm[4];
     const int count = *act_count, lane = threadIdx.x & 63;
-    float cnt = 0.f;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
         const long long seg = act_list[i];
+        if (covw[seg] != 0ull) continue;
         const long long gid = (seg << 6) + lane;
-        if (gid >= (long long)n * P) continue;
-        const bool covered = (covw[seg] >> lane) & 1ull;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (covered) r = rast[gid];
-        int t = (int)r.w - 1;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < F) {
-            float w2 = 1.0f - r.x - r.y;
-            o.w = r.x + r.y + w2;                                // interpolate of the ones attribute (:268-269)
-            if (mask[gid] > 0.f) {
-                int rem_;
-                const int b = fast_divmod(gid, (int)P, rem_);
-                float shc[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) shc[k] = sh[(size_t)b * 9 + k];
-                PixShade s;
-                shade_eval(r, tri, attr8, shc, s);
-                o.x = s.rad * s.ar; o.y = s.rad * s.ag; o.z = s.rad * s.ab;
-                cnt += 1.f;
-            }
-        }
-        shaded[gid] = o;
-        aa_init[gid] = o;
+        if (gid < N) { shaded[gid] = z; aa_init[gid] = z; }
     }
-    float s = block_sum(cnt, sm);
-    if (threadIdx.x == 0) part_cnt[blockIdx.x] = s;        // per-block partial: same-address atomics serialise at ~10 ns each
 }
 
 // losses + their per-pixel gradients over the active segments:
@@ -605,17 +521,12 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
     return FMHR_OK;
 }
 
-int shade_fwd_impl(const float* rast, const int32_t* tri, const float* attr8, const float* sh,
-                   const float* mask, int n, int F, int H, int W, const int* act_list, const int* act_count,
-                   const unsigned long long* covw, float* shaded, float* aa_init, float* part_cnt, int* n_valid, float* n_valid_f,
-                   hipStream_t st)
+int shade_finish_impl(long long N, const int* act_list, const int* act_count, const unsigned long long* covw, float* shaded,
+                      float* aa_init, const float* part_cnt, int nb, int* n_valid, float* n_valid_f, hipStream_t st)
 {
-    long long P = (long long)H * W;
-    if (n * P == 0) return FMHR_OK;
-    int nb = kPersistBlocks;
-    k_shade_fwd<<<nb, kBlock, 0, st>>>((const float4*)rast, tri, (const float4*)attr8, sh, mask, n, F, P, act_list, act_count, covw,
-                                       (float4*)shaded, (float4*)aa_init, part_cnt);
-    FMHR_CHECK_LAUNCH("k_shade_fwd");
+    if (N == 0) return FMHR_OK;
+    k_fill_uncovered<<<512, kBlock, 0, st>>>(N, act_list, act_count, covw, (float4*)shaded, (float4*)aa_init);
+    FMHR_CHECK_LAUNCH("k_fill_uncovered");
     k_reduce_count<<<1, 1024, 0, st>>>(part_cnt, nb, n_valid, n_valid_f);
     FMHR_CHECK_LAUNCH("k_reduce_count");
     return FMHR_OK;

@@ -1,0 +1,96 @@
+// fmhr_amd/csrc/shade_common.h — per-pixel shading shared by the forward (fused into the rasterizer's resolve pass, raster.hip)
+// and the backward (shade.hip): interpolate -> F.normalize -> SH radiance -> albedo product, /root/reference/mesh_sfs_optim.py:268-286.
+#pragma once
+#include "common.h"
+
+namespace fmhr {
+
+// value-only kernels: hardware reciprocal / square root (1 ulp) instead of the correctly rounded expansions (~10 dependent
+// instructions each) — the per-pixel kernels are bound by dependent ALU latency, and nothing discrete hangs on these values
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+__device__ __forceinline__ float sh9c(const float* c, float x, float y, float z)
+{
+    float r = c[0];
+    r = r + c[1] * y;
+    r = r + c[2] * z;
+    r = r + c[3] * x;
+    r = r + c[4] * x * y;
+    r = r + c[5] * y * z;
+    r = r + c[6] * (2.0f * z * z - x * x - y * y);
+    r = r + c[7] * z * x;
+    r = r + c[8] * (x * x - y * y);
+    return r;
+}
+
+struct PixShade {
+    float b0, b1, b2;        // barycentrics
+    int i0, i1, i2;
+    float nx, ny, nz, len;   // interpolated normal (raw) and its length
+    float hx, hy, hz;        // normalised
+    float ar, ag, ab;        // interpolated albedo
+    float rad;
+    float3 n0, n1, n2, a0, a1, a2;
+};
+
+__device__ __forceinline__ float3 ld3f(const float* p) { return make_float3(p[0], p[1], p[2]); }
+
+// attr8 [V,2] float4 = (normal.xyz, albedo.x | albedo.yz, 0, 0): two 16-B gathers per vertex instead of six 4-B ones (the pixel
+// kernels were bound by the number of load requests, not by bytes)
+__device__ __forceinline__ void shade_eval(const float4 r, const int32_t* __restrict__ tri, const float4* __restrict__ attr8,
+                                           const float* __restrict__ shc, PixShade& s)
+{
+    int t = (int)r.w - 1;
+    s.i0 = tri[t * 3]; s.i1 = tri[t * 3 + 1]; s.i2 = tri[t * 3 + 2];
+    s.b0 = r.x; s.b1 = r.y; s.b2 = 1.0f - r.x - r.y;
+    {
+        const float4 q0 = attr8[(size_t)s.i0 * 2], q1 = attr8[(size_t)s.i0 * 2 + 1];
+        const float4 u0 = attr8[(size_t)s.i1 * 2], u1 = attr8[(size_t)s.i1 * 2 + 1];
+        const float4 w0 = attr8[(size_t)s.i2 * 2], w1 = attr8[(size_t)s.i2 * 2 + 1];
+        s.n0 = make_float3(q0.x, q0.y, q0.z); s.a0 = make_float3(q0.w, q1.x, q1.y);
+        s.n1 = make_float3(u0.x, u0.y, u0.z); s.a1 = make_float3(u0.w, u1.x, u1.y);
+        s.n2 = make_float3(w0.x, w0.y, w0.z); s.a2 = make_float3(w0.w, w1.x, w1.y);
+    }
+    s.nx = s.b0 * s.n0.x + s.b1 * s.n1.x + s.b2 * s.n2.x;
+    s.ny = s.b0 * s.n0.y + s.b1 * s.n1.y + s.b2 * s.n2.y;
+    s.nz = s.b0 * s.n0.z + s.b1 * s.n1.z + s.b2 * s.n2.z;
+    s.ar = s.b0 * s.a0.x + s.b1 * s.a1.x + s.b2 * s.a2.x;
+    s.ag = s.b0 * s.a0.y + s.b1 * s.a1.y + s.b2 * s.a2.y;
+    s.ab = s.b0 * s.a0.z + s.b1 * s.a1.z + s.b2 * s.a2.z;
+    s.len = fsqrt(s.nx * s.nx + s.ny * s.ny + s.nz * s.nz);
+    float inv = frcp(fmaxf(s.len, 1e-12f));                  // F.normalize(p=2, dim=3), default eps (:273)
+    s.hx = s.nx * inv; s.hy = s.ny * inv; s.hz = s.nz * inv;
+    s.rad = sh9c(shc, s.hx, s.hy, s.hz);
+}
+
+// shade_eval with the six attr8 words already loaded
+__device__ __forceinline__ void shade_eval_attr(float u, float v, const float4 q0, const float4 q1, const float4 u0, const float4 u1,
+                                                const float4 w0, const float4 w1, const float* __restrict__ shc, PixShade& s)
+{
+    s.b0 = u; s.b1 = v; s.b2 = 1.0f - u - v;
+    s.n0 = make_float3(q0.x, q0.y, q0.z); s.a0 = make_float3(q0.w, q1.x, q1.y);
+    s.n1 = make_float3(u0.x, u0.y, u0.z); s.a1 = make_float3(u0.w, u1.x, u1.y);
+    s.n2 = make_float3(w0.x, w0.y, w0.z); s.a2 = make_float3(w0.w, w1.x, w1.y);
+    s.nx = s.b0 * s.n0.x + s.b1 * s.n1.x + s.b2 * s.n2.x;
+    s.ny = s.b0 * s.n0.y + s.b1 * s.n1.y + s.b2 * s.n2.y;
+    s.nz = s.b0 * s.n0.z + s.b1 * s.n1.z + s.b2 * s.n2.z;
+    s.ar = s.b0 * s.a0.x + s.b1 * s.a1.x + s.b2 * s.a2.x;
+    s.ag = s.b0 * s.a0.y + s.b1 * s.a1.y + s.b2 * s.a2.y;
+    s.ab = s.b0 * s.a0.z + s.b1 * s.a1.z + s.b2 * s.a2.z;
+    s.len = fsqrt(s.nx * s.nx + s.ny * s.ny + s.nz * s.nz);
+    float inv = frcp(fmaxf(s.len, 1e-12f));                  // F.normalize(p=2, dim=3), default eps (:273)
+    s.hx = s.nx * inv; s.hy = s.ny * inv; s.hz = s.nz * inv;
+    s.rad = sh9c(shc, s.hx, s.hy, s.hz);
+}
+
+// what the fused stage-2 step adds to the rasterizer's passes (all null for the stand-alone dr.rasterize path)
+struct RasterFused {
+    int4* cov16; int* stamp; unsigned char* own8;             // coverage entries, step counter, owner marks (face-parallel backward)
+    float4* bwd16; const float* mask;                         // per covered pixel (u, v, owner, flags)
+    const float4* attr8; const float* sh;                     // forward shading inputs
+    float4* shaded; float4* aa_init; float* part_cnt;         // forward shading outputs + per-workgroup valid-pixel counts
+    int* rearm2;                                              // two list cursors the resolve pass zeroes for the next kernel
+};
+
+}  // namespace fmhr
