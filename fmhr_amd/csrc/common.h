@@ -134,6 +134,8 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+struct alignas(4) F4U { float x, y, z, w; };     // a 16-B load from a dword-aligned address (global loads need no more)
+
 // keep a loaded 16-B word whole and its load where it was written: without this the compiler splits a float4 load whose
 // components are used at different times into several requests and sinks part of it below the first branch (an extra dependent
 // round trip); the per-pixel kernels are bound by the NUMBER of vector-memory requests

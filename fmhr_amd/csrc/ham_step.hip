@@ -41,7 +41,7 @@ int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, 
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
-int shade_finish_impl(long long, const int*, const int*, const unsigned long long*, float*, float*, const float*, int, int*,
+int shade_finish_impl(long long, const int*, const int*, float*, float*, const float*, int, int*,
                       float*, hipStream_t);
 int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
@@ -52,7 +52,7 @@ int finish_losses_impl(float*, const float*, const float*, const float*, int, co
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, cov_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
         g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, cnt_part, total;
 };
 
@@ -82,7 +82,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.act = take(off, (nP + 63) / 64);
     L.vmnz = take(off, (nP + 63) / 64);
     L.act_list = take(off, ((nP + 63) / 64) * 4);
-    L.cov_list = take(off, ((nP + 63) / 64) * 4);
+    L.fill_list = take(off, ((nP + 63) / 64) * 4);
     L.act_count = take(off, 16);
     L.cov16 = take(off, (size_t)d->n * d->F * 16); // coverage entries [n, F]: candidate-pixel mask, box origin, stamp | box width
     L.own8 = take(off, (size_t)d->n * d->F);      // per (view, face): low byte of the last step in which it owned a pixel
@@ -241,8 +241,8 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
         TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, (int*)(w + L.act_list),
-                                 (int*)(w + L.act_count), (int*)(w + L.cov_list), st));
-        TRY(shade_finish_impl(nP, (const int*)(w + L.act_list), (const int*)(w + L.act_count), covw, (float*)(w + L.shaded),
+                                 (int*)(w + L.act_count), (int*)(w + L.fill_list), st));
+        TRY(shade_finish_impl(nP, (const int*)(w + L.fill_list), (const int*)(w + L.act_count) + 1, (float*)(w + L.shaded),
                               (float*)(w + L.aa), (const float*)(w + L.cnt_part), (int)((nP + 255) / 256), n_valid_local,
                               (float*)(w + L.n_valid_f), st));
     }

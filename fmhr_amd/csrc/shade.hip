@@ -56,16 +56,16 @@ constexpr int kActBlock = 1024;   // few, fat workgroups: the list cursors are s
 __global__ void __launch_bounds__(kActBlock)
 k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
                   unsigned char* __restrict__ act, int* __restrict__ act_list, int* __restrict__ act_count,
-                  int* __restrict__ cov_list)
+                  int* __restrict__ fill_list)
 {
-    // act_count[0] = number of active segments (act_list), act_count[1] = number of COVERED segments (cov_list); both cursors
+    // act_count[0] = number of active segments (act_list), act_count[1] = number of active segments WITHOUT coverage (fill_list); both cursors
     // advance with ONE 64-bit atomic per workgroup (low word = active, high word = covered)
     constexpr int kWaves = kActBlock / 64;
     __shared__ int wcnt[kWaves], ccnt[kWaves];
     __shared__ int base, cbase;
     long long seg = (long long)blockIdx.x * kActBlock + threadIdx.x;
     bool a = (seg < nSeg) && segment_is_active(covw, vmnz, nSeg, W, seg, act);
-    bool cv = a && covw[seg] != 0ull;
+    bool cv = a && covw[seg] == 0ull;                                // active without coverage: needs its zeros (k_fill_uncovered)
     unsigned long long bal = __ballot(a), cbal = __ballot(cv);
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { wcnt[wv] = __popcll(bal); ccnt[wv] = __popcll(cbal); }
@@ -86,7 +86,7 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
     if (cv) {
         int off = cbase + __popcll(cbal & ((1ull << lane) - 1ull));
         for (int i = 0; i < wv; i++) off += ccnt[i];
-        cov_list[off] = (int)seg;
+        fill_list[off] = (int)seg;
     }
 }
 
@@ -114,14 +114,13 @@ k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __re
 // pixel of a segment that received fragments.  Active segments WITHOUT coverage (neighbours of covered ones, valid_mask-only
 // ones) get their zeros here.
 __global__ void __launch_bounds__(kBlock)
-k_fill_uncovered(long long N, const int* __restrict__ act_list, const int* __restrict__ act_count,
-                 const unsigned long long* __restrict__ covw, float4* __restrict__ shaded, float4* __restrict__ aa_init)
+k_fill_uncovered(long long N, const int* __restrict__ fill_list, const int* __restrict__ fill_count,
+                 float4* __restrict__ shaded, float4* __restrict__ aa_init)
 {
-    const int count = *act_count, lane = threadIdx.x & 63;
+    const int count = *fill_count, lane = threadIdx.x & 63;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
-        const long long seg = act_list[i];
-        if (covw[seg] != 0ull) continue;
+        const long long seg = fill_list[i];
         const long long gid = (seg << 6) + lane;
         if (gid < N) { shaded[gid] = z; aa_init[gid] = z; }
     }
@@ -503,11 +502,11 @@ int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char
 }
 
 int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
-                         int* act_list, int* act_count, int* cov_list, hipStream_t st)
+                         int* act_list, int* act_count, int* fill_list, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     long long nSeg = (N + 63) >> 6;
-    k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, cov_list);
+    k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, fill_list);
     FMHR_CHECK_LAUNCH("k_active_segments");
     return FMHR_OK;
 }
@@ -521,11 +520,11 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
     return FMHR_OK;
 }
 
-int shade_finish_impl(long long N, const int* act_list, const int* act_count, const unsigned long long* covw, float* shaded,
+int shade_finish_impl(long long N, const int* fill_list, const int* fill_count, float* shaded,
                       float* aa_init, const float* part_cnt, int nb, int* n_valid, float* n_valid_f, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_fill_uncovered<<<512, kBlock, 0, st>>>(N, act_list, act_count, covw, (float4*)shaded, (float4*)aa_init);
+    k_fill_uncovered<<<1024, kBlock, 0, st>>>(N, fill_list, fill_count, (float4*)shaded, (float4*)aa_init);
     FMHR_CHECK_LAUNCH("k_fill_uncovered");
     k_reduce_count<<<1, 1024, 0, st>>>(part_cnt, nb, n_valid, n_valid_f);
     FMHR_CHECK_LAUNCH("k_reduce_count");
