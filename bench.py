@@ -39,8 +39,9 @@ def alg_bytes(slot, n, P, V, F, nnz):
     per_view = {
         "geometry": 28 * V,                                   # transform fwd: 12V r + 16V w
         "raster_tris": 16 * V + 12 * F,                       # rasterize fwd reads
-        "raster_resolve": 16 * P,                             # rasterize fwd write
-        "shade_fwd": 92 * P + 28 * V + 12 * F,                # interpolate C=7 fwd + shade fwd
+        # the resolve pass also does the forward shading: rasterize fwd write + interpolate C=7 fwd + shade fwd
+        # (the "shade_fwd" launch group is only the segment lists, the zero fill and the valid-pixel count: no algorithmic bytes)
+        "raster_resolve": 16 * P + 92 * P + 28 * V + 12 * F,
         "aa_fwd": 64 * P + 32 * V + 24 * F,                   # antialias mask + image fwd
         "loss_pix": 88 * P,                                   # losses fwd + bwd
         "aa_bwd": 80 * P + 32 * V,                            # antialias bwd
