@@ -382,20 +382,77 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
                          outA, outB, items, alphas, counter, cap, nullptr, nullptr);
 }
 
-// fused step: persistent waves over the compacted list of active 64-pixel segments, rgba colour, in-place items
+// fused step: persistent waves over the compacted list of active 64-pixel segments, rgba colour, in-place items.
+// Per segment: the coverage words of the own / next / lower segments are wave-uniform loads; then every lane issues its two
+// rast loads (own, lower) together — the right neighbour's fragment is the next lane's register — and only pairs with different
+// triangle ids go on (silhouette byte first).  Colours are read as 16-B words only by the pairs that blend.
+__device__ __forceinline__ unsigned long long covw_or0(const unsigned long long* __restrict__ covw, long long w, long long nSeg)
+{
+    return (w >= 0 && w < nSeg) ? covw[w] : 0ull;
+}
+
 __global__ void __launch_bounds__(kBlock)
-k_aa_fwd_list(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
+k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
               const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
               const int* __restrict__ act_list, const int* __restrict__ act_count, const unsigned long long* __restrict__ covw,
               int n, int V, int F, int H, int W, float* __restrict__ out, unsigned char* __restrict__ px_code,
               float* __restrict__ px_alpha)
 {
     const int count = *act_count, lane = threadIdx.x & 63;
-    const long long N = (long long)n * H * W;
+    const long long P = (long long)H * W, N = (long long)n * P, nSeg = (N + 63) >> 6;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
-        const long long gid = ((long long)act_list[i] << 6) + lane;
-        aa_fwd_pixel<4, 0>(gid, gid < N, color, nullptr, rast, pos, tri, opp, silh, covw, n, V, F, H, W, 4, out, nullptr, nullptr,
-                           nullptr, nullptr, 0, px_code, px_alpha);
+        const long long seg = act_list[i];
+        const long long gid = (seg << 6) + lane;
+        const bool live = gid < N;
+        const long long gidD = gid + W;
+        const long long sD = ((seg << 6) + W) >> 6;
+        const unsigned long long w0 = covw[seg], wR = covw_or0(covw, seg + 1, nSeg), wD0 = covw_or0(covw, sD, nSeg),
+                                 wD1 = covw_or0(covw, sD + 1, nSeg);
+        int b = 0, px = 0, py = 0;
+        if (live) {
+            int rem;
+            b = fast_divmod(gid, (int)P, rem);
+            py = fast_divmod(rem, W, px);
+        }
+        const bool c0 = live && ((w0 >> lane) & 1ull);
+        const bool inR = live && px + 1 < W, inD = live && py + 1 < H;
+        const bool cD = inD && ((((gidD >> 6) == sD ? wD0 : wD1) >> (gidD & 63)) & 1ull);
+        const bool cR63 = inR && (wR & 1ull);                       // only lane 63 looks into the next segment
+        // in sparse mode rast is only defined on covered pixels: an uncovered pixel is the all-zero fragment
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), rD = r0, rR = r0;
+        if (c0) r0 = rast[gid];
+        if (cD) rD = rast[gidD];
+        if (lane == 63 && cR63) rR = rast[gid + 1];
+        pin(r0); pin(rD); pin(rR);
+        {
+            const float z = __shfl_down(r0.z, 1), w = __shfl_down(r0.w, 1);
+            if (lane < 63) { rR.z = z; rR.w = w; }
+        }
+        const float* posv = pos + (size_t)b * V * 4;
+        const unsigned char* sv = silh + (size_t)b * F;
+        int codes[2];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const float4 r1 = d ? rD : rR;
+            const long long gid1 = d ? gidD : gid + 1;
+            float alpha = 0.f;
+            int code = 0;
+            if ((d ? inD : inR) && r1.w != r0.w)
+                code = aa_analyse(posv, tri, opp, sv, V, F, H, W, px, py, d, r0.z, r0.w, r1.z, r1.w, alpha);
+            if (code != 0) {
+                const long long tgt = (alpha > 0.f) ? gid : gid1;
+                const float4 ca = color[gid], cb = color[gid1];
+                const float dc[4] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z, cb.w - ca.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (dc[c] != 0.f) atomicAdd(out + tgt * 4 + c, alpha * dc[c]);
+            }
+            // the work item stays in place (2 slots per pixel), no queue: a global queue costs one RETURNING same-address atomic
+            // per wave with an item, and ~30k of those serialise to ~0.25 ms per step
+            codes[d] = code;
+            if (code != 0) px_alpha[gid * 2 + d] = alpha;
+        }
+        if (live) reinterpret_cast<uchar2*>(px_code)[gid] = make_uchar2((unsigned char)codes[0], (unsigned char)codes[1]);
     }
 }
 
@@ -541,7 +598,7 @@ int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const i
                 const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw, int n,
                 int V, int F, int H, int W, float* out, unsigned char* px_code, float* px_alpha, hipStream_t st)
 {
-    k_aa_fwd_list<<<2048, kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
+    k_aa_fwd_list<<<2048, kBlock, 0, st>>>((const float4*)color, (const float4*)rast, pos, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
                                            out, px_code, px_alpha);
     FMHR_CHECK_LAUNCH("k_aa_fwd_list");
     return FMHR_OK;

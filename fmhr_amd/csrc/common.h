@@ -134,6 +134,7 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+struct alignas(4) F3U { float x, y, z; };
 struct alignas(4) F4U { float x, y, z, w; };     // a 16-B load from a dword-aligned address (global loads need no more)
 
 // keep a loaded 16-B word whole and its load where it was written: without this the compiler splits a float4 load whose

@@ -43,7 +43,7 @@ int transform_fwd_impl(const float*, const float*, const float*, int, int, float
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
 int shade_finish_impl(long long, const int*, const int*, float*, float*, const float*, int, int*,
                       float*, hipStream_t);
-int loss_pix_impl(const float*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
+int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
                   const int*, const int32_t*, const float*, int, int, int, int, int, float*, hipStream_t);
@@ -283,7 +283,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
         // losses on the antialiased rgba + their per-pixel gradients (written twice: g_aa and the AA-backward target)
-        TRY(loss_pix_impl((float*)(w + L.shaded), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
+        TRY(loss_pix_impl((const unsigned long long*)(w + L.covw), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
                           (const int*)(w + L.act_list), (const int*)(w + L.act_count), n_valid_global,
                           wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa), (float*)(w + L.g_shaded),
                           (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, losses, st));

@@ -131,7 +131,7 @@ k_fill_uncovered(long long N, const int* __restrict__ fill_list, const int* __re
 // exactly 0 to both.  g [.,4] = d loss / d antialiased rgba, written twice (g_aa = what the antialias backward reads as dy,
 // g_shaded = its accumulation target).
 __global__ void __launch_bounds__(kBlock)
-k_loss_pix(const float4* __restrict__ shaded, const float4* __restrict__ aa, const float* __restrict__ img,
+k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict__ aa, const float* __restrict__ img,
            const float* __restrict__ mask, const float* __restrict__ valid_mask, long long N,
            const int* __restrict__ act_list, const int* __restrict__ act_count, const float* __restrict__ n_valid_global,
            float w_sfs, float w_mask, float mse_den, float4* __restrict__ g_aa, float4* __restrict__ g_shaded,
@@ -144,19 +144,23 @@ k_loss_pix(const float4* __restrict__ shaded, const float4* __restrict__ aa, con
     float k1 = (den > 0.f) ? w_sfs / den : 0.f;
     float k2 = w_mask / mse_den;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
-        const long long gid = ((long long)act_list[i] << 6) + lane;
+        const long long seg = act_list[i];
+        const long long gid = (seg << 6) + lane;
         if (gid >= N) continue;
+        // every request of the iteration up front: aa (16 B), the image pixel (12 B, one request), the two masks
         float4 a = aa[gid];
-        float cov = shaded[gid].w;                            // != 0 exactly where the pixel is covered
+        const F3U im = *reinterpret_cast<const F3U*>(img + gid * 3);
+        const float mk = mask[gid], vm = valid_mask[gid];
+        const bool cov = (covw[seg] >> lane) & 1ull;          // covered pixel (the segment's coverage word)
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mask[gid] > 0.f && cov != 0.f) {
-            float d0 = a.x - img[gid * 3], d1 = a.y - img[gid * 3 + 1], d2 = a.z - img[gid * 3 + 2];
+        if (mk > 0.f && cov) {
+            float d0 = a.x - im.x, d1 = a.y - im.y, d2 = a.z - im.z;
             l1 += fabsf(d0) + fabsf(d1) + fabsf(d2);
             g.x = (d0 > 0.f) ? k1 : ((d0 < 0.f) ? -k1 : 0.f);
             g.y = (d1 > 0.f) ? k1 : ((d1 < 0.f) ? -k1 : 0.f);
             g.z = (d2 > 0.f) ? k1 : ((d2 < 0.f) ? -k1 : 0.f);
         }
-        float dm = a.w - valid_mask[gid];
+        float dm = a.w - vm;
         l2 += dm * dm;
         g.w = 2.0f * dm * k2;
         g_aa[gid] = g;
@@ -531,12 +535,12 @@ int shade_finish_impl(long long N, const int* fill_list, const int* fill_count, 
     return FMHR_OK;
 }
 
-int loss_pix_impl(const float* shaded, const float* aa, const float* img, const float* mask, const float* valid_mask,
+int loss_pix_impl(const unsigned long long* covw, const float* aa, const float* img, const float* mask, const float* valid_mask,
                   long long N, const int* act_list, const int* act_count, const float* n_valid_global, float w_sfs, float w_mask,
                   float mse_den, float* g_aa, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>((const float4*)shaded, (const float4*)aa, img, mask, valid_mask, N, act_list, act_count,
+    k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>(covw, (const float4*)aa, img, mask, valid_mask, N, act_list, act_count,
                                                   n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_aa, (float4*)g_shaded, part_l1,
                                                   part_l2, losses);
     FMHR_CHECK_LAUNCH("k_loss_pix");
