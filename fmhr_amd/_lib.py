@@ -54,6 +54,8 @@ SIGNATURES = {
     "fmhr_ncc_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "fmhr_ncc_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P]),
     "fmhr_adam_step": (c_int, [P, P, P, P, ctypes.c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
+    "fmhr_adam_step2": (c_int, [P, P, P, P, ctypes.c_longlong, c_float, c_float, c_float, c_float, c_int,
+                                P, P, P, P, ctypes.c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
     "fmhr_ham_workspace_bytes": (c_size_t, [ctypes.POINTER(HamDims)]),
     "fmhr_ham_workspace_offset": (ctypes.c_longlong, [ctypes.POINTER(HamDims), ctypes.c_char_p]),
     "fmhr_ham_workspace_views": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, ctypes.POINTER(HamViews)]),

@@ -15,7 +15,11 @@ struct MeshTailArgs {
     float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a;
     float* loss_part;
 };
-int mesh_tail_impl(const MeshTailArgs&, float*, float*, hipStream_t);
+struct FinishArgs {
+    float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
+    const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
+};
+int mesh_tail_impl(const MeshTailArgs&, float*, float*, const FinishArgs&, hipStream_t);
 int mesh_tail_blocks(int V);
 // raster.hip / antialias.hip / mesh.hip / shade.hip
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
@@ -24,7 +28,7 @@ int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*
                        void*, unsigned char*, unsigned long long*, const RasterFused*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, int*,
-                         hipStream_t);
+                         const float*, int, int*, float*, hipStream_t);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
                 const int*, const unsigned long long*, int, int, int, int, int, float*, unsigned char*, float*, hipStream_t);
@@ -41,14 +45,12 @@ int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, 
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
-int shade_finish_impl(long long, const int*, const int*, float*, float*, const float*, int, int*,
-                      float*, hipStream_t);
+int fill_uncovered_impl(long long, const int*, const int*, float*, float*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
                   const int*, const int32_t*, const float*, int, int, int, int, int, float*, hipStream_t);
 int face_bwd_groups(int n);
-int finish_losses_impl(float*, const float*, const float*, const float*, int, const float*, int, float, float, float, hipStream_t);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
@@ -241,10 +243,10 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
         TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, (int*)(w + L.act_list),
-                                 (int*)(w + L.act_count), (int*)(w + L.fill_list), st));
-        TRY(shade_finish_impl(nP, (const int*)(w + L.fill_list), (const int*)(w + L.act_count) + 1, (float*)(w + L.shaded),
-                              (float*)(w + L.aa), (const float*)(w + L.cnt_part), (int)((nP + 255) / 256), n_valid_local,
-                              (float*)(w + L.n_valid_f), st));
+                                 (int*)(w + L.act_count), (int*)(w + L.fill_list), (const float*)(w + L.cnt_part),
+                                 (int)((nP + 255) / 256), n_valid_local, (float*)(w + L.n_valid_f), st));
+        TRY(fill_uncovered_impl(nP, (const int*)(w + L.fill_list), (const int*)(w + L.act_count) + 1, (float*)(w + L.shaded),
+                                (float*)(w + L.aa), st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
@@ -315,9 +317,12 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         A.delta_w = wt->delta / (float)d->V; A.edge_mean = wt->edge_length_mean; A.rg = rg;
         A.gs = (float*)(w + L.gtmp); A.rowg_v = (float*)(w + L.rowg); A.rowg_a = (float*)(w + L.lx_a);
         A.gacc_v = gvert; A.gacc_a = (float*)(w + L.lx_v); A.loss_part = (float*)(w + L.tail_part);
-        TRY(mesh_tail_impl(A, gdelta, galbedo, st));
+        // one extra workgroup of the second tail kernel turns the per-workgroup partials into the loss vector
+        FinishArgs fin;
+        fin.losses = losses; fin.n_valid = n_valid_global; fin.part_l1 = (const float*)(w + L.partials) + nB;
+        fin.part_l2 = (const float*)(w + L.partials) + 2 * nB; fin.nb = (int)nB; fin.tail_part = (const float*)(w + L.tail_part);
+        fin.tail_nb = mesh_tail_blocks(d->V); fin.w_sfs = wt->sfs; fin.w_mask = wt->mask; fin.mse_den = wt->mse_denominator;
+        TRY(mesh_tail_impl(A, gdelta, galbedo, fin, st));
     }
-    TRY(finish_losses_impl(losses, n_valid_global, (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, (int)nB,
-                           (const float*)(w + L.tail_part), mesh_tail_blocks(d->V), wt->sfs, wt->mask, wt->mse_denominator, st));
     return FMHR_OK;
 }

@@ -365,6 +365,29 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
     p[i] = p[i] - step_size * (mi / denom);
 }
 
+struct AdamTensor {
+    float* p; const float* g; float* m; float* v; long long n;
+    float beta1, beta2, eps, step_size, bc2_sqrt;
+};
+
+// two parameters in one launch (the HAM loops step exactly two: delta + albedo, or albedo + SH): each launch is ~4.7 us of
+// fixed cost against ~0.6 MB of work
+__global__ void __launch_bounds__(kBlock) k_adam2(const AdamTensor A, const AdamTensor B)
+{
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const bool second = i >= A.n;
+    const AdamTensor& T = second ? B : A;
+    if (second) i -= A.n;
+    if (i >= T.n) return;
+    float gi = T.g[i];
+    float mi = T.m[i];
+    mi = mi + (gi - mi) * (1.0f - T.beta1);
+    float vi = T.v[i] * T.beta2 + (1.0f - T.beta2) * gi * gi;
+    T.m[i] = mi; T.v[i] = vi;
+    float denom = sqrtf(vi) / T.bc2_sqrt + T.eps;
+    T.p[i] = T.p[i] - T.step_size * (mi / denom);
+}
+
 // ------------------------------------------------------------------------------------------------ CSR-gather forms (fused step)
 // kSubLanes lanes per vertex walk its incident face corners (vf CSR, entry = 3*face + corner): no float atomics, deterministic
 // summation order.  The face-scatter forms above took ~40 us each on atomics into a 0.6 MB array; these take a few us.
@@ -611,13 +634,52 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
     s = block_sum(l_delta, sm); if (threadIdx.x == 0) A.loss_part[3 * gridDim.x + blockIdx.x] = s * A.delta_w;
 }
 
+// the step's loss vector from the per-workgroup partials of k_loss_pix and k_mesh_tail_a (run by one extra workgroup of
+// k_mesh_tail_b: saves a ~7 us launch); deterministic summation order
+struct FinishArgs {
+    float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
+    const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
+};
+
+__device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* sm4)
+{
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                 // regulariser sums of k_mesh_tail_a (already weighted): lap, albedo, edge, delta
+        float t = 0.f;
+        for (int j = threadIdx.x; j < A.tail_nb; j += kBlock) t += A.tail_part[(size_t)k * A.tail_nb + j];
+        r[k] = block_sum(t, sm4);
+    }
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    int i = threadIdx.x;
+    for (; i + kBlock < A.nb; i += 2 * kBlock) { a1 += A.part_l1[i]; a2 += A.part_l2[i]; b1 += A.part_l1[i + kBlock]; b2 += A.part_l2[i + kBlock]; }
+    for (; i < A.nb; i += kBlock) { a1 += A.part_l1[i]; a2 += A.part_l2[i]; }
+    float s1 = block_sum(a1 + b1, sm4);
+    float s2 = block_sum(a2 + b2, sm4);
+    if (threadIdx.x == 0) {
+        float* losses = A.losses;
+        float den = 3.0f * A.n_valid[0];
+        losses[FMHR_LOSS_SFS] = (den > 0.f) ? s1 * (A.w_sfs / den) : 0.f;
+        losses[FMHR_LOSS_MASK] = s2 * (A.w_mask / A.mse_den);
+        losses[FMHR_LOSS_LAP] = r[0]; losses[FMHR_LOSS_ALBEDO] = r[1]; losses[FMHR_LOSS_EDGE] = r[2]; losses[FMHR_LOSS_DELTA] = r[3];
+        losses[FMHR_LOSS_TOTAL] = losses[FMHR_LOSS_SFS] + losses[FMHR_LOSS_LAP] + losses[FMHR_LOSS_ALBEDO] +
+                                  losses[FMHR_LOSS_MASK] + losses[FMHR_LOSS_DELTA] + losses[FMHR_LOSS_EDGE];
+        losses[FMHR_LOSS_NVALID] = A.n_valid[0];
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_mesh_tail_b(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
               const int32_t* __restrict__ vf_idx, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
               const float* __restrict__ gs, const float* __restrict__ rowg_v, const float* __restrict__ rowg_a,
               const float* __restrict__ gacc_v, const float* __restrict__ gacc_a, int V, float* __restrict__ gdelta,
-              float* __restrict__ galbedo)
+              float* __restrict__ galbedo, const FinishArgs fin)
 {
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ float sm4[4];
+        finish_losses_block(fin, sm4);
+        return;
+    }
     const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
     const bool live = v < V;
     const int vv = live ? v : 0;
@@ -661,13 +723,13 @@ k_mesh_tail_b(const float* __restrict__ verts, const int32_t* __restrict__ tri, 
 
 int mesh_tail_blocks(int V) { return cdiv((long long)V * kSubLanes, kBlock); }
 
-int mesh_tail_impl(const MeshTailArgs& A, float* gdelta, float* galbedo, hipStream_t st)
+int mesh_tail_impl(const MeshTailArgs& A, float* gdelta, float* galbedo, const FinishArgs& fin, hipStream_t st)
 {
     if (A.V == 0) return FMHR_OK;
     k_mesh_tail_a<<<cdiv((long long)A.V * kSubLanes, kBlock), kBlock, 0, st>>>(A);
     FMHR_CHECK_LAUNCH("k_mesh_tail_a");
-    k_mesh_tail_b<<<cdiv((long long)A.V * kSubLanes, kBlock), kBlock, 0, st>>>(A.verts, A.tri, A.vf_ptr, A.vf_idx, A.row_ptr, A.col, A.gs, A.rowg_v, A.rowg_a,
-                                                       A.gacc_v, A.gacc_a, A.V, gdelta, galbedo);
+    k_mesh_tail_b<<<cdiv((long long)A.V * kSubLanes, kBlock) + 1, kBlock, 0, st>>>(A.verts, A.tri, A.vf_ptr, A.vf_idx, A.row_ptr, A.col, A.gs, A.rowg_v, A.rowg_a,
+                                                       A.gacc_v, A.gacc_a, A.V, gdelta, galbedo, fin);
     FMHR_CHECK_LAUNCH("k_mesh_tail_b");
     return FMHR_OK;
 }
@@ -821,6 +883,33 @@ extern "C" int fmhr_adam_step(float* param, const float* grad, float* exp_avg, f
     k_adam<<<cdiv(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps,
                                                                (float)((double)lr / bc1), (float)sqrt(bc2));
     FMHR_CHECK_LAUNCH("k_adam");
+    return FMHR_OK;
+}
+
+static int adam_tensor(AdamTensor& T, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                       float beta1, float beta2, float eps, int step)
+{
+    FMHR_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad n=%lld / step=%d", n, step);
+    FMHR_CHECK_ARG(n == 0 || (param && grad && exp_avg && exp_avg_sq), "adam_step: null pointer");
+    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    T.p = param; T.g = grad; T.m = exp_avg; T.v = exp_avg_sq; T.n = n;
+    T.beta1 = beta1; T.beta2 = beta2; T.eps = eps; T.step_size = (float)((double)lr / bc1); T.bc2_sqrt = (float)sqrt(bc2);
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_adam_step2(float* param_a, const float* grad_a, float* exp_avg_a, float* exp_avg_sq_a, long long n_a,
+                               float lr_a, float beta1_a, float beta2_a, float eps_a, int step_a, float* param_b,
+                               const float* grad_b, float* exp_avg_b, float* exp_avg_sq_b, long long n_b, float lr_b,
+                               float beta1_b, float beta2_b, float eps_b, int step_b, void* stream)
+{
+    AdamTensor A, B;
+    int rc = adam_tensor(A, param_a, grad_a, exp_avg_a, exp_avg_sq_a, n_a, lr_a, beta1_a, beta2_a, eps_a, step_a);
+    if (rc) return rc;
+    rc = adam_tensor(B, param_b, grad_b, exp_avg_b, exp_avg_sq_b, n_b, lr_b, beta1_b, beta2_b, eps_b, step_b);
+    if (rc) return rc;
+    if (n_a + n_b == 0) return FMHR_OK;
+    k_adam2<<<cdiv(n_a + n_b, kBlock), kBlock, 0, (hipStream_t)stream>>>(A, B);
+    FMHR_CHECK_LAUNCH("k_adam2");
     return FMHR_OK;
 }
 

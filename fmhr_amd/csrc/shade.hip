@@ -49,6 +49,32 @@ __device__ __forceinline__ bool segment_is_active(const unsigned long long* __re
     return any != 0ull;
 }
 
+// single-workgroup deterministic sums of per-block partials
+__device__ __forceinline__ float block1024_sum(float v, float* sm16)
+{
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm16[wv] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 16; i++) r += sm16[i];
+    __syncthreads();
+    return r;
+}
+
+// the valid-pixel count: sum of the resolve pass's per-workgroup counts (run by the extra last workgroup of k_active_segments)
+__device__ __forceinline__ void reduce_count_block(const float* __restrict__ part, int nb, int* __restrict__ n_valid,
+                                                   float* __restrict__ n_valid_f, float* sm16)
+{
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;     // independent chains: the loads overlap
+    int i = threadIdx.x;
+    for (; i + 3072 < nb; i += 4096) { acc0 += part[i]; acc1 += part[i + 1024]; acc2 += part[i + 2048]; acc3 += part[i + 3072]; }
+    for (; i < nb; i += 1024) acc0 += part[i];
+    float r = block1024_sum((acc0 + acc1) + (acc2 + acc3), sm16);
+    if (threadIdx.x == 0) { n_valid[0] = (int)(r + 0.5f); n_valid_f[0] = (float)(int)(r + 0.5f); }
+}
+
 // one lane per segment; the active ones are also compacted into act_list (order arbitrary) so that the per-pixel kernels
 // run as persistent loops over exactly the active segments: 2/3 of a frame's 197k waves would only be launched to exit
 constexpr int kActBlock = 1024;   // few, fat workgroups: the list cursors are same-address atomics (~10 ns each, serialised)
@@ -56,8 +82,15 @@ constexpr int kActBlock = 1024;   // few, fat workgroups: the list cursors are s
 __global__ void __launch_bounds__(kActBlock)
 k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
                   unsigned char* __restrict__ act, int* __restrict__ act_list, int* __restrict__ act_count,
-                  int* __restrict__ fill_list)
+                  int* __restrict__ fill_list, const float* __restrict__ part_cnt, int nb_cnt, int* __restrict__ n_valid,
+                  float* __restrict__ n_valid_f)
 {
+    static_assert(kActBlock == 1024, "reduce_count_block is written for 1024 threads");
+    if (blockIdx.x == gridDim.x - 1) {                               // one extra workgroup: saves a ~5 us launch
+        __shared__ float sm16[16];
+        reduce_count_block(part_cnt, nb_cnt, n_valid, n_valid_f, sm16);
+        return;
+    }
     // act_count[0] = number of active segments (act_list), act_count[1] = number of active segments WITHOUT coverage (fill_list); both cursors
     // advance with ONE 64-bit atomic per workgroup (low word = active, high word = covered)
     constexpr int kWaves = kActBlock / 64;
@@ -170,31 +203,6 @@ k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict
     float s2 = block_sum(l2, sm);
     if (threadIdx.x == 0) { part_l1[blockIdx.x] = s1; part_l2[blockIdx.x] = s2; }
     if (blockIdx.x == 0 && threadIdx.x < 8) losses[threadIdx.x] = 0.f;      // the regulariser kernels accumulate into these later
-}
-
-// single-workgroup deterministic sums of per-block partials
-__device__ __forceinline__ float block1024_sum(float v, float* sm16)
-{
-    v = wave_sum(v);
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) sm16[wv] = v;
-    __syncthreads();
-    float r = 0.f;
-    if (threadIdx.x == 0)
-        for (int i = 0; i < 16; i++) r += sm16[i];
-    __syncthreads();
-    return r;
-}
-
-__global__ void __launch_bounds__(1024) k_reduce_count(const float* __restrict__ part, int nb, int* __restrict__ n_valid, float* __restrict__ n_valid_f)
-{
-    __shared__ float sm[16];
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;     // independent chains: the loads overlap
-    int i = threadIdx.x;
-    for (; i + 3072 < nb; i += 4096) { acc0 += part[i]; acc1 += part[i + 1024]; acc2 += part[i + 2048]; acc3 += part[i + 3072]; }
-    for (; i < nb; i += 1024) acc0 += part[i];
-    float r = block1024_sum((acc0 + acc1) + (acc2 + acc3), sm);
-    if (threadIdx.x == 0) { n_valid[0] = (int)(r + 0.5f); n_valid_f[0] = (float)(int)(r + 0.5f); }
 }
 
 constexpr int kGroup = 8;  // views summed inside one lane group of the face-parallel backward
@@ -465,38 +473,6 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     }
 }
 
-__global__ void __launch_bounds__(1024)
-k_finish_losses(float* losses, const float* n_valid, const float* __restrict__ part_l1, const float* __restrict__ part_l2, int nb,
-                const float* __restrict__ tail_part, int tail_nb, float w_sfs, float w_mask, float mse_den)
-{
-    __shared__ float sm[16];
-    float r[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {                 // regulariser sums of k_mesh_tail_a (already weighted): lap, albedo, edge, delta
-        float t = 0.f;
-        for (int j = threadIdx.x; j < tail_nb; j += 1024) t += tail_part[(size_t)k * tail_nb + j];
-        r[k] = block1024_sum(t, sm);
-    }
-    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f, d1 = 0.f, d2 = 0.f;
-    int i = threadIdx.x;
-    for (; i + 3072 < nb; i += 4096) {
-        a1 += part_l1[i]; a2 += part_l2[i]; b1 += part_l1[i + 1024]; b2 += part_l2[i + 1024];
-        c1 += part_l1[i + 2048]; c2 += part_l2[i + 2048]; d1 += part_l1[i + 3072]; d2 += part_l2[i + 3072];
-    }
-    for (; i < nb; i += 1024) { a1 += part_l1[i]; a2 += part_l2[i]; }
-    float s1 = block1024_sum((a1 + b1) + (c1 + d1), sm);
-    float s2 = block1024_sum((a2 + b2) + (c2 + d2), sm);
-    if (threadIdx.x == 0) {
-        float den = 3.0f * n_valid[0];
-        losses[FMHR_LOSS_SFS] = (den > 0.f) ? s1 * (w_sfs / den) : 0.f;
-        losses[FMHR_LOSS_MASK] = s2 * (w_mask / mse_den);
-        losses[FMHR_LOSS_LAP] = r[0]; losses[FMHR_LOSS_ALBEDO] = r[1]; losses[FMHR_LOSS_EDGE] = r[2]; losses[FMHR_LOSS_DELTA] = r[3];
-        losses[FMHR_LOSS_TOTAL] = losses[FMHR_LOSS_SFS] + losses[FMHR_LOSS_LAP] + losses[FMHR_LOSS_ALBEDO] +
-                                  losses[FMHR_LOSS_MASK] + losses[FMHR_LOSS_DELTA] + losses[FMHR_LOSS_EDGE];
-        losses[FMHR_LOSS_NVALID] = n_valid[0];
-    }
-}
-
 int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char* vmnz, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
@@ -506,11 +482,13 @@ int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char
 }
 
 int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
-                         int* act_list, int* act_count, int* fill_list, hipStream_t st)
+                         int* act_list, int* act_count, int* fill_list, const float* part_cnt, int nb_cnt, int* n_valid,
+                         float* n_valid_f, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     long long nSeg = (N + 63) >> 6;
-    k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, fill_list);
+    k_active_segments<<<cdiv(nSeg, kActBlock) + 1, kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, fill_list, part_cnt,
+                                                                       nb_cnt, n_valid, n_valid_f);
     FMHR_CHECK_LAUNCH("k_active_segments");
     return FMHR_OK;
 }
@@ -524,14 +502,11 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
     return FMHR_OK;
 }
 
-int shade_finish_impl(long long N, const int* fill_list, const int* fill_count, float* shaded,
-                      float* aa_init, const float* part_cnt, int nb, int* n_valid, float* n_valid_f, hipStream_t st)
+int fill_uncovered_impl(long long N, const int* fill_list, const int* fill_count, float* shaded, float* aa_init, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     k_fill_uncovered<<<1024, kBlock, 0, st>>>(N, fill_list, fill_count, (float4*)shaded, (float4*)aa_init);
     FMHR_CHECK_LAUNCH("k_fill_uncovered");
-    k_reduce_count<<<1, 1024, 0, st>>>(part_cnt, nb, n_valid, n_valid_f);
-    FMHR_CHECK_LAUNCH("k_reduce_count");
     return FMHR_OK;
 }
 
@@ -570,14 +545,6 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     }
 #undef FMHR_FACE_BWD
     FMHR_CHECK_LAUNCH("k_face_bwd");
-    return FMHR_OK;
-}
-
-int finish_losses_impl(float* losses, const float* n_valid, const float* part_l1, const float* part_l2, int nb,
-                       const float* tail_part, int tail_nb, float w_sfs, float w_mask, float mse_den, hipStream_t st)
-{
-    k_finish_losses<<<1, 1024, 0, st>>>(losses, n_valid, part_l1, part_l2, nb, tail_part, tail_nb, w_sfs, w_mask, mse_den);
-    FMHR_CHECK_LAUNCH("k_finish_losses");
     return FMHR_OK;
 }
 

@@ -29,6 +29,7 @@ class Adam:
 
     @torch.no_grad()
     def step(self):
+        todo = []
         for g in self.param_groups:
             for p in g['params']:
                 if p.grad is None or not p.requires_grad:
@@ -38,5 +39,16 @@ class Adam:
                     st = self.state[p] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
                 st['step'] += 1
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                call("fmhr_adam_step", ptr(p), ptr(grad), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), p.numel(), g['lr'],
-                     g['betas'][0], g['betas'][1], g['eps'], st['step'], stream_ptr(p.device))
+                todo.append((p, grad, st, g))
+
+        def args(t):
+            p, grad, st, g = t
+            return (ptr(p), ptr(grad), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), p.numel(), g['lr'], g['betas'][0], g['betas'][1],
+                    g['eps'], st['step'])
+
+        i = 0
+        while i + 1 < len(todo) and todo[i][0].device == todo[i + 1][0].device:      # pairs share one launch
+            call("fmhr_adam_step2", *args(todo[i]), *args(todo[i + 1]), stream_ptr(todo[i][0].device))
+            i += 2
+        for t in todo[i:]:
+            call("fmhr_adam_step", *args(t), stream_ptr(t[0].device))

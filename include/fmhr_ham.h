@@ -119,6 +119,11 @@ int fmhr_ncc_bwd(const float* ref, const float* src, const float* src_valid_mask
  * mesh_sfs_optim.py:244,310.  `step` is the 1-based step count; exp_avg / exp_avg_sq are the caller-owned state (zeros at start). */
 int fmhr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                    float beta1, float beta2, float eps, int step, void* stream);
+/* the same for two parameters in ONE launch (the HAM loops step exactly two per iteration) */
+int fmhr_adam_step2(float* param_a, const float* grad_a, float* exp_avg_a, float* exp_avg_sq_a, long long n_a, float lr_a,
+                    float beta1_a, float beta2_a, float eps_a, int step_a, float* param_b, const float* grad_b,
+                    float* exp_avg_b, float* exp_avg_sq_b, long long n_b, float lr_b, float beta1_b, float beta2_b,
+                    float eps_b, int step_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ fused stage-2 step
  * One full forward+backward of mesh_sfs_optim.py:253-308 for the n views this rank owns.  See fmhr_ham_forward() / fmhr_ham_backward() below. */
