@@ -18,6 +18,7 @@ struct MeshTailArgs {
 struct FinishArgs {
     float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
     const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
+    float reg_scale;
 };
 int mesh_tail_impl(const MeshTailArgs&, float*, float*, const FinishArgs&, hipStream_t);
 int mesh_tail_blocks(int V);
@@ -322,6 +323,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         fin.losses = losses; fin.n_valid = n_valid_global; fin.part_l1 = (const float*)(w + L.partials) + nB;
         fin.part_l2 = (const float*)(w + L.partials) + 2 * nB; fin.nb = (int)nB; fin.tail_part = (const float*)(w + L.tail_part);
         fin.tail_nb = mesh_tail_blocks(d->V); fin.w_sfs = wt->sfs; fin.w_mask = wt->mask; fin.mse_den = wt->mse_denominator;
+        fin.reg_scale = (rg != 0.f) ? 1.f : 0.f;
         TRY(mesh_tail_impl(A, gdelta, galbedo, fin, st));
     }
     return FMHR_OK;

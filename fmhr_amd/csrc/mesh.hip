@@ -639,6 +639,8 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
 struct FinishArgs {
     float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
     const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
+    float reg_scale;      // 1 on the rank that owns the view-independent terms (and the n_valid slot), 0 elsewhere: summing the loss
+                          // vectors of all ranks then gives the global values with no fix-up
 };
 
 __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* sm4)
@@ -661,10 +663,11 @@ __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* 
         float den = 3.0f * A.n_valid[0];
         losses[FMHR_LOSS_SFS] = (den > 0.f) ? s1 * (A.w_sfs / den) : 0.f;
         losses[FMHR_LOSS_MASK] = s2 * (A.w_mask / A.mse_den);
-        losses[FMHR_LOSS_LAP] = r[0]; losses[FMHR_LOSS_ALBEDO] = r[1]; losses[FMHR_LOSS_EDGE] = r[2]; losses[FMHR_LOSS_DELTA] = r[3];
+        losses[FMHR_LOSS_LAP] = r[0] * A.reg_scale; losses[FMHR_LOSS_ALBEDO] = r[1] * A.reg_scale;
+        losses[FMHR_LOSS_EDGE] = r[2] * A.reg_scale; losses[FMHR_LOSS_DELTA] = r[3] * A.reg_scale;
         losses[FMHR_LOSS_TOTAL] = losses[FMHR_LOSS_SFS] + losses[FMHR_LOSS_LAP] + losses[FMHR_LOSS_ALBEDO] +
                                   losses[FMHR_LOSS_MASK] + losses[FMHR_LOSS_DELTA] + losses[FMHR_LOSS_EDGE];
-        losses[FMHR_LOSS_NVALID] = A.n_valid[0];
+        losses[FMHR_LOSS_NVALID] = A.n_valid[0] * A.reg_scale;
     }
 }
 

@@ -54,21 +54,24 @@ class ShardedStep:
         self.V = V
 
     def reduce(self, losses, gdelta, galbedo):
-        """Pack, all-reduce once, unpack into views of the bucket.  View-independent loss slots (lap, albedo, edge, delta)
-        are identical on all ranks and are averaged back; sfs / mask are partial sums over views and add up."""
+        """ONE all-reduce(SUM) of [gdelta | galbedo | losses].  Contract: every entry is this rank's SHARE — view terms are
+        partial sums over the rank's views, the view-independent terms (regulariser gradients and losses, the n_valid slot) come
+        from one rank only (HamStage2.step(reg_grads=rank == 0)) — so the sum is the global result and nothing is fixed up
+        afterwards.  When the three tensors already are HamStage2's contiguous bucket the collective runs in place on it (no
+        pack / unpack kernels: at 6 views per GPU a step is ~0.16 ms, a dozen tiny kernels would be a third of it)."""
         V = self.V
-        b = self.bucket
-        b[: V * 3].copy_(gdelta.reshape(-1))
-        b[V * 3: 2 * V * 3].copy_(galbedo.reshape(-1))
-        b[2 * V * 3:].copy_(losses)
+        es = gdelta.element_size()
+        in_place = (gdelta.is_contiguous() and galbedo.is_contiguous() and losses.is_contiguous() and
+                    galbedo.data_ptr() == gdelta.data_ptr() + 3 * V * es and losses.data_ptr() == galbedo.data_ptr() + 3 * V * es and
+                    gdelta._base is not None and gdelta._base is galbedo._base and gdelta._base is losses._base and
+                    gdelta._base.numel() == 6 * V + 8 and gdelta._base.data_ptr() == gdelta.data_ptr())
+        if in_place:
+            b = gdelta._base
+        else:
+            b = self.bucket
+            b[: V * 3].copy_(gdelta.reshape(-1))
+            b[V * 3: 2 * V * 3].copy_(galbedo.reshape(-1))
+            b[2 * V * 3:].copy_(losses)
         if self.world > 1:
             dist.all_reduce(b, group=self.group)
-        gd = b[: V * 3].view(V, 3)
-        ga = b[V * 3: 2 * V * 3].view(V, 3)
-        ls = b[2 * V * 3:].clone()
-        if self.world > 1:
-            for i in (1, 2, 4, 5):                 # lap, albedo, edge, delta: replicated values
-                ls[i] = ls[i] / self.world
-            ls[7] = ls[7] / self.world             # n_valid_global was already global on every rank
-            ls[6] = ls[0] + ls[1] + ls[2] + ls[3] + ls[4] + ls[5]
-        return ls, gd, ga
+        return b[2 * V * 3:], b[: V * 3].view(V, 3), b[V * 3: 2 * V * 3].view(V, 3)

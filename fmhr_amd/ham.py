@@ -67,9 +67,11 @@ class HamStage2:
         # fmhr_ham_forward also leaves float(n_valid_local) in the workspace: it IS n_valid_global on one rank, and the
         # all-reduce target (in place) when the views are sharded
         self.n_valid_global = self.raw("n_valid_f", torch.float32, 1)
-        self.losses = torch.zeros(8, dtype=torch.float32, device=self.dev)
-        self.gdelta = torch.zeros(self.V, 3, dtype=torch.float32, device=self.dev)
-        self.galbedo = torch.zeros(self.V, 3, dtype=torch.float32, device=self.dev)
+        # one contiguous bucket [gdelta | galbedo | losses]: a sharded caller all-reduces it in place (fmhr_amd.dist.ShardedStep)
+        self.bucket = torch.zeros(6 * self.V + 8, dtype=torch.float32, device=self.dev)
+        self.gdelta = self.bucket[: 3 * self.V].view(self.V, 3)
+        self.galbedo = self.bucket[3 * self.V: 6 * self.V].view(self.V, 3)
+        self.losses = self.bucket[6 * self.V:]
         self._views = None
         self._vm_key, self._vm_ref = None, None
 

@@ -166,7 +166,9 @@ size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
  *   n_valid_local: device int32[1] written by phase A.  n_valid_global: device float[1] read by phase B.  Phase A also
  *   leaves float(n_valid_local) in the workspace at fmhr_ham_workspace_offset(d, "n_valid_f"): a one-rank caller passes that
  *   address as n_valid_global; a sharded caller all-reduces it in place.
- *   losses: device float[8]; gdelta, galbedo [V,3] overwritten (view-dependent part only when reg_grads=0). */
+ *   losses: device float[8]; gdelta, galbedo [V,3] overwritten.  With reg_grad_scale = 0 (a rank that does not own the
+ *   view-independent terms) the gradients hold the view-dependent part only and the lap / albedo / edge / delta / n_valid slots
+ *   of `losses` are 0, so that the SUM of the vectors of all ranks is the global result with no fix-up. */
 /* Must be called once on a fresh workspace (and after any aborted step): sets up the self-cleaning state (depth keys, dirty
  * flags, antialias-backward vertex accumulator) that every completed forward+backward pair leaves clean again. */
 int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);

@@ -39,8 +39,11 @@ def _oracle_step(oracle, sc, s0, s1, n_total, reg_grads, reduce_fn):
     view_terms = out["sfs"] + out["mask"]
     reg_terms = out["lap"] + out["albedo"] + out["edge"] + out["delta"]
     (view_terms + (reg_terms if reg_grads else 0.0 * reg_terms)).backward()
-    losses = torch.stack([out[k].detach() for k in ("sfs", "lap", "albedo", "mask", "edge", "delta")] +
-                         [out["loss"].detach(), n_valid[0]]).to(torch.float32)
+    # the rank's SHARE of every slot (fmhr_amd.dist.ShardedStep.reduce contract): view-independent terms on one rank only
+    r = 1.0 if reg_grads else 0.0
+    share = {k: out[k].detach() * (r if k in ("lap", "albedo", "edge", "delta") else 1.0) for k in ("sfs", "lap", "albedo", "mask", "edge", "delta")}
+    losses = torch.stack([share[k] for k in ("sfs", "lap", "albedo", "mask", "edge", "delta")] +
+                         [sum(share.values()), n_valid[0] * r]).to(torch.float32)
     return losses, d.grad, a.grad[0]
 
 
