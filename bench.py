@@ -172,10 +172,11 @@ def main():
     opt = Adam(groups)
     sharded = fdist.ShardedStep(V, dev)
     group = torch.distributed.group.WORLD if world > 1 else None
+    reg_range = fdist.shard_views(V, rank, world)     # the view-independent terms are split over the ranks by vertex range
 
     def step():
         losses, gd, ga = hs.step(vtmp, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"],
-                                 group=group, reg_grads=(rank == 0))
+                                 group=group, reg_range=reg_range)
         if world > 1:
             losses, gd, ga = sharded.reduce(losses, gd, ga)
         delta.grad, albedo.grad = gd, ga.view(1, V, 3)

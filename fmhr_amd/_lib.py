@@ -19,7 +19,7 @@ class HamDims(ctypes.Structure):
 class HamWeights(ctypes.Structure):
     _fields_ = [("sfs", c_float), ("lap", c_float), ("albedo", c_float), ("mask", c_float), ("edge", c_float),
                 ("delta", c_float), ("edge_length_mean", c_float), ("mse_denominator", c_float),
-                ("reg_grad_scale", c_float)]
+                ("reg_grad_scale", c_float), ("reg_v0", ctypes.c_int32), ("reg_v1", ctypes.c_int32)]
 
 
 class HamViews(ctypes.Structure):

@@ -11,6 +11,7 @@ struct MeshTailArgs {
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     int V, F;
+    int v0, v1;
     float lap_w, alb_w, edge_w, delta_w, edge_mean, rg;
     float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a;
     float* loss_part;
@@ -18,7 +19,7 @@ struct MeshTailArgs {
 struct FinishArgs {
     float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
     const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
-    float reg_scale;
+    float reg_scale, nvalid_scale;
 };
 int mesh_tail_impl(const MeshTailArgs&, float*, float*, const FinishArgs&, hipStream_t);
 int mesh_tail_blocks(int V);
@@ -271,6 +272,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     FMHR_CHECK_ARG(wt && delta && albedo && sh && w2c && proj && img && mask && valid_mask && tri && row_ptr && col_idx &&
                        vf_ptr && vf_idx && corner_slot && n_valid_global && losses && gdelta && galbedo, "ham_backward: null pointer");
     FMHR_CHECK_ARG(wt->mse_denominator > 0.f, "ham_backward: mse_denominator must be > 0");
+    FMHR_CHECK_ARG(wt->reg_v0 >= 0 && wt->reg_v0 <= wt->reg_v1 && wt->reg_v1 <= d->V, "ham_backward: bad regulariser vertex range [%d, %d)",
+                   wt->reg_v0, wt->reg_v1);
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
     float* vertices = (float*)(w + L.vertices);
@@ -314,6 +317,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         A.verts = vertices; A.delta = delta; A.albedo = albedo; A.nsum = (const float*)(w + L.nsum);
         A.tri = tri; A.vf_ptr = vf_ptr; A.vf_idx = vf_idx; A.row_ptr = row_ptr; A.col = col_idx;
         A.V = d->V; A.F = d->F;
+        A.v0 = (rg != 0.f) ? wt->reg_v0 : 0; A.v1 = (rg != 0.f) ? wt->reg_v1 : 0;
         A.lap_w = wt->lap / (float)d->V; A.alb_w = wt->albedo / (float)d->V; A.edge_w = wt->edge / (3.0f * (float)d->F);
         A.delta_w = wt->delta / (float)d->V; A.edge_mean = wt->edge_length_mean; A.rg = rg;
         A.gs = (float*)(w + L.gtmp); A.rowg_v = (float*)(w + L.rowg); A.rowg_a = (float*)(w + L.lx_a);
@@ -324,6 +328,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         fin.part_l2 = (const float*)(w + L.partials) + 2 * nB; fin.nb = (int)nB; fin.tail_part = (const float*)(w + L.tail_part);
         fin.tail_nb = mesh_tail_blocks(d->V); fin.w_sfs = wt->sfs; fin.w_mask = wt->mask; fin.mse_den = wt->mse_denominator;
         fin.reg_scale = (rg != 0.f) ? 1.f : 0.f;
+        fin.nvalid_scale = (rg != 0.f && wt->reg_v0 == 0) ? 1.f : 0.f;
         TRY(mesh_tail_impl(A, gdelta, galbedo, fin, st));
     }
     return FMHR_OK;

@@ -510,6 +510,7 @@ struct MeshTailArgs {
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     int V, F;
+    int v0, v1;                                                                       // vertex range of the view-independent terms
     float lap_w, alb_w, edge_w, delta_w, edge_mean, rg;                               // weights (already / V or / 3F where due)
     float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a;
     float* loss_part;                                                                 // [4, gridDim.x] weighted per-block loss sums
@@ -548,7 +549,8 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
     float lv[3] = {0.f, 0.f, 0.f}, la[3] = {0.f, 0.f, 0.f};
     int deg = 0;
     float3 xv = make_float3(0.f, 0.f, 0.f), xa = xv;
-    if (live) {
+    const bool mine = live && v >= A.v0 && v < A.v1;                // this rank evaluates the regularisers of [v0, v1) only
+    if (mine) {
         const int ra = A.row_ptr[vv], rb = A.row_ptr[vv + 1];
         deg = rb - ra;
         xv = ld3(A.verts + (size_t)vv * 3); xa = ld3(A.albedo + (size_t)vv * 3);
@@ -561,7 +563,7 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
     }
     // (5) edge hinge (mesh_sfs_optim.py:296-302): a face's loss is accounted by its corner 0, gradients by each corner
     float3 eg = make_float3(0.f, 0.f, 0.f);
-    if (live) {
+    if (mine) {
         const float gk = 2.f * A.edge_w * A.rg;
         for (int e = A.vf_ptr[vv] + sub; e < A.vf_ptr[vv + 1]; e += kSubLanes) {
             int code = A.vf_idx[e];
@@ -604,7 +606,10 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
             A.gs[(size_t)v * 3] = o.x; A.gs[(size_t)v * 3 + 1] = o.y; A.gs[(size_t)v * 3 + 2] = o.z;
         }
         // (3) row norms -> loss, scaled rows -> backward (part B); an isolated vertex has the row -x (models/utils.py:684)
-        {
+        if (!mine) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { A.rowg_v[(size_t)v * 3 + c] = 0.f; A.rowg_a[(size_t)v * 3 + c] = 0.f; }
+        } else {
             const float inv = (deg > 0) ? 1.0f / (float)deg : 0.0f;
             const float xs[3] = {xv.x, xv.y, xv.z}, as[3] = {xa.x, xa.y, xa.z};
 #pragma unroll
@@ -617,7 +622,7 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
             for (int c = 0; c < 3; c++) { A.rowg_v[(size_t)v * 3 + c] = lv[c] * kv; A.rowg_a[(size_t)v * 3 + c] = la[c] * ka; }
         }
         // (4) delta term (mesh_sfs_optim.py:304)
-        {
+        if (mine) {
             float3 d = ld3(A.delta + (size_t)v * 3);
             l_delta = d.x * d.x + d.y * d.y + d.z * d.z;
             float k = 2.f * A.delta_w * A.rg;
@@ -639,8 +644,8 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
 struct FinishArgs {
     float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
     const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
-    float reg_scale;      // 1 on the rank that owns the view-independent terms (and the n_valid slot), 0 elsewhere: summing the loss
-                          // vectors of all ranks then gives the global values with no fix-up
+    float reg_scale;      // 0 switches the view-independent loss slots off (reg_grad_scale = 0)
+    float nvalid_scale;   // 1 on the one rank that reports n_valid: summing the loss vectors of all ranks gives the global values
 };
 
 __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* sm4)
@@ -667,7 +672,7 @@ __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* 
         losses[FMHR_LOSS_EDGE] = r[2] * A.reg_scale; losses[FMHR_LOSS_DELTA] = r[3] * A.reg_scale;
         losses[FMHR_LOSS_TOTAL] = losses[FMHR_LOSS_SFS] + losses[FMHR_LOSS_LAP] + losses[FMHR_LOSS_ALBEDO] +
                                   losses[FMHR_LOSS_MASK] + losses[FMHR_LOSS_DELTA] + losses[FMHR_LOSS_EDGE];
-        losses[FMHR_LOSS_NVALID] = A.n_valid[0] * A.reg_scale;
+        losses[FMHR_LOSS_NVALID] = A.n_valid[0] * A.nvalid_scale;
     }
 }
 

@@ -3,8 +3,10 @@ on ROCm) — SURVEY.md §8e.  The reference has no multi-GPU code; this is the b
 
 * the n views of a step are split contiguously over G ranks; every rank holds the whole mesh;
 * exchange 1: all-reduce(SUM) of the valid-pixel count (F.l1_loss divides by the batch-global 3*Pv, mesh_sfs_optim.py:289);
-* exchange 2: ONE all-reduce(SUM) per step of the packed per-vertex gradients [gdelta | galbedo] = [2,V,3] fp32
-  (1.18 MB at V = 49k: latency-bound on xGMI); regulariser gradients are view-independent and added by rank 0 only.
+* exchange 2: ONE all-reduce(SUM) per step, in place on HamStage2's bucket [gdelta | galbedo | 8 loss slots] = 6V+8 fp32
+  (1.18 MB at V = 49k: latency-bound on xGMI).  Every entry is the rank's share: the view terms of its views and the
+  view-independent terms (regularisers) of its VERTEX range — shard_views(V, rank, world) — so nothing is fixed up afterwards
+  and the regulariser work is split over the ranks too.
 """
 import os
 

@@ -84,10 +84,11 @@ class HamStage2:
              ptr(proj), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp), ptr(self.vf_ptr), ptr(self.vf_idx),
              changed, ptr(self.n_valid_local), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
 
-    def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True):
+    def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True, reg_range=None):
         w = self.weights
+        v0, v1 = (0, self.V) if reg_range is None else reg_range
         wt = HamWeights(w["sfs"], w["lap"], w["albedo"], w["mask"], w["edge"], w["delta"], self.edge_len_mean,
-                        float(self.n_global * self.H * self.W), 1.0 if reg_grads else 0.0)
+                        float(self.n_global * self.H * self.W), 1.0 if reg_grads else 0.0, int(v0), int(v1))
         call("fmhr_ham_backward", ctypes.byref(self.dims), ctypes.byref(wt), ptr(vertices_tmp), ptr(delta), ptr(albedo),
              ptr(sh), ptr(w2c), ptr(proj), ptr(img), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp),
              ptr(self.row_ptr), ptr(self.col_idx), ptr(self.vf_ptr), ptr(self.vf_idx), ptr(self.corner_slot),
@@ -95,14 +96,16 @@ class HamStage2:
              ptr(self.losses), ptr(self.gdelta),
              ptr(self.galbedo), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
 
-    def step(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group=None, reg_grads=True):
+    def step(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group=None, reg_grads=True, reg_range=None):
         """Full forward + backward.  Returns (losses[8] device tensor, gdelta [V,3], galbedo [V,3]) — buffers owned by this
-        object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded."""
+        object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded.
+        `reg_range` = (v0, v1): evaluate the view-independent terms for these vertices only (ranks take disjoint ranges covering
+        [0, V): fmhr_amd.dist.shard_views(V, rank, world)); `reg_grads=False` switches them off on this rank."""
         self._check(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask)
         self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask)
         if group is not None:
             torch.distributed.all_reduce(self.n_valid_global, group=group)
-        self.backward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=reg_grads)
+        self.backward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=reg_grads, reg_range=reg_range)
         return self.losses, self.gdelta, self.galbedo
 
     def _check(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask):

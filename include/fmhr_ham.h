@@ -140,6 +140,11 @@ typedef struct fmhr_ham_weights {
     float reg_grad_scale;                        /* 1: add the view-independent regulariser gradients (lap, albedo-lap, edge,
                                                     delta) to gdelta/galbedo; 0: leave them out (all ranks but one in the
                                                     view-sharded loop, so the all-reduce sums them once) */
+    int32_t reg_v0, reg_v1;                      /* the view-independent terms (losses and gradients) are evaluated for the
+                                                    vertices [reg_v0, reg_v1) only: ranks of a view-sharded loop take disjoint
+                                                    ranges that cover [0, V) and the all-reduce puts them together (a
+                                                    Laplacian row, a vertex's edge-hinge gradient, a face's edge loss via its
+                                                    corner 0 all belong to one vertex).  One rank: 0, V */
 } fmhr_ham_weights;
 
 /* loss vector layout (device, float[8]): sfs, lap, albedo, mask, edge, delta, total, n_valid_global as used */
@@ -166,9 +171,9 @@ size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
  *   n_valid_local: device int32[1] written by phase A.  n_valid_global: device float[1] read by phase B.  Phase A also
  *   leaves float(n_valid_local) in the workspace at fmhr_ham_workspace_offset(d, "n_valid_f"): a one-rank caller passes that
  *   address as n_valid_global; a sharded caller all-reduces it in place.
- *   losses: device float[8]; gdelta, galbedo [V,3] overwritten.  With reg_grad_scale = 0 (a rank that does not own the
- *   view-independent terms) the gradients hold the view-dependent part only and the lap / albedo / edge / delta / n_valid slots
- *   of `losses` are 0, so that the SUM of the vectors of all ranks is the global result with no fix-up. */
+ *   losses: device float[8]; gdelta, galbedo [V,3] overwritten.  Every entry is this rank's SHARE: the view terms of its
+ *   views, the view-independent terms of its vertex range [reg_v0, reg_v1) (none with reg_grad_scale = 0); the n_valid slot is
+ *   reported by the rank whose range starts at vertex 0.  The SUM over all ranks is the global result with no fix-up. */
 /* Must be called once on a fresh workspace (and after any aborted step): sets up the self-cleaning state (depth keys, dirty
  * flags, antialias-backward vertex accumulator) that every completed forward+backward pair leaves clean again. */
 int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);

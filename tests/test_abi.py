@@ -31,7 +31,7 @@ def test_header_and_library_agree(lib):
 
 def test_struct_layouts_match_header():
     from fmhr_amd._lib import HamDims, HamWeights, HamViews
-    assert ctypes.sizeof(HamDims) == 28 and ctypes.sizeof(HamWeights) == 36 and ctypes.sizeof(HamViews) == 48
+    assert ctypes.sizeof(HamDims) == 28 and ctypes.sizeof(HamWeights) == 44 and ctypes.sizeof(HamViews) == 48
 
 
 def test_argument_errors_without_gpu(lib):

@@ -35,7 +35,7 @@ def _scene():
     return sc, tg, faces, w2c, proj
 
 
-def _run(sc, tg, faces, w2c, proj, s0, s1, group, reg):
+def _run(sc, tg, faces, w2c, proj, s0, s1, group, reg_range):
     from fmhr_amd.ham import HamStage2, edge_length_mean
     dev = faces.device
     vt = sc["vertices"].to(dev)
@@ -43,7 +43,7 @@ def _run(sc, tg, faces, w2c, proj, s0, s1, group, reg):
     sl = slice(s0, s1)
     out = hs.step(vt, sc["delta"], sc["albedo0"].to(dev), sc["sh0"][sl].to(dev).contiguous(), w2c[sl].contiguous(),
                   proj[sl].contiguous(), tg["img"][sl].contiguous(), tg["mask"][sl].contiguous(), tg["valid_mask"][sl].contiguous(),
-                  group=group, reg_grads=reg)
+                  group=group, reg_range=reg_range)
     return [t.clone() for t in out]
 
 
@@ -56,7 +56,8 @@ def _worker(rank, world, port, q):
     torch.cuda.set_device(0)
     sc, tg, faces, w2c, proj = _scene()
     s0, s1 = fdist.shard_views(sc["views"], rank, world)
-    losses, gd, ga = _run(sc, tg, faces, w2c, proj, s0, s1, dist.group.WORLD, rank == 0)
+    # the view-independent terms are split over the ranks by vertex range
+    losses, gd, ga = _run(sc, tg, faces, w2c, proj, s0, s1, dist.group.WORLD, fdist.shard_views(sc["V"], rank, world))
     sh = fdist.ShardedStep(sc["V"], faces.device)
     ls, gd, ga = sh.reduce(losses, gd, ga)
     torch.cuda.synchronize()
@@ -81,7 +82,7 @@ def test_two_ranks_one_gpu_match_single_rank():
         p.join(120)
         assert p.exitcode == 0
     sc, tg, faces, w2c, proj = _scene()
-    l1, gd1, ga1 = _run(sc, tg, faces, w2c, proj, 0, sc["views"], None, True)
+    l1, gd1, ga1 = _run(sc, tg, faces, w2c, proj, 0, sc["views"], None, None)
     assert float(ls[7]) == float(l1[7]) and float(l1[7]) > 1000
     assert rel_err(ls[:7], l1[:7].cpu()) < 1e-5, (ls, l1)
     assert rel_err(gd, gd1.cpu()) < 5e-5 and rel_err(ga, ga1.cpu()) < 5e-5
