@@ -386,6 +386,9 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
 // Per segment: the coverage words of the own / next / lower segments are wave-uniform loads; then every lane issues its two
 // rast loads (own, lower) together — the right neighbour's fragment is the next lane's register — and only pairs with different
 // triangle ids go on (silhouette byte first).  Colours are read as 16-B words only by the pairs that blend.
+constexpr int kAaGrid = 2048;                 // workgroups of the fused antialias kernels = regions of the work-item list
+constexpr int kItemBuf = 512;                 // work items one workgroup of k_aa_fwd_list buffers in LDS
+
 __device__ __forceinline__ unsigned long long covw_or0(const unsigned long long* __restrict__ covw, long long w, long long nSeg)
 {
     return (w >= 0 && w < nSeg) ? covw[w] : 0ull;
@@ -395,9 +398,20 @@ __global__ void __launch_bounds__(kBlock)
 k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
               const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
               const int* __restrict__ act_list, const int* __restrict__ act_count, const unsigned long long* __restrict__ covw,
-              int n, int V, int F, int H, int W, float* __restrict__ out, unsigned char* __restrict__ px_code,
-              float* __restrict__ px_alpha)
+              int n, int V, int F, int H, int W, float* __restrict__ out, int4* __restrict__ items,
+              float* __restrict__ alphas, int32_t* __restrict__ counter, int32_t* __restrict__ region_cnt, int cap)
 {
+    // work items (pairs that blend; a few % of the pixels) for the backward: every workgroup owns a fixed region of the list
+    // (cap / gridDim items) and a count slot — no global atomics at all (a returning same-address atomic per wave with an item
+    // serialised to ~0.25 ms per step, one per workgroup at the kernel's end still to ~13 us); the backward runs one workgroup
+    // per region over dense items instead of scanning every active pixel
+    __shared__ int4 ibuf[kItemBuf];
+    __shared__ float abuf[kItemBuf];
+    __shared__ int inum;
+    const int region = cap / (int)gridDim.x;
+    const size_t rbase = (size_t)blockIdx.x * region;
+    if (threadIdx.x == 0) inum = 0;
+    __syncthreads();
     const int count = *act_count, lane = threadIdx.x & 63;
     const long long P = (long long)H * W, N = (long long)n * P, nSeg = (N + 63) >> 6;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
@@ -430,7 +444,6 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
         }
         const float* posv = pos + (size_t)b * V * 4;
         const unsigned char* sv = silh + (size_t)b * F;
-        int codes[2];
 #pragma unroll
         for (int d = 0; d < 2; d++) {
             const float4 r1 = d ? rD : rR;
@@ -447,12 +460,26 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
                 for (int c = 0; c < 4; c++)
                     if (dc[c] != 0.f) atomicAdd(out + tgt * 4 + c, alpha * dc[c]);
             }
-            // the work item stays in place (2 slots per pixel), no queue: a global queue costs one RETURNING same-address atomic
-            // per wave with an item, and ~30k of those serialise to ~0.25 ms per step
-            codes[d] = code;
-            if (code != 0) px_alpha[gid * 2 + d] = alpha;
+            if (code != 0) {
+                const int slot = atomicAdd(&inum, 1);                    // LDS
+                if (slot < kItemBuf) {
+                    ibuf[slot] = make_int4(px, py, b, code);
+                    abuf[slot] = alpha;
+                } else if (slot < region) {                              // buffer full (a silhouette-dense workgroup): straight to the region
+                    items[rbase + slot] = make_int4(px, py, b, code);
+                    alphas[rbase + slot] = alpha;
+                } else {
+                    counter[1] = 1;                                      // region overflow: the pair gets no gradient, flagged
+                }
+            }
         }
-        if (live) reinterpret_cast<uchar2*>(px_code)[gid] = make_uchar2((unsigned char)codes[0], (unsigned char)codes[1]);
+    }
+    __syncthreads();
+    const int nn = min(inum, min(kItemBuf, region));
+    for (int i = threadIdx.x; i < nn; i += kBlock) { items[rbase + i] = ibuf[i]; alphas[rbase + i] = abuf[i]; }
+    if (threadIdx.x == 0) {
+        region_cnt[blockIdx.x] = min(inum, region);
+        if (inum > region) counter[1] = 1;
     }
 }
 
@@ -550,25 +577,19 @@ k_aa_bwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
     }
 }
 
-// backward over in-place items (fused step): persistent waves over the active segments, two item slots per pixel
+// backward over the work-item list of the fused step: one workgroup per region of the list, dense items
 __global__ void __launch_bounds__(kBlock)
-k_aa_bwd_px(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
-            const int32_t* __restrict__ tri, const float* __restrict__ dy, const unsigned char* __restrict__ px_code,
-            const float* __restrict__ px_alpha, const int* __restrict__ act_list, const int* __restrict__ act_count, int n, int V,
-            int H, int W, float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert)
+k_aa_bwd_items(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
+               const int32_t* __restrict__ tri, const float* __restrict__ dy, const int4* __restrict__ items,
+               const float* __restrict__ alphas, const int32_t* __restrict__ region_cnt, int cap, int V, int H, int W,
+               float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert)
 {
-    long long P = (long long)H * W;
-    const int count = *act_count, lane = threadIdx.x & 63;
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
-        const long long gid = ((long long)act_list[i] << 6) + lane;
-        if (gid >= (long long)n * P) continue;
-        uchar2 cd = reinterpret_cast<const uchar2*>(px_code)[gid];
-        if ((cd.x | cd.y) == 0) continue;
-        int rem, px;
-        const int b = fast_divmod(gid, (int)P, rem);
-        const int py = fast_divmod(rem, W, px);
-        if (cd.x) aa_bwd_item<4, 0>(px, py, b, cd.x, px_alpha[gid * 2], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
-        if (cd.y) aa_bwd_item<4, 0>(px, py, b, cd.y, px_alpha[gid * 2 + 1], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr, nullptr, cmat, gvert);
+    const int region = cap / (int)gridDim.x, count = region_cnt[blockIdx.x];      // same grid as k_aa_fwd_list
+    const size_t rbase = (size_t)blockIdx.x * region;
+    for (int i = threadIdx.x; i < count; i += kBlock) {
+        const int4 it = items[rbase + i];
+        aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alphas[rbase + i], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr,
+                          nullptr, cmat, gvert);
     }
 }
 
@@ -596,21 +617,22 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
 // persistent grids over the active-segment list
 int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                 const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw, int n,
-                int V, int F, int H, int W, float* out, unsigned char* px_code, float* px_alpha, hipStream_t st)
+                int V, int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int32_t* region_cnt, int cap,
+                hipStream_t st)
 {
-    k_aa_fwd_list<<<2048, kBlock, 0, st>>>((const float4*)color, (const float4*)rast, pos, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
-                                           out, px_code, px_alpha);
+    k_aa_fwd_list<<<kAaGrid, kBlock, 0, st>>>((const float4*)color, (const float4*)rast, pos, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
+                                           out, (int4*)items, alphas, counter, region_cnt, cap);
     FMHR_CHECK_LAUNCH("k_aa_fwd_list");
     return FMHR_OK;
 }
 
 int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
-                const unsigned char* px_code, const float* px_alpha, const int* act_list, const int* act_count, int n, int V,
+                const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int V,
                 int H, int W, float* gcolor, const float* cmat, float* gvert, hipStream_t st)
 {
-    k_aa_bwd_px<<<2048, kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, dy, px_code, px_alpha, act_list, act_count, n, V, H, W,
-                                         gcolor, (const float4*)cmat, gvert);
-    FMHR_CHECK_LAUNCH("k_aa_bwd_px");
+    k_aa_bwd_items<<<kAaGrid, kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, dy, (const int4*)items, alphas, region_cnt, cap, V, H, W,
+                                           gcolor, (const float4*)cmat, gvert);
+    FMHR_CHECK_LAUNCH("k_aa_bwd_items");
     return FMHR_OK;
 }
 

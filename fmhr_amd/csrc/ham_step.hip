@@ -33,9 +33,9 @@ int active_segments_impl(const unsigned long long*, const unsigned char*, long l
                          const float*, int, int*, float*, hipStream_t);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
-                const int*, const unsigned long long*, int, int, int, int, int, float*, unsigned char*, float*, hipStream_t);
-int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const unsigned char*, const float*,
-                const int*, const int*, int, int, int, int, float*, const float*, float*, hipStream_t);
+                const int*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int, hipStream_t);
+int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const int32_t*, const float*,
+                const int32_t*, int, int, int, int, float*, const float*, float*, hipStream_t);
 int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, const float*,
                             float*, hipStream_t);
 int normals_bwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, float*,
@@ -56,7 +56,7 @@ int face_bwd_groups(int n);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, g_aa,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt, g_aa,
         g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, cnt_part, total;
 };
 
@@ -95,9 +95,10 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.rast = take(off, nP * 16);
     L.shaded = take(off, nP * 16);
     L.aa = take(off, nP * 16);
-    L.aa_items = take(off, nP * 2);           // in-place work-item codes: 2 slots (right / down pair) per pixel
-    L.aa_alphas = take(off, nP * 8);          // and their alphas
+    L.aa_items = take(off, (size_t)d->aa_cap * 16);   // antialias work items (px, py, view, code) of the pairs that blend
+    L.aa_alphas = take(off, (size_t)d->aa_cap * 4);   // and their alphas
     L.aa_counter = take(off, 16);
+    L.aa_region_cnt = take(off, 2048 * 4);            // items per region of the list (one region per workgroup of the AA kernels)
     L.g_aa = take(off, nP * 16);
     L.g_shaded = take(off, nP * 16);
     L.cmat = take(off, (size_t)d->n * 48);
@@ -120,7 +121,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
 static int check_dims(const fmhr_ham_dims* d)
 {
     FMHR_CHECK_ARG(d != nullptr, "ham: dims is null");
-    FMHR_CHECK_ARG(d->n >= 1 && d->V >= 1 && d->F >= 1 && d->H >= 1 && d->W >= 1 && d->aa_cap >= 1,
+    FMHR_CHECK_ARG(d->n >= 1 && d->V >= 1 && d->F >= 1 && d->H >= 1 && d->W >= 1 && d->aa_cap >= 2048,
                    "ham: bad dims n=%d V=%d F=%d H=%d W=%d aa_cap=%d", d->n, d->V, d->F, d->H, d->W, d->aa_cap);
     FMHR_CHECK_ARG(d->H <= 8192 && d->W <= 8192 && d->F < (1 << 24), "ham: H,W <= 8192 and F < 2^24 required");
     FMHR_CHECK_ARG(((long long)d->n * d->H * d->W) % 4 == 0, "ham: n*H*W must be a multiple of 4");
@@ -237,7 +238,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.bwd16 = (float4*)(w + L.bwd16); fu.mask = mask;
         fu.attr8 = (const float4*)(w + L.attr8); fu.sh = sh;
         fu.shaded = (float4*)(w + L.shaded); fu.aa_init = (float4*)(w + L.aa); fu.part_cnt = (float*)(w + L.cnt_part);
-        fu.rearm2 = (int*)(w + L.act_count);
+        fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
         TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
                                rast, w + L.raster_ws, (unsigned char*)(w + L.dirty), covw, &fu, st));
     }
@@ -253,7 +254,8 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
                     (const int*)(w + L.act_count), covw, d->n, d->V, d->F,
-                    d->H, d->W, (float*)(w + L.aa), (unsigned char*)(w + L.aa_items), (float*)(w + L.aa_alphas), st));
+                    d->H, d->W, (float*)(w + L.aa), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
+                    (int32_t*)(w + L.aa_counter), (int32_t*)(w + L.aa_region_cnt), d->aa_cap, st));
     return FMHR_OK;
 }
 
@@ -297,9 +299,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     {
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads (clip-transformed) into gvert_aa
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
-        TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (float*)(w + L.g_aa), (const unsigned char*)(w + L.aa_items),
-                        (const float*)(w + L.aa_alphas), (const int*)(w + L.act_list), (const int*)(w + L.act_count), d->n, d->V,
-                        d->H, d->W,
+        TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (float*)(w + L.g_aa), (const int32_t*)(w + L.aa_items),
+                        (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->V, d->H, d->W,
                         (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, st));
     }
     {

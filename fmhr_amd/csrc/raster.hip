@@ -308,6 +308,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         if (gid == 0) {                                              // k_raster_large is done: rearm its queue counter, and the
             *large_cnt = 0;                                          // caller's pair of list cursors (saves a memset launch)
             if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
+            if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
         }
         if (gid - (gid & 63) >= (long long)n * P) work = false;      // whole wave out of range
         else if (!__builtin_amdgcn_readfirstlane((int)dirty[seg])) {

@@ -91,6 +91,7 @@ struct RasterFused {
     const float4* attr8; const float* sh;                     // forward shading inputs
     float4* shaded; float4* aa_init; float* part_cnt;         // forward shading outputs + per-workgroup valid-pixel counts
     int* rearm2;                                              // two list cursors the resolve pass zeroes for the next kernel
+    int* rearm_aa;                                            // antialias work-item counter + overflow flag, likewise
 };
 
 }  // namespace fmhr

@@ -130,7 +130,8 @@ int fmhr_adam_step2(float* param_a, const float* grad_a, float* exp_avg_a, float
 typedef struct fmhr_ham_dims {
     int32_t n, V, F, H, W;      /* views on this rank, vertices, faces, image size */
     int32_t nnz;                /* adjacency nnz (row_ptr[V]) */
-    int32_t aa_cap;             /* unused by the fused step since the antialias items live in place; keep >= 1 */
+    int32_t aa_cap;             /* capacity of the antialias work-item list (pairs that blend, ∝ silhouette length); on overflow
+                                   aa_counter[1] of fmhr_ham_views is set and the excess pairs get no gradient */
 } fmhr_ham_dims;
 
 typedef struct fmhr_ham_weights {

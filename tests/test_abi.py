@@ -44,7 +44,7 @@ def test_argument_errors_without_gpu(lib):
     assert lib.fmhr_laplacian_uniform_fwd(None, None, None, 10, 5, 1.0, None, None, None) == -1
     bad = HamDims(0, 10, 10, 8, 8, 0, 16)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(bad)) == 0
-    ok = HamDims(2, 100, 180, 64, 48, 0, 1024)
+    ok = HamDims(2, 100, 180, 64, 48, 0, 4096)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(ok)) > 2 * 64 * 48 * 16
     assert lib.fmhr_rasterize_workspace_bytes(2, 7, 10, 8, 8) == 2 * 64 * 8 + 16 + 2 * 10 * 8 + 2 * 7 * 8
 
