@@ -387,11 +387,42 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
 // rast loads (own, lower) together — the right neighbour's fragment is the next lane's register — and only pairs with different
 // triangle ids go on (silhouette byte first).  Colours are read as 16-B words only by the pairs that blend.
 constexpr int kAaGrid = 2048;                 // workgroups of the fused antialias kernels = regions of the work-item list
+constexpr int kCandBuf = 512;                 // candidate pairs one workgroup parks before analysing them densely
 constexpr int kItemBuf = 512;                 // work items one workgroup of k_aa_fwd_list buffers in LDS
 
 __device__ __forceinline__ unsigned long long covw_or0(const unsigned long long* __restrict__ covw, long long w, long long nSeg)
 {
     return (w >= 0 && w < nSeg) ? covw[w] : 0ull;
+}
+
+// one candidate pair of the fused forward: full analysis, blend of the rgba, work item for the backward
+__device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float z0, float id0, float z1, float id1,
+                                            const float4* __restrict__ color, const float* __restrict__ pos,
+                                            const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
+                                            const unsigned char* __restrict__ silh, int V, int F, int H, int W,
+                                            float* __restrict__ out, int4* __restrict__ items, float* __restrict__ alphas,
+                                            int32_t* __restrict__ counter, int4* ibuf, float* abuf, int* inum, int region, size_t rbase)
+{
+    float alpha = 0.f;
+    const int code = aa_analyse(pos + (size_t)b * V * 4, tri, opp, silh + (size_t)b * F, V, F, H, W, px, py, d, z0, id0, z1, id1, alpha);
+    if (code == 0) return;
+    const long long gid = ((long long)b * H + py) * W + px, gid1 = gid + (d ? W : 1);
+    const long long tgt = (alpha > 0.f) ? gid : gid1;
+    const float4 ca = color[gid], cb = color[gid1];
+    const float dc[4] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z, cb.w - ca.w};
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (dc[c] != 0.f) atomicAdd(out + tgt * 4 + c, alpha * dc[c]);
+    const int slot = atomicAdd(inum, 1);                             // LDS
+    if (slot < kItemBuf) {
+        ibuf[slot] = make_int4(px, py, b, code);
+        abuf[slot] = alpha;
+    } else if (slot < region) {                                      // buffer full (a silhouette-dense workgroup): straight to the region
+        items[rbase + slot] = make_int4(px, py, b, code);
+        alphas[rbase + slot] = alpha;
+    } else {
+        counter[1] = 1;                                              // region overflow: the pair gets no gradient, flagged
+    }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -407,10 +438,12 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
     // per region over dense items instead of scanning every active pixel
     __shared__ int4 ibuf[kItemBuf];
     __shared__ float abuf[kItemBuf];
-    __shared__ int inum;
+    __shared__ int2 cpos[kCandBuf];                                // candidate pairs: px | py << 13 | d << 26, view
+    __shared__ float4 cfrag[kCandBuf];                             // (z, id) of the two pixels
+    __shared__ int inum, cnum;
     const int region = cap / (int)gridDim.x;
     const size_t rbase = (size_t)blockIdx.x * region;
-    if (threadIdx.x == 0) inum = 0;
+    if (threadIdx.x == 0) { inum = 0; cnum = 0; }
     __syncthreads();
     const int count = *act_count, lane = threadIdx.x & 63;
     const long long P = (long long)H * W, N = (long long)n * P, nSeg = (N + 63) >> 6;
@@ -442,36 +475,36 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
             const float z = __shfl_down(r0.z, 1), w = __shfl_down(r0.w, 1);
             if (lane < 63) { rR.z = z; rR.w = w; }
         }
-        const float* posv = pos + (size_t)b * V * 4;
         const unsigned char* sv = silh + (size_t)b * F;
 #pragma unroll
         for (int d = 0; d < 2; d++) {
             const float4 r1 = d ? rD : rR;
-            const long long gid1 = d ? gidD : gid + 1;
-            float alpha = 0.f;
-            int code = 0;
-            if ((d ? inD : inR) && r1.w != r0.w)
-                code = aa_analyse(posv, tri, opp, sv, V, F, H, W, px, py, d, r0.z, r0.w, r1.z, r1.w, alpha);
-            if (code != 0) {
-                const long long tgt = (alpha > 0.f) ? gid : gid1;
-                const float4 ca = color[gid], cb = color[gid1];
-                const float dc[4] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z, cb.w - ca.w};
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    if (dc[c] != 0.f) atomicAdd(out + tgt * 4 + c, alpha * dc[c]);
+            if (!((d ? inD : inR) && r1.w != r0.w)) continue;
+            // pre-test of aa_analyse (which triangle is in front, does it have a silhouette edge in this view): ends almost
+            // every pair of a micro-triangle mesh; the survivors (a few per wave) are parked and analysed DENSELY by the whole
+            // workgroup afterwards instead of by one or two lanes of every wave
+            const int tri0 = (int)r0.w - 1, tri1 = (int)r1.w - 1;
+            int t = (tri0 >= 0) ? tri0 : tri1;
+            if (tri0 >= 0 && tri1 >= 0) t = (r0.z < r1.z) ? tri0 : tri1;
+            if (t < 0 || t >= F || sv[t] == 0) continue;
+            const int slot = atomicAdd(&cnum, 1);                        // LDS
+            if (slot < kCandBuf) {
+                cpos[slot] = make_int2(px | (py << 13) | (d << 26), b);
+                cfrag[slot] = make_float4(r0.z, r0.w, r1.z, r1.w);
+            } else {
+                aa_fwd_pair(px, py, b, d, r0.z, r0.w, r1.z, r1.w, color, pos, tri, opp, silh, V, F, H, W, out, items, alphas, counter,
+                            ibuf, abuf, &inum, region, rbase);
             }
-            if (code != 0) {
-                const int slot = atomicAdd(&inum, 1);                    // LDS
-                if (slot < kItemBuf) {
-                    ibuf[slot] = make_int4(px, py, b, code);
-                    abuf[slot] = alpha;
-                } else if (slot < region) {                              // buffer full (a silhouette-dense workgroup): straight to the region
-                    items[rbase + slot] = make_int4(px, py, b, code);
-                    alphas[rbase + slot] = alpha;
-                } else {
-                    counter[1] = 1;                                      // region overflow: the pair gets no gradient, flagged
-                }
-            }
+        }
+    }
+    __syncthreads();
+    {
+        const int nc = min(cnum, kCandBuf);
+        for (int c = threadIdx.x; c < nc; c += kBlock) {
+            const int2 cp = cpos[c];
+            const float4 cf = cfrag[c];
+            aa_fwd_pair(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, color, pos, tri, opp, silh, V, F, H,
+                        W, out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
         }
     }
     __syncthreads();
