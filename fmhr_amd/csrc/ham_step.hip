@@ -30,7 +30,7 @@ int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*
                        void*, unsigned char*, unsigned long long*, const RasterFused*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, int*,
-                         const float*, int, int*, float*, hipStream_t);
+                         const int*, float*, hipStream_t);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
                 const int*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int, hipStream_t);
@@ -47,7 +47,7 @@ int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, 
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
-int fill_uncovered_impl(long long, const int*, const int*, float*, float*, hipStream_t);
+int fill_uncovered_impl(long long, const int*, const int*, float*, float*, const float*, int*, float*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
@@ -57,7 +57,7 @@ int face_bwd_groups(int n);
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt, g_aa,
-        g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, cnt_part, total;
+        g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, seg_valid, cnt_part, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -113,7 +113,8 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.rowg = take(off, V * 12);
     L.tail_part = take(off, (size_t)mesh_tail_blocks(d->V) * 16);    // per-workgroup regulariser loss sums [4, blocks]
     L.n_valid_f = take(off, 16);                    // float copy of n_valid_local (a ready n_valid_global for the one-rank case)
-    L.cnt_part = take(off, ((nP + 255) / 256) * 4);  // per-workgroup valid-pixel counts of the resolve pass
+    L.seg_valid = take(off, ((nP + 63) / 64) * 4);   // valid-pixel count of every segment (resolve pass)
+    L.cnt_part = take(off, (((nP + 63) / 64 + 1023) / 1024) * 4);   // the same per workgroup of k_active_segments
     L.total = off;
     return L;
 }
@@ -237,7 +238,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.cov16 = (int4*)(w + L.cov16); fu.stamp = (int*)(w + L.stamp); fu.own8 = (unsigned char*)(w + L.own8);
         fu.bwd16 = (float4*)(w + L.bwd16); fu.mask = mask;
         fu.attr8 = (const float4*)(w + L.attr8); fu.sh = sh;
-        fu.shaded = (float4*)(w + L.shaded); fu.aa_init = (float4*)(w + L.aa); fu.part_cnt = (float*)(w + L.cnt_part);
+        fu.shaded = (float4*)(w + L.shaded); fu.aa_init = (float4*)(w + L.aa); fu.seg_valid = (int*)(w + L.seg_valid);
         fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
         TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
                                rast, w + L.raster_ws, (unsigned char*)(w + L.dirty), covw, &fu, st));
@@ -246,10 +247,10 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
         TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, (int*)(w + L.act_list),
-                                 (int*)(w + L.act_count), (int*)(w + L.fill_list), (const float*)(w + L.cnt_part),
-                                 (int)((nP + 255) / 256), n_valid_local, (float*)(w + L.n_valid_f), st));
+                                 (int*)(w + L.act_count), (int*)(w + L.fill_list), (const int*)(w + L.seg_valid),
+                                 (float*)(w + L.cnt_part), st));
         TRY(fill_uncovered_impl(nP, (const int*)(w + L.fill_list), (const int*)(w + L.act_count) + 1, (float*)(w + L.shaded),
-                                (float*)(w + L.aa), st));
+                                (float*)(w + L.aa), (const float*)(w + L.cnt_part), n_valid_local, (float*)(w + L.n_valid_f), st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),

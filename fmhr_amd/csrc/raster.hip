@@ -298,27 +298,28 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
                  unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu)
 {
-    __shared__ float sm[4];
     const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long P = (long long)H * W;
     const bool sparse = dirty != nullptr;
     const long long seg = gid >> 6;
-    bool work = true;                                                // wave-uniform
     if (sparse) {
         if (gid == 0) {                                              // k_raster_large is done: rearm its queue counter, and the
             *large_cnt = 0;                                          // caller's pair of list cursors (saves a memset launch)
             if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
             if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
         }
-        if (gid - (gid & 63) >= (long long)n * P) work = false;      // whole wave out of range
-        else if (!__builtin_amdgcn_readfirstlane((int)dirty[seg])) {
-            if ((threadIdx.x & 63) == 0) covw[seg] = 0ull;
-            work = false;
+        if (gid - (gid & 63) >= (long long)n * P) return;            // whole wave out of range
+        if (!__builtin_amdgcn_readfirstlane((int)dirty[seg])) {
+            if ((threadIdx.x & 63) == 0) {
+                covw[seg] = 0ull;
+                if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;
+            }
+            return;                                                  // no workgroup barrier below: a clean wave leaves at once
         }
     }
-    float nvalid = 0.f;
+    bool valid_px = false;
     const int step_tag = (fu.stamp != nullptr) ? fu.stamp[0] - 1 : 0;   // read up front: inside the branch it costs a round trip
-    if (work) {
+    {
         const bool live = gid < (long long)n * P;
         unsigned long long key = live ? keys[gid] : ~0ull;
         const float mk = (live && fu.bwd16 != nullptr) ? fu.mask[gid] : 0.f;   // independent of the key: issued with it
@@ -379,7 +380,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                         PixShade s;
                         shade_eval_attr(fr.u, fr.v, q0, q1, u0, u1, w0, w1, shc, s);
                         col.x = s.rad * s.ar; col.y = s.rad * s.ag; col.z = s.rad * s.ab;
-                        nvalid = 1.f;
+                        valid_px = true;
                     }
                 }
             }
@@ -391,14 +392,14 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                 keys[gid] = ~0ull;
                 if (fu.shaded != nullptr) { fu.shaded[gid] = col; fu.aa_init[gid] = col; }   // zeros on the uncovered lanes
             }
-            if ((threadIdx.x & 63) == 0) { covw[seg] = bal; dirty[seg] = 0; }
+            const unsigned long long vbal = __ballot(valid_px);
+            if ((threadIdx.x & 63) == 0) {
+                covw[seg] = bal; dirty[seg] = 0;
+                if (fu.seg_valid != nullptr) fu.seg_valid[seg] = __popcll(vbal);     // valid (mask > 0 and covered) pixels of the segment
+            }
         } else if (live) {
             rast[gid] = o;
         }
-    }
-    if (fu.part_cnt != nullptr) {                                    // local count of valid (mask > 0 and covered) pixels
-        float s = block_sum(nvalid, sm);
-        if (threadIdx.x == 0) fu.part_cnt[blockIdx.x] = s;
     }
 }
 

@@ -63,18 +63,6 @@ __device__ __forceinline__ float block1024_sum(float v, float* sm16)
     return r;
 }
 
-// the valid-pixel count: sum of the resolve pass's per-workgroup counts (run by the extra last workgroup of k_active_segments)
-__device__ __forceinline__ void reduce_count_block(const float* __restrict__ part, int nb, int* __restrict__ n_valid,
-                                                   float* __restrict__ n_valid_f, float* sm16)
-{
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;     // independent chains: the loads overlap
-    int i = threadIdx.x;
-    for (; i + 3072 < nb; i += 4096) { acc0 += part[i]; acc1 += part[i + 1024]; acc2 += part[i + 2048]; acc3 += part[i + 3072]; }
-    for (; i < nb; i += 1024) acc0 += part[i];
-    float r = block1024_sum((acc0 + acc1) + (acc2 + acc3), sm16);
-    if (threadIdx.x == 0) { n_valid[0] = (int)(r + 0.5f); n_valid_f[0] = (float)(int)(r + 0.5f); }
-}
-
 // one lane per segment; the active ones are also compacted into act_list (order arbitrary) so that the per-pixel kernels
 // run as persistent loops over exactly the active segments: 2/3 of a frame's 197k waves would only be launched to exit
 constexpr int kActBlock = 1024;   // few, fat workgroups: the list cursors are same-address atomics (~10 ns each, serialised)
@@ -82,21 +70,21 @@ constexpr int kActBlock = 1024;   // few, fat workgroups: the list cursors are s
 __global__ void __launch_bounds__(kActBlock)
 k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
                   unsigned char* __restrict__ act, int* __restrict__ act_list, int* __restrict__ act_count,
-                  int* __restrict__ fill_list, const float* __restrict__ part_cnt, int nb_cnt, int* __restrict__ n_valid,
-                  float* __restrict__ n_valid_f)
+                  int* __restrict__ fill_list, const int* __restrict__ seg_valid, float* __restrict__ cnt_part)
 {
-    static_assert(kActBlock == 1024, "reduce_count_block is written for 1024 threads");
-    if (blockIdx.x == gridDim.x - 1) {                               // one extra workgroup: saves a ~5 us launch
-        __shared__ float sm16[16];
-        reduce_count_block(part_cnt, nb_cnt, n_valid, n_valid_f, sm16);
-        return;
-    }
     // act_count[0] = number of active segments (act_list), act_count[1] = number of active segments WITHOUT coverage (fill_list); both cursors
     // advance with ONE 64-bit atomic per workgroup (low word = active, high word = covered)
     constexpr int kWaves = kActBlock / 64;
     __shared__ int wcnt[kWaves], ccnt[kWaves];
     __shared__ int base, cbase;
+    __shared__ float sm16[16];
     long long seg = (long long)blockIdx.x * kActBlock + threadIdx.x;
+    {   // valid-pixel count: the resolve pass left one number per segment (it has no workgroup barrier: clean waves leave at
+        // once); summed per workgroup here, the next kernel adds the ~200 partials up
+        float v = (seg < nSeg && seg_valid != nullptr) ? (float)seg_valid[seg] : 0.f;
+        float sv = block1024_sum(v, sm16);
+        if (threadIdx.x == 0 && cnt_part != nullptr) cnt_part[blockIdx.x] = sv;
+    }
     bool a = (seg < nSeg) && segment_is_active(covw, vmnz, nSeg, W, seg, act);
     bool cv = a && covw[seg] == 0ull;                                // active without coverage: needs its zeros (k_fill_uncovered)
     unsigned long long bal = __ballot(a), cbal = __ballot(cv);
@@ -148,8 +136,16 @@ k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __re
 // ones) get their zeros here.
 __global__ void __launch_bounds__(kBlock)
 k_fill_uncovered(long long N, const int* __restrict__ fill_list, const int* __restrict__ fill_count,
-                 float4* __restrict__ shaded, float4* __restrict__ aa_init)
+                 float4* __restrict__ shaded, float4* __restrict__ aa_init, const float* __restrict__ cnt_part, int nb_cnt,
+                 int* __restrict__ n_valid, float* __restrict__ n_valid_f)
 {
+    if (blockIdx.x == 0) {                                           // the step's local valid-pixel count (saves a launch)
+        __shared__ float sm[4];
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < nb_cnt; i += kBlock) acc += cnt_part[i];
+        float r = block_sum(acc, sm);
+        if (threadIdx.x == 0) { n_valid[0] = (int)(r + 0.5f); n_valid_f[0] = (float)(int)(r + 0.5f); }
+    }
     const int count = *fill_count, lane = threadIdx.x & 63;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
@@ -482,13 +478,12 @@ int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char
 }
 
 int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
-                         int* act_list, int* act_count, int* fill_list, const float* part_cnt, int nb_cnt, int* n_valid,
-                         float* n_valid_f, hipStream_t st)
+                         int* act_list, int* act_count, int* fill_list, const int* seg_valid, float* cnt_part, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     long long nSeg = (N + 63) >> 6;
-    k_active_segments<<<cdiv(nSeg, kActBlock) + 1, kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, fill_list, part_cnt,
-                                                                       nb_cnt, n_valid, n_valid_f);
+    k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, fill_list, seg_valid,
+                                                                   cnt_part);
     FMHR_CHECK_LAUNCH("k_active_segments");
     return FMHR_OK;
 }
@@ -502,10 +497,13 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
     return FMHR_OK;
 }
 
-int fill_uncovered_impl(long long N, const int* fill_list, const int* fill_count, float* shaded, float* aa_init, hipStream_t st)
+int fill_uncovered_impl(long long N, const int* fill_list, const int* fill_count, float* shaded, float* aa_init, const float* cnt_part,
+                        int* n_valid, float* n_valid_f, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_fill_uncovered<<<1024, kBlock, 0, st>>>(N, fill_list, fill_count, (float4*)shaded, (float4*)aa_init);
+    const int nb_cnt = cdiv((N + 63) >> 6, kActBlock);               // workgroups of k_active_segments
+    k_fill_uncovered<<<1024, kBlock, 0, st>>>(N, fill_list, fill_count, (float4*)shaded, (float4*)aa_init, cnt_part, nb_cnt, n_valid,
+                                              n_valid_f);
     FMHR_CHECK_LAUNCH("k_fill_uncovered");
     return FMHR_OK;
 }

@@ -89,7 +89,7 @@ struct RasterFused {
     int4* cov16; int* stamp; unsigned char* own8;             // coverage entries, step counter, owner marks (face-parallel backward)
     float4* bwd16; const float* mask;                         // per covered pixel (u, v, owner, flags)
     const float4* attr8; const float* sh;                     // forward shading inputs
-    float4* shaded; float4* aa_init; float* part_cnt;         // forward shading outputs + per-workgroup valid-pixel counts
+    float4* shaded; float4* aa_init; int* seg_valid;          // forward shading outputs + valid-pixel count of every segment
     int* rearm2;                                              // two list cursors the resolve pass zeroes for the next kernel
     int* rearm_aa;                                            // antialias work-item counter + overflow flag, likewise
 };
