@@ -576,7 +576,7 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
     const float bx = g_xb * xh * wb, by = g_yb * yh * wb, bw = -(g_xb * pb.x * xh + g_yb * pb.y * yh) * wb * wb;
     if (cmat != nullptr) {
         // fused step: apply the clip-transform backward here and accumulate straight into the view-independent [V,3] buffer
-        const float4 c0 = cmat[(size_t)b * 3], c1 = cmat[(size_t)b * 3 + 1], c2 = cmat[(size_t)b * 3 + 2];
+        const float4 c0 = cmat[(size_t)b * 4], c1 = cmat[(size_t)b * 4 + 1], c2 = cmat[(size_t)b * 4 + 2];
         float* qa = gvert + (size_t)va * 3;
         float* qb = gvert + (size_t)vb * 3;
         atomicAdd(qa + 0, ax * c0.x + ay * c0.y + aw * c0.z);

@@ -51,7 +51,7 @@ int fill_uncovered_impl(long long, const int*, const int*, float*, float*, const
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
-                  const int*, const int32_t*, const float*, int, int, int, int, int, float*, hipStream_t);
+                  const int*, const int32_t*, const float*, const float*, int, int, int, int, int, float*, hipStream_t);
 int face_bwd_groups(int n);
 
 // workspace carving: every block 256-B aligned
@@ -101,7 +101,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.aa_region_cnt = take(off, 2048 * 4);            // items per region of the list (one region per workgroup of the AA kernels)
     L.g_aa = take(off, nP * 16);
     L.g_shaded = take(off, nP * 16);
-    L.cmat = take(off, (size_t)d->n * 48);
+    L.cmat = take(off, (size_t)d->n * 64);
     L.gvert_aa = take(off, V * 12);
     L.part = take(off, (size_t)face_bwd_groups(d->n) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
     L.partials = take(off, 2048 * 4 * 3);           // per-workgroup partial sums of the persistent pixel kernels
@@ -308,7 +308,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         // shade + interpolate + rasterize + clip-transform backward, face-parallel (shade.hip: k_face_bwd)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
         TRY(face_bwd_impl((const float*)(w + L.bwd16), tri, pos, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
-                          w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot, (const float*)(w + L.cmat), d->n,
+                          w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot, (const float*)(w + L.cmat), vertices, d->n,
                           d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
     }
     {

@@ -249,16 +249,17 @@ k_transform_fwd(const float* __restrict__ verts, const float* __restrict__ w2c, 
 {
     int v = blockIdx.x * kBlock + threadIdx.x;
     int b = blockIdx.y;
-    if (v >= V) return;
     const float* A = w2c + (size_t)b * 16;
     const float* B = proj + (size_t)b * 16;
-    if (cmat != nullptr && v < 3) {
-        // d pos_l / d vertex_v = (w2c @ proj)[v][l]: row v of the combined matrix, columns (x, y, w) — what the backward needs
+    if (cmat != nullptr && v < 4) {
+        // row v of the combined matrix w2c @ proj, columns (x, y, w): rows 0..2 = d pos / d vertex_v (the clip-transform backward),
+        // with the translation row 3 the backward also recomputes a face's clip positions from its three vertices
         float c[4];
 #pragma unroll
         for (int l = 0; l < 4; l++) c[l] = A[v * 4] * B[l] + A[v * 4 + 1] * B[4 + l] + A[v * 4 + 2] * B[8 + l] + A[v * 4 + 3] * B[12 + l];
-        cmat[(size_t)b * 3 + v] = make_float4(c[0], c[1], c[3], 0.f);
+        cmat[(size_t)b * 4 + v] = make_float4(c[0], c[1], c[3], 0.f);
     }
+    if (v >= V) return;
     float x = verts[(size_t)v * 3], y = verts[(size_t)v * 3 + 1], z = verts[(size_t)v * 3 + 2];
     float r[4], o[4];
 #pragma unroll

@@ -230,11 +230,11 @@ __device__ __forceinline__ float group_sum(float x)
 }
 
 struct int3a { int x, y, z; };
-struct FaceAttr { float3 n2, dn0, dn1, a2, da0, da1; };
+struct FaceAttr { float3 n2, dn0, dn1, a2, da0, da1, v0, v1, v2; };    // corner-2-relative attributes + the three vertex positions
 
 // backward of ONE pixel of a face for all three corners; A[k] += (g_normal.xyz, g_albedo.xyz, g_vertex.xyz) of corner k.
 // c = the view's 9 SH coefficients followed by its clip matrix rows (view_c layout).
-__device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr& fa_lds, const float4 p0, const float4 p1, const float4 p2,
+__device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr& fa_lds,
                                                const float* __restrict__ c, float u, float v, const float4 gs, int px, int py,
                                                float xs, float xo, float ys, float yo)
 {
@@ -269,9 +269,19 @@ __device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr&
     // rasterize backward (Appendix B.1) for the three corners, pushed through the view's clip transform (c[9..]: rows of
     // w2c @ proj, mesh.hip k_transform_fwd): the position gradients become view-independent
     const float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
-    const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-    const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-    const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    // the three clip positions (x, y, w) of this view, recomputed from the face's vertices and the view's combined matrix
+    // (c[9..24]: rows of w2c @ proj, columns x, y, w): 27 FMAs instead of three 16-B gathers per (face, view)
+    float pp[9];
+    {
+        const float3 vv[3] = {fa.v0, fa.v1, fa.v2};
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int l = 0; l < 3; l++) pp[k * 3 + l] = vv[k].x * c[9 + l] + vv[k].y * c[13 + l] + vv[k].z * c[17 + l] + c[21 + l];
+    }
+    const float p0x = pp[0] - fx * pp[2], p0y = pp[1] - fy * pp[2];
+    const float p1x = pp[3] - fx * pp[5], p1y = pp[4] - fy * pp[5];
+    const float p2x = pp[6] - fx * pp[8], p2y = pp[7] - fy * pp[8];
     const float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
     const float iw = frcp(e0 + e1 + e2);
     const float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * (e0 * iw) + gb1 * (e1 * iw);
@@ -289,35 +299,35 @@ __device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr&
     }
 }
 
-constexpr int kTaskG = 64;                       // candidate pixels a group expands per round
+constexpr int kTaskG = 32;                       // candidate pixels a group expands per round
 constexpr int kFacesPerBlock = kBlock / kGroup;
-constexpr int kMaxVPL = 3;                       // views per lane: a group of kGroup lanes covers kGroup * VPL views of one face
+constexpr int kMaxVPL = 6;                       // views per lane: a group of kGroup lanes covers kGroup * VPL views of one face
 
 // VPL views per lane: the fixed part of a (face, view group) — vertex ids, attributes, output slots, the DPP sum, the output
 // store, the launch — is paid once per kGroup * VPL views, and the partial planes the mesh tail has to add up shrink with it.
 template <int VPL>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(kBlock)
 k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
            const int4* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
-           const float4* __restrict__ cmat, int n, int V, int F, int H, int W, float4* __restrict__ part)
+           const float4* __restrict__ cmat, const float* __restrict__ verts, int n, int V, int F, int H, int W,
+           float4* __restrict__ part)
 {
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
     constexpr int GV = kGroup * VPL;                               // views per group
-    __shared__ float view_c[GV][24];                               // per view of the group: 9 SH coefficients, 12 clip-matrix entries
-    __shared__ float4 pk_pos[kBlock * VPL][3];                     // per (face, view): the three clip positions
-    __shared__ int2 pk_box[kBlock * VPL];                          // box origin (pxa | pya << 16), box width
+    __shared__ float view_c[GV][28];                               // per view of the group: 9 SH coefficients, 4 x 4 clip-matrix entries
+    __shared__ int pk_box[kBlock * VPL];                           // box: pxa | pya << 13 | (width - 1) << 26
     __shared__ FaceAttr pk_attr[kFacesPerBlock];
     __shared__ unsigned short tasks[kFacesPerBlock][kTaskG];
     const long long P = (long long)H * W;
     const int tid = threadIdx.x, j = tid & (kGroup - 1), gl = tid / kGroup, lane = tid & 63;
     const int f = blockIdx.x * kFacesPerBlock + gl;
     const int g = blockIdx.y, b0 = g * GV;                         // view of (lane j, slot v) = b0 + v * kGroup + j
-    for (int i = tid; i < GV * 24; i += kBlock) {
-        const int vb = i / 24, k = i - vb * 24, bb = b0 + vb;
+    for (int i = tid; i < GV * 28; i += kBlock) {
+        const int vb = i / 28, k = i - vb * 28, bb = b0 + vb;
         float v = 0.f;
-        if (bb < n) v = (k < 9) ? sh[(size_t)bb * 9 + k] : ((k < 21) ? reinterpret_cast<const float*>(cmat)[(size_t)bb * 12 + (k - 9)] : 0.f);
+        if (bb < n) v = (k < 9) ? sh[(size_t)bb * 9 + k] : ((k < 25) ? reinterpret_cast<const float*>(cmat)[(size_t)bb * 16 + (k - 9)] : 0.f);
         view_c[vb][k] = v;
     }
     __syncthreads();                                               // the only workgroup barrier: everything below is per wave
@@ -375,12 +385,8 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
 #pragma unroll
         for (int v = 0; v < VPL; v++)
             if (kind[v] != 0) {
-                const float* vp = pos + (size_t)(b0 + v * kGroup + j) * V * 4;
-                float4 p0 = ldg4(vp + (size_t)ti.x * 4), p1 = ldg4(vp + (size_t)ti.y * 4), p2 = ldg4(vp + (size_t)ti.z * 4);
-                pin(p0); pin(p1); pin(p2);
                 const int at = tid * VPL + v;
-                pk_pos[at][0] = p0; pk_pos[at][1] = p1; pk_pos[at][2] = p2;
-                pk_box[at] = make_int2(e[v].z, kind[v]);
+                pk_box[at] = (e[v].z & 0x1fff) | (((e[v].z >> 16) & 0x1fff) << 13) | (((kind[v] - 1) & 63) << 26);
             }
         if (j == 0 && group_any) {
             const float4 q0 = attr8[(size_t)ti.x * 2], q1 = attr8[(size_t)ti.x * 2 + 1];
@@ -392,6 +398,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             fa.da0 = make_float3(q0.w - fa.a2.x, q1.x - fa.a2.y, q1.y - fa.a2.z);
             fa.dn1 = make_float3(u0.x - fa.n2.x, u0.y - fa.n2.y, u0.z - fa.n2.z);
             fa.da1 = make_float3(u0.w - fa.a2.x, u1.x - fa.a2.y, u1.y - fa.a2.z);
+            fa.v0 = ld3f(verts + (size_t)ti.x * 3); fa.v1 = ld3f(verts + (size_t)ti.y * 3); fa.v2 = ld3f(verts + (size_t)ti.z * 3);
             pk_attr[gl] = fa;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -419,17 +426,17 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             for (int t = j; t < nt; t += kGroup) {
                 const int en = tasks[gl][t], vs = en >> 6, bit = en & 63;
                 const int src = ((tid & ~(kGroup - 1)) + (vs & (kGroup - 1))) * VPL + (vs >> 3);
-                const int2 box = pk_box[src];
+                const int box = pk_box[src];
                 int c;
-                const int r = fast_divmod(bit, box.y, c);
-                const int px = (box.x & 0xffff) + c, py = (box.x >> 16) + r;
+                const int r = fast_divmod(bit, ((box >> 26) & 63) + 1, c);
+                const int px = (box & 0x1fff) + c, py = ((box >> 13) & 0x1fff) + r;
                 const long long gid = (long long)(b0 + vs) * P + (long long)py * W + px;
                 float4 w = bwd16[gid];
                 float4 gs = g_shaded[gid];
                 pin(w); pin(gs);
                 // owner == this face, mask > 0 and not a list pixel (flags == 1), non-zero image gradient
                 if (__float_as_int(w.z) == f && w.w == 1.f && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f))
-                    pixel_backward(A, fa, pk_pos[src][0], pk_pos[src][1], pk_pos[src][2], &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
+                    pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -438,7 +445,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
 #pragma unroll
         for (int v = 0; v < VPL; v++) {
             if (kind[v] != 255) continue;
-            const int vs = v * kGroup + j, at = tid * VPL + v;
+            const int vs = v * kGroup + j;
             int p = e[v].x;
             while (p >= 0) {
                 const long long gid = (long long)(b0 + vs) * P + p;
@@ -448,7 +455,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
                 if (w.w == 3.f && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) {
                     int px;
                     const int py = fast_divmod(p, W, px);
-                    pixel_backward(A, fa, pk_pos[at][0], pk_pos[at][1], pk_pos[at][2], &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
+                    pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
                 }
                 p = __float_as_int(w.z);
             }
@@ -520,26 +527,30 @@ int loss_pix_impl(const unsigned long long* covw, const float* aa, const float* 
     return FMHR_OK;
 }
 
-// views per lane: one group spans the whole batch when it can (up to kGroup * kMaxVPL = 24 views; measured at 48 views:
-// 2 / 3 / 4 / 6 views per lane -> 149 / 119 / 149 / 202 us, the LDS parking limits the workgroups per CU beyond 3)
+// views per lane: one group spans the whole batch when it can (up to kGroup * kMaxVPL = 48 views).  Measured at 48 views, with
+// the clip positions recomputed in-kernel (no LDS parking of positions): 2 / 3 / 4 / 6 views per lane -> 124 / 111 / 110 / 97 us,
+// and one partial plane instead of several for the mesh tail to add up
 static int face_bwd_vpl(int n) { return min(kMaxVPL, cdiv(n, kGroup)); }
 
 int face_bwd_groups(int n) { return cdiv(n, kGroup * face_bwd_vpl(n)); }
 
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
                   const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
-                  int n, int V, int F, int H, int W, float* part, hipStream_t st)
+                  const float* verts, int n, int V, int F, int H, int W, float* part, hipStream_t st)
 {
     if (n == 0 || F == 0) return FMHR_OK;
     const dim3 grid(cdiv(F, kFacesPerBlock), face_bwd_groups(n));
 #define FMHR_FACE_BWD(VPL)                                                                                                          \
     k_face_bwd<VPL><<<grid, kBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
-                                             (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, n, V, F, H, W,     \
+                                             (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, n, V, F, H, W, \
                                              (float4*)part)
     switch (face_bwd_vpl(n)) {
         case 1: FMHR_FACE_BWD(1); break;
         case 2: FMHR_FACE_BWD(2); break;
-        default: FMHR_FACE_BWD(3); break;
+        case 3: FMHR_FACE_BWD(3); break;
+        case 4: FMHR_FACE_BWD(4); break;
+        case 5: FMHR_FACE_BWD(5); break;
+        default: FMHR_FACE_BWD(6); break;
     }
 #undef FMHR_FACE_BWD
     FMHR_CHECK_LAUNCH("k_face_bwd");
