@@ -266,6 +266,10 @@ def main():
                               "frac": step_gbs / HBM_PEAK_GBS, "alg_bytes_per_step": sb, "device_ms_per_step": step_dev_ms,
                               "traffic_low_high": [traffic["step_total_low"], traffic["step_total_high"]] if traffic else None},
             "kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
+            # every launch group against the same yardstick (untimed profiling pass): algorithmic GB/s and, where the committed PMC
+            # profile has it, the measured HBM bytes of the launch
+            "groups": {k: {"ms": round(v, 4), "alg_gbs": round(alg_bytes(k, n, P, V, F, hs.nnz) / max(v, 1e-9) / 1e6, 1),
+                           "hbm_bytes": (traffic or {}).get(k)} for k, v in kernels.items() if alg_bytes(k, n, P, V, F, hs.nnz) > 0},
             "losses": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in final.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -97,6 +97,63 @@ def test_fused_step_vs_oracle(oracle, case):
     assert rel_err(hs.gdelta, g1) < 5e-5
 
 
+def _step_vs_oracle(oracle, sc, name, osc=None):
+    """one fused step against the fp32 oracle (bit-identical rast) and the fp64-on-fp32-decisions oracle (values).
+    `osc`: the scene the oracle sees when it must differ from the GPU's (see the empty-valid-set case)."""
+    osc = osc or sc
+    from fmhr_amd.ham import HamStage2
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    losses, gdelta, galbedo = hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"],
+                                      g["valid_mask"])
+    ld = hs.loss_dict()
+    v = hs.views()
+    pos_gpu = v["pos"].cpu()
+
+    def run_oracle(dtype):
+        c = lambda t: t.to(dtype)
+        d = c(sc["delta"]).clone().requires_grad_(True)
+        a = c(sc["albedo"])[None].clone().requires_grad_(True)
+        ref = oracle.ham_stage2_losses(c(sc["vertices"]), d, a, c(sc["sh0"]), c(sc["w2c"]), c(sc["proj"]), c(sc["img"]),
+                                       c(osc["mask"]), c(sc["valid_mask"]), sc["faces"], (sc["H"], sc["W"]), osc["weights"],
+                                       sc["elm"], pos_value=pos_gpu)
+        ref["loss"].backward()
+        return ref, d.grad, a.grad[0]
+
+    ref, gd32, ga32 = run_oracle(torch.float32)
+    assert torch.equal(v["rast"].cpu(), ref["rast"]), name
+    assert osc is not sc or ld["n_valid"] == ref["n_valid"], name
+    with oracle.f32_decisions():
+        ref64, gd64, ga64 = run_oracle(torch.float64)
+    for k in ("sfs", "lap", "albedo", "mask", "edge", "delta"):
+        assert abs(ld[k] - float(ref64[k])) <= TOL * max(abs(float(ref64[k])), 1e-6), (name, k, ld[k], float(ref64[k]))
+    assert all(torch.isfinite(t).all() for t in (losses, gdelta, galbedo)), name
+    e_d, e_a = rel_err(gdelta, gd64), rel_err(galbedo, ga64)
+    o_d, o_a = rel_err(gd32, gd64), rel_err(ga32, ga64)
+    assert e_d < max(TOL, 2 * o_d) and e_a < max(TOL, 2 * o_a), (name, e_d, e_a, o_d, o_a)
+    return ld, v
+
+
+def test_fused_step_edge_cases(oracle):
+    """views without any coverage, and a batch without a single valid pixel (the L1 mean over an empty set)."""
+    # (a) the middle view looks past the mesh (clip x shifted by 5 w): no fragment, no coverage entry, empty segments
+    sc = prepare(oracle, (3, 96, 80, 12, 16), 11)
+    sc["proj"] = sc["proj"].clone()
+    sc["proj"][1, :, 0] += 5.0 * sc["proj"][1, :, 3]
+    sc["mask"] = sc["mask"].clone()
+    sc["mask"][1] = 0
+    ld, v = _step_vs_oracle(oracle, sc, "empty view")
+    assert float(v["rast"][1].abs().sum()) == 0.0 and float(v["pred_mask"][1].abs().sum()) == 0.0
+    # (b) no valid pixel at all: mask == 0 everywhere -> n_valid = 0.  The reference's F.l1_loss over an empty selection is NaN
+    # (0 / 0); the build defines the term and its gradient as 0 there, i.e. the step must equal the one with sfs weight 0
+    sc = prepare(oracle, (2, 96, 80, 12, 16), 12)
+    osc = dict(sc, weights=dict(sc["weights"], sfs=0.0))
+    sc = dict(sc, mask=torch.zeros_like(sc["mask"]))
+    ld, v = _step_vs_oracle(oracle, sc, "no valid pixel", osc)
+    assert ld["n_valid"] == 0 and ld["sfs"] == 0.0
+
+
 def test_unchanged_loop_body_on_dr(oracle):
     """the reference's own loop body (mesh_sfs_optim.py:253-306, restated verbatim in oracle.ham_stage2_losses) executed on
     fmhr_amd.dr / fmhr_amd.utils GPU ops must agree with the fused step and with the CPU oracle."""
