@@ -37,7 +37,7 @@ int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const 
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const int32_t*, const float*,
                 const int32_t*, int, int, int, int, float*, const float*, float*, hipStream_t);
 int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, const float*,
-                            float*, hipStream_t);
+                            float*, const float*, float*, hipStream_t);
 int normals_bwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, float*,
                             float*, hipStream_t);
 int edge_hinge_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, int, float, float, float, float*,
@@ -226,9 +226,9 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     unsigned long long* covw = (unsigned long long*)(w + L.covw);
     {
         ProfScope ps(FMHR_SLOT_GEOMETRY, st);
-        TRY(add_delta_impl(vertices_tmp, delta, d->V * 3, vertices, st));
-        TRY(normals_fwd_gather_impl(vertices, tri, vf_ptr, vf_idx, d->V, (float*)(w + L.nsum), (float*)(w + L.normals), albedo,
-                                    (float*)(w + L.attr8), st));
+        // vertices = vertices_tmp + delta is formed inside the normals kernel (and stored for everything after it)
+        TRY(normals_fwd_gather_impl(vertices_tmp, tri, vf_ptr, vf_idx, d->V, (float*)(w + L.nsum), (float*)(w + L.normals), albedo,
+                                    (float*)(w + L.attr8), delta, vertices, st));
         TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), st));
     }
     {

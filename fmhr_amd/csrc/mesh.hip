@@ -405,19 +405,28 @@ __device__ __forceinline__ float sum_sub(float x)
 __global__ void __launch_bounds__(kBlock)
 k_normals_gather(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
                  const int32_t* __restrict__ vf_idx, int V, float* __restrict__ nsum, float* __restrict__ normals,
-                 const float* __restrict__ albedo, float4* __restrict__ attr8)
+                 const float* __restrict__ albedo, float4* __restrict__ attr8, const float* __restrict__ delta,
+                 float* __restrict__ vout)
 {
+    // fused step: vertex = verts + delta (mesh_sfs_optim.py:255), formed on the fly and stored for the later kernels by the
+    // vertex's first lane (saves the separate add launch); stand-alone op: delta == nullptr
+    auto vertex = [&](int i) {
+        float3 q = ld3(verts + (size_t)i * 3);
+        if (delta != nullptr) { const float3 dl = ld3(delta + (size_t)i * 3); q.x = q.x + dl.x; q.y = q.y + dl.y; q.z = q.z + dl.z; }
+        return q;
+    };
     const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
     const bool live = v < V;
     const int vv = live ? v : 0;
     float3 acc = make_float3(0.f, 0.f, 0.f);
     if (live) {
-        float3 p = ld3(verts + (size_t)vv * 3);
+        float3 p = vertex(vv);
+        if (vout != nullptr && sub == 0) { vout[(size_t)vv * 3] = p.x; vout[(size_t)vv * 3 + 1] = p.y; vout[(size_t)vv * 3 + 2] = p.z; }
         for (int e = vf_ptr[vv] + sub; e < vf_ptr[vv + 1]; e += kSubLanes) {
             int code = vf_idx[e];
             int f = code / 3, k = code - f * 3;
             int k1 = (k + 1 == 3) ? 0 : k + 1, k2 = (k1 + 1 == 3) ? 0 : k1 + 1;
-            float3 a = ld3(verts + (size_t)tri[f * 3 + k1] * 3), b = ld3(verts + (size_t)tri[f * 3 + k2] * 3);
+            float3 a = vertex(tri[f * 3 + k1]), b = vertex(tri[f * 3 + k2]);
             float3 c = cross3(sub3(a, p), sub3(b, p));      // corner k: cross(v[k+1]-v[k], v[k+2]-v[k]) (models/utils.py:517-543)
             acc.x += c.x; acc.y += c.y; acc.z += c.z;
         }
@@ -745,10 +754,11 @@ int mesh_tail_impl(const MeshTailArgs& A, float* gdelta, float* galbedo, const F
 
 // ---- internal launchers used by ham_step.hip
 int normals_fwd_gather_impl(const float* verts, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, int V,
-                            float* nsum, float* normals, const float* albedo, float* attr8, hipStream_t st)
+                            float* nsum, float* normals, const float* albedo, float* attr8, const float* delta, float* vout,
+                            hipStream_t st)
 {
     if (V == 0) return FMHR_OK;
-    k_normals_gather<<<cdiv((long long)V * kSubLanes, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, (float4*)attr8);
+    k_normals_gather<<<cdiv((long long)V * kSubLanes, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, (float4*)attr8, delta, vout);
     FMHR_CHECK_LAUNCH("k_normals_gather");
     return FMHR_OK;
 }
