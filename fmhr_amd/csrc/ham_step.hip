@@ -19,6 +19,7 @@ struct MeshTailArgs {
 struct FinishArgs {
     float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
     const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
+    const float* edge_part; int edge_nb;
     float reg_scale, nvalid_scale;
 };
 int mesh_tail_impl(const MeshTailArgs&, float*, float*, const FinishArgs&, hipStream_t);
@@ -50,14 +51,16 @@ int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t
 int fill_uncovered_impl(long long, const int*, const int*, float*, float*, const float*, int*, float*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
+struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; };
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
-                  const int*, const int32_t*, const float*, const float*, int, int, int, int, int, float*, hipStream_t);
+                  const int*, const int32_t*, const float*, const float*, const EdgeTerm&, int, int, int, int, int, float*, hipStream_t);
 int face_bwd_groups(int n);
+int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt, g_aa,
-        g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, seg_valid, cnt_part, total;
+        g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, seg_valid, cnt_part, edge_part, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -115,6 +118,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.n_valid_f = take(off, 16);                    // float copy of n_valid_local (a ready n_valid_global for the one-rank case)
     L.seg_valid = take(off, ((nP + 63) / 64) * 4);   // valid-pixel count of every segment (resolve pass)
     L.cnt_part = take(off, (((nP + 63) / 64 + 1023) / 1024) * 4);   // the same per workgroup of k_active_segments
+    L.edge_part = take(off, (size_t)face_bwd_blocks(d->F) * 4);   // per-workgroup edge-hinge loss sums of k_face_bwd
     L.total = off;
     return L;
 }
@@ -307,9 +311,15 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     {
         // shade + interpolate + rasterize + clip-transform backward, face-parallel (shade.hip: k_face_bwd)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
+        // the per-face edge hinge rides along: faces [f0, f1) = this rank's share of the view-independent terms
+        EdgeTerm et;
+        et.part = (float*)(w + L.edge_part);
+        et.f0 = (rg != 0.f) ? (int)((long long)wt->reg_v0 * d->F / d->V) : 0;
+        et.f1 = (rg != 0.f) ? (int)((long long)wt->reg_v1 * d->F / d->V) : 0;
+        et.mean = wt->edge_length_mean; et.w = wt->edge / (3.0f * (float)d->F); et.gk = 2.f * et.w * rg;
         TRY(face_bwd_impl((const float*)(w + L.bwd16), tri, pos, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
-                          w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot, (const float*)(w + L.cmat), vertices, d->n,
-                          d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
+                          w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot,
+                          (const float*)(w + L.cmat), vertices, et, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
     }
     {
         // everything per-vertex after the gather, in two kernels (mesh.hip: k_mesh_tail_a / _b)
@@ -329,6 +339,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         fin.losses = losses; fin.n_valid = n_valid_global; fin.part_l1 = (const float*)(w + L.partials) + nB;
         fin.part_l2 = (const float*)(w + L.partials) + 2 * nB; fin.nb = (int)nB; fin.tail_part = (const float*)(w + L.tail_part);
         fin.tail_nb = mesh_tail_blocks(d->V); fin.w_sfs = wt->sfs; fin.w_mask = wt->mask; fin.mse_den = wt->mse_denominator;
+        fin.edge_part = (const float*)(w + L.edge_part); fin.edge_nb = face_bwd_blocks(d->F);
         fin.reg_scale = (rg != 0.f) ? 1.f : 0.f;
         fin.nvalid_scale = (rg != 0.f && wt->reg_v0 == 0) ? 1.f : 0.f;
         TRY(mesh_tail_impl(A, gdelta, galbedo, fin, st));

@@ -571,29 +571,10 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
             la[0] += ya.x - xa.x; la[1] += ya.y - xa.y; la[2] += ya.z - xa.z;
         }
     }
-    // (5) edge hinge (mesh_sfs_optim.py:296-302): a face's loss is accounted by its corner 0, gradients by each corner
-    float3 eg = make_float3(0.f, 0.f, 0.f);
-    if (mine) {
-        const float gk = 2.f * A.edge_w * A.rg;
-        for (int e = A.vf_ptr[vv] + sub; e < A.vf_ptr[vv + 1]; e += kSubLanes) {
-            int code = A.vf_idx[e];
-            int f = code / 3, c = code - f * 3;
-            float3 a = ld3(A.verts + (size_t)A.tri[f * 3] * 3), b = ld3(A.verts + (size_t)A.tri[f * 3 + 1] * 3),
-                   cc = ld3(A.verts + (size_t)A.tri[f * 3 + 2] * 3);
-            float3 ed[3] = {sub3(a, b), sub3(cc, b), sub3(a, cc)};
-            const float sgn[3][3] = {{1.f, 0.f, 1.f}, {-1.f, -1.f, 0.f}, {0.f, 1.f, -1.f}};
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                float l2 = ed[k].x * ed[k].x + ed[k].y * ed[k].y + ed[k].z * ed[k].z;
-                float d = l2 - A.edge_mean;
-                if (c == 0) l_edge += fminf(fmaxf(d, 0.f), 1.f);
-                float sg = sgn[c][k];
-                if (d > 0.f && d < 1.f && sg != 0.f) { eg.x += gk * sg * ed[k].x; eg.y += gk * sg * ed[k].y; eg.z += gk * sg * ed[k].z; }
-            }
-        }
-    }
+    // (5) the edge hinge (mesh_sfs_optim.py:296-302) is a per-FACE term: the face-parallel backward, which holds every face's
+    //     three vertices anyway, adds its gradient to the corner sums and keeps the loss partials (shade.hip: k_face_bwd)
     n0 = sum_sub(n0); n1 = sum_sub(n1); n2 = sum_sub(n2); a0 = sum_sub(a0); a1 = sum_sub(a1); a2 = sum_sub(a2);
-    gx = sum_sub(gx + eg.x); gy = sum_sub(gy + eg.y); gz = sum_sub(gz + eg.z);
+    gx = sum_sub(gx); gy = sum_sub(gy); gz = sum_sub(gz);
 #pragma unroll
     for (int c = 0; c < 3; c++) { lv[c] = sum_sub(lv[c]); la[c] = sum_sub(la[c]); }
     if (live && sub == 0) {
@@ -645,7 +626,7 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
     float s;
     s = block_sum(l_lap, sm);   if (threadIdx.x == 0) A.loss_part[blockIdx.x] = s * A.lap_w;
     s = block_sum(l_alb, sm);   if (threadIdx.x == 0) A.loss_part[gridDim.x + blockIdx.x] = s * A.alb_w;
-    s = block_sum(l_edge, sm);  if (threadIdx.x == 0) A.loss_part[2 * gridDim.x + blockIdx.x] = s * A.edge_w;
+    if (threadIdx.x == 0) A.loss_part[2 * gridDim.x + blockIdx.x] = 0.f;      // slot kept for layout; the edge term lives in edge_part
     s = block_sum(l_delta, sm); if (threadIdx.x == 0) A.loss_part[3 * gridDim.x + blockIdx.x] = s * A.delta_w;
 }
 
@@ -654,6 +635,7 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
 struct FinishArgs {
     float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
     const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
+    const float* edge_part; int edge_nb;      // weighted per-workgroup edge-hinge sums of k_face_bwd
     float reg_scale;      // 0 switches the view-independent loss slots off (reg_grad_scale = 0)
     float nvalid_scale;   // 1 on the one rank that reports n_valid: summing the loss vectors of all ranks gives the global values
 };
@@ -666,6 +648,11 @@ __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* 
         float t = 0.f;
         for (int j = threadIdx.x; j < A.tail_nb; j += kBlock) t += A.tail_part[(size_t)k * A.tail_nb + j];
         r[k] = block_sum(t, sm4);
+    }
+    {
+        float t = 0.f;
+        for (int j = threadIdx.x; j < A.edge_nb; j += kBlock) t += A.edge_part[j];
+        r[2] = block_sum(t, sm4);
     }
     float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
     int i = threadIdx.x;
