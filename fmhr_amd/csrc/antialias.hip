@@ -523,7 +523,8 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          const float* __restrict__ pos, const int32_t* __restrict__ tri, const float* __restrict__ dyA,
          const float* __restrict__ dyB, int V, int H, int W, int Cdyn,
          float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos,
-         const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr)
+         const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr, bool use_gl = false,
+         float4 gl = make_float4(0.f, 0.f, 0.f, 0.f))
 {
     const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
@@ -534,7 +535,9 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
     const int C = (CA > 0) ? CA : Cdyn;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        float g = dyA[tgt * C + c];
+        float g;                                                          // fused step: the target's gradient is handed in
+        if (use_gl) g = (c == 0) ? gl.x : ((c == 1) ? gl.y : ((c == 2) ? gl.z : gl.w));
+        else g = dyA[tgt * C + c];
         galpha += g * (colorA[pix1 * C + c] - colorA[pix0 * C + c]);
         if (gcolorA != nullptr && g != 0.f) {
             atomicAdd(gcolorA + pix1 * C + c, alpha * g);
@@ -610,19 +613,43 @@ k_aa_bwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
     }
 }
 
-// backward over the work-item list of the fused step: one workgroup per region of the list, dense items
+// backward over the work-item list of the fused step: one workgroup per region of the list, dense items.  d loss / d aa of an
+// item's target pixel is RECOMPUTED here from the loss definition (k_loss_pix: L1 over valid pixels + silhouette MSE) — a few
+// hundred thousand items — instead of being stored by k_loss_pix for all 4.4 M active pixels in a second gradient image
+struct LossGrad {
+    const float4* aa; const float* img; const float* mask; const float* valid_mask; const unsigned long long* covw;
+    const float* n_valid; float w_sfs, w_mask, mse_den;
+};
+
 __global__ void __launch_bounds__(kBlock)
 k_aa_bwd_items(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
-               const int32_t* __restrict__ tri, const float* __restrict__ dy, const int4* __restrict__ items,
+               const int32_t* __restrict__ tri, const LossGrad L, const int4* __restrict__ items,
                const float* __restrict__ alphas, const int32_t* __restrict__ region_cnt, int cap, int V, int H, int W,
                float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert)
 {
     const int region = cap / (int)gridDim.x, count = region_cnt[blockIdx.x];      // same grid as k_aa_fwd_list
     const size_t rbase = (size_t)blockIdx.x * region;
+    const float den = 3.0f * L.n_valid[0];
+    const float k1 = (den > 0.f) ? L.w_sfs / den : 0.f, k2 = L.w_mask / L.mse_den;
     for (int i = threadIdx.x; i < count; i += kBlock) {
         const int4 it = items[rbase + i];
-        aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alphas[rbase + i], color, nullptr, rast, pos, tri, dy, nullptr, V, H, W, 4, gcolor, nullptr,
-                          nullptr, cmat, gvert);
+        const float alpha = alphas[rbase + i];
+        const long long pix0 = ((long long)it.z * H + it.y) * W + it.x;
+        const long long tgt = (alpha > 0.f) ? pix0 : pix0 + ((it.w & AA_DOWN) ? W : 1);
+        const float4 a = L.aa[tgt];
+        const F3U im = *reinterpret_cast<const F3U*>(L.img + tgt * 3);
+        const float mk = L.mask[tgt], vm = L.valid_mask[tgt];
+        const bool cov = (L.covw[tgt >> 6] >> (tgt & 63)) & 1ull;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mk > 0.f && cov) {
+            const float d0 = a.x - im.x, d1 = a.y - im.y, d2 = a.z - im.z;
+            g.x = (d0 > 0.f) ? k1 : ((d0 < 0.f) ? -k1 : 0.f);
+            g.y = (d1 > 0.f) ? k1 : ((d1 < 0.f) ? -k1 : 0.f);
+            g.z = (d2 > 0.f) ? k1 : ((d2 < 0.f) ? -k1 : 0.f);
+        }
+        g.w = 2.0f * (a.w - vm) * k2;
+        aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, color, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
+                          nullptr, cmat, gvert, true, g);
     }
 }
 
@@ -659,11 +686,15 @@ int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const i
     return FMHR_OK;
 }
 
-int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
-                const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int V,
+int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* aa, const float* img,
+                const float* mask, const float* valid_mask, const unsigned long long* covw, const float* n_valid, float w_sfs,
+                float w_mask, float mse_den, const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int V,
                 int H, int W, float* gcolor, const float* cmat, float* gvert, hipStream_t st)
 {
-    k_aa_bwd_items<<<kAaGrid, kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, dy, (const int4*)items, alphas, region_cnt, cap, V, H, W,
+    LossGrad L;
+    L.aa = (const float4*)aa; L.img = img; L.mask = mask; L.valid_mask = valid_mask; L.covw = covw; L.n_valid = n_valid;
+    L.w_sfs = w_sfs; L.w_mask = w_mask; L.mse_den = mse_den;
+    k_aa_bwd_items<<<kAaGrid, kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W,
                                            gcolor, (const float4*)cmat, gvert);
     FMHR_CHECK_LAUNCH("k_aa_bwd_items");
     return FMHR_OK;

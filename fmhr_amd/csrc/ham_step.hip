@@ -35,8 +35,9 @@ int active_segments_impl(const unsigned long long*, const unsigned char*, long l
 int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
                 const int*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int, hipStream_t);
-int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const int32_t*, const float*,
-                const int32_t*, int, int, int, int, float*, const float*, float*, hipStream_t);
+int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
+                const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int,
+                int, int, float*, const float*, float*, hipStream_t);
 int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, const float*,
                             float*, const float*, float*, hipStream_t);
 int normals_bwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, float*,
@@ -50,7 +51,7 @@ int transform_fwd_impl(const float*, const float*, const float*, int, int, float
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
 int fill_uncovered_impl(long long, const int*, const int*, float*, float*, const float*, int*, float*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
-                  const float*, float, float, float, float*, float*, float*, float*, float*, hipStream_t);
+                  const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; };
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
                   const int*, const int32_t*, const float*, const float*, const EdgeTerm&, int, int, int, int, int, float*, hipStream_t);
@@ -59,7 +60,7 @@ int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt, g_aa,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt,
         g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, seg_valid, cnt_part, edge_part, total;
 };
 
@@ -102,7 +103,6 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.aa_alphas = take(off, (size_t)d->aa_cap * 4);   // and their alphas
     L.aa_counter = take(off, 16);
     L.aa_region_cnt = take(off, 2048 * 4);            // items per region of the list (one region per workgroup of the AA kernels)
-    L.g_aa = take(off, nP * 16);
     L.g_shaded = take(off, nP * 16);
     L.cmat = take(off, (size_t)d->n * 64);
     L.gvert_aa = take(off, V * 12);
@@ -161,7 +161,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(stamp); FMHR_OFF(bwd16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
-    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_aa); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
+    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(total);
 #undef FMHR_OFF
     set_error("ham_workspace_offset: unknown buffer '%s'", name);
@@ -295,16 +295,18 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
 
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
-        // losses on the antialiased rgba + their per-pixel gradients (written twice: g_aa and the AA-backward target)
+        // losses on the antialiased rgba + their per-pixel gradients
         TRY(loss_pix_impl((const unsigned long long*)(w + L.covw), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
                           (const int*)(w + L.act_list), (const int*)(w + L.act_count), n_valid_global,
-                          wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_aa), (float*)(w + L.g_shaded),
+                          wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_shaded),
                           (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, losses, st));
     }
     {
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads (clip-transformed) into gvert_aa
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
-        TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (float*)(w + L.g_aa), (const int32_t*)(w + L.aa_items),
+        TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (const float*)(w + L.aa), img, mask, valid_mask,
+                        (const unsigned long long*)(w + L.covw), n_valid_global, wt->sfs, wt->mask, wt->mse_denominator,
+                        (const int32_t*)(w + L.aa_items),
                         (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->V, d->H, d->W,
                         (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, st));
     }

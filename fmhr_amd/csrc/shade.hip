@@ -157,13 +157,13 @@ k_fill_uncovered(long long N, const int* __restrict__ fill_list, const int* __re
 
 // losses + their per-pixel gradients over the active segments:
 // sfs = w * mean_valid |aa.rgb - img| (:289), mask = w * mean (aa.a - valid_mask)^2 (:295) — inactive segments contribute
-// exactly 0 to both.  g [.,4] = d loss / d antialiased rgba, written twice (g_aa = what the antialias backward reads as dy,
-// g_shaded = its accumulation target).
+// exactly 0 to both.  g_shaded [.,4] = d loss / d antialiased rgba: the antialias backward adds its colour corrections to it,
+// the face-parallel backward consumes it.
 __global__ void __launch_bounds__(kBlock)
 k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict__ aa, const float* __restrict__ img,
            const float* __restrict__ mask, const float* __restrict__ valid_mask, long long N,
            const int* __restrict__ act_list, const int* __restrict__ act_count, const float* __restrict__ n_valid_global,
-           float w_sfs, float w_mask, float mse_den, float4* __restrict__ g_aa, float4* __restrict__ g_shaded,
+           float w_sfs, float w_mask, float mse_den, float4* __restrict__ g_shaded,
            float* __restrict__ part_l1, float* __restrict__ part_l2, float* __restrict__ losses)
 {
     __shared__ float sm[4];
@@ -192,8 +192,7 @@ k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict
         float dm = a.w - vm;
         l2 += dm * dm;
         g.w = 2.0f * dm * k2;
-        g_aa[gid] = g;
-        g_shaded[gid] = g;
+        g_shaded[gid] = g;        // (the antialias backward recomputes the few gradients it needs as dy: no second copy)
     }
     float s1 = block_sum(l1, sm);
     float s2 = block_sum(l2, sm);
@@ -547,11 +546,11 @@ int fill_uncovered_impl(long long N, const int* fill_list, const int* fill_count
 
 int loss_pix_impl(const unsigned long long* covw, const float* aa, const float* img, const float* mask, const float* valid_mask,
                   long long N, const int* act_list, const int* act_count, const float* n_valid_global, float w_sfs, float w_mask,
-                  float mse_den, float* g_aa, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
+                  float mse_den, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>(covw, (const float4*)aa, img, mask, valid_mask, N, act_list, act_count,
-                                                  n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_aa, (float4*)g_shaded, part_l1,
+                                                  n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_shaded, part_l1,
                                                   part_l2, losses);
     FMHR_CHECK_LAUNCH("k_loss_pix");
     return FMHR_OK;
