@@ -6,6 +6,7 @@
 // appended to the work queue by wave64 ballot + popcount prefix (one queue atomic per wave).  Only pairs that actually
 // blend are queued, so the queue length is proportional to the silhouette length, not to the number of triangle seams.
 #include "common.h"
+#include "shade_common.h"
 #include <float.h>
 
 namespace fmhr {
@@ -465,17 +466,23 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
         const bool inR = live && px + 1 < W, inD = live && py + 1 < H;
         const bool cD = inD && ((((gidD >> 6) == sD ? wD0 : wD1) >> (gidD & 63)) & 1ull);
         const bool cR63 = inR && (wR & 1ull);                       // only lane 63 looks into the next segment
-        // in sparse mode rast is only defined on covered pixels: an uncovered pixel is the all-zero fragment
+        // the per-pixel word (u, v, z/w, packed id | flags) is only defined on covered pixels: an uncovered pixel is the all-zero
+        // fragment.  After the loads .w holds the dr.rasterize id (face + 1 as a float) and .x the face's silhouette bits.
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), rD = r0, rR = r0;
         if (c0) r0 = rast[gid];
         if (cD) rD = rast[gidD];
         if (lane == 63 && cR63) rR = rast[gid + 1];
         pin(r0); pin(rD); pin(rR);
+        auto decode = [](float4& r, bool cov) {
+            const int p = __float_as_int(r.w);
+            r.x = cov ? (float)pix_silh(p) : 0.f;
+            r.w = cov ? (float)(pix_face(p) + 1) : 0.f;
+        };
+        decode(r0, c0); decode(rD, cD); decode(rR, lane == 63 && cR63);
         {
-            const float z = __shfl_down(r0.z, 1), w = __shfl_down(r0.w, 1);
-            if (lane < 63) { rR.z = z; rR.w = w; }
+            const float z = __shfl_down(r0.z, 1), w = __shfl_down(r0.w, 1), sb = __shfl_down(r0.x, 1);
+            if (lane < 63) { rR.z = z; rR.w = w; rR.x = sb; }
         }
-        const unsigned char* sv = silh + (size_t)b * F;
 #pragma unroll
         for (int d = 0; d < 2; d++) {
             const float4 r1 = d ? rD : rR;
@@ -486,7 +493,8 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
             const int tri0 = (int)r0.w - 1, tri1 = (int)r1.w - 1;
             int t = (tri0 >= 0) ? tri0 : tri1;
             if (tri0 >= 0 && tri1 >= 0) t = (r0.z < r1.z) ? tri0 : tri1;
-            if (t < 0 || t >= F || sv[t] == 0) continue;
+            // the silhouette bits of the nearer face came with its pixel's word: no gather
+            if (t < 0 || t >= F || ((t == tri0) ? r0.x : r1.x) == 0.f) continue;
             const int slot = atomicAdd(&cnum, 1);                        // LDS
             if (slot < kCandBuf) {
                 cpos[slot] = make_int2(px | (py << 13) | (d << 26), b);
@@ -524,7 +532,7 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          const float* __restrict__ dyB, int V, int H, int W, int Cdyn,
          float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos,
          const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr, bool use_gl = false,
-         float4 gl = make_float4(0.f, 0.f, 0.f, 0.f))
+         float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false)
 {
     const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
@@ -556,7 +564,8 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
         }
     }
     if ((code & AA_CLAMPED) || galpha == 0.f) return;
-    int t = (int)rast[(code & AA_TRI1) ? pix1 : pix0].w - 1;
+    const float idw = rast[(code & AA_TRI1) ? pix1 : pix0].w;
+    int t = packed ? pix_face(__float_as_int(idw)) : (int)idw - 1;      // fused step: the per-pixel word of shade_common.h
     int qx = px, qy = py;
     if (code & AA_TRI1) { qx += 1 - d; qy += d; }
     int e1 = di + 1; if (e1 >= 3) e1 -= 3;
@@ -649,7 +658,7 @@ k_aa_bwd_items(const float* __restrict__ color, const float4* __restrict__ rast,
         }
         g.w = 2.0f * (a.w - vm) * k2;
         aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, color, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
-                          nullptr, cmat, gvert, true, g);
+                          nullptr, cmat, gvert, true, g, true);
     }
 }
 

@@ -32,7 +32,7 @@ int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, int*,
                          const int*, float*, hipStream_t);
-int densify_impl(const unsigned long long*, const unsigned char*, long long, float*, float*, float*, hipStream_t);
+int densify_impl(const unsigned long long*, const unsigned char*, long long, const float*, float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
                 const int*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int, hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
@@ -54,13 +54,13 @@ int loss_pix_impl(const unsigned long long*, const float*, const float*, const f
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; };
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
-                  const int*, const int32_t*, const float*, const float*, const EdgeTerm&, int, int, int, int, int, float*, hipStream_t);
+                  const int*, const int32_t*, const float*, const float*, const int*, const EdgeTerm&, int, int, int, int, int, float*, hipStream_t);
 int face_bwd_groups(int n);
 int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, bwd16, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt,
         g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, seg_valid, cnt_part, edge_part, total;
 };
 
@@ -76,7 +76,6 @@ static Layout make_layout(const fmhr_ham_dims* d)
     Layout L;
     size_t off = 0;
     size_t V = d->V, nP = (size_t)d->n * d->H * d->W, nV = (size_t)d->n * d->V;
-    const int npad = (d->n + 7) / 8 * 8;
     L.vertices = take(off, V * 12);
     L.nsum = take(off, V * 12);
     L.normals = take(off, V * 12);
@@ -95,7 +94,8 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.cov16 = take(off, (size_t)d->n * d->F * 16); // coverage entries [n, F]: candidate-pixel mask, box origin, stamp | box width
     L.own8 = take(off, (size_t)d->n * d->F);      // per (view, face): low byte of the last step in which it owned a pixel
     L.stamp = take(off, 16);                       // step counter tagging the coverage entries
-    L.bwd16 = take(off, nP * 16);             // per covered pixel: (u, v, link of its face's pixel list, mask > 0) for the backward
+    L.pix16 = take(off, nP * 16);             // per covered pixel: (u, v, z/w, packed face id | flags | silhouette bits)
+    L.llink = take(off, nP * 4);              // list links of the pixels of large-box faces (written for those pixels only)
     L.rast = take(off, nP * 16);
     L.shaded = take(off, nP * 16);
     L.aa = take(off, nP * 16);
@@ -160,7 +160,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
     Layout L = make_layout(d);
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
-    FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(stamp); FMHR_OFF(bwd16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
+    FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(stamp); FMHR_OFF(pix16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
     FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(total);
 #undef FMHR_OFF
@@ -206,7 +206,8 @@ extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_byte
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_densify: workspace too small or null");
     char* w = (char*)ws;
     return densify_impl((const unsigned long long*)(w + L.covw), (const unsigned char*)(w + L.act), (long long)d->n * d->H * d->W,
-                        (float*)(w + L.rast), (float*)(w + L.shaded), (float*)(w + L.aa), (hipStream_t)stream);
+                        (const float*)(w + L.pix16), (float*)(w + L.rast), (float*)(w + L.shaded), (float*)(w + L.aa),
+                        (hipStream_t)stream);
 }
 
 extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
@@ -240,7 +241,8 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         // (view, face)s and rearms the two segment-list cursors
         RasterFused fu;
         fu.cov16 = (int4*)(w + L.cov16); fu.stamp = (int*)(w + L.stamp); fu.own8 = (unsigned char*)(w + L.own8);
-        fu.bwd16 = (float4*)(w + L.bwd16); fu.mask = mask;
+        fu.pix16 = (float4*)(w + L.pix16); fu.mask = mask;
+        fu.silh = (const unsigned char*)(w + L.silh); fu.llink = (int*)(w + L.llink);
         fu.attr8 = (const float4*)(w + L.attr8); fu.sh = sh;
         fu.shaded = (float4*)(w + L.shaded); fu.aa_init = (float4*)(w + L.aa); fu.seg_valid = (int*)(w + L.seg_valid);
         fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
@@ -257,7 +259,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
                                 (float*)(w + L.aa), (const float*)(w + L.cnt_part), n_valid_local, (float*)(w + L.n_valid_f), st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
-    TRY(aa_fwd_rgba((float*)(w + L.shaded), rast, pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
+    TRY(aa_fwd_rgba((float*)(w + L.shaded), (const float*)(w + L.pix16), pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
                     (const int*)(w + L.act_count), covw, d->n, d->V, d->F,
                     d->H, d->W, (float*)(w + L.aa), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
                     (int32_t*)(w + L.aa_counter), (int32_t*)(w + L.aa_region_cnt), d->aa_cap, st));
@@ -285,11 +287,9 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     char* w = (char*)ws;
     float* vertices = (float*)(w + L.vertices);
     float* pos = (float*)(w + L.pos);
-    float* rast = (float*)(w + L.rast);
     float* gvert_aa = (float*)(w + L.gvert_aa);
-    const int npad = (d->n + 7) / 8 * 8;
     float* gvert = (float*)(w + L.gvert);
-    size_t nP = (size_t)d->n * d->H * d->W, V = d->V;
+    size_t nP = (size_t)d->n * d->H * d->W;
     const float rg = wt->reg_grad_scale;
     const size_t nB = 2048;
 
@@ -304,7 +304,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     {
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads (clip-transformed) into gvert_aa
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
-        TRY(aa_bwd_rgba((float*)(w + L.shaded), rast, pos, tri, (const float*)(w + L.aa), img, mask, valid_mask,
+        TRY(aa_bwd_rgba((float*)(w + L.shaded), (const float*)(w + L.pix16), pos, tri, (const float*)(w + L.aa), img, mask, valid_mask,
                         (const unsigned long long*)(w + L.covw), n_valid_global, wt->sfs, wt->mask, wt->mse_denominator,
                         (const int32_t*)(w + L.aa_items),
                         (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->V, d->H, d->W,
@@ -319,9 +319,9 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         et.f0 = (rg != 0.f) ? (int)((long long)wt->reg_v0 * d->F / d->V) : 0;
         et.f1 = (rg != 0.f) ? (int)((long long)wt->reg_v1 * d->F / d->V) : 0;
         et.mean = wt->edge_length_mean; et.w = wt->edge / (3.0f * (float)d->F); et.gk = 2.f * et.w * rg;
-        TRY(face_bwd_impl((const float*)(w + L.bwd16), tri, pos, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
+        TRY(face_bwd_impl((const float*)(w + L.pix16), tri, pos, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
                           w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot,
-                          (const float*)(w + L.cmat), vertices, et, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
+                          (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), et, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
     }
     {
         // everything per-vertex after the gather, in two kernels (mesh.hip: k_mesh_tail_a / _b)

@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
 {
     __shared__ float sm[4];
     const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
-    float l_lap = 0.f, l_alb = 0.f, l_edge = 0.f, l_delta = 0.f;
+    float l_lap = 0.f, l_alb = 0.f, l_delta = 0.f;
     const bool live = v < A.V;                                     // uniform over a vertex's lanes
     const int vv = live ? v : 0;
     // (1) corner sums of the face-parallel backward: a vertex's corners are 3*deg consecutive float4 per view-group plane (vf CSR

@@ -322,7 +322,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
     {
         const bool live = gid < (long long)n * P;
         unsigned long long key = live ? keys[gid] : ~0ull;
-        const float mk = (live && fu.bwd16 != nullptr) ? fu.mask[gid] : 0.f;   // independent of the key: issued with it
+        const float mk = (live && fu.pix16 != nullptr) ? fu.mask[gid] : 0.f;   // independent of the key: issued with it
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f), col = o;
         bool covered = false;
         if (key != ~0ull) {
@@ -334,7 +334,9 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
             const float* vp = pos + (size_t)b * V * 4;
             float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
-            // fused step: the shading inputs ride in the same memory round trip as the clip positions
+            // fused step: the shading inputs and the face's silhouette bits ride in the same memory round trip as the clip positions
+            int sbits = 0;
+            if (fu.pix16 != nullptr) sbits = fu.silh[(size_t)b * F + f];
             float4 q0, q1, u0, u1, w0, w1;
             float shc[9];
             const bool shade = fu.shaded != nullptr && mk > 0.f;
@@ -359,17 +361,14 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
                 o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
                 covered = true;
-                if (fu.bwd16 != nullptr) {
-                    // everything the backward needs per pixel in ONE 16-B word: (u, v, owner, flags).  owner = the face id (the
-                    // face-parallel backward checks its candidate pixels against it); a large-box face has no candidate mask,
-                    // its pixels are threaded onto a list instead (head = .x of its coverage entry) and owner holds the link.
-                    // flags = (mask > 0) + 2 * large
-                    int owner = f;
-                    if (large) owner = atomicExch(reinterpret_cast<int*>(&fu.cov16[(size_t)b * F + f]), rem);
+                if (fu.pix16 != nullptr) {
+                    // everything the later kernels need per pixel in ONE 16-B word (shade_common.h: pix_pack); a large-box face
+                    // has no candidate mask: its pixels are threaded onto a list instead (head = .x of its coverage entry)
+                    if (large) fu.llink[gid] = atomicExch(reinterpret_cast<int*>(&fu.cov16[(size_t)b * F + f]), rem);
                     // "this (view, face) owns pixels in step <stamp>": lets the backward skip the coverage entries of hidden
                     // faces.  Only a hint (8-bit stamp; a stale match costs a wasted entry load, never a wrong result)
                     fu.own8[(size_t)b * F + f] = (unsigned char)step_tag;
-                    fu.bwd16[gid] = make_float4(fr.u, fr.v, __int_as_float(owner), ((mk > 0.f) ? 1.f : 0.f) + (large ? 2.f : 0.f));
+                    fu.pix16[gid] = make_float4(fr.u, fr.v, fr.zw, __int_as_float(pix_pack(f, mk > 0.f, large, sbits)));
                 }
                 if (fu.shaded != nullptr) {
                     // forward shading of the fused step (mesh_sfs_optim.py:268-286): rgb = SH radiance x albedo where mask > 0,
@@ -388,7 +387,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         if (sparse) {
             unsigned long long bal = __ballot(covered);
             if (live) {
-                if (covered) rast[gid] = o;
+                if (covered && fu.pix16 == nullptr) rast[gid] = o;   // fused step: pix16 replaces it (densify rebuilds rast on demand)
                 keys[gid] = ~0ull;
                 if (fu.shaded != nullptr) { fu.shaded[gid] = col; fu.aa_init[gid] = col; }   // zeros on the uncovered lanes
             }

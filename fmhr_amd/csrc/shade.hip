@@ -121,13 +121,18 @@ constexpr int kPersistBlocks = 2048;      // persistent per-pixel kernels: 8 wor
 // test/inspection helper: make the sparse buffers dense (zeros wherever the step did not write)
 __global__ void __launch_bounds__(kBlock)
 k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ act, long long N,
-          float4* __restrict__ rast, float4* __restrict__ shaded, float4* __restrict__ aa)
+          const float4* __restrict__ pix16, float4* __restrict__ rast, float4* __restrict__ shaded, float4* __restrict__ aa)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= N) return;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     bool covered = (covw[gid >> 6] >> (gid & 63)) & 1ull;
-    if (!covered) rast[gid] = z;
+    float4 r = z;
+    if (covered) {                                   // the dr.rasterize image (u, v, z/w, id + 1) from the step's per-pixel word
+        r = pix16[gid];
+        r.w = (float)(pix_face(__float_as_int(r.w)) + 1);
+    }
+    rast[gid] = r;
     if (!act[gid >> 6]) { shaded[gid] = z; aa[gid] = z; }
 }
 
@@ -313,8 +318,8 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
            const int4* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
-           const float4* __restrict__ cmat, const float* __restrict__ verts, int n, int V, int F, int H, int W,
-           float4* __restrict__ part, const EdgeTerm et)
+           const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
+           int H, int W, float4* __restrict__ part, const EdgeTerm et)
 {
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
     constexpr int GV = kGroup * VPL;                               // views per group
@@ -458,8 +463,9 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
                 float4 w = bwd16[gid];
                 float4 gs = g_shaded[gid];
                 pin(w); pin(gs);
-                // owner == this face, mask > 0 and not a list pixel (flags == 1), non-zero image gradient
-                if (__float_as_int(w.z) == f && w.w == 1.f && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f))
+                // owner == this face, mask > 0 (a box triangle's pixels are never list pixels), non-zero image gradient
+                const int pk = __float_as_int(w.w);
+                if (pix_face(pk) == f && pix_mask(pk) && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f))
                     pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -475,13 +481,14 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
                 const long long gid = (long long)(b0 + vs) * P + p;
                 float4 w = bwd16[gid];
                 float4 gs = g_shaded[gid];
+                const int link = llink[gid];
                 pin(w); pin(gs);
-                if (w.w == 3.f && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) {
+                if (pix_mask(__float_as_int(w.w)) && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) {
                     int px;
                     const int py = fast_divmod(p, W, px);
                     pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
                 }
-                p = __float_as_int(w.z);
+                p = link;
             }
         }
     }
@@ -524,11 +531,12 @@ int active_segments_impl(const unsigned long long* covw, const unsigned char* vm
     return FMHR_OK;
 }
 
-int densify_impl(const unsigned long long* covw, const unsigned char* act, long long N, float* rast, float* shaded, float* aa,
+int densify_impl(const unsigned long long* covw, const unsigned char* act, long long N, const float* pix16, float* rast, float* shaded,
+                 float* aa,
                  hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_densify<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, act, N, (float4*)rast, (float4*)shaded, (float4*)aa);
+    k_densify<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, act, N, (const float4*)pix16, (float4*)rast, (float4*)shaded, (float4*)aa);
     FMHR_CHECK_LAUNCH("k_densify");
     return FMHR_OK;
 }
@@ -566,13 +574,13 @@ int face_bwd_blocks(int F) { return cdiv(F, kBlock / kGroup); }
 
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
                   const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
-                  const float* verts, const EdgeTerm& et, int n, int V, int F, int H, int W, float* part, hipStream_t st)
+                  const float* verts, const int* llink, const EdgeTerm& et, int n, int V, int F, int H, int W, float* part, hipStream_t st)
 {
     if (n == 0 || F == 0) return FMHR_OK;
     const dim3 grid(cdiv(F, kFacesPerBlock), face_bwd_groups(n));
 #define FMHR_FACE_BWD(VPL)                                                                                                          \
     k_face_bwd<VPL><<<grid, kBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
-                                             (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, n, V, F, H, W, \
+                                             (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
                                              (float4*)part, et)
     switch (face_bwd_vpl(n)) {
         case 1: FMHR_FACE_BWD(1); break;

@@ -84,10 +84,20 @@ __device__ __forceinline__ void shade_eval_attr(float u, float v, const float4 q
     s.rad = sh9c(shc, s.hx, s.hy, s.hz);
 }
 
+// The fused step keeps ONE 16-B word per covered pixel, (u, v, z/w, packed), read by the antialias kernels (z/w, id, silhouette
+// bits) and by the face-parallel backward (u, v, owner, flags).  packed: bits 0..23 face id, 24 mask > 0, 25 large-box face,
+// 26..28 silhouette bits of the face in this view (antialias rule A3).  fmhr_ham_densify rebuilds the dr.rasterize image from it.
+__device__ __forceinline__ int pix_pack(int f, bool mask_pos, bool large, int silh) { return f | ((int)mask_pos << 24) | ((int)large << 25) | (silh << 26); }
+__device__ __forceinline__ int pix_face(int p) { return p & 0xFFFFFF; }
+__device__ __forceinline__ bool pix_mask(int p) { return (p >> 24) & 1; }
+__device__ __forceinline__ bool pix_large(int p) { return (p >> 25) & 1; }
+__device__ __forceinline__ int pix_silh(int p) { return (p >> 26) & 7; }
+
 // what the fused stage-2 step adds to the rasterizer's passes (all null for the stand-alone dr.rasterize path)
 struct RasterFused {
     int4* cov16; int* stamp; unsigned char* own8;             // coverage entries, step counter, owner marks (face-parallel backward)
-    float4* bwd16; const float* mask;                         // per covered pixel (u, v, owner, flags)
+    float4* pix16; const float* mask;                         // per covered pixel (u, v, z/w, packed id | flags): see pix_pack
+    const unsigned char* silh; int* llink;                    // silhouette bits per (view, face); list links of large-box faces' pixels
     const float4* attr8; const float* sh;                     // forward shading inputs
     float4* shaded; float4* aa_init; int* seg_valid;          // forward shading outputs + valid-pixel count of every segment
     int* rearm2;                                              // two list cursors the resolve pass zeroes for the next kernel
