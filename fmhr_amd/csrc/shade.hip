@@ -410,31 +410,26 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         }
     }
     if (anyk != 0ull) {                                            // wave-uniform
-        // ---- park: clip positions per covering (face, view), attributes once per face (lane 0 of the group)
+        // ---- one memory round trip for the face's attributes (lane 0 of the group) AND the first candidate pixel of every lane:
+        //      the attribute loads are issued first, the candidate masks (already here) are expanded into the task list, each lane
+        //      requests its first task's pixel word and image gradient, and only then are the attributes parked
+        const bool loader = j == 0 && group_any;
+        float4 q0, q1, u0, u1, w0, w1;
+        float3 vv0, vv1, vv2;
+        if (loader) {
+            q0 = attr8[(size_t)ti.x * 2]; q1 = attr8[(size_t)ti.x * 2 + 1];
+            u0 = attr8[(size_t)ti.y * 2]; u1 = attr8[(size_t)ti.y * 2 + 1];
+            w0 = attr8[(size_t)ti.z * 2]; w1 = attr8[(size_t)ti.z * 2 + 1];
+            vv0 = ld3f(verts + (size_t)ti.x * 3); vv1 = ld3f(verts + (size_t)ti.y * 3); vv2 = ld3f(verts + (size_t)ti.z * 3);
+        }
 #pragma unroll
         for (int v = 0; v < VPL; v++)
             if (kind[v] != 0) {
                 const int at = tid * VPL + v;
                 pk_box[at] = (e[v].z & 0x1fff) | (((e[v].z >> 16) & 0x1fff) << 13) | (((kind[v] - 1) & 63) << 26);
             }
-        if (j == 0 && group_any) {
-            const float4 q0 = attr8[(size_t)ti.x * 2], q1 = attr8[(size_t)ti.x * 2 + 1];
-            const float4 u0 = attr8[(size_t)ti.y * 2], u1 = attr8[(size_t)ti.y * 2 + 1];
-            const float4 w0 = attr8[(size_t)ti.z * 2], w1 = attr8[(size_t)ti.z * 2 + 1];
-            FaceAttr fa;
-            fa.n2 = make_float3(w0.x, w0.y, w0.z); fa.a2 = make_float3(w0.w, w1.x, w1.y);
-            fa.dn0 = make_float3(q0.x - fa.n2.x, q0.y - fa.n2.y, q0.z - fa.n2.z);
-            fa.da0 = make_float3(q0.w - fa.a2.x, q1.x - fa.a2.y, q1.y - fa.a2.z);
-            fa.dn1 = make_float3(u0.x - fa.n2.x, u0.y - fa.n2.y, u0.z - fa.n2.z);
-            fa.da1 = make_float3(u0.w - fa.a2.x, u1.x - fa.a2.y, u1.y - fa.a2.z);
-            fa.v0 = ld3f(verts + (size_t)ti.x * 3); fa.v1 = ld3f(verts + (size_t)ti.y * 3); fa.v2 = ld3f(verts + (size_t)ti.z * 3);
-            pk_attr[gl] = fa;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const FaceAttr& fa = pk_attr[gl];
-        // ---- candidate pixels of the group's box triangles, kTaskG per round; task = (view slot v * kGroup + j) << 6 | bit
-        for (int R = 0; __ballot(R < T) != 0ull; R += kTaskG) {     // wave-uniform trip count
+        // candidate pixels of the group's box triangles, kTaskG per round; task = (view slot v * kGroup + j) << 6 | bit
+        auto expand = [&](int R) {
             if (cnt != 0 && excl < R + kTaskG && excl + cnt > R) {
                 int idx = excl - R;
 #pragma unroll
@@ -451,23 +446,63 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int nt = min(kTaskG, T - R);
-            for (int t = j; t < nt; t += kGroup) {
-                const int en = tasks[gl][t], vs = en >> 6, bit = en & 63;
-                const int src = ((tid & ~(kGroup - 1)) + (vs & (kGroup - 1))) * VPL + (vs >> 3);
-                const int box = pk_box[src];
-                int c;
-                const int r = fast_divmod(bit, ((box >> 26) & 63) + 1, c);
-                const int px = (box & 0x1fff) + c, py = ((box >> 13) & 0x1fff) + r;
-                const long long gid = (long long)(b0 + vs) * P + (long long)py * W + px;
+        };
+        auto locate = [&](int t, int& vs, int& px, int& py) {       // task -> view slot, pixel, flat pixel index
+            const int en = tasks[gl][t], bit = en & 63;
+            vs = en >> 6;
+            const int src = ((tid & ~(kGroup - 1)) + (vs & (kGroup - 1))) * VPL + (vs >> 3);
+            const int box = pk_box[src];
+            int c;
+            const int r = fast_divmod(bit, ((box >> 26) & 63) + 1, c);
+            px = (box & 0x1fff) + c; py = ((box >> 13) & 0x1fff) + r;
+            return (long long)(b0 + vs) * P + (long long)py * W + px;
+        };
+        expand(0);
+        const int nt0 = min(kTaskG, T);
+        int pvs = 0, ppx = 0, ppy = 0;
+        float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), pgs = pw;
+        if (j < nt0) {
+            const long long gid = locate(j, pvs, ppx, ppy);
+            pw = bwd16[gid];
+            pgs = g_shaded[gid];
+        }
+        if (loader) {
+            pin(q0); pin(q1); pin(u0); pin(u1); pin(w0); pin(w1);
+            FaceAttr fa;
+            fa.n2 = make_float3(w0.x, w0.y, w0.z); fa.a2 = make_float3(w0.w, w1.x, w1.y);
+            fa.dn0 = make_float3(q0.x - fa.n2.x, q0.y - fa.n2.y, q0.z - fa.n2.z);
+            fa.da0 = make_float3(q0.w - fa.a2.x, q1.x - fa.a2.y, q1.y - fa.a2.z);
+            fa.dn1 = make_float3(u0.x - fa.n2.x, u0.y - fa.n2.y, u0.z - fa.n2.z);
+            fa.da1 = make_float3(u0.w - fa.a2.x, u1.x - fa.a2.y, u1.y - fa.a2.z);
+            fa.v0 = vv0; fa.v1 = vv1; fa.v2 = vv2;
+            pk_attr[gl] = fa;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const FaceAttr& fa = pk_attr[gl];
+        // owner == this face, mask > 0 (a box triangle's pixels are never list pixels), non-zero image gradient
+        auto consume = [&](float4 w, float4 gs, int vs, int px, int py) {
+            const int pk = __float_as_int(w.w);
+            if (pix_face(pk) == f && pix_mask(pk) && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f))
+                pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
+        };
+        auto run = [&](int tfirst, int nt) {
+            for (int t = tfirst; t < nt; t += kGroup) {
+                int vs, px, py;
+                const long long gid = locate(t, vs, px, py);
                 float4 w = bwd16[gid];
                 float4 gs = g_shaded[gid];
                 pin(w); pin(gs);
-                // owner == this face, mask > 0 (a box triangle's pixels are never list pixels), non-zero image gradient
-                const int pk = __float_as_int(w.w);
-                if (pix_face(pk) == f && pix_mask(pk) && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f))
-                    pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
+                consume(w, gs, vs, px, py);
             }
+        };
+        if (j < nt0) { pin(pw); pin(pgs); consume(pw, pgs, pvs, ppx, ppy); }
+        run(j + kGroup, nt0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int R = kTaskG; __ballot(R < T) != 0ull; R += kTaskG) {   // wave-uniform trip count; further rounds are rare
+            expand(R);
+            run(j, min(kTaskG, T - R));
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }

@@ -64,7 +64,7 @@ def _worker(rank, world, port, q):
     losses, gd, ga = _oracle_step(oracle, sc, s0, s1, sc["views"], rank == 0, lambda t: dist.all_reduce(t))
     ls, gd, ga = sh.reduce(losses, gd, ga)
     if rank == 0:
-        q.put((ls.clone(), gd.clone(), ga.clone(), (s0, s1)))
+        q.put((ls.numpy().copy(), gd.numpy().copy(), ga.numpy().copy(), (s0, s1)))       # by value (see test_gpu_sharded.py)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,6 +85,7 @@ def test_two_ranks_match_single_process(oracle):
     for p in procs:
         p.start()
     ls, gd, ga, shard0 = q.get(timeout=240)
+    ls, gd, ga = torch.from_numpy(ls), torch.from_numpy(gd), torch.from_numpy(ga)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

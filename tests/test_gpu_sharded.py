@@ -62,7 +62,9 @@ def _worker(rank, world, port, q):
     ls, gd, ga = sh.reduce(losses, gd, ga)
     torch.cuda.synchronize()
     if rank == 0:
-        q.put((ls.cpu(), gd.cpu(), ga.cpu()))
+        # numpy arrays are pickled by value: tensors would be handed over through a file descriptor of THIS process, which may
+        # have exited before the parent unpickles
+        q.put((ls.cpu().numpy(), gd.cpu().numpy(), ga.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,7 +79,7 @@ def test_two_ranks_one_gpu_match_single_rank():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ls, gd, ga = q.get(timeout=500)
+    ls, gd, ga = (torch.from_numpy(x) for x in q.get(timeout=500))
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
