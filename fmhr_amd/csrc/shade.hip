@@ -486,23 +486,34 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             if (pix_face(pk) == f && pix_mask(pk) && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f))
                 pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
         };
-        auto run = [&](int tfirst, int nt) {
-            for (int t = tfirst; t < nt; t += kGroup) {
-                int vs, px, py;
+        // a lane's tasks of one round, software-pipelined: the next task's two loads are in flight while the current one is
+        // evaluated (a lane has ~5 tasks at 48 views; `have` = the first task (t) is already loaded into w / gs)
+        auto run = [&](int t, int nt, bool have, float4 w, float4 gs, int vs, int px, int py) {
+            if (!have && t < nt) {
                 const long long gid = locate(t, vs, px, py);
-                float4 w = bwd16[gid];
-                float4 gs = g_shaded[gid];
+                w = bwd16[gid];
+                gs = g_shaded[gid];
+            }
+            while (t < nt) {
+                const int tn = t + kGroup;
+                float4 w2 = w, gs2 = gs;
+                int vs2 = 0, px2 = 0, py2 = 0;
+                if (tn < nt) {
+                    const long long gid2 = locate(tn, vs2, px2, py2);
+                    w2 = bwd16[gid2];
+                    gs2 = g_shaded[gid2];
+                }
                 pin(w); pin(gs);
                 consume(w, gs, vs, px, py);
+                w = w2; gs = gs2; vs = vs2; px = px2; py = py2; t = tn;
             }
         };
-        if (j < nt0) { pin(pw); pin(pgs); consume(pw, pgs, pvs, ppx, ppy); }
-        run(j + kGroup, nt0);
+        run(j, nt0, j < nt0, pw, pgs, pvs, ppx, ppy);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int R = kTaskG; __ballot(R < T) != 0ull; R += kTaskG) {   // wave-uniform trip count; further rounds are rare
             expand(R);
-            run(j, min(kTaskG, T - R));
+            run(j, min(kTaskG, T - R), false, pw, pgs, 0, 0, 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
