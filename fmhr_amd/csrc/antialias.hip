@@ -448,14 +448,27 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
     __syncthreads();
     const int count = *act_count, lane = threadIdx.x & 63;
     const long long P = (long long)H * W, N = (long long)n * P, nSeg = (N + 63) >> 6;
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
-        const long long seg = act_list[i];
+    // software-pipelined over the wave's segments: the segment id and the four coverage words of the NEXT iteration are requested
+    // while the current one runs (two dependent levels off every iteration's chain)
+    const int stride = gridDim.x * 4;
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long seg_n = 0;
+    unsigned long long w0_n = 0ull, wR_n = 0ull, wD0_n = 0ull, wD1_n = 0ull;
+    auto fetch = [&](int ii) {
+        if (ii < count) {
+            seg_n = act_list[ii];
+            const long long sDn = ((seg_n << 6) + W) >> 6;
+            w0_n = covw[seg_n]; wR_n = covw_or0(covw, seg_n + 1, nSeg); wD0_n = covw_or0(covw, sDn, nSeg); wD1_n = covw_or0(covw, sDn + 1, nSeg);
+        }
+    };
+    fetch(i);
+    for (; i < count; i += stride) {
+        const long long seg = seg_n;
+        const unsigned long long w0 = w0_n, wR = wR_n, wD0 = wD0_n, wD1 = wD1_n;
         const long long gid = (seg << 6) + lane;
         const bool live = gid < N;
         const long long gidD = gid + W;
         const long long sD = ((seg << 6) + W) >> 6;
-        const unsigned long long w0 = covw[seg], wR = covw_or0(covw, seg + 1, nSeg), wD0 = covw_or0(covw, sD, nSeg),
-                                 wD1 = covw_or0(covw, sD + 1, nSeg);
         int b = 0, px = 0, py = 0;
         if (live) {
             int rem;
@@ -472,6 +485,7 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
         if (c0) r0 = rast[gid];
         if (cD) rD = rast[gidD];
         if (lane == 63 && cR63) rR = rast[gid + 1];
+        fetch(i + stride);                                          // next iteration's segment + coverage words
         pin(r0); pin(rD); pin(rR);
         auto decode = [](float4& r, bool cov) {
             const int p = __float_as_int(r.w);
