@@ -431,7 +431,8 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
               const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
               const int* __restrict__ act_list, const int* __restrict__ act_count, const unsigned long long* __restrict__ covw,
               int n, int V, int F, int H, int W, float* __restrict__ out, int4* __restrict__ items,
-              float* __restrict__ alphas, int32_t* __restrict__ counter, int32_t* __restrict__ region_cnt, int cap)
+              float* __restrict__ alphas, int32_t* __restrict__ counter, int32_t* __restrict__ region_cnt, int cap,
+              const float* __restrict__ cnt_part, int nb_cnt, int* __restrict__ n_valid, float* __restrict__ n_valid_f)
 {
     // work items (pairs that blend; a few % of the pixels) for the backward: every workgroup owns a fixed region of the list
     // (cap / gridDim items) and a count slot — no global atomics at all (a returning same-address atomic per wave with an item
@@ -445,6 +446,13 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
     const int region = cap / (int)gridDim.x;
     const size_t rbase = (size_t)blockIdx.x * region;
     if (threadIdx.x == 0) { inum = 0; cnum = 0; }
+    if (blockIdx.x == 0 && cnt_part != nullptr) {                  // the step's local valid-pixel count (last forward kernel:
+        __shared__ float sm4[4];                                   // saves a launch): sum of k_active_segments' partials
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < nb_cnt; i += kBlock) acc += cnt_part[i];
+        float r = block_sum(acc, sm4);
+        if (threadIdx.x == 0) { n_valid[0] = (int)(r + 0.5f); n_valid_f[0] = (float)(int)(r + 0.5f); }
+    }
     __syncthreads();
     const int count = *act_count, lane = threadIdx.x & 63;
     const long long P = (long long)H * W, N = (long long)n * P, nSeg = (N + 63) >> 6;
@@ -701,10 +709,10 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
 int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                 const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw, int n,
                 int V, int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int32_t* region_cnt, int cap,
-                hipStream_t st)
+                const float* cnt_part, int nb_cnt, int* n_valid, float* n_valid_f, hipStream_t st)
 {
     k_aa_fwd_list<<<kAaGrid, kBlock, 0, st>>>((const float4*)color, (const float4*)rast, pos, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
-                                           out, (int4*)items, alphas, counter, region_cnt, cap);
+                                           out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f);
     FMHR_CHECK_LAUNCH("k_aa_fwd_list");
     return FMHR_OK;
 }

@@ -30,11 +30,13 @@ int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
                        void*, unsigned char*, unsigned long long*, const RasterFused*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
-int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, int*,
-                         const int*, float*, hipStream_t);
+int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, const int*,
+                         float*, float*, float*, hipStream_t);
+int active_segments_blocks(long long N);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, const float*, float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
-                const int*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int, hipStream_t);
+                const int*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int,
+                const float*, int, int*, float*, hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
                 const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int,
                 int, int, float*, const float*, float*, hipStream_t);
@@ -49,7 +51,6 @@ int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, 
 int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
 int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
-int fill_uncovered_impl(long long, const int*, const int*, float*, float*, const float*, int*, float*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; };
@@ -60,7 +61,7 @@ int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, fill_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt,
         g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, seg_valid, cnt_part, edge_part, total;
 };
 
@@ -89,7 +90,6 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.act = take(off, (nP + 63) / 64);
     L.vmnz = take(off, (nP + 63) / 64);
     L.act_list = take(off, ((nP + 63) / 64) * 4);
-    L.fill_list = take(off, ((nP + 63) / 64) * 4);
     L.act_count = take(off, 16);
     L.cov16 = take(off, (size_t)d->n * d->F * 16); // coverage entries [n, F]: candidate-pixel mask, box origin, stamp | box width
     L.own8 = take(off, (size_t)d->n * d->F);      // per (view, face): low byte of the last step in which it owned a pixel
@@ -253,16 +253,15 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
         TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, (int*)(w + L.act_list),
-                                 (int*)(w + L.act_count), (int*)(w + L.fill_list), (const int*)(w + L.seg_valid),
-                                 (float*)(w + L.cnt_part), st));
-        TRY(fill_uncovered_impl(nP, (const int*)(w + L.fill_list), (const int*)(w + L.act_count) + 1, (float*)(w + L.shaded),
-                                (float*)(w + L.aa), (const float*)(w + L.cnt_part), n_valid_local, (float*)(w + L.n_valid_f), st));
+                                 (int*)(w + L.act_count), (const int*)(w + L.seg_valid), (float*)(w + L.cnt_part),
+                                 (float*)(w + L.shaded), (float*)(w + L.aa), st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     TRY(aa_fwd_rgba((float*)(w + L.shaded), (const float*)(w + L.pix16), pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
                     (const int*)(w + L.act_count), covw, d->n, d->V, d->F,
                     d->H, d->W, (float*)(w + L.aa), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
-                    (int32_t*)(w + L.aa_counter), (int32_t*)(w + L.aa_region_cnt), d->aa_cap, st));
+                    (int32_t*)(w + L.aa_counter), (int32_t*)(w + L.aa_region_cnt), d->aa_cap, (const float*)(w + L.cnt_part),
+                    active_segments_blocks(nP), n_valid_local, (float*)(w + L.n_valid_f), st));
     return FMHR_OK;
 }
 

@@ -70,13 +70,13 @@ constexpr int kActBlock = 1024;   // few, fat workgroups: the list cursors are s
 __global__ void __launch_bounds__(kActBlock)
 k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
                   unsigned char* __restrict__ act, int* __restrict__ act_list, int* __restrict__ act_count,
-                  int* __restrict__ fill_list, const int* __restrict__ seg_valid, float* __restrict__ cnt_part)
+                  const int* __restrict__ seg_valid, float* __restrict__ cnt_part, long long N, float4* __restrict__ shaded,
+                  float4* __restrict__ aa_init)
 {
-    // act_count[0] = number of active segments (act_list), act_count[1] = number of active segments WITHOUT coverage (fill_list); both cursors
-    // advance with ONE 64-bit atomic per workgroup (low word = active, high word = covered)
+    // act_count[0] = number of active segments (act_list): the cursor advances with ONE atomic per workgroup
     constexpr int kWaves = kActBlock / 64;
-    __shared__ int wcnt[kWaves], ccnt[kWaves];
-    __shared__ int base, cbase;
+    __shared__ int wcnt[kWaves];
+    __shared__ int base;
     __shared__ float sm16[16];
     long long seg = (long long)blockIdx.x * kActBlock + threadIdx.x;
     {   // valid-pixel count: the resolve pass left one number per segment (it has no workgroup barrier: clean waves leave at
@@ -86,17 +86,15 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
         if (threadIdx.x == 0 && cnt_part != nullptr) cnt_part[blockIdx.x] = sv;
     }
     bool a = (seg < nSeg) && segment_is_active(covw, vmnz, nSeg, W, seg, act);
-    bool cv = a && covw[seg] == 0ull;                                // active without coverage: needs its zeros (k_fill_uncovered)
+    bool cv = a && covw[seg] == 0ull;                                // active without coverage: needs its zeros
     unsigned long long bal = __ballot(a), cbal = __ballot(cv);
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { wcnt[wv] = __popcll(bal); ccnt[wv] = __popcll(cbal); }
+    if (lane == 0) wcnt[wv] = __popcll(bal);
     __syncthreads();
     if (threadIdx.x == 0) {
-        int na = 0, nc = 0;
-        for (int i = 0; i < kWaves; i++) { na += wcnt[i]; nc += ccnt[i]; }
-        unsigned long long old = atomicAdd((unsigned long long*)act_count, ((unsigned long long)(unsigned)nc << 32) | (unsigned)na);
-        base = (int)(old & 0xffffffffull);
-        cbase = (int)(old >> 32);
+        int na = 0;
+        for (int i = 0; i < kWaves; i++) na += wcnt[i];
+        base = atomicAdd(act_count, na);
     }
     __syncthreads();
     if (a) {
@@ -104,10 +102,18 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
         for (int i = 0; i < wv; i++) off += wcnt[i];
         act_list[off] = (int)seg;
     }
-    if (cv) {
-        int off = cbase + __popcll(cbal & ((1ull << lane) - 1ull));
-        for (int i = 0; i < wv; i++) off += ccnt[i];
-        fill_list[off] = (int)seg;
+    // The forward shading is fused into the rasterizer's resolve pass (raster.hip), which writes the rgba pair for every pixel of
+    // a segment that received fragments.  Active segments WITHOUT coverage (neighbours of covered ones, valid_mask-only ones) get
+    // their zeros here, wave-cooperatively: one 64-pixel segment per iteration, 1 KB per store instruction
+    if (shaded != nullptr) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const long long wseg = seg - lane;                           // the wave's lanes hold consecutive segments
+        while (cbal != 0ull) {
+            const int src = __builtin_ctzll(cbal);
+            cbal &= cbal - 1ull;
+            const long long gid = ((wseg + src) << 6) + lane;
+            if (gid < N) { shaded[gid] = z; aa_init[gid] = z; }
+        }
     }
 }
 
@@ -134,30 +140,6 @@ k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __re
     }
     rast[gid] = r;
     if (!act[gid >> 6]) { shaded[gid] = z; aa[gid] = z; }
-}
-
-// The forward shading itself is fused into the rasterizer's resolve pass (raster.hip), which writes the rgba pair for every
-// pixel of a segment that received fragments.  Active segments WITHOUT coverage (neighbours of covered ones, valid_mask-only
-// ones) get their zeros here.
-__global__ void __launch_bounds__(kBlock)
-k_fill_uncovered(long long N, const int* __restrict__ fill_list, const int* __restrict__ fill_count,
-                 float4* __restrict__ shaded, float4* __restrict__ aa_init, const float* __restrict__ cnt_part, int nb_cnt,
-                 int* __restrict__ n_valid, float* __restrict__ n_valid_f)
-{
-    if (blockIdx.x == 0) {                                           // the step's local valid-pixel count (saves a launch)
-        __shared__ float sm[4];
-        float acc = 0.f;
-        for (int i = threadIdx.x; i < nb_cnt; i += kBlock) acc += cnt_part[i];
-        float r = block_sum(acc, sm);
-        if (threadIdx.x == 0) { n_valid[0] = (int)(r + 0.5f); n_valid_f[0] = (float)(int)(r + 0.5f); }
-    }
-    const int count = *fill_count, lane = threadIdx.x & 63;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
-        const long long seg = fill_list[i];
-        const long long gid = (seg << 6) + lane;
-        if (gid < N) { shaded[gid] = z; aa_init[gid] = z; }
-    }
 }
 
 // losses + their per-pixel gradients over the active segments:
@@ -567,15 +549,18 @@ int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char
 }
 
 int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
-                         int* act_list, int* act_count, int* fill_list, const int* seg_valid, float* cnt_part, hipStream_t st)
+                         int* act_list, int* act_count, const int* seg_valid, float* cnt_part, float* shaded, float* aa_init,
+                         hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     long long nSeg = (N + 63) >> 6;
-    k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, fill_list, seg_valid,
-                                                                   cnt_part);
+    k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, seg_valid, cnt_part, N,
+                                                                   (float4*)shaded, (float4*)aa_init);
     FMHR_CHECK_LAUNCH("k_active_segments");
     return FMHR_OK;
 }
+
+int active_segments_blocks(long long N) { return cdiv((N + 63) >> 6, kActBlock); }
 
 int densify_impl(const unsigned long long* covw, const unsigned char* act, long long N, const float* pix16, float* rast, float* shaded,
                  float* aa,
@@ -584,17 +569,6 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
     if (N == 0) return FMHR_OK;
     k_densify<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, act, N, (const float4*)pix16, (float4*)rast, (float4*)shaded, (float4*)aa);
     FMHR_CHECK_LAUNCH("k_densify");
-    return FMHR_OK;
-}
-
-int fill_uncovered_impl(long long N, const int* fill_list, const int* fill_count, float* shaded, float* aa_init, const float* cnt_part,
-                        int* n_valid, float* n_valid_f, hipStream_t st)
-{
-    if (N == 0) return FMHR_OK;
-    const int nb_cnt = cdiv((N + 63) >> 6, kActBlock);               // workgroups of k_active_segments
-    k_fill_uncovered<<<1024, kBlock, 0, st>>>(N, fill_list, fill_count, (float4*)shaded, (float4*)aa_init, cnt_part, nb_cnt, n_valid,
-                                              n_valid_f);
-    FMHR_CHECK_LAUNCH("k_fill_uncovered");
     return FMHR_OK;
 }
 
