@@ -554,7 +554,7 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          const float* __restrict__ dyB, int V, int H, int W, int Cdyn,
          float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos,
          const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr, bool use_gl = false,
-         float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false)
+         float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false, float4 dcol = make_float4(0.f, 0.f, 0.f, 0.f))
 {
     const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
@@ -568,7 +568,9 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
         float g;                                                          // fused step: the target's gradient is handed in
         if (use_gl) g = (c == 0) ? gl.x : ((c == 1) ? gl.y : ((c == 2) ? gl.z : gl.w));
         else g = dyA[tgt * C + c];
-        galpha += g * (colorA[pix1 * C + c] - colorA[pix0 * C + c]);
+        // fused step (use_gl): the colour difference of the pair is handed in as well (two 16-B loads by the caller)
+        const float dcl = use_gl ? ((c == 0) ? dcol.x : ((c == 1) ? dcol.y : ((c == 2) ? dcol.z : dcol.w))) : colorA[pix1 * C + c] - colorA[pix0 * C + c];
+        galpha += g * dcl;
         if (gcolorA != nullptr && g != 0.f) {
             atomicAdd(gcolorA + pix1 * C + c, alpha * g);
             atomicAdd(gcolorA + pix0 * C + c, -alpha * g);
@@ -679,8 +681,11 @@ k_aa_bwd_items(const float* __restrict__ color, const float4* __restrict__ rast,
             g.z = (d2 > 0.f) ? k1 : ((d2 < 0.f) ? -k1 : 0.f);
         }
         g.w = 2.0f * (a.w - vm) * k2;
+        const long long pix1 = pix0 + ((it.w & AA_DOWN) ? W : 1);
+        const float4 c0 = reinterpret_cast<const float4*>(color)[pix0], c1 = reinterpret_cast<const float4*>(color)[pix1];
+        const float4 dcol = make_float4(c1.x - c0.x, c1.y - c0.y, c1.z - c0.z, c1.w - c0.w);
         aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, color, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
-                          nullptr, cmat, gvert, true, g, true);
+                          nullptr, cmat, gvert, true, g, true, dcol);
     }
 }
 
