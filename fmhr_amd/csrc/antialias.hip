@@ -456,45 +456,58 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
     __syncthreads();
     const int count = *act_count, lane = threadIdx.x & 63;
     const long long P = (long long)H * W, N = (long long)n * P, nSeg = (N + 63) >> 6;
-    // software-pipelined over the wave's segments: the segment id and the four coverage words of the NEXT iteration are requested
-    // while the current one runs (two dependent levels off every iteration's chain)
+    // software-pipelined over the wave's segments, three stages: A(i) requests the segment id and its four coverage words, B(i)
+    // turns them into coverage flags and requests the lane's per-pixel words, C(i) decodes and tests the two pairs.  While
+    // C(i) runs, the loads of B(i+1) and A(i+2) are in flight: no iteration waits for a dependent chain of three loads.
     const int stride = gridDim.x * 4;
-    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    long long seg_n = 0;
-    unsigned long long w0_n = 0ull, wR_n = 0ull, wD0_n = 0ull, wD1_n = 0ull;
-    auto fetch = [&](int ii) {
+    struct Words { long long seg; unsigned long long w0, wR, wD0, wD1; };
+    struct Pix { long long seg; int b, px, py; bool live, c0, cD, cR63, inR, inD; float4 r0, rD, rR; };
+    auto stageA = [&](int ii, Words& wd) {
+        wd.seg = -1; wd.w0 = wd.wR = wd.wD0 = wd.wD1 = 0ull;
         if (ii < count) {
-            seg_n = act_list[ii];
-            const long long sDn = ((seg_n << 6) + W) >> 6;
-            w0_n = covw[seg_n]; wR_n = covw_or0(covw, seg_n + 1, nSeg); wD0_n = covw_or0(covw, sDn, nSeg); wD1_n = covw_or0(covw, sDn + 1, nSeg);
+            wd.seg = act_list[ii];
+            const long long sDn = ((wd.seg << 6) + W) >> 6;
+            wd.w0 = covw[wd.seg]; wd.wR = covw_or0(covw, wd.seg + 1, nSeg); wd.wD0 = covw_or0(covw, sDn, nSeg);
+            wd.wD1 = covw_or0(covw, sDn + 1, nSeg);
         }
     };
-    fetch(i);
-    for (; i < count; i += stride) {
-        const long long seg = seg_n;
-        const unsigned long long w0 = w0_n, wR = wR_n, wD0 = wD0_n, wD1 = wD1_n;
-        const long long gid = (seg << 6) + lane;
-        const bool live = gid < N;
-        const long long gidD = gid + W;
-        const long long sD = ((seg << 6) + W) >> 6;
-        int b = 0, px = 0, py = 0;
-        if (live) {
+    auto stageB = [&](const Words& wd, Pix& q) {
+        q.seg = wd.seg;
+        q.r0 = make_float4(0.f, 0.f, 0.f, 0.f); q.rD = q.r0; q.rR = q.r0;
+        q.b = 0; q.px = 0; q.py = 0;
+        q.live = false; q.c0 = q.cD = q.cR63 = q.inR = q.inD = false;
+        if (wd.seg < 0) return;
+        const long long gid = (wd.seg << 6) + lane, gidD = gid + W, sD = ((wd.seg << 6) + W) >> 6;
+        q.live = gid < N;
+        if (q.live) {
             int rem;
-            b = fast_divmod(gid, (int)P, rem);
-            py = fast_divmod(rem, W, px);
+            q.b = fast_divmod(gid, (int)P, rem);
+            q.py = fast_divmod(rem, W, q.px);
         }
-        const bool c0 = live && ((w0 >> lane) & 1ull);
-        const bool inR = live && px + 1 < W, inD = live && py + 1 < H;
-        const bool cD = inD && ((((gidD >> 6) == sD ? wD0 : wD1) >> (gidD & 63)) & 1ull);
-        const bool cR63 = inR && (wR & 1ull);                       // only lane 63 looks into the next segment
+        q.c0 = q.live && ((wd.w0 >> lane) & 1ull);
+        q.inR = q.live && q.px + 1 < W; q.inD = q.live && q.py + 1 < H;
+        q.cD = q.inD && ((((gidD >> 6) == sD ? wd.wD0 : wd.wD1) >> (gidD & 63)) & 1ull);
+        q.cR63 = q.inR && (wd.wR & 1ull);                            // only lane 63 looks into the next segment
         // the per-pixel word (u, v, z/w, packed id | flags) is only defined on covered pixels: an uncovered pixel is the all-zero
-        // fragment.  After the loads .w holds the dr.rasterize id (face + 1 as a float) and .x the face's silhouette bits.
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), rD = r0, rR = r0;
-        if (c0) r0 = rast[gid];
-        if (cD) rD = rast[gidD];
-        if (lane == 63 && cR63) rR = rast[gid + 1];
-        fetch(i + stride);                                          // next iteration's segment + coverage words
+        // fragment
+        if (q.c0) q.r0 = rast[gid];
+        if (q.cD) q.rD = rast[gidD];
+        if (lane == 63 && q.cR63) q.rR = rast[gid + 1];
+    };
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    Words wd;
+    Pix cur, nxt;
+    stageA(i, wd);
+    stageB(wd, cur);
+    stageA(i + stride, wd);
+    for (; i < count; i += stride) {
+        stageB(wd, nxt);                                             // pixel words of iteration i + 1
+        stageA(i + 2 * stride, wd);                                  // segment + coverage words of iteration i + 2
+        float4 r0 = cur.r0, rD = cur.rD, rR = cur.rR;
         pin(r0); pin(rD); pin(rR);
+        const int b = cur.b, px = cur.px, py = cur.py;
+        const bool c0 = cur.c0, cD = cur.cD, cR63 = cur.cR63, inR = cur.inR, inD = cur.inD;
+        // after the decode .w holds the dr.rasterize id (face + 1 as a float) and .x the face's silhouette bits
         auto decode = [](float4& r, bool cov) {
             const int p = __float_as_int(r.w);
             r.x = cov ? (float)pix_silh(p) : 0.f;
@@ -526,6 +539,7 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
                             ibuf, abuf, &inum, region, rbase);
             }
         }
+        cur = nxt;
     }
     __syncthreads();
     {
