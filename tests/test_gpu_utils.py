@@ -87,22 +87,26 @@ def test_large_mesh_vs_oracle(U, oracle):
 
 
 def test_adam_matches_torch():
-    """fmhr_amd.optim.Adam == torch.optim.Adam (per-group lr, default betas/eps) over 25 steps."""
+    """fmhr_amd.optim.Adam == torch.optim.Adam (per-group lr, default betas/eps) over 25 steps; three parameters, so both the
+    paired launch (fmhr_adam_step2) and the single one (fmhr_adam_step) run."""
     from fmhr_amd.optim import Adam
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    a0, b0 = torch.randn(1000, 3, device=dev), torch.randn(1, 777, 3, device=dev)
-    pa, pb = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
-    qa, qb = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
-    ref = torch.optim.Adam([{'params': pa, 'lr': 1e-4}, {'params': pb, 'lr': 5e-3}])
-    mine = Adam([{'params': qa, 'lr': 1e-4}, {'params': qb, 'lr': 5e-3}])
+    init = [torch.randn(1000, 3, device=dev), torch.randn(1, 777, 3, device=dev), torch.randn(48, 9, device=dev)]
+    lrs = [1e-4, 5e-3, 1e-3]
+    p = [t.clone().requires_grad_(True) for t in init]
+    q = [t.clone().requires_grad_(True) for t in init]
+    ref = torch.optim.Adam([{'params': t, 'lr': lr} for t, lr in zip(p, lrs)])
+    mine = Adam([{'params': t, 'lr': lr} for t, lr in zip(q, lrs)])
     for i in range(25):
-        ga, gb = torch.randn_like(a0) * (1 + i), torch.randn_like(b0) * 0.01
-        pa.grad, pb.grad, qa.grad, qb.grad = ga.clone(), gb.clone(), ga.clone(), gb.clone()
+        gs = [torch.randn_like(init[0]) * (1 + i), torch.randn_like(init[1]) * 0.01, torch.randn_like(init[2])]
+        for t, u, g in zip(p, q, gs):
+            t.grad, u.grad = g.clone(), g.clone()
         ref.step()
         mine.step()
-    assert rel_err(qa, pa) < 1e-6 and rel_err(qb, pb) < 1e-6
-    assert rel_err(qa - a0, pa - a0) < 1e-4 and rel_err(qb - b0, pb - b0) < 1e-4
+    for t, u, t0 in zip(p, q, init):
+        assert rel_err(u, t) < 1e-6
+        assert rel_err(u - t0, t - t0) < 1e-4
 
 
 def test_ncc_golden_and_grad(golden, oracle):
