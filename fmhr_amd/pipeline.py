@@ -76,6 +76,44 @@ def stage1_loss(ops, glctx, vertices, faces, albedo, sh_coeff, w2c, proj, img, m
     return sfs_weight * F.l1_loss(pred_img, img[valid_idx])
 
 
+class Stage1Cache:
+    """Everything of the stage-1 batch (mesh_sfs_optim.py:205-233) that does not depend on the optimised variables.  Stage 1 moves
+    only the albedo and the SH coefficients: the vertices, hence the clip positions, the rasterization, the antialiased +
+    normalised normals, their SH basis and the validity mask are the same in every one of its iterations.  They are computed once
+    per view here; an iteration is then interpolate(albedo) -> antialias -> (basis . sh) * albedo -> masked L1 — the reference
+    (and `stage1_loss`) re-rasterizes and re-derives the normals 150 x num / batch times."""
+
+    def __init__(self, ops, glctx, vertices, faces, w2cs, projs, masks, resolution, degree=3, chunk=8):
+        num = w2cs.shape[0]
+        self.faces, self.resolution = faces, resolution
+        rast, pos, basis, valid = [], [], [], []
+        with torch.no_grad():
+            for k in range(0, num, chunk):
+                w2c, proj = w2cs[k:k + chunk], projs[k:k + chunk]
+                vertsw, proj_verts = clip_positions(vertices, w2c, proj)
+                normals = ops.get_normals(vertsw[:, :, :3].contiguous(), faces.long())
+                r, _ = ops.rasterize(glctx, proj_verts, faces, resolution=resolution)
+                feat, _ = ops.interpolate(normals.contiguous(), r, faces)
+                pn = F.normalize(ops.antialias(feat.contiguous(), r, proj_verts, faces), p=2, dim=3)
+                rast.append(r); pos.append(proj_verts)
+                basis.append(ops.get_matrix(pn.reshape(-1, 3), degree).reshape(*pn.shape[:3], -1))     # [c,H,W,9]
+                valid.append(((masks[k:k + chunk] > 0) & (r[..., 3] > 0)).to(torch.float32))
+        self.rast, self.pos = torch.cat(rast), torch.cat(pos)
+        self.basis, self.valid = torch.cat(basis), torch.cat(valid)
+
+
+def stage1_loss_cached(ops, cache, idx, albedo, sh_coeff, img, sfs_weight):
+    """`stage1_loss` for the views `idx` of a Stage1Cache: same value and gradients (the constant sub-graph is cached, the boolean
+    gather of the valid pixels becomes a mask — no host synchronisation)."""
+    rast, pos = cache.rast[idx], cache.pos[idx]
+    feat, _ = ops.interpolate(albedo.expand(idx.shape[0], -1, -1).contiguous(), rast, cache.faces)
+    rast_albedo = ops.antialias(feat.contiguous(), rast, pos, cache.faces)
+    radiance = (cache.basis[idx] * sh_coeff[:, None, None, :]).sum(-1, keepdim=True)
+    valid = cache.valid[idx].unsqueeze(-1)
+    diff = ((radiance * rast_albedo - img) * valid).abs().sum()
+    return sfs_weight * diff / (3.0 * valid.sum())
+
+
 def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0):
     """The HAM optimisation end to end on GPU tensors.  conf: dict with the keys of conf/demo_sfs.conf that the loop reads.
     Returns dict(vertices, delta, albedo, sh_coeffs, history)."""
@@ -98,12 +136,12 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     # ---- stage 1: albedo + SH (:193-240)
     opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
     glctx = ops.RasterizeGLContext()
+    cache = Stage1Cache(ops, glctx, vertices_tmp, faces, w2cs, projs, masks, resolution, degree)
     for ep in range(int(conf["epoch_albedo"])):
         perm = torch.randperm(num, generator=gen).to(dev)
         for k in range(0, num, batch):
             idx = perm[k:k + batch]
-            loss = stage1_loss(ops, glctx, vertices_tmp, faces, albedo, sh_coeffs[idx], w2cs[idx], projs[idx], imgs[idx], masks[idx],
-                               resolution, conf["sfs_weight"], degree)
+            loss = stage1_loss_cached(ops, cache, idx, albedo, sh_coeffs[idx], imgs[idx], conf["sfs_weight"])
             opt.zero_grad()
             loss.backward()
             opt.step()

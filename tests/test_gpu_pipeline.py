@@ -39,6 +39,15 @@ def test_init_and_stage1_match_checker(oracle):
     # take the other side of a rule, hence the looser bound here (the decision-exact comparison is test_gpu_dr / test_gpu_ham)
     assert abs(float(lg) - float(lc)) < 1e-3 * abs(float(lc))
     assert rel_err(alb_g.grad, alb_c.grad) < 2e-2 and rel_err(sh_g.grad, sh_c.grad) < 2e-3
+    # the cached form run_ham uses (constant sub-graph of stage 1 computed once, validity as a mask): same value and gradients
+    cache = pipeline.Stage1Cache(ops, ops.RasterizeGLContext(), g["vertices"], g["faces"], g["w2c"], g["proj"], g["mask"], res)
+    alb_k = alb_g.detach().clone().requires_grad_(True)
+    sh_k = sh_g.detach().clone().requires_grad_(True)
+    idx = torch.arange(g["w2c"].shape[0], device=dev)
+    lk = pipeline.stage1_loss_cached(ops, cache, idx, alb_k, sh_k, g["img"], 50.0)
+    lk.backward()
+    assert abs(float(lk) - float(lg)) < 1e-5 * abs(float(lg))
+    assert rel_err(alb_k.grad, alb_g.grad) < 1e-4 and rel_err(sh_k.grad, sh_g.grad) < 1e-4
 
 
 def test_run_ham_end_to_end(oracle, tmp_path):
