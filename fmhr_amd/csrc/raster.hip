@@ -100,14 +100,14 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
 // and expand their coverage bits into a dense per-wave task list; every lane then takes tasks round-robin.  A lane looping over
 // its own bits made the whole wave iterate max(bits) times with ~a quarter of the lanes active (the ~100-instruction fragment
 // evaluation was 69 of this kernel's 127 us).
-constexpr int kTaskCap = 1024;       // tasks expanded per round (a wave can hold 64 x 64; more rounds then)
+constexpr int kTaskCap = 512;        // tasks expanded per round (a wave can hold 64 x 64; more rounds then)
 
 struct TriPark {
     float4 p0, p1, p2;
     int f, b, origin, bw;            // origin = pxa | pya << 16
 };
 
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, int* __restrict__ large_cnt,
