@@ -143,7 +143,7 @@ __global__ void k_adj_sort_rows(int V, const int* __restrict__ row_ptr, int* col
     }
 }
 
-// vertex -> incident face corners (code = 3*face + corner), CSR with sorted rows: the gather-style backward walks it
+// vertex -> incident face corners (code = 3*face + corner), CSR with sorted rows: the per-vertex kernels of the fused step walk it
 __global__ void k_vf_count(const int32_t* __restrict__ tri, int F, int V, int* deg)
 {
     int code = blockIdx.x * kBlock + threadIdx.x;
@@ -313,8 +313,7 @@ __device__ __forceinline__ void aa_fwd_pixel(long long gid, bool live, const flo
          const float* __restrict__ pos, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
          const unsigned char* __restrict__ silh, const unsigned long long* __restrict__ covw,
          int n, int V, int F, int H, int W, int Cdyn, float* __restrict__ outA, float* __restrict__ outB,
-         int4* __restrict__ items, float* __restrict__ alphas, int32_t* counter, int cap,
-         unsigned char* __restrict__ px_code, float* __restrict__ px_alpha)
+         int4* __restrict__ items, float* __restrict__ alphas, int32_t* counter, int cap)
 {
     long long P = (long long)H * W;
     int b = 0, px = 0, py = 0;
@@ -357,16 +356,7 @@ __device__ __forceinline__ void aa_fwd_pixel(long long gid, bool live, const flo
                 }
             }
         }
-        if (px_code != nullptr) {
-            // fused step: the work item stays in place (2 slots per pixel), no queue: a global queue costs one RETURNING
-            // same-address atomic per wave with an item, and ~30k of those serialise to ~0.25 ms per step
-            if (live) {
-                px_code[gid * 2 + d] = (unsigned char)code;
-                if (has) px_alpha[gid * 2 + d] = alpha;
-            }
-        } else {
-            queue_push(has, make_int4(px, py, b, code), alpha, counter, cap, items, alphas);
-        }
+        queue_push(has, make_int4(px, py, b, code), alpha, counter, cap, items, alphas);
     }
 }
 
@@ -380,10 +370,11 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     aa_fwd_pixel<CA, CB>(gid, gid < (long long)n * H * W, colorA, colorB, rast, pos, tri, opp, nullptr, nullptr, n, V, F, H, W, Cdyn,
-                         outA, outB, items, alphas, counter, cap, nullptr, nullptr);
+                         outA, outB, items, alphas, counter, cap);
 }
 
-// fused step: persistent waves over the compacted list of active 64-pixel segments, rgba colour, in-place items.
+// fused step: persistent waves over the compacted list of active 64-pixel segments, rgba colour, work items into the
+// workgroup's region of the list.
 // Per segment: the coverage words of the own / next / lower segments are wave-uniform loads; then every lane issues its two
 // rast loads (own, lower) together — the right neighbour's fragment is the next lane's register — and only pairs with different
 // triangle ids go on (silhouette byte first).  Colours are read as 16-B words only by the pairs that blend.
@@ -723,8 +714,8 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
     return FMHR_OK;
 }
 
-// fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour), in-place items,
-// persistent grids over the active-segment list
+// fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour), `rast` = the step's
+// per-pixel word (shade_common.h), work items in per-workgroup regions of one list, persistent grids
 int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                 const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw, int n,
                 int V, int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int32_t* region_cnt, int cap,

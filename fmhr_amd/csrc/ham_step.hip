@@ -42,15 +42,7 @@ int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const 
                 int, int, float*, const float*, float*, hipStream_t);
 int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, const float*,
                             float*, const float*, float*, hipStream_t);
-int normals_bwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float*, int, float*,
-                            float*, hipStream_t);
-int edge_hinge_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, int, float, float, float, float*,
-                           float*, hipStream_t);
-int lap_fwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, float*, float*, hipStream_t);
-int lap_bwd_impl(const float*, const int32_t*, const int32_t*, int, int, float, float*, float*, hipStream_t);
-int add_delta_impl(const float*, const float*, int, float*, hipStream_t);
 int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
-int delta_term_impl(const float*, int, float, float, float*, float*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; };
@@ -323,7 +315,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                           (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), et, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
     }
     {
-        // everything per-vertex after the gather, in two kernels (mesh.hip: k_mesh_tail_a / _b)
+        // everything per-vertex after the face-parallel backward, in two kernels (mesh.hip: k_mesh_tail_a / _b)
         ProfScope ps(FMHR_SLOT_REGULARISERS, st);
         MeshTailArgs A;
         A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n);

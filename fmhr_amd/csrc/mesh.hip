@@ -233,15 +233,6 @@ k_lap_bwd_gather(const float* __restrict__ rowg, const int32_t* __restrict__ row
     for (int c = 0; c < C; c++) gx[(size_t)j * C + c] += acc[c];
 }
 
-// ------------------------------------------------------------------------------------------------ fused-step mesh kernels
-// vertices = vertices_tmp + delta (mesh_sfs_optim.py:253)
-__global__ void __launch_bounds__(kBlock)
-k_add_delta(const float* __restrict__ a, const float* __restrict__ b, int N, float* __restrict__ o)
-{
-    int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < N) o[i] = a[i] + b[i];
-}
-
 // pos[b,v,:] = ([v,1] @ w2c[b]) @ proj[b]  — row-vector convention, two steps like the reference's two einsums
 __global__ void __launch_bounds__(kBlock)
 k_transform_fwd(const float* __restrict__ verts, const float* __restrict__ w2c, const float* __restrict__ proj, int V,
@@ -275,79 +266,7 @@ k_transform_fwd(const float* __restrict__ verts, const float* __restrict__ w2c, 
     }
 }
 
-// gverts[v] += sum_b ((gpos[b,v] @ proj[b]^T) @ w2c[b]^T)[:3]   (one lane per vertex, no atomics)
-__global__ void __launch_bounds__(kBlock)
-k_transform_bwd(const float4* __restrict__ gpos, const float* __restrict__ w2c, const float* __restrict__ proj, int n, int V,
-                float* __restrict__ gverts)
-{
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= V) return;
-    float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int b = 0; b < n; b++) {
-        const float* A = w2c + (size_t)b * 16;
-        const float* B = proj + (size_t)b * 16;
-        float4 g = gpos[(size_t)b * V + v];
-        float r[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = g.x * B[k * 4] + g.y * B[k * 4 + 1] + g.z * B[k * 4 + 2] + g.w * B[k * 4 + 3];
-        ax += r[0] * A[0] + r[1] * A[1] + r[2] * A[2] + r[3] * A[3];
-        ay += r[0] * A[4] + r[1] * A[5] + r[2] * A[6] + r[3] * A[7];
-        az += r[0] * A[8] + r[1] * A[9] + r[2] * A[10] + r[3] * A[11];
-    }
-    gverts[(size_t)v * 3] += ax; gverts[(size_t)v * 3 + 1] += ay; gverts[(size_t)v * 3 + 2] += az;
-}
-
-// edge hinge: mean over the 3F directed face edges of clip(|e|^2 - m, 0, 1) (mesh_sfs_optim.py:296-302)
-__global__ void __launch_bounds__(kBlock)
-k_edge_hinge(const float* __restrict__ verts, const int32_t* __restrict__ tri, int V, int F, float mean_len, float wscale,
-             float gscale, float* __restrict__ loss, float* __restrict__ gverts)
-{
-    __shared__ float sm[4];
-    int f = blockIdx.x * kBlock + threadIdx.x;
-    float part = 0.f;
-    if (f < F) {
-        int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
-        if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
-            float3 a = ld3(verts + (size_t)i0 * 3), b = ld3(verts + (size_t)i1 * 3), c = ld3(verts + (size_t)i2 * 3);
-            float3 e[3] = {sub3(a, b), sub3(c, b), sub3(a, c)};
-            int hi[3] = {i0, i2, i0}, lo[3] = {i1, i1, i2};
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                float l2 = e[k].x * e[k].x + e[k].y * e[k].y + e[k].z * e[k].z;
-                float d = l2 - mean_len;
-                part += fminf(fmaxf(d, 0.f), 1.f);
-                if (gscale != 0.f && d > 0.f && d < 1.f) {
-                    float3 g = make_float3(2.f * e[k].x * gscale, 2.f * e[k].y * gscale, 2.f * e[k].z * gscale);
-                    atomic_add3(gverts + (size_t)hi[k] * 3, g);
-                    atomic_add3(gverts + (size_t)lo[k] * 3, make_float3(-g.x, -g.y, -g.z));
-                }
-            }
-        }
-    }
-    float s = block_sum(part, sm);
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s * wscale);
-}
-
 // delta term: mean_v |delta_v|^2 (mesh_sfs_optim.py:304); gdelta += gscale * 2 delta
-__global__ void __launch_bounds__(kBlock)
-k_delta_term(const float* __restrict__ delta, int V, float wscale, float gscale, float* __restrict__ loss, float* __restrict__ gdelta)
-{
-    __shared__ float sm[4];
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    float part = 0.f;
-    if (v < V) {
-        float3 d = ld3(delta + (size_t)v * 3);
-        part = d.x * d.x + d.y * d.y + d.z * d.z;
-        if (gscale != 0.f) {
-            gdelta[(size_t)v * 3] += 2.f * d.x * gscale;
-            gdelta[(size_t)v * 3 + 1] += 2.f * d.y * gscale;
-            gdelta[(size_t)v * 3 + 2] += 2.f * d.z * gscale;
-        }
-    }
-    float s = block_sum(part, sm);
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s * wscale);
-}
-
 // ------------------------------------------------------------------------------------------------ Adam (A13)
 // torch.optim.Adam step (amsgrad=False, weight_decay=0, maximize=False) — mesh_sfs_optim.py:244,310.  torch's fused
 // multi_tensor kernel takes ~94 us per parameter group here (147k elements each); this one is bandwidth-trivial.
@@ -443,76 +362,10 @@ k_normals_gather(const float* __restrict__ verts, const int32_t* __restrict__ tr
     }
 }
 
-// gverts[v] += sum over incident faces of this vertex's share of d(sum_k g_s[i_k] . cross_k)/d verts
-__global__ void __launch_bounds__(kBlock)
-k_normals_bwd_gather(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
-                     const int32_t* __restrict__ vf_idx, const float* __restrict__ gs, int V, float* __restrict__ gverts)
-{
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= V) return;
-    float3 acc = make_float3(0.f, 0.f, 0.f);
-    for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
-        int code = vf_idx[e];
-        int f = code / 3, c = code - f * 3;
-        int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
-        float3 p[3] = {ld3(verts + (size_t)i[0] * 3), ld3(verts + (size_t)i[1] * 3), ld3(verts + (size_t)i[2] * 3)};
-        float3 g[3] = {ld3(gs + (size_t)i[0] * 3), ld3(gs + (size_t)i[1] * 3), ld3(gs + (size_t)i[2] * 3)};
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-            float3 e1 = sub3(p[k1], p[k]), e2 = sub3(p[k2], p[k]);
-            float3 ge1 = cross3(e2, g[k]), ge2 = cross3(g[k], e1);
-            if (c == k1) { acc.x += ge1.x; acc.y += ge1.y; acc.z += ge1.z; }
-            if (c == k2) { acc.x += ge2.x; acc.y += ge2.y; acc.z += ge2.z; }
-            if (c == k) { acc.x -= ge1.x + ge2.x; acc.y -= ge1.y + ge2.y; acc.z -= ge1.z + ge2.z; }
-        }
-    }
-    gverts[(size_t)v * 3] += acc.x; gverts[(size_t)v * 3 + 1] += acc.y; gverts[(size_t)v * 3 + 2] += acc.z;
-}
-
-// edge hinge by gather: the loss of a face's three directed edges is accounted by its corner 0; gradients by each corner
-__global__ void __launch_bounds__(kBlock)
-k_edge_hinge_gather(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
-                    const int32_t* __restrict__ vf_idx, int V, float mean_len, float wscale, float gscale,
-                    float* __restrict__ loss, float* __restrict__ gverts)
-{
-    __shared__ float sm[4];
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    float part = 0.f;
-    if (v < V) {
-        float3 acc = make_float3(0.f, 0.f, 0.f);
-        for (int e = vf_ptr[v]; e < vf_ptr[v + 1]; e++) {
-            int code = vf_idx[e];
-            int f = code / 3, c = code - f * 3;
-            float3 a = ld3(verts + (size_t)tri[f * 3] * 3), b = ld3(verts + (size_t)tri[f * 3 + 1] * 3),
-                   cc = ld3(verts + (size_t)tri[f * 3 + 2] * 3);
-            // edges (a-b), (c-b), (a-c) with signs per corner: corner0: +e0 +e2, corner1: -e0 -e1, corner2: +e1 -e2
-            float3 ed[3] = {sub3(a, b), sub3(cc, b), sub3(a, cc)};
-            const float sgn[3][3] = {{1.f, 0.f, 1.f}, {-1.f, -1.f, 0.f}, {0.f, 1.f, -1.f}};
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                float l2 = ed[k].x * ed[k].x + ed[k].y * ed[k].y + ed[k].z * ed[k].z;
-                float d = l2 - mean_len;
-                if (c == 0) part += fminf(fmaxf(d, 0.f), 1.f);
-                float sg = sgn[c][k];
-                if (d > 0.f && d < 1.f && sg != 0.f) {
-                    float w = 2.f * gscale * sg;
-                    acc.x += w * ed[k].x; acc.y += w * ed[k].y; acc.z += w * ed[k].z;
-                }
-            }
-        }
-        if (gscale != 0.f) {
-            gverts[(size_t)v * 3] += acc.x; gverts[(size_t)v * 3 + 1] += acc.y; gverts[(size_t)v * 3 + 2] += acc.z;
-        }
-    }
-    float s = block_sum(part, sm);
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s * wscale);
-}
-
 // ------------------------------------------------------------------------------------------------ fused backward tail
 // The stage-2 backward ends in thirteen tiny per-vertex kernels (each >= 4.5 us of launch + dependent-load latency for 49k
 // vertices); they collapse into two, split where a vertex needs its NEIGHBOURS' intermediate results.
-// A (own data only): sum the gather partials -> view-dependent gradients; normal-normalise backward -> gs; both uniform
+// A (own data only): sum the face-backward corner slots -> view-dependent gradients; normal-normalise backward -> gs; both uniform
 //    Laplacians forward -> loss terms and scaled row gradients; delta term; edge hinge (loss + gradient).
 // B (neighbour gathers): vertex-normal backward from gs, L^T r for both Laplacians -> final gdelta / galbedo.
 struct MeshTailArgs {
@@ -750,27 +603,6 @@ int normals_fwd_gather_impl(const float* verts, const int32_t* tri, const int32_
     return FMHR_OK;
 }
 
-int normals_bwd_gather_impl(const float* verts, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx,
-                            const float* nsum, const float* gn, int V, float* gtmp, float* gverts, hipStream_t st)
-{
-    if (V == 0) return FMHR_OK;
-    k_normals_bwd_vertex<<<cdiv(V, kBlock), kBlock, 0, st>>>(nsum, gn, 3, (long long)V, gtmp);
-    FMHR_CHECK_LAUNCH("k_normals_bwd_vertex");
-    k_normals_bwd_gather<<<cdiv(V, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, gtmp, V, gverts);
-    FMHR_CHECK_LAUNCH("k_normals_bwd_gather");
-    return FMHR_OK;
-}
-
-int edge_hinge_gather_impl(const float* verts, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, int V, int F,
-                           float mean_len, float weight, float gscale, float* loss, float* gverts, hipStream_t st)
-{
-    if (F == 0 || V == 0) return FMHR_OK;
-    k_edge_hinge_gather<<<cdiv(V, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, mean_len, weight / (3.0f * (float)F),
-                                                           gscale / (3.0f * (float)F), loss, gverts);
-    FMHR_CHECK_LAUNCH("k_edge_hinge_gather");
-    return FMHR_OK;
-}
-
 int normals_fwd_impl(const float* verts, const int32_t* tri, int nb, int V, int F, float* nsum, float* normals, hipStream_t st)
 {
     long long N = (long long)nb * V;
@@ -832,46 +664,12 @@ int lap_bwd_impl(const float* lx, const int32_t* row_ptr, const int32_t* col, in
     return FMHR_OK;
 }
 
-int add_delta_impl(const float* a, const float* b, int N, float* o, hipStream_t st)
-{
-    if (N == 0) return FMHR_OK;
-    k_add_delta<<<cdiv(N, kBlock), kBlock, 0, st>>>(a, b, N, o);
-    FMHR_CHECK_LAUNCH("k_add_delta");
-    return FMHR_OK;
-}
-
 int transform_fwd_impl(const float* verts, const float* w2c, const float* proj, int n, int V, float* pos, int H, int W,
                        int2* snap, float* cmat, hipStream_t st)
 {
     if (n == 0 || V == 0) return FMHR_OK;
     k_transform_fwd<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>(verts, w2c, proj, V, (float4*)pos, H, W, snap, (float4*)cmat);
     FMHR_CHECK_LAUNCH("k_transform_fwd");
-    return FMHR_OK;
-}
-
-int transform_bwd_impl(const float* gpos, const float* w2c, const float* proj, int n, int V, float* gverts, hipStream_t st)
-{
-    if (n == 0 || V == 0) return FMHR_OK;
-    k_transform_bwd<<<cdiv(V, kBlock), kBlock, 0, st>>>((const float4*)gpos, w2c, proj, n, V, gverts);
-    FMHR_CHECK_LAUNCH("k_transform_bwd");
-    return FMHR_OK;
-}
-
-int edge_hinge_impl(const float* verts, const int32_t* tri, int V, int F, float mean_len, float weight, float gscale,
-                    float* loss, float* gverts, hipStream_t st)
-{
-    if (F == 0) return FMHR_OK;
-    k_edge_hinge<<<cdiv(F, kBlock), kBlock, 0, st>>>(verts, tri, V, F, mean_len, weight / (3.0f * (float)F),
-                                                      gscale / (3.0f * (float)F), loss, gverts);
-    FMHR_CHECK_LAUNCH("k_edge_hinge");
-    return FMHR_OK;
-}
-
-int delta_term_impl(const float* delta, int V, float weight, float gscale, float* loss, float* gdelta, hipStream_t st)
-{
-    if (V == 0) return FMHR_OK;
-    k_delta_term<<<cdiv(V, kBlock), kBlock, 0, st>>>(delta, V, weight / (float)V, gscale / (float)V, loss, gdelta);
-    FMHR_CHECK_LAUNCH("k_delta_term");
     return FMHR_OK;
 }
 

@@ -287,12 +287,11 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
     }
 }
 
-// per pixel: decode the winning key, recompute its fragment, write (u, v, z/w, id+1) as one 16-B store; optionally thread
-// the pixel onto its triangle's list (head [F,npad] face-major with the views innermost / next [n,H,W]) for the gather-style
-// backward.
+// per pixel: decode the winning key, recompute its fragment, write (u, v, z/w, id+1) as one 16-B store.
 // Sparse mode (dirty != null, fused step): a wave owns one 64-pixel segment; a clean segment costs one scalar load; a dirty one
-// is resolved, its keys are reset to "empty" (the key buffer cleans itself: no per-step 100 MB memset), covered lanes get
-// their rast written (uncovered lanes are zero-filled later, only where a consumer will look), and the coverage word is stored.
+// is resolved, its keys are reset to "empty" (the key buffer cleans itself: no per-step 100 MB memset), and the coverage word is
+// stored.  The fused step (RasterFused) also shades the covered pixels here, leaves its per-pixel word (shade_common.h) instead
+// of `rast`, marks the owning (view, face) and counts the valid pixels of the segment.
 __global__ void __launch_bounds__(kBlock)
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
@@ -537,7 +536,7 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
     return FMHR_OK;
 }
 
-// snap [n,V] int2 must already hold the snapped vertices; head/next may be null.  dirty/covw non-null = sparse mode (the key
+// snap [n,V] int2 must already hold the snapped vertices; `fused` may be null.  dirty/covw non-null = sparse mode (the key
 // buffer must have been initialised by raster_sparse_init and is left clean again).
 int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, const int32_t* opp, unsigned char* silh, int n, int V,
                        int F, int H, int W, float* rast, void* ws, unsigned char* dirty, unsigned long long* covw,
