@@ -130,12 +130,12 @@ def cpu_baseline(scene, views_sample, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)      # 0.1 s of device time at ~0.5 ms per step
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="metric", choices=list(synthetic.CONFIGS))
     ap.add_argument("--views", type=int, default=None, help="override the view count of the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=16)
+    ap.add_argument("--cpu-views", type=int, default=48)   # the whole 48-view batch: 5 x ~2.6 s of CPU work, nothing extrapolated
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
