@@ -136,6 +136,15 @@ def _step_vs_oracle(oracle, sc, name, osc=None):
     return ld, v
 
 
+def test_fused_step_crumpled_mesh(oracle):
+    """a heavily perturbed (self-intersecting, crumpled) mesh: many silhouette pairs, thin and flipped triangles, long candidate
+    lists — the decisions must still match the fp32 oracle bit for bit and the antialias work-item list must not overflow."""
+    sc = prepare(oracle, (4, 128, 96, 16, 24), 21)
+    sc["delta"] = sc["delta"] * 40.0                      # ~8e-3: several edge lengths of this mesh
+    ld, v = _step_vs_oracle(oracle, sc, "crumpled")
+    assert int(v["aa_counter"][1]) == 0
+
+
 def test_fused_step_edge_cases(oracle):
     """views without any coverage, and a batch without a single valid pixel (the L1 mean over an empty set)."""
     # (a) the middle view looks past the mesh (clip x shifted by 5 w): no fragment, no coverage entry, empty segments
