@@ -288,7 +288,7 @@ __device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr&
     }
 }
 
-constexpr int kTaskG = 32;                       // candidate pixels a group expands per round
+constexpr int kTaskG = 64;                       // candidate pixels a group expands per round
 constexpr int kFacesPerBlock = kBlock / kGroup;
 constexpr int kMaxVPL = 6;                       // views per lane: a group of kGroup lanes covers kGroup * VPL views of one face
 
