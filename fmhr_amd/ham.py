@@ -73,6 +73,7 @@ class HamStage2:
         self.galbedo = self.bucket[3 * self.V: 6 * self.V].view(self.V, 3)
         self.losses = self.bucket[6 * self.V:]
         self._views = None
+        self._aa_flag = None
         self._vm_key, self._vm_ref = None, None
 
     # -- the two phases -------------------------------------------------------------------------------------------------
@@ -152,7 +153,15 @@ class HamStage2:
         return self.ws[off: off + nbytes].view(dtype)
 
     def loss_dict(self):
+        """The loss vector of the last step as a dict (one device -> host copy).  Also the place where a full antialias work-item
+        list is reported: the step never synchronises on its own, so the flag is checked when the caller reads results anyway."""
         vals = self.losses.tolist()
+        if self._aa_flag is None:
+            off = self.lib.fmhr_ham_workspace_offset(ctypes.byref(self.dims), b"aa_counter")
+            self._aa_flag = self.ws[off: off + 8].view(torch.int32)
+        if int(self._aa_flag[1]) != 0:
+            raise RuntimeError(f"HamStage2: the antialias work-item list overflowed (aa_cap={self.dims.aa_cap}): some silhouette pairs "
+                               "got no gradient in the last step; construct HamStage2 with a larger aa_cap")
         return dict(zip(LOSS_NAMES, vals))
 
 

@@ -145,6 +145,18 @@ def test_fused_step_crumpled_mesh(oracle):
     assert int(v["aa_counter"][1]) == 0
 
 
+def test_aa_list_overflow_is_reported(oracle):
+    """an antialias work-item list that is too small must not pass silently: loss_dict() raises."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (2, 128, 96, 16, 24), 22)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"], aa_cap=2048)   # 1 item per region
+    hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    with pytest.raises(RuntimeError, match="overflowed"):
+        hs.loss_dict()
+
+
 def test_fused_step_edge_cases(oracle):
     """views without any coverage, and a batch without a single valid pixel (the L1 mean over an empty set)."""
     # (a) the middle view looks past the mesh (clip x shifted by 5 w): no fragment, no coverage entry, empty segments
