@@ -40,9 +40,8 @@ int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const 
 int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
                 const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int,
                 int, int, float*, const float*, float*, hipStream_t);
-int normals_fwd_gather_impl(const float*, const int32_t*, const int32_t*, const int32_t*, int, float*, float*, const float*,
-                            float*, const float*, float*, hipStream_t);
-int transform_fwd_impl(const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, hipStream_t);
+int geometry_impl(const float*, const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, const int32_t*,
+                  const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; };
@@ -223,10 +222,10 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     unsigned long long* covw = (unsigned long long*)(w + L.covw);
     {
         ProfScope ps(FMHR_SLOT_GEOMETRY, st);
-        // vertices = vertices_tmp + delta is formed inside the normals kernel (and stored for everything after it)
-        TRY(normals_fwd_gather_impl(vertices_tmp, tri, vf_ptr, vf_idx, d->V, (float*)(w + L.nsum), (float*)(w + L.normals), albedo,
-                                    (float*)(w + L.attr8), delta, vertices, st));
-        TRY(transform_fwd_impl(vertices, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), st));
+        // one launch: clip transform of all views + vertex normals / packed attributes; vertices = vertices_tmp + delta is formed
+        // on the fly by both parts and stored for everything after them
+        TRY(geometry_impl(vertices_tmp, delta, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), tri,
+                          vf_ptr, vf_idx, (float*)(w + L.nsum), (float*)(w + L.normals), albedo, (float*)(w + L.attr8), vertices, st));
     }
     {
         // rasterize; the resolve pass also shades the covered pixels, leaves the per-pixel backward word, marks the owning

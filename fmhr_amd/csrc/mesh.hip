@@ -234,12 +234,11 @@ k_lap_bwd_gather(const float* __restrict__ rowg, const int32_t* __restrict__ row
 }
 
 // pos[b,v,:] = ([v,1] @ w2c[b]) @ proj[b]  — row-vector convention, two steps like the reference's two einsums
-__global__ void __launch_bounds__(kBlock)
-k_transform_fwd(const float* __restrict__ verts, const float* __restrict__ w2c, const float* __restrict__ proj, int V,
-                float4* __restrict__ pos, int H, int W, int2* __restrict__ snap, float4* __restrict__ cmat)
+__device__ __forceinline__ void transform_body(int v, int b, const float* __restrict__ verts, const float* __restrict__ delta,
+                                               const float* __restrict__ w2c, const float* __restrict__ proj, int V,
+                                               float4* __restrict__ pos, int H, int W, int2* __restrict__ snap,
+                                               float4* __restrict__ cmat)
 {
-    int v = blockIdx.x * kBlock + threadIdx.x;
-    int b = blockIdx.y;
     const float* A = w2c + (size_t)b * 16;
     const float* B = proj + (size_t)b * 16;
     if (cmat != nullptr && v < 4) {
@@ -252,6 +251,9 @@ k_transform_fwd(const float* __restrict__ verts, const float* __restrict__ w2c, 
     }
     if (v >= V) return;
     float x = verts[(size_t)v * 3], y = verts[(size_t)v * 3 + 1], z = verts[(size_t)v * 3 + 2];
+    if (delta != nullptr) {      // fused step: vertex = vertices_tmp + delta (mesh_sfs_optim.py:255), the same single add as the normals part
+        x = x + delta[(size_t)v * 3]; y = y + delta[(size_t)v * 3 + 1]; z = z + delta[(size_t)v * 3 + 2];
+    }
     float r[4], o[4];
 #pragma unroll
     for (int l = 0; l < 4; l++) r[l] = x * A[l] + y * A[4 + l] + z * A[8 + l] + A[12 + l];
@@ -321,11 +323,11 @@ __device__ __forceinline__ float sum_sub(float x)
     return x;
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_normals_gather(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
-                 const int32_t* __restrict__ vf_idx, int V, float* __restrict__ nsum, float* __restrict__ normals,
-                 const float* __restrict__ albedo, float4* __restrict__ attr8, const float* __restrict__ delta,
-                 float* __restrict__ vout)
+__device__ __forceinline__ void normals_gather_body(int blk, const float* __restrict__ verts, const int32_t* __restrict__ tri,
+                                                    const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx, int V,
+                                                    float* __restrict__ nsum, float* __restrict__ normals,
+                                                    const float* __restrict__ albedo, float4* __restrict__ attr8,
+                                                    const float* __restrict__ delta, float* __restrict__ vout)
 {
     // fused step: vertex = verts + delta (mesh_sfs_optim.py:255), formed on the fly and stored for the later kernels by the
     // vertex's first lane (saves the separate add launch); stand-alone op: delta == nullptr
@@ -334,7 +336,7 @@ k_normals_gather(const float* __restrict__ verts, const int32_t* __restrict__ tr
         if (delta != nullptr) { const float3 dl = ld3(delta + (size_t)i * 3); q.x = q.x + dl.x; q.y = q.y + dl.y; q.z = q.z + dl.z; }
         return q;
     };
-    const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
+    const int v = (blk * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
     const bool live = v < V;
     const int vv = live ? v : 0;
     float3 acc = make_float3(0.f, 0.f, 0.f);
@@ -593,15 +595,6 @@ int mesh_tail_impl(const MeshTailArgs& A, float* gdelta, float* galbedo, const F
 }
 
 // ---- internal launchers used by ham_step.hip
-int normals_fwd_gather_impl(const float* verts, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, int V,
-                            float* nsum, float* normals, const float* albedo, float* attr8, const float* delta, float* vout,
-                            hipStream_t st)
-{
-    if (V == 0) return FMHR_OK;
-    k_normals_gather<<<cdiv((long long)V * kSubLanes, kBlock), kBlock, 0, st>>>(verts, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, (float4*)attr8, delta, vout);
-    FMHR_CHECK_LAUNCH("k_normals_gather");
-    return FMHR_OK;
-}
 
 int normals_fwd_impl(const float* verts, const int32_t* tri, int nb, int V, int F, float* nsum, float* normals, hipStream_t st)
 {
@@ -664,12 +657,33 @@ int lap_bwd_impl(const float* lx, const int32_t* row_ptr, const int32_t* col, in
     return FMHR_OK;
 }
 
-int transform_fwd_impl(const float* verts, const float* w2c, const float* proj, int n, int V, float* pos, int H, int W,
-                       int2* snap, float* cmat, hipStream_t st)
+// ONE launch for the step's geometry: rows 0..n-1 of the grid transform the vertices into the n views (clip positions, snapped
+// vertices, combined matrices), the rows after them form the vertex normals (8 lanes per vertex) and store vertex = tmp + delta —
+// the two parts are independent, so the latency-bound normals walk hides under the bandwidth-bound transform
+__global__ void __launch_bounds__(kBlock)
+k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta, const float* __restrict__ w2c,
+           const float* __restrict__ proj, int n, int V, float4* __restrict__ pos, int H, int W, int2* __restrict__ snap,
+           float4* __restrict__ cmat, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
+           const int32_t* __restrict__ vf_idx, float* __restrict__ nsum, float* __restrict__ normals,
+           const float* __restrict__ albedo, float4* __restrict__ attr8, float* __restrict__ vout)
+{
+    if ((int)blockIdx.y < n)
+        transform_body(blockIdx.x * kBlock + threadIdx.x, blockIdx.y, verts_tmp, delta, w2c, proj, V, pos, H, W, snap, cmat);
+    else
+        normals_gather_body(((int)blockIdx.y - n) * gridDim.x + blockIdx.x, verts_tmp, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, attr8,
+                            delta, vout);
+}
+
+int geometry_impl(const float* verts_tmp, const float* delta, const float* w2c, const float* proj, int n, int V, float* pos, int H, int W,
+                  int2* snap, float* cmat, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, float* nsum,
+                  float* normals, const float* albedo, float* attr8, float* vout, hipStream_t st)
 {
     if (n == 0 || V == 0) return FMHR_OK;
-    k_transform_fwd<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>(verts, w2c, proj, V, (float4*)pos, H, W, snap, (float4*)cmat);
-    FMHR_CHECK_LAUNCH("k_transform_fwd");
+    const int gx = cdiv(V, kBlock);
+    const int rows_normals = cdiv(cdiv((long long)V * kSubLanes, kBlock), gx);
+    k_geometry<<<dim3(gx, n + rows_normals), kBlock, 0, st>>>(verts_tmp, delta, w2c, proj, n, V, (float4*)pos, H, W, snap, (float4*)cmat, tri,
+                                                              vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout);
+    FMHR_CHECK_LAUNCH("k_geometry");
     return FMHR_OK;
 }
 
