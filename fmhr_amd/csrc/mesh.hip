@@ -657,8 +657,8 @@ int lap_bwd_impl(const float* lx, const int32_t* row_ptr, const int32_t* col, in
     return FMHR_OK;
 }
 
-// ONE launch for the step's geometry: rows 0..n-1 of the grid transform the vertices into the n views (clip positions, snapped
-// vertices, combined matrices), the rows after them form the vertex normals (8 lanes per vertex) and store vertex = tmp + delta —
+// ONE launch for the step's geometry: the first rows of the grid form the vertex normals (8 lanes per vertex) and store vertex =
+// tmp + delta, the n rows after them transform the vertices into the n views (clip positions, snapped vertices, combined matrices) —
 // the two parts are independent, so the latency-bound normals walk hides under the bandwidth-bound transform
 __global__ void __launch_bounds__(kBlock)
 k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta, const float* __restrict__ w2c,
@@ -667,10 +667,12 @@ k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta,
            const int32_t* __restrict__ vf_idx, float* __restrict__ nsum, float* __restrict__ normals,
            const float* __restrict__ albedo, float4* __restrict__ attr8, float* __restrict__ vout)
 {
-    if ((int)blockIdx.y < n)
-        transform_body(blockIdx.x * kBlock + threadIdx.x, blockIdx.y, verts_tmp, delta, w2c, proj, V, pos, H, W, snap, cmat);
+    const int rows_normals = (int)gridDim.y - n;                     // dispatched first: their long dependent chains start early
+    if ((int)blockIdx.y >= rows_normals)
+        transform_body(blockIdx.x * kBlock + threadIdx.x, (int)blockIdx.y - rows_normals, verts_tmp, delta, w2c, proj, V, pos, H, W, snap,
+                       cmat);
     else
-        normals_gather_body(((int)blockIdx.y - n) * gridDim.x + blockIdx.x, verts_tmp, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, attr8,
+        normals_gather_body((int)blockIdx.y * gridDim.x + blockIdx.x, verts_tmp, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, attr8,
                             delta, vout);
 }
 
