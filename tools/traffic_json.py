@@ -5,9 +5,9 @@ import re
 import sys
 
 SLOT_KERNELS = {
-    "geometry": ["k_add_delta", "k_normals_gather", "k_transform_fwd"],
+    "geometry": ["k_geometry"],
     "raster_tris": ["k_raster_tris"], "raster_large": ["k_raster_large"], "raster_resolve": ["k_raster_resolve"],
-    "shade_fwd": ["k_active_segments", "k_fill_uncovered"], "aa_fwd": ["k_aa_fwd_list"], "loss_pix": ["k_loss_pix"],
+    "shade_fwd": ["k_active_segments"], "aa_fwd": ["k_aa_fwd_list"], "loss_pix": ["k_loss_pix"],
     "aa_bwd": ["k_aa_bwd_items"], "shade_bwd": ["k_face_bwd"], "regularisers": ["k_mesh_tail_a", "k_mesh_tail_b"],
 }
 src = sys.argv[1]
