@@ -157,6 +157,13 @@ __device__ __forceinline__ int fast_divmod(long long g, int d, int& r)
     return q;
 }
 
+// one clip coordinate of a vertex under one column (c0..c3) of the combined matrix w2c @ proj: the geometry kernel and the
+// face-parallel backward both go through this explicit chain, so their positions agree bit for bit whatever the compiler contracts
+__device__ __forceinline__ float clip_coord(float x, float y, float z, float c0, float c1, float c2, float c3)
+{
+    return __fmaf_rn(x, c0, __fmaf_rn(y, c1, __fmaf_rn(z, c2, c3)));
+}
+
 // block (256 threads = 4 waves) sum; result valid in thread 0
 __device__ __forceinline__ float block_sum(float v, float* sm4)
 {

@@ -233,7 +233,8 @@ k_lap_bwd_gather(const float* __restrict__ rowg, const int32_t* __restrict__ row
     for (int c = 0; c < C; c++) gx[(size_t)j * C + c] += acc[c];
 }
 
-// pos[b,v,:] = ([v,1] @ w2c[b]) @ proj[b]  — row-vector convention, two steps like the reference's two einsums
+// pos[b,v,:] = [v,1] @ (w2c[b] @ proj[b])  — row-vector convention; the reference's two einsums (mesh_sfs_optim.py:258-259)
+// associated the other way: equal to the last bit or two, and the oracle is evaluated at THESE positions
 __device__ __forceinline__ void transform_body(int v, int b, const float* __restrict__ verts, const float* __restrict__ delta,
                                                const float* __restrict__ w2c, const float* __restrict__ proj, int V,
                                                float4* __restrict__ pos, int H, int W, int2* __restrict__ snap,
@@ -241,24 +242,25 @@ __device__ __forceinline__ void transform_body(int v, int b, const float* __rest
 {
     const float* A = w2c + (size_t)b * 16;
     const float* B = proj + (size_t)b * 16;
-    if (cmat != nullptr && v < 4) {
-        // row v of the combined matrix w2c @ proj, columns (x, y, w): rows 0..2 = d pos / d vertex_v (the clip-transform backward),
-        // with the translation row 3 the backward also recomputes a face's clip positions from its three vertices
-        float c[4];
-#pragma unroll
-        for (int l = 0; l < 4; l++) c[l] = A[v * 4] * B[l] + A[v * 4 + 1] * B[4 + l] + A[v * 4 + 2] * B[8 + l] + A[v * 4 + 3] * B[12 + l];
-        cmat[(size_t)b * 4 + v] = make_float4(c[0], c[1], c[3], 0.f);
+    // the combined matrix w2c @ proj, one entry per thread through LDS.  The backward recomputes a face's clip positions from
+    // the published (x, y, w) columns with clip_coord() as well: the positions it differentiates at are then bit-identical to
+    // the ones rasterized (an edge-on triangle amplifies a last-bit difference between the two by 1 / area)
+    __shared__ float c[4][4];
+    if (threadIdx.x < 16) {
+        const int k = threadIdx.x >> 2, l = threadIdx.x & 3;
+        c[k][l] = __fmaf_rn(A[k * 4], B[l], __fmaf_rn(A[k * 4 + 1], B[4 + l], __fmaf_rn(A[k * 4 + 2], B[8 + l], A[k * 4 + 3] * B[12 + l])));
     }
+    __syncthreads();                 // block-uniform branch of k_geometry: every thread of a transform block gets here
+    if (cmat != nullptr && v < 4)    // row v, columns (x, y, w): rows 0..2 = d pos / d vertex_v (the clip-transform backward), row 3 the translation
+        cmat[(size_t)b * 4 + v] = make_float4(c[v][0], c[v][1], c[v][3], 0.f);
     if (v >= V) return;
     float x = verts[(size_t)v * 3], y = verts[(size_t)v * 3 + 1], z = verts[(size_t)v * 3 + 2];
     if (delta != nullptr) {      // fused step: vertex = vertices_tmp + delta (mesh_sfs_optim.py:255), the same single add as the normals part
         x = x + delta[(size_t)v * 3]; y = y + delta[(size_t)v * 3 + 1]; z = z + delta[(size_t)v * 3 + 2];
     }
-    float r[4], o[4];
+    float o[4];
 #pragma unroll
-    for (int l = 0; l < 4; l++) r[l] = x * A[l] + y * A[4 + l] + z * A[8 + l] + A[12 + l];
-#pragma unroll
-    for (int l = 0; l < 4; l++) o[l] = r[0] * B[l] + r[1] * B[4 + l] + r[2] * B[8 + l] + r[3] * B[12 + l];
+    for (int l = 0; l < 4; l++) o[l] = clip_coord(x, y, z, c[0][l], c[1][l], c[2][l], c[3][l]);
     float4 p = make_float4(o[0], o[1], o[2], o[3]);
     pos[(size_t)b * V + v] = p;
     if (snap != nullptr) {          // R1 + R2 of the rasterizer, once per (view, vertex)

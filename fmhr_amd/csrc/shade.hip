@@ -256,17 +256,18 @@ __device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr&
     const float gu = gnx * fa.dn0.x + gny * fa.dn0.y + gnz * fa.dn0.z + ga0 * fa.da0.x + ga1 * fa.da0.y + ga2 * fa.da0.z;
     const float gv = gnx * fa.dn1.x + gny * fa.dn1.y + gnz * fa.dn1.z + ga0 * fa.da1.x + ga1 * fa.da1.y + ga2 * fa.da1.z;
     // rasterize backward (Appendix B.1) for the three corners, pushed through the view's clip transform (c[9..]: rows of
-    // w2c @ proj, mesh.hip k_transform_fwd): the position gradients become view-independent
+    // w2c @ proj, mesh.hip transform_body): the position gradients become view-independent
     const float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
     // the three clip positions (x, y, w) of this view, recomputed from the face's vertices and the view's combined matrix
-    // (c[9..24]: rows of w2c @ proj, columns x, y, w): 27 FMAs instead of three 16-B gathers per (face, view)
+    // (c[9..24]: rows of w2c @ proj, columns x, y, w) exactly as the geometry kernel computed them: 27 FMAs instead of three
+    // 16-B gathers per (face, view)
     float pp[9];
     {
         const float3 vv[3] = {fa.v0, fa.v1, fa.v2};
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int l = 0; l < 3; l++) pp[k * 3 + l] = vv[k].x * c[9 + l] + vv[k].y * c[13 + l] + vv[k].z * c[17 + l] + c[21 + l];
+            for (int l = 0; l < 3; l++) pp[k * 3 + l] = clip_coord(vv[k].x, vv[k].y, vv[k].z, c[9 + l], c[13 + l], c[17 + l], c[21 + l]);
     }
     const float p0x = pp[0] - fx * pp[2], p0y = pp[1] - fy * pp[2];
     const float p1x = pp[3] - fx * pp[5], p1y = pp[4] - fy * pp[5];

@@ -133,6 +133,8 @@ def _step_vs_oracle(oracle, sc, name, osc=None):
     e_d, e_a = rel_err(gdelta, gd64), rel_err(galbedo, ga64)
     o_d, o_a = rel_err(gd32, gd64), rel_err(ga32, ga64)
     assert e_d < max(TOL, 2 * o_d) and e_a < max(TOL, 2 * o_a), (name, e_d, e_a, o_d, o_a)
+    print(f"{name}: grad rel err vs fp64 oracle: delta {e_d:.2e} albedo {e_a:.2e}; fp32 oracle's own: {o_d:.2e} {o_a:.2e}")
+    v = dict(v, gdelta=gdelta.clone(), galbedo=galbedo.clone(), gd64=gd64, ga64=ga64, o_d=o_d, o_a=o_a)
     return ld, v
 
 
@@ -176,26 +178,24 @@ def test_fused_step_edge_cases(oracle):
     assert ld["n_valid"] == 0 and ld["sfs"] == 0.0
 
 
-def test_unchanged_loop_body_on_dr(oracle):
-    """the reference's own loop body (mesh_sfs_optim.py:253-306, restated verbatim in oracle.ham_stage2_losses) executed on
-    fmhr_amd.dr / fmhr_amd.utils GPU ops must agree with the fused step and with the CPU oracle."""
+def _loop_body_on_dr(g, faces, n, H, W, weights, elm, pos_value=None, reg_dtype=torch.float32, lap_fn=None):
+    """the reference's own loop body (mesh_sfs_optim.py:253-306) on fmhr_amd.dr / fmhr_amd.utils GPU ops.  `pos_value`
+    substitutes the VALUE of the clip positions (straight-through: the gradient still flows through the einsums), so two
+    implementations can be compared on identical discrete decisions.  `reg_dtype=float64` evaluates the mesh regularisers
+    (torch ops only) in double on the fp32-rounded vertices: on a sub3-class mesh the uniform Laplacian cancels 3 digits
+    (|Lx| ~ 1e-4 |x|), so two fp32 evaluations of it differ by more than 1e-4 and neither can referee the other."""
     from fmhr_amd import dr, utils
-    from fmhr_amd.ham import HamStage2
-    sc = prepare(oracle, (2, 160, 120, 24, 32), 5)
-    dev = torch.device("cuda:0")
-    weights, elm = sc["weights"], sc["elm"]
-    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
-    faces = sc["faces"].to(dev)
     delta = g["delta"].clone().requires_grad_(True)
     albedo = g["albedo"][None].clone().requires_grad_(True)
     glctx = dr.RasterizeGLContext()
-    n = sc["views"]
     vertices = g["vertices"] + delta
     vertsw = torch.cat([vertices, torch.ones_like(vertices[:, 0:1])], axis=1).unsqueeze(0).expand(n, -1, -1)
     rot_verts = torch.einsum('ijk,ikl->ijl', vertsw, g["w2c"])
     proj_verts = torch.einsum('ijk,ikl->ijl', rot_verts, g["proj"])
+    if pos_value is not None:
+        proj_verts = pos_value.detach() + (proj_verts - proj_verts.detach())
     normals = utils.get_normals(vertsw[:, :, :3], faces.long())
-    rast_out, _ = dr.rasterize(glctx, proj_verts, faces, resolution=(sc["H"], sc["W"]))
+    rast_out, _ = dr.rasterize(glctx, proj_verts, faces, resolution=(H, W))
     feat = torch.cat([normals, albedo.expand(n, -1, -1), torch.ones_like(vertsw[:, :, :1])], dim=2)
     feat, _ = dr.interpolate(feat, rast_out, faces)
     pred_normals = F.normalize(feat[:, :, :, :3].contiguous(), p=2, dim=3)
@@ -207,17 +207,39 @@ def test_unchanged_loop_body_on_dr(oracle):
     tmp_img = torch.zeros_like(g["img"])
     tmp_img[valid_idx] = pred_img
     tmp_img = dr.antialias(tmp_img, rast_out, proj_verts, faces)
-    sfs_loss = weights["sfs"] * F.l1_loss(tmp_img[valid_idx], g["img"][valid_idx])
-    lap_loss = weights["lap"] * utils.laplacian_smoothing(vertices, faces.long(), method="uniform")
-    albedo_loss = weights["albedo"] * utils.laplacian_smoothing(albedo.squeeze(0), faces.long(), method="uniform")
-    mask_loss = weights["mask"] * F.mse_loss(pred_mask, g["valid_mask"])
+    terms = {}
+    terms["sfs"] = weights["sfs"] * F.l1_loss(tmp_img[valid_idx], g["img"][valid_idx])
+    rv, ra, rd = vertices.to(reg_dtype), albedo.squeeze(0).to(reg_dtype), delta.to(reg_dtype)
     fl = faces.long()
-    a, b, c = vertices[fl[:, 0]], vertices[fl[:, 1]], vertices[fl[:, 2]]
+    if lap_fn is None:
+        lap_fn = utils.laplacian_smoothing
+    else:                                             # the checker's torch Laplacian builds its operator on the CPU
+        rv, ra, rd, fl = rv.cpu(), ra.cpu(), rd.cpu(), fl.cpu()
+    terms["lap"] = (weights["lap"] * lap_fn(rv, fl, method="uniform")).to(delta.device)
+    terms["albedo"] = (weights["albedo"] * lap_fn(ra, fl, method="uniform")).to(delta.device)
+    terms["mask"] = weights["mask"] * F.mse_loss(pred_mask, g["valid_mask"])
+    a, b, c = rv[fl[:, 0]], rv[fl[:, 1]], rv[fl[:, 2]]
     edge_length = torch.cat([((a - b) ** 2).sum(1), ((c - b) ** 2).sum(1), ((a - c) ** 2).sum(1)])
-    edge_loss = torch.clip(edge_length - elm, 0, 1).mean() * weights["edge"]
-    delta_loss = (delta ** 2).sum(1).mean() * weights["delta"]
-    loss = sfs_loss + lap_loss + albedo_loss + mask_loss + delta_loss + edge_loss
+    terms["edge"] = (torch.clip(edge_length - float(elm), 0, 1).mean() * weights["edge"]).to(delta.device)
+    terms["delta"] = ((rd ** 2).sum(1).mean() * weights["delta"]).to(delta.device)
+    loss = terms["sfs"] + terms["lap"] + terms["albedo"] + terms["mask"] + terms["delta"] + terms["edge"]
     loss.backward()
+    return dict(loss=loss.detach(), terms={k: float(v) for k, v in terms.items()}, delta=delta, albedo=albedo,
+                rast=rast_out.detach(), pos=proj_verts.detach(), tmp_img=tmp_img.detach(), n_valid=valid_idx[0].numel())
+
+
+def test_unchanged_loop_body_on_dr(oracle):
+    """the reference's own loop body (restated verbatim in oracle.ham_stage2_losses) executed on fmhr_amd.dr / fmhr_amd.utils
+    GPU ops must agree with the fused step and with the CPU oracle."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (2, 160, 120, 24, 32), 5)
+    dev = torch.device("cuda:0")
+    weights, elm = sc["weights"], sc["elm"]
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    faces = sc["faces"].to(dev)
+    n = sc["views"]
+    out = _loop_body_on_dr(g, faces, n, sc["H"], sc["W"], weights, elm)
+    loss, delta, albedo = out["loss"], out["delta"], out["albedo"]
     # oracle (fp64 values on fp32 decisions) evaluated at the clip positions this composition produced (torch's GPU einsum)
     with oracle.f32_decisions():
         d = sc["delta"].double().clone().requires_grad_(True)
@@ -225,9 +247,9 @@ def test_unchanged_loop_body_on_dr(oracle):
         c = lambda t: t.double()
         ref = oracle.ham_stage2_losses(c(sc["vertices"]), d, al, c(sc["sh0"]), c(sc["w2c"]), c(sc["proj"]), c(sc["img"]),
                                        c(sc["mask"]), c(sc["valid_mask"]), sc["faces"], (sc["H"], sc["W"]), weights, elm,
-                                       pos_value=proj_verts.detach().cpu())
+                                       pos_value=out["pos"].cpu())
         ref["loss"].backward()
-    assert torch.equal(rast_out.detach().cpu()[..., 3].double(), ref["rast"][..., 3])
+    assert torch.equal(out["rast"].cpu()[..., 3].double(), ref["rast"][..., 3])
     assert abs(float(loss) - float(ref["loss"])) <= TOL * abs(float(ref["loss"]))
     assert rel_err(delta.grad, d.grad) < TOL and rel_err(albedo.grad, al.grad) < TOL
     # and the fused step agrees with the op-by-op composition (their clip positions differ in the last bit only)
@@ -236,6 +258,51 @@ def test_unchanged_loop_body_on_dr(oracle):
     ld = hs.loss_dict()
     assert abs(ld["total"] - float(loss)) <= 1e-3 * abs(float(loss))
     assert rel_err(hs.gdelta, delta.grad) < 2e-2 and rel_err(hs.galbedo, albedo.grad[0]) < 2e-2
+
+
+def test_full_size_step_vs_oracle_and_composed_ops(oracle):
+    """the metric's mesh (V=48693, F=97088) at 512x512, 3 views: (1) the fused step against the CPU oracle exactly as the small
+    cases are checked (bit-identical rast vs the fp32 twin, values vs fp64-on-fp32-decisions); (2) against the reference's loop
+    body composed from the generic fmhr_amd.dr / fmhr_amd.utils ops on identical clip positions: every discrete decision
+    (coverage, depth winner, AA pairs, valid set) agrees exactly, values to 1e-4."""
+    from fmhr_amd import synthetic as S
+    from fmhr_amd.ham import render_forward, edge_length_mean
+    dev = torch.device("cuda:0")
+    n, H, W = 3, 512, 512
+    sc = S.make_scene(n, H, W, 21, 37, 3, seed=3)
+    assert sc["V"] == 48693 and sc["F"] == 97088
+    faces = sc["faces"].to(dev)
+    fwd = lambda v, a, s, m: render_forward(faces, v, a, s, sc["w2c"].to(dev), sc["proj"].to(dev), m, H, W)
+    tg = S.make_targets(sc, fwd, device=dev)
+    gen = torch.Generator().manual_seed(11)
+    sc["delta"] = 2e-4 * torch.randn(sc["V"], 3, generator=gen)                       # off the start mesh: every term is live
+    sc["albedo"] = sc["albedo0"] + 0.05 * torch.rand(sc["V"], 3, generator=gen)       # not constant: |L a| = 0 has no gradient
+    sc.update({k: tg[k].cpu() for k in ("img", "mask", "valid_mask")})
+    sc["elm"] = float(edge_length_mean(sc["vertices"].to(dev), faces))
+    ld, v = _step_vs_oracle(oracle, sc, "metric_mesh")
+    assert ld["n_valid"] > 0.1 * n * H * W
+
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    # regularisers in fp64 (the checker's torch Laplacian): two fp32 evaluations of |L x| on this mesh differ by > 1e-4
+    out = _loop_body_on_dr(g, faces, n, H, W, sc["weights"], sc["elm"], pos_value=v["pos"], reg_dtype=torch.float64,
+                           lap_fn=oracle.laplacian_smoothing)
+    assert torch.equal(out["pos"], v["pos"])
+    assert torch.equal(out["rast"][..., 3], v["rast"][..., 3])                       # same winner in every pixel
+    assert float((out["rast"][..., :3] - v["rast"][..., :3]).abs().max()) <= 1e-6    # u, v, z/w
+    assert ld["n_valid"] == out["n_valid"]
+    assert float((out["tmp_img"] - v["tmp_img"]).abs().max()) <= 1e-5
+    for k in ("sfs", "lap", "albedo", "mask", "edge", "delta"):
+        assert abs(ld[k] - out["terms"][k]) <= TOL * max(abs(out["terms"][k]), 1e-6), (k, ld[k], out["terms"][k])
+    assert abs(ld["total"] - float(out["loss"])) <= TOL * abs(float(out["loss"]))
+    assert rel_err(v["galbedo"], out["albedo"].grad[0]) < TOL
+    # position gradients: the generic ops differentiate per pixel exactly as the fp32 oracle does, and share its conditioning
+    # on the mesh's edge-on triangles (a handful of vertices, 1e-3 of the largest gradient here); the fused step, which passed
+    # the fp64 bar in part (1), recomputes each face's clip positions bit-identically to the rasterized ones and is tighter
+    e_c = rel_err(out["delta"].grad, v["gd64"])
+    print(f"composed ops: gdelta rel err vs fp64 oracle {e_c:.2e} (fp32 oracle {v['o_d']:.2e}, fused "
+          f"{rel_err(v['gdelta'], v['gd64']):.2e})")
+    assert e_c < max(TOL, 2 * v["o_d"])
+    assert rel_err(v["gdelta"], out["delta"].grad) < max(TOL, 2 * v["o_d"])
 
 
 def test_full_size_properties():
