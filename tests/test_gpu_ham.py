@@ -260,15 +260,17 @@ def test_unchanged_loop_body_on_dr(oracle):
     assert rel_err(hs.gdelta, delta.grad) < 2e-2 and rel_err(hs.galbedo, albedo.grad[0]) < 2e-2
 
 
-def test_full_size_step_vs_oracle_and_composed_ops(oracle):
-    """the metric's mesh (V=48693, F=97088) at 512x512, 3 views: (1) the fused step against the CPU oracle exactly as the small
+@pytest.mark.parametrize("shape", [(3, 512, 512), (2, 1024, 1024), (1, 1024, 1280)], ids=lambda s: "x".join(map(str, s)))
+def test_full_size_step_vs_oracle_and_composed_ops(oracle, shape):
+    """the metric's mesh (V=48693, F=97088) at the metric's 512x512, at configs[3]'s 1024x1024 and at the demo capture's
+    1280x1024 (conf/demo_sfs.conf: w=1280, h=1024): (1) the fused step against the CPU oracle exactly as the small
     cases are checked (bit-identical rast vs the fp32 twin, values vs fp64-on-fp32-decisions); (2) against the reference's loop
     body composed from the generic fmhr_amd.dr / fmhr_amd.utils ops on identical clip positions: every discrete decision
     (coverage, depth winner, AA pairs, valid set) agrees exactly, values to 1e-4."""
     from fmhr_amd import synthetic as S
     from fmhr_amd.ham import render_forward, edge_length_mean
     dev = torch.device("cuda:0")
-    n, H, W = 3, 512, 512
+    n, H, W = shape
     sc = S.make_scene(n, H, W, 21, 37, 3, seed=3)
     assert sc["V"] == 48693 and sc["F"] == 97088
     faces = sc["faces"].to(dev)
@@ -279,8 +281,10 @@ def test_full_size_step_vs_oracle_and_composed_ops(oracle):
     sc["albedo"] = sc["albedo0"] + 0.05 * torch.rand(sc["V"], 3, generator=gen)       # not constant: |L a| = 0 has no gradient
     sc.update({k: tg[k].cpu() for k in ("img", "mask", "valid_mask")})
     sc["elm"] = float(edge_length_mean(sc["vertices"].to(dev), faces))
-    ld, v = _step_vs_oracle(oracle, sc, "metric_mesh")
+    ld, v = _step_vs_oracle(oracle, sc, "metric_mesh %dx%dx%d" % shape)
     assert ld["n_valid"] > 0.1 * n * H * W
+    if shape[1] != 512:
+        return
 
     g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
     # regularisers in fp64 (the checker's torch Laplacian): two fp32 evaluations of |L x| on this mesh differ by > 1e-4
