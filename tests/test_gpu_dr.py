@@ -107,6 +107,36 @@ def test_backward_parity(dr, oracle, case):
         assert rel_err(ga_gpu, ga64) < 2e-3
 
 
+def test_feature_rasterisation_c30(dr, oracle):
+    """the second consumer of the primitives: train_mlp.py:165-205 rasterizes once and interpolates a
+    30-channel per-vertex feature (shared over the views, attr [1,V,30]) — forward and the gradients w.r.t. feature and
+    barycentrics (-> pos) against the oracle."""
+    dev = torch.device("cuda:0")
+    sc = mesh_scene((2, 128, 112, 24, 32), seed=4)
+    pos, tri, H, W = sc["pos"], sc["faces"], 128, 112
+    V, C = pos.shape[1], 30
+    rng = np.random.default_rng(5)
+    feat0 = torch.tensor(rng.standard_normal((1, V, C)), dtype=torch.float32)
+    wt = torch.tensor(rng.standard_normal((2, H, W, C)), dtype=torch.float32)
+
+    def run(mod, p, a, w_, tri_, ctx):
+        p = p.clone().requires_grad_(True)
+        a = a.clone().requires_grad_(True)
+        rast, _ = mod.rasterize(ctx, p, tri_, resolution=(H, W))
+        feat, _ = mod.interpolate(a, rast, tri_)
+        (feat * w_).sum().backward()
+        return rast.detach(), feat.detach(), p.grad, a.grad
+
+    r_ref, f_ref, gp_ref, ga_ref = run(oracle, pos, feat0, wt, tri, None)
+    r_gpu, f_gpu, gp_gpu, ga_gpu = run(dr, pos.to(dev), feat0.to(dev), wt.to(dev), tri.to(dev), dr.RasterizeGLContext())
+    assert torch.equal(r_gpu.cpu(), r_ref)
+    assert f_gpu.shape == (2, H, W, C) and rel_err(f_gpu, f_ref) < 1e-6
+    assert rel_err(ga_gpu, ga_ref) < TOL and rel_err(gp_gpu, gp_ref) < TOL
+    _, _, gp64, ga64 = run(oracle, pos.double(), feat0.double(), wt.double(), tri, None)
+    if rel_err(gp_ref, gp64) < 1e-3:
+        assert rel_err(gp_gpu, gp64) < 2e-3 and rel_err(ga_gpu, ga64) < 2e-3
+
+
 def test_edge_cases(dr):
     dev = torch.device("cuda:0")
     ctx = dr.RasterizeGLContext()
