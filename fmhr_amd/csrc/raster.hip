@@ -292,7 +292,7 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
 // is resolved, its keys are reset to "empty" (the key buffer cleans itself: no per-step 100 MB memset), and the coverage word is
 // stored.  The fused step (RasterFused) also shades the covered pixels here, leaves its per-pixel word (shade_common.h) instead
 // of `rast`, marks the owning (view, face) and counts the valid pixels of the segment.
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
                  unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu)
