@@ -292,7 +292,12 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
 // is resolved, its keys are reset to "empty" (the key buffer cleans itself: no per-step 100 MB memset), and the coverage word is
 // stored.  The fused step (RasterFused) also shades the covered pixels here, leaves its per-pixel word (shade_common.h) instead
 // of `rast`, marks the owning (view, face) and counts the valid pixels of the segment.
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))
+// UNI: H * W is a multiple of 64, so a wave's 64-pixel segment lies in ONE view: the view index is a scalar, the base pointers
+// of the view's arrays are scalar and its SH row comes through the scalar cache into SGPRs (9 VGPRs and the 64-bit address
+// arithmetic of a dozen gathers less: the kernel fits 8 waves per SIMD)
+typedef const float __attribute__((address_space(4))) const_as4_float;
+template <bool UNI>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UNI ? 8 : 7, 8)))
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
                  unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu)
@@ -326,7 +331,8 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         bool covered = false;
         if (key != ~0ull) {
             int rem, px;
-            const int b = fast_divmod(gid, (int)P, rem);
+            int b = fast_divmod(gid, (int)P, rem);
+            if (UNI) b = __builtin_amdgcn_readfirstlane(b);
             const int py = fast_divmod(rem, W, px);
             const int f = (int)((unsigned)(key & 0xffffffffu) >> 1);
             const bool large = (key & 1ull) != 0ull;
@@ -343,7 +349,11 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                 q0 = fu.attr8[(size_t)i0 * 2]; q1 = fu.attr8[(size_t)i0 * 2 + 1];
                 u0 = fu.attr8[(size_t)i1 * 2]; u1 = fu.attr8[(size_t)i1 * 2 + 1];
                 w0 = fu.attr8[(size_t)i2 * 2]; w1 = fu.attr8[(size_t)i2 * 2 + 1];
-                {   // the view's SH row: 36 B, dword-aligned -> 2 x 16 B + 4 B requests instead of nine
+                if (UNI) {   // scalar loads (constant address space: the row is not written during the kernel)
+                    const_as4_float* sp = (const_as4_float*)(unsigned long long)(fu.sh + (size_t)b * 9);
+#pragma unroll
+                    for (int k = 0; k < 9; k++) shc[k] = sp[k];
+                } else {   // the view's SH row: 36 B, dword-aligned -> 2 x 16 B + 4 B requests instead of nine
                     const F4U* sp = reinterpret_cast<const F4U*>(fu.sh + (size_t)b * 9);
                     const F4U s0 = sp[0], s1 = sp[1];
                     shc[0] = s0.x; shc[1] = s0.y; shc[2] = s0.z; shc[3] = s0.w;
@@ -574,7 +584,10 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         FMHR_CHECK_LAUNCH("k_raster_large");
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-    k_raster_resolve<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
+    if (dirty != nullptr && (((long long)H * W) & 63) == 0)
+        k_raster_resolve<true><<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
+    else
+        k_raster_resolve<false><<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }
