@@ -41,7 +41,7 @@ int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const 
                 const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int,
                 int, int, float*, const float*, float*, hipStream_t);
 int geometry_impl(const float*, const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, const int32_t*,
-                  const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, hipStream_t);
+                  const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, int*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; };
@@ -151,7 +151,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
     Layout L = make_layout(d);
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
-    FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(stamp); FMHR_OFF(pix16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
+    FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(own8); FMHR_OFF(stamp); FMHR_OFF(pix16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
     FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(aa_counter); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(total);
 #undef FMHR_OFF
@@ -225,7 +225,8 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         // one launch: clip transform of all views + vertex normals / packed attributes; vertices = vertices_tmp + delta is formed
         // on the fly by both parts and stored for everything after them
         TRY(geometry_impl(vertices_tmp, delta, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), tri,
-                          vf_ptr, vf_idx, (float*)(w + L.nsum), (float*)(w + L.normals), albedo, (float*)(w + L.attr8), vertices, st));
+                          vf_ptr, vf_idx, (float*)(w + L.nsum), (float*)(w + L.normals), albedo, (float*)(w + L.attr8), vertices,
+                          (int*)(w + L.stamp), st));
     }
     {
         // rasterize; the resolve pass also shades the covered pixels, leaves the per-pixel backward word, marks the owning

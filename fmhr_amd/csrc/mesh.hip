@@ -667,8 +667,10 @@ k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta,
            const float* __restrict__ proj, int n, int V, float4* __restrict__ pos, int H, int W, int2* __restrict__ snap,
            float4* __restrict__ cmat, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
            const int32_t* __restrict__ vf_idx, float* __restrict__ nsum, float* __restrict__ normals,
-           const float* __restrict__ albedo, float4* __restrict__ attr8, float* __restrict__ vout)
+           const float* __restrict__ albedo, float4* __restrict__ attr8, float* __restrict__ vout, int* __restrict__ stamp)
 {
+    // the step counter that tags this step's coverage entries and owner marks (raster.hip, shade.hip): advanced by the step's first kernel
+    if (stamp != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamp[0] = stamp[0] + 1;
     const int rows_normals = (int)gridDim.y - n;                     // dispatched first: their long dependent chains start early
     if ((int)blockIdx.y >= rows_normals)
         transform_body(blockIdx.x * kBlock + threadIdx.x, (int)blockIdx.y - rows_normals, verts_tmp, delta, w2c, proj, V, pos, H, W, snap,
@@ -680,13 +682,13 @@ k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta,
 
 int geometry_impl(const float* verts_tmp, const float* delta, const float* w2c, const float* proj, int n, int V, float* pos, int H, int W,
                   int2* snap, float* cmat, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, float* nsum,
-                  float* normals, const float* albedo, float* attr8, float* vout, hipStream_t st)
+                  float* normals, const float* albedo, float* attr8, float* vout, int* stamp, hipStream_t st)
 {
     if (n == 0 || V == 0) return FMHR_OK;
     const int gx = cdiv(V, kBlock);
     const int rows_normals = cdiv(cdiv((long long)V * kSubLanes, kBlock), gx);
     k_geometry<<<dim3(gx, n + rows_normals), kBlock, 0, st>>>(verts_tmp, delta, w2c, proj, n, V, (float4*)pos, H, W, snap, (float4*)cmat, tri,
-                                                              vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout);
+                                                              vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp);
     FMHR_CHECK_LAUNCH("k_geometry");
     return FMHR_OK;
 }

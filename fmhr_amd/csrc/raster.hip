@@ -4,7 +4,7 @@
 // Forward = triangle-parallel scan conversion into a 64-bit (depth | triangle) key buffer with atomicMin, then a
 // per-pixel resolve that recomputes the winner's fragment.  The HAM meshes are micro-triangle meshes (~1.3 px per visible
 // triangle at 512^2): the work is per triangle, not per pixel, so one lane owns one triangle and walks its
-// (tiny) bounding box; triangles with a large box are queued and swept by a whole workgroup each.
+// (tiny) bounding box; a triangle with a large box is swept by the whole wave of its lane.
 #include "common.h"
 #include "shade_common.h"
 #include <string.h>
@@ -106,19 +106,26 @@ struct TriPark {
     float4 p0, p1, p2;
     int f, b, origin, bw;            // origin = pxa | pya << 16
 };
+// a large-box triangle handed to its whole wave: integer setup, clip positions, face and view
+struct LargePark {
+    TriSetup s;
+    float4 p0, p1, p2;
+    int f, b;
+};
 
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
-              int F, int H, int W, unsigned long long* __restrict__ keys, int* __restrict__ large_cnt,
-              int2* __restrict__ large_q, unsigned char* __restrict__ dirty, int4* __restrict__ cov16,
-              const int* __restrict__ stamp)
+              int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
+              int4* __restrict__ cov16, const int* __restrict__ stamp)
 {
     __shared__ TriPark park[kBlock];
     __shared__ unsigned short tasks[kBlock / 64][kTaskCap];
+    __shared__ LargePark lpark[kBlock / 64];
     const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long cm = 0ull;
+    bool is_large = false;
     int f = 0, b = 0, i0 = 0, i1 = 0, i2 = 0, o0 = -1, o1 = -1, o2 = -1, bw = 1;
     int2 s0 = make_int2(0, 0), s1 = s0, s2 = s0;
     TriSetup s;
@@ -139,9 +146,8 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         bw = s.pxb - s.pxa + 1;
         const int bh = s.pyb - s.pya + 1;
         if (bw * (long long)bh > kSmallBox) {
+            is_large = true;                                         // rasterized by the whole wave below
             write_silh(silh, opp, sv, s0, s1, s2, b, f, F);
-            int slot = atomicAdd(large_cnt, 1);
-            large_q[slot] = make_int2(b, f);
             // coverage entry of a large-box triangle: head of the pixel list the resolve pass threads (atomicExch on .x)
             if (cov16 != nullptr) cov16[(size_t)b * F + f] = make_int4(-1, 0, 0, (int)(((unsigned)stamp[0] << 8) | 0xFFu));
         } else {
@@ -193,7 +199,8 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         if (lane >= d) incl += t;
     }
     const int excl = incl - cnt, T = __shfl(incl, 63);
-    if (T == 0) return;                                              // wave-uniform
+    unsigned long long lbal = __ballot(is_large);                    // lanes holding a large-box triangle
+    if (T == 0 && lbal == 0ull) return;                              // wave-uniform
     if (cm != 0ull) {
         // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
         const float* vp = pos + (size_t)b * V * 4;
@@ -254,36 +261,36 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-}
-
-// one workgroup per queued large triangle (grid-stride over the queue; the count lives on the device)
-__global__ void __launch_bounds__(kBlock)
-k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
-               int F, int H, int W, unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt,
-               const int2* __restrict__ large_q, unsigned char* __restrict__ dirty, int* __restrict__ stamp)
-{
-    // k_raster_tris tagged this step's coverage entries with the old counter value; everything after this kernel sees value + 1
-    if (stamp != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stamp[0] = stamp[0] + 1;
-    const int cnt = *large_cnt;
-    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
-    float xo = 1.0f / (float)W; xo = xo - 1.0f;
-    float yo = 1.0f / (float)H; yo = yo - 1.0f;
-    for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
-        int2 bf = large_q[it];
-        int b = bf.x, f = bf.y;
-        int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
-        const int2* sv = snap + (size_t)b * V;
-        TriSetup s;
-        if (!setup_triangle(sv[i0], sv[i1], sv[i2], H, W, s)) continue;
+    // ---- large-box triangles (box > 64 pixels: none on a sub3-class mesh, all of them on a 778-vertex hand): each is rasterized
+    // by its whole wave, 64 box pixels per iteration (this replaced a queue + a second kernel: one launch less per step)
+    if (lbal == 0ull) return;                                        // wave-uniform
+    float4 lp0 = make_float4(0.f, 0.f, 0.f, 0.f), lp1 = lp0, lp2 = lp0;
+    if (is_large) {
         const float* vp = pos + (size_t)b * V * 4;
-        float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
-        pin(p0); pin(p1); pin(p2);
-        int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
-        unsigned long long* kv = keys + (size_t)b * H * W;
-        for (int i = threadIdx.x; i < bw * bh; i += kBlock) {
-            int py = s.pya + i / bw, px = s.pxa + i % bw;
-            if (covers(s, px, py)) emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W, dirty, (long long)b * H * W);
+        lp0 = ldg4(vp + (size_t)i0 * 4); lp1 = ldg4(vp + (size_t)i1 * 4); lp2 = ldg4(vp + (size_t)i2 * 4);
+    }
+    while (lbal != 0ull) {                                           // wave-uniform trip count
+        const int src = __builtin_ctzll(lbal);
+        lbal &= lbal - 1ull;
+        if (lane == src) {
+            LargePark& q = lpark[wv];
+            q.s = s; q.p0 = lp0; q.p1 = lp1; q.p2 = lp2; q.f = f; q.b = b;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            const LargePark& q = lpark[wv];
+            const int lbw = q.s.pxb - q.s.pxa + 1, lbh = q.s.pyb - q.s.pya + 1, np = lbw * lbh;
+            for (int i = lane; i < np; i += 64) {
+                int c;
+                const int r = fast_divmod(i, lbw, c);
+                const int px = q.s.pxa + c, py = q.s.pya + r;
+                if (covers(q.s, px, py))
+                    emit_fragment(q.p0, q.p1, q.p2, px, py, q.f, xs, xo, ys, yo, keys + (size_t)q.b * P, W, dirty, (long long)q.b * P);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                             // every lane has read the slot before the next one is parked
     }
 }
 
@@ -300,15 +307,14 @@ template <bool UNI>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UNI ? 8 : 7, 8)))
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
-                 unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu)
+                 unsigned long long* __restrict__ covw, const RasterFused fu)
 {
     const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long P = (long long)H * W;
     const bool sparse = dirty != nullptr;
     const long long seg = gid >> 6;
     if (sparse) {
-        if (gid == 0) {                                              // k_raster_large is done: rearm its queue counter, and the
-            *large_cnt = 0;                                          // caller's pair of list cursors (saves a memset launch)
+        if (gid == 0) {                                              // rearm the caller's pairs of list cursors (saves a memset launch)
             if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
             if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
         }
@@ -322,7 +328,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         }
     }
     bool valid_px = false;
-    const int step_tag = (fu.stamp != nullptr) ? fu.stamp[0] - 1 : 0;   // read up front: inside the branch it costs a round trip
+    const int step_tag = (fu.stamp != nullptr) ? fu.stamp[0] : 0;       // read up front: inside the branch it costs a round trip
     {
         const bool live = gid < (long long)n * P;
         unsigned long long key = live ? keys[gid] : ~0ull;
@@ -514,7 +520,7 @@ k_interp_bwd(const float* __restrict__ attr, const float4* __restrict__ rast, co
 using namespace fmhr;
 
 namespace fmhr {
-// [keys: n*H*W u64][large counter: 16 B][large queue: n*F int2]
+// [keys: n*H*W u64][16 B][n*F*8 B unused: the region of the former large-triangle queue — see DESIGN.md §5.3 on buffer offsets]
 size_t raster_core_ws_bytes(int n, int F, int H, int W) { return (size_t)n * H * W * 8 + 16 + (size_t)n * F * 8; }
 }  // namespace fmhr
 
@@ -541,8 +547,6 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
     if (e != hipSuccess) return hip_fail(e, "init keys");
     e = hipMemsetAsync(dirty, 0, (nP + 63) / 64, st);
     if (e != hipSuccess) return hip_fail(e, "init dirty");
-    e = hipMemsetAsync((char*)ws + nP * 8, 0, 16, st);               // large-triangle queue counter
-    if (e != hipSuccess) return hip_fail(e, "init large_cnt");
     return FMHR_OK;
 }
 
@@ -554,8 +558,6 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
 {
     size_t nP = (size_t)n * H * W;
     unsigned long long* keys = (unsigned long long*)ws;
-    int* large_cnt = (int*)((char*)ws + nP * 8);
-    int2* large_q = (int2*)((char*)ws + nP * 8 + 16);
     if (nP == 0) return FMHR_OK;
     RasterFused fu;
     memset(&fu, 0, sizeof(fu));
@@ -567,27 +569,19 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
             e = hipMemsetAsync(keys, 0xFF, nP * 8, st);
             if (e != hipSuccess) return hip_fail(e, "memset keys");
         }
-        if (dirty == nullptr) {          // sparse mode: the resolve pass re-zeroes the counter for the next call
-            e = hipMemsetAsync(large_cnt, 0, 16, st);
-            if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
-        }
     }
     if ((long long)n * F > 0) {
-        {
-            ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
-            k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, large_cnt,
-                                                                          large_q, dirty, fu.cov16, fu.stamp);
-            FMHR_CHECK_LAUNCH("k_raster_tris");
-        }
-        ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);
-        k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty, fu.stamp);
-        FMHR_CHECK_LAUNCH("k_raster_large");
+        ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
+        k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16,
+                                                                      fu.stamp);
+        FMHR_CHECK_LAUNCH("k_raster_tris");
     }
+    { ProfScope ps(FMHR_SLOT_RASTER_LARGE, st); }      // reserved slot: large-box triangles are rasterized inside k_raster_tris
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
     if (dirty != nullptr && (((long long)H * W) & 63) == 0)
-        k_raster_resolve<true><<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
+        k_raster_resolve<true><<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
     else
-        k_raster_resolve<false><<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
+        k_raster_resolve<false><<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }

@@ -296,7 +296,7 @@ constexpr int kMaxVPL = 6;                       // views per lane: a group of k
 // VPL views per lane: the fixed part of a (face, view group) — vertex ids, attributes, output slots, the DPP sum, the output
 // store, the launch — is paid once per kGroup * VPL views, and the partial planes the mesh tail has to add up shrink with it.
 template <int VPL>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4)))       // 168 VGPRs: at 170 the kernel drops to 2 waves per SIMD (82 -> 101 us)
 k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
            const int4* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
@@ -323,7 +323,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     __syncthreads();                                               // the only workgroup barrier: everything below is per wave
     const bool facelive = f < F;                                   // uniform over a group
     // ---- the coverage entries of this lane's (face, view)s; entries of other steps carry another stamp
-    const unsigned cur = ((unsigned)stamp[0] - 1u) & 0xFFFFFFu;    // k_raster_large advanced the counter after the tagging
+    const unsigned cur = (unsigned)stamp[0] & 0xFFFFFFu;           // advanced once per step by the geometry kernel
     // everything whose address is known up front is requested together (the kernel's time is #waves / wave slots x the length of
     // a wave's dependent-load chain): the owner marks, the entries, the face's vertex ids, the output slot
     int3a ti = {0, 0, 0};
