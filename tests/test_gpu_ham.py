@@ -147,6 +147,33 @@ def test_fused_step_crumpled_mesh(oracle):
     assert int(v["aa_counter"][1]) == 0
 
 
+def _sweep_cases():
+    """seeded random shapes: view counts around the lane-group sizes (8 views x 1..6 per lane), resolutions with and without
+    H*W % 64 == 0 (scalar-view resolve pass or not) and W % 64, meshes from 10-pixel triangles (all of them large-box: swept by
+    their wave) to sub-pixel ones, subdivided or not."""
+    rng = np.random.default_rng(20240807)
+    out = []
+    for k in range(14):
+        n = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 13, 17, 25, 33, 47]))
+        H = int(rng.choice([33, 40, 48, 64, 72, 96, 100, 128]))
+        W = int(rng.choice([31, 38, 48, 64, 80, 96, 120, 128]))
+        rings, segs = [(4, 6), (6, 8), (10, 14), (16, 24), (24, 32)][int(rng.integers(0, 5))]
+        sub = int(rng.integers(0, 2)) if rings <= 10 else 0
+        if n * H * W > 600_000:
+            n = max(1, 600_000 // (H * W))
+        out.append((f"s{k}_{n}x{H}x{W}_m{rings}x{segs}s{sub}", (n, H, W, rings, segs, sub), 100 + k))
+    return out
+
+
+@pytest.mark.parametrize("case", _sweep_cases(), ids=lambda c: c[0])
+def test_fused_step_shape_sweep(oracle, case):
+    name, dims, seed = case
+    sc = prepare(oracle, dims, seed)
+    if float((sc["mask"] > 0).float().mean()) == 0:
+        pytest.skip("no photometric pixel in this random scene")
+    _step_vs_oracle(oracle, sc, name)
+
+
 def test_aa_list_overflow_is_reported(oracle):
     """an antialias work-item list that is too small must not pass silently: loss_dict() raises."""
     from fmhr_amd.ham import HamStage2
