@@ -212,11 +212,11 @@ __device__ __forceinline__ int silhouette_bits_snapped(int2 s0, int2 s1, int2 s2
     return bits;
 }
 
-__device__ __forceinline__ int2 snap_or_reject(const float* posv, int v, float kx, float ky)
+__device__ __forceinline__ int2 snap_or_reject(const ClipView& cv, int v, float kx, float ky)
 {
     if (v < 0) return make_int2((int)0x80000000, 0);
     int x, y;
-    bool ok = snap_vertex(ldg4(posv + (size_t)v * 4), kx, ky, x, y);
+    bool ok = snap_vertex(cv.get(v), kx, ky, x, y);
     return ok ? make_int2(x, y) : make_int2((int)0x80000000, 0);
 }
 
@@ -224,7 +224,7 @@ __device__ __forceinline__ int2 snap_or_reject(const float* posv, int v, float k
 // `silh` (nullable) = this view's per-triangle silhouette bits precomputed by the rasterizer: most seams between
 // micro-triangles are not silhouettes and leave here after one byte load.
 // Returns the work-item code (0 = no blend) and alpha.  Statement-for-statement fp32 (no contraction).
-__device__ __forceinline__ int aa_analyse(const float* __restrict__ posv, const int32_t* __restrict__ tri,
+__device__ __forceinline__ int aa_analyse(const ClipView& cv, const int32_t* __restrict__ tri,
                                           const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
                                           int V, int F, int H, int W,
                                           int px, int py, int d, float z0, float id0, float z1, float id1, float& alpha_out)
@@ -245,13 +245,13 @@ __device__ __forceinline__ int aa_analyse(const float* __restrict__ posv, const 
     if (silh == nullptr) {
         const float kx = (float)W * 128.0f, ky = (float)H * 128.0f;
         int op0 = opp[t * 3], op1 = opp[t * 3 + 1], op2 = opp[t * 3 + 2];
-        sb = silhouette_bits_snapped(snap_or_reject(posv, vi0, kx, ky), snap_or_reject(posv, vi1, kx, ky),
-                                     snap_or_reject(posv, vi2, kx, ky), snap_or_reject(posv, op0, kx, ky),
-                                     snap_or_reject(posv, op1, kx, ky), snap_or_reject(posv, op2, kx, ky));
+        sb = silhouette_bits_snapped(snap_or_reject(cv, vi0, kx, ky), snap_or_reject(cv, vi1, kx, ky),
+                                     snap_or_reject(cv, vi2, kx, ky), snap_or_reject(cv, op0, kx, ky),
+                                     snap_or_reject(cv, op1, kx, ky), snap_or_reject(cv, op2, kx, ky));
         if (!sb) return 0;
     }
     bool s0 = sb & 1, s1 = sb & 2, s2 = sb & 4;
-    const float4 p0 = ldg4(posv + (size_t)vi0 * 4), p1 = ldg4(posv + (size_t)vi1 * 4), p2 = ldg4(posv + (size_t)vi2 * 4);
+    const float4 p0 = cv.get(vi0), p1 = cv.get(vi1), p2 = cv.get(vi2);
     float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     float w0 = 1.0f / p0.w, w1 = 1.0f / p1.w, w2 = 1.0f / p2.w;
     float fx = (float)qx + 0.5f; fx = fx - xh;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void aa_fwd_pixel(long long gid, bool live, const flo
         // in sparse mode rast is only defined on covered pixels: an uncovered pixel is the all-zero fragment
         if (covw == nullptr || ((covw[gid >> 6] >> (gid & 63)) & 1ull)) r0 = rast[gid];
     }
-    const float* posv = pos + (size_t)b * V * 4;
+    const ClipView cv = clip_view(pos, nullptr, nullptr, b, V);
 #pragma unroll
     for (int d = 0; d < 2; d++) {
         bool has = false;
@@ -336,7 +336,7 @@ __device__ __forceinline__ void aa_fwd_pixel(long long gid, bool live, const flo
             float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (covw == nullptr || ((covw[gid1 >> 6] >> (gid1 & 63)) & 1ull)) r1 = rast[gid1];
             if (r1.w != r0.w) {
-                code = aa_analyse(posv, tri, opp, silh ? silh + (size_t)b * F : nullptr, V, F, H, W, px, py, d, r0.z, r0.w, r1.z, r1.w, alpha);
+                code = aa_analyse(cv, tri, opp, silh ? silh + (size_t)b * F : nullptr, V, F, H, W, px, py, d, r0.z, r0.w, r1.z, r1.w, alpha);
                 has = code != 0;
             }
         }
@@ -391,13 +391,14 @@ __device__ __forceinline__ unsigned long long covw_or0(const unsigned long long*
 // one candidate pair of the fused forward: full analysis, blend of the rgba, work item for the backward
 __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float z0, float id0, float z1, float id1,
                                             const float4* __restrict__ color, const float* __restrict__ pos,
+                                            const float* __restrict__ verts, const float4* __restrict__ cmat,
                                             const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
                                             const unsigned char* __restrict__ silh, int V, int F, int H, int W,
                                             float* __restrict__ out, int4* __restrict__ items, float* __restrict__ alphas,
                                             int32_t* __restrict__ counter, int4* ibuf, float* abuf, int* inum, int region, size_t rbase)
 {
     float alpha = 0.f;
-    const int code = aa_analyse(pos + (size_t)b * V * 4, tri, opp, silh + (size_t)b * F, V, F, H, W, px, py, d, z0, id0, z1, id1, alpha);
+    const int code = aa_analyse(clip_view(pos, verts, cmat, b, V), tri, opp, silh + (size_t)b * F, V, F, H, W, px, py, d, z0, id0, z1, id1, alpha);
     if (code == 0) return;
     const long long gid = ((long long)b * H + py) * W + px, gid1 = gid + (d ? W : 1);
     const long long tgt = (alpha > 0.f) ? gid : gid1;
@@ -418,9 +419,23 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
     }
 }
 
+// the same, out of line: called from inside the pipelined segment loop only when a workgroup's candidate buffer is full (rare);
+// inlined there it would set the register budget of the whole loop
+__device__ __attribute__((noinline)) void aa_fwd_pair_overflow(int px, int py, int b, int d, float z0, float id0, float z1, float id1,
+                                            const float4* __restrict__ color, const float* __restrict__ pos,
+                                            const float* __restrict__ verts, const float4* __restrict__ cmat,
+                                            const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
+                                            const unsigned char* __restrict__ silh, int V, int F, int H, int W,
+                                            float* __restrict__ out, int4* __restrict__ items, float* __restrict__ alphas,
+                                            int32_t* __restrict__ counter, int4* ibuf, float* abuf, int* inum, int region, size_t rbase)
+{
+    aa_fwd_pair(px, py, b, d, z0, id0, z1, id1, color, pos, verts, cmat, tri, opp, silh, V, F, H, W, out, items, alphas, counter, ibuf, abuf,
+                inum, region, rbase);
+}
+
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
-              const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
+              const float* __restrict__ verts, const float4* __restrict__ cmat, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
               const int* __restrict__ act_list, const int* __restrict__ act_count, const unsigned long long* __restrict__ covw,
               int n, int V, int F, int H, int W, float* __restrict__ out, int4* __restrict__ items,
               float* __restrict__ alphas, int32_t* __restrict__ counter, int32_t* __restrict__ region_cnt, int cap,
@@ -527,7 +542,7 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
                 cpos[slot] = make_int2(px | (py << 13) | (d << 26), b);
                 cfrag[slot] = make_float4(r0.z, r0.w, r1.z, r1.w);
             } else {
-                aa_fwd_pair(px, py, b, d, r0.z, r0.w, r1.z, r1.w, color, pos, tri, opp, silh, V, F, H, W, out, items, alphas, counter,
+                aa_fwd_pair_overflow(px, py, b, d, r0.z, r0.w, r1.z, r1.w, color, pos, verts, cmat, tri, opp, silh, V, F, H, W, out, items, alphas, counter,
                             ibuf, abuf, &inum, region, rbase);
             }
         }
@@ -539,7 +554,7 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
         for (int c = threadIdx.x; c < nc; c += kBlock) {
             const int2 cp = cpos[c];
             const float4 cf = cfrag[c];
-            aa_fwd_pair(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, color, pos, tri, opp, silh, V, F, H,
+            aa_fwd_pair(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, color, pos, verts, cmat, tri, opp, silh, V, F, H,
                         W, out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
         }
     }
@@ -560,7 +575,8 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          const float* __restrict__ dyB, int V, int H, int W, int Cdyn,
          float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos,
          const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr, bool use_gl = false,
-         float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false, float4 dcol = make_float4(0.f, 0.f, 0.f, 0.f))
+         float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false, float4 dcol = make_float4(0.f, 0.f, 0.f, 0.f),
+         const float* __restrict__ verts = nullptr)
 {
     const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
@@ -601,7 +617,9 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
     int e1 = di + 1; if (e1 >= 3) e1 -= 3;
     int e2 = di + 2; if (e2 >= 3) e2 -= 3;
     int va = tri[t * 3 + e1], vb = tri[t * 3 + e2];
-    const float4 pa = ldg4(pos + ((size_t)b * V + va) * 4), pb = ldg4(pos + ((size_t)b * V + vb) * 4);
+    // fused step (pos == null): clip positions recomputed from the vertices and the view's combined matrix (ClipView)
+    const ClipView cv = clip_view(pos, verts, cmat, b, V);
+    const float4 pa = cv.get(va), pb = cv.get(vb);
     float fx = (float)qx + 0.5f - xh, fy = (float)qy + 0.5f - yh;
     float wa = 1.0f / pa.w, wb = 1.0f / pb.w;
     float xa = pa.x * wa * xh - fx, ya = pa.y * wa * yh - fy;
@@ -621,12 +639,12 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
         const float4 c0 = cmat[(size_t)b * 4], c1 = cmat[(size_t)b * 4 + 1], c2 = cmat[(size_t)b * 4 + 2];
         float* qa = gvert + (size_t)va * 3;
         float* qb = gvert + (size_t)vb * 3;
-        atomicAdd(qa + 0, ax * c0.x + ay * c0.y + aw * c0.z);
-        atomicAdd(qa + 1, ax * c1.x + ay * c1.y + aw * c1.z);
-        atomicAdd(qa + 2, ax * c2.x + ay * c2.y + aw * c2.z);
-        atomicAdd(qb + 0, bx * c0.x + by * c0.y + bw * c0.z);
-        atomicAdd(qb + 1, bx * c1.x + by * c1.y + bw * c1.z);
-        atomicAdd(qb + 2, bx * c2.x + by * c2.y + bw * c2.z);
+        atomicAdd(qa + 0, ax * c0.x + ay * c0.y + aw * c0.w);          // rows of w2c @ proj: columns x, y, (z,) w
+        atomicAdd(qa + 1, ax * c1.x + ay * c1.y + aw * c1.w);
+        atomicAdd(qa + 2, ax * c2.x + ay * c2.y + aw * c2.w);
+        atomicAdd(qb + 0, bx * c0.x + by * c0.y + bw * c0.w);
+        atomicAdd(qb + 1, bx * c1.x + by * c1.y + bw * c1.w);
+        atomicAdd(qb + 2, bx * c2.x + by * c2.y + bw * c2.w);
         return;
     }
     float* qa = gpos + ((size_t)b * V + va) * 4;
@@ -662,7 +680,7 @@ struct LossGrad {
 
 __global__ void __launch_bounds__(kBlock)
 k_aa_bwd_items(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
-               const int32_t* __restrict__ tri, const LossGrad L, const int4* __restrict__ items,
+               const float* __restrict__ verts, const int32_t* __restrict__ tri, const LossGrad L, const int4* __restrict__ items,
                const float* __restrict__ alphas, const int32_t* __restrict__ region_cnt, int cap, int V, int H, int W,
                float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert)
 {
@@ -691,7 +709,7 @@ k_aa_bwd_items(const float* __restrict__ color, const float4* __restrict__ rast,
         const float4 c0 = reinterpret_cast<const float4*>(color)[pix0], c1 = reinterpret_cast<const float4*>(color)[pix1];
         const float4 dcol = make_float4(c1.x - c0.x, c1.y - c0.y, c1.z - c0.z, c1.w - c0.w);
         aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, color, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
-                          nullptr, cmat, gvert, true, g, true, dcol);
+                          nullptr, cmat, gvert, true, g, true, dcol, verts);
     }
 }
 
@@ -717,18 +735,19 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
 
 // fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour), `rast` = the step's
 // per-pixel word (shade_common.h), work items in per-workgroup regions of one list, persistent grids
-int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
+int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const float* verts, const float* cmat, const int32_t* tri,
+                const int32_t* opp,
                 const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw, int n,
                 int V, int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int32_t* region_cnt, int cap,
                 const float* cnt_part, int nb_cnt, int* n_valid, float* n_valid_f, hipStream_t st)
 {
-    k_aa_fwd_list<<<kAaGrid, kBlock, 0, st>>>((const float4*)color, (const float4*)rast, pos, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
+    k_aa_fwd_list<<<kAaGrid, kBlock, 0, st>>>((const float4*)color, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
                                            out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f);
     FMHR_CHECK_LAUNCH("k_aa_fwd_list");
     return FMHR_OK;
 }
 
-int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* aa, const float* img,
+int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const float* verts, const int32_t* tri, const float* aa, const float* img,
                 const float* mask, const float* valid_mask, const unsigned long long* covw, const float* n_valid, float w_sfs,
                 float w_mask, float mse_den, const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int V,
                 int H, int W, float* gcolor, const float* cmat, float* gvert, hipStream_t st)
@@ -736,7 +755,7 @@ int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const i
     LossGrad L;
     L.aa = (const float4*)aa; L.img = img; L.mask = mask; L.valid_mask = valid_mask; L.covw = covw; L.n_valid = n_valid;
     L.w_sfs = w_sfs; L.w_mask = w_mask; L.mse_den = mse_den;
-    k_aa_bwd_items<<<kAaGrid, kBlock, 0, st>>>(color, (const float4*)rast, pos, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W,
+    k_aa_bwd_items<<<kAaGrid, kBlock, 0, st>>>(color, (const float4*)rast, pos, verts, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W,
                                            gcolor, (const float4*)cmat, gvert);
     FMHR_CHECK_LAUNCH("k_aa_bwd_items");
     return FMHR_OK;

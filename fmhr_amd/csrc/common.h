@@ -164,6 +164,32 @@ __device__ __forceinline__ float clip_coord(float x, float y, float z, float c0,
     return __fmaf_rn(x, c0, __fmaf_rn(y, c1, __fmaf_rn(z, c2, c3)));
 }
 
+// Clip positions of one view: a stored [V,4] array (generic ops: the caller's `pos`) or — fused step — recomputed from the
+// vertices and the view's combined matrix with the same clip_coord() chains wherever they are needed: the step never stores them
+// (37 MB per 48 views written, then gathered at random by the rasterizer passes; the [V,3] vertex array stays in cache).
+struct ClipView {
+    const float* posv;        // [V,4] or null
+    const float* verts;       // [V,3] (used when posv is null)
+    float4 c0, c1, c2, c3;    // rows of w2c @ proj (columns x, y, z, w)
+    __device__ __forceinline__ float4 get(int v) const
+    {
+        if (posv != nullptr) return ldg4(posv + (size_t)v * 4);
+        const float x = verts[(size_t)v * 3], y = verts[(size_t)v * 3 + 1], z = verts[(size_t)v * 3 + 2];
+        return make_float4(clip_coord(x, y, z, c0.x, c1.x, c2.x, c3.x), clip_coord(x, y, z, c0.y, c1.y, c2.y, c3.y),
+                           clip_coord(x, y, z, c0.z, c1.z, c2.z, c3.z), clip_coord(x, y, z, c0.w, c1.w, c2.w, c3.w));
+    }
+};
+__device__ __forceinline__ ClipView clip_view(const float* pos, const float* verts, const float4* cmat, int b, int V)
+{
+    ClipView cv;
+    cv.posv = (pos != nullptr) ? pos + (size_t)b * V * 4 : nullptr;
+    cv.verts = verts;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    cv.c0 = cv.c1 = cv.c2 = cv.c3 = z;
+    if (pos == nullptr) { cv.c0 = cmat[(size_t)b * 4]; cv.c1 = cmat[(size_t)b * 4 + 1]; cv.c2 = cmat[(size_t)b * 4 + 2]; cv.c3 = cmat[(size_t)b * 4 + 3]; }
+    return cv;
+}
+
 // block (256 threads = 4 waves) sum; result valid in thread 0
 __device__ __forceinline__ float block_sum(float v, float* sm4)
 {

@@ -34,12 +34,13 @@ int active_segments_impl(const unsigned long long*, const unsigned char*, long l
                          float*, float*, float*, hipStream_t);
 int active_segments_blocks(long long N);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, const float*, float*, float*, float*, hipStream_t);
-int aa_fwd_rgba(const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
+int aa_fwd_rgba(const float*, const float*, const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
                 const int*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int,
                 const float*, int, int*, float*, hipStream_t);
-int aa_bwd_rgba(const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
+int aa_bwd_rgba(const float*, const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
                 const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int,
                 int, int, float*, const float*, float*, hipStream_t);
+int clip_positions_impl(const float*, const float*, int, int, float*, hipStream_t);
 int geometry_impl(const float*, const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, const int32_t*,
                   const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, int*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
@@ -196,6 +197,8 @@ extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_byte
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_densify: workspace too small or null");
     char* w = (char*)ws;
+    // the step stores no clip positions: the `pos` view is filled here, bit-identical to what the kernels recomputed
+    TRY(clip_positions_impl((const float*)(w + L.vertices), (const float*)(w + L.cmat), d->n, d->V, (float*)(w + L.pos), (hipStream_t)stream));
     return densify_impl((const unsigned long long*)(w + L.covw), (const unsigned char*)(w + L.act), (long long)d->n * d->H * d->W,
                         (const float*)(w + L.pix16), (float*)(w + L.rast), (float*)(w + L.shaded), (float*)(w + L.aa),
                         (hipStream_t)stream);
@@ -215,7 +218,6 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
     float* vertices = (float*)(w + L.vertices);
-    float* pos = (float*)(w + L.pos);
     float* rast = (float*)(w + L.rast);
     const long long nP = (long long)d->n * d->H * d->W;
     unsigned char* act = (unsigned char*)(w + L.act);
@@ -224,7 +226,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         ProfScope ps(FMHR_SLOT_GEOMETRY, st);
         // one launch: clip transform of all views + vertex normals / packed attributes; vertices = vertices_tmp + delta is formed
         // on the fly by both parts and stored for everything after them
-        TRY(geometry_impl(vertices_tmp, delta, w2c, proj, d->n, d->V, pos, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), tri,
+        TRY(geometry_impl(vertices_tmp, delta, w2c, proj, d->n, d->V, nullptr, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), tri,
                           vf_ptr, vf_idx, (float*)(w + L.nsum), (float*)(w + L.normals), albedo, (float*)(w + L.attr8), vertices,
                           (int*)(w + L.stamp), st));
     }
@@ -237,8 +239,9 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.silh = (const unsigned char*)(w + L.silh); fu.llink = (int*)(w + L.llink);
         fu.attr8 = (const float4*)(w + L.attr8); fu.sh = sh;
         fu.shaded = (float4*)(w + L.shaded); fu.aa_init = (float4*)(w + L.aa); fu.seg_valid = (int*)(w + L.seg_valid);
+        fu.verts = vertices; fu.cmat = (const float4*)(w + L.cmat);
         fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
-        TRY(rasterize_fwd_impl(pos, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
+        TRY(rasterize_fwd_impl(nullptr, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
                                rast, w + L.raster_ws, (unsigned char*)(w + L.dirty), covw, &fu, st));
     }
     {
@@ -249,7 +252,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
                                  (float*)(w + L.shaded), (float*)(w + L.aa), st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
-    TRY(aa_fwd_rgba((float*)(w + L.shaded), (const float*)(w + L.pix16), pos, tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
+    TRY(aa_fwd_rgba((float*)(w + L.shaded), (const float*)(w + L.pix16), nullptr, vertices, (const float*)(w + L.cmat), tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
                     (const int*)(w + L.act_count), covw, d->n, d->V, d->F,
                     d->H, d->W, (float*)(w + L.aa), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
                     (int32_t*)(w + L.aa_counter), (int32_t*)(w + L.aa_region_cnt), d->aa_cap, (const float*)(w + L.cnt_part),
@@ -277,7 +280,6 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
     float* vertices = (float*)(w + L.vertices);
-    float* pos = (float*)(w + L.pos);
     float* gvert_aa = (float*)(w + L.gvert_aa);
     float* gvert = (float*)(w + L.gvert);
     size_t nP = (size_t)d->n * d->H * d->W;
@@ -295,7 +297,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     {
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads (clip-transformed) into gvert_aa
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
-        TRY(aa_bwd_rgba((float*)(w + L.shaded), (const float*)(w + L.pix16), pos, tri, (const float*)(w + L.aa), img, mask, valid_mask,
+        TRY(aa_bwd_rgba((float*)(w + L.shaded), (const float*)(w + L.pix16), nullptr, (const float*)(w + L.vertices), tri, (const float*)(w + L.aa), img, mask, valid_mask,
                         (const unsigned long long*)(w + L.covw), n_valid_global, wt->sfs, wt->mask, wt->mse_denominator,
                         (const int32_t*)(w + L.aa_items),
                         (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->V, d->H, d->W,
@@ -310,7 +312,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         et.f0 = (rg != 0.f) ? (int)((long long)wt->reg_v0 * d->F / d->V) : 0;
         et.f1 = (rg != 0.f) ? (int)((long long)wt->reg_v1 * d->F / d->V) : 0;
         et.mean = wt->edge_length_mean; et.w = wt->edge / (3.0f * (float)d->F); et.gk = 2.f * et.w * rg;
-        TRY(face_bwd_impl((const float*)(w + L.pix16), tri, pos, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
+        TRY(face_bwd_impl((const float*)(w + L.pix16), tri, nullptr, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
                           w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot,
                           (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), et, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
     }

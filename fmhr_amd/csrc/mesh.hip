@@ -251,8 +251,8 @@ __device__ __forceinline__ void transform_body(int v, int b, const float* __rest
         c[k][l] = __fmaf_rn(A[k * 4], B[l], __fmaf_rn(A[k * 4 + 1], B[4 + l], __fmaf_rn(A[k * 4 + 2], B[8 + l], A[k * 4 + 3] * B[12 + l])));
     }
     __syncthreads();                 // block-uniform branch of k_geometry: every thread of a transform block gets here
-    if (cmat != nullptr && v < 4)    // row v, columns (x, y, w): rows 0..2 = d pos / d vertex_v (the clip-transform backward), row 3 the translation
-        cmat[(size_t)b * 4 + v] = make_float4(c[v][0], c[v][1], c[v][3], 0.f);
+    if (cmat != nullptr && v < 4)    // row v of w2c @ proj: rows 0..2 = d pos / d vertex_v (the clip-transform backward), row 3 the translation
+        cmat[(size_t)b * 4 + v] = make_float4(c[v][0], c[v][1], c[v][2], c[v][3]);
     if (v >= V) return;
     float x = verts[(size_t)v * 3], y = verts[(size_t)v * 3 + 1], z = verts[(size_t)v * 3 + 2];
     if (delta != nullptr) {      // fused step: vertex = vertices_tmp + delta (mesh_sfs_optim.py:255), the same single add as the normals part
@@ -262,7 +262,7 @@ __device__ __forceinline__ void transform_body(int v, int b, const float* __rest
 #pragma unroll
     for (int l = 0; l < 4; l++) o[l] = clip_coord(x, y, z, c[0][l], c[1][l], c[2][l], c[3][l]);
     float4 p = make_float4(o[0], o[1], o[2], o[3]);
-    pos[(size_t)b * V + v] = p;
+    if (pos != nullptr) pos[(size_t)b * V + v] = p;        // the fused step keeps only the snapped vertices
     if (snap != nullptr) {          // R1 + R2 of the rasterizer, once per (view, vertex)
         int x, y;
         bool ok = snap_vertex(p, (float)W * 128.0f, (float)H * 128.0f, x, y);
@@ -678,6 +678,24 @@ k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta,
     else
         normals_gather_body((int)blockIdx.y * gridDim.x + blockIdx.x, verts_tmp, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, attr8,
                             delta, vout);
+}
+
+// inspection helper (fmhr_ham_densify): the clip positions the fused step never stores, from its vertices and combined matrices
+// with the same chains every consumer uses (common.h: ClipView)
+__global__ void __launch_bounds__(kBlock)
+k_clip_positions(const float* __restrict__ verts, const float4* __restrict__ cmat, int n, int V, float4* __restrict__ pos)
+{
+    const int v = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+    if (v >= V) return;
+    pos[(size_t)b * V + v] = clip_view(nullptr, verts, cmat, b, V).get(v);
+}
+
+int clip_positions_impl(const float* verts, const float* cmat, int n, int V, float* pos, hipStream_t st)
+{
+    if (n == 0 || V == 0) return FMHR_OK;
+    k_clip_positions<<<dim3(cdiv(V, kBlock), n), kBlock, 0, st>>>(verts, (const float4*)cmat, n, V, (float4*)pos);
+    FMHR_CHECK_LAUNCH("k_clip_positions");
+    return FMHR_OK;
 }
 
 int geometry_impl(const float* verts_tmp, const float* delta, const float* w2c, const float* proj, int n, int V, float* pos, int H, int W,

@@ -11,6 +11,9 @@
 
 namespace fmhr {
 
+// loads through this pointer type go through the scalar cache when the address is wave-uniform (data constant during the kernel)
+typedef const float __attribute__((address_space(4))) const_as4_float;
+
 constexpr int kSmallBox = 64;   // boxes up to this many pixel centres are walked by the owning lane
 
 struct TriSetup {
@@ -84,14 +87,15 @@ __device__ __forceinline__ unsigned char silh_bits(const int2 s0, const int2 s1,
     return (unsigned char)((((a0 < 0) == (bb < 0)) ? 1 : 0) | (((a1 < 0) == (bb < 0)) ? 2 : 0) | (((a2 < 0) == (bb < 0)) ? 4 : 0));
 }
 
-__device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, const int32_t* __restrict__ opp, const int2* __restrict__ sv,
+template <class SnapFn>
+__device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, const int32_t* __restrict__ opp, const SnapFn& snapv,
                                            const int2 s0, const int2 s1, const int2 s2, int b, int f, int F)
 {
     if (silh == nullptr) return;
     const int REJ = (int)0x80000000;
     int o0 = opp[f * 3], o1 = opp[f * 3 + 1], o2 = opp[f * 3 + 2];
-    int2 q0 = (o0 < 0) ? make_int2(REJ, 0) : sv[o0], q1 = (o1 < 0) ? make_int2(REJ, 0) : sv[o1],
-         q2 = (o2 < 0) ? make_int2(REJ, 0) : sv[o2];
+    int2 q0 = (o0 < 0) ? make_int2(REJ, 0) : snapv(o0), q1 = (o1 < 0) ? make_int2(REJ, 0) : snapv(o1),
+         q2 = (o2 < 0) ? make_int2(REJ, 0) : snapv(o2);
     silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
 }
 
@@ -113,11 +117,17 @@ struct LargePark {
     int f, b;
 };
 
+// FV (fused step): no stored clip positions — a lane whose triangle covers a pixel centre transforms its three vertices with the
+// view's combined matrix (the same clip_coord() chains everywhere: bit-identical); the [V,3] vertex array stays in cache, the
+// [n,V,4] position array (37 MB written + gathered per 48 views) does not exist.  UNI: F % 64 == 0, a wave's 64 (view, triangle)
+// pairs share the view: the matrix comes through the scalar cache.
+template <bool UNI, bool FV>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
-              int4* __restrict__ cov16, const int* __restrict__ stamp)
+              int4* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
+              const float4* __restrict__ cmat)
 {
     __shared__ TriPark park[kBlock];
     __shared__ unsigned short tasks[kBlock / 64][kTaskCap];
@@ -137,9 +147,34 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         i0 = tri[f * 3]; i1 = tri[f * 3 + 1]; i2 = tri[f * 3 + 2];
         ok = (unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V;
     }
+    // the view's combined matrix (FV).  UNI: one view per wave — its index is computed from the wave's first pair so that the
+    // 16 entries are wave-uniform values in SGPRs (assigned under the divergent `ok` they would become per-lane registers)
+    float cmx[16];
+    if (FV && UNI) {
+        int f0;
+        const long long g0 = gid - lane;
+        const int bu = __builtin_amdgcn_readfirstlane(fast_divmod(g0 < (long long)n * F ? g0 : 0, F, f0));
+        const_as4_float* cp = (const_as4_float*)(unsigned long long)(cmat + (size_t)bu * 4);
+#pragma unroll
+        for (int k = 0; k < 16; k++) cmx[k] = cp[k];
+    }
+    auto clipv = [&](int v) -> float4 {                              // clip position of vertex v in this lane's view
+        if (!FV) return ldg4(pos + ((size_t)b * V + v) * 4);
+        if (!UNI) {                                                  // several views in the wave: per-lane matrix, loaded at the use
+            const float4 r0 = cmat[(size_t)b * 4], r1 = cmat[(size_t)b * 4 + 1], r2 = cmat[(size_t)b * 4 + 2], r3 = cmat[(size_t)b * 4 + 3];
+            cmx[0] = r0.x; cmx[1] = r0.y; cmx[2] = r0.z; cmx[3] = r0.w; cmx[4] = r1.x; cmx[5] = r1.y; cmx[6] = r1.z; cmx[7] = r1.w;
+            cmx[8] = r2.x; cmx[9] = r2.y; cmx[10] = r2.z; cmx[11] = r2.w; cmx[12] = r3.x; cmx[13] = r3.y; cmx[14] = r3.z; cmx[15] = r3.w;
+        }
+        const F3U x = *reinterpret_cast<const F3U*>(verts + (size_t)v * 3);
+        return make_float4(clip_coord(x.x, x.y, x.z, cmx[0], cmx[4], cmx[8], cmx[12]), clip_coord(x.x, x.y, x.z, cmx[1], cmx[5], cmx[9], cmx[13]),
+                           clip_coord(x.x, x.y, x.z, cmx[2], cmx[6], cmx[10], cmx[14]), clip_coord(x.x, x.y, x.z, cmx[3], cmx[7], cmx[11], cmx[15]));
+    };
+    // the snapped vertices (R1 + R2 of the rasterizer) stay a stored [n,V] array also in the fused step: snapping in every lane
+    // (an IEEE division and a dozen compare / round steps per vertex, for all 4.7 M (view, triangle) pairs) doubled this kernel
+    auto snapv = [&](int v) -> int2 { return sv[v]; };
     if (ok) {
         sv = snap + (size_t)b * V;
-        s0 = sv[i0]; s1 = sv[i1]; s2 = sv[i2];
+        s0 = snapv(i0); s1 = snapv(i1); s2 = snapv(i2);
         ok = setup_triangle(s0, s1, s2, H, W, s);
     }
     if (ok) {
@@ -147,7 +182,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         const int bh = s.pyb - s.pya + 1;
         if (bw * (long long)bh > kSmallBox) {
             is_large = true;                                         // rasterized by the whole wave below
-            write_silh(silh, opp, sv, s0, s1, s2, b, f, F);
+            write_silh(silh, opp, snapv, s0, s1, s2, b, f, F);
             // coverage entry of a large-box triangle: head of the pixel list the resolve pass threads (atomicExch on .x)
             if (cov16 != nullptr) cov16[(size_t)b * F + f] = make_int4(-1, 0, 0, (int)(((unsigned)stamp[0] << 8) | 0xFFu));
         } else {
@@ -203,10 +238,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     if (T == 0 && lbal == 0ull) return;                              // wave-uniform
     if (cm != 0ull) {
         // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
-        const float* vp = pos + (size_t)b * V * 4;
-        float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+        float4 p0 = clipv(i0), p1 = clipv(i1), p2 = clipv(i2);
         const int2 rej = make_int2(kRejected, 0);
-        const int2 q0 = (o0 < 0) ? rej : sv[o0], q1 = (o1 < 0) ? rej : sv[o1], q2 = (o2 < 0) ? rej : sv[o2];
+        const int2 q0 = (o0 < 0) ? rej : snapv(o0), q1 = (o1 < 0) ? rej : snapv(o1), q2 = (o2 < 0) ? rej : snapv(o2);
         pin(p0); pin(p1); pin(p2);
         // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
         if (silh != nullptr) silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
@@ -265,10 +299,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     // by its whole wave, 64 box pixels per iteration (this replaced a queue + a second kernel: one launch less per step)
     if (lbal == 0ull) return;                                        // wave-uniform
     float4 lp0 = make_float4(0.f, 0.f, 0.f, 0.f), lp1 = lp0, lp2 = lp0;
-    if (is_large) {
-        const float* vp = pos + (size_t)b * V * 4;
-        lp0 = ldg4(vp + (size_t)i0 * 4); lp1 = ldg4(vp + (size_t)i1 * 4); lp2 = ldg4(vp + (size_t)i2 * 4);
-    }
+    if (is_large) { lp0 = clipv(i0); lp1 = clipv(i1); lp2 = clipv(i2); }
     while (lbal != 0ull) {                                           // wave-uniform trip count
         const int src = __builtin_ctzll(lbal);
         lbal &= lbal - 1ull;
@@ -302,9 +333,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
 // UNI: H * W is a multiple of 64, so a wave's 64-pixel segment lies in ONE view: the view index is a scalar, the base pointers
 // of the view's arrays are scalar and its SH row comes through the scalar cache into SGPRs (9 VGPRs and the 64-bit address
 // arithmetic of a dozen gathers less: the kernel fits 8 waves per SIMD)
-typedef const float __attribute__((address_space(4))) const_as4_float;
-template <bool UNI>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UNI ? 8 : 7, 8)))
+// FV: the clip positions are recomputed from the vertices (fused step) instead of loaded
+template <bool UNI, bool FV>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((UNI && !FV) ? 8 : 7, 8)))
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
                  unsigned long long* __restrict__ covw, const RasterFused fu)
@@ -343,9 +374,30 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             const int f = (int)((unsigned)(key & 0xffffffffu) >> 1);
             const bool large = (key & 1ull) != 0ull;
             const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
-            const float* vp = pos + (size_t)b * V * 4;
-            float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
-            // fused step: the shading inputs and the face's silhouette bits ride in the same memory round trip as the clip positions
+            // clip positions: loaded (generic op), or recomputed from the three vertices and the view's combined matrix (fused step)
+            constexpr bool from_verts = FV;
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+            F3U x0 = {0.f, 0.f, 0.f}, x1 = x0, x2 = x0;
+            float cm[16];
+            if (from_verts) {
+                x0 = *reinterpret_cast<const F3U*>(fu.verts + (size_t)i0 * 3);
+                x1 = *reinterpret_cast<const F3U*>(fu.verts + (size_t)i1 * 3);
+                x2 = *reinterpret_cast<const F3U*>(fu.verts + (size_t)i2 * 3);
+                if (UNI) {               // scalar view: the 16 matrix entries come through the scalar cache into SGPRs
+                    const_as4_float* cp = (const_as4_float*)(unsigned long long)(fu.cmat + (size_t)b * 4);
+#pragma unroll
+                    for (int k = 0; k < 16; k++) cm[k] = cp[k];
+                } else {
+                    const float4 r0 = fu.cmat[(size_t)b * 4], r1 = fu.cmat[(size_t)b * 4 + 1], r2 = fu.cmat[(size_t)b * 4 + 2],
+                                 r3 = fu.cmat[(size_t)b * 4 + 3];
+                    cm[0] = r0.x; cm[1] = r0.y; cm[2] = r0.z; cm[3] = r0.w; cm[4] = r1.x; cm[5] = r1.y; cm[6] = r1.z; cm[7] = r1.w;
+                    cm[8] = r2.x; cm[9] = r2.y; cm[10] = r2.z; cm[11] = r2.w; cm[12] = r3.x; cm[13] = r3.y; cm[14] = r3.z; cm[15] = r3.w;
+                }
+            } else {
+                const float* vp = pos + (size_t)b * V * 4;
+                p0 = ldg4(vp + (size_t)i0 * 4); p1 = ldg4(vp + (size_t)i1 * 4); p2 = ldg4(vp + (size_t)i2 * 4);
+            }
+            // fused step: the shading inputs and the face's silhouette bits ride in the same memory round trip as the vertices
             int sbits = 0;
             if (fu.pix16 != nullptr) sbits = fu.silh[(size_t)b * F + f];
             float4 q0, q1, u0, u1, w0, w1;
@@ -369,6 +421,15 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                 pin(q0); pin(q1); pin(u0); pin(u1); pin(w0); pin(w1);
             }
             pin(p0); pin(p1); pin(p2);
+            if (from_verts) {            // the same clip_coord() chains as every other producer of these positions: bit-identical
+                asm volatile("" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z));
+                p0 = make_float4(clip_coord(x0.x, x0.y, x0.z, cm[0], cm[4], cm[8], cm[12]), clip_coord(x0.x, x0.y, x0.z, cm[1], cm[5], cm[9], cm[13]),
+                                 clip_coord(x0.x, x0.y, x0.z, cm[2], cm[6], cm[10], cm[14]), clip_coord(x0.x, x0.y, x0.z, cm[3], cm[7], cm[11], cm[15]));
+                p1 = make_float4(clip_coord(x1.x, x1.y, x1.z, cm[0], cm[4], cm[8], cm[12]), clip_coord(x1.x, x1.y, x1.z, cm[1], cm[5], cm[9], cm[13]),
+                                 clip_coord(x1.x, x1.y, x1.z, cm[2], cm[6], cm[10], cm[14]), clip_coord(x1.x, x1.y, x1.z, cm[3], cm[7], cm[11], cm[15]));
+                p2 = make_float4(clip_coord(x2.x, x2.y, x2.z, cm[0], cm[4], cm[8], cm[12]), clip_coord(x2.x, x2.y, x2.z, cm[1], cm[5], cm[9], cm[13]),
+                                 clip_coord(x2.x, x2.y, x2.z, cm[2], cm[6], cm[10], cm[14]), clip_coord(x2.x, x2.y, x2.z, cm[3], cm[7], cm[11], cm[15]));
+            }
             const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
             float xo = 1.0f / (float)W; xo = xo - 1.0f;
             float yo = 1.0f / (float)H; yo = yo - 1.0f;
@@ -572,16 +633,25 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     }
     if ((long long)n * F > 0) {
         ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
-        k_raster_tris<<<cdiv((long long)n * F, kBlock), kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16,
-                                                                      fu.stamp);
+        const dim3 tgrid(cdiv((long long)n * F, kBlock));
+        const float4* cmat = fu.cmat;
+        if (fu.verts != nullptr && (F & 63) == 0)
+            k_raster_tris<true, true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, cmat);
+        else if (fu.verts != nullptr)
+            k_raster_tris<false, true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, cmat);
+        else
+            k_raster_tris<false, false><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr);
         FMHR_CHECK_LAUNCH("k_raster_tris");
     }
     { ProfScope ps(FMHR_SLOT_RASTER_LARGE, st); }      // reserved slot: large-box triangles are rasterized inside k_raster_tris
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-    if (dirty != nullptr && (((long long)H * W) & 63) == 0)
-        k_raster_resolve<true><<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
+    const dim3 rgrid(cdiv((long long)nP, kBlock));
+    if (fu.verts != nullptr && dirty != nullptr && (((long long)H * W) & 63) == 0)
+        k_raster_resolve<true, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
+    else if (fu.verts != nullptr)
+        k_raster_resolve<false, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
     else
-        k_raster_resolve<false><<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
+        k_raster_resolve<false, false><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }

@@ -317,7 +317,9 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     for (int i = tid; i < GV * 28; i += kBlock) {
         const int vb = i / 28, k = i - vb * 28, bb = b0 + vb;
         float v = 0.f;
-        if (bb < n) v = (k < 9) ? sh[(size_t)bb * 9 + k] : ((k < 25) ? reinterpret_cast<const float*>(cmat)[(size_t)bb * 16 + (k - 9)] : 0.f);
+        // columns (x, y, w, z) of the view's combined matrix rows: the kernel only uses the first three of each row
+        if (bb < n) v = (k < 9) ? sh[(size_t)bb * 9 + k]
+                                : ((k < 25) ? reinterpret_cast<const float*>(cmat)[(size_t)bb * 16 + ((k - 9) & ~3) + (((k - 9) & 3) == 2 ? 3 : (((k - 9) & 3) == 3 ? 2 : ((k - 9) & 3)))] : 0.f);
         view_c[vb][k] = v;
     }
     __syncthreads();                                               // the only workgroup barrier: everything below is per wave

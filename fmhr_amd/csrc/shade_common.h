@@ -102,6 +102,9 @@ struct RasterFused {
     float4* shaded; float4* aa_init; int* seg_valid;          // forward shading outputs + valid-pixel count of every segment
     int* rearm2;                                              // two list cursors the resolve pass zeroes for the next kernel
     int* rearm_aa;                                            // antialias work-item counter + overflow flag, likewise
+    const float* verts; const float4* cmat;                   // non-null: clip positions / snapped vertices are recomputed from the
+                                                              // [V,3] vertices and the views' combined matrices (common.h: ClipView),
+                                                              // `pos` and `snap` are not read
 };
 
 }  // namespace fmhr
