@@ -122,7 +122,7 @@ struct LargePark {
 // [n,V,4] position array (37 MB written + gathered per 48 views) does not exist.  UNI: F % 64 == 0, a wave's 64 (view, triangle)
 // pairs share the view: the matrix comes through the scalar cache.
 template <bool UNI, bool FV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((FV && !UNI) ? 5 : 7, 8)))   // per-lane matrix: 16 more VGPRs
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
@@ -335,7 +335,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
 // arithmetic of a dozen gathers less: the kernel fits 8 waves per SIMD)
 // FV: the clip positions are recomputed from the vertices (fused step) instead of loaded
 template <bool UNI, bool FV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((UNI && !FV) ? 8 : 7, 8)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((FV && !UNI) ? 5 : ((UNI && !FV) ? 8 : 7), 8)))
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
                  unsigned long long* __restrict__ covw, const RasterFused fu)
