@@ -127,7 +127,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
               int4* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
-              const float4* __restrict__ cmat)
+              const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q)
 {
     __shared__ TriPark park[kBlock];
     __shared__ unsigned short tasks[kBlock / 64][kTaskCap];
@@ -181,7 +181,11 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         bw = s.pxb - s.pxa + 1;
         const int bh = s.pyb - s.pya + 1;
         if (bw * (long long)bh > kSmallBox) {
-            is_large = true;                                         // rasterized by the whole wave below
+            // a mesh of large triangles (a 778-vertex hand at 512 x 334: every triangle) goes through a queue and one workgroup
+            // per triangle (k_raster_large: the triangle kernel's own grid is then a few dozen workgroups); on a micro-triangle
+            // mesh the odd large box is swept by its wave below and that kernel is not launched at all
+            if (large_q != nullptr) large_q[atomicAdd(large_cnt, 1)] = make_int2(b, f);
+            else is_large = true;
             write_silh(silh, opp, snapv, s0, s1, s2, b, f, F);
             // coverage entry of a large-box triangle: head of the pixel list the resolve pass threads (atomicExch on .x)
             if (cov16 != nullptr) cov16[(size_t)b * F + f] = make_int4(-1, 0, 0, (int)(((unsigned)stamp[0] << 8) | 0xFFu));
@@ -325,6 +329,36 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     }
 }
 
+// one workgroup per queued large-box triangle (grid-stride over the queue; the count lives on the device)
+__global__ void __launch_bounds__(kBlock)
+k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
+               int F, int H, int W, unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt,
+               const int2* __restrict__ large_q, unsigned char* __restrict__ dirty, const float* __restrict__ verts,
+               const float4* __restrict__ cmat)
+{
+    const int cnt = *large_cnt;
+    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
+    float xo = 1.0f / (float)W; xo = xo - 1.0f;
+    float yo = 1.0f / (float)H; yo = yo - 1.0f;
+    for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
+        int2 bf = large_q[it];
+        int b = bf.x, f = bf.y;
+        int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+        const int2* sv = snap + (size_t)b * V;
+        TriSetup s;
+        if (!setup_triangle(sv[i0], sv[i1], sv[i2], H, W, s)) continue;
+        const ClipView cv = clip_view(pos, verts, cmat, b, V);       // stored positions (generic op) or recomputed (fused step)
+        float4 p0 = cv.get(i0), p1 = cv.get(i1), p2 = cv.get(i2);
+        pin(p0); pin(p1); pin(p2);
+        int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
+        unsigned long long* kv = keys + (size_t)b * H * W;
+        for (int i = threadIdx.x; i < bw * bh; i += kBlock) {
+            int py = s.pya + i / bw, px = s.pxa + i % bw;
+            if (covers(s, px, py)) emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W, dirty, (long long)b * H * W);
+        }
+    }
+}
+
 // per pixel: decode the winning key, recompute its fragment, write (u, v, z/w, id+1) as one 16-B store.
 // Sparse mode (dirty != null, fused step): a wave owns one 64-pixel segment; a clean segment costs one scalar load; a dirty one
 // is resolved, its keys are reset to "empty" (the key buffer cleans itself: no per-step 100 MB memset), and the coverage word is
@@ -338,14 +372,15 @@ template <bool UNI, bool FV>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((FV && !UNI) ? 5 : ((UNI && !FV) ? 8 : 7), 8)))
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
-                 unsigned long long* __restrict__ covw, const RasterFused fu)
+                 unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu)
 {
     const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long P = (long long)H * W;
     const bool sparse = dirty != nullptr;
     const long long seg = gid >> 6;
     if (sparse) {
-        if (gid == 0) {                                              // rearm the caller's pairs of list cursors (saves a memset launch)
+        if (gid == 0) {                                              // rearm the large-triangle queue and the caller's pairs of
+            *large_cnt = 0;                                          // list cursors (saves memset launches)
             if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
             if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
         }
@@ -581,7 +616,7 @@ k_interp_bwd(const float* __restrict__ attr, const float4* __restrict__ rast, co
 using namespace fmhr;
 
 namespace fmhr {
-// [keys: n*H*W u64][16 B][n*F*8 B unused: the region of the former large-triangle queue — see DESIGN.md §5.3 on buffer offsets]
+// [keys: n*H*W u64][large-triangle counter: 16 B][large-triangle queue: n*F int2]
 size_t raster_core_ws_bytes(int n, int F, int H, int W) { return (size_t)n * H * W * 8 + 16 + (size_t)n * F * 8; }
 }  // namespace fmhr
 
@@ -608,6 +643,8 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
     if (e != hipSuccess) return hip_fail(e, "init keys");
     e = hipMemsetAsync(dirty, 0, (nP + 63) / 64, st);
     if (e != hipSuccess) return hip_fail(e, "init dirty");
+    e = hipMemsetAsync((char*)ws + nP * 8, 0, 16, st);               // large-triangle queue counter
+    if (e != hipSuccess) return hip_fail(e, "init large_cnt");
     return FMHR_OK;
 }
 
@@ -619,7 +656,12 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
 {
     size_t nP = (size_t)n * H * W;
     unsigned long long* keys = (unsigned long long*)ws;
+    int* large_cnt = (int*)((char*)ws + nP * 8);
+    int2* large_q = (int2*)((char*)ws + nP * 8 + 16);
     if (nP == 0) return FMHR_OK;
+    // large-box triangles: through the queue + k_raster_large when the mesh is coarse for the resolution (>= 8 pixels per face at
+    // 50 % coverage: most boxes exceed 64 pixels), else swept by their wave inside k_raster_tris (no second launch)
+    const bool use_queue = (long long)H * W > 16ll * F;
     RasterFused fu;
     memset(&fu, 0, sizeof(fu));
     if (fused != nullptr) fu = *fused;
@@ -629,29 +671,38 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         if (dirty == nullptr) {
             e = hipMemsetAsync(keys, 0xFF, nP * 8, st);
             if (e != hipSuccess) return hip_fail(e, "memset keys");
+            e = hipMemsetAsync(large_cnt, 0, 16, st);                // sparse mode: the resolve pass re-zeroes the counter itself
+            if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
         }
     }
+    int2* lq = use_queue ? large_q : nullptr;
     if ((long long)n * F > 0) {
         ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
         const dim3 tgrid(cdiv((long long)n * F, kBlock));
         const float4* cmat = fu.cmat;
         if (fu.verts != nullptr && (F & 63) == 0)
-            k_raster_tris<true, true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, cmat);
+            k_raster_tris<true, true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, cmat, large_cnt, lq);
         else if (fu.verts != nullptr)
-            k_raster_tris<false, true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, cmat);
+            k_raster_tris<false, true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, cmat, large_cnt, lq);
         else
-            k_raster_tris<false, false><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr);
+            k_raster_tris<false, false><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq);
         FMHR_CHECK_LAUNCH("k_raster_tris");
     }
-    { ProfScope ps(FMHR_SLOT_RASTER_LARGE, st); }      // reserved slot: large-box triangles are rasterized inside k_raster_tris
+    {
+        ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);          // empty on a micro-triangle mesh
+        if (use_queue && (long long)n * F > 0) {
+            k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty, fu.verts, fu.cmat);
+            FMHR_CHECK_LAUNCH("k_raster_large");
+        }
+    }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
     const dim3 rgrid(cdiv((long long)nP, kBlock));
     if (fu.verts != nullptr && dirty != nullptr && (((long long)H * W) & 63) == 0)
-        k_raster_resolve<true, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
+        k_raster_resolve<true, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
     else if (fu.verts != nullptr)
-        k_raster_resolve<false, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
+        k_raster_resolve<false, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
     else
-        k_raster_resolve<false, false><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, fu);
+        k_raster_resolve<false, false><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }

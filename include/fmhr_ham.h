@@ -212,7 +212,7 @@ int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* st
 #define FMHR_SLOT_GEOMETRY 0        /* vertices = tmp+delta, vertex normals, clip transform */
 #define FMHR_SLOT_RASTER_CLEAR 1
 #define FMHR_SLOT_RASTER_TRIS 2
-#define FMHR_SLOT_RASTER_LARGE 3    /* reserved (empty): large-box triangles are rasterized inside RASTER_TRIS */
+#define FMHR_SLOT_RASTER_LARGE 3    /* queued large-box triangles (coarse meshes only; empty when they are swept inside RASTER_TRIS) */
 #define FMHR_SLOT_RASTER_RESOLVE 4
 #define FMHR_SLOT_SHADE_FWD 5
 #define FMHR_SLOT_AA_FWD 6          /* the two image copies + the antialias kernel */
