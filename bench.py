@@ -254,7 +254,7 @@ def main():
             "value": K / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n_total} views x {H}x{W}, blob mesh V={V} F={F} (MANO sub3 class), "
+            "config": {"workload": f"{args.config}: {n_total} views x {H}x{W}, blob mesh V={V} F={F} ({'MANO sub3' if V > 40000 else 'MANO base / coarse'} class), "
                                    f"stage-2 step = render + 6 losses + backward + grad all-reduce + Adam",
                        "views": n_total, "views_per_gpu": n, "H": H, "W": W, "V": V, "F": F,
                        "coverage": round(tg["coverage"], 4), "parallelism": f"views sharded over {world} GPU(s)"},
