@@ -164,6 +164,12 @@ __device__ __forceinline__ float clip_coord(float x, float y, float z, float c0,
     return __fmaf_rn(x, c0, __fmaf_rn(y, c1, __fmaf_rn(z, c2, c3)));
 }
 
+// Large-box triangles (box > 64 pixels) go through a queue and dedicated kernels (forward: k_raster_large, backward:
+// k_face_bwd_large, one workgroup / wave per (view, triangle)) when the mesh is coarse for the resolution — at least 8 pixels
+// per face at 50 % coverage: most boxes are large and the per-(view, triangle)-lane kernels would have a few dozen workgroups
+// with minutes-long lanes; on a micro-triangle mesh the odd large box is handled in place and those kernels are not launched
+inline bool raster_use_queue(int H, int W, int F) { return (long long)H * W > 16ll * F; }
+
 // Clip positions of one view: a stored [V,4] array (generic ops: the caller's `pos`) or — fused step — recomputed from the
 // vertices and the view's combined matrix with the same clip_coord() chains wherever they are needed: the step never stores them
 // (37 MB per 48 views written, then gathered at random by the rasterizer passes; the [V,3] vertex array stays in cache).

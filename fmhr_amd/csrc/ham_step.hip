@@ -45,9 +45,10 @@ int geometry_impl(const float*, const float*, const float*, const float*, int, i
                   const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, int*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
-struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; };
+struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; int skip_lists; };
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
-                  const int*, const int32_t*, const float*, const float*, const int*, const EdgeTerm&, int, int, int, int, int, float*, hipStream_t);
+                  const int*, const int32_t*, const float*, const float*, const int*, const EdgeTerm&, int, int, int, int, int, float*,
+                  const int2*, const int2*, const int*, const unsigned long long*, hipStream_t);
 int face_bwd_groups(int n);
 int face_bwd_blocks(int F);
 
@@ -311,10 +312,12 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         et.part = (float*)(w + L.edge_part);
         et.f0 = (rg != 0.f) ? (int)((long long)wt->reg_v0 * d->F / d->V) : 0;
         et.f1 = (rg != 0.f) ? (int)((long long)wt->reg_v1 * d->F / d->V) : 0;
-        et.mean = wt->edge_length_mean; et.w = wt->edge / (3.0f * (float)d->F); et.gk = 2.f * et.w * rg;
+        et.mean = wt->edge_length_mean; et.w = wt->edge / (3.0f * (float)d->F); et.gk = 2.f * et.w * rg; et.skip_lists = 0;
         TRY(face_bwd_impl((const float*)(w + L.pix16), tri, nullptr, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
                           w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot,
-                          (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), et, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part), st));
+                          (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), et, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part),
+                          (const int2*)(w + L.snap), (const int2*)(w + L.raster_ws + (size_t)d->n * d->H * d->W * 8 + 16),
+                          (const int*)(w + L.raster_ws + (size_t)d->n * d->H * d->W * 8), (const unsigned long long*)(w + L.covw), st));
     }
     {
         // everything per-vertex after the face-parallel backward, in two kernels (mesh.hip: k_mesh_tail_a / _b)

@@ -380,7 +380,8 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
     const long long seg = gid >> 6;
     if (sparse) {
         if (gid == 0) {                                              // rearm the large-triangle queue and the caller's pairs of
-            *large_cnt = 0;                                          // list cursors (saves memset launches)
+            large_cnt[1] = large_cnt[0];                             // list cursors (saves memset launches); the backward's large-face
+            large_cnt[0] = 0;                                        // kernel reads the copy of the count
             if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
             if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
         }
@@ -661,7 +662,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     if (nP == 0) return FMHR_OK;
     // large-box triangles: through the queue + k_raster_large when the mesh is coarse for the resolution (>= 8 pixels per face at
     // 50 % coverage: most boxes exceed 64 pixels), else swept by their wave inside k_raster_tris (no second launch)
-    const bool use_queue = (long long)H * W > 16ll * F;
+    const bool use_queue = raster_use_queue(H, W, F);
     RasterFused fu;
     memset(&fu, 0, sizeof(fu));
     if (fused != nullptr) fu = *fused;

@@ -218,7 +218,7 @@ __device__ __forceinline__ float group_sum(float x)
 struct int3a { int x, y, z; };
 
 // the edge-hinge regulariser rides in the face-parallel backward: faces [f0, f1), weight / (3F), 2 * weight / (3F) * grad scale
-struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; };
+struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; int skip_lists; };   // skip_lists: large-box faces have their own kernel
 struct FaceAttr { float3 n2, dn0, dn1, a2, da0, da1, v0, v1, v2; };    // corner-2-relative attributes + the three vertex positions
 
 // backward of ONE pixel of a face for all three corners; A[k] += (g_normal.xyz, g_albedo.xyz, g_vertex.xyz) of corner k.
@@ -505,7 +505,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         // ---- large-box triangles: the owning lane walks the pixel list (head in the entry, links in the owner field)
 #pragma unroll
         for (int v = 0; v < VPL; v++) {
-            if (kind[v] != 255) continue;
+            if (kind[v] != 255 || et.skip_lists) continue;
             const int vs = v * kGroup + j;
             int p = e[v].x;
             while (p >= 0) {
@@ -587,6 +587,94 @@ int loss_pix_impl(const unsigned long long* covw, const float* aa, const float* 
     return FMHR_OK;
 }
 
+// Backward of the queued large-box (view, face)s of a coarse mesh (raster_use_queue): ONE WAVE per (view, face) scans the face's
+// bounding box, 64 pixels per iteration (independent loads), does the per-pixel backward for the pixels the face owns, sums the
+// 27 corner values over the wave and adds them to the face's corner slots (k_face_bwd wrote them before; float atomics, a few
+// hundred thousand per step).  Inside k_face_bwd one lane walks a ~200-pixel linked list per (view, face): a dependent load per
+// pixel — 187 us for a 778-vertex hand in 8 views of 512 x 334.
+__global__ void __launch_bounds__(kBlock)
+k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const int2* __restrict__ snap,
+                 const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
+                 const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, const float* __restrict__ verts,
+                 const int2* __restrict__ large_q, const int* __restrict__ large_cnt, const unsigned long long* __restrict__ covw,
+                 int n, int V, int F, int H, int W, int GV, float* __restrict__ part)
+{
+    constexpr int kWaves = kBlock / 64;
+    __shared__ float view_c[kWaves][28];
+    __shared__ FaceAttr pk[kWaves];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cnt = large_cnt[1];                                  // the resolve pass kept a copy when it rearmed the queue
+    const long long P = (long long)H * W;
+    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
+    for (int it = blockIdx.x * kWaves + wv; it < cnt; it += gridDim.x * kWaves) {      // wave-uniform
+        const int2 bf = large_q[it];
+        const int b = bf.x, f = bf.y;
+        const int3a ti = *reinterpret_cast<const int3a*>(tri + (size_t)f * 3);
+        if (lane < 28) {
+            const int k = lane;                                    // the view's SH row, then the matrix rows as (x, y, w, z)
+            view_c[wv][k] = (k < 9) ? sh[(size_t)b * 9 + k]
+                                    : ((k < 25) ? reinterpret_cast<const float*>(cmat)[(size_t)b * 16 + ((k - 9) & ~3) + (((k - 9) & 3) == 2 ? 3 : (((k - 9) & 3) == 3 ? 2 : ((k - 9) & 3)))] : 0.f);
+        }
+        if (lane == 0) {
+            const float4 q0 = attr8[(size_t)ti.x * 2], q1 = attr8[(size_t)ti.x * 2 + 1], u0 = attr8[(size_t)ti.y * 2], u1 = attr8[(size_t)ti.y * 2 + 1],
+                         w0 = attr8[(size_t)ti.z * 2], w1 = attr8[(size_t)ti.z * 2 + 1];
+            FaceAttr fa;
+            fa.n2 = make_float3(w0.x, w0.y, w0.z); fa.a2 = make_float3(w0.w, w1.x, w1.y);
+            fa.dn0 = make_float3(q0.x - fa.n2.x, q0.y - fa.n2.y, q0.z - fa.n2.z);
+            fa.da0 = make_float3(q0.w - fa.a2.x, q1.x - fa.a2.y, q1.y - fa.a2.z);
+            fa.dn1 = make_float3(u0.x - fa.n2.x, u0.y - fa.n2.y, u0.z - fa.n2.z);
+            fa.da1 = make_float3(u0.w - fa.a2.x, u1.x - fa.a2.y, u1.y - fa.a2.z);
+            fa.v0 = ld3f(verts + (size_t)ti.x * 3); fa.v1 = ld3f(verts + (size_t)ti.y * 3); fa.v2 = ld3f(verts + (size_t)ti.z * 3);
+            pk[wv] = fa;
+        }
+        // the face's pixel box from its snapped vertices (rule R3, as the forward's setup)
+        const int2 s0 = snap[(size_t)b * V + ti.x], s1 = snap[(size_t)b * V + ti.y], s2 = snap[(size_t)b * V + ti.z];
+        const int mnx = min(s0.x, min(s1.x, s2.x)), mxx = max(s0.x, max(s1.x, s2.x));
+        const int mny = min(s0.y, min(s1.y, s2.y)), mxy = max(s0.y, max(s1.y, s2.y));
+        const int pxa = max((mnx - kHalf + kSub - 1) >> 8, 0), pxb = min((mxx - kHalf) >> 8, W - 1);
+        const int pya = max((mny - kHalf + kSub - 1) >> 8, 0), pyb = min((mxy - kHalf) >> 8, H - 1);
+        const int bw = pxb - pxa + 1, np = bw * (pyb - pya + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float A[3][9];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 9; c++) A[k][c] = 0.f;
+        for (int i = lane; i < np; i += 64) {
+            int c;
+            const int r = fast_divmod(i, bw, c);
+            const int px = pxa + c, py = pya + r;
+            const long long gid = (long long)b * P + (long long)py * W + px;
+            // a pixel nobody covers in this step keeps the word of an earlier one (possibly this face's): the segment's coverage
+            // word tells; a covered pixel's word is this step's, and the owner test settles the rest
+            if (!((covw[gid >> 6] >> (gid & 63)) & 1ull)) continue;
+            const float4 w = bwd16[gid];
+            const int pkd = __float_as_int(w.w);
+            if (pix_face(pkd) == f && pix_mask(pkd)) {
+                const float4 gs = g_shaded[gid];
+                if (!(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) pixel_backward(A, pk[wv], &view_c[wv][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 9; c++)                             // wave_sum is valid in lane 0: broadcast it
+                A[k][c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wave_sum(A[k][c]))));
+        if (lane < 3) {
+            float o[9];
+#pragma unroll
+            for (int c = 0; c < 9; c++) o[c] = (lane == 0) ? A[0][c] : ((lane == 1) ? A[1][c] : A[2][c]);
+            float* dst = part + (((size_t)(b / GV) * 3 * F + corner_slot[f * 3 + lane]) * 3) * 4;
+#pragma unroll
+            for (int c = 0; c < 9; c++)
+                if (o[c] != 0.f) atomicAdd(dst + c, o[c]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // the LDS slots are free for the wave's next item
+    }
+}
+
 // views per lane: one group spans the whole batch when it can (up to kGroup * kMaxVPL = 48 views).  Measured at 48 views, with
 // the clip positions recomputed in-kernel (no LDS parking of positions): 2 / 3 / 4 / 6 views per lane -> 124 / 111 / 110 / 97 us,
 // and one partial plane instead of several for the mesh tail to add up
@@ -597,10 +685,13 @@ int face_bwd_blocks(int F) { return cdiv(F, kBlock / kGroup); }
 
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
                   const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
-                  const float* verts, const int* llink, const EdgeTerm& et, int n, int V, int F, int H, int W, float* part, hipStream_t st)
+                  const float* verts, const int* llink, const EdgeTerm& et_in, int n, int V, int F, int H, int W, float* part,
+                  const int2* snap, const int2* large_q, const int* large_cnt, const unsigned long long* covw, hipStream_t st)
 {
     if (n == 0 || F == 0) return FMHR_OK;
     const dim3 grid(cdiv(F, kFacesPerBlock), face_bwd_groups(n));
+    EdgeTerm et = et_in;
+    et.skip_lists = raster_use_queue(H, W, F) ? 1 : 0;             // coarse mesh: the queued large-box faces get their own kernel
 #define FMHR_FACE_BWD(VPL)                                                                                                          \
     k_face_bwd<VPL><<<grid, kBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
                                              (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
@@ -615,6 +706,11 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     }
 #undef FMHR_FACE_BWD
     FMHR_CHECK_LAUNCH("k_face_bwd");
+    if (et.skip_lists) {
+        k_face_bwd_large<<<2048, kBlock, 0, st>>>((const float4*)bwd16, tri, snap, (const float4*)attr8, sh, (const float4*)g_shaded, corner_slot,
+                                                  (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, kGroup * face_bwd_vpl(n), part);
+        FMHR_CHECK_LAUNCH("k_face_bwd_large");
+    }
     return FMHR_OK;
 }
 
