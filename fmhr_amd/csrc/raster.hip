@@ -184,8 +184,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             // a mesh of large triangles (a 778-vertex hand at 512 x 334: every triangle) goes through a queue and one workgroup
             // per triangle (k_raster_large: the triangle kernel's own grid is then a few dozen workgroups); on a micro-triangle
             // mesh the odd large box is swept by its wave below and that kernel is not launched at all
-            if (large_q != nullptr) large_q[atomicAdd(large_cnt, 1)] = make_int2(b, f);
-            else is_large = true;
+            is_large = true;
             write_silh(silh, opp, snapv, s0, s1, s2, b, f, F);
             // coverage entry of a large-box triangle: head of the pixel list the resolve pass threads (atomicExch on .x)
             if (cov16 != nullptr) cov16[(size_t)b * F + f] = make_int4(-1, 0, 0, (int)(((unsigned)stamp[0] << 8) | 0xFFu));
@@ -239,6 +238,15 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     }
     const int excl = incl - cnt, T = __shfl(incl, 63);
     unsigned long long lbal = __ballot(is_large);                    // lanes holding a large-box triangle
+    if (large_q != nullptr && lbal != 0ull) {                        // queue mode: one cursor atomic per wave (same-address atomics
+        int base = 0;                                                // serialise at ~10 ns each: 1.5 k pushes of a hand in one view)
+        const int leader = __builtin_ctzll(lbal);
+        if (lane == leader) base = atomicAdd(large_cnt, __popcll(lbal));
+        base = __shfl(base, leader, 64);
+        if (is_large) large_q[base + __popcll(lbal & ((1ull << lane) - 1ull))] = make_int2(b, f);
+        is_large = false;
+        lbal = 0ull;
+    }
     if (T == 0 && lbal == 0ull) return;                              // wave-uniform
     if (cm != 0ull) {
         // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
