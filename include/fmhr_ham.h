@@ -190,7 +190,8 @@ int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const f
                       float* losses, float* gdelta, float* galbedo, void* ws, size_t ws_bytes, void* stream);
 /* Views of the step's intermediates inside the workspace (for parity tests / rendering): returns device pointers. */
 typedef struct fmhr_ham_views {
-    float* pos;        /* [n,V,4]   */
+    float* pos;        /* [n,V,4] clip positions: NOT stored by the step (every kernel recomputes them from the vertices and the
+                          views' combined matrices) — filled, bit-identical to what the kernels used, by fmhr_ham_densify */
     float* normals;    /* [V,3]     */
     float* rast;       /* [n,H,W,4] */
     float* shaded;     /* [n,H,W,4] rgb = shaded image before antialias (tmp_img, :285-286), a = coverage colour (:272) */
@@ -200,8 +201,9 @@ typedef struct fmhr_ham_views {
 int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, fmhr_ham_views* out);
 /* byte offset of a named internal buffer inside the workspace (tests / debugging), -1 if unknown */
 long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const char* name);
-/* The step only writes rast / shaded / aa inside "active" 64-pixel segments (covered pixels, their 4-neighbours, non-zero
- * valid_mask); this fills the rest with zeros so the views above can be inspected as dense images. */
+/* The step only writes shaded / aa inside "active" 64-pixel segments (covered pixels, their 4-neighbours, non-zero valid_mask)
+ * and stores neither the dr.rasterize image nor the clip positions; this fills the zeros, rebuilds `rast` from the per-pixel
+ * words and computes `pos`, so the views above can be inspected as dense arrays.  Call it after the step whose state you want. */
 int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ per-kernel timing (optional)
