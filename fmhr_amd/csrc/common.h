@@ -176,11 +176,13 @@ inline bool raster_use_queue(int H, int W, int F) { return (long long)H * W > 16
 struct ClipView {
     const float* posv;        // [V,4] or null
     const float* verts;       // [V,3] (used when posv is null)
-    float4 c0, c1, c2, c3;    // rows of w2c @ proj (columns x, y, z, w)
+    const float4* cm;         // the view's 4 rows of w2c @ proj (columns x, y, z, w); loaded at the use: the callers are the rare
+                              // paths (silhouette pairs, queued large triangles) and should not carry 16 registers around
     __device__ __forceinline__ float4 get(int v) const
     {
         if (posv != nullptr) return ldg4(posv + (size_t)v * 4);
         const float x = verts[(size_t)v * 3], y = verts[(size_t)v * 3 + 1], z = verts[(size_t)v * 3 + 2];
+        const float4 c0 = cm[0], c1 = cm[1], c2 = cm[2], c3 = cm[3];
         return make_float4(clip_coord(x, y, z, c0.x, c1.x, c2.x, c3.x), clip_coord(x, y, z, c0.y, c1.y, c2.y, c3.y),
                            clip_coord(x, y, z, c0.z, c1.z, c2.z, c3.z), clip_coord(x, y, z, c0.w, c1.w, c2.w, c3.w));
     }
@@ -190,9 +192,7 @@ __device__ __forceinline__ ClipView clip_view(const float* pos, const float* ver
     ClipView cv;
     cv.posv = (pos != nullptr) ? pos + (size_t)b * V * 4 : nullptr;
     cv.verts = verts;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    cv.c0 = cv.c1 = cv.c2 = cv.c3 = z;
-    if (pos == nullptr) { cv.c0 = cmat[(size_t)b * 4]; cv.c1 = cmat[(size_t)b * 4 + 1]; cv.c2 = cmat[(size_t)b * 4 + 2]; cv.c3 = cmat[(size_t)b * 4 + 3]; }
+    cv.cm = (pos == nullptr) ? cmat + (size_t)b * 4 : nullptr;
     return cv;
 }
 
