@@ -308,7 +308,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         __builtin_amdgcn_wave_barrier();
     }
     // ---- large-box triangles (box > 64 pixels: none on a sub3-class mesh, all of them on a 778-vertex hand): each is rasterized
-    // by its whole wave, 64 box pixels per iteration (this replaced a queue + a second kernel: one launch less per step)
+    // by its whole wave, 64 box pixels per iteration (no second launch; coarse meshes took the queue above instead)
     if (lbal == 0ull) return;                                        // wave-uniform
     float4 lp0 = make_float4(0.f, 0.f, 0.f, 0.f), lp1 = lp0, lp2 = lp0;
     if (is_large) { lp0 = clipv(i0); lp1 = clipv(i1); lp2 = clipv(i2); }
