@@ -61,7 +61,7 @@ SIGNATURES = {
     "fmhr_ham_workspace_views": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, ctypes.POINTER(HamViews)]),
     "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),
     "fmhr_ham_workspace_init": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),
-    "fmhr_ham_densify": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),
+    "fmhr_ham_densify": (c_int, [ctypes.POINTER(HamDims), P, P, P, c_size_t, P]),
     "fmhr_ham_backward": (c_int, [ctypes.POINTER(HamDims), ctypes.POINTER(HamWeights), P, P, P, P, P, P, P, P, P, P, P, P, P,
                                   P, P, P, P, P, P, P, P, c_size_t, P]),
     "fmhr_corner_slots_build": (c_int, [P, c_int, P, P]),

@@ -378,8 +378,8 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
 // Per segment: the coverage words of the own / next / lower segments are wave-uniform loads; then every lane issues its two
 // rast loads (own, lower) together — the right neighbour's fragment is the next lane's register — and only pairs with different
 // triangle ids go on (silhouette byte first).  Colours are read as 16-B words only by the pairs that blend.
-constexpr int kAaGrid = 1536;                 // workgroups of the fused antialias kernels = regions of the work-item list: ONE resident round
-                                              // of k_aa_fwd_list at its 6 waves per SIMD (80 VGPRs; 2048 workgroups ran as 1.6 rounds: 40.5 -> 32.7 us)
+constexpr int kAaGrid = 1280;                 // workgroups of the fused antialias kernels = regions of the work-item list: ONE resident round
+                                              // of k_aa_fwd_list at its 5 waves per SIMD (96 VGPRs; 2048 workgroups ran as 1.6 rounds: 40.5 -> 32.7 us)
 constexpr int kCandBuf = 512;                 // candidate pairs one workgroup parks before analysing them densely
 constexpr int kItemBuf = 512;                 // work items one workgroup of k_aa_fwd_list buffers in LDS
 
@@ -388,9 +388,14 @@ __device__ __forceinline__ unsigned long long covw_or0(const unsigned long long*
     return (w >= 0 && w < nSeg) ? covw[w] : 0ull;
 }
 
+// The fused step keeps no shaded image (53 MB of stores per step in the resolve pass, read back here for a few hundred thousand
+// pixels): the colours of the two pixels of a pair that blends are re-shaded from their per-pixel words (shade_common.h:
+// shade_word, bit-identical to the resolve pass), and the pair's colour difference is stored with its work item for the backward.
+struct AaShade { const float4* words; const float4* attr8; const float* sh; float4* dcols; };
+
 // one candidate pair of the fused forward: full analysis, blend of the rgba, work item for the backward
 __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float z0, float id0, float z1, float id1,
-                                            const float4* __restrict__ color, const float* __restrict__ pos,
+                                            const AaShade& sd, const float* __restrict__ pos,
                                             const float* __restrict__ verts, const float4* __restrict__ cmat,
                                             const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
                                             const unsigned char* __restrict__ silh, int V, int F, int H, int W,
@@ -402,12 +407,15 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
     if (code == 0) return;
     const long long gid = ((long long)b * H + py) * W + px, gid1 = gid + (d ? W : 1);
     const long long tgt = (alpha > 0.f) ? gid : gid1;
-    const float4 ca = color[gid], cb = color[gid1];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);           // an uncovered pixel (id 0) has the all-zero colour
+    const float4 ca = (id0 != 0.f) ? shade_word(sd.words[gid], tri, sd.attr8, sd.sh + (size_t)b * 9) : zero;
+    const float4 cb = (id1 != 0.f) ? shade_word(sd.words[gid1], tri, sd.attr8, sd.sh + (size_t)b * 9) : zero;
     const float dc[4] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z, cb.w - ca.w};
 #pragma unroll
     for (int c = 0; c < 4; c++)
         if (dc[c] != 0.f) atomicAdd(out + tgt * 4 + c, alpha * dc[c]);
     const int slot = atomicAdd(inum, 1);                             // LDS
+    if (slot < region) sd.dcols[rbase + slot] = make_float4(dc[0], dc[1], dc[2], dc[3]);   // straight to the item's final place
     if (slot < kItemBuf) {
         ibuf[slot] = make_int4(px, py, b, code);
         abuf[slot] = alpha;
@@ -422,19 +430,19 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
 // the same, out of line: called from inside the pipelined segment loop only when a workgroup's candidate buffer is full (rare);
 // inlined there it would set the register budget of the whole loop
 __device__ __attribute__((noinline)) void aa_fwd_pair_overflow(int px, int py, int b, int d, float z0, float id0, float z1, float id1,
-                                            const float4* __restrict__ color, const float* __restrict__ pos,
+                                            const AaShade& sd, const float* __restrict__ pos,
                                             const float* __restrict__ verts, const float4* __restrict__ cmat,
                                             const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
                                             const unsigned char* __restrict__ silh, int V, int F, int H, int W,
                                             float* __restrict__ out, int4* __restrict__ items, float* __restrict__ alphas,
                                             int32_t* __restrict__ counter, int4* ibuf, float* abuf, int* inum, int region, size_t rbase)
 {
-    aa_fwd_pair(px, py, b, d, z0, id0, z1, id1, color, pos, verts, cmat, tri, opp, silh, V, F, H, W, out, items, alphas, counter, ibuf, abuf,
+    aa_fwd_pair(px, py, b, d, z0, id0, z1, id1, sd, pos, verts, cmat, tri, opp, silh, V, F, H, W, out, items, alphas, counter, ibuf, abuf,
                 inum, region, rbase);
 }
 
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8)))
+k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __restrict__ pos,
               const float* __restrict__ verts, const float4* __restrict__ cmat, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
               const int* __restrict__ act_list, const int* __restrict__ act_count, const unsigned long long* __restrict__ covw,
               int n, int V, int F, int H, int W, float* __restrict__ out, int4* __restrict__ items,
@@ -542,7 +550,7 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
                 cpos[slot] = make_int2(px | (py << 13) | (d << 26), b);
                 cfrag[slot] = make_float4(r0.z, r0.w, r1.z, r1.w);
             } else {
-                aa_fwd_pair_overflow(px, py, b, d, r0.z, r0.w, r1.z, r1.w, color, pos, verts, cmat, tri, opp, silh, V, F, H, W, out, items, alphas, counter,
+                aa_fwd_pair_overflow(px, py, b, d, r0.z, r0.w, r1.z, r1.w, sd, pos, verts, cmat, tri, opp, silh, V, F, H, W, out, items, alphas, counter,
                             ibuf, abuf, &inum, region, rbase);
             }
         }
@@ -554,7 +562,7 @@ k_aa_fwd_list(const float4* __restrict__ color, const float4* __restrict__ rast,
         for (int c = threadIdx.x; c < nc; c += kBlock) {
             const int2 cp = cpos[c];
             const float4 cf = cfrag[c];
-            aa_fwd_pair(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, color, pos, verts, cmat, tri, opp, silh, V, F, H,
+            aa_fwd_pair(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, sd, pos, verts, cmat, tri, opp, silh, V, F, H,
                         W, out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
         }
     }
@@ -679,7 +687,7 @@ struct LossGrad {
 };
 
 __global__ void __launch_bounds__(kBlock)
-k_aa_bwd_items(const float* __restrict__ color, const float4* __restrict__ rast, const float* __restrict__ pos,
+k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast, const float* __restrict__ pos,
                const float* __restrict__ verts, const int32_t* __restrict__ tri, const LossGrad L, const int4* __restrict__ items,
                const float* __restrict__ alphas, const int32_t* __restrict__ region_cnt, int cap, int V, int H, int W,
                float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert)
@@ -705,10 +713,8 @@ k_aa_bwd_items(const float* __restrict__ color, const float4* __restrict__ rast,
             g.z = (d2 > 0.f) ? k1 : ((d2 < 0.f) ? -k1 : 0.f);
         }
         g.w = 2.0f * (a.w - vm) * k2;
-        const long long pix1 = pix0 + ((it.w & AA_DOWN) ? W : 1);
-        const float4 c0 = reinterpret_cast<const float4*>(color)[pix0], c1 = reinterpret_cast<const float4*>(color)[pix1];
-        const float4 dcol = make_float4(c1.x - c0.x, c1.y - c0.y, c1.z - c0.z, c1.w - c0.w);
-        aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, color, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
+        const float4 dcol = dcols[rbase + i];                      // colour difference of the pair, left by the forward
+        aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, nullptr, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
                           nullptr, cmat, gvert, true, g, true, dcol, verts);
     }
 }
@@ -735,19 +741,21 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
 
 // fused-step entry points (ham_step.hip): ONE 4-channel colour (rgb = shaded image, a = coverage colour), `rast` = the step's
 // per-pixel word (shade_common.h), work items in per-workgroup regions of one list, persistent grids
-int aa_fwd_rgba(const float* color, const float* rast, const float* pos, const float* verts, const float* cmat, const int32_t* tri,
-                const int32_t* opp,
+int aa_fwd_rgba(const float* attr8, const float* sh, float* dcols, const float* rast, const float* pos, const float* verts,
+                const float* cmat, const int32_t* tri, const int32_t* opp,
                 const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw, int n,
                 int V, int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int32_t* region_cnt, int cap,
                 const float* cnt_part, int nb_cnt, int* n_valid, float* n_valid_f, hipStream_t st)
 {
-    k_aa_fwd_list<<<kAaGrid, kBlock, 0, st>>>((const float4*)color, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
+    AaShade sd;
+    sd.words = (const float4*)rast; sd.attr8 = (const float4*)attr8; sd.sh = sh; sd.dcols = (float4*)dcols;
+    k_aa_fwd_list<<<kAaGrid, kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
                                            out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f);
     FMHR_CHECK_LAUNCH("k_aa_fwd_list");
     return FMHR_OK;
 }
 
-int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const float* verts, const int32_t* tri, const float* aa, const float* img,
+int aa_bwd_rgba(const float* dcols, const float* rast, const float* pos, const float* verts, const int32_t* tri, const float* aa, const float* img,
                 const float* mask, const float* valid_mask, const unsigned long long* covw, const float* n_valid, float w_sfs,
                 float w_mask, float mse_den, const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int V,
                 int H, int W, float* gcolor, const float* cmat, float* gvert, hipStream_t st)
@@ -755,7 +763,7 @@ int aa_bwd_rgba(const float* color, const float* rast, const float* pos, const f
     LossGrad L;
     L.aa = (const float4*)aa; L.img = img; L.mask = mask; L.valid_mask = valid_mask; L.covw = covw; L.n_valid = n_valid;
     L.w_sfs = w_sfs; L.w_mask = w_mask; L.mse_den = mse_den;
-    k_aa_bwd_items<<<kAaGrid, kBlock, 0, st>>>(color, (const float4*)rast, pos, verts, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W,
+    k_aa_bwd_items<<<kAaGrid, kBlock, 0, st>>>((const float4*)dcols, (const float4*)rast, pos, verts, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W,
                                            gcolor, (const float4*)cmat, gvert);
     FMHR_CHECK_LAUNCH("k_aa_bwd_items");
     return FMHR_OK;

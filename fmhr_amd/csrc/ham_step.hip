@@ -31,10 +31,11 @@ int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*
                        void*, unsigned char*, unsigned long long*, const RasterFused*, hipStream_t);
 int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, const int*,
-                         float*, float*, float*, hipStream_t);
+                         float*, float*, hipStream_t);
+int reshade_dense_impl(const unsigned long long*, const float*, const int32_t*, const float*, const float*, int, int, int, float*, hipStream_t);
 int active_segments_blocks(long long N);
-int densify_impl(const unsigned long long*, const unsigned char*, long long, const float*, float*, float*, float*, hipStream_t);
-int aa_fwd_rgba(const float*, const float*, const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
+int densify_impl(const unsigned long long*, const unsigned char*, long long, const float*, float*, float*, hipStream_t);
+int aa_fwd_rgba(const float*, const float*, float*, const float*, const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
                 const int*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int,
                 const float*, int, int*, float*, hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
@@ -54,7 +55,7 @@ int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_counter, aa_region_cnt,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
         g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, seg_valid, cnt_part, edge_part, total;
 };
 
@@ -90,10 +91,11 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.pix16 = take(off, nP * 16);             // per covered pixel: (u, v, z/w, packed face id | flags | silhouette bits)
     L.llink = take(off, nP * 4);              // list links of the pixels of large-box faces (written for those pixels only)
     L.rast = take(off, nP * 16);
-    L.shaded = take(off, nP * 16);
+    L.shaded = take(off, nP * 16);            // inspection only (fmhr_ham_densify re-shades into it): the step keeps no shaded image
     L.aa = take(off, nP * 16);
     L.aa_items = take(off, (size_t)d->aa_cap * 16);   // antialias work items (px, py, view, code) of the pairs that blend
     L.aa_alphas = take(off, (size_t)d->aa_cap * 4);   // and their alphas
+    L.aa_dcol = take(off, (size_t)d->aa_cap * 16);    // and the colour difference of each pair (the backward's d alpha)
     L.aa_counter = take(off, 16);
     L.aa_region_cnt = take(off, 2048 * 4);            // items per region of the list (one region per workgroup of the AA kernels)
     L.g_shaded = take(off, nP * 16);
@@ -192,17 +194,20 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, d->W, (hipStream_t)stream);
 }
 
-extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream)
+extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, const int32_t* tri, const float* sh, void* ws, size_t ws_bytes, void* stream)
 {
     TRY(check_dims(d));
     Layout L = make_layout(d);
-    FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_densify: workspace too small or null");
+    FMHR_CHECK_ARG(ws && ws_bytes >= L.total && tri && sh, "ham_densify: workspace too small or null pointer");
     char* w = (char*)ws;
-    // the step stores no clip positions: the `pos` view is filled here, bit-identical to what the kernels recomputed
-    TRY(clip_positions_impl((const float*)(w + L.vertices), (const float*)(w + L.cmat), d->n, d->V, (float*)(w + L.pos), (hipStream_t)stream));
+    hipStream_t st = (hipStream_t)stream;
+    // the step stores neither clip positions nor a shaded image: both views are produced here, bit-identical to what the
+    // kernels computed on the fly (same FMA chains / same shading statements)
+    TRY(clip_positions_impl((const float*)(w + L.vertices), (const float*)(w + L.cmat), d->n, d->V, (float*)(w + L.pos), st));
+    TRY(reshade_dense_impl((const unsigned long long*)(w + L.covw), (const float*)(w + L.pix16), tri, (const float*)(w + L.attr8), sh, d->n,
+                           d->H, d->W, (float*)(w + L.shaded), st));
     return densify_impl((const unsigned long long*)(w + L.covw), (const unsigned char*)(w + L.act), (long long)d->n * d->H * d->W,
-                        (const float*)(w + L.pix16), (float*)(w + L.rast), (float*)(w + L.shaded), (float*)(w + L.aa),
-                        (hipStream_t)stream);
+                        (const float*)(w + L.pix16), (float*)(w + L.rast), (float*)(w + L.aa), st);
 }
 
 extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
@@ -239,7 +244,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.pix16 = (float4*)(w + L.pix16); fu.mask = mask;
         fu.silh = (const unsigned char*)(w + L.silh); fu.llink = (int*)(w + L.llink);
         fu.attr8 = (const float4*)(w + L.attr8); fu.sh = sh;
-        fu.shaded = (float4*)(w + L.shaded); fu.aa_init = (float4*)(w + L.aa); fu.seg_valid = (int*)(w + L.seg_valid);
+        fu.aa_init = (float4*)(w + L.aa); fu.seg_valid = (int*)(w + L.seg_valid);
         fu.verts = vertices; fu.cmat = (const float4*)(w + L.cmat);
         fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
         TRY(rasterize_fwd_impl(nullptr, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
@@ -250,10 +255,10 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
         TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, (int*)(w + L.act_list),
                                  (int*)(w + L.act_count), (const int*)(w + L.seg_valid), (float*)(w + L.cnt_part),
-                                 (float*)(w + L.shaded), (float*)(w + L.aa), st));
+                                 (float*)(w + L.aa), st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
-    TRY(aa_fwd_rgba((float*)(w + L.shaded), (const float*)(w + L.pix16), nullptr, vertices, (const float*)(w + L.cmat), tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
+    TRY(aa_fwd_rgba((const float*)(w + L.attr8), sh, (float*)(w + L.aa_dcol), (const float*)(w + L.pix16), nullptr, vertices, (const float*)(w + L.cmat), tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
                     (const int*)(w + L.act_count), covw, d->n, d->V, d->F,
                     d->H, d->W, (float*)(w + L.aa), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
                     (int32_t*)(w + L.aa_counter), (int32_t*)(w + L.aa_region_cnt), d->aa_cap, (const float*)(w + L.cnt_part),
@@ -298,7 +303,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     {
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads (clip-transformed) into gvert_aa
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
-        TRY(aa_bwd_rgba((float*)(w + L.shaded), (const float*)(w + L.pix16), nullptr, (const float*)(w + L.vertices), tri, (const float*)(w + L.aa), img, mask, valid_mask,
+        TRY(aa_bwd_rgba((const float*)(w + L.aa_dcol), (const float*)(w + L.pix16), nullptr, (const float*)(w + L.vertices), tri, (const float*)(w + L.aa), img, mask, valid_mask,
                         (const unsigned long long*)(w + L.covw), n_valid_global, wt->sfs, wt->mask, wt->mse_denominator,
                         (const int32_t*)(w + L.aa_items),
                         (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->V, d->H, d->W,

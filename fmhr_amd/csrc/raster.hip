@@ -446,7 +446,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             if (fu.pix16 != nullptr) sbits = fu.silh[(size_t)b * F + f];
             float4 q0, q1, u0, u1, w0, w1;
             float shc[9];
-            const bool shade = fu.shaded != nullptr && mk > 0.f;
+            const bool shade = fu.aa_init != nullptr && mk > 0.f;
             if (shade) {
                 q0 = fu.attr8[(size_t)i0 * 2]; q1 = fu.attr8[(size_t)i0 * 2 + 1];
                 u0 = fu.attr8[(size_t)i1 * 2]; u1 = fu.attr8[(size_t)i1 * 2 + 1];
@@ -490,7 +490,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                     fu.own8[(size_t)b * F + f] = (unsigned char)step_tag;
                     fu.pix16[gid] = make_float4(fr.u, fr.v, fr.zw, __int_as_float(pix_pack(f, mk > 0.f, large, sbits)));
                 }
-                if (fu.shaded != nullptr) {
+                if (fu.aa_init != nullptr) {
                     // forward shading of the fused step (mesh_sfs_optim.py:268-286): rgb = SH radiance x albedo where mask > 0,
                     // a = the interpolated ones attribute
                     const float w2 = 1.0f - fr.u - fr.v;
@@ -509,7 +509,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             if (live) {
                 if (covered && fu.pix16 == nullptr) rast[gid] = o;   // fused step: pix16 replaces it (densify rebuilds rast on demand)
                 keys[gid] = ~0ull;
-                if (fu.shaded != nullptr) { fu.shaded[gid] = col; fu.aa_init[gid] = col; }   // zeros on the uncovered lanes
+                if (fu.aa_init != nullptr) fu.aa_init[gid] = col;    // zeros on the uncovered lanes (blend targets start from them)
             }
             const unsigned long long vbal = __ballot(valid_px);
             if ((threadIdx.x & 63) == 0) {
@@ -520,6 +520,34 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             rast[gid] = o;
         }
     }
+}
+
+// inspection helper (fmhr_ham_densify): the shaded rgba image before antialias, which the step itself never stores — every covered
+// pixel re-shaded from its per-pixel word exactly as the resolve pass did (same translation unit: same arithmetic), zeros elsewhere
+__global__ void __launch_bounds__(kBlock)
+k_reshade_dense(const unsigned long long* __restrict__ covw, const float4* __restrict__ pix16, const int32_t* __restrict__ tri,
+                const float4* __restrict__ attr8, const float* __restrict__ sh, long long N, long long P, float4* __restrict__ shaded)
+{
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= N) return;
+    float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((covw[gid >> 6] >> (gid & 63)) & 1ull) {
+        int rem;
+        const int b = fast_divmod(gid, (int)P, rem);
+        col = shade_word(pix16[gid], tri, attr8, sh + (size_t)b * 9);
+    }
+    shaded[gid] = col;
+}
+
+int reshade_dense_impl(const unsigned long long* covw, const float* pix16, const int32_t* tri, const float* attr8, const float* sh,
+                       int n, int H, int W, float* shaded, hipStream_t st)
+{
+    const long long N = (long long)n * H * W;
+    if (N == 0) return FMHR_OK;
+    k_reshade_dense<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, (const float4*)pix16, tri, (const float4*)attr8, sh, N, (long long)H * W,
+                                                        (float4*)shaded);
+    FMHR_CHECK_LAUNCH("k_reshade_dense");
+    return FMHR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ rasterize backward

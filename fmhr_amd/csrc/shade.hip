@@ -70,8 +70,7 @@ constexpr int kActBlock = 1024;   // few, fat workgroups: the list cursors are s
 __global__ void __launch_bounds__(kActBlock)
 k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
                   unsigned char* __restrict__ act, int* __restrict__ act_list, int* __restrict__ act_count,
-                  const int* __restrict__ seg_valid, float* __restrict__ cnt_part, long long N, float4* __restrict__ shaded,
-                  float4* __restrict__ aa_init)
+                  const int* __restrict__ seg_valid, float* __restrict__ cnt_part, long long N, float4* __restrict__ aa_init)
 {
     // act_count[0] = number of active segments (act_list): the cursor advances with ONE atomic per workgroup
     constexpr int kWaves = kActBlock / 64;
@@ -102,17 +101,17 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
         for (int i = 0; i < wv; i++) off += wcnt[i];
         act_list[off] = (int)seg;
     }
-    // The forward shading is fused into the rasterizer's resolve pass (raster.hip), which writes the rgba pair for every pixel of
+    // The forward shading is fused into the rasterizer's resolve pass (raster.hip), which writes the rgba for every pixel of
     // a segment that received fragments.  Active segments WITHOUT coverage (neighbours of covered ones, valid_mask-only ones) get
     // their zeros here, wave-cooperatively: one 64-pixel segment per iteration, 1 KB per store instruction
-    if (shaded != nullptr) {
+    if (aa_init != nullptr) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         const long long wseg = seg - lane;                           // the wave's lanes hold consecutive segments
         while (cbal != 0ull) {
             const int src = __builtin_ctzll(cbal);
             cbal &= cbal - 1ull;
             const long long gid = ((wseg + src) << 6) + lane;
-            if (gid < N) { shaded[gid] = z; aa_init[gid] = z; }
+            if (gid < N) aa_init[gid] = z;
         }
     }
 }
@@ -127,7 +126,7 @@ constexpr int kPersistBlocks = 2048;      // persistent per-pixel kernels: 8 wor
 // test/inspection helper: make the sparse buffers dense (zeros wherever the step did not write)
 __global__ void __launch_bounds__(kBlock)
 k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ act, long long N,
-          const float4* __restrict__ pix16, float4* __restrict__ rast, float4* __restrict__ shaded, float4* __restrict__ aa)
+          const float4* __restrict__ pix16, float4* __restrict__ rast, float4* __restrict__ aa)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= N) return;
@@ -139,7 +138,7 @@ k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __re
         r.w = (float)(pix_face(__float_as_int(r.w)) + 1);
     }
     rast[gid] = r;
-    if (!act[gid >> 6]) { shaded[gid] = z; aa[gid] = z; }
+    if (!act[gid >> 6]) aa[gid] = z;
 }
 
 // losses + their per-pixel gradients over the active segments:
@@ -552,25 +551,23 @@ int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char
 }
 
 int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
-                         int* act_list, int* act_count, const int* seg_valid, float* cnt_part, float* shaded, float* aa_init,
-                         hipStream_t st)
+                         int* act_list, int* act_count, const int* seg_valid, float* cnt_part, float* aa_init, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     long long nSeg = (N + 63) >> 6;
     k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, seg_valid, cnt_part, N,
-                                                                   (float4*)shaded, (float4*)aa_init);
+                                                                   (float4*)aa_init);
     FMHR_CHECK_LAUNCH("k_active_segments");
     return FMHR_OK;
 }
 
 int active_segments_blocks(long long N) { return cdiv((N + 63) >> 6, kActBlock); }
 
-int densify_impl(const unsigned long long* covw, const unsigned char* act, long long N, const float* pix16, float* rast, float* shaded,
-                 float* aa,
+int densify_impl(const unsigned long long* covw, const unsigned char* act, long long N, const float* pix16, float* rast, float* aa,
                  hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_densify<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, act, N, (const float4*)pix16, (float4*)rast, (float4*)shaded, (float4*)aa);
+    k_densify<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, act, N, (const float4*)pix16, (float4*)rast, (float4*)aa);
     FMHR_CHECK_LAUNCH("k_densify");
     return FMHR_OK;
 }

@@ -93,13 +93,42 @@ __device__ __forceinline__ bool pix_mask(int p) { return (p >> 24) & 1; }
 __device__ __forceinline__ bool pix_large(int p) { return (p >> 25) & 1; }
 __device__ __forceinline__ int pix_silh(int p) { return (p >> 26) & 7; }
 
+// rgba of a covered pixel from its per-pixel word: the resolve pass's forward shading, recomputed statement for statement (compile
+// with -ffp-contract=off like raster.hip).  The step keeps no shaded image: the antialias forward re-shades the two pixels of the
+// pairs that blend, fmhr_ham_densify re-shades everything for inspection.  shc = the view's 9 SH coefficients.
+__device__ __forceinline__ float4 shade_word(const float4 w, const int32_t* __restrict__ tri, const float4* __restrict__ attr8,
+                                             const float* __restrict__ shc_view)
+{
+    const int pk = __float_as_int(w.w), f = pix_face(pk);
+    float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float w2 = 1.0f - w.x - w.y;
+    col.w = w.x + w.y + w2;
+    if (pix_mask(pk)) {
+        const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+        const float4 q0 = attr8[(size_t)i0 * 2], q1 = attr8[(size_t)i0 * 2 + 1], u0 = attr8[(size_t)i1 * 2], u1 = attr8[(size_t)i1 * 2 + 1],
+                     w0 = attr8[(size_t)i2 * 2], w1 = attr8[(size_t)i2 * 2 + 1];
+        float shc[9];
+        {   // the view's SH row: 36 B, dword-aligned -> 2 x 16 B + 4 B requests instead of nine
+            const F4U* sp = reinterpret_cast<const F4U*>(shc_view);
+            const F4U s0 = sp[0], s1 = sp[1];
+            shc[0] = s0.x; shc[1] = s0.y; shc[2] = s0.z; shc[3] = s0.w; shc[4] = s1.x; shc[5] = s1.y; shc[6] = s1.z; shc[7] = s1.w;
+            shc[8] = shc_view[8];
+        }
+        PixShade s;
+        shade_eval_attr(w.x, w.y, q0, q1, u0, u1, w0, w1, shc, s);
+        col.x = s.rad * s.ar; col.y = s.rad * s.ag; col.z = s.rad * s.ab;
+    }
+    return col;
+}
+
 // what the fused stage-2 step adds to the rasterizer's passes (all null for the stand-alone dr.rasterize path)
 struct RasterFused {
     int4* cov16; int* stamp; unsigned char* own8;             // coverage entries, step counter, owner marks (face-parallel backward)
     float4* pix16; const float* mask;                         // per covered pixel (u, v, z/w, packed id | flags): see pix_pack
     const unsigned char* silh; int* llink;                    // silhouette bits per (view, face); list links of large-box faces' pixels
     const float4* attr8; const float* sh;                     // forward shading inputs
-    float4* shaded; float4* aa_init; int* seg_valid;          // forward shading outputs + valid-pixel count of every segment
+    float4* aa_init; int* seg_valid;                          // forward shading output (the rgba the antialias pass starts from) +
+                                                              // valid-pixel count of every segment
     int* rearm2;                                              // two list cursors the resolve pass zeroes for the next kernel
     int* rearm_aa;                                            // antialias work-item counter + overflow flag, likewise
     const float* verts; const float4* cmat;                   // non-null: clip positions / snapped vertices are recomputed from the

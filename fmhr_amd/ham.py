@@ -56,7 +56,7 @@ class HamStage2:
         self.corner_slot = torch.zeros(3 * self.F, dtype=torch.int32, device=self.dev)
         call("fmhr_corner_slots_build", ptr(self.vf_idx), self.F, ptr(self.corner_slot), st)
         # antialias work items: only pairs that blend are listed (∝ silhouette length); 1/4 of the pixels is a generous bound
-        cap = int(aa_cap or max(2048 * 256, self.n * self.H * self.W // 4))     # 1536 regions (one per workgroup of the AA kernels) of >= 341 items
+        cap = int(aa_cap or max(2048 * 256, self.n * self.H * self.W // 4))     # 1280 regions (one per workgroup of the AA kernels) of >= 409 items
         self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap)
         self.ws_bytes = self.lib.fmhr_ham_workspace_bytes(ctypes.byref(self.dims))
         if self.ws_bytes == 0:
@@ -75,12 +75,14 @@ class HamStage2:
         self._views = None
         self._aa_flag = None
         self._vm_key, self._vm_ref = None, None
+        self._last_sh = None
 
     # -- the two phases -------------------------------------------------------------------------------------------------
     def forward(self, vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask):
         key = (valid_mask.data_ptr(), valid_mask._version)
         changed = 1 if key != self._vm_key else 0            # the tensor is kept alive below, so its address is not reused
         self._vm_key, self._vm_ref = key, valid_mask
+        self._last_sh = sh                                   # views() re-shades the dense `shaded` image with it
         call("fmhr_ham_forward", ctypes.byref(self.dims), ptr(vertices_tmp), ptr(delta), ptr(albedo), ptr(sh), ptr(w2c),
              ptr(proj), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp), ptr(self.vf_ptr), ptr(self.vf_idx),
              changed, ptr(self.n_valid_local), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
@@ -124,7 +126,10 @@ class HamStage2:
     # -- intermediates (views into the workspace; valid until the next step) ----------------------------------------------
     def views(self):
         """dense views of the last step's intermediates (zero-fills what the sparse step did not write)."""
-        call("fmhr_ham_densify", ctypes.byref(self.dims), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
+        if self._last_sh is None:
+            raise RuntimeError("HamStage2.views: no forward has run on this object yet")
+        call("fmhr_ham_densify", ctypes.byref(self.dims), ptr(self.faces), ptr(self._last_sh), ptr(self.ws), self.ws_bytes,
+             stream_ptr(self.dev))
         if self._views is None:
             hv = HamViews()
             call("fmhr_ham_workspace_views", ctypes.byref(self.dims), ptr(self.ws), self.ws_bytes, ctypes.byref(hv))

@@ -194,7 +194,8 @@ typedef struct fmhr_ham_views {
                           views' combined matrices) — filled, bit-identical to what the kernels used, by fmhr_ham_densify */
     float* normals;    /* [V,3]     */
     float* rast;       /* [n,H,W,4] */
-    float* shaded;     /* [n,H,W,4] rgb = shaded image before antialias (tmp_img, :285-286), a = coverage colour (:272) */
+    float* shaded;     /* [n,H,W,4] rgb = shaded image before antialias (tmp_img, :285-286), a = coverage colour (:272); not kept by
+                          the step: filled by fmhr_ham_densify */
     float* aa;         /* [n,H,W,4] the same after antialias: rgb = tmp_img (:287), a = pred_mask (:274) */
     int32_t* aa_counter; /* [2] */
 } fmhr_ham_views;
@@ -202,9 +203,10 @@ int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, 
 /* byte offset of a named internal buffer inside the workspace (tests / debugging), -1 if unknown */
 long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const char* name);
 /* The step only writes shaded / aa inside "active" 64-pixel segments (covered pixels, their 4-neighbours, non-zero valid_mask)
- * and stores neither the dr.rasterize image nor the clip positions; this fills the zeros, rebuilds `rast` from the per-pixel
- * words and computes `pos`, so the views above can be inspected as dense arrays.  Call it after the step whose state you want. */
-int fmhr_ham_densify(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);
+ * and stores neither the dr.rasterize image, nor the clip positions, nor the shaded image before antialias; this fills the zeros,
+ * rebuilds `rast` from the per-pixel words, computes `pos` and re-shades `shaded` (tri / sh: the arrays the last forward was given),
+ * so the views above can be inspected as dense arrays.  Call it after the step whose state you want. */
+int fmhr_ham_densify(const fmhr_ham_dims* d, const int32_t* tri, const float* sh, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ per-kernel timing (optional)
  * Attach an array of 2*FMHR_SLOT_COUNT hipEvent_t (created by the caller with timing enabled) to the CALLING THREAD: while
