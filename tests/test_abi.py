@@ -47,6 +47,11 @@ def test_argument_errors_without_gpu(lib):
     ok = HamDims(2, 100, 180, 64, 48, 0, 4096)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(ok)) > 2 * 64 * 48 * 16
     assert lib.fmhr_rasterize_workspace_bytes(2, 7, 10, 8, 8) == 2 * 64 * 8 + 16 + 2 * 10 * 8 + 2 * 7 * 8
+    # fmhr_ham_densify re-shades / recomputes the views the step does not store: it needs the last forward's tri and sh
+    lib.fmhr_ham_densify.restype = ctypes.c_int
+    lib.fmhr_ham_densify.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]
+    assert lib.fmhr_ham_densify(ctypes.byref(ok), None, None, None, 0, None) == -1
+    assert b"ham_densify" in lib.fmhr_last_error()
 
 
 def test_product_fails_loudly_on_cpu_tensors():
