@@ -260,6 +260,9 @@ def main():
                        "coverage": round(tg["coverage"], 4), "parallelism": f"views sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": SLOTS[dom], "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get(SLOTS[dom]),
+                         # the same launch priced by its MEASURED HBM bytes (upper estimate of the PMC profile): how busy HBM really was
+                         "traffic_gbs": ((traffic or {}).get(SLOTS[dom]) or 0) / (dom_ms * 1e-3) / 1e9 or None,
+                         "traffic_frac": ((traffic or {}).get(SLOTS[dom]) or 0) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS or None,
                          "traffic_source": (traffic or {}).get("_source"), "alg_bytes_per_launch": dom_bytes,
                          "avg_launch_ms": dom_ms, "event_samples": len(sampled)},
             "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
