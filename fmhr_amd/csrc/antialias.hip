@@ -584,7 +584,7 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos,
          const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr, bool use_gl = false,
          float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false, float4 dcol = make_float4(0.f, 0.f, 0.f, 0.f),
-         const float* __restrict__ verts = nullptr)
+         const float* __restrict__ verts = nullptr, bool keep0 = true, bool keep1 = true)
 {
     const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
@@ -601,9 +601,9 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
         // fused step (use_gl): the colour difference of the pair is handed in as well (two 16-B loads by the caller)
         const float dcl = use_gl ? ((c == 0) ? dcol.x : ((c == 1) ? dcol.y : ((c == 2) ? dcol.z : dcol.w))) : colorA[pix1 * C + c] - colorA[pix0 * C + c];
         galpha += g * dcl;
-        if (gcolorA != nullptr && g != 0.f) {
-            atomicAdd(gcolorA + pix1 * C + c, alpha * g);
-            atomicAdd(gcolorA + pix0 * C + c, -alpha * g);
+        if (gcolorA != nullptr && g != 0.f) {                            // fused step: an uncovered pixel's gradient is read by nobody
+            if (keep1) atomicAdd(gcolorA + pix1 * C + c, alpha * g);
+            if (keep0) atomicAdd(gcolorA + pix0 * C + c, -alpha * g);
         }
     }
     if (CB > 0) {
@@ -714,8 +714,11 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
         }
         g.w = 2.0f * (a.w - vm) * k2;
         const float4 dcol = dcols[rbase + i];                      // colour difference of the pair, left by the forward
+        const long long pix1 = pix0 + ((it.w & AA_DOWN) ? W : 1);
+        // d loss / d shaded colour exists for covered pixels only (k_loss_pix stores it for them, the owner face reads it)
+        const bool cov0 = (L.covw[pix0 >> 6] >> (pix0 & 63)) & 1ull, cov1 = (L.covw[pix1 >> 6] >> (pix1 & 63)) & 1ull;
         aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, nullptr, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
-                          nullptr, cmat, gvert, true, g, true, dcol, verts);
+                          nullptr, cmat, gvert, true, g, true, dcol, verts, cov0, cov1);
     }
 }
 

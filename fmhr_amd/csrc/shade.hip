@@ -178,7 +178,7 @@ k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict
         float dm = a.w - vm;
         l2 += dm * dm;
         g.w = 2.0f * dm * k2;
-        g_shaded[gid] = g;        // (the antialias backward recomputes the few gradients it needs as dy: no second copy)
+        if (cov) g_shaded[gid] = g;   // read by the owner face only (the antialias backward recomputes the gradients it needs)
     }
     float s1 = block_sum(l1, sm);
     float s2 = block_sum(l2, sm);
