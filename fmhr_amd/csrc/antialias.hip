@@ -601,7 +601,9 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
         // fused step (use_gl): the colour difference of the pair is handed in as well (two 16-B loads by the caller)
         const float dcl = use_gl ? ((c == 0) ? dcol.x : ((c == 1) ? dcol.y : ((c == 2) ? dcol.z : dcol.w))) : colorA[pix1 * C + c] - colorA[pix0 * C + c];
         galpha += g * dcl;
-        if (gcolorA != nullptr && g != 0.f) {                            // fused step: an uncovered pixel's gradient is read by nobody
+        // fused step: an uncovered pixel's gradient is read by nobody, and neither is the alpha channel's (the interpolated
+        // "ones" attribute is constant 1: no gradient flows to the barycentrics; it only moves the crossing point, via galpha)
+        if (gcolorA != nullptr && g != 0.f && !(packed && c == 3)) {
             if (keep1) atomicAdd(gcolorA + pix1 * C + c, alpha * g);
             if (keep0) atomicAdd(gcolorA + pix0 * C + c, -alpha * g);
         }
