@@ -11,7 +11,7 @@ for f in $SRCS common.h shade_common.h ../../include/fmhr_ham.h build.sh; do
 done
 if [ "$NEW" = "0" ] && [ "${FMHR_FORCE_BUILD:-0}" = "0" ]; then echo "libfmhr_ham.so up to date"; exit 0; fi
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -Wall -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -Wall -Wno-unused-result ${FMHR_EXTRA_FLAGS:-}"
 # raster.hip / antialias.hip hold every discrete decision (snap, coverage, depth order, antialias analysis): strict, one IEEE
 # operation per statement.  The value-only kernels may fuse a*b+c WITHIN an expression (never across statements, so the shared
 # decision helpers of common.h stay exact even there).

@@ -117,6 +117,19 @@ __device__ __forceinline__ bool fragment(const float4 p0, const float4 p1, const
     return true;
 }
 
+// NDC coordinates of a pixel centre (rule R5): fx = xs * px + xo, fy = ys * py + yo.  Computed ONCE on the host (IEEE fp32, one
+// rounding per operation: bit-identical to the same statements on the device) and handed to the kernels: evaluated per wave the
+// four correctly rounded divisions cost ~45 vector instructions, 6 % of the triangle kernel.
+struct PixGrid { float xs, xo, ys, yo; };
+inline PixGrid make_pix_grid(int H, int W)
+{
+    PixGrid g;
+    volatile float iw = 1.0f / (float)W, ih = 1.0f / (float)H;      // volatile: no host-side re-association / wider intermediates
+    g.xs = 2.0f / (float)W; g.ys = 2.0f / (float)H;
+    g.xo = iw - 1.0f; g.yo = ih - 1.0f;
+    return g;
+}
+
 // order-preserving map float -> uint32 (smaller float => smaller key)
 __device__ __forceinline__ uint32_t mono_key(float f)
 {

@@ -14,7 +14,7 @@ namespace fmhr {
 // loads through this pointer type go through the scalar cache when the address is wave-uniform (data constant during the kernel)
 typedef const float __attribute__((address_space(4))) const_as4_float;
 
-constexpr int kSmallBox = 64;   // boxes up to this many pixel centres are walked by the owning lane
+constexpr int kSmallBox = 32;   // boxes up to this many pixel centres are walked by the owning lane (32-bit coverage mask)
 
 struct TriSetup {
     int x0, y0, x1, y1, x2, y2;     // CCW-normalised snapped coordinates
@@ -99,72 +99,66 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
     silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
 }
 
-// one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup, integer coverage mask of the (<= 64-pixel) box.
+// one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup, integer coverage mask of the (<= 32-pixel) box.
 // The fragments are then emitted WAVE-cooperatively: the covering lanes park their triangle (clip positions, box origin) in LDS
 // and expand their coverage bits into a dense per-wave task list; every lane then takes tasks round-robin.  A lane looping over
-// its own bits made the whole wave iterate max(bits) times with ~a quarter of the lanes active (the ~100-instruction fragment
-// evaluation was 69 of this kernel's 127 us).
-constexpr int kTaskCap = 512;        // tasks expanded per round (a wave can hold 64 x 64; more rounds then)
+// its own bits made the whole wave iterate max(bits) times with ~a quarter of the lanes active.
+// The kernel is bound by the NUMBER OF VECTOR-ALU INSTRUCTIONS it issues (profiles/r02_v62_issue.txt: 755 per wave x 4 cycles = 92 %
+// of its duration), so everything here is written for instruction count: the grid is 2-D (view = blockIdx.y: no index division,
+// every wave lies in one view, the view's matrix sits in SGPRs), the pixel-grid constants come from the host, the coverage
+// mask is 32 bits wide and filled by ONE flat loop over the box (nested row / column loops run max(rows) x max(columns) of the
+// wave's lanes), and a task's pixel is decoded with a float multiply instead of an integer division.
+constexpr int kTaskCap = 512;        // tasks expanded per round (a wave can hold 64 x 32; more rounds then)
 
 struct TriPark {
     float4 p0, p1, p2;
-    int f, b, origin, bw;            // origin = pxa | pya << 16
+    int f; float rbw; int origin, bw;        // origin = pxa | pya << 16; rbw ~ 1 / bw (task -> pixel decode)
 };
-// a large-box triangle handed to its whole wave: integer setup, clip positions, face and view
+// a large-box triangle handed to its whole wave: integer setup, clip positions, face
 struct LargePark {
     TriSetup s;
     float4 p0, p1, p2;
-    int f, b;
+    int f;
 };
 
 // FV (fused step): no stored clip positions — a lane whose triangle covers a pixel centre transforms its three vertices with the
 // view's combined matrix (the same clip_coord() chains everywhere: bit-identical); the [V,3] vertex array stays in cache, the
-// [n,V,4] position array (37 MB written + gathered per 48 views) does not exist.  UNI: F % 64 == 0, a wave's 64 (view, triangle)
-// pairs share the view: the matrix comes through the scalar cache.
-template <bool UNI, bool FV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((FV && !UNI) ? 5 : 7, 8)))   // per-lane matrix: 16 more VGPRs
+// [n,V,4] position array (37 MB written + gathered per 48 views) does not exist.
+template <bool FV>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
               int4* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
-              const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q)
+              const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg)
 {
     __shared__ TriPark park[kBlock];
     __shared__ unsigned short tasks[kBlock / 64][kTaskCap];
     __shared__ LargePark lpark[kBlock / 64];
-    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int f = blockIdx.x * kBlock + threadIdx.x;
+    const int b = blockIdx.y;                                        // wave-uniform (SGPR)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned long long cm = 0ull;
+    unsigned cm = 0u;
     bool is_large = false;
-    int f = 0, b = 0, i0 = 0, i1 = 0, i2 = 0, o0 = -1, o1 = -1, o2 = -1, bw = 1;
+    int i0 = 0, i1 = 0, i2 = 0, o0 = -1, o1 = -1, o2 = -1, bw = 1;
     int2 s0 = make_int2(0, 0), s1 = s0, s2 = s0;
     TriSetup s;
     s.pxa = s.pya = 0;
-    const int2* sv = snap;
-    bool ok = gid < (long long)n * F;
+    const int2* sv = snap + (size_t)b * V;
+    bool ok = f < F;
     if (ok) {
-        b = fast_divmod(gid, F, f);
         i0 = tri[f * 3]; i1 = tri[f * 3 + 1]; i2 = tri[f * 3 + 2];
         ok = (unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V;
     }
-    // the view's combined matrix (FV).  UNI: one view per wave — its index is computed from the wave's first pair so that the
-    // 16 entries are wave-uniform values in SGPRs (assigned under the divergent `ok` they would become per-lane registers)
+    // the view's combined matrix (FV): wave-uniform, through the scalar cache into SGPRs
     float cmx[16];
-    if (FV && UNI) {
-        int f0;
-        const long long g0 = gid - lane;
-        const int bu = __builtin_amdgcn_readfirstlane(fast_divmod(g0 < (long long)n * F ? g0 : 0, F, f0));
-        const_as4_float* cp = (const_as4_float*)(unsigned long long)(cmat + (size_t)bu * 4);
+    if (FV) {
+        const_as4_float* cp = (const_as4_float*)(unsigned long long)(cmat + (size_t)b * 4);
 #pragma unroll
         for (int k = 0; k < 16; k++) cmx[k] = cp[k];
     }
-    auto clipv = [&](int v) -> float4 {                              // clip position of vertex v in this lane's view
+    auto clipv = [&](int v) -> float4 {                              // clip position of vertex v in this view
         if (!FV) return ldg4(pos + ((size_t)b * V + v) * 4);
-        if (!UNI) {                                                  // several views in the wave: per-lane matrix, loaded at the use
-            const float4 r0 = cmat[(size_t)b * 4], r1 = cmat[(size_t)b * 4 + 1], r2 = cmat[(size_t)b * 4 + 2], r3 = cmat[(size_t)b * 4 + 3];
-            cmx[0] = r0.x; cmx[1] = r0.y; cmx[2] = r0.z; cmx[3] = r0.w; cmx[4] = r1.x; cmx[5] = r1.y; cmx[6] = r1.z; cmx[7] = r1.w;
-            cmx[8] = r2.x; cmx[9] = r2.y; cmx[10] = r2.z; cmx[11] = r2.w; cmx[12] = r3.x; cmx[13] = r3.y; cmx[14] = r3.z; cmx[15] = r3.w;
-        }
         const F3U x = *reinterpret_cast<const F3U*>(verts + (size_t)v * 3);
         return make_float4(clip_coord(x.x, x.y, x.z, cmx[0], cmx[4], cmx[8], cmx[12]), clip_coord(x.x, x.y, x.z, cmx[1], cmx[5], cmx[9], cmx[13]),
                            clip_coord(x.x, x.y, x.z, cmx[2], cmx[6], cmx[10], cmx[14]), clip_coord(x.x, x.y, x.z, cmx[3], cmx[7], cmx[11], cmx[15]));
@@ -173,14 +167,14 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     // (an IEEE division and a dozen compare / round steps per vertex, for all 4.7 M (view, triangle) pairs) doubled this kernel
     auto snapv = [&](int v) -> int2 { return sv[v]; };
     if (ok) {
-        sv = snap + (size_t)b * V;
         s0 = snapv(i0); s1 = snapv(i1); s2 = snapv(i2);
         ok = setup_triangle(s0, s1, s2, H, W, s);
     }
     if (ok) {
         bw = s.pxb - s.pxa + 1;
         const int bh = s.pyb - s.pya + 1;
-        if (bw * (long long)bh > kSmallBox) {
+        const int box = bw * bh;                                     // bw <= W, bh <= H <= 8192: no overflow
+        if (box > kSmallBox) {
             // a mesh of large triangles (a 778-vertex hand at 512 x 334: every triangle) goes through a queue and one workgroup
             // per triangle (k_raster_large: the triangle kernel's own grid is then a few dozen workgroups); on a micro-triangle
             // mesh the odd large box is swept by its wave below and that kernel is not launched at all
@@ -197,39 +191,41 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             // within the box +-1 px, so every product stays below 2^29 (every small-box triangle unless it pokes far off screen)
             if (ext < 16384) {
                 // incremental edge functions: E_k = e_k - (tie rule admits e_k == 0 ? 0 : 1), inside <=> all three E_k >= 0 <=>
-                // the OR of the three has a clear sign bit; a pixel step adds a constant per edge (all values stay below 2^30)
+                // the OR of the three has a clear sign bit; a step to the right adds sx_k, the wrap to the next row's first
+                // pixel adds wr_k = sy_k - (bw - 1) * sx_k (all values stay below 2^30)
                 const int cx0 = s.pxa * kSub + kHalf, cy0 = s.pya * kSub + kHalf;
-                int E0, E1, E2, sx0, sx1, sx2, sy0, sy1, sy2;
+                int e0, e1, e2, sx0, sx1, sx2, wr0, wr1, wr2;
                 {
                     int dx = s.x1 - s.x0, dy = s.y1 - s.y0;
-                    E0 = dx * (cy0 - s.y0) - dy * (cx0 - s.x0) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
-                    sx0 = -dy * kSub; sy0 = dx * kSub;
+                    e0 = dx * (cy0 - s.y0) - dy * (cx0 - s.x0) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
+                    sx0 = -dy * kSub; wr0 = dx * kSub - (bw - 1) * sx0;
                     dx = s.x2 - s.x1; dy = s.y2 - s.y1;
-                    E1 = dx * (cy0 - s.y1) - dy * (cx0 - s.x1) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
-                    sx1 = -dy * kSub; sy1 = dx * kSub;
+                    e1 = dx * (cy0 - s.y1) - dy * (cx0 - s.x1) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
+                    sx1 = -dy * kSub; wr1 = dx * kSub - (bw - 1) * sx1;
                     dx = s.x0 - s.x2; dy = s.y0 - s.y2;
-                    E2 = dx * (cy0 - s.y2) - dy * (cx0 - s.x2) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
-                    sx2 = -dy * kSub; sy2 = dx * kSub;
+                    e2 = dx * (cy0 - s.y2) - dy * (cx0 - s.x2) - (((dy > 0) || (dy == 0 && dx > 0)) ? 0 : 1);
+                    sx2 = -dy * kSub; wr2 = dx * kSub - (bw - 1) * sx2;
                 }
-                int bit = 0;
-                for (int r = 0; r < bh; r++) {
-                    int e0 = E0, e1 = E1, e2 = E2;
-                    for (int c = 0; c < bw; c++, bit++) {
-                        if ((e0 | e1 | e2) >= 0) cm |= 1ull << bit;
-                        e0 += sx0; e1 += sx1; e2 += sx2;
-                    }
-                    E0 += sy0; E1 += sy1; E2 += sy2;
+                unsigned om = 0u;                                    // OUTSIDE bits (the sign of the OR), complemented below
+                int c = bw;                                          // columns left in the current row
+                for (int bit = 0; bit < box; bit++) {
+                    om |= ((unsigned)(e0 | e1 | e2) >> 31) << bit;
+                    c--;
+                    const bool wrap = c == 0;
+                    e0 += wrap ? wr0 : sx0; e1 += wrap ? wr1 : sx1; e2 += wrap ? wr2 : sx2;
+                    c = wrap ? bw : c;
                 }
+                cm = ~om & (0xffffffffu >> (32 - box));              // 1 <= box <= 32
             } else {
                 int bit = 0;
                 for (int py = s.pya; py <= s.pyb; py++)
                     for (int px = s.pxa; px <= s.pxb; px++, bit++)
-                        if (covers(s, px, py)) cm |= 1ull << bit;
+                        if (covers(s, px, py)) cm |= 1u << bit;
             }
         }
     }
     // ---- wave-wide task numbering: exclusive scan of the per-lane fragment counts
-    const int cnt = __popcll(cm);
+    const int cnt = __popc(cm);
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -248,7 +244,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         lbal = 0ull;
     }
     if (T == 0 && lbal == 0ull) return;                              // wave-uniform
-    if (cm != 0ull) {
+    if (cm != 0u) {
         // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
         float4 p0 = clipv(i0), p1 = clipv(i1), p2 = clipv(i2);
         const int2 rej = make_int2(kRejected, 0);
@@ -258,22 +254,21 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         if (silh != nullptr) silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
         // coverage entry (face-parallel backward): candidate-pixel mask of the box, its origin and width, tagged with the step stamp
         if (cov16 != nullptr)
-            cov16[(size_t)b * F + f] = make_int4((int)(unsigned)(cm & 0xffffffffull), (int)(unsigned)(cm >> 32), s.pxa | (s.pya << 16),
-                                                 (int)(((unsigned)stamp[0] << 8) | (unsigned)bw));
+            cov16[(size_t)b * F + f] = make_int4((int)cm, 0, s.pxa | (s.pya << 16), (int)(((unsigned)stamp[0] << 8) | (unsigned)bw));
         TriPark& t = park[threadIdx.x];
-        t.p0 = p0; t.p1 = p1; t.p2 = p2; t.f = f; t.b = b; t.origin = s.pxa | (s.pya << 16); t.bw = bw;
+        t.p0 = p0; t.p1 = p1; t.p2 = p2; t.f = f; t.rbw = __builtin_amdgcn_rcpf((float)bw); t.origin = s.pxa | (s.pya << 16); t.bw = bw;
     }
-    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
-    float xo = 1.0f / (float)W; xo = xo - 1.0f;
-    float yo = 1.0f / (float)H; yo = yo - 1.0f;
     const long long P = (long long)H * W;
+    unsigned long long* const keys_view = keys + (size_t)b * P;      // wave-uniform bases: the per-task offsets are 32-bit
+    const long long segbase = ((long long)b * P) >> 6;
+    const int segrem = (int)(((long long)b * P) & 63);
     for (int R = 0; R < T; R += kTaskCap) {
-        if (cm != 0ull && excl < R + kTaskCap && excl + cnt > R) {
-            unsigned long long m = cm;
+        if (cm != 0u && excl < R + kTaskCap && excl + cnt > R) {
+            unsigned m = cm;
             int idx = excl - R;
-            while (m != 0ull) {
-                const int bit = __builtin_ctzll(m);
-                m &= m - 1ull;
+            while (m != 0u) {
+                const int bit = __builtin_ctz(m);
+                m &= m - 1u;
                 if (idx >= 0 && idx < kTaskCap) tasks[wv][idx] = (unsigned short)((lane << 6) | bit);
                 idx++;
             }
@@ -283,31 +278,44 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         const int nt = min(kTaskCap, T - R);
         for (int t0 = 0; t0 < nt; t0 += 64) {                       // uniform trip count: the shuffles below need every lane
             const int t = t0 + lane;
-            long long segl = -1;
+            int segl = -1;
             if (t < nt) {
                 const int e = tasks[wv][t], o = e >> 6, bit = e & 63;
                 const TriPark& q = park[wv * 64 + o];
-                int c;
-                const int r = fast_divmod(bit, q.bw, c);
+                // row / column of the task's pixel in the box: bit < 32, 1 <= bw <= 32, so (bit + 0.5) / bw is at least 1 / 64 away
+                // from an integer and the 1-ulp reciprocal cannot change the truncated quotient (an integer division costs ~25 instructions)
+                float qf = (float)bit + 0.5f;
+                qf = qf * q.rbw;
+                const int r = (int)qf, c = bit - r * q.bw;
                 const int px = (q.origin & 0xffff) + c, py = (q.origin >> 16) + r;
                 Frag fr;
-                if (fragment(q.p0, q.p1, q.p2, px, py, xs, xo, ys, yo, fr)) {
+                if (fragment(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr)) {
                     const unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)q.f << 1);
-                    const long long pix = (long long)q.b * P + (long long)py * W + px;
-                    atomicMin(&keys[pix], key);
-                    segl = pix >> 6;
+                    const int pix = py * W + px;                     // < 2^26
+#if defined(FMHR_X_NOATOMIC)
+                    if (key == 0x123456789abcdefull) keys_view[pix] = key;
+#elif defined(FMHR_X_STORE)
+                    keys_view[pix] = key;
+#else
+                    atomicMin(&keys_view[pix], key);
+#endif
+                    segl = (pix + segrem) >> 6;                      // segment index relative to the view's first segment
                 }
             }
             if (dirty != nullptr) {
                 // consecutive tasks mostly land in the same 64-pixel segment: one flag store per run
-                const long long prev = __shfl_up(segl, 1);
-                if (segl >= 0 && (lane == 0 || prev != segl)) dirty[segl] = 1;
+                const int prev = __shfl_up(segl, 1);
+#if !defined(FMHR_X_NODIRTY)
+                if (segl >= 0 && (lane == 0 || prev != segl)) dirty[segbase + segl] = 1;
+#else
+                if (segl == 0x7ffffff0 && prev == 5) dirty[segbase + segl] = 1;
+#endif
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    // ---- large-box triangles (box > 64 pixels: none on a sub3-class mesh, all of them on a 778-vertex hand): each is rasterized
+    // ---- large-box triangles (box > 32 pixels: none on a sub3-class mesh, all of them on a 778-vertex hand): each is rasterized
     // by its whole wave, 64 box pixels per iteration (no second launch; coarse meshes took the queue above instead)
     if (lbal == 0ull) return;                                        // wave-uniform
     float4 lp0 = make_float4(0.f, 0.f, 0.f, 0.f), lp1 = lp0, lp2 = lp0;
@@ -317,7 +325,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         lbal &= lbal - 1ull;
         if (lane == src) {
             LargePark& q = lpark[wv];
-            q.s = s; q.p0 = lp0; q.p1 = lp1; q.p2 = lp2; q.f = f; q.b = b;
+            q.s = s; q.p0 = lp0; q.p1 = lp1; q.p2 = lp2; q.f = f;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -329,7 +337,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 const int r = fast_divmod(i, lbw, c);
                 const int px = q.s.pxa + c, py = q.s.pya + r;
                 if (covers(q.s, px, py))
-                    emit_fragment(q.p0, q.p1, q.p2, px, py, q.f, xs, xo, ys, yo, keys + (size_t)q.b * P, W, dirty, (long long)q.b * P);
+                    emit_fragment(q.p0, q.p1, q.p2, px, py, q.f, pg.xs, pg.xo, pg.ys, pg.yo, keys_view, W, dirty, (long long)b * P);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -342,12 +350,10 @@ __global__ void __launch_bounds__(kBlock)
 k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
                int F, int H, int W, unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt,
                const int2* __restrict__ large_q, unsigned char* __restrict__ dirty, const float* __restrict__ verts,
-               const float4* __restrict__ cmat)
+               const float4* __restrict__ cmat, const PixGrid pg)
 {
     const int cnt = *large_cnt;
-    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
-    float xo = 1.0f / (float)W; xo = xo - 1.0f;
-    float yo = 1.0f / (float)H; yo = yo - 1.0f;
+    const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;
     for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
         int2 bf = large_q[it];
         int b = bf.x, f = bf.y;
@@ -380,7 +386,7 @@ template <bool UNI, bool FV>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((FV && !UNI) ? 5 : ((UNI && !FV) ? 8 : 7), 8)))
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
-                 unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu)
+                 unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu, const PixGrid pg)
 {
     const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long P = (long long)H * W;
@@ -474,9 +480,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                 p2 = make_float4(clip_coord(x2.x, x2.y, x2.z, cm[0], cm[4], cm[8], cm[12]), clip_coord(x2.x, x2.y, x2.z, cm[1], cm[5], cm[9], cm[13]),
                                  clip_coord(x2.x, x2.y, x2.z, cm[2], cm[6], cm[10], cm[14]), clip_coord(x2.x, x2.y, x2.z, cm[3], cm[7], cm[11], cm[15]));
             }
-            const float xs = 2.0f / (float)W, ys = 2.0f / (float)H;
-            float xo = 1.0f / (float)W; xo = xo - 1.0f;
-            float yo = 1.0f / (float)H; yo = yo - 1.0f;
+            const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;
             Frag fr;
             if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
                 o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
@@ -696,6 +700,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     int* large_cnt = (int*)((char*)ws + nP * 8);
     int2* large_q = (int2*)((char*)ws + nP * 8 + 16);
     if (nP == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(n <= 65535, "rasterize: at most 65535 views per call (the view is a grid dimension), got %d", n);
     // large-box triangles: through the queue + k_raster_large when the mesh is coarse for the resolution (>= 8 pixels per face at
     // 50 % coverage: most boxes exceed 64 pixels), else swept by their wave inside k_raster_tris (no second launch)
     const bool use_queue = raster_use_queue(H, W, F);
@@ -713,33 +718,31 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         }
     }
     int2* lq = use_queue ? large_q : nullptr;
+    const PixGrid pg = make_pix_grid(H, W);
     if ((long long)n * F > 0) {
         ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
-        const dim3 tgrid(cdiv((long long)n * F, kBlock));
-        const float4* cmat = fu.cmat;
-        if (fu.verts != nullptr && (F & 63) == 0)
-            k_raster_tris<true, true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, cmat, large_cnt, lq);
-        else if (fu.verts != nullptr)
-            k_raster_tris<false, true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, cmat, large_cnt, lq);
+        const dim3 tgrid(cdiv(F, kBlock), n);                        // view = blockIdx.y
+        if (fu.verts != nullptr)
+            k_raster_tris<true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg);
         else
-            k_raster_tris<false, false><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq);
+            k_raster_tris<false><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg);
         FMHR_CHECK_LAUNCH("k_raster_tris");
     }
     {
         ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);          // empty on a micro-triangle mesh
         if (use_queue && (long long)n * F > 0) {
-            k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty, fu.verts, fu.cmat);
+            k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty, fu.verts, fu.cmat, pg);
             FMHR_CHECK_LAUNCH("k_raster_large");
         }
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
     const dim3 rgrid(cdiv((long long)nP, kBlock));
     if (fu.verts != nullptr && dirty != nullptr && (((long long)H * W) & 63) == 0)
-        k_raster_resolve<true, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
+        k_raster_resolve<true, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
     else if (fu.verts != nullptr)
-        k_raster_resolve<false, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
+        k_raster_resolve<false, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
     else
-        k_raster_resolve<false, false><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu);
+        k_raster_resolve<false, false><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }
