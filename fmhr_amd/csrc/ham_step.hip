@@ -26,6 +26,7 @@ int mesh_tail_impl(const MeshTailArgs&, float*, float*, const FinishArgs&, hipSt
 int mesh_tail_blocks(int V);
 // raster.hip / antialias.hip / mesh.hip / shade.hip
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
+size_t raster_keys_bytes(int n, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
 int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
                        void*, unsigned char*, unsigned long long*, const RasterFused*, hipStream_t);
@@ -321,8 +322,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         TRY(face_bwd_impl((const float*)(w + L.pix16), tri, nullptr, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
                           w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot,
                           (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), et, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part),
-                          (const int2*)(w + L.snap), (const int2*)(w + L.raster_ws + (size_t)d->n * d->H * d->W * 8 + 16),
-                          (const int*)(w + L.raster_ws + (size_t)d->n * d->H * d->W * 8), (const unsigned long long*)(w + L.covw), st));
+                          (const int2*)(w + L.snap), (const int2*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W) + 16),
+                          (const int*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W)), (const unsigned long long*)(w + L.covw), st));
     }
     {
         // everything per-vertex after the face-parallel backward, in two kernels (mesh.hip: k_mesh_tail_a / _b)

@@ -67,7 +67,7 @@ __device__ __forceinline__ void emit_fragment(const float4 p0, const float4 p1, 
     Frag fr;
     if (!fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) return;
     unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)f << 1) | 1u;   // bit 0: large-box triangle
-    size_t pix = (size_t)py * W + px;
+    const size_t pix = (size_t)py * W + px;
     atomicMin(&keys_view[pix], key);
     if (dirty != nullptr) dirty[(pixbase + (long long)pix) >> 6] = 1;
 }
@@ -108,7 +108,7 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
 // every wave lies in one view, the view's matrix sits in SGPRs), the pixel-grid constants come from the host, the coverage
 // mask is 32 bits wide and filled by ONE flat loop over the box (nested row / column loops run max(rows) x max(columns) of the
 // wave's lanes), and a task's pixel is decoded with a float multiply instead of an integer division.
-constexpr int kTaskCap = 512;        // tasks expanded per round (a wave can hold 64 x 32; more rounds then)
+constexpr int kTaskCap = 1024;       // tasks the workgroup expands per round (it can hold 256 x 32; more rounds then)
 
 struct TriPark {
     float4 p0, p1, p2;
@@ -124,8 +124,9 @@ struct LargePark {
 // FV (fused step): no stored clip positions — a lane whose triangle covers a pixel centre transforms its three vertices with the
 // view's combined matrix (the same clip_coord() chains everywhere: bit-identical); the [V,3] vertex array stays in cache, the
 // [n,V,4] position array (37 MB written + gathered per 48 views) does not exist.
+// 64 VGPRs and < 20 KB of LDS per workgroup: 8 waves per SIMD (5 / 6 / 7 / 8 waves: 105 / 100 / 97.5 / 94 us)
 template <bool FV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
@@ -133,7 +134,8 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
               const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg)
 {
     __shared__ TriPark park[kBlock];
-    __shared__ unsigned short tasks[kBlock / 64][kTaskCap];
+    __shared__ unsigned short tasks[kTaskCap];                       // the workgroup's task list: lane (8 bits) << 5 | bit of its mask
+    __shared__ int wtot[kBlock / 64];
     __shared__ LargePark lpark[kBlock / 64];
     const int f = blockIdx.x * kBlock + threadIdx.x;
     const int b = blockIdx.y;                                        // wave-uniform (SGPR)
@@ -224,7 +226,10 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             }
         }
     }
-    // ---- wave-wide task numbering: exclusive scan of the per-lane fragment counts
+    // ---- task numbering over the WORKGROUP: wave-wide exclusive scan of the per-lane fragment counts + the waves' totals.  The
+    // four waves share one task list and take dense 64-task slices of it: a wave of a sub3-class mesh has 64 +- 15 fragments, so
+    // with a list of its own every other wave ran a second, nearly empty round of the ~110-instruction fragment evaluation (1.56
+    // rounds per wave; pooled: ~1.1) and issued its atomics in two instructions that touched some key lines twice
     const int cnt = __popc(cm);
     int incl = cnt;
 #pragma unroll
@@ -232,7 +237,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         int t = __shfl_up(incl, d);
         if (lane >= d) incl += t;
     }
-    const int excl = incl - cnt, T = __shfl(incl, 63);
+    if (lane == 63) wtot[wv] = incl;
     unsigned long long lbal = __ballot(is_large);                    // lanes holding a large-box triangle
     if (large_q != nullptr && lbal != 0ull) {                        // queue mode: one cursor atomic per wave (same-address atomics
         int base = 0;                                                // serialise at ~10 ns each: 1.5 k pushes of a hand in one view)
@@ -243,7 +248,6 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         is_large = false;
         lbal = 0ull;
     }
-    if (T == 0 && lbal == 0ull) return;                              // wave-uniform
     if (cm != 0u) {
         // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
         float4 p0 = clipv(i0), p1 = clipv(i1), p2 = clipv(i2);
@@ -258,30 +262,39 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         TriPark& t = park[threadIdx.x];
         t.p0 = p0; t.p1 = p1; t.p2 = p2; t.f = f; t.rbw = __builtin_amdgcn_rcpf((float)bw); t.origin = s.pxa | (s.pya << 16); t.bw = bw;
     }
+    __syncthreads();                                                 // every wave of the workgroup gets here (no early return above)
+    int wbase = 0, T = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; i++) {
+        const int w = wtot[i];
+        if (i < wv) wbase += w;
+        T += w;
+    }
+    const int excl = wbase + incl - cnt;                             // this lane's first task in the workgroup's numbering
     const long long P = (long long)H * W;
     unsigned long long* const keys_view = keys + (size_t)b * P;      // wave-uniform bases: the per-task offsets are 32-bit
     const long long segbase = ((long long)b * P) >> 6;
     const int segrem = (int)(((long long)b * P) & 63);
-    for (int R = 0; R < T; R += kTaskCap) {
+    for (int R = 0; R < T; R += kTaskCap) {                          // workgroup-uniform trip count (one round unless boxes are large)
+        if (R > 0) __syncthreads();                                  // the previous round's list has been consumed
         if (cm != 0u && excl < R + kTaskCap && excl + cnt > R) {
             unsigned m = cm;
             int idx = excl - R;
             while (m != 0u) {
                 const int bit = __builtin_ctz(m);
                 m &= m - 1u;
-                if (idx >= 0 && idx < kTaskCap) tasks[wv][idx] = (unsigned short)((lane << 6) | bit);
+                if (idx >= 0 && idx < kTaskCap) tasks[idx] = (unsigned short)((threadIdx.x << 5) | bit);
                 idx++;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         const int nt = min(kTaskCap, T - R);
-        for (int t0 = 0; t0 < nt; t0 += 64) {                       // uniform trip count: the shuffles below need every lane
+        for (int t0 = wv * 64; t0 < nt; t0 += kBlock) {             // wave-uniform trip count: the shuffle below needs every lane
             const int t = t0 + lane;
             int segl = -1;
             if (t < nt) {
-                const int e = tasks[wv][t], o = e >> 6, bit = e & 63;
-                const TriPark& q = park[wv * 64 + o];
+                const int e = tasks[t], o = e >> 5, bit = e & 31;
+                const TriPark& q = park[o];
                 // row / column of the task's pixel in the box: bit < 32, 1 <= bw <= 32, so (bit + 0.5) / bw is at least 1 / 64 away
                 // from an integer and the 1-ulp reciprocal cannot change the truncated quotient (an integer division costs ~25 instructions)
                 float qf = (float)bit + 0.5f;
@@ -292,28 +305,16 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 if (fragment(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr)) {
                     const unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)q.f << 1);
                     const int pix = py * W + px;                     // < 2^26
-#if defined(FMHR_X_NOATOMIC)
-                    if (key == 0x123456789abcdefull) keys_view[pix] = key;
-#elif defined(FMHR_X_STORE)
-                    keys_view[pix] = key;
-#else
                     atomicMin(&keys_view[pix], key);
-#endif
                     segl = (pix + segrem) >> 6;                      // segment index relative to the view's first segment
                 }
             }
             if (dirty != nullptr) {
                 // consecutive tasks mostly land in the same 64-pixel segment: one flag store per run
                 const int prev = __shfl_up(segl, 1);
-#if !defined(FMHR_X_NODIRTY)
                 if (segl >= 0 && (lane == 0 || prev != segl)) dirty[segbase + segl] = 1;
-#else
-                if (segl == 0x7ffffff0 && prev == 5) dirty[segbase + segl] = 1;
-#endif
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
     // ---- large-box triangles (box > 32 pixels: none on a sub3-class mesh, all of them on a 778-vertex hand): each is rasterized
     // by its whole wave, 64 box pixels per iteration (no second launch; coarse meshes took the queue above instead)
@@ -658,7 +659,8 @@ using namespace fmhr;
 
 namespace fmhr {
 // [keys: n*H*W u64][large-triangle counter: 16 B][large-triangle queue: n*F int2]
-size_t raster_core_ws_bytes(int n, int F, int H, int W) { return (size_t)n * H * W * 8 + 16 + (size_t)n * F * 8; }
+size_t raster_keys_bytes(int n, int H, int W) { return (size_t)n * H * W * 8; }
+size_t raster_core_ws_bytes(int n, int F, int H, int W) { return raster_keys_bytes(n, H, W) + 16 + (size_t)n * F * 8; }
 }  // namespace fmhr
 
 extern "C" size_t fmhr_rasterize_workspace_bytes(int n, int V, int F, int H, int W)
@@ -680,11 +682,12 @@ int snap_vertices_impl(const float* pos, int n, int V, int H, int W, int2* snap,
 int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
-    hipError_t e = hipMemsetAsync(ws, 0xFF, nP * 8, st);
+    const size_t kb = raster_keys_bytes(n, H, W);
+    hipError_t e = hipMemsetAsync(ws, 0xFF, kb, st);
     if (e != hipSuccess) return hip_fail(e, "init keys");
     e = hipMemsetAsync(dirty, 0, (nP + 63) / 64, st);
     if (e != hipSuccess) return hip_fail(e, "init dirty");
-    e = hipMemsetAsync((char*)ws + nP * 8, 0, 16, st);               // large-triangle queue counter
+    e = hipMemsetAsync((char*)ws + kb, 0, 16, st);                   // large-triangle queue counter
     if (e != hipSuccess) return hip_fail(e, "init large_cnt");
     return FMHR_OK;
 }
@@ -696,9 +699,10 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
                        const RasterFused* fused, hipStream_t st)
 {
     size_t nP = (size_t)n * H * W;
+    const size_t kb = raster_keys_bytes(n, H, W);
     unsigned long long* keys = (unsigned long long*)ws;
-    int* large_cnt = (int*)((char*)ws + nP * 8);
-    int2* large_q = (int2*)((char*)ws + nP * 8 + 16);
+    int* large_cnt = (int*)((char*)ws + kb);
+    int2* large_q = (int2*)((char*)ws + kb + 16);
     if (nP == 0) return FMHR_OK;
     FMHR_CHECK_ARG(n <= 65535, "rasterize: at most 65535 views per call (the view is a grid dimension), got %d", n);
     // large-box triangles: through the queue + k_raster_large when the mesh is coarse for the resolution (>= 8 pixels per face at
@@ -711,7 +715,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         ProfScope ps(FMHR_SLOT_RASTER_CLEAR, st);
         hipError_t e;
         if (dirty == nullptr) {
-            e = hipMemsetAsync(keys, 0xFF, nP * 8, st);
+            e = hipMemsetAsync(keys, 0xFF, kb, st);
             if (e != hipSuccess) return hip_fail(e, "memset keys");
             e = hipMemsetAsync(large_cnt, 0, 16, st);                // sparse mode: the resolve pass re-zeroes the counter itself
             if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
