@@ -4,8 +4,8 @@
 One "step" = one full stage-2 iteration of /root/reference/mesh_sfs_optim.py:253-310 on the metric workload (48 views,
 512x512, sub3-class mesh V=48693/F=97088): render + six losses + backward + gradient exchange + Adam step.
 `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under torch.distributed.run, one rank per GPU,
-views sharded contiguously over ranks (strong scaling: the 48-view batch is fixed), ONE packed all-reduce of the per-vertex
-gradients per step plus the valid-pixel count all-reduce.
+views sharded contiguously over ranks (strong scaling: the 48-view batch is fixed), ONE packed all-reduce per step (the
+photometric share of the gradient travels with its L1 divisor left out: fmhr_amd/dist.py).
 
 Prints ONE JSON line on rank 0 with the contract fields plus:
   roofline     — dominant launch group of the step: algorithmic bytes (SURVEY.md §8d per-primitive table) / its mean HIP-event
@@ -170,15 +170,12 @@ def main():
     groups = [{'params': delta, 'lr': lr["lr"]}, {'params': albedo, 'lr': lr["albedo_lr"]}]
     from fmhr_amd.optim import Adam          # same update rule as torch.optim.Adam (tests/test_gpu_utils.py::test_adam)
     opt = Adam(groups)
-    sharded = fdist.ShardedStep(V, dev)
     group = torch.distributed.group.WORLD if world > 1 else None
     reg_range = fdist.shard_views(V, rank, world)     # the view-independent terms are split over the ranks by vertex range
 
     def step():
         losses, gd, ga = hs.step(vtmp, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"],
-                                 group=group, reg_range=reg_range)
-        if world > 1:
-            losses, gd, ga = sharded.reduce(losses, gd, ga)
+                                 group=group, reg_range=reg_range)        # N > 1: includes the step's one all-reduce
         delta.grad, albedo.grad = gd, ga.view(1, V, 3)
         opt.step()
         return losses

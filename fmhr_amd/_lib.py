@@ -62,8 +62,10 @@ SIGNATURES = {
     "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),
     "fmhr_ham_workspace_init": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),
     "fmhr_ham_densify": (c_int, [ctypes.POINTER(HamDims), P, P, P, c_size_t, P]),
-    "fmhr_ham_backward": (c_int, [ctypes.POINTER(HamDims), ctypes.POINTER(HamWeights), P, P, P, P, P, P, P, P, P, P, P, P, P,
-                                  P, P, P, P, P, P, P, P, c_size_t, P]),
+    "fmhr_ham_backward": (c_int, [ctypes.POINTER(HamDims), ctypes.POINTER(HamWeights), P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                                  P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "fmhr_ham_combine": (c_int, [c_int, P, P]),
+    "fmhr_edge_multiplicity_build": (c_int, [P, c_int, c_int, P, P, c_int, P, P]),
     "fmhr_corner_slots_build": (c_int, [P, c_int, P, P]),
     "fmhr_vertex_faces_workspace_bytes": (c_size_t, [c_int]),
     "fmhr_vertex_faces_build": (c_int, [P, c_int, c_int, P, P, P, c_size_t, P]),
@@ -83,7 +85,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.fmhr_abi_version() != 1:
+        if lib.fmhr_abi_version() != 2:
             raise RuntimeError("fmhr_amd: ABI version mismatch")
         _lib = lib
     return _lib

@@ -584,14 +584,14 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos,
          const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr, bool use_gl = false,
          float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false, float4 dcol = make_float4(0.f, 0.f, 0.f, 0.f),
-         const float* __restrict__ verts = nullptr, bool keep0 = true, bool keep1 = true)
+         const float* __restrict__ verts = nullptr, bool keep0 = true, bool keep1 = true, float* __restrict__ gvert2 = nullptr)
 {
     const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
     long long pix0 = ((long long)b * H + py) * W + px;
     long long pix1 = pix0 + (d ? W : 1);
     long long tgt = (alpha > 0.f) ? pix0 : pix1;
-    float galpha = 0.f;
+    float galpha = 0.f, galpha_a = 0.f;       // galpha_a: the alpha channel's share (fused step: the silhouette-MSE term)
     const int C = (CA > 0) ? CA : Cdyn;
 #pragma unroll
     for (int c = 0; c < C; c++) {
@@ -601,6 +601,7 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
         // fused step (use_gl): the colour difference of the pair is handed in as well (two 16-B loads by the caller)
         const float dcl = use_gl ? ((c == 0) ? dcol.x : ((c == 1) ? dcol.y : ((c == 2) ? dcol.z : dcol.w))) : colorA[pix1 * C + c] - colorA[pix0 * C + c];
         galpha += g * dcl;
+        if (packed && c == 3) galpha_a = g * dcl;
         // fused step: an uncovered pixel's gradient is read by nobody, and neither is the alpha channel's (the interpolated
         // "ones" attribute is constant 1: no gradient flows to the barycentrics; it only moves the crossing point, via galpha)
         if (gcolorA != nullptr && g != 0.f && !(packed && c == 3)) {
@@ -635,7 +636,9 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
     float xa = pa.x * wa * xh - fx, ya = pa.y * wa * yh - fy;
     float xb = pb.x * wb * xh - fx, yb = pb.y * wb * yh - fy;
     if (d) { float tt; tt = xa; xa = ya; ya = tt; tt = xb; xb = yb; yb = tt; }
-    float gxc = -galpha;
+    // the position gradient is linear in galpha: a view-sharded caller (gvert2 != null) keeps the photometric share (rgb channels,
+    // normalised by the batch-global valid-pixel count AFTER the gradient all-reduce) apart from the silhouette share (alpha)
+    float gxc = (gvert2 != nullptr) ? -1.0f : -galpha;
     float iden = 1.0f / (ya - yb);
     float tpar = ya * iden;
     float g_xa = gxc * (1.0f - tpar), g_xb = gxc * tpar;
@@ -647,14 +650,20 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
     if (cmat != nullptr) {
         // fused step: apply the clip-transform backward here and accumulate straight into the view-independent [V,3] buffer
         const float4 c0 = cmat[(size_t)b * 4], c1 = cmat[(size_t)b * 4 + 1], c2 = cmat[(size_t)b * 4 + 2];
-        float* qa = gvert + (size_t)va * 3;
-        float* qb = gvert + (size_t)vb * 3;
-        atomicAdd(qa + 0, ax * c0.x + ay * c0.y + aw * c0.w);          // rows of w2c @ proj: columns x, y, (z,) w
-        atomicAdd(qa + 1, ax * c1.x + ay * c1.y + aw * c1.w);
-        atomicAdd(qa + 2, ax * c2.x + ay * c2.y + aw * c2.w);
-        atomicAdd(qb + 0, bx * c0.x + by * c0.y + bw * c0.w);
-        atomicAdd(qb + 1, bx * c1.x + by * c1.y + bw * c1.w);
-        atomicAdd(qb + 2, bx * c2.x + by * c2.y + bw * c2.w);
+        const float ga[3] = {ax * c0.x + ay * c0.y + aw * c0.w, ax * c1.x + ay * c1.y + aw * c1.w, ax * c2.x + ay * c2.y + aw * c2.w};
+        const float gb[3] = {bx * c0.x + by * c0.y + bw * c0.w, bx * c1.x + by * c1.y + bw * c1.w, bx * c2.x + by * c2.y + bw * c2.w};
+        if (gvert2 == nullptr) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { atomicAdd(gvert + (size_t)va * 3 + k, ga[k]); atomicAdd(gvert + (size_t)vb * 3 + k, gb[k]); }
+        } else {
+            const float s1 = galpha - galpha_a, s2 = galpha_a;         // (ga, gb) are per unit of galpha here
+            if (s1 != 0.f)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { atomicAdd(gvert + (size_t)va * 3 + k, s1 * ga[k]); atomicAdd(gvert + (size_t)vb * 3 + k, s1 * gb[k]); }
+            if (s2 != 0.f)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { atomicAdd(gvert2 + (size_t)va * 3 + k, s2 * ga[k]); atomicAdd(gvert2 + (size_t)vb * 3 + k, s2 * gb[k]); }
+        }
         return;
     }
     float* qa = gpos + ((size_t)b * V + va) * 4;
@@ -692,7 +701,7 @@ __global__ void __launch_bounds__(kBlock)
 k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast, const float* __restrict__ pos,
                const float* __restrict__ verts, const int32_t* __restrict__ tri, const LossGrad L, const int4* __restrict__ items,
                const float* __restrict__ alphas, const int32_t* __restrict__ region_cnt, int cap, int V, int H, int W,
-               float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert)
+               float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert, float* __restrict__ gvert2)
 {
     const int region = cap / (int)gridDim.x, count = region_cnt[blockIdx.x];      // same grid as k_aa_fwd_list
     const size_t rbase = (size_t)blockIdx.x * region;
@@ -720,7 +729,7 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
         // d loss / d shaded colour exists for covered pixels only (k_loss_pix stores it for them, the owner face reads it)
         const bool cov0 = (L.covw[pix0 >> 6] >> (pix0 & 63)) & 1ull, cov1 = (L.covw[pix1 >> 6] >> (pix1 & 63)) & 1ull;
         aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, nullptr, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
-                          nullptr, cmat, gvert, true, g, true, dcol, verts, cov0, cov1);
+                          nullptr, cmat, gvert, true, g, true, dcol, verts, cov0, cov1, gvert2);
     }
 }
 
@@ -763,13 +772,13 @@ int aa_fwd_rgba(const float* attr8, const float* sh, float* dcols, const float* 
 int aa_bwd_rgba(const float* dcols, const float* rast, const float* pos, const float* verts, const int32_t* tri, const float* aa, const float* img,
                 const float* mask, const float* valid_mask, const unsigned long long* covw, const float* n_valid, float w_sfs,
                 float w_mask, float mse_den, const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int V,
-                int H, int W, float* gcolor, const float* cmat, float* gvert, hipStream_t st)
+                int H, int W, float* gcolor, const float* cmat, float* gvert, float* gvert2, hipStream_t st)
 {
     LossGrad L;
     L.aa = (const float4*)aa; L.img = img; L.mask = mask; L.valid_mask = valid_mask; L.covw = covw; L.n_valid = n_valid;
     L.w_sfs = w_sfs; L.w_mask = w_mask; L.mse_den = mse_den;
     k_aa_bwd_items<<<kAaGrid, kBlock, 0, st>>>((const float4*)dcols, (const float4*)rast, pos, verts, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W,
-                                           gcolor, (const float4*)cmat, gvert);
+                                           gcolor, (const float4*)cmat, gvert, gvert2);
     FMHR_CHECK_LAUNCH("k_aa_bwd_items");
     return FMHR_OK;
 }

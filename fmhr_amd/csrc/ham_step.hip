@@ -8,22 +8,27 @@
 namespace fmhr {
 struct MeshTailArgs {
     const float4* part; float* gvert_aa; int G;
+    float* gvert_aa2;
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
+    const int32_t* col_mult;
     int V, F;
     int v0, v1;
     float lap_w, alb_w, edge_w, delta_w, edge_mean, rg;
-    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a;
+    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a; float* gacc_r;
     float* loss_part;
+    float* gdelta; float* galbedo; float* gd_rest; float* ga_rest;
 };
 struct FinishArgs {
     float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
     const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
-    const float* edge_part; int edge_nb;
-    float reg_scale, nvalid_scale;
+    float reg_scale;
+    const float* nvalid_report; float nvalid_scale;
+    int split;
 };
-int mesh_tail_impl(const MeshTailArgs&, float*, float*, const FinishArgs&, hipStream_t);
+int mesh_tail_impl(const MeshTailArgs&, const FinishArgs&, hipStream_t);
 int mesh_tail_blocks(int V);
+int ham_combine_impl(float*, int, hipStream_t);
 // raster.hip / antialias.hip / mesh.hip / shade.hip
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 size_t raster_keys_bytes(int n, int H, int W);
@@ -41,15 +46,14 @@ int aa_fwd_rgba(const float*, const float*, float*, const float*, const float*, 
                 const float*, int, int*, float*, hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
                 const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int,
-                int, int, float*, const float*, float*, hipStream_t);
+                int, int, float*, const float*, float*, float*, hipStream_t);
 int clip_positions_impl(const float*, const float*, int, int, float*, hipStream_t);
 int geometry_impl(const float*, const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, const int32_t*,
                   const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, int*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
-struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; int skip_lists; };
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
-                  const int*, const int32_t*, const float*, const float*, const int*, const EdgeTerm&, int, int, int, int, int, float*,
+                  const int*, const int32_t*, const float*, const float*, const int*, int, int, int, int, int, float*,
                   const int2*, const int2*, const int*, const unsigned long long*, hipStream_t);
 int face_bwd_groups(int n);
 int face_bwd_blocks(int F);
@@ -57,7 +61,7 @@ int face_bwd_blocks(int F);
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
-        g_shaded, cmat, gvert_aa, part, partials, gnormal, gvert, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, seg_valid, cnt_part, edge_part, total;
+        g_shaded, cmat, gvert_aa, gvert_aa2, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -102,19 +106,21 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.g_shaded = take(off, nP * 16);
     L.cmat = take(off, (size_t)d->n * 64);
     L.gvert_aa = take(off, V * 12);
+    L.gvert_aa2 = take(off, V * 12);             // view-sharded step: the silhouette share of the antialias position gradient
     L.part = take(off, (size_t)face_bwd_groups(d->n) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
     L.partials = take(off, 2048 * 4 * 3);           // per-workgroup partial sums of the persistent pixel kernels
     L.gnormal = take(off, V * 12);
     L.gvert = take(off, V * 12);
+    L.gvert_r = take(off, V * 12);
     L.gtmp = take(off, V * 12);
     L.lx_v = take(off, V * 12);
     L.lx_a = take(off, V * 12);
     L.rowg = take(off, V * 12);
     L.tail_part = take(off, (size_t)mesh_tail_blocks(d->V) * 16);    // per-workgroup regulariser loss sums [4, blocks]
     L.n_valid_f = take(off, 16);                    // float copy of n_valid_local (a ready n_valid_global for the one-rank case)
+    L.one_third = take(off, 16);                    // the constant 1/3: the "valid-pixel count" that leaves the L1 divisor out (view-sharded step)
     L.seg_valid = take(off, ((nP + 63) / 64) * 4);   // valid-pixel count of every segment (resolve pass)
     L.cnt_part = take(off, (((nP + 63) / 64 + 1023) / 1024) * 4);   // the same per workgroup of k_active_segments
-    L.edge_part = take(off, (size_t)face_bwd_blocks(d->F) * 4);   // per-workgroup edge-hinge loss sums of k_face_bwd
     L.total = off;
     return L;
 }
@@ -188,6 +194,12 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, (hipStream_t)stream), "init aa_counter");
     // self-cleaning accumulator: k_mesh_tail_a zeroes each entry after consuming it
     HIPTRY(hipMemsetAsync(w + L.gvert_aa, 0, (size_t)d->V * 12, (hipStream_t)stream), "init gvert_aa");
+    HIPTRY(hipMemsetAsync(w + L.gvert_aa2, 0, (size_t)d->V * 12, (hipStream_t)stream), "init gvert_aa2");
+    {
+        const float third = 1.0f / 3.0f;           // 3 * (1/3) == 1 exactly in fp32: the kernels' divisor 3 * n_valid becomes 1
+        HIPTRY(hipMemcpyAsync(w + L.one_third, &third, 4, hipMemcpyHostToDevice, (hipStream_t)stream), "init one_third");
+        HIPTRY(hipStreamSynchronize((hipStream_t)stream), "init one_third sync");      // `third` lives on this stack frame
+    }
     // coverage entries are recognised by the step stamp: start with no entry valid, counter at 0
     HIPTRY(hipMemsetAsync(w + L.cov16, 0xFF, (size_t)d->n * d->F * 16, (hipStream_t)stream), "init cov16");
     HIPTRY(hipMemsetAsync(w + L.stamp, 0, 16, (hipStream_t)stream), "init stamp");
@@ -270,17 +282,20 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
 extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* wt, const float* vertices_tmp,
                                  const float* delta, const float* albedo, const float* sh, const float* w2c, const float* proj,
                                  const float* img, const float* mask, const float* valid_mask, const int32_t* tri,
-                                 const int32_t* opp, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* vf_ptr,
-                                 const int32_t* vf_idx, const int32_t* corner_slot,
+                                 const int32_t* opp, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* col_mult,
+                                 const int32_t* vf_ptr, const int32_t* vf_idx, const int32_t* corner_slot,
                                  const float* n_valid_global, float* losses, float* gdelta,
-                                 float* galbedo, void* ws, size_t ws_bytes, void* stream)
+                                 float* galbedo, float* gdelta_rest, float* galbedo_rest, void* ws, size_t ws_bytes, void* stream)
 {
     (void)vertices_tmp; (void)opp;
     TRY(check_dims(d));
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_backward: workspace too small (%zu < %zu)", ws_bytes, L.total);
-    FMHR_CHECK_ARG(wt && delta && albedo && sh && w2c && proj && img && mask && valid_mask && tri && row_ptr && col_idx &&
-                       vf_ptr && vf_idx && corner_slot && n_valid_global && losses && gdelta && galbedo, "ham_backward: null pointer");
+    FMHR_CHECK_ARG(wt && delta && albedo && sh && w2c && proj && img && mask && valid_mask && tri && row_ptr && col_idx && col_mult &&
+                       vf_ptr && vf_idx && corner_slot && losses && gdelta && galbedo, "ham_backward: null pointer");
+    FMHR_CHECK_ARG((gdelta_rest != nullptr) == (galbedo_rest != nullptr), "ham_backward: gdelta_rest and galbedo_rest go together");
+    const bool split = gdelta_rest != nullptr;         // view-sharded caller: photometric share apart, L1 divisor left out
+    FMHR_CHECK_ARG(split || n_valid_global != nullptr, "ham_backward: n_valid_global is null");
     FMHR_CHECK_ARG(wt->mse_denominator > 0.f, "ham_backward: mse_denominator must be > 0");
     FMHR_CHECK_ARG(wt->reg_v0 >= 0 && wt->reg_v0 <= wt->reg_v1 && wt->reg_v1 <= d->V, "ham_backward: bad regulariser vertex range [%d, %d)",
                    wt->reg_v0, wt->reg_v1);
@@ -288,6 +303,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     char* w = (char*)ws;
     float* vertices = (float*)(w + L.vertices);
     float* gvert_aa = (float*)(w + L.gvert_aa);
+    // the count the per-pixel kernels divide the L1 term by: the caller's batch-global one, or "1/3" (divisor 3 * n = 1) when split
+    const float* nv_div = split ? (const float*)(w + L.one_third) : n_valid_global;
     float* gvert = (float*)(w + L.gvert);
     size_t nP = (size_t)d->n * d->H * d->W;
     const float rg = wt->reg_grad_scale;
@@ -297,7 +314,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
         // losses on the antialiased rgba + their per-pixel gradients
         TRY(loss_pix_impl((const unsigned long long*)(w + L.covw), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
-                          (const int*)(w + L.act_list), (const int*)(w + L.act_count), n_valid_global,
+                          (const int*)(w + L.act_list), (const int*)(w + L.act_count), nv_div,
                           wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_shaded),
                           (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, losses, st));
     }
@@ -305,23 +322,17 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         // antialias backward: colour grads into g_shaded (atomics over the short queue), position grads (clip-transformed) into gvert_aa
         ProfScope ps(FMHR_SLOT_AA_BWD, st);
         TRY(aa_bwd_rgba((const float*)(w + L.aa_dcol), (const float*)(w + L.pix16), nullptr, (const float*)(w + L.vertices), tri, (const float*)(w + L.aa), img, mask, valid_mask,
-                        (const unsigned long long*)(w + L.covw), n_valid_global, wt->sfs, wt->mask, wt->mse_denominator,
+                        (const unsigned long long*)(w + L.covw), nv_div, wt->sfs, wt->mask, wt->mse_denominator,
                         (const int32_t*)(w + L.aa_items),
                         (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->V, d->H, d->W,
-                        (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, st));
+                        (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, split ? (float*)(w + L.gvert_aa2) : nullptr, st));
     }
     {
         // shade + interpolate + rasterize + clip-transform backward, face-parallel (shade.hip: k_face_bwd)
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
-        // the per-face edge hinge rides along: faces [f0, f1) = this rank's share of the view-independent terms
-        EdgeTerm et;
-        et.part = (float*)(w + L.edge_part);
-        et.f0 = (rg != 0.f) ? (int)((long long)wt->reg_v0 * d->F / d->V) : 0;
-        et.f1 = (rg != 0.f) ? (int)((long long)wt->reg_v1 * d->F / d->V) : 0;
-        et.mean = wt->edge_length_mean; et.w = wt->edge / (3.0f * (float)d->F); et.gk = 2.f * et.w * rg; et.skip_lists = 0;
         TRY(face_bwd_impl((const float*)(w + L.pix16), tri, nullptr, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
                           w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot,
-                          (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), et, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part),
+                          (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part),
                           (const int2*)(w + L.snap), (const int2*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W) + 16),
                           (const int*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W)), (const unsigned long long*)(w + L.covw), st));
     }
@@ -330,6 +341,9 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         ProfScope ps(FMHR_SLOT_REGULARISERS, st);
         MeshTailArgs A;
         A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n);
+        A.gvert_aa2 = split ? (float*)(w + L.gvert_aa2) : nullptr; A.col_mult = col_mult;
+        A.gacc_r = (float*)(w + L.gvert_r);
+        A.gdelta = gdelta; A.galbedo = galbedo; A.gd_rest = gdelta_rest; A.ga_rest = galbedo_rest;
         A.verts = vertices; A.delta = delta; A.albedo = albedo; A.nsum = (const float*)(w + L.nsum);
         A.tri = tri; A.vf_ptr = vf_ptr; A.vf_idx = vf_idx; A.row_ptr = row_ptr; A.col = col_idx;
         A.V = d->V; A.F = d->F;
@@ -340,13 +354,21 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         A.gacc_v = gvert; A.gacc_a = (float*)(w + L.lx_v); A.loss_part = (float*)(w + L.tail_part);
         // one extra workgroup of the second tail kernel turns the per-workgroup partials into the loss vector
         FinishArgs fin;
-        fin.losses = losses; fin.n_valid = n_valid_global; fin.part_l1 = (const float*)(w + L.partials) + nB;
+        fin.losses = losses; fin.n_valid = nv_div; fin.part_l1 = (const float*)(w + L.partials) + nB;
         fin.part_l2 = (const float*)(w + L.partials) + 2 * nB; fin.nb = (int)nB; fin.tail_part = (const float*)(w + L.tail_part);
         fin.tail_nb = mesh_tail_blocks(d->V); fin.w_sfs = wt->sfs; fin.w_mask = wt->mask; fin.mse_den = wt->mse_denominator;
-        fin.edge_part = (const float*)(w + L.edge_part); fin.edge_nb = face_bwd_blocks(d->F);
         fin.reg_scale = (rg != 0.f) ? 1.f : 0.f;
-        fin.nvalid_scale = (rg != 0.f && wt->reg_v0 == 0) ? 1.f : 0.f;
-        TRY(mesh_tail_impl(A, gdelta, galbedo, fin, st));
+        // the n_valid slot: one rank reports the count it was given; a view-sharded rank reports its LOCAL count (the slots are summed)
+        fin.split = split ? 1 : 0;
+        fin.nvalid_report = split ? (const float*)(w + L.n_valid_f) : n_valid_global;
+        fin.nvalid_scale = split ? 1.f : ((rg != 0.f && wt->reg_v0 == 0) ? 1.f : 0.f);
+        TRY(mesh_tail_impl(A, fin, st));
     }
     return FMHR_OK;
+}
+
+extern "C" int fmhr_ham_combine(int V, float* bucket, void* stream)
+{
+    FMHR_CHECK_ARG(V >= 1 && bucket != nullptr, "ham_combine: bad V or null bucket");
+    return ham_combine_impl(bucket, V, (hipStream_t)stream);
 }

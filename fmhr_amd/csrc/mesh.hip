@@ -374,13 +374,18 @@ __device__ __forceinline__ void normals_gather_body(int blk, const float* __rest
 // B (neighbour gathers): vertex-normal backward from gs, L^T r for both Laplacians -> final gdelta / galbedo.
 struct MeshTailArgs {
     const float4* part; float* gvert_aa; int G;                                       // face-backward corner sums [G, 3F] x 3 float4
+    float* gvert_aa2;                                                                 // split mode: the silhouette share of the antialias position gradient
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
+    const int32_t* col_mult;                                                          // faces per adjacency entry (fmhr_edge_multiplicity_build)
     int V, F;
     int v0, v1;                                                                       // vertex range of the view-independent terms
     float lap_w, alb_w, edge_w, delta_w, edge_mean, rg;                               // weights (already / V or / 3F where due)
-    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a;
+    float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a; float* gacc_r;
     float* loss_part;                                                                 // [4, gridDim.x] weighted per-block loss sums
+    // tail B outputs.  One rank: gdelta / galbedo = the whole gradient (gd_rest == null).  View-sharded (split): gdelta / galbedo =
+    // the PHOTOMETRIC share, computed with the L1 divisor left out; gd_rest / ga_rest = everything else (silhouette, regularisers)
+    float* gdelta; float* galbedo; float* gd_rest; float* ga_rest;
 };
 
 // Both kernels give a vertex kSub lanes: 49k vertices are < 1 wave per SIMD, so a lane-per-vertex launch leaves every dependent
@@ -417,27 +422,43 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
     int deg = 0;
     float3 xv = make_float3(0.f, 0.f, 0.f), xa = xv;
     const bool mine = live && v >= A.v0 && v < A.v1;                // this rank evaluates the regularisers of [v0, v1) only
+    // (5) the edge hinge (mesh_sfs_optim.py:296-302): mean over the 3F directed face edges of clip(|e|^2 - mean, 0, 1).  An edge {i, j}
+    //     appears once per face that holds it (col_mult, 1 on the boundary, 2 inside), so the sum over faces is a sum over the
+    //     adjacency with that multiplicity: this vertex owns the half-edges that leave it (half the loss of each edge) and the whole
+    //     gradient with respect to its own position, sum_j m_ij [0 < d < 1] 2 w (x_i - x_j) — evaluated in the neighbour walk the
+    //     Laplacians need anyway
+    float hg[3] = {0.f, 0.f, 0.f}, l_edge = 0.f;
     if (mine) {
         const int ra = A.row_ptr[vv], rb = A.row_ptr[vv + 1];
         deg = rb - ra;
         xv = ld3(A.verts + (size_t)vv * 3); xa = ld3(A.albedo + (size_t)vv * 3);
+        const float hk = 2.f * A.edge_w * A.rg;
         for (int j = ra + sub; j < rb; j += kSubLanes) {
             int i = A.col[j];
+            const float m = (float)A.col_mult[j];
             float3 yv = ld3(A.verts + (size_t)i * 3), ya = ld3(A.albedo + (size_t)i * 3);
-            lv[0] += yv.x - xv.x; lv[1] += yv.y - xv.y; lv[2] += yv.z - xv.z;
+            const float ex = xv.x - yv.x, ey = xv.y - yv.y, ez = xv.z - yv.z;
+            lv[0] -= ex; lv[1] -= ey; lv[2] -= ez;
             la[0] += ya.x - xa.x; la[1] += ya.y - xa.y; la[2] += ya.z - xa.z;
+            const float d = ex * ex + ey * ey + ez * ez - A.edge_mean;
+            l_edge += 0.5f * m * fminf(fmaxf(d, 0.f), 1.f);
+            if (d > 0.f && d < 1.f) { const float w = hk * m; hg[0] += w * ex; hg[1] += w * ey; hg[2] += w * ez; }
         }
     }
-    // (5) the edge hinge (mesh_sfs_optim.py:296-302) is a per-FACE term: the face-parallel backward, which holds every face's
-    //     three vertices anyway, adds its gradient to the corner sums and keeps the loss partials (shade.hip: k_face_bwd)
     n0 = sum_sub(n0); n1 = sum_sub(n1); n2 = sum_sub(n2); a0 = sum_sub(a0); a1 = sum_sub(a1); a2 = sum_sub(a2);
     gx = sum_sub(gx); gy = sum_sub(gy); gz = sum_sub(gz);
 #pragma unroll
-    for (int c = 0; c < 3; c++) { lv[c] = sum_sub(lv[c]); la[c] = sum_sub(la[c]); }
+    for (int c = 0; c < 3; c++) { lv[c] = sum_sub(lv[c]); la[c] = sum_sub(la[c]); hg[c] = sum_sub(hg[c]); }
     if (live && sub == 0) {
         float* ga = A.gvert_aa + (size_t)v * 3;           // antialias-backward atomics; consumed and re-zeroed for the next step
         gx += ga[0]; gy += ga[1]; gz += ga[2];
         ga[0] = 0.f; ga[1] = 0.f; ga[2] = 0.f;
+        float rx = hg[0], ry = hg[1], rz = hg[2];         // everything that is NOT the photometric term: hinge, delta, silhouette share
+        if (A.gvert_aa2 != nullptr) {
+            float* g2 = A.gvert_aa2 + (size_t)v * 3;
+            rx += g2[0]; ry += g2[1]; rz += g2[2];
+            g2[0] = 0.f; g2[1] = 0.f; g2[2] = 0.f;
+        }
         // (2) d/d nsum of the normalised vertex normal (models/utils.py:545, eps 1e-6)
         {
             float3 s = ld3(A.nsum + (size_t)v * 3);
@@ -474,16 +495,17 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
             float3 d = ld3(A.delta + (size_t)v * 3);
             l_delta = d.x * d.x + d.y * d.y + d.z * d.z;
             float k = 2.f * A.delta_w * A.rg;
-            gx += k * d.x; gy += k * d.y; gz += k * d.z;
+            rx += k * d.x; ry += k * d.y; rz += k * d.z;
         }
         A.gacc_v[(size_t)v * 3] = gx; A.gacc_v[(size_t)v * 3 + 1] = gy; A.gacc_v[(size_t)v * 3 + 2] = gz;
+        A.gacc_r[(size_t)v * 3] = rx; A.gacc_r[(size_t)v * 3 + 1] = ry; A.gacc_r[(size_t)v * 3 + 2] = rz;
         A.gacc_a[(size_t)v * 3] = a0; A.gacc_a[(size_t)v * 3 + 1] = a1; A.gacc_a[(size_t)v * 3 + 2] = a2;
     }
     // per-block partials (k_finish_losses adds them up): 4 x 1.5k same-address atomics would serialise for ~60 us
     float s;
     s = block_sum(l_lap, sm);   if (threadIdx.x == 0) A.loss_part[blockIdx.x] = s * A.lap_w;
     s = block_sum(l_alb, sm);   if (threadIdx.x == 0) A.loss_part[gridDim.x + blockIdx.x] = s * A.alb_w;
-    if (threadIdx.x == 0) A.loss_part[2 * gridDim.x + blockIdx.x] = 0.f;      // slot kept for layout; the edge term lives in edge_part
+    s = block_sum(l_edge, sm);  if (threadIdx.x == 0) A.loss_part[2 * gridDim.x + blockIdx.x] = s * A.edge_w;
     s = block_sum(l_delta, sm); if (threadIdx.x == 0) A.loss_part[3 * gridDim.x + blockIdx.x] = s * A.delta_w;
 }
 
@@ -492,9 +514,10 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
 struct FinishArgs {
     float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
     const float* tail_part; int tail_nb; float w_sfs, w_mask, mse_den;
-    const float* edge_part; int edge_nb;      // weighted per-workgroup edge-hinge sums of k_face_bwd
     float reg_scale;      // 0 switches the view-independent loss slots off (reg_grad_scale = 0)
-    float nvalid_scale;   // 1 on the one rank that reports n_valid: summing the loss vectors of all ranks gives the global values
+    const float* nvalid_report; float nvalid_scale;   // the count this rank reports in the n_valid slot (x scale): the loss vectors of
+                                                      // all ranks must SUM to the global values
+    int split;            // view-sharded: the photometric slot holds w_sfs * sum |d| with the L1 divisor left out (fmhr_ham_combine)
 };
 
 __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* sm4)
@@ -506,11 +529,6 @@ __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* 
         for (int j = threadIdx.x; j < A.tail_nb; j += kBlock) t += A.tail_part[(size_t)k * A.tail_nb + j];
         r[k] = block_sum(t, sm4);
     }
-    {
-        float t = 0.f;
-        for (int j = threadIdx.x; j < A.edge_nb; j += kBlock) t += A.edge_part[j];
-        r[2] = block_sum(t, sm4);
-    }
     float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
     int i = threadIdx.x;
     for (; i + kBlock < A.nb; i += 2 * kBlock) { a1 += A.part_l1[i]; a2 += A.part_l2[i]; b1 += A.part_l1[i + kBlock]; b2 += A.part_l2[i + kBlock]; }
@@ -519,37 +537,35 @@ __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* 
     float s2 = block_sum(a2 + b2, sm4);
     if (threadIdx.x == 0) {
         float* losses = A.losses;
-        float den = 3.0f * A.n_valid[0];
+        float den = A.split ? 1.0f : 3.0f * A.n_valid[0];
         losses[FMHR_LOSS_SFS] = (den > 0.f) ? s1 * (A.w_sfs / den) : 0.f;
         losses[FMHR_LOSS_MASK] = s2 * (A.w_mask / A.mse_den);
         losses[FMHR_LOSS_LAP] = r[0] * A.reg_scale; losses[FMHR_LOSS_ALBEDO] = r[1] * A.reg_scale;
         losses[FMHR_LOSS_EDGE] = r[2] * A.reg_scale; losses[FMHR_LOSS_DELTA] = r[3] * A.reg_scale;
         losses[FMHR_LOSS_TOTAL] = losses[FMHR_LOSS_SFS] + losses[FMHR_LOSS_LAP] + losses[FMHR_LOSS_ALBEDO] +
                                   losses[FMHR_LOSS_MASK] + losses[FMHR_LOSS_DELTA] + losses[FMHR_LOSS_EDGE];
-        losses[FMHR_LOSS_NVALID] = A.n_valid[0] * A.nvalid_scale;
+        losses[FMHR_LOSS_NVALID] = A.nvalid_report[0] * A.nvalid_scale;
     }
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_mesh_tail_b(const float* __restrict__ verts, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
-              const int32_t* __restrict__ vf_idx, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-              const float* __restrict__ gs, const float* __restrict__ rowg_v, const float* __restrict__ rowg_a,
-              const float* __restrict__ gacc_v, const float* __restrict__ gacc_a, int V, float* __restrict__ gdelta,
-              float* __restrict__ galbedo, const FinishArgs fin)
+__global__ void __launch_bounds__(kBlock) k_mesh_tail_b(const MeshTailArgs A, const FinishArgs fin)
 {
     if (blockIdx.x == gridDim.x - 1) {
         __shared__ float sm4[4];
         finish_losses_block(fin, sm4);
         return;
     }
+    const float* __restrict__ verts = A.verts;
+    const int32_t* __restrict__ tri = A.tri;
+    const float* __restrict__ gs = A.gs;
     const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
-    const bool live = v < V;
+    const bool live = v < A.V;
     const int vv = live ? v : 0;
-    float3 acc = make_float3(0.f, 0.f, 0.f), aca = acc;
+    float3 acc = make_float3(0.f, 0.f, 0.f), acl = acc, aca = acc;   // normal backward (photometric) | L^T r vertices | L^T r albedo
     if (live) {
         // vertex-normal backward: this vertex's share of d(sum_k gs[i_k] . cross_k)/d verts over its incident faces
-        for (int e = vf_ptr[vv] + sub; e < vf_ptr[vv + 1]; e += kSubLanes) {
-            int code = vf_idx[e];
+        for (int e = A.vf_ptr[vv] + sub; e < A.vf_ptr[vv + 1]; e += kSubLanes) {
+            int code = A.vf_idx[e];
             int f = code / 3, c = code - f * 3;
             int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
             float3 p[3] = {ld3(verts + (size_t)i[0] * 3), ld3(verts + (size_t)i[1] * 3), ld3(verts + (size_t)i[2] * 3)};
@@ -565,33 +581,86 @@ k_mesh_tail_b(const float* __restrict__ verts, const int32_t* __restrict__ tri, 
             }
         }
         // L^T r for both Laplacians (the adjacency is symmetric): sum_{i in N(v)} r_i / deg_i - r_v
-        for (int e = row_ptr[vv] + sub; e < row_ptr[vv + 1]; e += kSubLanes) {
-            int i = col[e];
-            float inv = 1.0f / (float)(row_ptr[i + 1] - row_ptr[i]);
-            float3 qv = ld3(rowg_v + (size_t)i * 3), qa = ld3(rowg_a + (size_t)i * 3);
-            acc.x += qv.x * inv; acc.y += qv.y * inv; acc.z += qv.z * inv;
+        for (int e = A.row_ptr[vv] + sub; e < A.row_ptr[vv + 1]; e += kSubLanes) {
+            int i = A.col[e];
+            float inv = 1.0f / (float)(A.row_ptr[i + 1] - A.row_ptr[i]);
+            float3 qv = ld3(A.rowg_v + (size_t)i * 3), qa = ld3(A.rowg_a + (size_t)i * 3);
+            acl.x += qv.x * inv; acl.y += qv.y * inv; acl.z += qv.z * inv;
             aca.x += qa.x * inv; aca.y += qa.y * inv; aca.z += qa.z * inv;
         }
     }
     acc.x = sum_sub(acc.x); acc.y = sum_sub(acc.y); acc.z = sum_sub(acc.z);
+    acl.x = sum_sub(acl.x); acl.y = sum_sub(acl.y); acl.z = sum_sub(acl.z);
     aca.x = sum_sub(aca.x); aca.y = sum_sub(aca.y); aca.z = sum_sub(aca.z);
     if (live && sub == 0) {
-        float3 g0 = ld3(gacc_v + (size_t)v * 3), h0 = ld3(gacc_a + (size_t)v * 3);
-        float3 rv = ld3(rowg_v + (size_t)v * 3), ra = ld3(rowg_a + (size_t)v * 3);
-        gdelta[(size_t)v * 3] = g0.x + acc.x - rv.x; gdelta[(size_t)v * 3 + 1] = g0.y + acc.y - rv.y; gdelta[(size_t)v * 3 + 2] = g0.z + acc.z - rv.z;
-        galbedo[(size_t)v * 3] = h0.x + aca.x - ra.x; galbedo[(size_t)v * 3 + 1] = h0.y + aca.y - ra.y; galbedo[(size_t)v * 3 + 2] = h0.z + aca.z - ra.z;
+        const float3 g0 = ld3(A.gacc_v + (size_t)v * 3), r0 = ld3(A.gacc_r + (size_t)v * 3), h0 = ld3(A.gacc_a + (size_t)v * 3);
+        const float3 rv = ld3(A.rowg_v + (size_t)v * 3), ra = ld3(A.rowg_a + (size_t)v * 3);
+        // photometric share (with the batch-global L1 divisor already in it on one rank, left out when view-sharded) | the rest
+        const float pd[3] = {g0.x + acc.x, g0.y + acc.y, g0.z + acc.z}, rd[3] = {r0.x + acl.x - rv.x, r0.y + acl.y - rv.y, r0.z + acl.z - rv.z};
+        const float pa[3] = {h0.x, h0.y, h0.z}, rr[3] = {aca.x - ra.x, aca.y - ra.y, aca.z - ra.z};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (A.gd_rest != nullptr) {
+                A.gdelta[(size_t)v * 3 + c] = pd[c]; A.galbedo[(size_t)v * 3 + c] = pa[c];
+                A.gd_rest[(size_t)v * 3 + c] = rd[c]; A.ga_rest[(size_t)v * 3 + c] = rr[c];
+            } else {
+                A.gdelta[(size_t)v * 3 + c] = pd[c] + rd[c]; A.galbedo[(size_t)v * 3 + c] = pa[c] + rr[c];
+            }
+        }
     }
+}
+
+// After the ONE all-reduce of a view-sharded step: bucket = [P_delta | P_albedo | R_delta | R_albedo | 8 loss slots], summed over
+// the ranks.  g = P / (3 * n_valid_global) + R (mesh_sfs_optim.py:289: F.l1_loss averages over the batch-global 3 * Pv), written
+// over P; the photometric loss slot gets the same divisor and the total is formed.  n_valid == 0: the photometric term is 0.
+__global__ void __launch_bounds__(kBlock) k_ham_combine(float* __restrict__ bucket, long long n3)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    float* losses = bucket + 4 * n3;
+    const float nv = losses[FMHR_LOSS_NVALID];
+    const float sc = (nv > 0.f) ? 1.0f / (3.0f * nv) : 0.f;
+    if (i < 2 * n3) bucket[i] = bucket[i] * sc + bucket[2 * n3 + i];
+    if (i == 2 * n3) {                      // one thread beyond the gradient range finishes the loss vector
+        const float sfs = losses[FMHR_LOSS_SFS] * sc;
+        losses[FMHR_LOSS_SFS] = sfs;
+        losses[FMHR_LOSS_TOTAL] = sfs + losses[FMHR_LOSS_LAP] + losses[FMHR_LOSS_ALBEDO] + losses[FMHR_LOSS_MASK] + losses[FMHR_LOSS_DELTA] +
+                                  losses[FMHR_LOSS_EDGE];
+    }
+}
+
+int ham_combine_impl(float* bucket, int V, hipStream_t st)
+{
+    const long long n3 = 3ll * V;
+    k_ham_combine<<<cdiv(2 * n3 + 1, kBlock), kBlock, 0, st>>>(bucket, n3);
+    FMHR_CHECK_LAUNCH("k_ham_combine");
+    return FMHR_OK;
+}
+
+// faces per adjacency entry: one lane per face corner k adds 1 to the entries (a -> b) and (b -> a) of its edge (a, b) = (tri[k+1],
+// tri[k+2]); rows are sorted and short (valence ~6): linear search
+__global__ void __launch_bounds__(kBlock)
+k_edge_multiplicity(const int32_t* __restrict__ tri, int F, int V, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                    int32_t* __restrict__ mult)
+{
+    const int code = blockIdx.x * kBlock + threadIdx.x;
+    if (code >= 3 * F) return;
+    const int f = code / 3, k = code - f * 3;
+    const int a = tri[f * 3 + (k + 1) % 3], b = tri[f * 3 + (k + 2) % 3];
+    if ((unsigned)a >= (unsigned)V || (unsigned)b >= (unsigned)V || a == b) return;
+    for (int e = row_ptr[a]; e < row_ptr[a + 1]; e++)
+        if (col[e] == b) { atomicAdd(mult + e, 1); break; }
+    for (int e = row_ptr[b]; e < row_ptr[b + 1]; e++)
+        if (col[e] == a) { atomicAdd(mult + e, 1); break; }
 }
 
 int mesh_tail_blocks(int V) { return cdiv((long long)V * kSubLanes, kBlock); }
 
-int mesh_tail_impl(const MeshTailArgs& A, float* gdelta, float* galbedo, const FinishArgs& fin, hipStream_t st)
+int mesh_tail_impl(const MeshTailArgs& A, const FinishArgs& fin, hipStream_t st)
 {
     if (A.V == 0) return FMHR_OK;
     k_mesh_tail_a<<<cdiv((long long)A.V * kSubLanes, kBlock), kBlock, 0, st>>>(A);
     FMHR_CHECK_LAUNCH("k_mesh_tail_a");
-    k_mesh_tail_b<<<cdiv((long long)A.V * kSubLanes, kBlock) + 1, kBlock, 0, st>>>(A.verts, A.tri, A.vf_ptr, A.vf_idx, A.row_ptr, A.col, A.gs, A.rowg_v, A.rowg_a,
-                                                       A.gacc_v, A.gacc_a, A.V, gdelta, galbedo, fin);
+    k_mesh_tail_b<<<cdiv((long long)A.V * kSubLanes, kBlock) + 1, kBlock, 0, st>>>(A, fin);
     FMHR_CHECK_LAUNCH("k_mesh_tail_b");
     return FMHR_OK;
 }
@@ -752,6 +821,19 @@ extern "C" int fmhr_adam_step2(float* param_a, const float* grad_a, float* exp_a
     if (n_a + n_b == 0) return FMHR_OK;
     k_adam2<<<cdiv(n_a + n_b, kBlock), kBlock, 0, (hipStream_t)stream>>>(A, B);
     FMHR_CHECK_LAUNCH("k_adam2");
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_edge_multiplicity_build(const int32_t* tri, int F, int V, const int32_t* row_ptr, const int32_t* col_idx, int nnz,
+                                            int32_t* col_mult, void* stream)
+{
+    FMHR_CHECK_ARG(F >= 0 && V >= 0 && nnz >= 0, "edge_multiplicity_build: bad dims");
+    if (nnz == 0 || F == 0) return FMHR_OK;
+    FMHR_CHECK_ARG(tri && row_ptr && col_idx && col_mult, "edge_multiplicity_build: null pointer");
+    hipError_t e = hipMemsetAsync(col_mult, 0, (size_t)nnz * 4, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "memset col_mult");
+    k_edge_multiplicity<<<cdiv(3ll * F, kBlock), kBlock, 0, (hipStream_t)stream>>>(tri, F, V, row_ptr, col_idx, col_mult);
+    FMHR_CHECK_LAUNCH("k_edge_multiplicity");
     return FMHR_OK;
 }
 

@@ -216,8 +216,6 @@ __device__ __forceinline__ float group_sum(float x)
 
 struct int3a { int x, y, z; };
 
-// the edge-hinge regulariser rides in the face-parallel backward: faces [f0, f1), weight / (3F), 2 * weight / (3F) * grad scale
-struct EdgeTerm { float* part; int f0, f1; float mean, w, gk; int skip_lists; };   // skip_lists: large-box faces have their own kernel
 struct FaceAttr { float3 n2, dn0, dn1, a2, da0, da1, v0, v1, v2; };    // corner-2-relative attributes + the three vertex positions
 
 // backward of ONE pixel of a face for all three corners; A[k] += (g_normal.xyz, g_albedo.xyz, g_vertex.xyz) of corner k.
@@ -301,7 +299,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
            const int4* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
            const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
-           int H, int W, float4* __restrict__ part, const EdgeTerm et)
+           int H, int W, float4* __restrict__ part, const int skip_lists)       // skip_lists: queued large-box faces have their own kernel
 {
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
     constexpr int GV = kGroup * VPL;                               // views per group
@@ -371,28 +369,6 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
 #pragma unroll
         for (int c = 0; c < 9; c++) A[k][c] = 0.f;
     const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
-    // ---- edge hinge of this face (mesh_sfs_optim.py:296-302): a per-face regulariser, evaluated here because the face's
-    //      vertices are at hand and its corner sums are being formed anyway (first lane of the first view group only)
-    float l_edge = 0.f;
-    if (et.part != nullptr && j == 0 && g == 0 && facelive && f >= et.f0 && f < et.f1) {
-        const float3 a = ld3f(verts + (size_t)ti.x * 3), b = ld3f(verts + (size_t)ti.y * 3), c = ld3f(verts + (size_t)ti.z * 3);
-        const float3 ed[3] = {make_float3(a.x - b.x, a.y - b.y, a.z - b.z), make_float3(c.x - b.x, c.y - b.y, c.z - b.z),
-                              make_float3(a.x - c.x, a.y - c.y, a.z - c.z)};
-        const float sgn[3][3] = {{1.f, 0.f, 1.f}, {-1.f, -1.f, 0.f}, {0.f, 1.f, -1.f}};    // d edge_k / d corner
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float l2 = ed[k].x * ed[k].x + ed[k].y * ed[k].y + ed[k].z * ed[k].z;
-            const float d = l2 - et.mean;
-            l_edge += fminf(fmaxf(d, 0.f), 1.f);
-            if (d > 0.f && d < 1.f) {
-#pragma unroll
-                for (int cn = 0; cn < 3; cn++) {
-                    const float w = et.gk * sgn[cn][k];
-                    A[cn][6] += w * ed[k].x; A[cn][7] += w * ed[k].y; A[cn][8] += w * ed[k].z;
-                }
-            }
-        }
-    }
     if (anyk != 0ull) {                                            // wave-uniform
         // ---- one memory round trip for the face's attributes (lane 0 of the group) AND the first candidate pixel of every lane:
         //      the attribute loads are issued first, the candidate masks (already here) are expanded into the task list, each lane
@@ -504,7 +480,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         // ---- large-box triangles: the owning lane walks the pixel list (head in the entry, links in the owner field)
 #pragma unroll
         for (int v = 0; v < VPL; v++) {
-            if (kind[v] != 255 || et.skip_lists) continue;
+            if (kind[v] != 255 || skip_lists) continue;
             const int vs = v * kGroup + j;
             int p = e[v].x;
             while (p >= 0) {
@@ -534,11 +510,6 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         dst[0] = make_float4(o[0], o[1], o[2], o[3]);
         dst[1] = make_float4(o[4], o[5], o[6], o[7]);
         dst[2] = make_float4(o[8], 0.f, 0.f, 0.f);
-    }
-    if (et.part != nullptr && g == 0) {                            // weighted edge-hinge loss of the workgroup's faces
-        __shared__ float sm4[4];
-        const float s = block_sum(l_edge, sm4);
-        if (tid == 0) et.part[blockIdx.x] = s * et.w;
     }
 }
 
@@ -682,17 +653,16 @@ int face_bwd_blocks(int F) { return cdiv(F, kBlock / kGroup); }
 
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
                   const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
-                  const float* verts, const int* llink, const EdgeTerm& et_in, int n, int V, int F, int H, int W, float* part,
+                  const float* verts, const int* llink, int n, int V, int F, int H, int W, float* part,
                   const int2* snap, const int2* large_q, const int* large_cnt, const unsigned long long* covw, hipStream_t st)
 {
     if (n == 0 || F == 0) return FMHR_OK;
     const dim3 grid(cdiv(F, kFacesPerBlock), face_bwd_groups(n));
-    EdgeTerm et = et_in;
-    et.skip_lists = raster_use_queue(H, W, F) ? 1 : 0;             // coarse mesh: the queued large-box faces get their own kernel
+    const int skip_lists = raster_use_queue(H, W, F) ? 1 : 0;      // coarse mesh: the queued large-box faces get their own kernel
 #define FMHR_FACE_BWD(VPL)                                                                                                          \
     k_face_bwd<VPL><<<grid, kBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
                                              (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
-                                             (float4*)part, et)
+                                             (float4*)part, skip_lists)
     switch (face_bwd_vpl(n)) {
         case 1: FMHR_FACE_BWD(1); break;
         case 2: FMHR_FACE_BWD(2); break;
@@ -703,7 +673,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     }
 #undef FMHR_FACE_BWD
     FMHR_CHECK_LAUNCH("k_face_bwd");
-    if (et.skip_lists) {
+    if (skip_lists) {
         k_face_bwd_large<<<2048, kBlock, 0, st>>>((const float4*)bwd16, tri, snap, (const float4*)attr8, sh, (const float4*)g_shaded, corner_slot,
                                                   (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, kGroup * face_bwd_vpl(n), part);
         FMHR_CHECK_LAUNCH("k_face_bwd_large");

@@ -2,11 +2,15 @@
 on ROCm) — SURVEY.md §8e.  The reference has no multi-GPU code; this is the build's data-parallel axis:
 
 * the n views of a step are split contiguously over G ranks; every rank holds the whole mesh;
-* exchange 1: all-reduce(SUM) of the valid-pixel count (F.l1_loss divides by the batch-global 3*Pv, mesh_sfs_optim.py:289);
-* exchange 2: ONE all-reduce(SUM) per step, in place on HamStage2's bucket [gdelta | galbedo | 8 loss slots] = 6V+8 fp32
-  (1.18 MB at V = 49k: latency-bound on xGMI).  Every entry is the rank's share: the view terms of its views and the
-  view-independent terms (regularisers) of its VERTEX range — shard_views(V, rank, world) — so nothing is fixed up afterwards
-  and the regulariser work is split over the ranks too.
+* ONE all-reduce(SUM) per step and nothing else.  F.l1_loss divides by the batch-GLOBAL 3*Pv (mesh_sfs_optim.py:289), which a
+  rank only knows after an exchange; instead of exchanging the count between forward and backward (a second, blocking
+  collective in the middle of a ~0.15 ms step) every rank back-propagates the photometric term with the divisor LEFT OUT and
+  keeps that share of the gradient apart from the rest (the photometric gradient only flows through the rgb channels, the
+  silhouette MSE only through alpha, so the split is free): bucket = [P_delta | P_albedo | R_delta | R_albedo | 8 loss slots] =
+  12V+8 fp32 (2.35 MB at V = 49k: latency-bound on xGMI).  After the all-reduce, g = P / (3 * n_valid_global) + R
+  (fmhr_ham_combine), n_valid_global being the summed count slot.  Every entry is the rank's share: the view terms of its
+  views and the view-independent terms (regularisers) of its VERTEX range — shard_views(V, rank, world) — so the regulariser
+  work is split over the ranks too.
 """
 import os
 
@@ -42,38 +46,41 @@ def shard_views(n_views, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def combine_bucket(bucket, V):
+    """The arithmetic of fmhr_ham_combine on any device (the GPU step uses the kernel; this is the host-side statement the CPU
+    rehearsal checks): bucket = [P_delta | P_albedo | R_delta | R_albedo | 8 loss slots] summed over the ranks."""
+    n3 = 3 * V
+    losses = bucket[4 * n3:]
+    nv = float(losses[7])
+    sc = 1.0 / (3.0 * nv) if nv > 0 else 0.0
+    g = bucket[: 2 * n3] * sc + bucket[2 * n3: 4 * n3]
+    losses = losses.clone()
+    losses[0] = losses[0] * sc
+    losses[6] = losses[0] + losses[1] + losses[2] + losses[3] + losses[4] + losses[5]
+    return losses, g[:n3].view(V, 3), g[n3:].view(V, 3)
+
+
 class ShardedStep:
-    """Wraps a per-rank step function `local_step(n_valid_reduce, reg_grads) -> (losses[8], gdelta[V,3], galbedo[V,3])`
-    and performs the gradient exchange.  `local_step` must call `n_valid_reduce(t)` on its valid-pixel count tensor between
-    its forward and backward phases (HamStage2.step does, via `group`)."""
+    """The single-collective exchange on plain tensors (any device): pack the rank's shares, all-reduce once, combine.
+    HamStage2.step(group=...) does the same in place on its own bucket with the combine kernel; this class is the host-side
+    reference of the protocol (tests/test_dist_gloo.py runs it over gloo with the CPU oracle as the compute)."""
 
     def __init__(self, V, device, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        # one packed bucket: [gdelta | galbedo | 8 loss slots]
-        self.bucket = torch.zeros(2 * V * 3 + 8, dtype=torch.float32, device=device)
+        self.bucket = torch.zeros(12 * V + 8, dtype=torch.float32, device=device)
         self.V = V
 
-    def reduce(self, losses, gdelta, galbedo):
-        """ONE all-reduce(SUM) of [gdelta | galbedo | losses].  Contract: every entry is this rank's SHARE — view terms are
-        partial sums over the rank's views, the view-independent terms (regulariser gradients and losses, the n_valid slot) come
-        from one rank only (HamStage2.step(reg_grads=rank == 0)) — so the sum is the global result and nothing is fixed up
-        afterwards.  When the three tensors already are HamStage2's contiguous bucket the collective runs in place on it (no
-        pack / unpack kernels: at 6 views per GPU a step is ~0.16 ms, a dozen tiny kernels would be a third of it)."""
-        V = self.V
-        es = gdelta.element_size()
-        in_place = (gdelta.is_contiguous() and galbedo.is_contiguous() and losses.is_contiguous() and
-                    galbedo.data_ptr() == gdelta.data_ptr() + 3 * V * es and losses.data_ptr() == galbedo.data_ptr() + 3 * V * es and
-                    gdelta._base is not None and gdelta._base is galbedo._base and gdelta._base is losses._base and
-                    gdelta._base.numel() == 6 * V + 8 and gdelta._base.data_ptr() == gdelta.data_ptr())
-        if in_place:
-            b = gdelta._base
-        else:
-            b = self.bucket
-            b[: V * 3].copy_(gdelta.reshape(-1))
-            b[V * 3: 2 * V * 3].copy_(galbedo.reshape(-1))
-            b[2 * V * 3:].copy_(losses)
+    def reduce(self, losses, p_delta, p_albedo, r_delta, r_albedo):
+        """losses[8]: this rank's share of every slot — slot 0 = w_sfs * sum |d| over its valid pixels (no divisor), slot 7 = its LOCAL
+        valid-pixel count; p_* = photometric gradient share without the divisor, r_* = everything else.  Returns the batch-global
+        (losses, gdelta, galbedo)."""
+        V, b = self.V, self.bucket
+        n3 = 3 * V
+        for k, t in enumerate((p_delta, p_albedo, r_delta, r_albedo)):
+            b[k * n3: (k + 1) * n3].copy_(t.reshape(-1))
+        b[4 * n3:].copy_(losses)
         if self.world > 1:
             dist.all_reduce(b, group=self.group)
-        return b[2 * V * 3:], b[: V * 3].view(V, 3), b[V * 3: 2 * V * 3].view(V, 3)
+        return combine_bucket(b, V)

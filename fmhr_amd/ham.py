@@ -1,8 +1,9 @@
 """fmhr_amd.ham — the fused stage-2 HAM iteration (render + six losses + backward) and the optimisation loop.
 
 Replaces the loop body of /root/reference/mesh_sfs_optim.py:253-310.  One `HamStage2.step()` issues two C-ABI calls
-(fmhr_ham_forward / fmhr_ham_backward, include/fmhr_ham.h) on the current stream; the only thing in between is the
-valid-pixel count hand-over (an all-reduce when views are sharded over ranks).
+(fmhr_ham_forward / fmhr_ham_backward, include/fmhr_ham.h) on the current stream.  With the views sharded over ranks (SURVEY.md
+§8e) the step has exactly ONE collective: the backward keeps the photometric share of the gradient apart with the batch-global
+L1 divisor left out, the bucket [P | R | losses] is all-reduced once and fmhr_ham_combine applies P / (3 * n_valid_global) + R.
 """
 import ctypes
 
@@ -48,6 +49,10 @@ class HamStage2:
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.dev)
         call("fmhr_adjacency_build", ptr(self.faces), self.F, self.V, ptr(self.row_ptr), ptr(self.col_idx), ptr(ws), nb, st)
         self.nnz = int(self.row_ptr[-1])
+        # faces per adjacency entry: the edge-length hinge (a mean over FACE edges) rides in the Laplacians' neighbour walk
+        self.col_mult = torch.zeros(max(self.nnz, 1), dtype=torch.int32, device=self.dev)
+        call("fmhr_edge_multiplicity_build", ptr(self.faces), self.F, self.V, ptr(self.row_ptr), ptr(self.col_idx), self.nnz,
+             ptr(self.col_mult), st)
         self.vf_ptr = torch.zeros(self.V + 1, dtype=torch.int32, device=self.dev)
         self.vf_idx = torch.zeros(3 * self.F, dtype=torch.int32, device=self.dev)
         nb = self.lib.fmhr_vertex_faces_workspace_bytes(self.V)
@@ -67,11 +72,15 @@ class HamStage2:
         # fmhr_ham_forward also leaves float(n_valid_local) in the workspace: it IS n_valid_global on one rank, and the
         # all-reduce target (in place) when the views are sharded
         self.n_valid_global = self.raw("n_valid_f", torch.float32, 1)
-        # one contiguous bucket [gdelta | galbedo | losses]: a sharded caller all-reduces it in place (fmhr_amd.dist.ShardedStep)
-        self.bucket = torch.zeros(6 * self.V + 8, dtype=torch.float32, device=self.dev)
-        self.gdelta = self.bucket[: 3 * self.V].view(self.V, 3)
-        self.galbedo = self.bucket[3 * self.V: 6 * self.V].view(self.V, 3)
-        self.losses = self.bucket[6 * self.V:]
+        # one contiguous bucket [gdelta | galbedo | gdelta_rest | galbedo_rest | losses]: one rank uses the first two and the loss
+        # slots; a view-sharded step fills all of it (photometric share | the rest), all-reduces it in place ONCE and combines
+        self.bucket = torch.zeros(12 * self.V + 8, dtype=torch.float32, device=self.dev)
+        V3 = 3 * self.V
+        self.gdelta = self.bucket[:V3].view(self.V, 3)
+        self.galbedo = self.bucket[V3: 2 * V3].view(self.V, 3)
+        self.gdelta_rest = self.bucket[2 * V3: 3 * V3].view(self.V, 3)
+        self.galbedo_rest = self.bucket[3 * V3: 4 * V3].view(self.V, 3)
+        self.losses = self.bucket[4 * V3:]
         self._views = None
         self._aa_flag = None
         self._vm_key, self._vm_ref = None, None
@@ -87,28 +96,39 @@ class HamStage2:
              ptr(proj), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp), ptr(self.vf_ptr), ptr(self.vf_idx),
              changed, ptr(self.n_valid_local), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
 
-    def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True, reg_range=None):
+    def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True, reg_range=None, split=False):
+        """split=True: the view-sharded form — gdelta / galbedo get the photometric share without the L1 divisor, gdelta_rest /
+        galbedo_rest the rest (include/fmhr_ham.h); the caller all-reduces self.bucket and calls combine()."""
         w = self.weights
         v0, v1 = (0, self.V) if reg_range is None else reg_range
         wt = HamWeights(w["sfs"], w["lap"], w["albedo"], w["mask"], w["edge"], w["delta"], self.edge_len_mean,
                         float(self.n_global * self.H * self.W), 1.0 if reg_grads else 0.0, int(v0), int(v1))
         call("fmhr_ham_backward", ctypes.byref(self.dims), ctypes.byref(wt), ptr(vertices_tmp), ptr(delta), ptr(albedo),
              ptr(sh), ptr(w2c), ptr(proj), ptr(img), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp),
-             ptr(self.row_ptr), ptr(self.col_idx), ptr(self.vf_ptr), ptr(self.vf_idx), ptr(self.corner_slot),
+             ptr(self.row_ptr), ptr(self.col_idx), ptr(self.col_mult), ptr(self.vf_ptr), ptr(self.vf_idx), ptr(self.corner_slot),
              ptr(self.n_valid_global),
              ptr(self.losses), ptr(self.gdelta),
-             ptr(self.galbedo), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
+             ptr(self.galbedo), ptr(self.gdelta_rest if split else None), ptr(self.galbedo_rest if split else None),
+             ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
+
+    def combine(self):
+        """after the all-reduce of self.bucket (view-sharded step): g = P / (3 n_valid_global) + R in place, loss vector finished."""
+        call("fmhr_ham_combine", self.V, ptr(self.bucket), stream_ptr(self.dev))
 
     def step(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group=None, reg_grads=True, reg_range=None):
         """Full forward + backward.  Returns (losses[8] device tensor, gdelta [V,3], galbedo [V,3]) — buffers owned by this
-        object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded.
+        object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded: the results
+        are then the batch-global ones (summed over the ranks), identical on every rank.
         `reg_range` = (v0, v1): evaluate the view-independent terms for these vertices only (ranks take disjoint ranges covering
         [0, V): fmhr_amd.dist.shard_views(V, rank, world)); `reg_grads=False` switches them off on this rank."""
         self._check(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask)
         self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask)
+        self.backward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=reg_grads, reg_range=reg_range,
+                      split=group is not None)
         if group is not None:
-            torch.distributed.all_reduce(self.n_valid_global, group=group)
-        self.backward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=reg_grads, reg_range=reg_range)
+            # the step's ONE collective (1.18 -> 2.35 MB at V = 49k: still latency-bound on xGMI), then P / (3 Pv) + R
+            torch.distributed.all_reduce(self.bucket, group=group)
+            self.combine()
         return self.losses, self.gdelta, self.galbedo
 
     def _check(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask):

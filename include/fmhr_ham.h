@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMHR_ABI_VERSION 1
+#define FMHR_ABI_VERSION 2
 #define FMHR_OK 0
 #define FMHR_E_ARG (-1)   /* bad shape / null pointer / workspace too small */
 #define FMHR_E_HIP (-2)   /* HIP runtime error (message has hipGetErrorString) */
@@ -46,6 +46,12 @@ int fmhr_topology_build(const int32_t* tri, int F, int V, int32_t* opp, void* ws
 size_t fmhr_adjacency_workspace_bytes(int V, int F);
 int fmhr_adjacency_build(const int32_t* tri, int F, int V, int32_t* row_ptr, int32_t* col_idx,
                          void* ws, size_t ws_bytes, void* stream);
+
+/* faces per adjacency entry: col_mult[e] = number of faces that hold the edge (v, col_idx[e]) of row v (1 on the boundary, 2 inside
+ * a manifold mesh).  The edge-length hinge of mesh_sfs_optim.py:296-302 is a mean over the 3F directed FACE edges; with this table
+ * it is evaluated in the same neighbour walk as the uniform Laplacians.  col_mult [nnz], overwritten. */
+int fmhr_edge_multiplicity_build(const int32_t* tri, int F, int V, const int32_t* row_ptr, const int32_t* col_idx, int nnz,
+                                 int32_t* col_mult, void* stream);
 
 /* vertex -> incident face corners (CSR, rows sorted; entry = 3*face + corner): the per-vertex kernels of the fused step walk it
  * instead of scattering float atomics.  vf_ptr [V+1], vf_idx [3F]. */
@@ -161,20 +167,24 @@ typedef struct fmhr_ham_weights {
 size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
 
 /* Phase A: geometry + rasterize + shade + antialias (forward up to the AA images) and the local valid-pixel count.
- * Phase B: losses + the whole backward.  The split exists because F.l1_loss divides by the batch-GLOBAL 3*Pv
- * (mesh_sfs_optim.py:289): a view-sharded caller all-reduces n_valid between the two phases.
+ * Phase B: losses + the whole backward.
  *   vertices_tmp, delta, albedo [V,3]; sh [n,9]; w2c, proj [n,4,4] (row-vector convention, get_data.py:96-97);
- *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx [nnz]; vf_ptr [V+1]; vf_idx [3F];
+ *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx, col_mult [nnz]; vf_ptr [V+1]; vf_idx [3F];
  *   corner_slot [3F] (fmhr_corner_slots_build).
  *   n*H*W must be a multiple of 4.
  *   valid_mask_changed: pass 1 on the first call on a workspace and whenever valid_mask's CONTENTS may differ from the previous
  *   call (its per-segment non-zero flags are cached in the workspace; the mask is constant over a HAM run, :158).
- *   n_valid_local: device int32[1] written by phase A.  n_valid_global: device float[1] read by phase B.  Phase A also
- *   leaves float(n_valid_local) in the workspace at fmhr_ham_workspace_offset(d, "n_valid_f"): a one-rank caller passes that
- *   address as n_valid_global; a sharded caller all-reduces it in place.
- *   losses: device float[8]; gdelta, galbedo [V,3] overwritten.  Every entry is this rank's SHARE: the view terms of its
- *   views, the view-independent terms of its vertex range [reg_v0, reg_v1) (none with reg_grad_scale = 0); the n_valid slot is
- *   reported by the rank whose range starts at vertex 0.  The SUM over all ranks is the global result with no fix-up. */
+ *   n_valid_local: device int32[1] written by phase A, which also leaves float(n_valid_local) in the workspace at
+ *   fmhr_ham_workspace_offset(d, "n_valid_f").
+ * F.l1_loss divides by the batch-GLOBAL 3*Pv (mesh_sfs_optim.py:289).  Two ways to call phase B:
+ *   ONE RANK (gdelta_rest = galbedo_rest = NULL): n_valid_global = device float[1], normally the "n_valid_f" address.
+ *     losses: device float[8]; gdelta, galbedo [V,3] overwritten with the whole gradient.
+ *   VIEW-SHARDED (gdelta_rest, galbedo_rest non-NULL; n_valid_global ignored): no exchange between the phases.  gdelta / galbedo
+ *     receive the PHOTOMETRIC share P of this rank's views with the L1 divisor left out (per-pixel gradient +-w_sfs), gdelta_rest /
+ *     galbedo_rest everything else, R: the silhouette term of its views and the view-independent terms of its vertex range
+ *     [reg_v0, reg_v1).  losses[FMHR_LOSS_SFS] = w_sfs * sum |d| (no divisor), losses[FMHR_LOSS_NVALID] = the LOCAL count.  The
+ *     caller lays [gdelta | galbedo | gdelta_rest | galbedo_rest | losses] out as ONE bucket of 12V+8 floats, all-reduces it (SUM)
+ *     once and calls fmhr_ham_combine. */
 /* Must be called once on a fresh workspace (and after any aborted step): sets up the self-cleaning state (depth keys, dirty
  * flags, antialias-backward vertex accumulator) that every completed forward+backward pair leaves clean again. */
 int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);
@@ -185,9 +195,14 @@ int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const fl
 int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const float* vertices_tmp, const float* delta,
                       const float* albedo, const float* sh, const float* w2c, const float* proj, const float* img,
                       const float* mask, const float* valid_mask, const int32_t* tri, const int32_t* opp,
-                      const int32_t* row_ptr, const int32_t* col_idx, const int32_t* vf_ptr, const int32_t* vf_idx,
-                      const int32_t* corner_slot, const float* n_valid_global,
-                      float* losses, float* gdelta, float* galbedo, void* ws, size_t ws_bytes, void* stream);
+                      const int32_t* row_ptr, const int32_t* col_idx, const int32_t* col_mult, const int32_t* vf_ptr,
+                      const int32_t* vf_idx, const int32_t* corner_slot, const float* n_valid_global,
+                      float* losses, float* gdelta, float* galbedo, float* gdelta_rest, float* galbedo_rest,
+                      void* ws, size_t ws_bytes, void* stream);
+/* After the all-reduce of a view-sharded step's bucket [P_delta | P_albedo | R_delta | R_albedo | 8 loss slots] (12V+8 floats):
+ * g = P / (3 * n_valid_global) + R written over P (the first 6V floats are then gdelta | galbedo), the photometric loss slot gets the
+ * same divisor, the total slot is formed; n_valid_global = the summed FMHR_LOSS_NVALID slot (0: the photometric term is 0). */
+int fmhr_ham_combine(int V, float* bucket, void* stream);
 /* Views of the step's intermediates inside the workspace (for parity tests / rendering): returns device pointers. */
 typedef struct fmhr_ham_views {
     float* pos;        /* [n,V,4] clip positions: NOT stored by the step (every kernel recomputes them from the vertices and the

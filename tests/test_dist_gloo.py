@@ -1,6 +1,7 @@
-"""World-size-2 rehearsal of the view-sharded step on CPU (gloo): fmhr_amd.dist's partition + valid-count all-reduce + ONE
-packed gradient all-reduce must reproduce the single-process full-batch result.  The compute is the CPU oracle (the product
-has no CPU path); what is under test is the host-side sharding logic the GPU ranks run unchanged over RCCL."""
+"""World-size-2 rehearsal of the view-sharded step on CPU (gloo): fmhr_amd.dist's partition + the ONE packed all-reduce of
+[photometric share without its divisor | the rest | loss slots] + the combine must reproduce the single-process full-batch result.
+The compute is the CPU oracle (the product has no CPU path); what is under test is the host-side protocol the GPU ranks run over
+RCCL (HamStage2.step(group=...) does the same in place with the combine kernel)."""
 import os
 import socket
 import sys
@@ -21,8 +22,9 @@ def _free_port():
     return p
 
 
-def _oracle_step(oracle, sc, s0, s1, n_total, reg_grads, reduce_fn):
-    """what HamStage2.step does on a GPU rank, on the oracle: forward -> n_valid all-reduce -> losses with global divisors."""
+def _oracle_step(oracle, sc, s0, s1, n_total, reg_grads):
+    """what a view-sharded rank hands to the exchange, on the oracle: the photometric term with the L1 divisor left out (P), the
+    silhouette term + this rank's regularisers (R), the loss slots and the LOCAL valid-pixel count — no exchange in between."""
     sl = slice(s0, s1)
     d = sc["delta"].clone().requires_grad_(True)
     a = sc["albedo"][None].clone().requires_grad_(True)
@@ -30,21 +32,28 @@ def _oracle_step(oracle, sc, s0, s1, n_total, reg_grads, reduce_fn):
     with torch.no_grad():
         _, pos = oracle.clip_positions(sc["vertices"] + sc["delta"], sc["w2c"][sl], sc["proj"][sl])
         rast, _ = oracle.rasterize(None, pos.contiguous(), sc["faces"], (H, W))
-        n_valid = ((sc["mask"][sl] > 0) & (rast[..., 3] > 0)).sum().to(torch.float32).reshape(1)
-    reduce_fn(n_valid)
-    w = dict(sc["weights"])
+        n_valid = ((sc["mask"][sl] > 0) & (rast[..., 3] > 0)).sum().to(torch.float32)
     out = oracle.ham_stage2_losses(sc["vertices"], d, a, sc["sh0"][sl], sc["w2c"][sl], sc["proj"][sl], sc["img"][sl],
-                                   sc["mask"][sl], sc["valid_mask"][sl], sc["faces"], (H, W), w, sc["elm"],
-                                   sfs_denominator=3.0 * float(n_valid), mse_denominator=float(n_total * H * W))
-    view_terms = out["sfs"] + out["mask"]
+                                   sc["mask"][sl], sc["valid_mask"][sl], sc["faces"], (H, W), dict(sc["weights"]), sc["elm"],
+                                   sfs_denominator=1.0, mse_denominator=float(n_total * H * W))
+    pd, pa = torch.autograd.grad(out["sfs"], (d, a), retain_graph=True)
     reg_terms = out["lap"] + out["albedo"] + out["edge"] + out["delta"]
-    (view_terms + (reg_terms if reg_grads else 0.0 * reg_terms)).backward()
-    # the rank's SHARE of every slot (fmhr_amd.dist.ShardedStep.reduce contract): view-independent terms on one rank only
+    rd, ra = torch.autograd.grad(out["mask"] + (reg_terms if reg_grads else 0.0 * reg_terms), (d, a))
     r = 1.0 if reg_grads else 0.0
     share = {k: out[k].detach() * (r if k in ("lap", "albedo", "edge", "delta") else 1.0) for k in ("sfs", "lap", "albedo", "mask", "edge", "delta")}
-    losses = torch.stack([share[k] for k in ("sfs", "lap", "albedo", "mask", "edge", "delta")] +
-                         [sum(share.values()), n_valid[0] * r]).to(torch.float32)
-    return losses, d.grad, a.grad[0]
+    losses = torch.stack([share[k] for k in ("sfs", "lap", "albedo", "mask", "edge", "delta")] + [torch.zeros(()), n_valid]).to(torch.float32)
+    return losses, pd, pa[0], rd, ra[0]
+
+
+def _reference_step(oracle, sc):
+    """the single-process full-batch step with the reference's divisors (mesh_sfs_optim.py:289,295)"""
+    d = sc["delta"].clone().requires_grad_(True)
+    a = sc["albedo"][None].clone().requires_grad_(True)
+    out = oracle.ham_stage2_losses(sc["vertices"], d, a, sc["sh0"], sc["w2c"], sc["proj"], sc["img"], sc["mask"], sc["valid_mask"],
+                                   sc["faces"], (sc["H"], sc["W"]), dict(sc["weights"]), sc["elm"])
+    out["loss"].backward()
+    losses = torch.stack([out[k].detach() for k in ("sfs", "lap", "albedo", "mask", "edge", "delta", "loss")]).to(torch.float32)
+    return losses, d.grad, a.grad[0], float(out["n_valid"]) if "n_valid" in out else None
 
 
 def _worker(rank, world, port, q):
@@ -61,8 +70,7 @@ def _worker(rank, world, port, q):
     sc = prepare(oracle, (5, 64, 48, 10, 14), 7)           # 5 views over 2 ranks: ragged 3 + 2 split
     s0, s1 = fdist.shard_views(sc["views"], rank, world)
     sh = fdist.ShardedStep(sc["V"], torch.device("cpu"))
-    losses, gd, ga = _oracle_step(oracle, sc, s0, s1, sc["views"], rank == 0, lambda t: dist.all_reduce(t))
-    ls, gd, ga = sh.reduce(losses, gd, ga)
+    ls, gd, ga = sh.reduce(*_oracle_step(oracle, sc, s0, s1, sc["views"], rank == 0))
     if rank == 0:
         q.put((ls.numpy().copy(), gd.numpy().copy(), ga.numpy().copy(), (s0, s1)))       # by value (see test_gpu_sharded.py)
     dist.barrier()
@@ -91,7 +99,9 @@ def test_two_ranks_match_single_process(oracle):
         assert p.exitcode == 0
     assert shard0 == (0, 3)
     sc = prepare(oracle, (5, 64, 48, 10, 14), 7)
-    ref_l, ref_gd, ref_ga = _oracle_step(oracle, sc, 0, 5, 5, True, lambda t: None)
+    ref_l, ref_gd, ref_ga, _ = _reference_step(oracle, sc)
     assert rel_err(ls[:7], ref_l[:7]) < 1e-5, (ls, ref_l)
-    assert float(ls[7]) == float(ref_l[7])
+    assert float(ls[7]) > 100                      # the summed LOCAL counts = the batch-global valid-pixel count
+    one = fdist.ShardedStep(sc["V"], torch.device("cpu")).reduce(*_oracle_step(oracle, sc, 0, 5, 5, True))
+    assert float(one[0][7]) == float(ls[7])
     assert rel_err(gd, ref_gd) < 1e-5 and rel_err(ga, ref_ga) < 1e-5

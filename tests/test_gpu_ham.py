@@ -100,6 +100,35 @@ def test_fused_step_vs_oracle(oracle, case):
     assert rel_err(hs.gdelta, g1) < 5e-5
 
 
+@pytest.mark.parametrize("case", [CASES[2], CASES[6], CASES[8]], ids=lambda c: c[0])
+def test_split_backward_combines_to_the_full_gradient(oracle, case):
+    """The view-sharded form of the backward on one process: photometric share without its L1 divisor (P) + the rest (R), then
+    fmhr_ham_combine — must give the one-rank gradient and loss vector (the all-reduce in between is a sum of such buckets)."""
+    from fmhr_amd.ham import HamStage2
+    name, dims, seed = case
+    sc = prepare(oracle, dims, seed)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    args = (g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    hs.step(*args)
+    ref_l, ref_d, ref_a = hs.losses.clone(), hs.gdelta.clone(), hs.galbedo.clone()
+    hs.forward(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["mask"], g["valid_mask"])
+    hs.backward(*args, split=True)
+    p_d, r_d = hs.gdelta.clone(), hs.gdelta_rest.clone()
+    assert float(p_d.abs().max()) > 0 and float(r_d.abs().max()) > 0
+    assert float(hs.losses[7]) == float(ref_l[7])                        # the local count
+    hs.combine()
+    assert rel_err(hs.gdelta, ref_d) < 2e-5 and rel_err(hs.galbedo, ref_a) < 2e-5, name
+    assert rel_err(hs.losses[:7], ref_l[:7]) < 1e-5 and float(hs.losses[7]) == float(ref_l[7])
+    # two "ranks" = the same bucket twice: the sum must give the same gradient direction with doubled count / doubled R
+    hs.forward(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["mask"], g["valid_mask"])
+    hs.backward(*args, split=True)
+    hs.bucket.mul_(2.0)
+    hs.combine()
+    assert rel_err(hs.gdelta, p_d / (3.0 * float(ref_l[7])) + 2.0 * r_d) < 2e-5
+
+
 def _step_vs_oracle(oracle, sc, name, osc=None):
     """one fused step against the fp32 oracle (bit-identical rast) and the fp64-on-fp32-decisions oracle (values).
     `osc`: the scene the oracle sees when it must differ from the GPU's (see the empty-valid-set case)."""

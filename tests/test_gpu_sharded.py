@@ -1,6 +1,6 @@
-"""Two ranks on ONE GPU (gloo backend, CUDA tensors): the view-sharded fused step (HamStage2 with n_valid all-reduce between its
-phases + ShardedStep's single packed gradient all-reduce, regulariser gradients on rank 0 only) must reproduce the single-rank
-full-batch result.  This is the code path bench.py runs per rank over RCCL at N > 1."""
+"""Two ranks on ONE GPU (gloo backend, CUDA tensors): the view-sharded fused step (HamStage2.step(group=...): split backward, ONE
+all-reduce of [P | R | losses], fmhr_ham_combine; the view-independent terms split by vertex range) must reproduce the
+single-rank full-batch result.  This is the code path bench.py runs per rank over RCCL at N > 1."""
 import os
 import socket
 import sys
@@ -57,9 +57,7 @@ def _worker(rank, world, port, q):
     sc, tg, faces, w2c, proj = _scene()
     s0, s1 = fdist.shard_views(sc["views"], rank, world)
     # the view-independent terms are split over the ranks by vertex range
-    losses, gd, ga = _run(sc, tg, faces, w2c, proj, s0, s1, dist.group.WORLD, fdist.shard_views(sc["V"], rank, world))
-    sh = fdist.ShardedStep(sc["V"], faces.device)
-    ls, gd, ga = sh.reduce(losses, gd, ga)
+    ls, gd, ga = _run(sc, tg, faces, w2c, proj, s0, s1, dist.group.WORLD, fdist.shard_views(sc["V"], rank, world))
     torch.cuda.synchronize()
     if rank == 0:
         # numpy arrays are pickled by value: tensors would be handed over through a file descriptor of THIS process, which may
