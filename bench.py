@@ -238,7 +238,7 @@ def main():
         # HBM traffic of the launch groups comes from the committed PMC profile of this same command (counters cannot be
         # collected live next to the timed region); null when the workload differs from the profiled one
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
         if os.path.exists(tpath) and args.config == "metric" and world == 1 and args.views is None:
             traffic = json.load(open(tpath))
         ms_per_step = elapsed / K * 1e3

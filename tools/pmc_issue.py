@@ -25,6 +25,7 @@ PASSES = [
     "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE",
     "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU",
     "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_LDS_BANK_CONFLICT",
+    "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum",
 ]
 # (a pass with TA_* / TCP_* counters hung rocprofv3 on this pool for its whole 400 s limit: not collected)
 if os.environ.get("PASSES"):
@@ -80,13 +81,13 @@ for k in order:
     d = sorted(dur.get(k, [0.0]))
     us = d[len(d) // 2]
     lanes = v.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(v.get("SQ_ACTIVE_INST_VALU", 0.0), 1.0) / 4.0
-    hit, miss = v.get("TCC_HIT", 0.0), v.get("TCC_MISS", 0.0)
+    hit, miss = v.get("TCC_HIT_sum", 0.0), v.get("TCC_MISS_sum", 0.0)
     row = (k.replace("fmhr::", "").replace("void ", "")[:34], us, w, iv / w, v.get("SQ_INSTS_SALU", 0) / w, v.get("SQ_INSTS_LDS", 0) / w,
            v.get("SQ_INSTS_VMEM_RD", 0) / w, v.get("SQ_INSTS_VMEM_WR", 0) / w, lanes, iv * 4 / 1024 / CLK * 1e6,
            100 * v.get("SQ_INSTS_VALU_INT32", 0) / max(iv, 1), 100 * v.get("SQ_INSTS_VALU_INT64", 0) / max(iv, 1),
            100 * v.get("SQ_INSTS_VALU_FMA_F32", 0) / max(iv, 1), 100 * v.get("SQ_INSTS_VALU_TRANS_F32", 0) / max(iv, 1),
            v.get("TA_FLAT_READ_WAVEFRONTS", 0), v.get("TA_FLAT_WRITE_WAVEFRONTS", 0), v.get("TA_FLAT_ATOMIC_WAVEFRONTS", 0),
-           100 * hit / max(hit + miss, 1), v.get("TCC_EA0_RDREQ", 0), v.get("TCC_EA0_WRREQ", 0), v.get("TCC_EA0_ATOMIC", 0))
+           100 * hit / max(hit + miss, 1), v.get("TCC_EA0_RDREQ", 0), v.get("TCC_EA0_WRREQ", 0), v.get("TCC_EA0_ATOMIC_sum", 0))
     lines.append(" ".join((("%.4g" % x).rjust(9) if i else x.ljust(34)) for i, x in enumerate(row)))
 lines.append("")
 lines.append("raw counters (mean per dispatch):")
