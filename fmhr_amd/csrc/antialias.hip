@@ -227,7 +227,8 @@ __device__ __forceinline__ int2 snap_or_reject(const ClipView& cv, int v, float 
 __device__ __forceinline__ int aa_analyse(const ClipView& cv, const int32_t* __restrict__ tri,
                                           const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
                                           int V, int F, int H, int W,
-                                          int px, int py, int d, float z0, float id0, float z1, float id1, float& alpha_out)
+                                          int px, int py, int d, float z0, float id0, float z1, float id1, float& alpha_out,
+                                          int* edge_va = nullptr, int* edge_vb = nullptr)
 {
     int tri0 = (int)id0 - 1, tri1 = (int)id1 - 1;
     int t = (tri0 >= 0) ? tri0 : tri1;
@@ -285,6 +286,10 @@ __device__ __forceinline__ int aa_analyse(const ClipView& cv, const int32_t* __r
     float al = 0.5f - dc;
     al = ds * al;
     alpha_out = al;
+    if (edge_va != nullptr) {                    // the two vertices of the crossing edge (the backward's position gradient goes to them)
+        *edge_va = (di == 0) ? vi1 : ((di == 1) ? vi2 : vi0);
+        *edge_vb = (di == 0) ? vi2 : ((di == 1) ? vi0 : vi1);
+    }
     return code;
 }
 
@@ -403,8 +408,13 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
                                             int32_t* __restrict__ counter, int4* ibuf, float* abuf, int* inum, int region, size_t rbase)
 {
     float alpha = 0.f;
-    const int code = aa_analyse(clip_view(pos, verts, cmat, b, V), tri, opp, silh + (size_t)b * F, V, F, H, W, px, py, d, z0, id0, z1, id1, alpha);
+    int va = 0, vb = 0;
+    const int code = aa_analyse(clip_view(pos, verts, cmat, b, V), tri, opp, silh + (size_t)b * F, V, F, H, W, px, py, d, z0, id0, z1, id1, alpha,
+                                &va, &vb);
     if (code == 0) return;
+    // work item of the fused step: (px | py << 16, view | code << 16, edge vertex a, edge vertex b) — the backward starts its vertex
+    // loads straight from the item instead of walking pixel word -> face -> tri (two dependent round trips of a latency-bound kernel)
+    const int4 item = make_int4(px | (py << 16), b | (code << 16), va, vb);
     const long long gid = ((long long)b * H + py) * W + px, gid1 = gid + (d ? W : 1);
     const long long tgt = (alpha > 0.f) ? gid : gid1;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);           // an uncovered pixel (id 0) has the all-zero colour
@@ -417,10 +427,10 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
     const int slot = atomicAdd(inum, 1);                             // LDS
     if (slot < region) sd.dcols[rbase + slot] = make_float4(dc[0], dc[1], dc[2], dc[3]);   // straight to the item's final place
     if (slot < kItemBuf) {
-        ibuf[slot] = make_int4(px, py, b, code);
+        ibuf[slot] = item;
         abuf[slot] = alpha;
     } else if (slot < region) {                                      // buffer full (a silhouette-dense workgroup): straight to the region
-        items[rbase + slot] = make_int4(px, py, b, code);
+        items[rbase + slot] = item;
         alphas[rbase + slot] = alpha;
     } else {
         counter[1] = 1;                                              // region overflow: the pair gets no gradient, flagged
@@ -584,8 +594,12 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          float* __restrict__ gcolorA, float* __restrict__ gcolorB, float* __restrict__ gpos,
          const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr, bool use_gl = false,
          float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false, float4 dcol = make_float4(0.f, 0.f, 0.f, 0.f),
-         const float* __restrict__ verts = nullptr, bool keep0 = true, bool keep1 = true, float* __restrict__ gvert2 = nullptr)
+         const float* __restrict__ verts = nullptr, bool keep0 = true, bool keep1 = true, float* __restrict__ gvert2 = nullptr,
+         int known_va = -1, int known_vb = -1, const float4* pre = nullptr)
 {
+    // pre (fused step): the edge's two clip positions and the view's three matrix rows, loaded by the caller TOGETHER with everything
+    // else the item needs: memory operations of a wave complete in order, so a load issued behind the colour atomics below would wait
+    // for them (a memory-side float atomic takes microseconds) before the position atomics could even start
     const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
     long long pix0 = ((long long)b * H + py) * W + px;
@@ -621,16 +635,19 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
         }
     }
     if ((code & AA_CLAMPED) || galpha == 0.f) return;
-    const float idw = rast[(code & AA_TRI1) ? pix1 : pix0].w;
-    int t = packed ? pix_face(__float_as_int(idw)) : (int)idw - 1;      // fused step: the per-pixel word of shade_common.h
     int qx = px, qy = py;
     if (code & AA_TRI1) { qx += 1 - d; qy += d; }
-    int e1 = di + 1; if (e1 >= 3) e1 -= 3;
-    int e2 = di + 2; if (e2 >= 3) e2 -= 3;
-    int va = tri[t * 3 + e1], vb = tri[t * 3 + e2];
+    int va = known_va, vb = known_vb;
+    if (va < 0) {                                 // generic op: pixel -> face -> the edge's vertices
+        const float idw = rast[(code & AA_TRI1) ? pix1 : pix0].w;
+        int t = packed ? pix_face(__float_as_int(idw)) : (int)idw - 1;
+        int e1 = di + 1; if (e1 >= 3) e1 -= 3;
+        int e2 = di + 2; if (e2 >= 3) e2 -= 3;
+        va = tri[t * 3 + e1]; vb = tri[t * 3 + e2];
+    }
     // fused step (pos == null): clip positions recomputed from the vertices and the view's combined matrix (ClipView)
     const ClipView cv = clip_view(pos, verts, cmat, b, V);
-    const float4 pa = cv.get(va), pb = cv.get(vb);
+    const float4 pa = (pre != nullptr) ? pre[0] : cv.get(va), pb = (pre != nullptr) ? pre[1] : cv.get(vb);
     float fx = (float)qx + 0.5f - xh, fy = (float)qy + 0.5f - yh;
     float wa = 1.0f / pa.w, wb = 1.0f / pb.w;
     float xa = pa.x * wa * xh - fx, ya = pa.y * wa * yh - fy;
@@ -649,7 +666,8 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
     const float bx = g_xb * xh * wb, by = g_yb * yh * wb, bw = -(g_xb * pb.x * xh + g_yb * pb.y * yh) * wb * wb;
     if (cmat != nullptr) {
         // fused step: apply the clip-transform backward here and accumulate straight into the view-independent [V,3] buffer
-        const float4 c0 = cmat[(size_t)b * 4], c1 = cmat[(size_t)b * 4 + 1], c2 = cmat[(size_t)b * 4 + 2];
+        const float4 c0 = (pre != nullptr) ? pre[2] : cmat[(size_t)b * 4], c1 = (pre != nullptr) ? pre[3] : cmat[(size_t)b * 4 + 1],
+                     c2 = (pre != nullptr) ? pre[4] : cmat[(size_t)b * 4 + 2];
         const float ga[3] = {ax * c0.x + ay * c0.y + aw * c0.w, ax * c1.x + ay * c1.y + aw * c1.w, ax * c2.x + ay * c2.y + aw * c2.w};
         const float gb[3] = {bx * c0.x + by * c0.y + bw * c0.w, bx * c1.x + by * c1.y + bw * c1.w, bx * c2.x + by * c2.y + bw * c2.w};
         if (gvert2 == nullptr) {
@@ -705,10 +723,17 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
 {
     const int region = cap / (int)gridDim.x, count = region_cnt[blockIdx.x];      // same grid as k_aa_fwd_list
     const size_t rbase = (size_t)blockIdx.x * region;
+    // A silhouette vertex collects the items of several adjacent pixel pairs (up to ~30 in the metric step) and float atomics on ONE
+    // address are served one after the other at the memory side (~0.4 us each): with 2.4 k items in the whole 48-view step this
+    // kernel spent half its time waiting for such chains.  The [V,3] accumulators are therefore kept in kAaReplicas copies, a
+    // workgroup adds to copy (blockIdx & 7) — a vertex's items come from unrelated workgroups — and the mesh tail sums the copies.
+    gvert += (size_t)(blockIdx.x & (kAaReplicas - 1)) * V * 3;
+    if (gvert2 != nullptr) gvert2 += (size_t)(blockIdx.x & (kAaReplicas - 1)) * V * 3;
     const float den = 3.0f * L.n_valid[0];
     const float k1 = (den > 0.f) ? L.w_sfs / den : 0.f, k2 = L.w_mask / L.mse_den;
     for (int i = threadIdx.x; i < count; i += kBlock) {
-        const int4 it = items[rbase + i];
+        const int4 raw = items[rbase + i];                          // (px | py << 16, view | code << 16, edge vertex a, edge vertex b)
+        const int4 it = make_int4(raw.x & 0xffff, (int)((unsigned)raw.x >> 16), raw.y & 0xffff, (int)((unsigned)raw.y >> 16));
         const float alpha = alphas[rbase + i];
         const long long pix0 = ((long long)it.z * H + it.y) * W + it.x;
         const long long tgt = (alpha > 0.f) ? pix0 : pix0 + ((it.w & AA_DOWN) ? W : 1);
@@ -725,11 +750,18 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
         }
         g.w = 2.0f * (a.w - vm) * k2;
         const float4 dcol = dcols[rbase + i];                      // colour difference of the pair, left by the forward
+        float4 pre[5];                                             // edge vertices' clip positions + the view's matrix rows (see aa_bwd_item)
+        {
+            const ClipView cv = clip_view(pos, verts, cmat, it.z, V);
+            pre[0] = cv.get(raw.z); pre[1] = cv.get(raw.w);
+            pre[2] = cmat[(size_t)it.z * 4]; pre[3] = cmat[(size_t)it.z * 4 + 1]; pre[4] = cmat[(size_t)it.z * 4 + 2];
+            pin(pre[0]); pin(pre[1]); pin(pre[2]); pin(pre[3]); pin(pre[4]);
+        }
         const long long pix1 = pix0 + ((it.w & AA_DOWN) ? W : 1);
         // d loss / d shaded colour exists for covered pixels only (k_loss_pix stores it for them, the owner face reads it)
         const bool cov0 = (L.covw[pix0 >> 6] >> (pix0 & 63)) & 1ull, cov1 = (L.covw[pix1 >> 6] >> (pix1 & 63)) & 1ull;
         aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, nullptr, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
-                          nullptr, cmat, gvert, true, g, true, dcol, verts, cov0, cov1, gvert2);
+                          nullptr, cmat, gvert, true, g, true, dcol, verts, cov0, cov1, gvert2, raw.z, raw.w, pre);
     }
 }
 

@@ -44,6 +44,7 @@ bool debug_sync();                                   // abi.cpp: FMHR_DEBUG_SYNC
     } while (0)
 
 constexpr int kBlock = 256;
+constexpr int kAaReplicas = 8;   // copies of the antialias-backward vertex accumulators (antialias.hip: k_aa_bwd_items)
 constexpr int kSub = 256;        // sub-pixel units per pixel (8 bits)
 constexpr int kHalf = 128;
 constexpr float kSnapLim = 4194304.0f;   // 2^22 sub-pixel guard band

@@ -105,8 +105,8 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.aa_region_cnt = take(off, 2048 * 4);            // items per region of the list (one region per workgroup of the AA kernels)
     L.g_shaded = take(off, nP * 16);
     L.cmat = take(off, (size_t)d->n * 64);
-    L.gvert_aa = take(off, V * 12);
-    L.gvert_aa2 = take(off, V * 12);             // view-sharded step: the silhouette share of the antialias position gradient
+    L.gvert_aa = take(off, V * 12 * kAaReplicas);
+    L.gvert_aa2 = take(off, V * 12 * kAaReplicas);             // view-sharded step: the silhouette share of the antialias position gradient
     L.part = take(off, (size_t)face_bwd_groups(d->n) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
     L.partials = take(off, 2048 * 4 * 3);           // per-workgroup partial sums of the persistent pixel kernels
     L.gnormal = take(off, V * 12);
@@ -193,8 +193,8 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     char* w = (char*)ws;
     HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, (hipStream_t)stream), "init aa_counter");
     // self-cleaning accumulator: k_mesh_tail_a zeroes each entry after consuming it
-    HIPTRY(hipMemsetAsync(w + L.gvert_aa, 0, (size_t)d->V * 12, (hipStream_t)stream), "init gvert_aa");
-    HIPTRY(hipMemsetAsync(w + L.gvert_aa2, 0, (size_t)d->V * 12, (hipStream_t)stream), "init gvert_aa2");
+    HIPTRY(hipMemsetAsync(w + L.gvert_aa, 0, (size_t)d->V * 12 * kAaReplicas, (hipStream_t)stream), "init gvert_aa");
+    HIPTRY(hipMemsetAsync(w + L.gvert_aa2, 0, (size_t)d->V * 12 * kAaReplicas, (hipStream_t)stream), "init gvert_aa2");
     {
         const float third = 1.0f / 3.0f;           // 3 * (1/3) == 1 exactly in fp32: the kernels' divisor 3 * n_valid becomes 1
         HIPTRY(hipMemcpyAsync(w + L.one_third, &third, 4, hipMemcpyHostToDevice, (hipStream_t)stream), "init one_third");

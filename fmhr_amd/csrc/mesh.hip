@@ -449,16 +449,26 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
     gx = sum_sub(gx); gy = sum_sub(gy); gz = sum_sub(gz);
 #pragma unroll
     for (int c = 0; c < 3; c++) { lv[c] = sum_sub(lv[c]); la[c] = sum_sub(la[c]); hg[c] = sum_sub(hg[c]); }
-    if (live && sub == 0) {
-        float* ga = A.gvert_aa + (size_t)v * 3;           // antialias-backward atomics; consumed and re-zeroed for the next step
-        gx += ga[0]; gy += ga[1]; gz += ga[2];
-        ga[0] = 0.f; ga[1] = 0.f; ga[2] = 0.f;
-        float rx = hg[0], ry = hg[1], rz = hg[2];         // everything that is NOT the photometric term: hinge, delta, silhouette share
+    // antialias-backward atomics: kAaReplicas copies of the [V,3] accumulators (one per lane of the vertex), consumed and re-zeroed
+    // for the next step
+    static_assert(kAaReplicas == kSubLanes, "one replica per lane of a vertex");
+    float aa1[3] = {0.f, 0.f, 0.f}, aa2[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        float* ga = A.gvert_aa + ((size_t)sub * A.V + v) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { aa1[c] = ga[c]; if (aa1[c] != 0.f) ga[c] = 0.f; }
         if (A.gvert_aa2 != nullptr) {
-            float* g2 = A.gvert_aa2 + (size_t)v * 3;
-            rx += g2[0]; ry += g2[1]; rz += g2[2];
-            g2[0] = 0.f; g2[1] = 0.f; g2[2] = 0.f;
+            float* g2 = A.gvert_aa2 + ((size_t)sub * A.V + v) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) { aa2[c] = g2[c]; if (aa2[c] != 0.f) g2[c] = 0.f; }
         }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { aa1[c] = sum_sub(aa1[c]); aa2[c] = sum_sub(aa2[c]); }
+    if (live && sub == 0) {
+        float rx = hg[0], ry = hg[1], rz = hg[2];         // everything that is NOT the photometric term: hinge, delta, silhouette share
+        gx += aa1[0]; gy += aa1[1]; gz += aa1[2];
+        rx += aa2[0]; ry += aa2[1]; rz += aa2[2];
         // (2) d/d nsum of the normalised vertex normal (models/utils.py:545, eps 1e-6)
         {
             float3 s = ld3(A.nsum + (size_t)v * 3);
