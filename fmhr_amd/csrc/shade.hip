@@ -299,7 +299,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
            const int4* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
            const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
-           int H, int W, float4* __restrict__ part, const int skip_lists)       // skip_lists: queued large-box faces have their own kernel
+           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg)       // skip_lists: queued large-box faces have their own kernel
 {
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
     constexpr int GV = kGroup * VPL;                               // views per group
@@ -368,7 +368,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int c = 0; c < 9; c++) A[k][c] = 0.f;
-    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
+    const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;        // host constants: four IEEE divisions per wave otherwise
     if (anyk != 0ull) {                                            // wave-uniform
         // ---- one memory round trip for the face's attributes (lane 0 of the group) AND the first candidate pixel of every lane:
         //      the attribute loads are issued first, the candidate masks (already here) are expanded into the task list, each lane
@@ -412,8 +412,10 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             vs = en >> 6;
             const int src = ((tid & ~(kGroup - 1)) + (vs & (kGroup - 1))) * VPL + (vs >> 3);
             const int box = pk_box[src];
-            int c;
-            const int r = fast_divmod(bit, ((box >> 26) & 63) + 1, c);
+            // row / column of candidate `bit` in the box: bit < 64, 1 <= width <= 64: (bit + 0.5) / width is at least 1 / 128 away from an
+            // integer, so the 1-ulp reciprocal cannot change the truncated quotient (the exact integer division costs ~25 instructions)
+            const int bwd = ((box >> 26) & 63) + 1;
+            const int r = (int)(((float)bit + 0.5f) * frcp((float)bwd)), c = bit - r * bwd;
             px = (box & 0x1fff) + c; py = ((box >> 13) & 0x1fff) + r;
             return (long long)(b0 + vs) * P + (long long)py * W + px;
         };
@@ -565,7 +567,7 @@ k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ t
                  const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
                  const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, const float* __restrict__ verts,
                  const int2* __restrict__ large_q, const int* __restrict__ large_cnt, const unsigned long long* __restrict__ covw,
-                 int n, int V, int F, int H, int W, int GV, float* __restrict__ part)
+                 int n, int V, int F, int H, int W, int GV, float* __restrict__ part, const PixGrid pg)
 {
     constexpr int kWaves = kBlock / 64;
     __shared__ float view_c[kWaves][28];
@@ -573,7 +575,7 @@ k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ t
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cnt = large_cnt[1];                                  // the resolve pass kept a copy when it rearmed the queue
     const long long P = (long long)H * W;
-    const float xs = 2.0f / (float)W, ys = 2.0f / (float)H, xo = 1.0f / (float)W - 1.0f, yo = 1.0f / (float)H - 1.0f;
+    const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;
     for (int it = blockIdx.x * kWaves + wv; it < cnt; it += gridDim.x * kWaves) {      // wave-uniform
         const int2 bf = large_q[it];
         const int b = bf.x, f = bf.y;
@@ -659,10 +661,11 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     if (n == 0 || F == 0) return FMHR_OK;
     const dim3 grid(cdiv(F, kFacesPerBlock), face_bwd_groups(n));
     const int skip_lists = raster_use_queue(H, W, F) ? 1 : 0;      // coarse mesh: the queued large-box faces get their own kernel
+    const PixGrid pg = make_pix_grid(H, W);
 #define FMHR_FACE_BWD(VPL)                                                                                                          \
     k_face_bwd<VPL><<<grid, kBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
                                              (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
-                                             (float4*)part, skip_lists)
+                                             (float4*)part, skip_lists, pg)
     switch (face_bwd_vpl(n)) {
         case 1: FMHR_FACE_BWD(1); break;
         case 2: FMHR_FACE_BWD(2); break;
@@ -675,7 +678,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     FMHR_CHECK_LAUNCH("k_face_bwd");
     if (skip_lists) {
         k_face_bwd_large<<<2048, kBlock, 0, st>>>((const float4*)bwd16, tri, snap, (const float4*)attr8, sh, (const float4*)g_shaded, corner_slot,
-                                                  (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, kGroup * face_bwd_vpl(n), part);
+                                                  (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, kGroup * face_bwd_vpl(n), part, pg);
         FMHR_CHECK_LAUNCH("k_face_bwd_large");
     }
     return FMHR_OK;
