@@ -174,10 +174,11 @@ def main():
     reg_range = fdist.shard_views(V, rank, world)     # the view-independent terms are split over the ranks by vertex range
 
     def step():
+        # the Adam update of (delta, albedo) is applied by the kernel that forms their final gradients (the mesh tail; after the
+        # step's one all-reduce the combine kernel): same rule as opt.step(), no launch of its own
         losses, gd, ga = hs.step(vtmp, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"],
-                                 group=group, reg_range=reg_range)        # N > 1: includes the step's one all-reduce
+                                 group=group, reg_range=reg_range, optimizer=opt, params=(delta, albedo))
         delta.grad, albedo.grad = gd, ga.view(1, V, 3)
-        opt.step()
         return losses
 
     def barrier():

@@ -27,6 +27,11 @@ class HamViews(ctypes.Structure):
                 ("aa_counter", c_void_p)]
 
 
+class AdamParam(ctypes.Structure):
+    _fields_ = [("param", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("lr", c_float), ("beta1", c_float),
+                ("beta2", c_float), ("eps", c_float), ("step", ctypes.c_int32)]
+
+
 P = c_void_p
 # name -> (restype, argtypes); every name declared in include/fmhr_ham.h is listed (tests/test_abi.py checks both ways)
 SIGNATURES = {
@@ -63,8 +68,8 @@ SIGNATURES = {
     "fmhr_ham_workspace_init": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),
     "fmhr_ham_densify": (c_int, [ctypes.POINTER(HamDims), P, P, P, c_size_t, P]),
     "fmhr_ham_backward": (c_int, [ctypes.POINTER(HamDims), ctypes.POINTER(HamWeights), P, P, P, P, P, P, P, P, P, P, P, P, P, P,
-                                  P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
-    "fmhr_ham_combine": (c_int, [c_int, P, P]),
+                                  P, P, P, P, P, P, P, P, P, ctypes.POINTER(AdamParam), ctypes.POINTER(AdamParam), P, c_size_t, P]),
+    "fmhr_ham_combine": (c_int, [c_int, P, ctypes.POINTER(AdamParam), ctypes.POINTER(AdamParam), P]),
     "fmhr_edge_multiplicity_build": (c_int, [P, c_int, c_int, P, P, c_int, P, P]),
     "fmhr_corner_slots_build": (c_int, [P, c_int, P, P]),
     "fmhr_vertex_faces_workspace_bytes": (c_size_t, [c_int]),

@@ -6,6 +6,11 @@
 #include <string.h>
 
 namespace fmhr {
+struct AdamTensor {
+    float* p; const float* g; float* m; float* v; long long n;
+    float beta1, beta2, eps, step_size, bc2_sqrt;
+};
+int adam_tensor_from(AdamTensor&, const fmhr_adam_param*, long long);
 struct MeshTailArgs {
     const float4* part; float* gvert_aa; int G;
     float* gvert_aa2;
@@ -18,6 +23,7 @@ struct MeshTailArgs {
     float* gs; float* rowg_v; float* rowg_a; float* gacc_v; float* gacc_a; float* gacc_r;
     float* loss_part;
     float* gdelta; float* galbedo; float* gd_rest; float* ga_rest;
+    AdamTensor ad_d, ad_a;
 };
 struct FinishArgs {
     float* losses; const float* n_valid; const float* part_l1; const float* part_l2; int nb;
@@ -28,7 +34,7 @@ struct FinishArgs {
 };
 int mesh_tail_impl(const MeshTailArgs&, const FinishArgs&, hipStream_t);
 int mesh_tail_blocks(int V);
-int ham_combine_impl(float*, int, hipStream_t);
+int ham_combine_impl(float*, int, const fmhr_adam_param*, const fmhr_adam_param*, hipStream_t);
 // raster.hip / antialias.hip / mesh.hip / shade.hip
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 size_t raster_keys_bytes(int n, int H, int W);
@@ -285,7 +291,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                                  const int32_t* opp, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* col_mult,
                                  const int32_t* vf_ptr, const int32_t* vf_idx, const int32_t* corner_slot,
                                  const float* n_valid_global, float* losses, float* gdelta,
-                                 float* galbedo, float* gdelta_rest, float* galbedo_rest, void* ws, size_t ws_bytes, void* stream)
+                                 float* galbedo, float* gdelta_rest, float* galbedo_rest, const fmhr_adam_param* adam_delta,
+                                 const fmhr_adam_param* adam_albedo, void* ws, size_t ws_bytes, void* stream)
 {
     (void)vertices_tmp; (void)opp;
     TRY(check_dims(d));
@@ -296,6 +303,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     FMHR_CHECK_ARG((gdelta_rest != nullptr) == (galbedo_rest != nullptr), "ham_backward: gdelta_rest and galbedo_rest go together");
     const bool split = gdelta_rest != nullptr;         // view-sharded caller: photometric share apart, L1 divisor left out
     FMHR_CHECK_ARG(split || n_valid_global != nullptr, "ham_backward: n_valid_global is null");
+    FMHR_CHECK_ARG(!split || (adam_delta == nullptr && adam_albedo == nullptr),
+                   "ham_backward: the fused optimiser update belongs to fmhr_ham_combine when the outputs are split");
     FMHR_CHECK_ARG(wt->mse_denominator > 0.f, "ham_backward: mse_denominator must be > 0");
     FMHR_CHECK_ARG(wt->reg_v0 >= 0 && wt->reg_v0 <= wt->reg_v1 && wt->reg_v1 <= d->V, "ham_backward: bad regulariser vertex range [%d, %d)",
                    wt->reg_v0, wt->reg_v1);
@@ -344,6 +353,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         A.gvert_aa2 = split ? (float*)(w + L.gvert_aa2) : nullptr; A.col_mult = col_mult;
         A.gacc_r = (float*)(w + L.gvert_r);
         A.gdelta = gdelta; A.galbedo = galbedo; A.gd_rest = gdelta_rest; A.ga_rest = galbedo_rest;
+        TRY(adam_tensor_from(A.ad_d, adam_delta, 3ll * d->V));
+        TRY(adam_tensor_from(A.ad_a, adam_albedo, 3ll * d->V));
         A.verts = vertices; A.delta = delta; A.albedo = albedo; A.nsum = (const float*)(w + L.nsum);
         A.tri = tri; A.vf_ptr = vf_ptr; A.vf_idx = vf_idx; A.row_ptr = row_ptr; A.col = col_idx;
         A.V = d->V; A.F = d->F;
@@ -367,8 +378,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     return FMHR_OK;
 }
 
-extern "C" int fmhr_ham_combine(int V, float* bucket, void* stream)
+extern "C" int fmhr_ham_combine(int V, float* bucket, const fmhr_adam_param* adam_delta, const fmhr_adam_param* adam_albedo, void* stream)
 {
     FMHR_CHECK_ARG(V >= 1 && bucket != nullptr, "ham_combine: bad V or null bucket");
-    return ham_combine_impl(bucket, V, (hipStream_t)stream);
+    return ham_combine_impl(bucket, V, adam_delta, adam_albedo, (hipStream_t)stream);
 }

@@ -4,6 +4,7 @@
 // 208-226, 696-722 and the inline code of /root/reference/mesh_sfs_optim.py:262-264, 296-304.
 #include "common.h"
 #include <math.h>
+#include <string.h>
 
 namespace fmhr {
 
@@ -274,25 +275,29 @@ __device__ __forceinline__ void transform_body(int v, int b, const float* __rest
 // ------------------------------------------------------------------------------------------------ Adam (A13)
 // torch.optim.Adam step (amsgrad=False, weight_decay=0, maximize=False) — mesh_sfs_optim.py:244,310.  torch's fused
 // multi_tensor kernel takes ~94 us per parameter group here (147k elements each); this one is bandwidth-trivial.
-__global__ void __launch_bounds__(kBlock)
-k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-       float beta1, float beta2, float eps, float step_size, float bc2_sqrt)
-{
-    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    float gi = g[i];
-    float mi = m[i];
-    mi = mi + (gi - mi) * (1.0f - beta1);                    // exp_avg.lerp_(grad, 1 - beta1)
-    float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    m[i] = mi; v[i] = vi;
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
-}
-
 struct AdamTensor {
     float* p; const float* g; float* m; float* v; long long n;
     float beta1, beta2, eps, step_size, bc2_sqrt;
 };
+
+// one element of torch.optim.Adam's update; every user (k_adam, k_adam2, the fused forms in k_mesh_tail_b / k_ham_combine) goes
+// through these statements, so the fused and the stand-alone update agree bit for bit
+__device__ __forceinline__ void adam_element(const AdamTensor& T, long long i, float gi)
+{
+    float mi = T.m[i];
+    mi = mi + (gi - mi) * (1.0f - T.beta1);                      // exp_avg.lerp_(grad, 1 - beta1)
+    float vi = T.v[i] * T.beta2 + (1.0f - T.beta2) * gi * gi;    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    T.m[i] = mi; T.v[i] = vi;
+    float denom = sqrtf(vi) / T.bc2_sqrt + T.eps;
+    T.p[i] = T.p[i] - T.step_size * (mi / denom);
+}
+
+__global__ void __launch_bounds__(kBlock) k_adam(const AdamTensor T)
+{
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T.n) return;
+    adam_element(T, i, T.g[i]);
+}
 
 // two parameters in one launch (the HAM loops step exactly two: delta + albedo, or albedo + SH): each launch is ~4.7 us of
 // fixed cost against ~0.6 MB of work
@@ -303,13 +308,7 @@ __global__ void __launch_bounds__(kBlock) k_adam2(const AdamTensor A, const Adam
     const AdamTensor& T = second ? B : A;
     if (second) i -= A.n;
     if (i >= T.n) return;
-    float gi = T.g[i];
-    float mi = T.m[i];
-    mi = mi + (gi - mi) * (1.0f - T.beta1);
-    float vi = T.v[i] * T.beta2 + (1.0f - T.beta2) * gi * gi;
-    T.m[i] = mi; T.v[i] = vi;
-    float denom = sqrtf(vi) / T.bc2_sqrt + T.eps;
-    T.p[i] = T.p[i] - T.step_size * (mi / denom);
+    adam_element(T, i, T.g[i]);
 }
 
 // ------------------------------------------------------------------------------------------------ CSR-gather forms (fused step)
@@ -386,6 +385,7 @@ struct MeshTailArgs {
     // tail B outputs.  One rank: gdelta / galbedo = the whole gradient (gd_rest == null).  View-sharded (split): gdelta / galbedo =
     // the PHOTOMETRIC share, computed with the L1 divisor left out; gd_rest / ga_rest = everything else (silhouette, regularisers)
     float* gdelta; float* galbedo; float* gd_rest; float* ga_rest;
+    AdamTensor ad_d, ad_a;                                                            // fused optimiser update (p == null: off)
 };
 
 // Both kernels give a vertex kSub lanes: 49k vertices are < 1 wave per SIMD, so a lane-per-vertex launch leaves every dependent
@@ -614,7 +614,11 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_b(const MeshTailArgs A, co
                 A.gdelta[(size_t)v * 3 + c] = pd[c]; A.galbedo[(size_t)v * 3 + c] = pa[c];
                 A.gd_rest[(size_t)v * 3 + c] = rd[c]; A.ga_rest[(size_t)v * 3 + c] = rr[c];
             } else {
-                A.gdelta[(size_t)v * 3 + c] = pd[c] + rd[c]; A.galbedo[(size_t)v * 3 + c] = pa[c] + rr[c];
+                const float gd = pd[c] + rd[c], gal = pa[c] + rr[c];
+                A.gdelta[(size_t)v * 3 + c] = gd; A.galbedo[(size_t)v * 3 + c] = gal;
+                // the parameters' final gradients are in registers: apply the optimiser step here (nothing in this kernel reads them)
+                if (A.ad_d.p != nullptr) adam_element(A.ad_d, (long long)v * 3 + c, gd);
+                if (A.ad_a.p != nullptr) adam_element(A.ad_a, (long long)v * 3 + c, gal);
             }
         }
     }
@@ -623,13 +627,18 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_b(const MeshTailArgs A, co
 // After the ONE all-reduce of a view-sharded step: bucket = [P_delta | P_albedo | R_delta | R_albedo | 8 loss slots], summed over
 // the ranks.  g = P / (3 * n_valid_global) + R (mesh_sfs_optim.py:289: F.l1_loss averages over the batch-global 3 * Pv), written
 // over P; the photometric loss slot gets the same divisor and the total is formed.  n_valid == 0: the photometric term is 0.
-__global__ void __launch_bounds__(kBlock) k_ham_combine(float* __restrict__ bucket, long long n3)
+__global__ void __launch_bounds__(kBlock) k_ham_combine(float* __restrict__ bucket, long long n3, const AdamTensor ad_d, const AdamTensor ad_a)
 {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     float* losses = bucket + 4 * n3;
     const float nv = losses[FMHR_LOSS_NVALID];
     const float sc = (nv > 0.f) ? 1.0f / (3.0f * nv) : 0.f;
-    if (i < 2 * n3) bucket[i] = bucket[i] * sc + bucket[2 * n3 + i];
+    if (i < 2 * n3) {
+        const float g = bucket[i] * sc + bucket[2 * n3 + i];
+        bucket[i] = g;
+        if (i < n3) { if (ad_d.p != nullptr) adam_element(ad_d, i, g); }
+        else if (ad_a.p != nullptr) adam_element(ad_a, i - n3, g);
+    }
     if (i == 2 * n3) {                      // one thread beyond the gradient range finishes the loss vector
         const float sfs = losses[FMHR_LOSS_SFS] * sc;
         losses[FMHR_LOSS_SFS] = sfs;
@@ -638,10 +647,16 @@ __global__ void __launch_bounds__(kBlock) k_ham_combine(float* __restrict__ buck
     }
 }
 
-int ham_combine_impl(float* bucket, int V, hipStream_t st)
+int adam_tensor_from(AdamTensor& T, const fmhr_adam_param* a, long long n);
+int ham_combine_impl(float* bucket, int V, const fmhr_adam_param* adam_delta, const fmhr_adam_param* adam_albedo, hipStream_t st)
 {
     const long long n3 = 3ll * V;
-    k_ham_combine<<<cdiv(2 * n3 + 1, kBlock), kBlock, 0, st>>>(bucket, n3);
+    AdamTensor ad, aa;
+    int rc = adam_tensor_from(ad, adam_delta, n3);
+    if (rc) return rc;
+    rc = adam_tensor_from(aa, adam_albedo, n3);
+    if (rc) return rc;
+    k_ham_combine<<<cdiv(2 * n3 + 1, kBlock), kBlock, 0, st>>>(bucket, n3, ad, aa);
     FMHR_CHECK_LAUNCH("k_ham_combine");
     return FMHR_OK;
 }
@@ -801,8 +816,10 @@ extern "C" int fmhr_adam_step(float* param, const float* grad, float* exp_avg, f
     if (n == 0) return FMHR_OK;
     FMHR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "adam_step: null pointer");
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    k_adam<<<cdiv(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps,
-                                                               (float)((double)lr / bc1), (float)sqrt(bc2));
+    AdamTensor T;
+    T.p = param; T.g = grad; T.m = exp_avg; T.v = exp_avg_sq; T.n = n;
+    T.beta1 = beta1; T.beta2 = beta2; T.eps = eps; T.step_size = (float)((double)lr / bc1); T.bc2_sqrt = (float)sqrt(bc2);
+    k_adam<<<cdiv(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(T);
     FMHR_CHECK_LAUNCH("k_adam");
     return FMHR_OK;
 }
@@ -811,12 +828,22 @@ static int adam_tensor(AdamTensor& T, float* param, const float* grad, float* ex
                        float beta1, float beta2, float eps, int step)
 {
     FMHR_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad n=%lld / step=%d", n, step);
-    FMHR_CHECK_ARG(n == 0 || (param && grad && exp_avg && exp_avg_sq), "adam_step: null pointer");
+    FMHR_CHECK_ARG(n == 0 || (param && exp_avg && exp_avg_sq), "adam_step: null pointer");
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     T.p = param; T.g = grad; T.m = exp_avg; T.v = exp_avg_sq; T.n = n;
     T.beta1 = beta1; T.beta2 = beta2; T.eps = eps; T.step_size = (float)((double)lr / bc1); T.bc2_sqrt = (float)sqrt(bc2);
     return FMHR_OK;
 }
+
+namespace fmhr {
+// device-side form of an optional fused optimiser update (null: switched off)
+int adam_tensor_from(AdamTensor& T, const fmhr_adam_param* a, long long n)
+{
+    memset(&T, 0, sizeof(T));
+    if (a == nullptr) return FMHR_OK;
+    return adam_tensor(T, a->param, nullptr, a->exp_avg, a->exp_avg_sq, n, a->lr, a->beta1, a->beta2, a->eps, a->step);
+}
+}  // namespace fmhr
 
 extern "C" int fmhr_adam_step2(float* param_a, const float* grad_a, float* exp_avg_a, float* exp_avg_sq_a, long long n_a,
                                float lr_a, float beta1_a, float beta2_a, float eps_a, int step_a, float* param_b,

@@ -96,7 +96,8 @@ class HamStage2:
              ptr(proj), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp), ptr(self.vf_ptr), ptr(self.vf_idx),
              changed, ptr(self.n_valid_local), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
 
-    def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True, reg_range=None, split=False):
+    def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True, reg_range=None, split=False,
+                 adam=(None, None)):
         """split=True: the view-sharded form — gdelta / galbedo get the photometric share without the L1 divisor, gdelta_rest /
         galbedo_rest the rest (include/fmhr_ham.h); the caller all-reduces self.bucket and calls combine()."""
         w = self.weights
@@ -109,26 +110,38 @@ class HamStage2:
              ptr(self.n_valid_global),
              ptr(self.losses), ptr(self.gdelta),
              ptr(self.galbedo), ptr(self.gdelta_rest if split else None), ptr(self.galbedo_rest if split else None),
+             ctypes.byref(adam[0]) if adam[0] is not None else None, ctypes.byref(adam[1]) if adam[1] is not None else None,
              ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
 
-    def combine(self):
+    def combine(self, adam=(None, None)):
         """after the all-reduce of self.bucket (view-sharded step): g = P / (3 n_valid_global) + R in place, loss vector finished."""
-        call("fmhr_ham_combine", self.V, ptr(self.bucket), stream_ptr(self.dev))
+        call("fmhr_ham_combine", self.V, ptr(self.bucket), ctypes.byref(adam[0]) if adam[0] is not None else None,
+             ctypes.byref(adam[1]) if adam[1] is not None else None, stream_ptr(self.dev))
 
-    def step(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group=None, reg_grads=True, reg_range=None):
+    def step(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group=None, reg_grads=True, reg_range=None,
+             optimizer=None, params=None):
         """Full forward + backward.  Returns (losses[8] device tensor, gdelta [V,3], galbedo [V,3]) — buffers owned by this
         object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded: the results
         are then the batch-global ones (summed over the ranks), identical on every rank.
+        `optimizer`, `params`: apply the Adam update of (delta, albedo) inside the step (no separate optimizer.step() launch).
         `reg_range` = (v0, v1): evaluate the view-independent terms for these vertices only (ranks take disjoint ranges covering
         [0, V): fmhr_amd.dist.shard_views(V, rank, world)); `reg_grads=False` switches them off on this rank."""
         self._check(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask)
+        adam = (None, None)
+        if optimizer is not None:
+            # fused optimiser step: `params` = the (delta, albedo) parameter tensors `optimizer` (fmhr_amd.optim.Adam) owns, whose
+            # storage the `delta` / `albedo` arguments view; they are updated in place by the kernel that forms their final gradient
+            p_delta, p_albedo = params
+            if p_delta.data_ptr() != delta.data_ptr() or p_albedo.data_ptr() != albedo.data_ptr():
+                raise RuntimeError("HamStage2.step: `params` must be the tensors behind the `delta` / `albedo` arguments")
+            adam = (optimizer.fused_param(p_delta), optimizer.fused_param(p_albedo))
         self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask)
         self.backward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=reg_grads, reg_range=reg_range,
-                      split=group is not None)
+                      split=group is not None, adam=adam if group is None else (None, None))
         if group is not None:
             # the step's ONE collective (1.18 -> 2.35 MB at V = 49k: still latency-bound on xGMI), then P / (3 Pv) + R
             torch.distributed.all_reduce(self.bucket, group=group)
-            self.combine()
+            self.combine(adam)
         return self.losses, self.gdelta, self.galbedo
 
     def _check(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask):

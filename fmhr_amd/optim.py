@@ -27,6 +27,20 @@ class Adam:
             for p in g['params']:
                 p.grad = None if set_to_none else (p.grad.zero_() if p.grad is not None else None)
 
+    def fused_param(self, p):
+        """The C-ABI form of ONE pending update of parameter `p` (include/fmhr_ham.h: fmhr_adam_param) for the kernels that apply
+        Adam where the gradient is formed (HamStage2.step(optimizer=...)): advances p's step count exactly as step() would."""
+        for g in self.param_groups:
+            if any(q is p for q in g['params']):
+                st = self.state.get(p)
+                if st is None:
+                    st = self.state[p] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+                st['step'] += 1
+                from ._lib import AdamParam
+                return AdamParam(p.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), g['lr'], g['betas'][0],
+                                 g['betas'][1], g['eps'], st['step'])
+        raise RuntimeError("fmhr_amd.optim.Adam.fused_param: the tensor is not a parameter of this optimiser")
+
     @torch.no_grad()
     def step(self):
         todo = []

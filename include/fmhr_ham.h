@@ -131,6 +131,16 @@ int fmhr_adam_step2(float* param_a, const float* grad_a, float* exp_avg_a, float
                     float* exp_avg_b, float* exp_avg_sq_b, long long n_b, float lr_b, float beta1_b, float beta2_b,
                     float eps_b, int step_b, void* stream);
 
+/* Optional fused optimiser update (same rule as fmhr_adam_step): passed to fmhr_ham_backward (one-rank form) or fmhr_ham_combine
+ * (view-sharded form), the parameter is updated IN PLACE by the kernel that forms its final gradient — no extra launch (the two
+ * [V,3] parameters of a stage-2 iteration are 0.3 M floats: a launch of their own costs more than the arithmetic).  The gradient
+ * outputs are still written.  NULL: no update. */
+typedef struct fmhr_adam_param {
+    float* param; float* exp_avg; float* exp_avg_sq;     /* [V,3] each; the moments are caller-owned state (zeros at start) */
+    float lr, beta1, beta2, eps;
+    int32_t step;                                        /* 1-based count of THIS update */
+} fmhr_adam_param;
+
 /* ------------------------------------------------------------------------------------------------ fused stage-2 step
  * One full forward+backward of mesh_sfs_optim.py:253-308 for the n views this rank owns.  See fmhr_ham_forward() / fmhr_ham_backward() below. */
 typedef struct fmhr_ham_dims {
@@ -198,11 +208,12 @@ int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const f
                       const int32_t* row_ptr, const int32_t* col_idx, const int32_t* col_mult, const int32_t* vf_ptr,
                       const int32_t* vf_idx, const int32_t* corner_slot, const float* n_valid_global,
                       float* losses, float* gdelta, float* galbedo, float* gdelta_rest, float* galbedo_rest,
+                      const fmhr_adam_param* adam_delta, const fmhr_adam_param* adam_albedo,   /* one-rank form only; may be NULL */
                       void* ws, size_t ws_bytes, void* stream);
 /* After the all-reduce of a view-sharded step's bucket [P_delta | P_albedo | R_delta | R_albedo | 8 loss slots] (12V+8 floats):
  * g = P / (3 * n_valid_global) + R written over P (the first 6V floats are then gdelta | galbedo), the photometric loss slot gets the
  * same divisor, the total slot is formed; n_valid_global = the summed FMHR_LOSS_NVALID slot (0: the photometric term is 0). */
-int fmhr_ham_combine(int V, float* bucket, void* stream);
+int fmhr_ham_combine(int V, float* bucket, const fmhr_adam_param* adam_delta, const fmhr_adam_param* adam_albedo, void* stream);
 /* Views of the step's intermediates inside the workspace (for parity tests / rendering): returns device pointers. */
 typedef struct fmhr_ham_views {
     float* pos;        /* [n,V,4] clip positions: NOT stored by the step (every kernel recomputes them from the vertices and the

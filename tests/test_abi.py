@@ -32,6 +32,8 @@ def test_header_and_library_agree(lib):
 def test_struct_layouts_match_header():
     from fmhr_amd._lib import HamDims, HamWeights, HamViews
     assert ctypes.sizeof(HamDims) == 28 and ctypes.sizeof(HamWeights) == 44 and ctypes.sizeof(HamViews) == 48
+    from fmhr_amd._lib import AdamParam
+    assert ctypes.sizeof(AdamParam) == 48
 
 
 def test_argument_errors_without_gpu(lib):

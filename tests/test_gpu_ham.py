@@ -129,6 +129,44 @@ def test_split_backward_combines_to_the_full_gradient(oracle, case):
     assert rel_err(hs.gdelta, p_d / (3.0 * float(ref_l[7])) + 2.0 * r_d) < 2e-5
 
 
+def test_fused_adam_matches_separate_optimizer_step(oracle):
+    """HamStage2.step(optimizer=...) applies Adam inside the mesh tail (one rank) or inside fmhr_ham_combine (view-sharded form):
+    three steps must leave the same parameters and moments as step() + optimizer.step()."""
+    from fmhr_amd.ham import HamStage2
+    from fmhr_amd.optim import Adam
+    name, dims, seed = CASES[2]
+    sc = prepare(oracle, dims, seed)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+
+    def run(mode):
+        hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+        delta = g["delta"].clone().requires_grad_(True)
+        albedo = g["albedo"][None].clone().requires_grad_(True)
+        opt = Adam([{'params': delta, 'lr': 1e-4}, {'params': albedo, 'lr': 5e-3}])
+        for _ in range(3):
+            args = (g["vertices"], delta.detach(), albedo.detach()[0], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+            if mode == "separate":
+                _, gd, ga = hs.step(*args)
+                delta.grad, albedo.grad = gd, ga.view(1, -1, 3)
+                opt.step()
+            elif mode == "fused":
+                hs.step(*args, optimizer=opt, params=(delta, albedo))
+            else:                                    # the view-sharded form on one process: split backward, combine with the update
+                hs.forward(*args[:6], g["mask"], g["valid_mask"])
+                hs.backward(*args, split=True)
+                hs.combine((opt.fused_param(delta), opt.fused_param(albedo)))
+        return delta.detach().clone(), albedo.detach().clone(), opt.state[delta]['exp_avg_sq'].clone()
+
+    d0, a0, v0 = run("separate")
+    d1, a1, v1 = run("fused")
+    assert float((d0 - g["delta"]).abs().max()) > 0
+    # run-to-run spread of the float-atomic parts of the gradient aside, the update rule is the same statements
+    assert rel_err(d1 - g["delta"], d0 - g["delta"]) < 1e-4 and rel_err(a1, a0) < 1e-6 and rel_err(v1, v0) < 1e-4
+    d2, a2, v2 = run("sharded-form")
+    assert rel_err(d2 - g["delta"], d0 - g["delta"]) < 1e-4 and rel_err(a2, a0) < 1e-6 and rel_err(v2, v0) < 1e-4
+
+
 def _step_vs_oracle(oracle, sc, name, osc=None):
     """one fused step against the fp32 oracle (bit-identical rast) and the fp64-on-fp32-decisions oracle (values).
     `osc`: the scene the oracle sees when it must differ from the GPU's (see the empty-valid-set case)."""
