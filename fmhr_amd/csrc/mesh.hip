@@ -392,7 +392,6 @@ struct MeshTailArgs {
 // gather chain (CSR row -> neighbour -> value) exposed; kSub lanes stride over the vertex's rows and combine with xor-shuffles.
 __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
 {
-    __shared__ float sm[4];
     const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
     float l_lap = 0.f, l_alb = 0.f, l_delta = 0.f;
     const bool live = v < A.V;                                     // uniform over a vertex's lanes
@@ -511,12 +510,22 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
         A.gacc_r[(size_t)v * 3] = rx; A.gacc_r[(size_t)v * 3 + 1] = ry; A.gacc_r[(size_t)v * 3 + 2] = rz;
         A.gacc_a[(size_t)v * 3] = a0; A.gacc_a[(size_t)v * 3 + 1] = a1; A.gacc_a[(size_t)v * 3 + 2] = a2;
     }
-    // per-block partials (k_finish_losses adds them up): 4 x 1.5k same-address atomics would serialise for ~60 us
-    float s;
-    s = block_sum(l_lap, sm);   if (threadIdx.x == 0) A.loss_part[blockIdx.x] = s * A.lap_w;
-    s = block_sum(l_alb, sm);   if (threadIdx.x == 0) A.loss_part[gridDim.x + blockIdx.x] = s * A.alb_w;
-    s = block_sum(l_edge, sm);  if (threadIdx.x == 0) A.loss_part[2 * gridDim.x + blockIdx.x] = s * A.edge_w;
-    s = block_sum(l_delta, sm); if (threadIdx.x == 0) A.loss_part[3 * gridDim.x + blockIdx.x] = s * A.delta_w;
+    // per-block partials (the finish block of k_mesh_tail_b adds them up: 4 x 1.5k same-address atomics would serialise for ~60 us).
+    // ONE reduction for the four sums: four block_sum() calls in a row were eight workgroup barriers at the end of every workgroup
+    {
+        __shared__ float sm4x4[4][4];
+        float r[4] = {wave_sum(l_lap), wave_sum(l_alb), wave_sum(l_edge), wave_sum(l_delta)};
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 4; k++) sm4x4[wv][k] = r[k];
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int k = threadIdx.x;
+            const float w = (k == 0) ? A.lap_w : ((k == 1) ? A.alb_w : ((k == 2) ? A.edge_w : A.delta_w));
+            A.loss_part[(size_t)k * gridDim.x + blockIdx.x] = (sm4x4[0][k] + sm4x4[1][k] + sm4x4[2][k] + sm4x4[3][k]) * w;
+        }
+    }
 }
 
 // the step's loss vector from the per-workgroup partials of k_loss_pix and k_mesh_tail_a (run by one extra workgroup of
@@ -530,22 +539,41 @@ struct FinishArgs {
     int split;            // view-sharded: the photometric slot holds w_sfs * sum |d| with the L1 divisor left out (fmhr_ham_combine)
 };
 
-__device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* sm4)
+// All ~10 k partials are requested before the first is used (six arrays, up to kFinU strided loads per thread and array, then ONE
+// combined reduction): as serial strided loops with a block_sum() each, this single workgroup took 14 us — it, not the per-vertex
+// work, was the duration of k_mesh_tail_b.
+constexpr int kFinU = 8;          // loads per thread and array in flight (covers 2048 entries with 256 threads)
+__device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float (*sm)[6])
 {
-    float r[4];
+    const float* arr[6] = {A.tail_part, A.tail_part + A.tail_nb, A.tail_part + 2 * (size_t)A.tail_nb, A.tail_part + 3 * (size_t)A.tail_nb,
+                           A.part_l1, A.part_l2};
+    const int len[6] = {A.tail_nb, A.tail_nb, A.tail_nb, A.tail_nb, A.nb, A.nb};
+    float v[6][kFinU];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {                 // regulariser sums of k_mesh_tail_a (already weighted): lap, albedo, edge, delta
+    for (int k = 0; k < 6; k++)
+#pragma unroll
+        for (int u = 0; u < kFinU; u++) {
+            const int j = threadIdx.x + u * kBlock;
+            v[k][u] = (j < len[k]) ? arr[k][j] : 0.f;
+        }
+    float r[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
         float t = 0.f;
-        for (int j = threadIdx.x; j < A.tail_nb; j += kBlock) t += A.tail_part[(size_t)k * A.tail_nb + j];
-        r[k] = block_sum(t, sm4);
+#pragma unroll
+        for (int u = 0; u < kFinU; u++) t += v[k][u];
+        for (int j = threadIdx.x + kFinU * kBlock; j < len[k]; j += kBlock) t += arr[k][j];      // longer arrays (V > 65 k): the rest
+        r[k] = wave_sum(t);
     }
-    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
-    int i = threadIdx.x;
-    for (; i + kBlock < A.nb; i += 2 * kBlock) { a1 += A.part_l1[i]; a2 += A.part_l2[i]; b1 += A.part_l1[i + kBlock]; b2 += A.part_l2[i + kBlock]; }
-    for (; i < A.nb; i += kBlock) { a1 += A.part_l1[i]; a2 += A.part_l2[i]; }
-    float s1 = block_sum(a1 + b1, sm4);
-    float s2 = block_sum(a2 + b2, sm4);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 6; k++) sm[wv][k] = r[k];
+    __syncthreads();
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) r[k] = sm[0][k] + sm[1][k] + sm[2][k] + sm[3][k];
+        const float s1 = r[4], s2 = r[5];
         float* losses = A.losses;
         float den = A.split ? 1.0f : 3.0f * A.n_valid[0];
         losses[FMHR_LOSS_SFS] = (den > 0.f) ? s1 * (A.w_sfs / den) : 0.f;
@@ -560,15 +588,15 @@ __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float* 
 
 __global__ void __launch_bounds__(kBlock) k_mesh_tail_b(const MeshTailArgs A, const FinishArgs fin)
 {
-    if (blockIdx.x == gridDim.x - 1) {
-        __shared__ float sm4[4];
-        finish_losses_block(fin, sm4);
+    if (blockIdx.x == 0) {                       // dispatched first: its one long round trip overlaps the per-vertex workgroups
+        __shared__ float sm46[4][6];
+        finish_losses_block(fin, sm46);
         return;
     }
     const float* __restrict__ verts = A.verts;
     const int32_t* __restrict__ tri = A.tri;
     const float* __restrict__ gs = A.gs;
-    const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
+    const int v = (((int)blockIdx.x - 1) * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
     const bool live = v < A.V;
     const int vv = live ? v : 0;
     float3 acc = make_float3(0.f, 0.f, 0.f), acl = acc, aca = acc;   // normal backward (photometric) | L^T r vertices | L^T r albedo
