@@ -8,6 +8,7 @@
 #include "common.h"
 #include "shade_common.h"
 #include <float.h>
+#include <string.h>
 
 namespace fmhr {
 
@@ -451,13 +452,17 @@ __device__ __attribute__((noinline)) void aa_fwd_pair_overflow(int px, int py, i
                 inum, region, rbase);
 }
 
+// ROW: W % 64 == 0 — a 64-pixel segment lies in ONE row of ONE view, so (view, row, first column) are wave-uniform and come from
+// two scalar magic divisions (common.h: UDiv) instead of two ~25-instruction integer divisions in every lane of every segment
+struct SegRows { UDiv per_view, per_row; unsigned segs_per_view, segs_per_row; };
+template <bool ROW>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __restrict__ pos,
               const float* __restrict__ verts, const float4* __restrict__ cmat, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
               const int* __restrict__ act_list, const int* __restrict__ act_count, const unsigned long long* __restrict__ covw,
               int n, int V, int F, int H, int W, float* __restrict__ out, int4* __restrict__ items,
               float* __restrict__ alphas, int32_t* __restrict__ counter, int32_t* __restrict__ region_cnt, int cap,
-              const float* __restrict__ cnt_part, int nb_cnt, int* __restrict__ n_valid, float* __restrict__ n_valid_f)
+              const float* __restrict__ cnt_part, int nb_cnt, int* __restrict__ n_valid, float* __restrict__ n_valid_f, const SegRows sr)
 {
     // work items (pairs that blend; a few % of the pixels) for the backward: every workgroup owns a fixed region of the list
     // (cap / gridDim items) and a count slot — no global atomics at all (a returning same-address atomic per wave with an item
@@ -504,7 +509,12 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
         if (wd.seg < 0) return;
         const long long gid = (wd.seg << 6) + lane, gidD = gid + W, sD = ((wd.seg << 6) + W) >> 6;
         q.live = gid < N;
-        if (q.live) {
+        if (ROW) {                                                   // every lane is live (N is a multiple of 64)
+            const unsigned sg = (unsigned)__builtin_amdgcn_readfirstlane((int)wd.seg);
+            const unsigned vb = udiv(sg, sr.per_view), r = sg - vb * sr.segs_per_view;
+            const unsigned row = udiv(r, sr.per_row);
+            q.b = (int)vb; q.py = (int)row; q.px = (int)((r - row * sr.segs_per_row) << 6) + lane;
+        } else if (q.live) {
             int rem;
             q.b = fast_divmod(gid, (int)P, rem);
             q.py = fast_divmod(rem, W, q.px);
@@ -795,8 +805,18 @@ int aa_fwd_rgba(const float* attr8, const float* sh, float* dcols, const float* 
 {
     AaShade sd;
     sd.words = (const float4*)rast; sd.attr8 = (const float4*)attr8; sd.sh = sh; sd.dcols = (float4*)dcols;
-    k_aa_fwd_list<<<kAaGrid, kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
-                                           out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f);
+    SegRows sr;
+    memset(&sr, 0, sizeof(sr));
+    const bool row = (W & 63) == 0 && ((long long)n * H * W) < (1ll << 36);      // segment ids below 2^30
+    if (row) {
+        sr.segs_per_view = (unsigned)((long long)H * W >> 6); sr.segs_per_row = (unsigned)(W >> 6);
+        sr.per_view = make_udiv(sr.segs_per_view); sr.per_row = make_udiv(sr.segs_per_row);
+        k_aa_fwd_list<true><<<kAaGrid, kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
+                                           out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f, sr);
+    } else {
+        k_aa_fwd_list<false><<<kAaGrid, kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
+                                           out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f, sr);
+    }
     FMHR_CHECK_LAUNCH("k_aa_fwd_list");
     return FMHR_OK;
 }

@@ -171,6 +171,22 @@ __device__ __forceinline__ int fast_divmod(long long g, int d, int& r)
     return q;
 }
 
+// Division of a wave-uniform unsigned value by a launch constant on the SCALAR unit: q = (mulhi(n, m) + n) >> l with
+// l = ceil(log2 d), m = ceil(2^(32+l) / d) - 2^32 (Granlund-Montgomery; exact for n < 2^31, d >= 1).  Used where a per-lane
+// integer division of a flat index would cost ~25 vector instructions per lane for a value the whole wave shares.
+struct UDiv { unsigned m, l, d; };
+inline UDiv make_udiv(unsigned d)
+{
+    UDiv u; u.d = d; u.l = 0;
+    while ((1ull << u.l) < d) u.l++;
+    const unsigned long long two32 = 1ull << 32;
+    // ceil(2^(32+l) / d) - 2^32, in 128-bit-free arithmetic: 2^(32+l) = two32 << l fits 64 bits for l <= 31
+    const unsigned long long num = two32 << u.l;
+    u.m = (unsigned)((num + d - 1) / d - two32);
+    return u;
+}
+__device__ __forceinline__ unsigned udiv(unsigned n, const UDiv& u) { return (__umulhi(n, u.m) + n) >> u.l; }
+
 // one clip coordinate of a vertex under one column (c0..c3) of the combined matrix w2c @ proj: the geometry kernel and the
 // face-parallel backward both go through this explicit chain, so their positions agree bit for bit whatever the compiler contracts
 __device__ __forceinline__ float clip_coord(float x, float y, float z, float c0, float c1, float c2, float c3)
