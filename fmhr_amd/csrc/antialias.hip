@@ -495,7 +495,9 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
     auto stageA = [&](int ii, Words& wd) {
         wd.seg = -1; wd.w0 = wd.wR = wd.wD0 = wd.wD1 = 0ull;
         if (ii < count) {
-            wd.seg = act_list[ii];
+            const int ent = act_list[ii];
+            if (ent >= 0) return;                                    // no silhouette-face pixel in reach of this segment: nothing to find
+            wd.seg = ent & 0x7fffffff;
             const long long sDn = ((wd.seg << 6) + W) >> 6;
             wd.w0 = covw[wd.seg]; wd.wR = covw_or0(covw, wd.seg + 1, nSeg); wd.wD0 = covw_or0(covw, sDn, nSeg);
             wd.wD1 = covw_or0(covw, sDn + 1, nSeg);
@@ -538,6 +540,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
     for (; i < count; i += stride) {
         stageB(wd, nxt);                                             // pixel words of iteration i + 1
         stageA(i + 2 * stride, wd);                                  // segment + coverage words of iteration i + 2
+        if (cur.seg < 0) { cur = nxt; continue; }                    // skipped segment (wave-uniform)
         float4 r0 = cur.r0, rD = cur.rD, rR = cur.rR;
         pin(r0); pin(rD); pin(rR);
         const int b = cur.b, px = cur.px, py = cur.py;

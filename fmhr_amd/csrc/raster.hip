@@ -409,7 +409,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             return;                                                  // no workgroup barrier below: a clean wave leaves at once
         }
     }
-    bool valid_px = false;
+    bool valid_px = false, sbits_any = false;
     const int step_tag = (fu.stamp != nullptr) ? fu.stamp[0] : 0;       // read up front: inside the branch it costs a round trip
     {
         const bool live = gid < (long long)n * P;
@@ -494,6 +494,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                     // faces.  Only a hint (8-bit stamp; a stale match costs a wasted entry load, never a wrong result)
                     fu.own8[(size_t)b * F + f] = (unsigned char)step_tag;
                     fu.pix16[gid] = make_float4(fr.u, fr.v, fr.zw, __int_as_float(pix_pack(f, mk > 0.f, large, sbits)));
+                    sbits_any = sbits != 0;
                 }
                 if (fu.aa_init != nullptr) {
                     // forward shading of the fused step (mesh_sfs_optim.py:268-286): rgb = SH radiance x albedo where mask > 0,
@@ -517,9 +518,13 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                 if (fu.aa_init != nullptr) fu.aa_init[gid] = col;    // zeros on the uncovered lanes (blend targets start from them)
             }
             const unsigned long long vbal = __ballot(valid_px);
+            // does any covered pixel of the segment belong to a face with a silhouette edge in this view?  Only such pixels can be
+            // the "nearer" side of an antialias pair: the antialias scan skips segments without any in reach (k_active_segments)
+            const unsigned long long sbal = __ballot(covered && sbits_any);
             if ((threadIdx.x & 63) == 0) {
                 covw[seg] = bal; dirty[seg] = 0;
-                if (fu.seg_valid != nullptr) fu.seg_valid[seg] = __popcll(vbal);     // valid (mask > 0 and covered) pixels of the segment
+                // valid (mask > 0 and covered) pixels of the segment | bit 8: holds a silhouette-face pixel
+                if (fu.seg_valid != nullptr) fu.seg_valid[seg] = __popcll(vbal) | (sbal != 0ull ? 0x100 : 0);
             }
         } else if (live) {
             rast[gid] = o;

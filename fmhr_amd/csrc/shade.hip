@@ -80,7 +80,7 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
     long long seg = (long long)blockIdx.x * kActBlock + threadIdx.x;
     {   // valid-pixel count: the resolve pass left one number per segment (it has no workgroup barrier: clean waves leave at
         // once); summed per workgroup here, the next kernel adds the ~200 partials up
-        float v = (seg < nSeg && seg_valid != nullptr) ? (float)seg_valid[seg] : 0.f;
+        float v = (seg < nSeg && seg_valid != nullptr) ? (float)(seg_valid[seg] & 0xff) : 0.f;
         float sv = block1024_sum(v, sm16);
         if (threadIdx.x == 0 && cnt_part != nullptr) cnt_part[blockIdx.x] = sv;
     }
@@ -99,7 +99,19 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
     if (a) {
         int off = base + __popcll(bal & ((1ull << lane) - 1ull));
         for (int i = 0; i < wv; i++) off += wcnt[i];
-        act_list[off] = (int)seg;
+        // bit 31 of the entry: the antialias scan has something to find here — a pixel of this segment, of the next one (lane 63's
+        // right neighbour) or of the segments below holds a face with a silhouette edge (bit 8 of the resolve pass's per-segment
+        // word); the nearer pixel of a pair that blends is always such a pixel, so every other active segment is skipped by the scan
+        unsigned flag = 0u;
+        if (seg_valid != nullptr) {
+            const long long dn = ((seg << 6) + W) >> 6;
+            int sv = seg_valid[seg];
+            if (seg + 1 < nSeg) sv |= seg_valid[seg + 1];
+            if (dn < nSeg) sv |= seg_valid[dn];
+            if (dn + 1 < nSeg) sv |= seg_valid[dn + 1];
+            flag = (sv & 0x100) ? 0x80000000u : 0u;
+        }
+        act_list[off] = (int)((unsigned)seg | flag);
     }
     // The forward shading is fused into the rasterizer's resolve pass (raster.hip), which writes the rgba for every pixel of
     // a segment that received fragments.  Active segments WITHOUT coverage (neighbours of covered ones, valid_mask-only ones) get
@@ -159,7 +171,7 @@ k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict
     float k1 = (den > 0.f) ? w_sfs / den : 0.f;
     float k2 = w_mask / mse_den;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += gridDim.x * 4) {
-        const long long seg = act_list[i];
+        const long long seg = act_list[i] & 0x7fffffff;            // (bit 31 is the antialias scan's flag)
         const long long gid = (seg << 6) + lane;
         if (gid >= N) continue;
         // every request of the iteration up front: aa (16 B), the image pixel (12 B, one request), the two masks
