@@ -305,7 +305,7 @@ constexpr int kMaxVPL = 6;                       // views per lane: a group of k
 // VPL views per lane: the fixed part of a (face, view group) — vertex ids, attributes, output slots, the DPP sum, the output
 // store, the launch — is paid once per kGroup * VPL views, and the partial planes the mesh tail has to add up shrink with it.
 template <int VPL>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4)))       // 168 VGPRs: at 170 the kernel drops to 2 waves per SIMD (82 -> 101 us)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))       // <= 128 VGPRs: 4 waves per SIMD (the few spills sit in the prologue, outside the pixel loop: 77.5 -> 72.5 us)
 k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
            const int4* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
@@ -343,6 +343,26 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         ti = *reinterpret_cast<const int3a*>(tri + (size_t)f * 3);
         if (j < 3) es = corner_slot[f * 3 + j];
     }
+    // kind: 0 nothing, 1..32 box width of a candidate mask, 255 pixel list.  Triangles that own no pixel this step (off screen, no
+    // pixel centre, hidden: 2/3 of all) are dropped by the owner mark of the resolve pass; a stale mark only costs candidate checks.
+    // The entries are needed once — box + candidate mask go into LDS task lists right away — and again only on two rare paths
+    // (a face with more than kTaskG candidates, pixel lists of large boxes), which LOAD THEM AGAIN: kept alive through the pixel
+    // loop their 36 registers were the difference between 3 and 4 waves per SIMD.
+    auto load_entries = [&](int ff, int4 (&e)[VPL], int (&kind)[VPL]) {
+#pragma unroll
+        for (int v = 0; v < VPL; v++) {
+            const int b = b0 + v * kGroup + j;
+            e[v] = make_int4(0, 0, 0, -1);
+            unsigned char mark = 0;
+            const bool live = facelive && b < n;
+            if (live) {
+                mark = own8[(size_t)b * F + ff];
+                e[v] = cov16[(size_t)b * F + ff];
+            }
+            kind[v] = (live && mark == (unsigned char)cur && ((unsigned)e[v].w >> 8) == cur) ? (e[v].w & 0xFF) : 0;
+        }
+    };
+    // first use: every request up front (owner marks and entries of all the lane's views together with the vertex ids above)
     int4 e[VPL];
     unsigned char mark[VPL];
 #pragma unroll
@@ -355,16 +375,15 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             e[v] = cov16[(size_t)b * F + f];
         }
     }
-    // kind: 0 nothing, 1..64 box width of a candidate mask, 255 pixel list.  Triangles that own no pixel this step (off screen, no
-    // pixel centre, hidden: 2/3 of all) are dropped by the owner mark of the resolve pass; a stale mark only costs candidate checks
     int kind[VPL], cnt = 0;
-    bool anyv = false;
+    bool anyv = false, has_list = false;
 #pragma unroll
     for (int v = 0; v < VPL; v++) {
         const bool live = facelive && (b0 + v * kGroup + j) < n;
         kind[v] = (live && mark[v] == (unsigned char)cur && ((unsigned)e[v].w >> 8) == cur) ? (e[v].w & 0xFF) : 0;
-        if (kind[v] >= 1 && kind[v] <= 64) cnt += __popc((unsigned)e[v].x) + __popc((unsigned)e[v].y);
+        if (kind[v] >= 1 && kind[v] <= 64) cnt += __popc((unsigned)e[v].x);       // (boxes hold at most 32 pixels: .y is 0)
         anyv = anyv || kind[v] != 0;
+        has_list = has_list || kind[v] == 255;
     }
     int incl = cnt;
 #pragma unroll
@@ -401,16 +420,16 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
                 pk_box[at] = (e[v].z & 0x1fff) | (((e[v].z >> 16) & 0x1fff) << 13) | (((kind[v] - 1) & 63) << 26);
             }
         // candidate pixels of the group's box triangles, kTaskG per round; task = (view slot v * kGroup + j) << 6 | bit
-        auto expand = [&](int R) {
+        auto expand = [&](int R, const int4 (&e)[VPL], const int (&kind)[VPL]) {
             if (cnt != 0 && excl < R + kTaskG && excl + cnt > R) {
                 int idx = excl - R;
 #pragma unroll
                 for (int v = 0; v < VPL; v++) {
                     if (!(kind[v] >= 1 && kind[v] <= 64)) continue;
-                    unsigned long long m = ((unsigned long long)(unsigned)e[v].y << 32) | (unsigned)e[v].x;
-                    while (m != 0ull) {
-                        const int bit = __builtin_ctzll(m);
-                        m &= m - 1ull;
+                    unsigned m = (unsigned)e[v].x;
+                    while (m != 0u) {
+                        const int bit = __builtin_ctz(m);
+                        m &= m - 1u;
                         if (idx >= 0 && idx < kTaskG) tasks[gl][idx] = (unsigned short)(((v * kGroup + j) << 6) | bit);
                         idx++;
                     }
@@ -431,7 +450,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             px = (box & 0x1fff) + c; py = ((box >> 13) & 0x1fff) + r;
             return (long long)(b0 + vs) * P + (long long)py * W + px;
         };
-        expand(0);
+        expand(0, e, kind);
         const int nt0 = min(kTaskG, T);
         int pvs = 0, ppx = 0, ppy = 0;
         float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), pgs = pw;
@@ -485,18 +504,29 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         run(j, nt0, j < nt0, pw, pgs, pvs, ppx, ppy);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int R = kTaskG; __ballot(R < T) != 0ull; R += kTaskG) {   // wave-uniform trip count; further rounds are rare
-            expand(R);
-            run(j, min(kTaskG, T - R), false, pw, pgs, 0, 0, 0);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        int fl = f;
+        asm volatile("" : "+v"(fl));                                 // the rare paths below load the entries again through this copy
+        if (__ballot(kTaskG < T) != 0ull) {                            // wave-uniform; further rounds are rare (> 64 candidates of a face)
+            int4 e2[VPL];
+            int kind2[VPL];
+            load_entries(fl, e2, kind2);
+            for (int R = kTaskG; __ballot(R < T) != 0ull; R += kTaskG) {
+                expand(R, e2, kind2);
+                run(j, min(kTaskG, T - R), false, pw, pgs, 0, 0, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         // ---- large-box triangles: the owning lane walks the pixel list (head in the entry, links in the owner field)
+        if (!skip_lists && __ballot(has_list) != 0ull) {              // wave-uniform
+        int4 e2[VPL];
+        int kind2[VPL];
+        load_entries(fl, e2, kind2);
 #pragma unroll
         for (int v = 0; v < VPL; v++) {
-            if (kind[v] != 255 || skip_lists) continue;
+            if (kind2[v] != 255) continue;
             const int vs = v * kGroup + j;
-            int p = e[v].x;
+            int p = e2[v].x;
             while (p >= 0) {
                 const long long gid = (long long)(b0 + vs) * P + p;
                 float4 w = bwd16[gid];
@@ -510,6 +540,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
                 }
                 p = link;
             }
+        }
         }
     }
 #pragma unroll
