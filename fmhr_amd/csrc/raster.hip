@@ -383,16 +383,45 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
 // of the view's arrays are scalar and its SH row comes through the scalar cache into SGPRs (9 VGPRs and the 64-bit address
 // arithmetic of a dozen gathers less: the kernel fits 8 waves per SIMD)
 // FV: the clip positions are recomputed from the vertices (fused step) instead of loaded
+#ifdef FMHR_X_TS
+// measurement build only (tools/analysis/resolve_timeline.py): every wave of the resolve pass leaves 100-MHz timestamps of its
+// dependent steps (each taken after an s_waitcnt, which serialises what little overlap the chain has)
+__device__ unsigned long long g_ts[8 * 262144];
+#define FMHR_TS(k) do { if (ts_on) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tsv[k] = wall_clock64(); } } while (0)
+#define FMHR_TS_FLUSH() do { if (ts_on && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 8; k_++) g_ts[ts_slot * 8 + k_] = tsv[k_]; } } while (0)
+#else
+#define FMHR_TS(k) do { } while (0)
+#define FMHR_TS_FLUSH() do { } while (0)
+#endif
+constexpr int kResolveBlock = kBlock;
 template <bool UNI, bool FV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((FV && !UNI) ? 5 : ((UNI && !FV) ? 8 : 7), 8)))
+__global__ void __launch_bounds__(kResolveBlock) __attribute__((amdgpu_waves_per_eu((FV && !UNI) ? 5 : ((UNI && !FV) ? 8 : 7), 8)))
 k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
                  unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu, const PixGrid pg)
 {
-    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    // (Workgroup i runs on XCD i % 8 and a 512-pixel row is two workgroups: with the hand in columns 256-384 of every view XCDs 1, 3,
+    // 5, 7 resolve 56 % dirty waves and XCDs 0, 2, 4, 6 0.7 % (tools/analysis/resolve_timeline.py).  Rotating the blocks by a hash
+    // of the group index evens that out per XCD and per CU and changes nothing — 82 vs 85 us: at four or more busy XCDs the pass
+    // is bound by what lies behind the L2s; 64- / 128-thread workgroups put all dirty work on TWO XCDs: 137 / 120 us.)
+    const unsigned blk = blockIdx.x;
+    const long long seg_w = (long long)blk * (kResolveBlock / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long gid = (long long)blk * kResolveBlock + threadIdx.x;
     const long long P = (long long)H * W;
     const bool sparse = dirty != nullptr;
     const long long seg = gid >> 6;
+#ifdef FMHR_X_TS
+    const bool ts_on = seg < 262144;
+    const long long ts_slot = seg;
+    unsigned long long tsv[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    if (ts_on) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tsv[6] = ((unsigned long long)xcc << 32) | hw;
+        tsv[0] = wall_clock64();
+    }
+#endif
     if (sparse) {
         if (gid == 0) {                                              // rearm the large-triangle queue and the caller's pairs of
             large_cnt[1] = large_cnt[0];                             // list cursors (saves memset launches); the backward's large-face
@@ -401,11 +430,22 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
         }
         if (gid - (gid & 63) >= (long long)n * P) return;            // whole wave out of range
-        if (!__builtin_amdgcn_readfirstlane((int)dirty[seg])) {
+        // the segment's dirty byte through the SCALAR cache (the four waves of a workgroup and the fifteen workgroups after it
+        // read the same 64-B line of flags; a wave only ever uses — and resets — its own byte, so the non-coherent scalar
+        // cache cannot show it a stale value within the launch)
+        typedef const unsigned __attribute__((address_space(4))) const_as4_u32;
+        const unsigned dword = *(const_as4_u32*)(unsigned long long)(dirty + (seg_w & ~3ll));
+        const bool is_dirty = ((dword >> (8 * (int)(seg_w & 3))) & 0xffu) != 0u;
+        FMHR_TS(1);
+        if (!is_dirty) {
             if ((threadIdx.x & 63) == 0) {
                 covw[seg] = 0ull;
                 if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;
             }
+#ifdef FMHR_X_TS
+            if (ts_on) tsv[5] = wall_clock64();
+#endif
+            FMHR_TS_FLUSH();
             return;                                                  // no workgroup barrier below: a clean wave leaves at once
         }
     }
@@ -417,6 +457,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         const float mk = (live && fu.pix16 != nullptr) ? fu.mask[gid] : 0.f;   // independent of the key: issued with it
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f), col = o;
         bool covered = false;
+        FMHR_TS(2);
         if (key != ~0ull) {
             int rem, px;
             int b = fast_divmod(gid, (int)P, rem);
@@ -425,6 +466,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             const int f = (int)((unsigned)(key & 0xffffffffu) >> 1);
             const bool large = (key & 1ull) != 0ull;
             const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+            FMHR_TS(3);
             // clip positions: loaded (generic op), or recomputed from the three vertices and the view's combined matrix (fused step)
             constexpr bool from_verts = FV;
             float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
@@ -472,6 +514,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                 pin(q0); pin(q1); pin(u0); pin(u1); pin(w0); pin(w1);
             }
             pin(p0); pin(p1); pin(p2);
+            FMHR_TS(4);
             if (from_verts) {            // the same clip_coord() chains as every other producer of these positions: bit-identical
                 asm volatile("" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z));
                 p0 = make_float4(clip_coord(x0.x, x0.y, x0.z, cm[0], cm[4], cm[8], cm[12]), clip_coord(x0.x, x0.y, x0.z, cm[1], cm[5], cm[9], cm[13]),
@@ -514,7 +557,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             unsigned long long bal = __ballot(covered);
             if (live) {
                 if (covered && fu.pix16 == nullptr) rast[gid] = o;   // fused step: pix16 replaces it (densify rebuilds rast on demand)
-                keys[gid] = ~0ull;
+                keys[gid] = ~0ull;                                   // (deletion builds: this store is worth 3 us of the pass, the next 10 us)
                 if (fu.aa_init != nullptr) fu.aa_init[gid] = col;    // zeros on the uncovered lanes (blend targets start from them)
             }
             const unsigned long long vbal = __ballot(valid_px);
@@ -529,6 +572,11 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         } else if (live) {
             rast[gid] = o;
         }
+#ifdef FMHR_X_TS
+        if (ts_on) tsv[5] = wall_clock64();
+        FMHR_TS(7);                                                  // ... and once every store has been acknowledged
+#endif
+        FMHR_TS_FLUSH();
     }
 }
 
@@ -662,6 +710,15 @@ k_interp_bwd(const float* __restrict__ attr, const float4* __restrict__ rast, co
 
 using namespace fmhr;
 
+#ifdef FMHR_X_TS
+extern "C" int fmhr_debug_ts(void* out, size_t bytes)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(fmhr::g_ts), bytes < sizeof(fmhr::g_ts) ? bytes : sizeof(fmhr::g_ts));
+    return e == hipSuccess ? 0 : 1;
+}
+#endif
+
 namespace fmhr {
 // [keys: n*H*W u64][large-triangle counter: 16 B][large-triangle queue: n*F int2]
 size_t raster_keys_bytes(int n, int H, int W) { return (size_t)n * H * W * 8; }
@@ -745,13 +802,13 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         }
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-    const dim3 rgrid(cdiv((long long)nP, kBlock));
+    const dim3 rgrid(cdiv((long long)nP, kResolveBlock));
     if (fu.verts != nullptr && dirty != nullptr && (((long long)H * W) & 63) == 0)
-        k_raster_resolve<true, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
+        k_raster_resolve<true, true><<<rgrid, kResolveBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
     else if (fu.verts != nullptr)
-        k_raster_resolve<false, true><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
+        k_raster_resolve<false, true><<<rgrid, kResolveBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
     else
-        k_raster_resolve<false, false><<<rgrid, kBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
+        k_raster_resolve<false, false><<<rgrid, kResolveBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }
