@@ -226,6 +226,34 @@ __device__ __forceinline__ ClipView clip_view(const float* pos, const float* ver
     return cv;
 }
 
+#ifdef FMHR_X_TS
+// measurement build only: start / end timestamps (100 MHz) and the hardware slot of every wave of a kernel, one array per
+// translation unit (FMHR_WTS_DEFINE), read back through fmhr_debug_wts_<unit>() by tools/analysis/wave_timeline.py
+#define FMHR_WTS_DEFINE(unit)                                                                                          \
+    __device__ unsigned long long g_wts_##unit[4 * 81920];                                                              \
+    extern "C" int fmhr_debug_wts_##unit(void* out, size_t bytes)                                                     \
+    {                                                                                                                  \
+        hipError_t e = hipDeviceSynchronize();                                                                         \
+        if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wts_##unit), bytes < sizeof(g_wts_##unit) ? bytes : sizeof(g_wts_##unit)); \
+        return e == hipSuccess ? 0 : 1;                                                                                \
+    }
+#define FMHR_WTS_BEGIN(unit, wave_index)                                                                               \
+    const long long wts_w_ = (wave_index);                                                                             \
+    if ((threadIdx.x & 63) == 0 && wts_w_ < 81920) {                                                                   \
+        unsigned hw_, xcc_;                                                                                            \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                              \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                            \
+        g_wts_##unit[wts_w_ * 4 + 2] = ((unsigned long long)xcc_ << 32) | hw_;                                         \
+        g_wts_##unit[wts_w_ * 4] = wall_clock64();                                                                     \
+    }
+#define FMHR_WTS_END(unit)                                                                                             \
+    if ((threadIdx.x & 63) == 0 && wts_w_ < 81920) g_wts_##unit[wts_w_ * 4 + 1] = wall_clock64();
+#else
+#define FMHR_WTS_DEFINE(unit)
+#define FMHR_WTS_BEGIN(unit, wave_index)
+#define FMHR_WTS_END(unit)
+#endif
+
 // block (256 threads = 4 waves) sum; result valid in thread 0
 __device__ __forceinline__ float block_sum(float v, float* sm4)
 {

@@ -108,6 +108,7 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
 // every wave lies in one view, the view's matrix sits in SGPRs), the pixel-grid constants come from the host, the coverage
 // mask is 32 bits wide and filled by ONE flat loop over the box (nested row / column loops run max(rows) x max(columns) of the
 // wave's lanes), and a task's pixel is decoded with a float multiply instead of an integer division.
+FMHR_WTS_DEFINE(raster)
 constexpr int kTaskCap = 1024;       // tasks the workgroup expands per round (it can hold 256 x 32; more rounds then)
 
 struct TriPark {
@@ -133,6 +134,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
               int4* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
               const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg)
 {
+    FMHR_WTS_BEGIN(raster, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6));
     __shared__ TriPark park[kBlock];
     __shared__ unsigned short tasks[kTaskCap];                       // the workgroup's task list: lane (8 bits) << 5 | bit of its mask
     __shared__ int wtot[kBlock / 64];
@@ -318,6 +320,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     }
     // ---- large-box triangles (box > 32 pixels: none on a sub3-class mesh, all of them on a 778-vertex hand): each is rasterized
     // by its whole wave, 64 box pixels per iteration (no second launch; coarse meshes took the queue above instead)
+    FMHR_WTS_END(raster);
     if (lbal == 0ull) return;                                        // wave-uniform
     float4 lp0 = make_float4(0.f, 0.f, 0.f, 0.f), lp1 = lp0, lp2 = lp0;
     if (is_large) { lp0 = clipv(i0); lp1 = clipv(i1); lp2 = clipv(i2); }

@@ -298,6 +298,7 @@ __device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr&
     }
 }
 
+FMHR_WTS_DEFINE(shade)
 constexpr int kTaskG = 64;                       // candidate pixels a group expands per round
 constexpr int kFacesPerBlock = kBlock / kGroup;
 constexpr int kMaxVPL = 6;                       // views per lane: a group of kGroup lanes covers kGroup * VPL views of one face
@@ -313,6 +314,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
            const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
            int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg)       // skip_lists: queued large-box faces have their own kernel
 {
+    FMHR_WTS_BEGIN(shade, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6));
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
     constexpr int GV = kGroup * VPL;                               // views per group
     __shared__ float view_c[GV][28];                               // per view of the group: 9 SH coefficients, 4 x 4 clip-matrix entries
@@ -556,6 +558,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         dst[1] = make_float4(o[4], o[5], o[6], o[7]);
         dst[2] = make_float4(o[8], 0.f, 0.f, 0.f);
     }
+    FMHR_WTS_END(shade);
 }
 
 int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char* vmnz, hipStream_t st)
