@@ -109,6 +109,10 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
 // mask is 32 bits wide and filled by ONE flat loop over the box (nested row / column loops run max(rows) x max(columns) of the
 // wave's lanes), and a task's pixel is decoded with a float multiply instead of an integer division.
 FMHR_WTS_DEFINE(raster)
+#ifndef FMHR_TRIS_BLOCK
+#define FMHR_TRIS_BLOCK 256
+#endif
+constexpr int kTrisBlock = FMHR_TRIS_BLOCK;     // threads (= faces of one view) per workgroup of k_raster_tris
 constexpr int kTaskCap = 1024;       // tasks the workgroup expands per round (it can hold 256 x 32; more rounds then)
 
 struct TriPark {
@@ -127,19 +131,19 @@ struct LargePark {
 // [n,V,4] position array (37 MB written + gathered per 48 views) does not exist.
 // 64 VGPRs and < 20 KB of LDS per workgroup: 8 waves per SIMD (5 / 6 / 7 / 8 waves: 105 / 100 / 97.5 / 94 us)
 template <bool FV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(kTrisBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
               int4* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
               const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg)
 {
-    FMHR_WTS_BEGIN(raster, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6));
-    __shared__ TriPark park[kBlock];
+    FMHR_WTS_BEGIN(raster, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kTrisBlock / 64) + (threadIdx.x >> 6));
+    __shared__ TriPark park[kTrisBlock];
     __shared__ unsigned short tasks[kTaskCap];                       // the workgroup's task list: lane (8 bits) << 5 | bit of its mask
-    __shared__ int wtot[kBlock / 64];
-    __shared__ LargePark lpark[kBlock / 64];
-    const int f = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ int wtot[kTrisBlock / 64];
+    __shared__ LargePark lpark[kTrisBlock / 64];
+    const int f = blockIdx.x * kTrisBlock + threadIdx.x;
     const int b = blockIdx.y;                                        // wave-uniform (SGPR)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned cm = 0u;
@@ -267,7 +271,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     __syncthreads();                                                 // every wave of the workgroup gets here (no early return above)
     int wbase = 0, T = 0;
 #pragma unroll
-    for (int i = 0; i < kBlock / 64; i++) {
+    for (int i = 0; i < kTrisBlock / 64; i++) {
         const int w = wtot[i];
         if (i < wv) wbase += w;
         T += w;
@@ -291,7 +295,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         }
         __syncthreads();
         const int nt = min(kTaskCap, T - R);
-        for (int t0 = wv * 64; t0 < nt; t0 += kBlock) {             // wave-uniform trip count: the shuffle below needs every lane
+        for (int t0 = wv * 64; t0 < nt; t0 += kTrisBlock) {             // wave-uniform trip count: the shuffle below needs every lane
             const int t = t0 + lane;
             int segl = -1;
             if (t < nt) {
@@ -790,11 +794,11 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     const PixGrid pg = make_pix_grid(H, W);
     if ((long long)n * F > 0) {
         ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
-        const dim3 tgrid(cdiv(F, kBlock), n);                        // view = blockIdx.y
+        const dim3 tgrid(cdiv(F, kTrisBlock), n);                    // view = blockIdx.y
         if (fu.verts != nullptr)
-            k_raster_tris<true><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg);
+            k_raster_tris<true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg);
         else
-            k_raster_tris<false><<<tgrid, kBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg);
+            k_raster_tris<false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg);
         FMHR_CHECK_LAUNCH("k_raster_tris");
     }
     {

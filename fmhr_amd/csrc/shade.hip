@@ -300,13 +300,17 @@ __device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr&
 
 FMHR_WTS_DEFINE(shade)
 constexpr int kTaskG = 64;                       // candidate pixels a group expands per round
-constexpr int kFacesPerBlock = kBlock / kGroup;
+#ifndef FMHR_FB_BLOCK
+#define FMHR_FB_BLOCK 256
+#endif
+constexpr int kFbBlock = FMHR_FB_BLOCK;          // threads per workgroup of k_face_bwd
+constexpr int kFacesPerBlock = kFbBlock / kGroup;
 constexpr int kMaxVPL = 6;                       // views per lane: a group of kGroup lanes covers kGroup * VPL views of one face
 
 // VPL views per lane: the fixed part of a (face, view group) — vertex ids, attributes, output slots, the DPP sum, the output
 // store, the launch — is paid once per kGroup * VPL views, and the partial planes the mesh tail has to add up shrink with it.
 template <int VPL>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))       // <= 128 VGPRs: 4 waves per SIMD (the few spills sit in the prologue, outside the pixel loop: 77.5 -> 72.5 us)
+__global__ void __launch_bounds__(kFbBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))       // <= 128 VGPRs: 4 waves per SIMD (the few spills sit in the prologue, outside the pixel loop: 77.5 -> 72.5 us)
 k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
            const int4* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
@@ -314,18 +318,18 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
            const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
            int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg)       // skip_lists: queued large-box faces have their own kernel
 {
-    FMHR_WTS_BEGIN(shade, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6));
+    FMHR_WTS_BEGIN(shade, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kFbBlock / 64) + (threadIdx.x >> 6));
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
     constexpr int GV = kGroup * VPL;                               // views per group
     __shared__ float view_c[GV][28];                               // per view of the group: 9 SH coefficients, 4 x 4 clip-matrix entries
-    __shared__ int pk_box[kBlock * VPL];                           // box: pxa | pya << 13 | (width - 1) << 26
+    __shared__ int pk_box[kFbBlock * VPL];                           // box: pxa | pya << 13 | (width - 1) << 26
     __shared__ FaceAttr pk_attr[kFacesPerBlock];
     __shared__ unsigned short tasks[kFacesPerBlock][kTaskG];
     const long long P = (long long)H * W;
     const int tid = threadIdx.x, j = tid & (kGroup - 1), gl = tid / kGroup, lane = tid & 63;
     const int f = blockIdx.x * kFacesPerBlock + gl;
     const int g = blockIdx.y, b0 = g * GV;                         // view of (lane j, slot v) = b0 + v * kGroup + j
-    for (int i = tid; i < GV * 28; i += kBlock) {
+    for (int i = tid; i < GV * 28; i += kFbBlock) {
         const int vb = i / 28, k = i - vb * 28, bb = b0 + vb;
         float v = 0.f;
         // columns (x, y, w, z) of the view's combined matrix rows: the kernel only uses the first three of each row
@@ -697,7 +701,7 @@ k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ t
 static int face_bwd_vpl(int n) { return min(kMaxVPL, cdiv(n, kGroup)); }
 
 int face_bwd_groups(int n) { return cdiv(n, kGroup * face_bwd_vpl(n)); }
-int face_bwd_blocks(int F) { return cdiv(F, kBlock / kGroup); }
+int face_bwd_blocks(int F) { return cdiv(F, kFacesPerBlock); }
 
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
                   const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
@@ -709,7 +713,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     const int skip_lists = raster_use_queue(H, W, F) ? 1 : 0;      // coarse mesh: the queued large-box faces get their own kernel
     const PixGrid pg = make_pix_grid(H, W);
 #define FMHR_FACE_BWD(VPL)                                                                                                          \
-    k_face_bwd<VPL><<<grid, kBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
+    k_face_bwd<VPL><<<grid, kFbBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
                                              (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
                                              (float4*)part, skip_lists, pg)
     switch (face_bwd_vpl(n)) {
