@@ -127,3 +127,50 @@ def test_ncc_golden_and_grad(golden, oracle):
     sg = T(g["n_src"]).to(dev).requires_grad_(True)
     (NCC(rg, sg, None, T(g["n_mask"]).to(dev)) * w.to(dev)).sum().backward()
     assert rel_err(rg.grad, r64.grad) < TOL and rel_err(sg.grad, s64.grad) < TOL
+
+
+def test_edge_multiplicity_table_and_hinge_identity(oracle):
+    """fmhr_edge_multiplicity_build: faces per adjacency entry — 1 on a boundary edge, 2 inside, 3 on a non-manifold edge — and the
+    identity the mesh tail relies on: the reference's hinge, a sum over the 3F directed FACE edges (mesh_sfs_optim.py:296-302),
+    equals half the sum over the adjacency entries weighted by that multiplicity."""
+    from fmhr_amd._lib import call, ptr, stream_ptr, load
+    dev = torch.device("cuda:0")
+    lib = load()
+    sc = mesh_scene((1, 32, 32, 12, 16), seed=2)                 # open wrist: boundary edges
+    f = sc["faces"].clone()
+    v = sc["vertices"]
+    V = sc["V"]
+    # a fin on an existing edge makes it non-manifold (three faces), its two other edges are boundary edges of a new vertex
+    a, b = int(f[0, 0]), int(f[0, 1])
+    v = torch.cat([v, (v[a] + v[b])[None] * 0.5 + 0.01])
+    f = torch.cat([f, torch.tensor([[a, b, V]], dtype=f.dtype)])
+    V += 1
+    F = f.shape[0]
+    fd = f.to(dev).int().contiguous()
+    row_ptr = torch.zeros(V + 1, dtype=torch.int32, device=dev)
+    col = torch.zeros(6 * F, dtype=torch.int32, device=dev)
+    nb = lib.fmhr_adjacency_workspace_bytes(V, F)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    st = stream_ptr(dev)
+    call("fmhr_adjacency_build", ptr(fd), F, V, ptr(row_ptr), ptr(col), ptr(ws), nb, st)
+    nnz = int(row_ptr[-1])
+    mult = torch.zeros(nnz, dtype=torch.int32, device=dev)
+    call("fmhr_edge_multiplicity_build", ptr(fd), F, V, ptr(row_ptr), ptr(col), nnz, ptr(mult), st)
+    torch.cuda.synchronize()
+    rp, cc, mm = row_ptr.cpu().numpy(), col.cpu().numpy()[:nnz], mult.cpu().numpy()
+    fn = f.numpy()
+    cnt = {}
+    for t in fn:
+        for k in range(3):
+            e = (int(t[k]), int(t[(k + 1) % 3]))
+            cnt[(min(e), max(e))] = cnt.get((min(e), max(e)), 0) + 1
+    want = np.array([cnt[(min(i, int(j)), max(i, int(j)))] for i in range(V) for j in cc[rp[i]:rp[i + 1]]])
+    assert np.array_equal(mm, want)
+    assert set(np.unique(mm)) == {1, 2, 3}                       # boundary, interior, the fin's edge
+    assert mm.sum() == 2 * 3 * F                                 # every directed face edge is counted at both of its ends
+    # hinge identity on this mesh (fp64): sum over face edges == 1/2 sum over adjacency entries x multiplicity
+    x = v.double().numpy()
+    mean = 0.0003
+    face_sum = sum(np.clip(((x[t[k]] - x[t[(k + 1) % 3]]) ** 2).sum() - mean, 0.0, 1.0) for t in fn for k in range(3))
+    adj_sum = 0.5 * sum(mm[e] * np.clip(((x[i] - x[cc[e]]) ** 2).sum() - mean, 0.0, 1.0) for i in range(V) for e in range(rp[i], rp[i + 1]))
+    assert abs(face_sum - adj_sum) <= 1e-12 * max(1.0, abs(face_sum))
