@@ -32,6 +32,12 @@ class AdamParam(ctypes.Structure):
                 ("beta2", c_float), ("eps", c_float), ("step", ctypes.c_int32)]
 
 
+class Stage1Plan(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("V", ctypes.c_int32), ("rows", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("view_row0", c_void_p), ("view_valid", c_void_p), ("row_ptr", c_void_p), ("ent_col", c_void_p), ("ent_w", c_void_p),
+                ("row_n", c_void_p), ("row_img", c_void_p), ("t_ptr", c_void_p), ("t_row", c_void_p), ("t_w", c_void_p)]
+
+
 P = c_void_p
 # name -> (restype, argtypes); every name declared in include/fmhr_ham.h is listed (tests/test_abi.py checks both ways)
 SIGNATURES = {
@@ -74,6 +80,16 @@ SIGNATURES = {
     "fmhr_corner_slots_build": (c_int, [P, c_int, P, P]),
     "fmhr_vertex_faces_workspace_bytes": (c_size_t, [c_int]),
     "fmhr_vertex_faces_build": (c_int, [P, c_int, c_int, P, P, P, c_size_t, P]),
+    "fmhr_stage1_rows_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fmhr_stage1_rows": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, ctypes.c_longlong, P, c_size_t, P]),
+    "fmhr_stage1_row_ptr_workspace_bytes": (c_size_t, [c_int]),
+    "fmhr_stage1_row_ptr": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
+    "fmhr_stage1_fill": (c_int, [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    "fmhr_stage1_transpose_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "fmhr_stage1_transpose": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    "fmhr_stage1_step_workspace_bytes": (c_size_t, [ctypes.POINTER(Stage1Plan)]),
+    "fmhr_stage1_step": (c_int, [ctypes.POINTER(Stage1Plan), P, P, P, c_float, P, P, P, ctypes.POINTER(AdamParam),
+                                 ctypes.POINTER(AdamParam), P, c_size_t, P]),
 }
 
 _lib = None

@@ -4,9 +4,9 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libfmhr_ham.so
-SRCS="abi.cpp raster.hip antialias.hip mesh.hip shade.hip ncc.hip ham_step.hip"
+SRCS="abi.cpp raster.hip antialias.hip mesh.hip shade.hip ncc.hip ham_step.hip stage1.hip"
 NEW=0
-for f in $SRCS common.h shade_common.h ../../include/fmhr_ham.h build.sh; do
+for f in $SRCS common.h shade_common.h adam.h ../../include/fmhr_ham.h build.sh; do
   if [ ! -f "$OUT" ] || [ "$f" -nt "$OUT" ]; then NEW=1; fi
 done
 if [ "$NEW" = "0" ] && [ "${FMHR_FORCE_BUILD:-0}" = "0" ]; then echo "libfmhr_ham.so up to date"; exit 0; fi

@@ -3,14 +3,10 @@
 // caller's stream, nothing synchronises, so the pair is hipGraph-capturable.
 #include "common.h"
 #include "shade_common.h"
+#include "adam.h"
 #include <string.h>
 
 namespace fmhr {
-struct AdamTensor {
-    float* p; const float* g; float* m; float* v; long long n;
-    float beta1, beta2, eps, step_size, bc2_sqrt;
-};
-int adam_tensor_from(AdamTensor&, const fmhr_adam_param*, long long);
 struct MeshTailArgs {
     const float4* part; float* gvert_aa; int G;
     float* gvert_aa2;

@@ -3,6 +3,7 @@
 // Replaces get_normals / get_radiance / laplacian_smoothing("uniform") of /root/reference/models/utils.py:508-548,
 // 208-226, 696-722 and the inline code of /root/reference/mesh_sfs_optim.py:262-264, 296-304.
 #include "common.h"
+#include "adam.h"
 #include <math.h>
 #include <string.h>
 
@@ -275,23 +276,6 @@ __device__ __forceinline__ void transform_body(int v, int b, const float* __rest
 // ------------------------------------------------------------------------------------------------ Adam (A13)
 // torch.optim.Adam step (amsgrad=False, weight_decay=0, maximize=False) — mesh_sfs_optim.py:244,310.  torch's fused
 // multi_tensor kernel takes ~94 us per parameter group here (147k elements each); this one is bandwidth-trivial.
-struct AdamTensor {
-    float* p; const float* g; float* m; float* v; long long n;
-    float beta1, beta2, eps, step_size, bc2_sqrt;
-};
-
-// one element of torch.optim.Adam's update; every user (k_adam, k_adam2, the fused forms in k_mesh_tail_b / k_ham_combine) goes
-// through these statements, so the fused and the stand-alone update agree bit for bit
-__device__ __forceinline__ void adam_element(const AdamTensor& T, long long i, float gi)
-{
-    float mi = T.m[i];
-    mi = mi + (gi - mi) * (1.0f - T.beta1);                      // exp_avg.lerp_(grad, 1 - beta1)
-    float vi = T.v[i] * T.beta2 + (1.0f - T.beta2) * gi * gi;    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    T.m[i] = mi; T.v[i] = vi;
-    float denom = sqrtf(vi) / T.bc2_sqrt + T.eps;
-    T.p[i] = T.p[i] - T.step_size * (mi / denom);
-}
-
 __global__ void __launch_bounds__(kBlock) k_adam(const AdamTensor T)
 {
     long long i = (long long)blockIdx.x * kBlock + threadIdx.x;

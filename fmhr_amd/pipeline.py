@@ -1,6 +1,7 @@
 """fmhr_amd.pipeline — the whole HAM optimisation of /root/reference/mesh_sfs_optim.py:30-343 on the MI355X library
-(SURVEY.md §8f rows N3 / N4): SH least-squares initialisation (:124-174), stage 1 "albedo" (:193-240, op-by-op on
-fmhr_amd.dr / fmhr_amd.utils with autograd), stage 2 "sfs" (:242-317, the fused HamStage2 step), export (:319-343).
+(SURVEY.md §8f rows N3 / N4): SH least-squares initialisation (:124-174), stage 1 "albedo" (:193-240, the fused HamStage1 step;
+`stage1_loss` is its op-by-op form on fmhr_amd.dr / fmhr_amd.utils with autograd), stage 2 "sfs" (:242-317, the fused HamStage2
+step), export (:319-343).
 
 `init_sh` and `stage1_loss` take the operator module as an argument (anything with the nvdiffrast surface + the models/utils.py
 helpers), so the parity tests can run the very same code on the CPU checker; the product passes fmhr_amd.dr / fmhr_amd.utils.
@@ -134,19 +135,23 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     elm = edge_length_mean(vertices_tmp, faces)                                      # :184-188
     history = []
     # ---- stage 1: albedo + SH (:193-240)
+    # the fused step (fmhr_amd.stage1.HamStage1): the constant sub-graph and the linear interpolate + antialias operator are built
+    # once, an iteration is one C call (two launches), the Adam update of both parameters applied inside it.  `stage1_loss` /
+    # `stage1_loss_cached` above are the op-by-op forms the parity tests compare it with.
+    if degree != 3:
+        raise RuntimeError("run_ham: the fused stage-1 step evaluates the order-3 SH basis (degree = 3, conf/demo_sfs.conf:29)")
+    from .stage1 import HamStage1
     opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
-    glctx = ops.RasterizeGLContext()
-    cache = Stage1Cache(ops, glctx, vertices_tmp, faces, w2cs, projs, masks, resolution, degree)
+    hs1 = HamStage1(vertices_tmp, faces, w2cs, projs, imgs, masks, resolution, conf["sfs_weight"])
     for ep in range(int(conf["epoch_albedo"])):
         perm = torch.randperm(num, generator=gen).to(dev)
         for k in range(0, num, batch):
             idx = perm[k:k + batch]
-            loss = stage1_loss_cached(ops, cache, idx, albedo, sh_coeffs[idx], imgs[idx], conf["sfs_weight"])
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
+            loss_view, _, _ = hs1.step(albedo, sh_coeffs, idx=None if idx.numel() == num else idx, optimizer=opt,
+                                       params=(albedo, sh_coeffs))
         if log_every and ep % log_every == 0:
-            history.append(("albedo", ep, float(loss)))
+            history.append(("albedo", ep, float(loss_view.sum())))
+    del hs1
     # ---- stage 2: vertex offsets + albedo (:242-317), fused step
     sh_fixed = sh_coeffs.detach()
     weights = dict(sfs=conf["sfs_weight"], lap=conf["lap_weight"], albedo=conf["albedo_weight"], mask=conf["mask_weight"],

@@ -1,0 +1,122 @@
+"""fmhr_amd.stage1 — the fused stage-1 ("albedo") iteration of /root/reference/mesh_sfs_optim.py:196-240.
+
+Stage 1 optimises the albedo [1,V,3] and the SH coefficients [num,9] with the vertices frozen (:191, :195), so everything geometric
+of its loop body (:205-219) — rasterization, interpolated + antialiased + normalised normals, the validity mask, and the antialias
+operator itself, a linear map of its colour input once the geometry is fixed — is the same in every iteration.  `HamStage1` computes
+that constant part ONCE with the generic ops (fmhr_amd.dr / fmhr_amd.utils: the same C-ABI kernels `stage1_loss` uses), hands it to
+the library's plan builder (include/fmhr_ham.h: fmhr_stage1_rows / _row_ptr / _fill / _transpose) and then runs an iteration as ONE
+C call of two launches, `fmhr_stage1_step`: value and gradients of `pipeline.stage1_loss`, Adam optionally applied in the kernel.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, dr, utils
+from ._lib import call, ptr, stream_ptr
+
+
+class HamStage1:
+    def __init__(self, vertices, faces, w2cs, projs, imgs, masks, resolution, sfs_weight, chunk=8):
+        """vertices [V,3], faces [F,3], w2cs / projs [num,4,4], imgs [num,H,W,3], masks [num,H,W] (all on the GPU)."""
+        _lib.require_gpu("HamStage1", vertices, w2cs, projs, imgs, masks)
+        self.lib = _lib.load()
+        dev = vertices.device
+        self.dev, self.sfs_weight = dev, float(sfs_weight)
+        H, W = resolution
+        num, V = w2cs.shape[0], vertices.shape[0]
+        self.n, self.V, self.H, self.W = num, V, H, W
+        faces = faces.to(device=dev, dtype=torch.int32).contiguous()
+        Fn = faces.shape[0]
+        imgs = imgs.to(torch.float32).contiguous()
+        masks = masks.to(torch.float32).contiguous()
+        st = stream_ptr(dev)
+        # ---- the constant sub-graph (:207-218), `chunk` views at a time: rast, normals, antialias work items
+        rast = torch.empty(num, H, W, 4, dtype=torch.float32, device=dev)
+        normals = torch.empty(num, H, W, 3, dtype=torch.float32, device=dev)
+        items, alphas = [], []
+        glctx = dr.RasterizeGLContext()
+        with torch.no_grad():
+            for k in range(0, num, chunk):
+                w2c, proj = w2cs[k:k + chunk], projs[k:k + chunk]
+                c = w2c.shape[0]
+                vertsw = torch.cat([vertices, torch.ones_like(vertices[:, 0:1])], dim=1).unsqueeze(0).expand(c, -1, -1)
+                pos = torch.einsum('ijk,ikl->ijl', torch.einsum('ijk,ikl->ijl', vertsw, w2c), proj).contiguous()
+                vn = utils.get_normals(vertsw[:, :, :3].contiguous(), faces.long())
+                r, _ = dr.rasterize(glctx, pos, faces, resolution=resolution)
+                feat, _ = dr.interpolate(vn.contiguous(), r, faces)
+                aa, it, al, overflow = dr.antialias_debug_items(feat.contiguous(), r, pos, faces)
+                if overflow:
+                    raise RuntimeError("HamStage1: antialias work-item list overflow")
+                rast[k:k + c] = r
+                normals[k:k + c] = F.normalize(aa, p=2, dim=3)
+                it = it.clone()
+                it[:, 2] += k                                        # view index within the chunk -> global
+                items.append(it); alphas.append(al.clone())
+        items = torch.cat(items).contiguous() if items else torch.zeros(0, 4, dtype=torch.int32, device=dev)
+        alphas = torch.cat(alphas).contiguous() if alphas else torch.zeros(0, dtype=torch.float32, device=dev)
+        n_items = int(items.shape[0])
+        self.n_items = n_items
+        # ---- the plan
+        N = num * H * W
+        i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        rowid, self.view_row0, self.view_valid = i32(N), i32(num + 1), i32(num)
+        flags_len = N + num * 255
+        row_flags = i32(flags_len)
+        nb = self.lib.fmhr_stage1_rows_workspace_bytes(num, H, W)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        call("fmhr_stage1_rows", ptr(rast), ptr(masks), num, H, W, ptr(rowid), ptr(self.view_row0), ptr(self.view_valid), ptr(row_flags),
+             flags_len, ptr(ws), nb, st)
+        rows = int(self.view_row0[num])                               # host read (setup only)
+        self.rows = rows
+        self.row_ptr = i32(rows + 1)
+        nb = self.lib.fmhr_stage1_row_ptr_workspace_bytes(rows)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        call("fmhr_stage1_row_ptr", ptr(rast), ptr(rowid), ptr(items), ptr(alphas), n_items, num, H, W, rows, ptr(row_flags),
+             ptr(self.row_ptr), ptr(ws), nb, st)
+        E = int(self.row_ptr[rows])
+        self.entries = E
+        self.ent_col, self.ent_w = i32(max(E, 1)), f32(max(E, 1))
+        self.row_n, self.row_img = f32(max(rows, 1), 3), f32(max(rows, 1), 3)
+        call("fmhr_stage1_fill", ptr(rast), ptr(faces), ptr(rowid), ptr(items), ptr(alphas), n_items, ptr(normals), ptr(imgs), num, V, Fn, H, W,
+             rows, ptr(row_flags), ptr(self.row_ptr), ptr(self.ent_col), ptr(self.ent_w), ptr(self.row_n), ptr(self.row_img), st)
+        self.t_ptr, self.t_row, self.t_w = i32(num * V + 1), i32(max(E, 1)), f32(max(E, 1))
+        nb = self.lib.fmhr_stage1_transpose_workspace_bytes(num, V)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        call("fmhr_stage1_transpose", ptr(self.row_ptr), ptr(self.ent_col), ptr(self.ent_w), ptr(self.view_row0), num, V, rows,
+             ptr(self.t_ptr), ptr(self.t_row), ptr(self.t_w), ptr(ws), nb, st)
+        torch.cuda.synchronize(dev)                                   # the scratch tensors above go out of scope
+        self.plan = _lib.Stage1Plan(num, V, rows, 0, self.view_row0.data_ptr(), self.view_valid.data_ptr(), self.row_ptr.data_ptr(),
+                                    self.ent_col.data_ptr(), self.ent_w.data_ptr(), self.row_n.data_ptr(), self.row_img.data_ptr(),
+                                    self.t_ptr.data_ptr(), self.t_row.data_ptr(), self.t_w.data_ptr())
+        self.ws_bytes = self.lib.fmhr_stage1_step_workspace_bytes(ctypes.byref(self.plan))
+        self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
+        self.galbedo, self.gsh, self.loss_view = f32(V, 3), f32(num, 9), f32(num)
+        self.view_sel = torch.ones(num, dtype=torch.int32, device=dev)
+        self.rast, self.normals = rast, normals                      # kept for inspection / the parity tests
+
+    def step(self, albedo, sh_coeffs, idx=None, optimizer=None, params=None):
+        """One iteration on the views `idx` (None: all).  albedo [1,V,3] or [V,3], sh_coeffs [num,9].  Returns (loss_view [num],
+        galbedo [V,3], gsh [num,9]) — device tensors, overwritten by the next call; the loss of mesh_sfs_optim.py:233 is
+        loss_view.sum() (the views' shares; no extra launch unless somebody asks).  With `optimizer` (fmhr_amd.optim.Adam) and
+        params = (albedo, sh_coeffs) the Adam update of both is applied by the step's second kernel (no optimizer.step())."""
+        _lib.require_gpu("HamStage1.step", albedo, sh_coeffs)
+        a = albedo.detach().reshape(self.V, 3)
+        s = sh_coeffs.detach()
+        if not (a.is_contiguous() and s.is_contiguous() and a.dtype == torch.float32 and s.dtype == torch.float32):
+            raise RuntimeError("HamStage1.step: albedo / sh_coeffs must be contiguous float32")
+        if s.shape != (self.n, 9):
+            raise RuntimeError(f"HamStage1.step: sh_coeffs must be [{self.n}, 9]")
+        sel = None
+        if idx is not None:
+            self.view_sel.zero_()
+            self.view_sel[idx.long()] = 1
+            sel = self.view_sel
+        adam = (None, None)
+        if optimizer is not None:
+            adam = (optimizer.fused_param(params[0]), optimizer.fused_param(params[1]))
+        call("fmhr_stage1_step", ctypes.byref(self.plan), ptr(a), ptr(s), ptr(sel), self.sfs_weight, ptr(self.galbedo), ptr(self.gsh),
+             ptr(self.loss_view), ctypes.byref(adam[0]) if adam[0] is not None else None,
+             ctypes.byref(adam[1]) if adam[1] is not None else None, ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
+        return self.loss_view, self.galbedo, self.gsh

@@ -234,6 +234,47 @@ long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const char* name);
  * so the views above can be inspected as dense arrays.  Call it after the step whose state you want. */
 int fmhr_ham_densify(const fmhr_ham_dims* d, const int32_t* tri, const float* sh, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ fused stage-1 step
+ * The "albedo" iteration, mesh_sfs_optim.py:205-236 (vertices constant; parameters albedo [V,3] and sh_coeffs [n,9]; loss =
+ * sfs_weight * L1 over the valid pixels of the batch).  With the geometry fixed, interpolate + antialias of the albedo is one fixed
+ * sparse linear map per valid pixel; the PLAN holds it (and its per-view transpose) and is built ONCE per stage from the outputs of
+ * the generic ops above, in four calls with two host reads of a count in between:
+ *   1. fmhr_stage1_rows      rast / mask -> rowid [n*H*W] (row of a valid pixel = mask > 0 and covered, else -1), view_row0 [n+1]
+ *                            (first row of each view, multiples of 256; [n] = total rows, padding included), view_valid [n]
+ *   2. fmhr_stage1_row_ptr   + the antialias work items (fmhr_antialias_fwd's items / alphas of ANY colour on this rast) ->
+ *                            row_ptr [rows+1]; row_ptr[rows] = number of entries
+ *   3. fmhr_stage1_fill      -> entries (ent_col, ent_w) and the rows' constants: row_n [rows,3] = the antialiased, normalised normal
+ *                            (:217-218, computed by the caller with the generic ops), row_img [rows,3] = the target colour
+ *   4. fmhr_stage1_transpose -> t_ptr [V*n+1], t_row / t_w [entries]: per (vertex, view) the rows it contributes to, sorted by row
+ * A step is then fmhr_stage1_step: two launches, gather-only (deterministic), the two Adam updates optionally fused in. */
+size_t fmhr_stage1_rows_workspace_bytes(int n, int H, int W);
+/* row_flags: scratch of row_flags_len >= n*H*W + n*255 ints, kept by the caller until step 3 */
+int fmhr_stage1_rows(const float* rast, const float* mask, int n, int H, int W, int32_t* rowid, int32_t* view_row0,
+                     int32_t* view_valid, int32_t* row_flags, long long row_flags_len, void* ws, size_t ws_bytes, void* stream);
+size_t fmhr_stage1_row_ptr_workspace_bytes(int rows);
+int fmhr_stage1_row_ptr(const float* rast, const int32_t* rowid, const int32_t* items, const float* alphas, int n_items, int n,
+                        int H, int W, int rows, int32_t* row_flags, int32_t* row_ptr, void* ws, size_t ws_bytes, void* stream);
+int fmhr_stage1_fill(const float* rast, const int32_t* tri, const int32_t* rowid, const int32_t* items, const float* alphas,
+                     int n_items, const float* normals, const float* img, int n, int V, int F, int H, int W, int rows,
+                     const int32_t* row_flags, const int32_t* row_ptr, int32_t* ent_col, float* ent_w, float* row_n,
+                     float* row_img, void* stream);
+size_t fmhr_stage1_transpose_workspace_bytes(int n, int V);
+int fmhr_stage1_transpose(const int32_t* row_ptr, const int32_t* ent_col, const float* ent_w, const int32_t* view_row0, int n, int V,
+                          int rows, int32_t* t_ptr, int32_t* t_row, float* t_w, void* ws, size_t ws_bytes, void* stream);
+typedef struct fmhr_stage1_plan {
+    int32_t n, V, rows, reserved;           /* views, vertices, rows (a multiple of 256) */
+    const int32_t* view_row0; const int32_t* view_valid; const int32_t* row_ptr; const int32_t* ent_col; const float* ent_w;
+    const float* row_n; const float* row_img; const int32_t* t_ptr; const int32_t* t_row; const float* t_w;
+} fmhr_stage1_plan;
+size_t fmhr_stage1_step_workspace_bytes(const fmhr_stage1_plan* plan);
+/* One iteration on the views with view_sel[b] != 0 (view_sel == NULL: all n).  albedo [V,3], sh [n,9] (row b = view b).
+ * Out: galbedo [V,3], gsh [n,9] (zero rows outside the batch), loss_view [n]: the views' shares of the loss (their sum is the
+ * loss value of :233).  adam_albedo / adam_sh (may be NULL): the parameters are updated in place, every row of sh included (a
+ * view outside the batch has a zero gradient, its moments still decay — torch.optim.Adam on the dense gradient). */
+int fmhr_stage1_step(const fmhr_stage1_plan* plan, const float* albedo, const float* sh, const int32_t* view_sel, float sfs_weight,
+                     float* galbedo, float* gsh, float* loss_view, const fmhr_adam_param* adam_albedo,
+                     const fmhr_adam_param* adam_sh, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ per-kernel timing (optional)
  * Attach an array of 2*FMHR_SLOT_COUNT hipEvent_t (created by the caller with timing enabled) to the CALLING THREAD: while
  * attached, fmhr_ham_forward/backward record events[2*slot] / events[2*slot+1] around launch group `slot` on the step's

@@ -31,3 +31,20 @@ t0 = time.perf_counter()
 for _ in range(K): l = step()
 torch.cuda.synchronize()
 print(f"stage-1 step, {n} views {H}x{W}, V={V}: {1e3*(time.perf_counter()-t0)/K:.3f} ms/step (cached rasterization: {cache is not None}), loss {float(l):.5f}")
+
+# the fused form (fmhr_amd.stage1.HamStage1: plan built once, two launches per iteration, Adam inside)
+from fmhr_amd.stage1 import HamStage1
+t0 = time.perf_counter()
+hs = HamStage1(vt, faces, w2c, proj, tg["img"], tg["mask"], (H, W), 50.0)
+torch.cuda.synchronize()
+t_plan = time.perf_counter() - t0
+albedo2 = sc["albedo0"][None].to(dev).clone().requires_grad_(True)
+sh2 = sh.clone().requires_grad_(True)
+opt2 = Adam([{'params': albedo2, 'lr': 5e-3}, {'params': sh2, 'lr': 5e-3}])
+for _ in range(5): hs.step(albedo2, sh2, optimizer=opt2, params=(albedo2, sh2))
+torch.cuda.synchronize()
+K = 200
+t0 = time.perf_counter()
+for _ in range(K): l2, _, _ = hs.step(albedo2, sh2, optimizer=opt2, params=(albedo2, sh2))
+torch.cuda.synchronize()
+print(f"fused stage-1 step: {1e3*(time.perf_counter()-t0)/K:.4f} ms/step (plan: {t_plan*1e3:.0f} ms once; rows {hs.rows}, entries {hs.entries}, antialias items {hs.n_items}), loss {float(l2.sum()):.5f}")
