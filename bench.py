@@ -13,6 +13,8 @@ Prints ONE JSON line on rank 0 with the contract fields plus:
   step_roofline— the same for the whole step: n*B_alg(view)+const bytes / device time of the step
   kernels      — mean HIP-event milliseconds per launch group (from an untimed profiling pass)
   cpu_baseline — the CPU oracle restatement ("port") timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+  stage1       — side measurement (N=1 only, after the timed region): the fused stage-1 iteration of the same optimisation
+                 (mesh_sfs_optim.py:205-236) on the same workload; not part of `value`
 """
 import argparse
 import json
@@ -127,6 +129,39 @@ def cpu_baseline(scene, views_sample, seed):
                        f"C rasterizer is single-threaded, torch ops use {cores} threads")
 
 
+def stage1_side_measurement(scene, faces, w2c, proj, sh, tg, vtmp, H, W, dev, steps=100):
+    """Not the headline metric: the OTHER loop of the HAM optimisation, stage 1 (mesh_sfs_optim.py:196-240: albedo + SH, vertices
+    frozen), on the same workload — the fused HamStage1 step (two launches, Adam inside) timed with HIP events after the timed
+    region, and priced against the bytes of its own tables (every table read once, the gradient image written and gathered once)."""
+    from fmhr_amd.optim import Adam
+    from fmhr_amd.stage1 import HamStage1
+    t0 = time.perf_counter()
+    hs1 = HamStage1(vtmp, faces, w2c, proj, tg["img"], tg["mask"], (H, W), scene["weights"]["sfs"])
+    torch.cuda.synchronize()
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    albedo = scene["albedo0"][None].to(dev).clone().requires_grad_(True)
+    shc = sh.clone().requires_grad_(True)
+    lr = scene["lr"]
+    opt = Adam([{'params': albedo, 'lr': lr["albedo_lr"]}, {'params': shc, 'lr': lr.get("sh_lr", lr["albedo_lr"])}])
+    for _ in range(5):
+        hs1.step(albedo, shc, optimizer=opt, params=(albedo, shc))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        lv, _, _ = hs1.step(albedo, shc, optimizer=opt, params=(albedo, shc))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    V = albedo.shape[1]
+    # forward: row_ptr + entries + normal + target + R per row; backward: transposed entries + one R gather per entry + Adam state
+    nbytes = hs1.rows * (4 + 12 + 12 + 12) + hs1.entries * 8 + hs1.entries * (8 + 12) + V * 3 * 4 * 7
+    return {"what": "fused stage-1 (albedo + SH) step, mesh_sfs_optim.py:205-236, same views / mesh", "ms_per_step": round(ms, 4),
+            "iterations_per_s": round(1e3 / ms, 1), "plan_ms_once": round(plan_ms, 1), "rows": hs1.rows, "entries": hs1.entries,
+            "antialias_items": hs1.n_items, "table_bytes_per_step": nbytes, "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "loss": round(float(lv.sum()), 6), "steps": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +170,7 @@ def main():
     ap.add_argument("--config", default="metric", choices=list(synthetic.CONFIGS))
     ap.add_argument("--views", type=int, default=None, help="override the view count of the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage1", action="store_true", help="skip the stage-1 side measurement (N = 1 only; after the timed region)")
     ap.add_argument("--cpu-views", type=int, default=48)   # the whole 48-view batch: 5 x ~2.6 s of CPU work, nothing extrapolated
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -273,6 +309,8 @@ def main():
                            "hbm_bytes": (traffic or {}).get(k)} for k, v in kernels.items() if alg_bytes(k, n, P, V, F, hs.nnz) > 0},
             "losses": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in final.items()},
         }
+        if world == 1 and not args.no_stage1:
+            out["stage1"] = stage1_side_measurement(scene, faces, w2c, proj, sh, tg, vtmp, H, W, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, max(1, min(args.cpu_views, n_total)), args.seed)
         print(json.dumps(out))

@@ -18,8 +18,14 @@
 
 namespace fmhr {
 
-constexpr int kS1Sub = 16;           // lanes per vertex in the backward
-constexpr int kS1U = 4;              // entries a lane has in flight
+#ifndef FMHR_S1_SUB
+#define FMHR_S1_SUB 16
+#endif
+#ifndef FMHR_S1_U
+#define FMHR_S1_U 8
+#endif
+constexpr int kS1Sub = FMHR_S1_SUB;  // lanes per vertex in the backward
+constexpr int kS1U = FMHR_S1_U;      // entries a lane has in flight (8 / 16 / 32 lanes x 2 / 4 / 8 entries: 0.090 - 0.094 ms per step, 64 lanes 0.101)
 constexpr int AA_DOWN_BIT = 4;       // antialias.hip: item code bit "the pair is (pixel, pixel below)"
 
 // ------------------------------------------------------------------------------------------------ plan: rows
@@ -256,23 +262,32 @@ k_s1_fwd(const S1Plan P, const float* __restrict__ albedo, const float* __restri
     for (int i = 0; i < 10; i++) acc[i] = 0.f;
     const int e0 = P.row_ptr[row], e1 = P.row_ptr[row + 1];
     if (e1 > e0) {
+        // the row's constants do not depend on its entries: requested with them (one dependent chain row_ptr -> entries -> albedo)
+        const F3U nrm = *reinterpret_cast<const F3U*>(P.row_n + (size_t)row * 3);
+        const F3U tgt = *reinterpret_cast<const F3U*>(P.row_img + (size_t)row * 3);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int e = e0; e < e1; e++) {
-            const float w = P.ent_w[e];
-            const float* q = albedo + (size_t)P.ent_col[e] * 3;
-            a0 += w * q[0]; a1 += w * q[1]; a2 += w * q[2];
+        {   // every row has at least the three entries of its own triangle: all three in flight at once
+            const int c0 = P.ent_col[e0], c1 = P.ent_col[e0 + 1], c2 = P.ent_col[e0 + 2];
+            const float w0 = P.ent_w[e0], w1 = P.ent_w[e0 + 1], w2 = P.ent_w[e0 + 2];
+            const F3U q0 = *reinterpret_cast<const F3U*>(albedo + (size_t)c0 * 3), q1 = *reinterpret_cast<const F3U*>(albedo + (size_t)c1 * 3),
+                      q2 = *reinterpret_cast<const F3U*>(albedo + (size_t)c2 * 3);
+            a0 = w0 * q0.x + w1 * q1.x + w2 * q2.x; a1 = w0 * q0.y + w1 * q1.y + w2 * q2.y; a2 = w0 * q0.z + w1 * q1.z + w2 * q2.z;
         }
-        const float x = P.row_n[(size_t)row * 3], y = P.row_n[(size_t)row * 3 + 1], z = P.row_n[(size_t)row * 3 + 2];
+        for (int e = e0 + 3; e < e1; e++) {                          // pairs that blend into this pixel (a few rows in a thousand)
+            const float w = P.ent_w[e];
+            const F3U q = *reinterpret_cast<const F3U*>(albedo + (size_t)P.ent_col[e] * 3);
+            a0 += w * q.x; a1 += w * q.y; a2 += w * q.z;
+        }
+        const float x = nrm.x, y = nrm.y, z = nrm.z;
         const float bs[9] = {1.0f, y, z, x, x * y, y * z, 2.0f * z * z - x * x - y * y, z * x, x * x - y * y};
         float rad = 0.f;
 #pragma unroll
         for (int i = 0; i < 9; i++) rad += sh[(size_t)b * 9 + i] * bs[i];
-        const float d0 = rad * a0 - P.row_img[(size_t)row * 3], d1 = rad * a1 - P.row_img[(size_t)row * 3 + 1],
-                    d2 = rad * a2 - P.row_img[(size_t)row * 3 + 2];
+        const float d0 = rad * a0 - tgt.x, d1 = rad * a1 - tgt.y, d2 = rad * a2 - tgt.z;
         const float s0 = (d0 > 0.f) ? 1.f : ((d0 < 0.f) ? -1.f : 0.f), s1 = (d1 > 0.f) ? 1.f : ((d1 < 0.f) ? -1.f : 0.f),
                     s2 = (d2 > 0.f) ? 1.f : ((d2 < 0.f) ? -1.f : 0.f);
         const float kr = k * rad;
-        R[(size_t)row * 3] = kr * s0; R[(size_t)row * 3 + 1] = kr * s1; R[(size_t)row * 3 + 2] = kr * s2;
+        *reinterpret_cast<F3U*>(R + (size_t)row * 3) = F3U{kr * s0, kr * s1, kr * s2};
         const float t = k * (s0 * a0 + s1 * a1 + s2 * a2);          // d loss / d radiance
 #pragma unroll
         for (int i = 0; i < 9; i++) acc[i] = t * bs[i];

@@ -16,7 +16,8 @@ glctx = ops.RasterizeGLContext()
 albedo = sc["albedo0"][None].to(dev).clone().requires_grad_(True)
 shc = sh.clone().requires_grad_(True)
 opt = Adam([{'params': albedo, 'lr': 5e-3}, {'params': shc, 'lr': 5e-3}])
-cache = pipeline.Stage1Cache(ops, glctx, vt, faces, w2c, proj, tg["mask"], (H, W)) if (len(sys.argv) < 3 or sys.argv[2] != "nocache") else None
+cache = pipeline.Stage1Cache(ops, glctx, vt, faces, w2c, proj, tg["mask"], (H, W)) if (len(sys.argv) < 3 or sys.argv[2] not in ("nocache", "fusedonly")) else None
+fusedonly = len(sys.argv) > 2 and sys.argv[2] == "fusedonly"
 def step():
     if cache is not None:
         loss = pipeline.stage1_loss_cached(ops, cache, torch.arange(n, device=dev), albedo, shc, tg["img"], 50.0)
@@ -24,13 +25,13 @@ def step():
         loss = pipeline.stage1_loss(ops, glctx, vt, faces, albedo, shc, w2c, proj, tg["img"], tg["mask"], (H, W), 50.0)
     opt.zero_grad(); loss.backward(); opt.step()
     return loss
-for _ in range(5): step()
+K = 30 if not fusedonly else 0
+for _ in range(5 if not fusedonly else 0): step()
 torch.cuda.synchronize()
-K = 30
 t0 = time.perf_counter()
 for _ in range(K): l = step()
 torch.cuda.synchronize()
-print(f"stage-1 step, {n} views {H}x{W}, V={V}: {1e3*(time.perf_counter()-t0)/K:.3f} ms/step (cached rasterization: {cache is not None}), loss {float(l):.5f}")
+if not fusedonly: print(f"stage-1 step, {n} views {H}x{W}, V={V}: {1e3*(time.perf_counter()-t0)/K:.3f} ms/step (cached rasterization: {cache is not None}), loss {float(l):.5f}")
 
 # the fused form (fmhr_amd.stage1.HamStage1: plan built once, two launches per iteration, Adam inside)
 from fmhr_amd.stage1 import HamStage1
