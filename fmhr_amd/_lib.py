@@ -87,6 +87,8 @@ SIGNATURES = {
     "fmhr_stage1_fill": (c_int, [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "fmhr_stage1_transpose_workspace_bytes": (c_size_t, [c_int, c_int]),
     "fmhr_stage1_transpose": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    "fmhr_sh_normal_equations": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "fmhr_sh_albedo_sums": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "fmhr_stage1_step_workspace_bytes": (c_size_t, [ctypes.POINTER(Stage1Plan)]),
     "fmhr_stage1_step": (c_int, [ctypes.POINTER(Stage1Plan), P, P, P, c_float, P, P, P, ctypes.POINTER(AdamParam),
                                  ctypes.POINTER(AdamParam), P, c_size_t, P]),

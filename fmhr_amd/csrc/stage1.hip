@@ -387,6 +387,88 @@ k_s1_bwd(const S1Plan P, const float* __restrict__ R, const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ SH least-squares initialisation
+// mesh_sfs_optim.py:150-154,164-166: per view (and over all views) the 9 SH coefficients that fit the gray image on the valid pixels,
+// np.linalg.lstsq on a [Pv, 9] float64 design matrix — on the host, one view at a time, 2.8 of the 3.0 s of a 48-view run_ham.
+// The normal equations need only sum phi phi^T (45 numbers) and sum phi g (9) per view: accumulated here in float64 over the valid
+// pixels (the basis products in float32 first, as get_matrix forms them from float32 normals, models/utils.py:188-205), as per-
+// workgroup partials (summed on the host in a fixed order); the 9 x 9 solves stay on the host.
+constexpr int kShAcc = 55;           // 45 upper-triangle entries, 9 right-hand sides, the pixel count
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_sh_normal_eq(const float* __restrict__ normals, const float4* __restrict__ rast, const float* __restrict__ mask, const float* __restrict__ gray,
+               long long P, double* __restrict__ part)
+{
+    __shared__ double sm[4][kShAcc];
+    const int b = blockIdx.y;
+    double acc[kShAcc];
+#pragma unroll
+    for (int i = 0; i < kShAcc; i++) acc[i] = 0.0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < P; i += (long long)gridDim.x * kBlock) {
+        const long long g = (long long)b * P + i;
+        if (!(mask[g] > 0.f && rast[g].w > 0.f)) continue;
+        const float x = normals[g * 3], y = normals[g * 3 + 1], z = normals[g * 3 + 2];
+        const float t0 = 2.0f * z * z, t1 = x * x, t2 = y * y;
+        const double ph[9] = {1.0, (double)y, (double)z, (double)x, (double)(x * y), (double)(y * z), (double)((t0 - t1) - t2), (double)(z * x),
+                              (double)(t1 - t2)};
+        const double gv = (double)gray[g];
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++)
+#pragma unroll
+            for (int c = r; c < 9; c++) acc[k++] += ph[r] * ph[c];
+#pragma unroll
+        for (int r = 0; r < 9; r++) acc[45 + r] += ph[r] * gv;
+        acc[54] += 1.0;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kShAcc; i++) {
+        const double r = wave_sum_d(acc[i]);
+        if (lane == 0) sm[wv][i] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < kShAcc)
+        part[((size_t)b * gridDim.x + blockIdx.x) * kShAcc + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+}
+
+// sums of img / radiance(sh, normal) over the valid pixels (:173-174: albedo_mean), float32 per pixel as the reference's GPU tensors
+__global__ void __launch_bounds__(kBlock)
+k_sh_albedo_sums(const float* __restrict__ normals, const float4* __restrict__ rast, const float* __restrict__ mask, const float* __restrict__ img,
+                 const float* __restrict__ sh, long long P, double* __restrict__ part)
+{
+    __shared__ double sm[4][4];
+    const int b = blockIdx.y;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    float c[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) c[i] = sh[i];
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < P; i += (long long)gridDim.x * kBlock) {
+        const long long g = (long long)b * P + i;
+        if (!(mask[g] > 0.f && rast[g].w > 0.f)) continue;
+        const float x = normals[g * 3], y = normals[g * 3 + 1], z = normals[g * 3 + 2];
+        float r = c[0];                                              // models/utils.py:214-226, statement for statement
+        r = r + c[1] * y; r = r + c[2] * z; r = r + c[3] * x;
+        r = r + c[4] * x * y; r = r + c[5] * y * z; r = r + c[6] * (2.0f * z * z - x * x - y * y); r = r + c[7] * z * x; r = r + c[8] * (x * x - y * y);
+        acc[0] += (double)(img[g * 3] / r); acc[1] += (double)(img[g * 3 + 1] / r); acc[2] += (double)(img[g * 3 + 2] / r);
+        acc[3] += 1.0;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double r = wave_sum_d(acc[i]);
+        if (lane == 0) sm[wv][i] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) part[((size_t)b * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+}
+
 static int scan_exclusive(const int* in, int* out, size_t count, void* tmp, size_t tmp_bytes, hipStream_t st)
 {
     size_t need = 0;
@@ -562,5 +644,28 @@ extern "C" int fmhr_stage1_step(const fmhr_stage1_plan* p, const float* albedo, 
     const int vblocks = cdiv((long long)p->V * kS1Sub, kBlock);
     k_s1_bwd<<<vblocks + p->n, kBlock, 0, st>>>(P, R, part, view_sel, sfs_weight, galbedo, gsh, loss_view, ad_a, ad_s, vblocks);
     FMHR_CHECK_LAUNCH("k_s1_bwd");
+    return FMHR_OK;
+}
+
+// ---- SH least-squares initialisation: per-workgroup partial sums, part [n, nblk, 55] doubles (45 upper-triangle entries of
+// sum phi phi^T row by row, 9 entries of sum phi gray, the valid-pixel count); the caller adds the nblk partials and solves 9 x 9
+extern "C" int fmhr_sh_normal_equations(const float* normals, const float* rast, const float* mask, const float* gray, int n, int H, int W,
+                                        int nblk, double* part, void* stream)
+{
+    FMHR_CHECK_ARG(n >= 1 && H >= 1 && W >= 1 && nblk >= 1 && n <= 65535, "sh_normal_equations: bad dims");
+    FMHR_CHECK_ARG(normals && rast && mask && gray && part, "sh_normal_equations: null pointer");
+    k_sh_normal_eq<<<dim3(nblk, n), kBlock, 0, (hipStream_t)stream>>>(normals, (const float4*)rast, mask, gray, (long long)H * W, part);
+    FMHR_CHECK_LAUNCH("k_sh_normal_eq");
+    return FMHR_OK;
+}
+
+// part [n, nblk, 4] doubles: sums of img / radiance(sh, normal) per channel over the valid pixels, and their count (sh: 9 floats)
+extern "C" int fmhr_sh_albedo_sums(const float* normals, const float* rast, const float* mask, const float* img, const float* sh, int n,
+                                   int H, int W, int nblk, double* part, void* stream)
+{
+    FMHR_CHECK_ARG(n >= 1 && H >= 1 && W >= 1 && nblk >= 1 && n <= 65535, "sh_albedo_sums: bad dims");
+    FMHR_CHECK_ARG(normals && rast && mask && img && sh && part, "sh_albedo_sums: null pointer");
+    k_sh_albedo_sums<<<dim3(nblk, n), kBlock, 0, (hipStream_t)stream>>>(normals, (const float4*)rast, mask, img, sh, (long long)H * W, part);
+    FMHR_CHECK_LAUNCH("k_sh_albedo_sums");
     return FMHR_OK;
 }

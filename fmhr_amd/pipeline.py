@@ -127,7 +127,15 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     num = imgs.shape[0]
     H, W = resolution
     gen = torch.Generator(device="cpu").manual_seed(seed)
-    init = init_sh(ops, vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, degree)
+    if degree != 3:
+        raise RuntimeError("run_ham: the fused stage-1 path evaluates the order-3 SH basis (degree = 3, conf/demo_sfs.conf:29)")
+    # The constant sub-graph of init + stage 1 (:137-148 = :207-218: rasterization, antialiased + normalised normals, validity, start
+    # silhouettes) is computed ONCE for all views by HamStage1; the SH least squares of :150-174 then run on it (normal equations
+    # accumulated on the GPU, 9 x 9 solves on the host: `init_sh` above — the reference's own per-view host loop — took 2.8 of the
+    # 3.0 s of a 48-view run)
+    from . import stage1 as s1
+    hs1 = s1.HamStage1(vertices.detach(), faces, w2cs, projs, imgs, masks, resolution, conf["sfs_weight"], want_pred_masks=True)
+    init = s1.init_sh(hs1, grayimgs)
     sh_coeffs = init["sh_coeffs"].clone().requires_grad_(True)                       # :168-170
     albedo = (torch.zeros_like(vertices) + init["albedo_mean"]).unsqueeze(0).contiguous().requires_grad_(True)   # :175-176
     delta = torch.zeros_like(vertices).requires_grad_(True)
@@ -138,11 +146,7 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     # the fused step (fmhr_amd.stage1.HamStage1): the constant sub-graph and the linear interpolate + antialias operator are built
     # once, an iteration is one C call (two launches), the Adam update of both parameters applied inside it.  `stage1_loss` /
     # `stage1_loss_cached` above are the op-by-op forms the parity tests compare it with.
-    if degree != 3:
-        raise RuntimeError("run_ham: the fused stage-1 step evaluates the order-3 SH basis (degree = 3, conf/demo_sfs.conf:29)")
-    from .stage1 import HamStage1
     opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
-    hs1 = HamStage1(vertices_tmp, faces, w2cs, projs, imgs, masks, resolution, conf["sfs_weight"])
     for ep in range(int(conf["epoch_albedo"])):
         perm = torch.randperm(num, generator=gen).to(dev)
         for k in range(0, num, batch):

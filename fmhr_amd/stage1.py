@@ -17,8 +17,10 @@ from ._lib import call, ptr, stream_ptr
 
 
 class HamStage1:
-    def __init__(self, vertices, faces, w2cs, projs, imgs, masks, resolution, sfs_weight, chunk=8):
-        """vertices [V,3], faces [F,3], w2cs / projs [num,4,4], imgs [num,H,W,3], masks [num,H,W] (all on the GPU)."""
+    def __init__(self, vertices, faces, w2cs, projs, imgs, masks, resolution, sfs_weight, chunk=8, want_pred_masks=False):
+        """vertices [V,3], faces [F,3], w2cs / projs [num,4,4], imgs [num,H,W,3], masks [num,H,W] (all on the GPU).
+        want_pred_masks: also keep the antialiased coverage of every view (`pred_mask` of mesh_sfs_optim.py:145-146, the start
+        silhouettes stage 2 uses as `valid_masks`, :158) in self.pred_masks [num,H,W]."""
         _lib.require_gpu("HamStage1", vertices, w2cs, projs, imgs, masks)
         self.lib = _lib.load()
         dev = vertices.device
@@ -35,6 +37,7 @@ class HamStage1:
         rast = torch.empty(num, H, W, 4, dtype=torch.float32, device=dev)
         normals = torch.empty(num, H, W, 3, dtype=torch.float32, device=dev)
         items, alphas = [], []
+        self.pred_masks = torch.empty(num, H, W, dtype=torch.float32, device=dev) if want_pred_masks else None
         glctx = dr.RasterizeGLContext()
         with torch.no_grad():
             for k in range(0, num, chunk):
@@ -44,7 +47,12 @@ class HamStage1:
                 pos = torch.einsum('ijk,ikl->ijl', torch.einsum('ijk,ikl->ijl', vertsw, w2c), proj).contiguous()
                 vn = utils.get_normals(vertsw[:, :, :3].contiguous(), faces.long())
                 r, _ = dr.rasterize(glctx, pos, faces, resolution=resolution)
-                feat, _ = dr.interpolate(vn.contiguous(), r, faces)
+                if want_pred_masks:                                  # :143-146: normals and a ones channel through one interpolate
+                    f4, _ = dr.interpolate(torch.cat([vn, torch.ones_like(vertsw[:, :, :1])], 2).contiguous(), r, faces)
+                    feat = f4[..., :3]
+                    self.pred_masks[k:k + c] = dr.antialias(f4[..., 3:4].contiguous(), r, pos, faces).squeeze(-1)
+                else:
+                    feat, _ = dr.interpolate(vn.contiguous(), r, faces)
                 aa, it, al, overflow = dr.antialias_debug_items(feat.contiguous(), r, pos, faces)
                 if overflow:
                     raise RuntimeError("HamStage1: antialias work-item list overflow")
@@ -94,7 +102,7 @@ class HamStage1:
         self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
         self.galbedo, self.gsh, self.loss_view = f32(V, 3), f32(num, 9), f32(num)
         self.view_sel = torch.ones(num, dtype=torch.int32, device=dev)
-        self.rast, self.normals = rast, normals                      # kept for inspection / the parity tests
+        self.rast, self.normals, self.masks, self.imgs = rast, normals, masks, imgs      # the constant sub-graph (also read by init_sh)
 
     def step(self, albedo, sh_coeffs, idx=None, optimizer=None, params=None):
         """One iteration on the views `idx` (None: all).  albedo [1,V,3] or [V,3], sh_coeffs [num,9].  Returns (loss_view [num],
@@ -120,3 +128,35 @@ class HamStage1:
              ptr(self.loss_view), ctypes.byref(adam[0]) if adam[0] is not None else None,
              ctypes.byref(adam[1]) if adam[1] is not None else None, ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
         return self.loss_view, self.galbedo, self.gsh
+
+
+def init_sh(hs1, grayimgs, nblk=64):
+    """The SH least-squares initialisation of mesh_sfs_optim.py:124-174 on the constant sub-graph a HamStage1 already holds (the same
+    rasterization / antialiased normals / validity): per-view and global coefficients, the mean albedo.  The reference solves
+    [Pv, 9] float64 least-squares problems with np.linalg.lstsq on the host, one view at a time; here the GPU accumulates the normal
+    equations (fmhr_sh_normal_equations: 55 float64 sums per view) and only the 9 x 9 solves run on the host.
+    Returns dict(sh_coeffs [num,9], sh_global [9], albedo_mean [3], valid_masks = hs1.pred_masks)."""
+    import numpy as np
+    dev, n, H, W = hs1.dev, hs1.n, hs1.H, hs1.W
+    gray = grayimgs.to(torch.float32).contiguous()
+    st = stream_ptr(dev)
+    part = torch.empty(n, nblk, 55, dtype=torch.float64, device=dev)
+    call("fmhr_sh_normal_equations", ptr(hs1.normals), ptr(hs1.rast), ptr(hs1.masks), ptr(gray), n, H, W, nblk, ptr(part), st)
+    acc = part.sum(1).cpu().numpy()                                   # [n, 55]
+    iu = np.triu_indices(9)
+
+    def solve(a):
+        G = np.zeros((9, 9))
+        G[iu] = a[:45]
+        G = G + np.triu(G, 1).T
+        # minimum-norm least-squares solution of the normal equations (= np.linalg.lstsq on the design matrix whenever it has full
+        # column rank; a view with fewer than 9 valid pixels gets the minimum-norm solution of what it has)
+        return np.linalg.lstsq(G, a[45:54], rcond=None)[0]
+    sh_views = np.stack([solve(acc[b]) for b in range(n)]).astype(np.float32)
+    sh_global = solve(acc.sum(0)).astype(np.float32)
+    shg = torch.from_numpy(sh_global).to(dev)
+    part2 = torch.empty(n, nblk, 4, dtype=torch.float64, device=dev)
+    call("fmhr_sh_albedo_sums", ptr(hs1.normals), ptr(hs1.rast), ptr(hs1.masks), ptr(hs1.imgs), ptr(shg), n, H, W, nblk, ptr(part2), st)
+    tot = part2.sum((0, 1)).cpu().numpy()
+    albedo_mean = torch.from_numpy((tot[:3] / max(tot[3], 1.0)).astype(np.float32)).to(dev)
+    return dict(sh_coeffs=torch.from_numpy(sh_views).to(dev), sh_global=shg, albedo_mean=albedo_mean, valid_masks=hs1.pred_masks)

@@ -275,6 +275,17 @@ int fmhr_stage1_step(const fmhr_stage1_plan* plan, const float* albedo, const fl
                      float* galbedo, float* gsh, float* loss_view, const fmhr_adam_param* adam_albedo,
                      const fmhr_adam_param* adam_sh, void* ws, size_t ws_bytes, void* stream);
 
+/* SH least-squares initialisation, mesh_sfs_optim.py:150-154,164-166,173-174: the reference fits 9 coefficients per view (and once
+ * over all views) with np.linalg.lstsq on the host.  The normal equations need only sum phi phi^T and sum phi gray over the valid
+ * pixels (mask > 0 and covered): accumulated here in float64 as per-workgroup partials, part [n, nblk, 55] (45 upper-triangle
+ * entries row by row, 9 right-hand sides, the pixel count); the caller adds the nblk partials and solves the 9 x 9 systems.
+ * normals [n,H,W,3] = the antialiased, normalised normals (:147-148), rast [n,H,W,4], mask / gray [n,H,W]. */
+int fmhr_sh_normal_equations(const float* normals, const float* rast, const float* mask, const float* gray, int n, int H, int W,
+                             int nblk, double* part, void* stream);
+/* sums of img / radiance(sh, normal) per channel over the valid pixels + their count (albedo_mean, :173-174): part [n, nblk, 4] */
+int fmhr_sh_albedo_sums(const float* normals, const float* rast, const float* mask, const float* img, const float* sh, int n,
+                        int H, int W, int nblk, double* part, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ per-kernel timing (optional)
  * Attach an array of 2*FMHR_SLOT_COUNT hipEvent_t (created by the caller with timing enabled) to the CALLING THREAD: while
  * attached, fmhr_ham_forward/backward record events[2*slot] / events[2*slot+1] around launch group `slot` on the step's

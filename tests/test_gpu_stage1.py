@@ -136,3 +136,21 @@ def test_fused_stage1_metric_mesh(views):
     loss = lv.sum()
     assert abs(float(loss) - float(lk)) < TOL * abs(float(lk))
     assert rel_err(ga, a.grad[0]) < TOL and rel_err(gs, s.grad) < TOL
+
+
+def test_fused_sh_initialisation_matches_the_per_view_lstsq_loop():
+    """stage1.init_sh (normal equations accumulated on the GPU, 9 x 9 solves on the host) against pipeline.init_sh (the reference's loop
+    :124-174: one view at a time, np.linalg.lstsq on the [Pv, 9] design matrix) on the product's generic ops"""
+    from fmhr_amd import pipeline, stage1
+    dev = torch.device("cuda:0")
+    sc, faces, w2c, proj, tg = _scene(dev, views=5, seed=7)
+    vt = sc["vertices"].to(dev).contiguous()
+    res = (sc["H"], sc["W"])
+    img = tg["img"]
+    gray = (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).contiguous()
+    ref = pipeline.init_sh(pipeline.product_ops(), vt, faces, img, gray, tg["mask"], w2c, proj, res)
+    hs = stage1.HamStage1(vt, faces, w2c, proj, img, tg["mask"], res, 50.0, chunk=2, want_pred_masks=True)
+    got = stage1.init_sh(hs, gray)
+    assert torch.equal(got["valid_masks"], ref["valid_masks"])
+    assert rel_err(got["sh_coeffs"], ref["sh_coeffs"]) < 1e-4 and rel_err(got["sh_global"], ref["sh_global"]) < 1e-4
+    assert rel_err(got["albedo_mean"], ref["albedo_mean"]) < 1e-5
