@@ -34,6 +34,8 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(HamDims) == 28 and ctypes.sizeof(HamWeights) == 44 and ctypes.sizeof(HamViews) == 48
     from fmhr_amd._lib import AdamParam
     assert ctypes.sizeof(AdamParam) == 48
+    from fmhr_amd._lib import Stage1Plan
+    assert ctypes.sizeof(Stage1Plan) == 16 + 10 * 8
 
 
 def test_argument_errors_without_gpu(lib):
@@ -54,6 +56,20 @@ def test_argument_errors_without_gpu(lib):
     lib.fmhr_ham_densify.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]
     assert lib.fmhr_ham_densify(ctypes.byref(ok), None, None, None, 0, None) == -1
     assert b"ham_densify" in lib.fmhr_last_error()
+    # the stage-1 entry points check their arguments before they touch the device
+    from fmhr_amd._lib import Stage1Plan
+    assert lib.fmhr_stage1_step(None, None, None, None, 50.0, None, None, None, None, None, None, 0, None) == -1
+    assert b"plan is null" in lib.fmhr_last_error()
+    plan = Stage1Plan(2, 10, 300, 0, *([None] * 10))             # rows must be a multiple of 256
+    assert lib.fmhr_stage1_step(ctypes.byref(plan), None, None, None, 50.0, None, None, None, None, None, None, 0, None) == -1
+    assert b"bad plan" in lib.fmhr_last_error()
+    plan = Stage1Plan(2, 10, 512, 0, *([None] * 10))
+    assert lib.fmhr_stage1_step(ctypes.byref(plan), None, None, None, 50.0, None, None, None, None, None, None, 0, None) == -1
+    assert b"null table" in lib.fmhr_last_error()
+    assert lib.fmhr_stage1_step_workspace_bytes(ctypes.byref(plan)) >= 512 * 12 + 2 * 40
+    assert lib.fmhr_stage1_rows(None, None, 0, 8, 8, None, None, None, None, 0, None, 0, None) == -1
+    assert lib.fmhr_stage1_transpose(None, None, None, None, 1, 10, 0, None, None, None, None, 0, None) == -1
+    assert lib.fmhr_sh_normal_equations(None, None, None, None, 1, 8, 8, 4, None, None) == -1
 
 
 def test_product_fails_loudly_on_cpu_tensors():
