@@ -227,17 +227,18 @@ struct S1Plan {
 
 // sum over the batch's views of their valid-pixel counts (F.l1_loss averages over the batch's 3 Pv elements, :231); every workgroup
 // recomputes it from the n <= a few dozen counts: no kernel of its own, no host round trip
-__device__ __forceinline__ float s1_batch_valid(const int* __restrict__ view_valid, const int* __restrict__ view_sel, int n, float* sm4)
+__device__ __forceinline__ float s1_batch_valid(const int* __restrict__ view_valid, const int* __restrict__ view_sel, int n, int* sm4)
 {
-    float c = 0.f;
-    for (int b = threadIdx.x; b < n; b += kBlock) c += (view_sel == nullptr || view_sel[b] != 0) ? (float)view_valid[b] : 0.f;
-    c = wave_sum(c);
+    int c = 0;                                                      // integer sum: exact whatever the batch size
+    for (int b = threadIdx.x; b < n; b += kBlock) c += (view_sel == nullptr || view_sel[b] != 0) ? view_valid[b] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) sm4[wv] = c;
     __syncthreads();
-    const float r = sm4[0] + sm4[1] + sm4[2] + sm4[3];
+    const int r = sm4[0] + sm4[1] + sm4[2] + sm4[3];
     __syncthreads();
-    return r;
+    return (float)r;
 }
 
 // forward + the pixel half of the backward, one lane per valid pixel (row): a = sum w albedo[col]; radiance = SH basis of the row's
@@ -248,7 +249,7 @@ k_s1_fwd(const S1Plan P, const float* __restrict__ albedo, const float* __restri
          float* __restrict__ R, float* __restrict__ part)
 {
     __shared__ float sm[4][10];
-    __shared__ float sm4[4];
+    __shared__ int sm4[4];
     const int row = blockIdx.x * kBlock + threadIdx.x;
     const int b = s1_view_of_row(P.view_row0, P.n, blockIdx.x * kBlock);      // workgroup-uniform
     if (view_sel != nullptr && view_sel[b] == 0) {                            // not in this batch: its rows carry no gradient
@@ -320,7 +321,7 @@ k_s1_bwd(const S1Plan P, const float* __restrict__ R, const float* __restrict__ 
 {
     if ((int)blockIdx.x >= vblocks) {
         __shared__ float sm[4][10];
-        __shared__ float sm4[4];
+        __shared__ int sm4[4];
         const int b = (int)blockIdx.x - vblocks;
         const bool on = view_sel == nullptr || view_sel[b] != 0;
         const float pv = s1_batch_valid(P.view_valid, view_sel, P.n, sm4);
@@ -500,7 +501,7 @@ extern "C" size_t fmhr_stage1_rows_workspace_bytes(int n, int H, int W)
 extern "C" int fmhr_stage1_rows(const float* rast, const float* mask, int n, int H, int W, int32_t* rowid, int32_t* view_row0,
                                 int32_t* view_valid, int32_t* row_flags, long long row_flags_len, void* ws, size_t ws_bytes, void* stream)
 {
-    FMHR_CHECK_ARG(n >= 1 && H >= 1 && W >= 1 && (long long)n * H * W < (1ll << 31), "stage1_rows: bad dims n=%d H=%d W=%d", n, H, W);
+    FMHR_CHECK_ARG(n >= 1 && H >= 1 && W >= 1 && (long long)n * H * W + (long long)n * kBlock < (1ll << 31), "stage1_rows: bad dims n=%d H=%d W=%d", n, H, W);
     FMHR_CHECK_ARG(rast && mask && rowid && view_row0 && view_valid && row_flags && ws, "stage1_rows: null pointer");
     FMHR_CHECK_ARG(ws_bytes >= fmhr_stage1_rows_workspace_bytes(n, H, W), "stage1_rows: workspace too small");
     const long long N = (long long)n * H * W, P = (long long)H * W;

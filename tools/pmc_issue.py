@@ -40,7 +40,7 @@ for p, counters in enumerate(PASSES):
         raise SystemExit("the first pass must hold SQ_WAVES / SQ_INSTS_VALU")
     out = os.path.join(ROOT, "gpurun_out", f"{TAG}_issue{p}")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters.split(), "-d", out, "-o", "pmc", "--output-format", "csv", "--",
-           "python3", os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", *BENCH_ARGS]
+           "python3", os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-stage1", *BENCH_ARGS]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=150)
     open(out + ".log", "w").write(r.stdout)
     if r.returncode != 0:
