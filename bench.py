@@ -309,10 +309,17 @@ def main():
                            "hbm_bytes": (traffic or {}).get(k)} for k, v in kernels.items() if alg_bytes(k, n, P, V, F, hs.nnz) > 0},
             "losses": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in final.items()},
         }
+        # the two side measurements must never cost the headline line: a failure is reported in their place
         if world == 1 and not args.no_stage1:
-            out["stage1"] = stage1_side_measurement(scene, faces, w2c, proj, sh, tg, vtmp, H, W, dev)
+            try:
+                out["stage1"] = stage1_side_measurement(scene, faces, w2c, proj, sh, tg, vtmp, H, W, dev)
+            except Exception as e:  # noqa: BLE001
+                out["stage1"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, max(1, min(args.cpu_views, n_total)), args.seed)
+            try:
+                out["cpu_baseline"] = cpu_baseline(scene, max(1, min(args.cpu_views, n_total)), args.seed)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
