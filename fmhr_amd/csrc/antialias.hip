@@ -608,7 +608,8 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          const float4* __restrict__ cmat = nullptr, float* __restrict__ gvert = nullptr, bool use_gl = false,
          float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false, float4 dcol = make_float4(0.f, 0.f, 0.f, 0.f),
          const float* __restrict__ verts = nullptr, bool keep0 = true, bool keep1 = true, float* __restrict__ gvert2 = nullptr,
-         int known_va = -1, int known_vb = -1, const float4* pre = nullptr)
+         int known_va = -1, int known_vb = -1, const float4* pre = nullptr, unsigned* st_off = nullptr, float* st_val = nullptr,
+         float* split2 = nullptr)
 {
     // pre (fused step): the edge's two clip positions and the view's three matrix rows, loaded by the caller TOGETHER with everything
     // else the item needs: memory operations of a wave complete in order, so a load issued behind the colour atomics below would wait
@@ -632,8 +633,15 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
         // fused step: an uncovered pixel's gradient is read by nobody, and neither is the alpha channel's (the interpolated
         // "ones" attribute is constant 1: no gradient flows to the barycentrics; it only moves the crossing point, via galpha)
         if (gcolorA != nullptr && g != 0.f && !(packed && c == 3)) {
-            if (keep1) atomicAdd(gcolorA + pix1 * C + c, alpha * g);
-            if (keep0) atomicAdd(gcolorA + pix0 * C + c, -alpha * g);
+            if (st_val != nullptr) {       // staged (k_aa_bwd_items): entries 0-2 = pixel 1's channels, 3-5 = pixel 0's
+                if (c < 3) {
+                    if (keep1) { st_off[c] = (unsigned)(pix1 * C + c); st_val[c] = alpha * g; }
+                    if (keep0) { st_off[3 + c] = (unsigned)(pix0 * C + c); st_val[3 + c] = -alpha * g; }
+                }
+            } else {
+                if (keep1) atomicAdd(gcolorA + pix1 * C + c, alpha * g);
+                if (keep0) atomicAdd(gcolorA + pix0 * C + c, -alpha * g);
+            }
         }
     }
     if (CB > 0) {
@@ -683,6 +691,16 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
                      c2 = (pre != nullptr) ? pre[4] : cmat[(size_t)b * 4 + 2];
         const float ga[3] = {ax * c0.x + ay * c0.y + aw * c0.w, ax * c1.x + ay * c1.y + aw * c1.w, ax * c2.x + ay * c2.y + aw * c2.w};
         const float gb[3] = {bx * c0.x + by * c0.y + bw * c0.w, bx * c1.x + by * c1.y + bw * c1.w, bx * c2.x + by * c2.y + bw * c2.w};
+        if (st_val != nullptr) {           // staged: entries 6-8 = vertex a's components, 9-11 = vertex b's (both into gvert); the
+            const float s1 = (gvert2 == nullptr) ? 1.0f : galpha - galpha_a, s2 = (gvert2 == nullptr) ? 0.f : galpha_a;     // silhouette
+#pragma unroll
+            for (int k = 0; k < 3; k++) {                                                                                       // share
+                st_off[6 + k] = (unsigned)(va * 3 + k); st_val[6 + k] = s1 * ga[k];                                             // (gvert2)
+                st_off[9 + k] = (unsigned)(vb * 3 + k); st_val[9 + k] = s1 * gb[k];                                             // is handed
+                if (split2 != nullptr) { split2[k] = s2 * ga[k]; split2[3 + k] = s2 * gb[k]; }                                  // back
+            }
+            return;
+        }
         if (gvert2 == nullptr) {
 #pragma unroll
             for (int k = 0; k < 3; k++) { atomicAdd(gvert + (size_t)va * 3 + k, ga[k]); atomicAdd(gvert + (size_t)vb * 3 + k, gb[k]); }
@@ -744,7 +762,24 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
     if (gvert2 != nullptr) gvert2 += (size_t)(blockIdx.x & (kAaReplicas - 1)) * V * 3;
     const float den = 3.0f * L.n_valid[0];
     const float k1 = (den > 0.f) ? L.w_sfs / den : 0.f, k2 = L.w_mask / L.mse_den;
-    for (int i = threadIdx.x; i < count; i += kBlock) {
+    // The twelve float atomics of an item go to FOUR cache lines (a pixel's three colour channels are one 16-B word, a vertex's three
+    // components 12 B) and a posted atomic costs ~23 cycles of the CU's memory pipeline per distinct line it touches, whatever the
+    // number of lanes on that line (tools/micro/atomic_lines.hip): issued item by item — lane = item, one instruction per component —
+    // the 55 k items of a steady-state step are 660 k line requests = this kernel's whole 24 us (5 workgroups x 43 items x 12 per
+    // CU).  So the contributions are staged in LDS, twelve (offset, value) entries per item, and issued TRANSPOSED: lane = entry, so
+    // that the lanes of one instruction that belong to one item hit that item's four lines together.
+    constexpr int kE = 12;
+    __shared__ unsigned st_off[kBlock * kE];
+    __shared__ float st_val[kBlock * kE];
+    for (int base = 0; base < count; base += kBlock) {               // workgroup-uniform trip count (one round unless a region is dense)
+        const int i = base + (int)threadIdx.x;
+        const int nround = min(kBlock, count - base);
+        float split2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        unsigned* const my_off = st_off + threadIdx.x * kE;
+        float* const my_val = st_val + threadIdx.x * kE;
+        if (i < count) {
+#pragma unroll
+        for (int e = 0; e < kE; e++) my_val[e] = 0.f;
         const int4 raw = items[rbase + i];                          // (px | py << 16, view | code << 16, edge vertex a, edge vertex b)
         const int4 it = make_int4(raw.x & 0xffff, (int)((unsigned)raw.x >> 16), raw.y & 0xffff, (int)((unsigned)raw.y >> 16));
         const float alpha = alphas[rbase + i];
@@ -774,7 +809,30 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
         // d loss / d shaded colour exists for covered pixels only (k_loss_pix stores it for them, the owner face reads it)
         const bool cov0 = (L.covw[pix0 >> 6] >> (pix0 & 63)) & 1ull, cov1 = (L.covw[pix1 >> 6] >> (pix1 & 63)) & 1ull;
         aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, nullptr, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
-                          nullptr, cmat, gvert, true, g, true, dcol, verts, cov0, cov1, gvert2, raw.z, raw.w, pre);
+                          nullptr, cmat, gvert, true, g, true, dcol, verts, cov0, cov1, gvert2, raw.z, raw.w, pre, my_off, my_val,
+                          (gvert2 != nullptr) ? split2 : nullptr);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nround * kE; e += kBlock) {
+            const float v = st_val[e];
+            if (v != 0.f) {
+                const int k = e - (e / kE) * kE;
+                atomicAdd(((k < 6) ? gcolor : gvert) + st_off[e], v);
+            }
+        }
+        if (gvert2 != nullptr) {                                     // view-sharded step: the silhouette share, same vertices (entries 6-11)
+            __syncthreads();
+            if (i < count)
+#pragma unroll
+                for (int k = 0; k < 6; k++) my_val[6 + k] = split2[k];
+            __syncthreads();
+            for (int e = threadIdx.x; e < nround * 6; e += kBlock) {
+                const int item = e / 6, k = e - item * 6;
+                const float v = st_val[item * kE + 6 + k];
+                if (v != 0.f) atomicAdd(gvert2 + st_off[item * kE + 6 + k], v);
+            }
+        }
+        __syncthreads();                                             // the stage is free for the next round
     }
 }
 

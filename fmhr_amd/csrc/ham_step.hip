@@ -134,7 +134,7 @@ static int check_dims(const fmhr_ham_dims* d)
                    "ham: bad dims n=%d V=%d F=%d H=%d W=%d aa_cap=%d", d->n, d->V, d->F, d->H, d->W, d->aa_cap);
     FMHR_CHECK_ARG(d->H <= 8192 && d->W <= 8192 && d->F < (1 << 24), "ham: H,W <= 8192 and F < 2^24 required");
     FMHR_CHECK_ARG(((long long)d->n * d->H * d->W) % 4 == 0, "ham: n*H*W must be a multiple of 4");
-    FMHR_CHECK_ARG(d->n <= 65535 && ((long long)d->n * d->H * d->W) < (1ll << 36), "ham: n <= 65535 and n*H*W < 2^36 required");
+    FMHR_CHECK_ARG(d->n <= 65535 && ((long long)d->n * d->H * d->W) < (1ll << 30), "ham: n <= 65535 and n*H*W < 2^30 required (32-bit channel offsets in k_aa_bwd_items)");
     return FMHR_OK;
 }
 
