@@ -455,6 +455,7 @@ __device__ __attribute__((noinline)) void aa_fwd_pair_overflow(int px, int py, i
 // ROW: W % 64 == 0 — a 64-pixel segment lies in ONE row of ONE view, so (view, row, first column) are wave-uniform and come from
 // two scalar magic divisions (common.h: UDiv) instead of two ~25-instruction integer divisions in every lane of every segment
 struct SegRows { UDiv per_view, per_row; unsigned segs_per_view, segs_per_row; };
+FMHR_WTS_DEFINE(aaf)
 template <bool ROW>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8)))
 k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __restrict__ pos,
@@ -468,6 +469,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
     // (cap / gridDim items) and a count slot — no global atomics at all (a returning same-address atomic per wave with an item
     // serialised to ~0.25 ms per step, one per workgroup at the kernel's end still to ~13 us); the backward runs one workgroup
     // per region over dense items instead of scanning every active pixel
+    FMHR_WTS_BEGIN(aaf, (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     __shared__ int4 ibuf[kItemBuf];
     __shared__ float abuf[kItemBuf];
     __shared__ int2 cpos[kCandBuf];                                // candidate pairs: px | py << 13 | d << 26, view
@@ -596,6 +598,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
         region_cnt[blockIdx.x] = min(inum, region);
         if (inum > region) counter[1] = 1;
     }
+    FMHR_WTS_END(aaf);
 }
 
 // backward of one work item: colour gradients (+-alpha * dy[target]) and the position gradient of the crossing point
@@ -741,6 +744,7 @@ k_aa_bwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
 // backward over the work-item list of the fused step: one workgroup per region of the list, dense items.  d loss / d aa of an
 // item's target pixel is RECOMPUTED here from the loss definition (k_loss_pix: L1 over valid pixels + silhouette MSE) — a few
 // hundred thousand items — instead of being stored by k_loss_pix for all 4.4 M active pixels in a second gradient image
+FMHR_WTS_DEFINE(aab)
 struct LossGrad {
     const float4* aa; const float* img; const float* mask; const float* valid_mask; const unsigned long long* covw;
     const float* n_valid; float w_sfs, w_mask, mse_den;
@@ -752,6 +756,7 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
                const float* __restrict__ alphas, const int32_t* __restrict__ region_cnt, int cap, int V, int H, int W,
                float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert, float* __restrict__ gvert2)
 {
+    FMHR_WTS_BEGIN(aab, (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     const int region = cap / (int)gridDim.x, count = region_cnt[blockIdx.x];      // same grid as k_aa_fwd_list
     const size_t rbase = (size_t)blockIdx.x * region;
     // A silhouette vertex collects the items of several adjacent pixel pairs (up to ~30 in the metric step) and float atomics on ONE
@@ -834,6 +839,7 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
         }
         __syncthreads();                                             // the stage is free for the next round
     }
+    FMHR_WTS_END(aab);
 }
 
 static unsigned table_size(int F)

@@ -1,4 +1,4 @@
-"""Start / end / hardware slot of every wave of k_raster_tris and k_face_bwd (measurement build -DFMHR_X_TS): slot utilisation, the
+"""Start / end / hardware slot of every wave of k_raster_tris, k_face_bwd, k_aa_fwd_list and k_aa_bwd_items (measurement build -DFMHR_X_TS): slot utilisation, the
 tail of the launch and the balance over XCDs / CUs.  On the GPU box:
     FMHR_FORCE_BUILD=1 FMHR_EXTRA_FLAGS=-DFMHR_X_TS fmhr_amd/csrc/build.sh   (here, before gpurun)
     python tools/analysis/wave_timeline.py > gpurun_out/wave_timeline.txt
@@ -61,3 +61,5 @@ def report(name, fn, nwaves, slots_per_simd):
 
 report("tris", hs.lib.fmhr_debug_wts_raster, ((F + 255) // 256) * 48 * 4, 8)
 report("face_bwd", hs.lib.fmhr_debug_wts_shade, ((F + 31) // 32) * 4, 4)
+report("aa_fwd_list", hs.lib.fmhr_debug_wts_aaf, 1280 * 4, 5)
+report("aa_bwd_items", hs.lib.fmhr_debug_wts_aab, 1280 * 4, 7)
