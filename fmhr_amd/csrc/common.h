@@ -254,6 +254,39 @@ __device__ __forceinline__ ClipView clip_view(const float* pos, const float* ver
 #define FMHR_WTS_END(unit)
 #endif
 
+// Scatter-add of 3 x 3 values per lane, TRANSPOSED: lane `on` adds val[3 k + m] to base[row[k] * STRIDE + (m == 2 ? C2 : m)] for k, m in
+// 0..2 (a pixel's / face's three vertices x three components).  Issued lane = (item, k, m) from a per-wave LDS stage (sv [64 * 9], sx
+// [64 * 3], this wave's slices), the three components of a vertex are ONE cache-line request: a posted atomic costs per distinct line per
+// instruction — issued lane = item, one instruction per component, they were three.  Every lane of the wave must call.
+template <int STRIDE, int C2>
+__device__ __forceinline__ void wave_add_3x3(float* __restrict__ base, bool on, const float (&val)[9], const unsigned (&row)[3], float* sv,
+                                             unsigned* sx)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bal = __ballot(on);
+    const int cnt = __popcll(bal);
+    if (cnt == 0) return;                                            // wave-uniform
+    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) sv[rank * 9 + k] = val[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) sx[rank * 3 + k] = row[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = lane; e < cnt * 9; e += 64) {
+        const float v = sv[e];
+        if (v != 0.f) {
+            const int kv = e / 3, m = e - kv * 3;
+            atomicAdd(base + (size_t)sx[kv] * STRIDE + (m == 2 ? C2 : m), v);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the stage may be refilled by the caller's next round
+    __builtin_amdgcn_wave_barrier();
+}
+
 // block (256 threads = 4 waves) sum; result valid in thread 0
 __device__ __forceinline__ float block_sum(float v, float* sm4)
 {

@@ -22,20 +22,32 @@ __device__ __forceinline__ void atomic_add3(float* p, float3 v) { atomicAdd(p, v
 __global__ void __launch_bounds__(kBlock)
 k_normals_faces(const float* __restrict__ verts, const int32_t* __restrict__ tri, int nb, int V, int F, float* __restrict__ nsum)
 {
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= (long long)nb * F) return;
-    int f;
-    const int b = fast_divmod(gid, F, f);
-    int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
-    if ((unsigned)i[0] >= (unsigned)V || (unsigned)i[1] >= (unsigned)V || (unsigned)i[2] >= (unsigned)V) return;
-    const float* vb = verts + (size_t)b * V * 3;
-    float3 v[3] = {ld3(vb + (size_t)i[0] * 3), ld3(vb + (size_t)i[1] * 3), ld3(vb + (size_t)i[2] * 3)};
-    float* nb_ = nsum + (size_t)b * V * 3;
+    __shared__ float st_val[kBlock * 9];
+    __shared__ unsigned st_row[kBlock * 3];
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    bool on = gid < (long long)nb * F;
+    float val[9];
+    unsigned row[3] = {0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float3 c = cross3(sub3(v[(k + 1) % 3], v[k]), sub3(v[(k + 2) % 3], v[k]));
-        atomic_add3(nb_ + (size_t)i[k] * 3, c);
+    for (int k = 0; k < 9; k++) val[k] = 0.f;
+    if (on) {
+        int f;
+        const int b = fast_divmod(gid, F, f);
+        int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
+        on = !((unsigned)i[0] >= (unsigned)V || (unsigned)i[1] >= (unsigned)V || (unsigned)i[2] >= (unsigned)V);
+        if (on) {
+            const float* vb = verts + (size_t)b * V * 3;
+            float3 v[3] = {ld3(vb + (size_t)i[0] * 3), ld3(vb + (size_t)i[1] * 3), ld3(vb + (size_t)i[2] * 3)};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float3 c = cross3(sub3(v[(k + 1) % 3], v[k]), sub3(v[(k + 2) % 3], v[k]));
+                val[k * 3] = c.x; val[k * 3 + 1] = c.y; val[k * 3 + 2] = c.z;
+                row[k] = (unsigned)((long long)b * V + i[k]);
+            }
+        }
     }
+    // nine float atomics per face, to three 12-B vertex rows: issued transposed (common.h: wave_add_3x3)
+    wave_add_3x3<3, 2>(nsum, on, val, row, st_val + (threadIdx.x & ~63) * 9, st_row + (threadIdx.x & ~63) * 3);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -74,29 +86,42 @@ __global__ void __launch_bounds__(kBlock)
 k_normals_bwd_faces(const float* __restrict__ verts, const int32_t* __restrict__ tri, const float* __restrict__ gs,
                     int nb, int V, int F, float* __restrict__ gverts)
 {
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= (long long)nb * F) return;
-    int f;
-    const int b = fast_divmod(gid, F, f);
-    int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
-    if ((unsigned)i[0] >= (unsigned)V || (unsigned)i[1] >= (unsigned)V || (unsigned)i[2] >= (unsigned)V) return;
-    const float* vb = verts + (size_t)b * V * 3;
-    const float* gb = gs + (size_t)b * V * 3;
-    float3 v[3] = {ld3(vb + (size_t)i[0] * 3), ld3(vb + (size_t)i[1] * 3), ld3(vb + (size_t)i[2] * 3)};
-    float3 acc[3] = {make_float3(0, 0, 0), make_float3(0, 0, 0), make_float3(0, 0, 0)};
+    __shared__ float st_val[kBlock * 9];
+    __shared__ unsigned st_row[kBlock * 3];
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    bool on = gid < (long long)nb * F;
+    float val[9];
+    unsigned row[3] = {0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-        float3 e1 = sub3(v[k1], v[k]), e2 = sub3(v[k2], v[k]);
-        float3 gc = ld3(gb + (size_t)i[k] * 3);
-        float3 ge1 = cross3(e2, gc), ge2 = cross3(gc, e1);
-        acc[k1].x += ge1.x; acc[k1].y += ge1.y; acc[k1].z += ge1.z;
-        acc[k2].x += ge2.x; acc[k2].y += ge2.y; acc[k2].z += ge2.z;
-        acc[k].x -= ge1.x + ge2.x; acc[k].y -= ge1.y + ge2.y; acc[k].z -= ge1.z + ge2.z;
+    for (int k = 0; k < 9; k++) val[k] = 0.f;
+    if (on) {
+        int f;
+        const int b = fast_divmod(gid, F, f);
+        int i[3] = {tri[f * 3], tri[f * 3 + 1], tri[f * 3 + 2]};
+        on = !((unsigned)i[0] >= (unsigned)V || (unsigned)i[1] >= (unsigned)V || (unsigned)i[2] >= (unsigned)V);
+        if (on) {
+            const float* vb = verts + (size_t)b * V * 3;
+            const float* gb = gs + (size_t)b * V * 3;
+            float3 v[3] = {ld3(vb + (size_t)i[0] * 3), ld3(vb + (size_t)i[1] * 3), ld3(vb + (size_t)i[2] * 3)};
+            float3 acc[3] = {make_float3(0, 0, 0), make_float3(0, 0, 0), make_float3(0, 0, 0)};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+                float3 e1 = sub3(v[k1], v[k]), e2 = sub3(v[k2], v[k]);
+                float3 gc = ld3(gb + (size_t)i[k] * 3);
+                float3 ge1 = cross3(e2, gc), ge2 = cross3(gc, e1);
+                acc[k1].x += ge1.x; acc[k1].y += ge1.y; acc[k1].z += ge1.z;
+                acc[k2].x += ge2.x; acc[k2].y += ge2.y; acc[k2].z += ge2.z;
+                acc[k].x -= ge1.x + ge2.x; acc[k].y -= ge1.y + ge2.y; acc[k].z -= ge1.z + ge2.z;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                val[k * 3] = acc[k].x; val[k * 3 + 1] = acc[k].y; val[k * 3 + 2] = acc[k].z;
+                row[k] = (unsigned)((long long)b * V + i[k]);
+            }
+        }
     }
-    float* go = gverts + (size_t)b * V * 3;
-#pragma unroll
-    for (int k = 0; k < 3; k++) atomic_add3(go + (size_t)i[k] * 3, acc[k]);
+    wave_add_3x3<3, 2>(gverts, on, val, row, st_val + (threadIdx.x & ~63) * 9, st_row + (threadIdx.x & ~63) * 3);
 }
 
 // ------------------------------------------------------------------------------------------------ SH radiance (order 3, 9 terms)
@@ -892,6 +917,7 @@ extern "C" int fmhr_vertex_normals_fwd(const float* verts, const int32_t* tri, i
     FMHR_CHECK_ARG(b >= 0 && V >= 0 && F >= 0, "vertex_normals_fwd: bad dims");
     if ((long long)b * V == 0) return FMHR_OK;
     FMHR_CHECK_ARG(verts && nsum && normals && (tri || F == 0), "vertex_normals_fwd: null pointer");
+    FMHR_CHECK_ARG((long long)b * V < (1ll << 32), "vertex_normals_fwd: b * V must be below 2^32");
     return normals_fwd_impl(verts, tri, b, V, F, nsum, normals, (hipStream_t)stream);
 }
 
@@ -901,6 +927,7 @@ extern "C" int fmhr_vertex_normals_bwd(const float* verts, const int32_t* tri, c
     FMHR_CHECK_ARG(b >= 0 && V >= 0 && F >= 0, "vertex_normals_bwd: bad dims");
     if ((long long)b * V == 0) return FMHR_OK;
     FMHR_CHECK_ARG(verts && nsum && gnormals && gtmp && gverts && (tri || F == 0), "vertex_normals_bwd: null pointer");
+    FMHR_CHECK_ARG((long long)b * V < (1ll << 32), "vertex_normals_bwd: b * V must be below 2^32");
     return normals_bwd_impl(verts, tri, nsum, gnormals, 3, b, V, F, gtmp, gverts, (hipStream_t)stream);
 }
 

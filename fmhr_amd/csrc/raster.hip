@@ -616,45 +616,53 @@ int reshade_dense_impl(const unsigned long long* covw, const float* pix16, const
 }
 
 // ------------------------------------------------------------------------------------------------ rasterize backward
+// The nine float atomics of a pixel (x, y, w of its triangle's three clip positions) go to THREE 16-B words: staged per wave in LDS and
+// issued lane = (pixel, vertex, component), so that a vertex's three components are one cache-line request (k_interp_bwd)
 __global__ void __launch_bounds__(kBlock)
 k_raster_bwd(const float* __restrict__ pos, const int32_t* __restrict__ tri, const float4* __restrict__ rast,
              const float4* __restrict__ dy, int n, int V, int F, int H, int W, float* __restrict__ gpos)
 {
-    long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    long long P = (long long)H * W;
-    if (gid >= (long long)n * P) return;
-    float4 r = rast[gid];
-    int t = (int)r.w - 1;
-    if (t < 0 || t >= F) return;
-    float4 g = dy[gid];
-    if (g.x == 0.f && g.y == 0.f) return;
-    int rem, px;
-    const int b = fast_divmod(gid, (int)P, rem);
-    const int py = fast_divmod(rem, W, px);
-    int i0 = tri[t * 3], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
-    const float* vp = pos + (size_t)b * V * 4;
-    const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
-    float fx = (2.0f / (float)W) * (float)px + (1.0f / (float)W - 1.0f);
-    float fy = (2.0f / (float)H) * (float)py + (1.0f / (float)H - 1.0f);
-    float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-    float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-    float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-    float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
-    float iw = 1.0f / (a0 + a1 + a2);
-    float b0 = a0 * iw, b1 = a1 * iw;
-    float gb0 = g.x * iw, gb1 = g.y * iw, gbb = gb0 * b0 + gb1 * b1;
-    float g0x = gbb * (p2y - p1y) - gb1 * p2y;
-    float g1x = gbb * (p0y - p2y) + gb0 * p2y;
-    float g2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
-    float g0y = gbb * (p1x - p2x) + gb1 * p2x;
-    float g1y = gbb * (p2x - p0x) - gb0 * p2x;
-    float g2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
-    float* q0 = gpos + ((size_t)b * V + i0) * 4;
-    float* q1 = gpos + ((size_t)b * V + i1) * 4;
-    float* q2 = gpos + ((size_t)b * V + i2) * 4;
-    atomicAdd(q0 + 0, g0x); atomicAdd(q0 + 1, g0y); atomicAdd(q0 + 3, -fx * g0x - fy * g0y);
-    atomicAdd(q1 + 0, g1x); atomicAdd(q1 + 1, g1y); atomicAdd(q1 + 3, -fx * g1x - fy * g1y);
-    atomicAdd(q2 + 0, g2x); atomicAdd(q2 + 1, g2y); atomicAdd(q2 + 3, -fx * g2x - fy * g2y);
+    __shared__ float st_val[kBlock * 9];
+    __shared__ unsigned st_vtx[kBlock * 3];                          // row (view * V + vertex) of gpos: < 2^32 (checked by the launcher)
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long P = (long long)H * W;
+    bool on = gid < (long long)n * P;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f), g = r;
+    int t = -1;
+    if (on) { r = rast[gid]; t = (int)r.w - 1; on = t >= 0 && t < F; }
+    if (on) { g = dy[gid]; on = !(g.x == 0.f && g.y == 0.f); }
+    float val[9];
+    unsigned vtx[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 9; k++) val[k] = 0.f;
+    if (on) {
+        int rem, px;
+        const int b = fast_divmod(gid, (int)P, rem);
+        const int py = fast_divmod(rem, W, px);
+        int i0 = tri[t * 3], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
+        const float* vp = pos + (size_t)b * V * 4;
+        const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
+        float fx = (2.0f / (float)W) * (float)px + (1.0f / (float)W - 1.0f);
+        float fy = (2.0f / (float)H) * (float)py + (1.0f / (float)H - 1.0f);
+        float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+        float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+        float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+        float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+        float iw = 1.0f / (a0 + a1 + a2);
+        float b0 = a0 * iw, b1 = a1 * iw;
+        float gb0 = g.x * iw, gb1 = g.y * iw, gbb = gb0 * b0 + gb1 * b1;
+        float g0x = gbb * (p2y - p1y) - gb1 * p2y;
+        float g1x = gbb * (p0y - p2y) + gb0 * p2y;
+        float g2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
+        float g0y = gbb * (p1x - p2x) + gb1 * p2x;
+        float g1y = gbb * (p2x - p0x) - gb0 * p2x;
+        float g2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
+        val[0] = g0x; val[1] = g0y; val[2] = -fx * g0x - fy * g0y;
+        val[3] = g1x; val[4] = g1y; val[5] = -fx * g1x - fy * g1y;
+        val[6] = g2x; val[7] = g2y; val[8] = -fx * g2x - fy * g2y;
+        vtx[0] = (unsigned)((long long)b * V + i0); vtx[1] = (unsigned)((long long)b * V + i1); vtx[2] = (unsigned)((long long)b * V + i2);
+    }
+    wave_add_3x3<4, 3>(gpos, on, val, vtx, st_val + (threadIdx.x & ~63) * 9, st_vtx + (threadIdx.x & ~63) * 3);
 }
 
 // ------------------------------------------------------------------------------------------------ interpolate
@@ -893,6 +901,7 @@ extern "C" int fmhr_rasterize_bwd(const float* pos, const int32_t* tri, const fl
     size_t nP = (size_t)n * H * W;
     if (nP == 0 || F == 0) return FMHR_OK;
     FMHR_CHECK_ARG(pos && tri && rast && dy && gpos, "rasterize_bwd: null pointer");
+    FMHR_CHECK_ARG((long long)n * V < (1ll << 32), "rasterize_bwd: n * V must be below 2^32");
     k_raster_bwd<<<cdiv((long long)nP, kBlock), kBlock, 0, (hipStream_t)stream>>>(pos, tri, (const float4*)rast,
                                                                                   (const float4*)dy, n, V, F, H, W, gpos);
     FMHR_CHECK_LAUNCH("k_raster_bwd");
