@@ -92,7 +92,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.vmnz = take(off, (nP + 63) / 64);
     L.act_list = take(off, ((nP + 63) / 64) * 4);
     L.act_count = take(off, 16);
-    L.cov16 = take(off, (size_t)d->n * d->F * 16); // coverage entries [n, F]: candidate-pixel mask, box origin, stamp | box width
+    L.cov16 = take(off, (size_t)d->n * d->F * 8);  // coverage entries [n, F]: candidate-pixel mask | box origin and width (raster.hip)
     L.own8 = take(off, (size_t)d->n * d->F);      // per (view, face): low byte of the last step in which it owned a pixel
     L.stamp = take(off, 16);                       // step counter tagging the coverage entries
     L.pix16 = take(off, nP * 16);             // per covered pixel: (u, v, z/w, packed face id | flags | silhouette bits)
@@ -204,7 +204,7 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
         HIPTRY(hipStreamSynchronize((hipStream_t)stream), "init one_third sync");      // `third` lives on this stack frame
     }
     // coverage entries are recognised by the step stamp: start with no entry valid, counter at 0
-    HIPTRY(hipMemsetAsync(w + L.cov16, 0xFF, (size_t)d->n * d->F * 16, (hipStream_t)stream), "init cov16");
+    HIPTRY(hipMemsetAsync(w + L.cov16, 0xFF, (size_t)d->n * d->F * 8, (hipStream_t)stream), "init cov16");
     HIPTRY(hipMemsetAsync(w + L.stamp, 0, 16, (hipStream_t)stream), "init stamp");
     HIPTRY(hipMemsetAsync(w + L.own8, 0, (size_t)d->n * d->F, (hipStream_t)stream), "init own8");
     return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, d->W, (hipStream_t)stream);
@@ -256,7 +256,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         // rasterize; the resolve pass also shades the covered pixels, leaves the per-pixel backward word, marks the owning
         // (view, face)s and rearms the two segment-list cursors
         RasterFused fu;
-        fu.cov16 = (int4*)(w + L.cov16); fu.stamp = (int*)(w + L.stamp); fu.own8 = (unsigned char*)(w + L.own8);
+        fu.cov16 = (int2*)(w + L.cov16); fu.stamp = (int*)(w + L.stamp); fu.own8 = (unsigned char*)(w + L.own8);
         fu.pix16 = (float4*)(w + L.pix16); fu.mask = mask;
         fu.silh = (const unsigned char*)(w + L.silh); fu.llink = (int*)(w + L.llink);
         fu.attr8 = (const float4*)(w + L.attr8); fu.sh = sh;

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(kTrisBlock) __attribute__((amdgpu_waves_per_eu
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
-              int4* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
+              int2* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
               const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg)
 {
     FMHR_WTS_BEGIN(raster, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kTrisBlock / 64) + (threadIdx.x >> 6));
@@ -189,7 +189,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             is_large = true;
             write_silh(silh, opp, snapv, s0, s1, s2, b, f, F);
             // coverage entry of a large-box triangle: head of the pixel list the resolve pass threads (atomicExch on .x)
-            if (cov16 != nullptr) cov16[(size_t)b * F + f] = make_int4(-1, 0, 0, (int)(((unsigned)stamp[0] << 8) | 0xFFu));
+            if (cov16 != nullptr) cov16[(size_t)b * F + f] = make_int2(-1, (int)((63u << 26) | ((unsigned)stamp[0] & 0x3FFFFFFu)));
         } else {
             // the opposite-vertex ids (antialias rule A3) are requested now and arrive while the coverage mask is computed
             if (silh != nullptr) { o0 = opp[f * 3]; o1 = opp[f * 3 + 1]; o2 = opp[f * 3 + 2]; }
@@ -262,9 +262,12 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         pin(p0); pin(p1); pin(p2);
         // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
         if (silh != nullptr) silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
-        // coverage entry (face-parallel backward): candidate-pixel mask of the box, its origin and width, tagged with the step stamp
+        // coverage entry (face-parallel backward), 8 B: candidate-pixel mask of the box | origin x, y (13 bits each) and width - 1 (6 bits,
+        // 63 = the pixel-list entry of a large-box face, which carries the step stamp instead of a box).  A small-box entry needs no
+        // stamp: the backward reads it only under a matching owner mark, an owner's entry was written this step, and a stale mark
+        // (8 bits) meets a stale entry only to have its candidates fail the owner test
         if (cov16 != nullptr)
-            cov16[(size_t)b * F + f] = make_int4((int)cm, 0, s.pxa | (s.pya << 16), (int)(((unsigned)stamp[0] << 8) | (unsigned)bw));
+            cov16[(size_t)b * F + f] = make_int2((int)cm, s.pxa | (s.pya << 13) | ((bw - 1) << 26));
         TriPark& t = park[threadIdx.x];
         t.p0 = p0; t.p1 = p1; t.p2 = p2; t.f = f; t.rbw = __builtin_amdgcn_rcpf((float)bw); t.origin = s.pxa | (s.pya << 16); t.bw = bw;
     }

@@ -313,7 +313,7 @@ template <int VPL>
 __global__ void __launch_bounds__(kFbBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))       // <= 128 VGPRs: 4 waves per SIMD (the few spills sit in the prologue, outside the pixel loop: 77.5 -> 72.5 us)
 k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
-           const int4* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
+           const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
            const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
            int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg)       // skip_lists: queued large-box faces have their own kernel
@@ -341,6 +341,13 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     const bool facelive = f < F;                                   // uniform over a group
     // ---- the coverage entries of this lane's (face, view)s; entries of other steps carry another stamp
     const unsigned cur = (unsigned)stamp[0] & 0xFFFFFFu;           // advanced once per step by the geometry kernel
+    // second word of a coverage entry (raster.hip): bits 26..31 = box width - 1, 63 = pixel-list entry of a large-box face, valid if its
+    // low 26 bits hold this step's stamp (a stale list head could chain into links that newer steps rewrote)
+    auto entry_kind = [&](int y) -> int {
+        const unsigned fld = (unsigned)y >> 26;
+        if (fld == 63u) return (((unsigned)y & 0x3FFFFFFu) == ((unsigned)stamp[0] & 0x3FFFFFFu)) ? 255 : 0;
+        return (int)fld + 1;
+    };
     // everything whose address is known up front is requested together (the kernel's time is #waves / wave slots x the length of
     // a wave's dependent-load chain): the owner marks, the entries, the face's vertex ids, the output slot
     int3a ti = {0, 0, 0};
@@ -354,27 +361,27 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     // The entries are needed once — box + candidate mask go into LDS task lists right away — and again only on two rare paths
     // (a face with more than kTaskG candidates, pixel lists of large boxes), which LOAD THEM AGAIN: kept alive through the pixel
     // loop their 36 registers were the difference between 3 and 4 waves per SIMD.
-    auto load_entries = [&](int ff, int4 (&e)[VPL], int (&kind)[VPL]) {
+    auto load_entries = [&](int ff, int2 (&e)[VPL], int (&kind)[VPL]) {
 #pragma unroll
         for (int v = 0; v < VPL; v++) {
             const int b = b0 + v * kGroup + j;
-            e[v] = make_int4(0, 0, 0, -1);
+            e[v] = make_int2(0, -1);
             unsigned char mark = 0;
             const bool live = facelive && b < n;
             if (live) {
                 mark = own8[(size_t)b * F + ff];
                 e[v] = cov16[(size_t)b * F + ff];
             }
-            kind[v] = (live && mark == (unsigned char)cur && ((unsigned)e[v].w >> 8) == cur) ? (e[v].w & 0xFF) : 0;
+            kind[v] = (live && mark == (unsigned char)cur) ? entry_kind(e[v].y) : 0;
         }
     };
     // first use: every request up front (owner marks and entries of all the lane's views together with the vertex ids above)
-    int4 e[VPL];
+    int2 e[VPL];
     unsigned char mark[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; v++) {
         const int b = b0 + v * kGroup + j;
-        e[v] = make_int4(0, 0, 0, -1);
+        e[v] = make_int2(0, -1);
         mark[v] = 0;
         if (facelive && b < n) {
             mark[v] = own8[(size_t)b * F + f];
@@ -386,7 +393,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
 #pragma unroll
     for (int v = 0; v < VPL; v++) {
         const bool live = facelive && (b0 + v * kGroup + j) < n;
-        kind[v] = (live && mark[v] == (unsigned char)cur && ((unsigned)e[v].w >> 8) == cur) ? (e[v].w & 0xFF) : 0;
+        kind[v] = (live && mark[v] == (unsigned char)cur) ? entry_kind(e[v].y) : 0;
         if (kind[v] >= 1 && kind[v] <= 64) cnt += __popc((unsigned)e[v].x);       // (boxes hold at most 32 pixels: .y is 0)
         anyv = anyv || kind[v] != 0;
         has_list = has_list || kind[v] == 255;
@@ -423,10 +430,10 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         for (int v = 0; v < VPL; v++)
             if (kind[v] != 0) {
                 const int at = tid * VPL + v;
-                pk_box[at] = (e[v].z & 0x1fff) | (((e[v].z >> 16) & 0x1fff) << 13) | (((kind[v] - 1) & 63) << 26);
+                pk_box[at] = e[v].y;                                 // the entry's second word IS the packed box
             }
         // candidate pixels of the group's box triangles, kTaskG per round; task = (view slot v * kGroup + j) << 6 | bit
-        auto expand = [&](int R, const int4 (&e)[VPL], const int (&kind)[VPL]) {
+        auto expand = [&](int R, const int2 (&e)[VPL], const int (&kind)[VPL]) {
             if (cnt != 0 && excl < R + kTaskG && excl + cnt > R) {
                 int idx = excl - R;
 #pragma unroll
@@ -513,7 +520,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         int fl = f;
         asm volatile("" : "+v"(fl));                                 // the rare paths below load the entries again through this copy
         if (__ballot(kTaskG < T) != 0ull) {                            // wave-uniform; further rounds are rare (> 64 candidates of a face)
-            int4 e2[VPL];
+            int2 e2[VPL];
             int kind2[VPL];
             load_entries(fl, e2, kind2);
             for (int R = kTaskG; __ballot(R < T) != 0ull; R += kTaskG) {
@@ -525,7 +532,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         }
         // ---- large-box triangles: the owning lane walks the pixel list (head in the entry, links in the owner field)
         if (!skip_lists && __ballot(has_list) != 0ull) {              // wave-uniform
-        int4 e2[VPL];
+        int2 e2[VPL];
         int kind2[VPL];
         load_entries(fl, e2, kind2);
 #pragma unroll
@@ -714,7 +721,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     const PixGrid pg = make_pix_grid(H, W);
 #define FMHR_FACE_BWD(VPL)                                                                                                          \
     k_face_bwd<VPL><<<grid, kFbBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
-                                             (const int4*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
+                                             (const int2*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
                                              (float4*)part, skip_lists, pg)
     switch (face_bwd_vpl(n)) {
         case 1: FMHR_FACE_BWD(1); break;

@@ -123,7 +123,7 @@ __device__ __forceinline__ float4 shade_word(const float4 w, const int32_t* __re
 
 // what the fused stage-2 step adds to the rasterizer's passes (all null for the stand-alone dr.rasterize path)
 struct RasterFused {
-    int4* cov16; int* stamp; unsigned char* own8;             // coverage entries, step counter, owner marks (face-parallel backward)
+    int2* cov16; int* stamp; unsigned char* own8;             // coverage entries, step counter, owner marks (face-parallel backward)
     float4* pix16; const float* mask;                         // per covered pixel (u, v, z/w, packed id | flags): see pix_pack
     const unsigned char* silh; int* llink;                    // silhouette bits per (view, face); list links of large-box faces' pixels
     const float4* attr8; const float* sh;                     // forward shading inputs
