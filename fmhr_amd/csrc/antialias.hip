@@ -384,7 +384,13 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
 // Per segment: the coverage words of the own / next / lower segments are wave-uniform loads; then every lane issues its two
 // rast loads (own, lower) together — the right neighbour's fragment is the next lane's register — and only pairs with different
 // triangle ids go on (silhouette byte first).  Colours are read as 16-B words only by the pairs that blend.
-constexpr int kAaGrid = 1280;                 // workgroups of the fused antialias kernels = regions of the work-item list: ONE resident round
+// Workgroups of the fused antialias kernels = regions of the work-item list: ONE resident round.  Row-aligned segments (W % 64 == 0:
+// the mask scan of k_aa_fwd_list): 768 workgroups at 3 waves per SIMD — the kernel needs ~137 VGPRs; at 1280 / 5 (96 VGPRs) it spilled
+// 37-59 registers into its latency-bound phases: 35 vs 23.5 us; 1024 / 4: 27 us; 512 / 2: 26 us.  The per-pixel scan of the other
+// case is the faster the more waves share its load latency: 1280 / 5 (36 us; 1024 / 4: 37, 768 / 3: 42).
+constexpr int kAaGridRow = 768, kAaGridAny = 1280;
+static bool aa_row_aligned(int n, int H, int W) { return (W & 63) == 0 && ((long long)n * H * W) < (1ll << 36); }   // segment ids below 2^30
+static int aa_grid(bool row) { return row ? kAaGridRow : kAaGridAny; }
                                               // of k_aa_fwd_list at its 5 waves per SIMD (96 VGPRs; 2048 workgroups ran as 1.6 rounds: 40.5 -> 32.7 us)
 constexpr int kCandBuf = 512;                 // candidate pairs one workgroup parks before analysing them densely
 constexpr int kItemBuf = 512;                 // work items one workgroup of k_aa_fwd_list buffers in LDS
@@ -457,11 +463,11 @@ __device__ __attribute__((noinline)) void aa_fwd_pair_overflow(int px, int py, i
 struct SegRows { UDiv per_view, per_row; unsigned segs_per_view, segs_per_row; };
 FMHR_WTS_DEFINE(aaf)
 template <bool ROW>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ROW ? 3 : 5, 8)))
 k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __restrict__ pos,
               const float* __restrict__ verts, const float4* __restrict__ cmat, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
               const int* __restrict__ act_list, const int* __restrict__ act_count, const unsigned long long* __restrict__ covw,
-              int n, int V, int F, int H, int W, float* __restrict__ out, int4* __restrict__ items,
+              const unsigned long long* __restrict__ silw, int n, int V, int F, int H, int W, float* __restrict__ out, int4* __restrict__ items,
               float* __restrict__ alphas, int32_t* __restrict__ counter, int32_t* __restrict__ region_cnt, int cap,
               const float* __restrict__ cnt_part, int nb_cnt, int* __restrict__ n_valid, float* __restrict__ n_valid_f, const SegRows sr)
 {
@@ -533,38 +539,15 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
         if (q.cD) q.rD = rast[gidD];
         if (lane == 63 && q.cR63) q.rR = rast[gid + 1];
     };
-    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    Words wd;
-    Pix cur, nxt;
-    stageA(i, wd);
-    stageB(wd, cur);
-    stageA(i + stride, wd);
-    for (; i < count; i += stride) {
-        stageB(wd, nxt);                                             // pixel words of iteration i + 1
-        stageA(i + 2 * stride, wd);                                  // segment + coverage words of iteration i + 2
-        if (cur.seg < 0) { cur = nxt; continue; }                    // skipped segment (wave-uniform)
-        float4 r0 = cur.r0, rD = cur.rD, rR = cur.rR;
-        pin(r0); pin(rD); pin(rR);
-        const int b = cur.b, px = cur.px, py = cur.py;
-        const bool c0 = cur.c0, cD = cur.cD, cR63 = cur.cR63, inR = cur.inR, inD = cur.inD;
-        // after the decode .w holds the dr.rasterize id (face + 1 as a float) and .x the face's silhouette bits
-        auto decode = [](float4& r, bool cov) {
-            const int p = __float_as_int(r.w);
-            r.x = cov ? (float)pix_silh(p) : 0.f;
-            r.w = cov ? (float)(pix_face(p) + 1) : 0.f;
-        };
-        decode(r0, c0); decode(rD, cD); decode(rR, lane == 63 && cR63);
-        {
-            const float z = __shfl_down(r0.z, 1), w = __shfl_down(r0.w, 1), sb = __shfl_down(r0.x, 1);
-            if (lane < 63) { rR.z = z; rR.w = w; rR.x = sb; }
-        }
+    // the pre-test of one pixel's two pairs (right, below): which triangle is in front, does it have a silhouette edge in this view?
+    // Ends almost every pair of a micro-triangle mesh; the survivors (a few per wave) are parked and analysed DENSELY by the whole
+    // workgroup afterwards instead of by one or two lanes of every wave.  r0 / rR / rD: decoded words (.x silhouette bits, .z depth,
+    // .w dr.rasterize id) of the pixel, its right and its lower neighbour
+    auto test_pairs = [&](int b, int px, int py, bool inR, bool inD, const float4& r0, const float4& rR, const float4& rD) {
 #pragma unroll
         for (int d = 0; d < 2; d++) {
             const float4 r1 = d ? rD : rR;
             if (!((d ? inD : inR) && r1.w != r0.w)) continue;
-            // pre-test of aa_analyse (which triangle is in front, does it have a silhouette edge in this view): ends almost
-            // every pair of a micro-triangle mesh; the survivors (a few per wave) are parked and analysed DENSELY by the whole
-            // workgroup afterwards instead of by one or two lanes of every wave
             const int tri0 = (int)r0.w - 1, tri1 = (int)r1.w - 1;
             int t = (tri0 >= 0) ? tri0 : tri1;
             if (tri0 >= 0 && tri1 >= 0) t = (r0.z < r1.z) ? tri0 : tri1;
@@ -579,9 +562,149 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
                             ibuf, abuf, &inum, region, rbase);
             }
         }
+    };
+    // after the decode .w holds the dr.rasterize id (face + 1 as a float) and .x the face's silhouette bits
+    auto decode = [](float4& r, bool cov) {
+        const int p = __float_as_int(r.w);
+        r.x = cov ? (float)pix_silh(p) : 0.f;
+        r.w = cov ? (float)(pix_face(p) + 1) : 0.f;
+    };
+    if (ROW) {
+        // ---- scan by MASKS.  A pair can only blend if the nearer of its two pixels belongs to a face with a silhouette edge, and the
+        // resolve pass left, per segment, the word of such pixels next to the coverage word.  So the scan does not look at pixels at
+        // all: per segment six 64-bit words (coverage + silhouette of the segment, of the next one in its row, of the one below) give
+        // the mask M of pixels whose right or lower pair CAN blend (the pixel itself, its right or its lower neighbour is such a
+        // pixel) — 4.8 of 64 on the metric mesh (tools/analysis/aa_scan_share.py).  Lane = segment for the masks, then the
+        // candidate pixels are numbered over the wave, expanded into a per-wave list and tested lane = candidate: the per-pixel
+        // words are loaded for them only, and the pre-test runs on dense waves.  As a per-segment pass over all 64 pixels (three
+        // 16-B loads, decode, shuffle, two tests per lane) the scan was 28 of this kernel's 35 us.
+        constexpr int kPixBuf = 256;                                 // candidate pixels a wave tests per round
+        __shared__ int2 pixl[kBlock / 64][kPixBuf];                  // (segment << 6 | lane, flags: c0, cR, cD, inR, inD)
+        const int wv = threadIdx.x >> 6;
+        int2* const pl = pixl[wv];
+        const unsigned spr = sr.segs_per_row;
+        // lane = one of the wave's segments (a wave has ~10 of them on the metric step: usually ONE pass)
+#ifdef FMHR_X_TS
+        unsigned long long tsx[4] = {0ull, 0ull, 0ull, 0ull};
+        const unsigned long long ts_a = wall_clock64();
+#endif
+        for (int base = blockIdx.x * 4 + wv; base < count; base += stride * 64) {       // wave-uniform trip count
+            const int ii = base + lane * stride;
+            const int ent = (ii < count) ? act_list[ii] : 0;
+            unsigned long long M = 0ull, c0w = 0ull, cRw = 0ull, cDw = 0ull;
+            unsigned sg = 0u;
+            bool lastcol = false, lastrow = false;
+            if (ent < 0) {                                           // (>= 0: no silhouette-face pixel in reach, k_active_segments)
+                sg = (unsigned)ent & 0x7fffffffu;
+                const unsigned vb = udiv(sg, sr.per_view), r = sg - vb * sr.segs_per_view;
+                const unsigned row = udiv(r, sr.per_row);
+                lastcol = r - row * spr == spr - 1; lastrow = (int)row == H - 1;
+                c0w = covw[sg];
+                unsigned long long s0w = silw[sg], sRw = 0ull, sDw = 0ull;
+                if (!lastcol) { cRw = covw[sg + 1]; sRw = silw[sg + 1]; }
+                if (!lastrow) { cDw = covw[sg + spr]; sDw = silw[sg + spr]; }
+                // the resolve pass writes a segment's silhouette word only when it resolves it: next to an empty coverage word it is stale
+                s0w = c0w ? s0w : 0ull; sRw = cRw ? sRw : 0ull; sDw = cDw ? sDw : 0ull;
+                M = s0w | (s0w >> 1) | (sRw << 63) | sDw;
+            }
+#ifdef FMHR_X_TS
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (tsx[0] == 0ull) tsx[0] = wall_clock64();
+#endif
+            const int cnt = __popcll(M);
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            const int excl = incl - cnt, T = __shfl(incl, 63, 64);
+            for (int R = 0; R < T; R += kPixBuf) {                   // wave-uniform
+                if (cnt != 0 && excl < R + kPixBuf && excl + cnt > R) {
+                    unsigned long long m = M;
+                    int idx = excl - R;
+                    while (m != 0ull) {
+                        const int bit = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        if (idx >= 0 && idx < kPixBuf) {
+                            const bool c0 = (c0w >> bit) & 1ull, cR = (bit < 63) ? ((c0w >> (bit + 1)) & 1ull) : (cRw & 1ull), cD = (cDw >> bit) & 1ull;
+                            const bool inR = bit < 63 || !lastcol, inD = !lastrow;
+                            pl[idx] = make_int2((int)((sg << 6) | (unsigned)bit),
+                                                (int)c0 | ((int)cR << 1) | ((int)cD << 2) | ((int)inR << 3) | ((int)inD << 4));
+                        }
+                        idx++;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef FMHR_X_TS
+                if (tsx[1] == 0ull) tsx[1] = wall_clock64();
+#endif
+                const int nr = min(kPixBuf, T - R);
+                for (int k0 = 0; k0 < nr; k0 += 64) {                // lane = candidate pixel
+                    const int k = k0 + lane;
+                    if (k < nr) {
+                        const int2 e = pl[k];
+                        const long long gid = (long long)(unsigned)e.x;
+                        const bool c0 = e.y & 1, cR = e.y & 2, cD = e.y & 4, inR = e.y & 8, inD = e.y & 16;
+                        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), rR = r0, rD = r0;
+                        if (c0) r0 = rast[gid];
+                        if (cR) rR = rast[gid + 1];
+                        if (cD) rD = rast[gid + W];
+                        pin(r0); pin(rR); pin(rD);
+#ifdef FMHR_X_TS
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        if (tsx[2] == 0ull) tsx[2] = wall_clock64();
+#endif
+                        decode(r0, c0); decode(rR, cR); decode(rD, cD);
+                        const unsigned sg2 = (unsigned)e.x >> 6;
+                        const unsigned vb = udiv(sg2, sr.per_view), r = sg2 - vb * sr.segs_per_view;
+                        const unsigned row = udiv(r, sr.per_row);
+                        test_pairs((int)vb, (int)((r - row * spr) << 6) + (e.x & 63), (int)row, inR, inD, r0, rR, rD);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the list is refilled by the next round
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#ifdef FMHR_X_TS
+        if (lane == 0 && wts_w_ < 81920) {
+            const unsigned long long t0_ = g_wts_aaf[wts_w_ * 4];
+            auto d16 = [&](unsigned long long t) -> unsigned long long { return t == 0ull ? 0ull : ((t - t0_) & 0xffffull); };
+            g_wts_aaf[wts_w_ * 4 + 2] = d16(ts_a) | (d16(tsx[0]) << 16) | (d16(tsx[1]) << 32) | (d16(tsx[2]) << 48);
+        }
+#endif
+    } else {
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    Words wd;
+    Pix cur, nxt;
+    stageA(i, wd);
+    stageB(wd, cur);
+    stageA(i + stride, wd);
+    for (; i < count; i += stride) {
+        stageB(wd, nxt);                                             // pixel words of iteration i + 1
+        stageA(i + 2 * stride, wd);                                  // segment + coverage words of iteration i + 2
+        if (cur.seg < 0) { cur = nxt; continue; }                    // skipped segment (wave-uniform)
+        float4 r0 = cur.r0, rD = cur.rD, rR = cur.rR;
+        pin(r0); pin(rD); pin(rR);
+        const bool c0 = cur.c0, cD = cur.cD, cR63 = cur.cR63;
+        decode(r0, c0); decode(rD, cD); decode(rR, lane == 63 && cR63);
+        {
+            const float z = __shfl_down(r0.z, 1), w = __shfl_down(r0.w, 1), sb = __shfl_down(r0.x, 1);
+            if (lane < 63) { rR.z = z; rR.w = w; rR.x = sb; }
+        }
+        test_pairs(cur.b, cur.px, cur.py, cur.inR, cur.inD, r0, rR, rD);
         cur = nxt;
     }
+    }
+#ifdef FMHR_X_TS
+    const unsigned long long ts_scan = wall_clock64();
+#endif
     __syncthreads();
+#ifdef FMHR_X_TS
+    const unsigned long long ts_bar = wall_clock64();
+#endif
     {
         const int nc = min(cnum, kCandBuf);
         for (int c = threadIdx.x; c < nc; c += kBlock) {
@@ -591,6 +714,14 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
                         W, out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
         }
     }
+#ifdef FMHR_X_TS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long ts_dense = wall_clock64();
+    if ((threadIdx.x & 63) == 0 && wts_w_ < 81920) {
+        const unsigned long long t0_ = g_wts_aaf[wts_w_ * 4];
+        g_wts_aaf[wts_w_ * 4 + 3] = ((ts_scan - t0_) & 0xfffff) | (((ts_bar - t0_) & 0xfffff) << 20) | (((ts_dense - t0_) & 0xfffff) << 40) | ((unsigned long long)min(cnum, 4095) << 52);
+    }
+#endif
     __syncthreads();
     const int nn = min(inum, min(kItemBuf, region));
     for (int i = threadIdx.x; i < nn; i += kBlock) { items[rbase + i] = ibuf[i]; alphas[rbase + i] = abuf[i]; }
@@ -866,22 +997,22 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
 // per-pixel word (shade_common.h), work items in per-workgroup regions of one list, persistent grids
 int aa_fwd_rgba(const float* attr8, const float* sh, float* dcols, const float* rast, const float* pos, const float* verts,
                 const float* cmat, const int32_t* tri, const int32_t* opp,
-                const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw, int n,
-                int V, int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int32_t* region_cnt, int cap,
+                const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw,
+                const unsigned long long* silw, int n, int V, int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int32_t* region_cnt, int cap,
                 const float* cnt_part, int nb_cnt, int* n_valid, float* n_valid_f, hipStream_t st)
 {
     AaShade sd;
     sd.words = (const float4*)rast; sd.attr8 = (const float4*)attr8; sd.sh = sh; sd.dcols = (float4*)dcols;
     SegRows sr;
     memset(&sr, 0, sizeof(sr));
-    const bool row = (W & 63) == 0 && ((long long)n * H * W) < (1ll << 36);      // segment ids below 2^30
+    const bool row = aa_row_aligned(n, H, W);
     if (row) {
         sr.segs_per_view = (unsigned)((long long)H * W >> 6); sr.segs_per_row = (unsigned)(W >> 6);
         sr.per_view = make_udiv(sr.segs_per_view); sr.per_row = make_udiv(sr.segs_per_row);
-        k_aa_fwd_list<true><<<kAaGrid, kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
+        k_aa_fwd_list<true><<<aa_grid(true), kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, silw, n, V, F, H, W,
                                            out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f, sr);
     } else {
-        k_aa_fwd_list<false><<<kAaGrid, kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, n, V, F, H, W,
+        k_aa_fwd_list<false><<<aa_grid(false), kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, silw, n, V, F, H, W,
                                            out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f, sr);
     }
     FMHR_CHECK_LAUNCH("k_aa_fwd_list");
@@ -890,13 +1021,14 @@ int aa_fwd_rgba(const float* attr8, const float* sh, float* dcols, const float* 
 
 int aa_bwd_rgba(const float* dcols, const float* rast, const float* pos, const float* verts, const int32_t* tri, const float* aa, const float* img,
                 const float* mask, const float* valid_mask, const unsigned long long* covw, const float* n_valid, float w_sfs,
-                float w_mask, float mse_den, const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int V,
+                float w_mask, float mse_den, const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int n, int V,
                 int H, int W, float* gcolor, const float* cmat, float* gvert, float* gvert2, hipStream_t st)
 {
     LossGrad L;
     L.aa = (const float4*)aa; L.img = img; L.mask = mask; L.valid_mask = valid_mask; L.covw = covw; L.n_valid = n_valid;
     L.w_sfs = w_sfs; L.w_mask = w_mask; L.mse_den = mse_den;
-    k_aa_bwd_items<<<kAaGrid, kBlock, 0, st>>>((const float4*)dcols, (const float4*)rast, pos, verts, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W,
+    k_aa_bwd_items<<<aa_grid(aa_row_aligned(n, H, W)), kBlock, 0, st>>>(       // the forward's grid: one workgroup per region
+        (const float4*)dcols, (const float4*)rast, pos, verts, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W,
                                            gcolor, (const float4*)cmat, gvert, gvert2);
     FMHR_CHECK_LAUNCH("k_aa_bwd_items");
     return FMHR_OK;

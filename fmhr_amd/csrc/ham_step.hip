@@ -44,10 +44,10 @@ int reshade_dense_impl(const unsigned long long*, const float*, const int32_t*, 
 int active_segments_blocks(long long N);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, const float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, float*, const float*, const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
-                const int*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int,
+                const int*, const unsigned long long*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int,
                 const float*, int, int*, float*, hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
-                const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int,
+                const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int, int,
                 int, int, float*, const float*, float*, float*, hipStream_t);
 int clip_positions_impl(const float*, const float*, int, int, float*, hipStream_t);
 int geometry_impl(const float*, const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, const int32_t*,
@@ -63,7 +63,7 @@ int face_bwd_blocks(int F);
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
-        g_shaded, cmat, gvert_aa, gvert_aa2, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, total;
+        g_shaded, cmat, gvert_aa, gvert_aa2, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -123,6 +123,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.one_third = take(off, 16);                    // the constant 1/3: the "valid-pixel count" that leaves the L1 divisor out (view-sharded step)
     L.seg_valid = take(off, ((nP + 63) / 64) * 4);   // valid-pixel count of every segment (resolve pass)
     L.cnt_part = take(off, (((nP + 63) / 64 + 1023) / 1024) * 4);   // the same per workgroup of k_active_segments
+    L.silw = take(off, ((nP + 63) / 64) * 8);        // per segment: pixels of silhouette faces (resolve pass -> antialias scan)
     L.total = off;
     return L;
 }
@@ -167,7 +168,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(own8); FMHR_OFF(stamp); FMHR_OFF(pix16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
     FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(aa_counter); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
-    FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(total);
+    FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(silw); FMHR_OFF(total);
 #undef FMHR_OFF
     set_error("ham_workspace_offset: unknown buffer '%s'", name);
     return -1;
@@ -260,7 +261,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.pix16 = (float4*)(w + L.pix16); fu.mask = mask;
         fu.silh = (const unsigned char*)(w + L.silh); fu.llink = (int*)(w + L.llink);
         fu.attr8 = (const float4*)(w + L.attr8); fu.sh = sh;
-        fu.aa_init = (float4*)(w + L.aa); fu.seg_valid = (int*)(w + L.seg_valid);
+        fu.aa_init = (float4*)(w + L.aa); fu.seg_valid = (int*)(w + L.seg_valid); fu.silw = (unsigned long long*)(w + L.silw);
         fu.verts = vertices; fu.cmat = (const float4*)(w + L.cmat);
         fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
         TRY(rasterize_fwd_impl(nullptr, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
@@ -275,7 +276,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     TRY(aa_fwd_rgba((const float*)(w + L.attr8), sh, (float*)(w + L.aa_dcol), (const float*)(w + L.pix16), nullptr, vertices, (const float*)(w + L.cmat), tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
-                    (const int*)(w + L.act_count), covw, d->n, d->V, d->F,
+                    (const int*)(w + L.act_count), covw, (const unsigned long long*)(w + L.silw), d->n, d->V, d->F,
                     d->H, d->W, (float*)(w + L.aa), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
                     (int32_t*)(w + L.aa_counter), (int32_t*)(w + L.aa_region_cnt), d->aa_cap, (const float*)(w + L.cnt_part),
                     active_segments_blocks(nP), n_valid_local, (float*)(w + L.n_valid_f), st));
@@ -330,7 +331,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         TRY(aa_bwd_rgba((const float*)(w + L.aa_dcol), (const float*)(w + L.pix16), nullptr, (const float*)(w + L.vertices), tri, (const float*)(w + L.aa), img, mask, valid_mask,
                         (const unsigned long long*)(w + L.covw), nv_div, wt->sfs, wt->mask, wt->mse_denominator,
                         (const int32_t*)(w + L.aa_items),
-                        (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->V, d->H, d->W,
+                        (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->n, d->V, d->H, d->W,
                         (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, split ? (float*)(w + L.gvert_aa2) : nullptr, st));
     }
     {

@@ -450,7 +450,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         if (!is_dirty) {
             if ((threadIdx.x & 63) == 0) {
                 covw[seg] = 0ull;
-                if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;
+                if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;      // (silw keeps its stale word: it is only read next to a non-zero coverage word)
             }
 #ifdef FMHR_X_TS
             if (ts_on) tsv[5] = wall_clock64();
@@ -578,6 +578,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                 covw[seg] = bal; dirty[seg] = 0;
                 // valid (mask > 0 and covered) pixels of the segment | bit 8: holds a silhouette-face pixel
                 if (fu.seg_valid != nullptr) fu.seg_valid[seg] = __popcll(vbal) | (sbal != 0ull ? 0x100 : 0);
+                if (fu.silw != nullptr) fu.silw[seg] = sbal;         // the antialias scan tests only pixels next to one of these
             }
         } else if (live) {
             rast[gid] = o;

@@ -127,6 +127,7 @@ struct RasterFused {
     float4* pix16; const float* mask;                         // per covered pixel (u, v, z/w, packed id | flags): see pix_pack
     const unsigned char* silh; int* llink;                    // silhouette bits per (view, face); list links of large-box faces' pixels
     const float4* attr8; const float* sh;                     // forward shading inputs
+    unsigned long long* silw;                                 // per segment: which of its covered pixels belong to a face with a silhouette edge
     float4* aa_init; int* seg_valid;                          // forward shading output (the rgba the antialias pass starts from) +
                                                               // valid-pixel count of every segment
     int* rearm2;                                              // two list cursors the resolve pass zeroes for the next kernel

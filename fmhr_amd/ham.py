@@ -61,7 +61,7 @@ class HamStage2:
         self.corner_slot = torch.zeros(3 * self.F, dtype=torch.int32, device=self.dev)
         call("fmhr_corner_slots_build", ptr(self.vf_idx), self.F, ptr(self.corner_slot), st)
         # antialias work items: only pairs that blend are listed (∝ silhouette length); 1/4 of the pixels is a generous bound
-        cap = int(aa_cap or max(2048 * 256, self.n * self.H * self.W // 4))     # 1280 regions (one per workgroup of the AA kernels) of >= 409 items
+        cap = int(aa_cap or max(2048 * 256, self.n * self.H * self.W // 4))     # 768 or 1280 regions (one per workgroup of the AA kernels) of >= 409 items
         self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap)
         self.ws_bytes = self.lib.fmhr_ham_workspace_bytes(ctypes.byref(self.dims))
         if self.ws_bytes == 0:

@@ -18,5 +18,5 @@ for it in range(241):
     hs.step(vt, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"], optimizer=opt, params=(delta, albedo))
     if it in (0, 10, 30, 60, 120, 240):
         torch.cuda.synchronize()
-        rc = hs.ws[o + 256: o + 256 + 1280 * 4].view(torch.int32)
+        rc = hs.ws[o + 256: o + 256 + 768 * 4].view(torch.int32)          # 768 regions when W % 64 == 0 (antialias.hip: aa_grid)
         print("step", it, "aa items", int(rc.sum()), "max per region", int(rc.max()), "delta max", float(delta.abs().max()))

@@ -51,7 +51,7 @@ def report(name, fn, nwaves, slots_per_simd):
     print("   resident waves at 10 % steps of the span:", [int(((start <= x) & (end > x)).sum()) for x in np.linspace(0.05, 0.95, 10) * T])
     for x in range(8):
         m = xcc == x
-        print(f"   XCD {x}: waves {m.sum()}, wave-time {life[m].sum():.0f} us, last end {end[m].max():.1f} us")
+        if m.any(): print(f"   XCD {x}: waves {m.sum()}, wave-time {life[m].sum():.0f} us, last end {end[m].max():.1f} us")
     key = xcc * 256 + cu
     u = np.unique(key)
     busy = np.array([life[key == k].sum() for k in u])
@@ -61,5 +61,21 @@ def report(name, fn, nwaves, slots_per_simd):
 
 report("tris", hs.lib.fmhr_debug_wts_raster, ((F + 255) // 256) * 48 * 4, 8)
 report("face_bwd", hs.lib.fmhr_debug_wts_shade, ((F + 31) // 32) * 4, 4)
-report("aa_fwd_list", hs.lib.fmhr_debug_wts_aaf, 1280 * 4, 5)
-report("aa_bwd_items", hs.lib.fmhr_debug_wts_aab, 1280 * 4, 7)
+report("aa_fwd_list", hs.lib.fmhr_debug_wts_aaf, 768 * 4, 3)
+report("aa_bwd_items", hs.lib.fmhr_debug_wts_aab, 768 * 4, 7)
+
+t = np.load("gpurun_out/wts_aa_fwd_list.npy")
+ph = t[:, 3].astype(np.uint64)
+m1, m2, m3 = (ph & np.uint64(0xfffff)).astype(float) / 100.0, ((ph >> np.uint64(20)) & np.uint64(0xfffff)).astype(float) / 100.0, ((ph >> np.uint64(40)) & np.uint64(0xfff)).astype(float) / 100.0
+nc = (ph >> np.uint64(52)).astype(int)
+life = (t[:, 1] - t[:, 0]) / 100.0
+print(f"aa_fwd_list per wave (median / p90): scan done {np.median(m1):.2f} / {np.percentile(m1, 90):.2f} us, past the barrier {np.median(m2):.2f} / {np.percentile(m2, 90):.2f}, "
+      f"candidates analysed {np.median(m3):.2f} / {np.percentile(m3, 90):.2f} (12-bit wrap at 40.96), wave end {np.median(life):.2f} / {np.percentile(life, 90):.2f}; "
+      f"candidate pairs per workgroup median {np.median(nc[::4])}, max {nc.max()}, total {nc[::4].sum()}")
+
+px = t[:, 2].astype(np.uint64)
+f = lambda k: ((px >> np.uint64(16 * k)) & np.uint64(0xffff)).astype(float) / 100.0
+a_, b_, c_, d_ = f(0), f(1), f(2), f(3)
+ok = d_ > 0
+print(f"aa_fwd_list scan phases from wave start (median over waves with candidates): prologue done {np.median(a_[ok]):.2f} us, mask words back {np.median(b_[ok]):.2f}, "
+      f"candidates listed {np.median(c_[ok]):.2f}, their pixel words back {np.median(d_[ok]):.2f}, pre-test done {np.median(m1[ok]):.2f}")
