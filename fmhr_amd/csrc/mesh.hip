@@ -399,8 +399,10 @@ struct MeshTailArgs {
 
 // Both kernels give a vertex kSub lanes: 49k vertices are < 1 wave per SIMD, so a lane-per-vertex launch leaves every dependent
 // gather chain (CSR row -> neighbour -> value) exposed; kSub lanes stride over the vertex's rows and combine with xor-shuffles.
+FMHR_WTS_DEFINE(taila)
 __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
 {
+    FMHR_WTS_BEGIN(taila, (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     const int v = (blockIdx.x * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
     float l_lap = 0.f, l_alb = 0.f, l_delta = 0.f;
     const bool live = v < A.V;                                     // uniform over a vertex's lanes
@@ -535,6 +537,7 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
             A.loss_part[(size_t)k * gridDim.x + blockIdx.x] = (sm4x4[0][k] + sm4x4[1][k] + sm4x4[2][k] + sm4x4[3][k]) * w;
         }
     }
+    FMHR_WTS_END(taila);
 }
 
 // the step's loss vector from the per-workgroup partials of k_loss_pix and k_mesh_tail_a (run by one extra workgroup of
@@ -595,11 +598,14 @@ __device__ __forceinline__ void finish_losses_block(const FinishArgs& A, float (
     }
 }
 
+FMHR_WTS_DEFINE(tailb)
 __global__ void __launch_bounds__(kBlock) k_mesh_tail_b(const MeshTailArgs A, const FinishArgs fin)
 {
+    FMHR_WTS_BEGIN(tailb, (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     if (blockIdx.x == 0) {                       // dispatched first: its one long round trip overlaps the per-vertex workgroups
         __shared__ float sm46[4][6];
         finish_losses_block(fin, sm46);
+        FMHR_WTS_END(tailb);
         return;
     }
     const float* __restrict__ verts = A.verts;
@@ -659,6 +665,7 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_b(const MeshTailArgs A, co
             }
         }
     }
+    FMHR_WTS_END(tailb);
 }
 
 // After the ONE all-reduce of a view-sharded step: bucket = [P_delta | P_albedo | R_delta | R_albedo | 8 loss slots], summed over

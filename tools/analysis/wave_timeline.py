@@ -63,6 +63,10 @@ report("tris", hs.lib.fmhr_debug_wts_raster, ((F + 255) // 256) * 48 * 4, 8)
 report("face_bwd", hs.lib.fmhr_debug_wts_shade, ((F + 31) // 32) * 4, 4)
 report("aa_fwd_list", hs.lib.fmhr_debug_wts_aaf, 768 * 4, 3)
 report("aa_bwd_items", hs.lib.fmhr_debug_wts_aab, 768 * 4, 7)
+nvb = (V * 8 + 255) // 256
+report("mesh_tail_a", hs.lib.fmhr_debug_wts_taila, nvb * 4, 8)
+report("mesh_tail_b", hs.lib.fmhr_debug_wts_tailb, (nvb + 1) * 4, 8)
+tb = np.load("gpurun_out/wts_mesh_tail_b.npy"); print("   tail_b finish block (workgroup 0): waves end at", [(round((x - tb[:, 0].min()) / 100.0, 2)) for x in tb[:4, 1]], "us")
 
 t = np.load("gpurun_out/wts_aa_fwd_list.npy")
 ph = t[:, 3].astype(np.uint64)
