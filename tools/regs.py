@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fmhr_amd", "csrc")
 STRICT = {"raster.hip", "antialias.hip"}          # -ffp-contract=off, as in build.sh
 want = sys.argv[1:]                               # optional substrings of kernel names
-for f in ("raster.hip", "antialias.hip", "shade.hip", "mesh.hip", "ncc.hip"):
+for f in ("raster.hip", "antialias.hip", "shade.hip", "mesh.hip", "ncc.hip", "stage1.hip"):
     with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math",
                "-ffp-contract=" + ("off" if f in STRICT else "on"), "-x", "hip", "-S", "--cuda-device-only", os.path.join(SRC, f),
