@@ -254,3 +254,34 @@ def test_topology_build(oracle):
     assert opp[0].tolist() == [4, 3, -1]
     assert opp[1].tolist() == [-1, -1, 1]
     assert opp[2].tolist() == [-1, -1, 0]
+
+
+def test_antialias_is_linear_in_colour_for_a_fixed_geometry(oracle):
+    """What the fused stage-1 step (fmhr_amd/stage1.py) rests on: with rast / pos fixed, antialias is a LINEAR map of its
+    colour input — out[tgt] += alpha (in[gid1] - in[gid]) per blending pair, the pairs and alphas depending on the geometry only — and
+    that map is a 4-neighbour stencil: out[p] = in[p] + sum over the pairs that blend into p of |alpha| (in[other] - in[p])."""
+    from util import mesh_scene, sort_items
+    sc = mesh_scene((2, 48, 40, 9, 13), seed=3)
+    pos, tri = sc["pos"].double(), sc["faces"]
+    H, W = sc["H"], sc["W"]
+    rast, _ = oracle.rasterize(None, pos, tri, (H, W))
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, H, W, 3, generator=g, dtype=torch.float64)
+    y = torch.rand(2, H, W, 3, generator=g, dtype=torch.float64)
+    ax, items_x, alphas_x = oracle.antialias(x, rast, pos, tri, return_items=True)
+    ay, items_y, alphas_y = oracle.antialias(y, rast, pos, tri, return_items=True)
+    assert items_x.shape[0] > 0, "the scene must have blending pairs"
+    ix, lx = sort_items(items_x, alphas_x)
+    iy, ly = sort_items(items_y, alphas_y)
+    assert torch.equal(ix, iy) and torch.equal(lx, ly)              # the work items do not depend on the colour
+    a, b = 0.37, -1.9
+    axy = oracle.antialias(a * x + b * y, rast, pos, tri)
+    assert (axy - (a * ax + b * ay)).abs().max() < 1e-12
+    # the stencil form, rebuilt from the items exactly as fmhr_stage1_row_ptr / _fill do
+    want = x.clone()
+    for (px, py, bv, code), al in zip(ix.tolist(), lx.tolist()):
+        down = (code >> 2) & 1
+        p0, p1 = (bv, py, px), (bv, py + down, px + 1 - down)
+        tgt, oth = (p0, p1) if al > 0 else (p1, p0)
+        want[tgt] += abs(al) * (x[oth] - x[tgt])
+    assert (want - ax).abs().max() < 1e-12
