@@ -108,7 +108,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.fmhr_abi_version() != 2:
+        if lib.fmhr_abi_version() != 3:
             raise RuntimeError("fmhr_amd: ABI version mismatch")
         _lib = lib
     return _lib

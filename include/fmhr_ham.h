@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMHR_ABI_VERSION 2
+#define FMHR_ABI_VERSION 3
 #define FMHR_OK 0
 #define FMHR_E_ARG (-1)   /* bad shape / null pointer / workspace too small */
 #define FMHR_E_HIP (-2)   /* HIP runtime error (message has hipGetErrorString) */

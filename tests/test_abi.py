@@ -26,7 +26,7 @@ def test_header_and_library_agree(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     exported = set(re.findall(r" T (fmhr_[a-z_0-9]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.fmhr_abi_version() == 2
+    assert lib.fmhr_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
