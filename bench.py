@@ -2,7 +2,10 @@
 """bench.py — HAM stage-2 iterations/sec on MI355X (BASELINE.json metric).
 
 One "step" = one full stage-2 iteration of /root/reference/mesh_sfs_optim.py:253-310 on the metric workload (48 views,
-512x512, sub3-class mesh V=48693/F=97088): render + six losses + backward + gradient exchange + Adam step.
+512x512, sub3 mesh V=49281/F=98432 — the sizes train_mlp.py:150-154 hard-codes): render + six losses + backward + gradient
+exchange + Adam step.  Before --warmup the optimisation is PRE-ROLLED untimed until the antialias work list is stationary (the
+synthetic targets roughen the contour: 2.4 k -> ~55 k silhouette pairs over the first ~50 steps, and the step slows by 6-7 % with
+it), so that a 20-step run and a 200-step run time the same workload.
 `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under torch.distributed.run, one rank per GPU,
 views sharded contiguously over ranks (strong scaling: the 48-view batch is fixed), ONE packed all-reduce per step (the
 photometric share of the gradient travels with its L1 divisor left out: fmhr_amd/dist.py).
@@ -10,7 +13,11 @@ photometric share of the gradient travels with its L1 divisor left out: fmhr_amd
 Prints ONE JSON line on rank 0 with the contract fields plus:
   roofline     — dominant launch group of the step: algorithmic bytes (SURVEY.md §8d per-primitive table) / its mean HIP-event
                  duration over the timed region, vs the 8 TB/s HBM peak
-  step_roofline— the same for the whole step: n*B_alg(view)+const bytes / device time of the step
+  step_roofline— the whole step: `traffic_frac` = MEASURED HBM bytes (PMC profile of this command) / device time / peak and
+                 `fused_bound_frac` = the fused lower bound (52 P + 96 V + 24 F per view) / device time / peak are the
+                 physical fractions; `op_granular_equivalent` prices the step by the reference's primitive chain (7.4x more bytes
+                 than the fused step moves: it exceeds the peak and is NOT a roofline fraction)
+  collective   — N > 1: per-rank milliseconds of the step's one all-reduce and of the combine (+ Adam) kernel (HIP events)
   kernels      — mean HIP-event milliseconds per launch group (from an untimed profiling pass)
   cpu_baseline — the CPU oracle restatement ("port") timed on this box's host cores on a bounded sample (rank 0, N=1 only)
   stage1       — side measurement (N=1 only, after the timed region): the fused stage-1 iteration of the same optimisation
@@ -60,6 +67,11 @@ def alg_bytes(slot, n, P, V, F, nnz):
 
 def step_alg_bytes(n, P, V, F, nnz):
     return n * (508 * P + 252 * V + 72 * F) + (48 * V + 24 * F) + 4 * (8 * nnz + 24 * V) + (24 * F + 60 * V) + 2 * 7 * 12 * V
+
+
+def step_fused_bound_bytes(n, P, V, F, nnz):
+    """the fully fused lower bound (inputs once, rast written + re-read, gradients once) + the per-step constant."""
+    return n * (52 * P + 96 * V + 24 * F) + (48 * V + 24 * F) + 4 * (8 * nnz + 24 * V) + (24 * F + 60 * V) + 2 * 7 * 12 * V
 
 
 class Timing:
@@ -172,6 +184,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage1", action="store_true", help="skip the stage-1 side measurement (N = 1 only; after the timed region)")
     ap.add_argument("--cpu-views", type=int, default=48)   # the whole 48-view batch: 5 x ~2.6 s of CPU work, nothing extrapolated
+    ap.add_argument("--preroll", type=int, default=240, help="upper bound of the untimed pre-roll (stops earlier once the antialias "
+                    "work list is stationary; at least 64 steps; 0 = none)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -217,12 +231,42 @@ def main():
         delta.grad, albedo.grad = gd, ga.view(1, V, 3)
         return losses
 
+    def step_parts():
+        """the view-sharded step with HIP events around its exchange: (kernels, all-reduce, combine + Adam) in ms — untimed
+        profiling pass only (N > 1)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        a = (vtmp, delta.detach(), albedo.detach()[0], sh, w2c, proj)
+        ev[0].record(stream)
+        hs.forward(*a, tg["mask"], tg["valid_mask"])
+        hs.backward(*a, tg["img"], tg["mask"], tg["valid_mask"], reg_range=reg_range, split=True)
+        ev[1].record(stream)
+        torch.distributed.all_reduce(hs.bucket, group=group)
+        ev[2].record(stream)
+        hs.combine((opt.fused_param(delta), opt.fused_param(albedo)))
+        ev[3].record(stream)
+        torch.cuda.synchronize()
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream()
+    # untimed pre-roll to the stationary workload: at least 64 optimiser steps, then until the antialias work-item count of a
+    # 16-step block is within 2 % of the previous block's (every rank runs the same number of steps: the criterion is evaluated on
+    # the all-reduced count), at most --preroll steps
+    preroll, aa_hist = 0, []
+    while preroll < args.preroll:
+        for _ in range(16):
+            step()
+        preroll += 16
+        cnt = hs.aa_item_count().to(torch.float32).reshape(1)
+        if world > 1:
+            torch.distributed.all_reduce(cnt)
+        aa_hist.append(float(cnt))
+        if preroll >= 64 and len(aa_hist) >= 2 and abs(aa_hist[-1] - aa_hist[-2]) <= 0.02 * max(aa_hist[-1], 1.0):
+            break
     for _ in range(args.warmup):
         step()
     barrier()
@@ -236,6 +280,14 @@ def main():
     Timing.detach()
     torch.cuda.synchronize()
     kernels = {name: sum(tm.ms(i, k) for i in range(prof_steps)) / prof_steps for k, name in enumerate(SLOTS)}
+    collective = None
+    if world > 1:
+        parts = torch.tensor([step_parts() for _ in range(5)][1:], dtype=torch.float64).mean(0).to(dev)     # [kernels, all-reduce, combine]
+        allp = [torch.zeros_like(parts) for _ in range(world)]
+        torch.distributed.all_gather(allp, parts)
+        collective = {"per_rank_ms": {"kernels": [round(float(p[0]), 4) for p in allp], "all_reduce": [round(float(p[1]), 4) for p in allp],
+                                      "combine_adam": [round(float(p[2]), 4) for p in allp]},
+                      "bytes": int(hs.bucket.numel() * 4), "note": "all_reduce includes the wait for the slowest rank's kernels"}
     P = H * W
     dom = max((k for k in range(len(SLOTS)) if alg_bytes(SLOTS[k], n, P, V, F, hs.nnz) > 0), key=lambda k: kernels[SLOTS[k]])
 
@@ -269,13 +321,24 @@ def main():
     elapsed = float(elapsed)
     dom_ms = sum(tk.ms(j, dom) for j in range(len(sampled))) / len(sampled)
     step_dev_ms = sum(ev0[j].elapsed_time(ev1[j]) for j in range(len(sampled))) / len(sampled)
-    final = hs.loss_dict() if world == 1 else dict(zip(("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid"), losses.tolist()))
+    # a full antialias work-item list (some silhouette pairs without a gradient) invalidates the run — on EVERY rank
+    ovf = torch.tensor([1.0 if hs.aa_overflowed() else 0.0], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(ovf)
+    if float(ovf) != 0:
+        raise SystemExit(f"bench.py: the antialias work-item list overflowed on {int(float(ovf))} rank(s) (aa_cap={hs.dims.aa_cap})")
+    final = dict(zip(("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid"), losses.tolist()))
+    aa_items = hs.aa_item_count().to(torch.float32).reshape(1)
+    if world > 1:
+        torch.distributed.all_reduce(aa_items)
 
     if rank == 0:
         # HBM traffic of the launch groups comes from the committed PMC profile of this same command (counters cannot be
         # collected live next to the timed region); null when the workload differs from the profiled one
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
         if os.path.exists(tpath) and args.config == "metric" and world == 1 and args.views is None:
             traffic = json.load(open(tpath))
         ms_per_step = elapsed / K * 1e3
@@ -283,15 +346,21 @@ def main():
         dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
         sb = step_alg_bytes(n, P, V, F, hs.nnz)
         step_gbs = sb / (step_dev_ms * 1e-3) / 1e9
+        fb = step_fused_bound_bytes(n, P, V, F, hs.nnz)
+        fused_gbs = fb / (step_dev_ms * 1e-3) / 1e9
+        t_lo, t_hi = (traffic["step_total_low"], traffic["step_total_high"]) if traffic else (None, None)
         out = {
             "metric": "HAM render+backward iters/sec (48 views, 49k verts, 512x512)",
             "value": K / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n_total} views x {H}x{W}, blob mesh V={V} F={F} ({'MANO sub3' if V > 40000 else 'MANO base / coarse'} class), "
-                                   f"stage-2 step = render + 6 losses + backward + grad all-reduce + Adam",
+            "config": {"workload": f"{args.config}: {n_total} views x {H}x{W}, synthetic hand mesh V={V} F={F} "
+                                   f"({'MANO sub3 counts' if V % 49281 == 0 else 'MANO base counts' if V % 778 == 0 else 'custom'}"
+                                   f"{', two hands' if scene.get('hands', 1) == 2 else ''}), "
+                                   f"stage-2 step = render + 6 losses + backward + grad all-reduce + Adam, stationary (pre-rolled {preroll} steps)",
                        "views": n_total, "views_per_gpu": n, "H": H, "W": W, "V": V, "F": F,
-                       "coverage": round(tg["coverage"], 4), "parallelism": f"views sharded over {world} GPU(s)"},
+                       "coverage": round(tg["coverage"], 4), "parallelism": f"views sharded over {world} GPU(s)",
+                       "preroll_steps": preroll, "aa_items_per_step": int(float(aa_items)), "aa_items_during_preroll": [int(x) for x in aa_hist]},
             "roofline": {"bound": "hbm", "kernel": SLOTS[dom], "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get(SLOTS[dom]),
                          # the same launch priced by its MEASURED HBM bytes (upper estimate of the PMC profile): how busy HBM really was
@@ -299,9 +368,14 @@ def main():
                          "traffic_frac": ((traffic or {}).get(SLOTS[dom]) or 0) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS or None,
                          "traffic_source": (traffic or {}).get("_source"), "alg_bytes_per_launch": dom_bytes,
                          "avg_launch_ms": dom_ms, "event_samples": len(sampled)},
-            "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": step_gbs / HBM_PEAK_GBS, "alg_bytes_per_step": sb, "device_ms_per_step": step_dev_ms,
-                              "traffic_low_high": [traffic["step_total_low"], traffic["step_total_high"]] if traffic else None},
+            "step_roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "device_ms_per_step": step_dev_ms,
+                              # physical: measured HBM bytes of the step (PMC profile; FETCH_SIZE x1 .. x2 + WRITE_SIZE) per device time
+                              "traffic_low_high": [t_lo, t_hi] if traffic else None,
+                              "traffic_frac": [t_lo / (step_dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, t_hi / (step_dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS] if traffic else None,
+                              # physical: the least a fully fused step must move (SURVEY.md §8d lower bound) per device time
+                              "fused_bound_bytes_per_step": fb, "fused_bound_gbs": fused_gbs, "fused_bound_frac": fused_gbs / HBM_PEAK_GBS,
+                              # NOT a roofline fraction: the reference's op-by-op primitive chain priced at this step's time
+                              "op_granular_equivalent": {"alg_bytes_per_step": sb, "gbs": step_gbs, "x_of_peak": step_gbs / HBM_PEAK_GBS}},
             "kernels_ms": {k: round(v, 4) for k, v in kernels.items()},
             # every launch group against the same yardstick (untimed profiling pass): algorithmic GB/s and, where the committed PMC
             # profile has it, the measured HBM bytes of the launch
@@ -309,6 +383,8 @@ def main():
                            "hbm_bytes": (traffic or {}).get(k)} for k, v in kernels.items() if alg_bytes(k, n, P, V, F, hs.nnz) > 0},
             "losses": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in final.items()},
         }
+        if collective is not None:
+            out["collective"] = collective
         # the two side measurements must never cost the headline line: a failure is reported in their place
         if world == 1 and not args.no_stage1:
             try:

@@ -167,7 +167,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(own8); FMHR_OFF(stamp); FMHR_OFF(pix16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
-    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(aa_counter); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
+    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(aa_counter); FMHR_OFF(aa_region_cnt); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(silw); FMHR_OFF(total);
 #undef FMHR_OFF
     set_error("ham_workspace_offset: unknown buffer '%s'", name);
@@ -196,6 +196,7 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_workspace_init: workspace too small or null");
     char* w = (char*)ws;
     HIPTRY(hipMemsetAsync(w + L.aa_counter, 0, 16, (hipStream_t)stream), "init aa_counter");
+    HIPTRY(hipMemsetAsync(w + L.aa_region_cnt, 0, 2048 * 4, (hipStream_t)stream), "init aa_region_cnt");   // regions beyond the grid stay 0
     // self-cleaning accumulator: k_mesh_tail_a zeroes each entry after consuming it
     HIPTRY(hipMemsetAsync(w + L.gvert_aa, 0, (size_t)d->V * 12 * kAaReplicas, (hipStream_t)stream), "init gvert_aa");
     HIPTRY(hipMemsetAsync(w + L.gvert_aa2, 0, (size_t)d->V * 12 * kAaReplicas, (hipStream_t)stream), "init gvert_aa2");

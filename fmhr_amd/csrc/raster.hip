@@ -136,7 +136,8 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
               int2* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
-              const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg)
+              const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg,
+              unsigned char* __restrict__ own8)
 {
     FMHR_WTS_BEGIN(raster, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kTrisBlock / 64) + (threadIdx.x >> 6));
     __shared__ TriPark park[kTrisBlock];
@@ -146,6 +147,18 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     const int f = blockIdx.x * kTrisBlock + threadIdx.x;
     const int b = blockIdx.y;                                        // wave-uniform (SGPR)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // Owner marks (resolve pass -> face-parallel backward) are the low BYTE of the step that wrote them, and the backward trusts a
+    // matching mark: a (view, face) that owned a pixel in step s, covers no pixel centre afterwards while that pixel stays
+    // uncovered, would meet its stale mark, stale coverage entry, stale pixel word and stale image gradient again in step s + 256.
+    // So no mark lives longer than 128 steps: every 128th step this kernel — one lane per (view, face), ahead of the resolve pass
+    // that writes the step's fresh marks — resets all of them to a value that cannot match before the next reset (scalar test on
+    // the other 127 steps: nothing on the hot path).  tests/test_gpu_ham.py::test_stale_owner_mark_after_256_steps
+#ifndef FMHR_X_NO_MARK_WIPE                                          // (measurement / regression-validation builds only)
+    if (own8 != nullptr) {
+        const int st = stamp[0];                                     // scalar load, wave-uniform
+        if ((st & 127) == 0 && f < F) own8[(size_t)b * F + f] = (unsigned char)(st + 128);
+    }
+#endif
     unsigned cm = 0u;
     bool is_large = false;
     int i0 = 0, i1 = 0, i2 = 0, o0 = -1, o1 = -1, o2 = -1, bw = 1;
@@ -544,7 +557,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                     // has no candidate mask: its pixels are threaded onto a list instead (head = .x of its coverage entry)
                     if (large) fu.llink[gid] = atomicExch(reinterpret_cast<int*>(&fu.cov16[(size_t)b * F + f]), rem);
                     // "this (view, face) owns pixels in step <stamp>": lets the backward skip the coverage entries of hidden
-                    // faces.  Only a hint (8-bit stamp; a stale match costs a wasted entry load, never a wrong result)
+                    // faces (8-bit stamp; k_raster_tris wipes all marks every 128 steps, so a mark never meets its value again)
                     fu.own8[(size_t)b * F + f] = (unsigned char)step_tag;
                     fu.pix16[gid] = make_float4(fr.u, fr.v, fr.zw, __int_as_float(pix_pack(f, mk > 0.f, large, sbits)));
                     sbits_any = sbits != 0;
@@ -858,9 +871,9 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
         const dim3 tgrid(cdiv(F, kTrisBlock), n);                    // view = blockIdx.y
         if (fu.verts != nullptr)
-            k_raster_tris<true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg);
+            k_raster_tris<true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8);
         else
-            k_raster_tris<false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg);
+            k_raster_tris<false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg, fu.stamp != nullptr ? fu.own8 : nullptr);
         FMHR_CHECK_LAUNCH("k_raster_tris");
     }
     {

@@ -190,17 +190,66 @@ class HamStage2:
         nbytes = count * torch.empty((), dtype=dtype).element_size()
         return self.ws[off: off + nbytes].view(dtype)
 
+    def aa_item_count(self):
+        """number of antialias work items (silhouette pixel pairs that blend) of the last step: a device tensor, no synchronisation.
+        It grows while the optimisation roughens the contour (2.4 k -> ~55 k over the first ~50 steps of the metric workload), and
+        the antialias kernels' time with it: benchmarks pre-roll until it is stationary."""
+        if getattr(self, "_aa_regions", None) is None:
+            off = self.lib.fmhr_ham_workspace_offset(ctypes.byref(self.dims), b"aa_region_cnt")
+            self._aa_regions = self.ws[off: off + 2048 * 4].view(torch.int32)
+        return self._aa_regions.sum()
+
+    def aa_overflowed(self):
+        """True if the antialias work-item list was full in the last step (one device -> host copy)."""
+        if self._aa_flag is None:
+            off = self.lib.fmhr_ham_workspace_offset(ctypes.byref(self.dims), b"aa_counter")
+            self._aa_flag = self.ws[off: off + 8].view(torch.int32)
+        return int(self._aa_flag[1]) != 0
+
     def loss_dict(self):
         """The loss vector of the last step as a dict (one device -> host copy).  Also the place where a full antialias work-item
         list is reported: the step never synchronises on its own, so the flag is checked when the caller reads results anyway."""
         vals = self.losses.tolist()
-        if self._aa_flag is None:
-            off = self.lib.fmhr_ham_workspace_offset(ctypes.byref(self.dims), b"aa_counter")
-            self._aa_flag = self.ws[off: off + 8].view(torch.int32)
-        if int(self._aa_flag[1]) != 0:
+        if self.aa_overflowed():
             raise RuntimeError(f"HamStage2: the antialias work-item list overflowed (aa_cap={self.dims.aa_cap}): some silhouette pairs "
                                "got no gradient in the last step; construct HamStage2 with a larger aa_cap")
         return dict(zip(LOSS_NAMES, vals))
+
+
+class _HamStepFn(torch.autograd.Function):
+    """The whole stage-2 loop body (mesh_sfs_optim.py:253-306) as ONE differentiable op: forward runs fmhr_ham_forward +
+    fmhr_ham_backward (the fused step always forms the gradients: the loss vector is a by-product of the backward's reductions),
+    backward hands the stored gradients to autograd.  `loss.backward()` then fills `delta.grad` / `albedo.grad` exactly as the
+    reference's `loss.backward()` (:309) does, and `optimizer.step()` (:310) stays the caller's."""
+
+    @staticmethod
+    def forward(ctx, hs, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group, reg_range):
+        alb = albedo.detach()
+        ctx.albedo_shape = tuple(albedo.shape)
+        if alb.dim() == 3:                               # the reference keeps albedo as [1,V,3] (:176)
+            if alb.shape[0] != 1:
+                raise RuntimeError("ham_step: albedo must be [V,3] or [1,V,3]")
+            alb = alb[0]
+        losses, gdelta, galbedo = hs.step(vertices_tmp, delta.detach(), alb, sh, w2c, proj, img, mask, valid_mask, group=group,
+                                          reg_range=reg_range)
+        # the step's buffers are overwritten by the next step: autograd gets its own copies (2 x 0.6 MB at V = 49k)
+        ctx.save_for_backward(gdelta.clone(), galbedo.clone())
+        out = losses.clone()
+        ctx.mark_non_differentiable(out)
+        return out[6].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_losses):
+        gdelta, galbedo = ctx.saved_tensors
+        return (None, None, gdelta * g_total, (galbedo * g_total).view(ctx.albedo_shape), None, None, None, None, None, None,
+                None, None)
+
+
+def ham_step(hs, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group=None, reg_range=None):
+    """-> (loss, losses[8]): `loss` is the scalar of mesh_sfs_optim.py:306, differentiable w.r.t. `delta` [V,3] and `albedo`
+    ([V,3] or the reference's [1,V,3]); `losses` = [sfs, lap, albedo, mask, edge, delta, total, n_valid] (detached; read it every
+    k steps instead of six .item() per step, :312-314).  `hs`: the HamStage2 that owns the mesh tables and the workspace."""
+    return _HamStepFn.apply(hs, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group, reg_range)
 
 
 def render_forward(faces, vertices, albedo, sh, w2c, proj, mask, H, W):

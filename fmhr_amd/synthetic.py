@@ -16,14 +16,20 @@ DEMO_LR = dict(lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
 SEMI_AXES = (0.0965, 0.0306, 0.0838)
 
 CONFIGS = {
-    # name: (views, H, W, rings, segments, subdivisions).  The base blob 21 x 37 has V=778 / F=1517 (MANO: 778 / 1538); three
-    # 1:4 subdivisions give V=48693 / F=97088 (MANO sub3: 49281 / 98432) with MANO-like bounded valence and the face/vertex
-    # order contract of SURVEY.md Appendix E.
-    "C1": (1, 256, 256, 21, 37, 0),
-    "C2": (8, 512, 334, 21, 37, 0),
-    "C3": (16, 512, 512, 21, 37, 3),
-    "metric": (48, 512, 512, 21, 37, 3),
-    "C4": (48, 1024, 1024, 21, 37, 3),
+    # name: (views, H, W, rings, segments, subdivisions[, hands[, frames]]).  rings = "mano": the tapered disc base of `mano_disc_base`
+    # with EXACTLY MANO's counts (V=778 / F=1538 / E=2315, 16 boundary edges: mano/TEMPLATE_RIGHT.obj); three 1:4 subdivisions give
+    # V=49281 / F=98432 / E=147712 — the sizes /root/reference/train_mlp.py:150-154 hard-codes — with MANO-like bounded valence and
+    # the face/vertex order contract of SURVEY.md Appendix E.  (A plain rings x segments UV blob, e.g. 21 x 37, has V=778 / F=1517
+    # and subdivides to 48693 / 97088: it stays available for the parity tests' small shapes.)
+    "C1": (1, 256, 256, "mano", 0, 0),
+    "C2": (8, 512, 334, "mano", 0, 0),
+    "C3": (16, 512, 512, "mano", 0, 3),
+    "metric": (48, 512, 512, "mano", 0, 3),
+    "C4": (48, 1024, 1024, "mano", 0, 3),
+    # BASELINE.json configs[4]: two hands (each subdivided on its own, concatenated as mesh_sfs_optim.py:76-87,100-111 does),
+    # 32 views x 8 frames of 334 x 512 (conf/ih_sfsseq.conf:11-13); a frame is an independent (delta, albedo) problem on the shared
+    # topology (fmhr_amd.dist.shard_frames_views)
+    "C5": (32, 512, 334, "mano", 0, 3, 2, 8),
 }
 
 
@@ -78,6 +84,61 @@ def blob_mesh(rings, segs, seed=0, bump=0.10, subdiv=0):
         faces.append(np.stack([a0 + ring0, b0 + ring0, b0 + nxt], 1))
         faces.append(np.stack([a0 + ring0, b0 + nxt, a0 + nxt], 1))
     faces = np.concatenate(faces, 0).astype(np.int32)
+    th, ph, faces = _subdivide_params(th, ph, faces, subdiv)
+    verts = _blob_surface(th[:, None], ph[:, None], seed, bump)[:, 0, :]
+    return verts.astype(np.float32), faces.astype(np.int32)
+
+
+def mano_disc_base():
+    """Tapered open-wrist blob with exactly the counts of the MANO template (V=778, F=1538, E=2315; disc topology with a
+    16-edge wrist loop): a pole + 29 latitude rings whose segment counts follow the ring circumference (max 38) down to 16 at the
+    open wrist, neighbouring rings zipped by angle.  F = 2(V-1) - B holds for any such ring profile; the profile below sums to
+    777 ring vertices.  Returns (th [V], ph [V], faces [F,3] int32): parameters on the blob surface, so that subdivision can put
+    new vertices on the analytic surface."""
+    rings, wrist = 29, 16
+    sin = np.sin(TH_MAX * np.arange(1, rings + 1) / rings)
+    k = wrist / sin[-1]
+    counts = np.maximum(6, np.rint(k * sin)).astype(np.int64)
+    counts[-1] = wrist
+    # hit 777 exactly by trimming / padding the widest rings one vertex at a time (deterministic order)
+    order = np.argsort(-sin[:-1], kind="stable")
+    i = 0
+    while counts.sum() != 777:
+        counts[order[i % order.size]] += 1 if counts.sum() < 777 else -1
+        i += 1
+    th = [0.0]
+    ph = [0.0]
+    start = [1]
+    for r, c in enumerate(counts):
+        th += [TH_MAX * (r + 1) / rings] * int(c)
+        ph += list(2 * math.pi * np.arange(c) / c)
+        start.append(start[-1] + int(c))
+    faces = [[0, 1 + j, 1 + (j + 1) % int(counts[0])] for j in range(int(counts[0]))]
+    for r in range(rings - 1):
+        m, kk = int(counts[r]), int(counts[r + 1])
+        u0, l0 = start[r], start[r + 1]
+        i = j = 0
+        for _ in range(m + kk):
+            # next angle on either ring, in exact integer arithmetic: (i+1)/m vs (j+1)/kk
+            lower = j < kk and (i == m or (j + 1) * m <= (i + 1) * kk)
+            if lower:
+                faces.append([u0 + i % m, l0 + j % kk, l0 + (j + 1) % kk])
+                j += 1
+            else:
+                faces.append([u0 + i % m, l0 + j % kk, u0 + (i + 1) % m])
+                i += 1
+    return np.array(th), np.array(ph), np.array(faces, dtype=np.int32)
+
+
+def mano_disc_mesh(seed=0, bump=0.10, subdiv=0):
+    """`mano_disc_base` on the bumpy ellipsoid, subdivided `subdiv` times 1:4 (new vertices on the analytic surface)."""
+    th, ph, faces = mano_disc_base()
+    th, ph, faces = _subdivide_params(th, ph, faces, subdiv)
+    verts = _blob_surface(th[:, None], ph[:, None], seed, bump)[:, 0, :]
+    return verts.astype(np.float32), faces.astype(np.int32)
+
+
+def _subdivide_params(th, ph, faces, subdiv):
     for _ in range(subdiv):
         V = th.shape[0]
         faces, edges, _ = subdivide(faces, V)
@@ -89,8 +150,16 @@ def blob_mesh(rings, segs, seed=0, bump=0.10, subdiv=0):
         dphi = (pb - pa + math.pi) % (2 * math.pi) - math.pi
         th = np.concatenate([th, 0.5 * (th[a] + th[b])])
         ph = np.concatenate([ph, pa + 0.5 * dphi])
-    verts = _blob_surface(th[:, None], ph[:, None], seed, bump)[:, 0, :]
-    return verts.astype(np.float32), faces.astype(np.int32)
+    return th, ph, faces
+
+
+def two_hands(verts, faces, gap=0.075):
+    """Second hand = the first mirrored in y and shifted (orientation kept by swapping two corners), concatenated as the reference
+    concatenates its per-hand subdivisions (mesh_sfs_optim.py:76-87): vertices [2V,3], faces [2F,3] with the second hand's indices
+    offset by V — two connected components, two boundary loops."""
+    v2 = verts * np.array([1.0, -1.0, 1.0], dtype=verts.dtype) + np.array([0.0, gap, 0.0], dtype=verts.dtype)
+    f2 = faces[:, [0, 2, 1]] + verts.shape[0]
+    return np.concatenate([verts, v2], 0).astype(np.float32), np.concatenate([faces, f2], 0).astype(np.int32)
 
 
 def fibonacci_dirs(n):
@@ -135,10 +204,16 @@ def cameras(verts, n, H, W, coverage=0.25, dist=0.6):
     return np.stack(w2cs).astype(np.float32), np.stack(projs).astype(np.float32)
 
 
-def make_scene(views, H, W, rings, segs, subdiv=0, seed=0, coverage=0.25):
-    """Everything the stage-2 loop needs except the rendered targets (see make_targets)."""
+def make_scene(views, H, W, rings, segs, subdiv=0, seed=0, coverage=0.25, hands=1):
+    """Everything the stage-2 loop needs except the rendered targets (see make_targets).  rings = "mano": the exact-count disc
+    base (segs ignored); hands = 2: the two-component mesh of the reference's two-hand captures."""
     rng = np.random.default_rng(seed)
-    verts, faces = blob_mesh(rings, segs, seed, subdiv=subdiv)
+    if rings == "mano":
+        verts, faces = mano_disc_mesh(seed, subdiv=subdiv)
+    else:
+        verts, faces = blob_mesh(rings, segs, seed, subdiv=subdiv)
+    if hands == 2:
+        verts, faces = two_hands(verts, faces)
     w2c, proj = cameras(verts, views, H, W, coverage)
     V = verts.shape[0]
     sh_true = np.concatenate([np.full((views, 1), 0.8), 0.1 * rng.standard_normal((views, 8))], 1).astype(np.float32)
@@ -147,15 +222,18 @@ def make_scene(views, H, W, rings, segs, subdiv=0, seed=0, coverage=0.25):
     sh0 = (sh_true + 0.02 * rng.standard_normal(sh_true.shape)).astype(np.float32)
     albedo0 = np.full((V, 3), 0.6, dtype=np.float32)
     t = torch.from_numpy
-    return dict(views=views, H=H, W=W, V=V, F=faces.shape[0],
+    return dict(views=views, H=H, W=W, V=V, F=faces.shape[0], hands=hands,
                 vertices=t(verts), faces=t(faces), w2c=t(w2c), proj=t(proj),
                 vertices_true=t(verts_true), albedo_true=t(albedo_true), sh_true=t(sh_true),
                 albedo0=t(albedo0), sh0=t(sh0), weights=dict(DEMO_WEIGHTS), lr=dict(DEMO_LR))
 
 
 def scene_from_config(name, seed=0, views=None):
-    v, H, W, r, c, sd = CONFIGS[name]
-    return make_scene(views or v, H, W, r, c, sd, seed)
+    v, H, W, r, c, sd = CONFIGS[name][:6]
+    hands = CONFIGS[name][6] if len(CONFIGS[name]) > 6 else 1
+    sc = make_scene(views or v, H, W, r, c, sd, seed, hands=hands)
+    sc["frames"] = CONFIGS[name][7] if len(CONFIGS[name]) > 7 else 1
+    return sc
 
 
 def make_targets(scene, forward_fn, device=None):

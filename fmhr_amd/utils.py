@@ -6,6 +6,7 @@ argument meaning, backed by gfx950 kernels (C ABI).  GPU tensors only; there is 
     get_radiance(coeff[9] or [n,9], normal[n,3], 3)     models/utils.py:208-226
     laplacian_smoothing(verts[V,C], faces, "uniform")   models/utils.py:696-722
 """
+import numpy as np
 import torch
 
 from . import _lib
@@ -54,8 +55,25 @@ def get_normals(vertices, faces):
 
 
 def get_matrix(normal, degree=3):
-    """SH design matrix [n, degree^2], columns (1, y, z, x, xy, yz, 2z^2-x^2-y^2, zx, x^2-y^2).  Plain tensor algebra: it
-    is only used for the one-off least-squares initialisation (mesh_sfs_optim.py:153,165)."""
+    """SH design matrix [n, degree^2], columns (1, y, z, x, xy, yz, 2z^2-x^2-y^2, zx, x^2-y^2).  Plain array algebra: it
+    is only used for the one-off least-squares initialisation, where the reference hands it a NumPy array of the valid pixels'
+    normals (mesh_sfs_optim.py:153,165) — np.ndarray in -> float64 np.ndarray out, exactly as models/utils.py:188-190 (the
+    products are formed in the input's precision and stored into a float64 matrix); torch.Tensor in -> tensor out."""
+    if isinstance(normal, np.ndarray):
+        matrix = np.zeros((normal.shape[0], degree ** 2))
+        matrix[:, 0] = 1
+        if degree > 1:
+            matrix[:, 1], matrix[:, 2], matrix[:, 3] = normal[:, 1], normal[:, 2], normal[:, 0]
+        if degree > 2:
+            x, y, z = normal[:, 0], normal[:, 1], normal[:, 2]
+            matrix[:, 4] = x * y
+            matrix[:, 5] = y * z
+            matrix[:, 6] = 2 * z * z - x * x - y * y
+            matrix[:, 7] = z * x
+            matrix[:, 8] = x * x - y * y
+        return matrix
+    if not isinstance(normal, torch.Tensor):
+        raise RuntimeError("get_matrix: normal must be a numpy array or a torch tensor [n,3]")
     x, y, z = normal[:, 0], normal[:, 1], normal[:, 2]
     cols = [torch.ones_like(x)]
     if degree > 1:
@@ -89,9 +107,15 @@ class _RadianceFn(torch.autograd.Function):
 
 
 def get_radiance(coeff, normal, degree=3):
-    """coeff 9 or n 9, normal n 3 -> radiance n (order-3 SH irradiance polynomial, no normalisation constants)."""
-    if degree != 3:
-        raise RuntimeError("get_radiance: only degree=3 is on the HAM hot path (conf/demo_sfs.conf:23)")
+    """coeff degree^2 or n degree^2, normal n 3 -> radiance n (SH irradiance polynomial without normalisation constants;
+    degree 3 on the HAM hot path, conf/demo_sfs.conf:29; degrees 1 and 2 are the same polynomial with the higher bands' coefficients
+    zero: the coefficient rows are zero-padded to 9, autograd slices the gradient back)."""
+    if degree not in (1, 2, 3):
+        raise RuntimeError("get_radiance: degree must be 1, 2 or 3")
+    if degree < 3:
+        if coeff.shape[-1] < degree ** 2:
+            raise RuntimeError("get_radiance: coeff must have at least degree^2 entries")
+        coeff = torch.nn.functional.pad(coeff[..., :degree ** 2], (0, 9 - degree ** 2))
     if normal.dim() != 2 or normal.shape[1] != 3 or coeff.shape[-1] != 9 or coeff.dim() not in (1, 2):
         raise RuntimeError("get_radiance: coeff must be [9] or [n,9], normal [n,3]")
     if coeff.dim() == 2 and coeff.shape[0] != normal.shape[0]:

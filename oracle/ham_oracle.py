@@ -310,12 +310,18 @@ def clip_positions(vertices, w2c, proj):
 
 def ham_stage2_losses(vertices_tmp, delta, albedo, sh_coeff, w2c, proj, img, mask, valid_mask, faces, resolution,
                       weights, edge_length_mean, degree=3, sfs_denominator=None, mse_denominator=None, dr=None,
-                      pos_value=None):
+                      pos_value=None, decisions=None):
     """One stage-2 forward of the reference (mesh_sfs_optim.py:253-306) on top of the oracle `dr` ops.
 
     weights: dict(sfs, lap, albedo, mask, edge, delta).  Returns dict with the six losses, `loss`, and the named
     intermediates.  `sfs_denominator` / `mse_denominator` override the batch-local divisors 3*Pv and n*P (used by the
-    view-sharded path).  `pos_value` injects clip positions (values only)."""
+    view-sharded path).  `pos_value` injects clip positions (values only).
+    `decisions`: the `decisions` entry a previous fp32 run of the same inputs returned.  The loop body has two discrete decisions of
+    its own besides the rasterizer's (which the C library's "mix" variants take from the fp32 twin under f32_decisions): the SIGN of
+    every L1 residual (:289, d |d| = sign(d)) and the ACTIVE SET of the edge hinge (:302, clip(x, 0, 1) has a gradient only for
+    0 < x < 1).  A residual or a hinge argument within fp32 rounding of its threshold is decided differently by exact arithmetic —
+    one flipped edge of 295 k moves the gradient by 7e-4 of its maximum on the sub3 mesh — so "fp64 values on fp32 decisions"
+    takes these from the fp32 run as well: sum(sign32 * d64) and where(active32, x64, const)."""
     import torch.nn.functional as F
     import sys
     dr = dr or sys.modules[__name__]
@@ -341,7 +347,14 @@ def ham_stage2_losses(vertices_tmp, delta, albedo, sh_coeff, w2c, proj, img, mas
     tmp_img = torch.zeros_like(img)
     tmp_img[valid_idx] = pred_img
     tmp_img = dr.antialias(tmp_img, rast_out, proj_verts, faces)
-    diff = (tmp_img[valid_idx] - img[valid_idx]).abs()
+    resid = tmp_img[valid_idx] - img[valid_idx]
+    l1_sign = torch.sign(resid.detach())
+    if decisions is not None:
+        l1_sign = decisions["l1_sign"].to(resid.dtype)
+        assert l1_sign.shape == resid.shape, "decisions come from a run with another valid set"
+        diff = l1_sign * resid                                   # == |resid| wherever the two runs agree on the sign
+    else:
+        diff = resid.abs()
     den = diff.numel() if sfs_denominator is None else sfs_denominator
     sfs_loss = weights["sfs"] * diff.sum() / den
     lap_loss = weights["lap"] * laplacian_smoothing(vertices, faces.long(), method="uniform")
@@ -351,12 +364,18 @@ def ham_stage2_losses(vertices_tmp, delta, albedo, sh_coeff, w2c, proj, img, mas
     fl = faces.long()
     a, b, c = vertices[fl[:, 0]], vertices[fl[:, 1]], vertices[fl[:, 2]]
     edge_length = torch.cat([((a - b) ** 2).sum(1), ((c - b) ** 2).sum(1), ((a - c) ** 2).sum(1)])
-    edge_loss = torch.clip(edge_length - edge_length_mean, 0, 1).mean() * weights["edge"]
+    hinge_x = edge_length - edge_length_mean
+    hinge_active = ((hinge_x > 0) & (hinge_x < 1)).detach()
+    if decisions is not None:
+        hinge_active = decisions["hinge_active"]
+        edge_loss = torch.where(hinge_active, hinge_x, torch.clip(hinge_x, 0, 1).detach()).mean() * weights["edge"]
+    else:
+        edge_loss = torch.clip(hinge_x, 0, 1).mean() * weights["edge"]
     delta_loss = (delta ** 2).sum(1).mean() * weights["delta"]
     loss = sfs_loss + lap_loss + albedo_loss + mask_loss + delta_loss + edge_loss
     return dict(loss=loss, sfs=sfs_loss, lap=lap_loss, albedo=albedo_loss, mask=mask_loss, edge=edge_loss, delta=delta_loss,
                 pos=proj_verts, normals=normals, rast=rast_out, pred_normals=pred_normals, pred_mask=pred_mask,
-                tmp_img=tmp_img, n_valid=int(valid.sum()))
+                tmp_img=tmp_img, n_valid=int(valid.sum()), decisions=dict(l1_sign=l1_sign, hinge_active=hinge_active))
 
 
 def edge_length_mean(vertices, faces):

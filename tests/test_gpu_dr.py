@@ -29,6 +29,10 @@ def scenes():
     out.append(("C2", sc["pos"], sc["faces"], 512, 334))
     sc = mesh_scene((2, 256, 256, 96, 128), seed=2)         # micro-triangle regime
     out.append(("micro", sc["pos"], sc["faces"], 256, 256))
+    # two hands: two connected components, each with its own boundary loop, concatenated as mesh_sfs_optim.py:76-87 does; they
+    # occlude each other in some views (inter-component depth order and silhouette pairs), W = 334 (conf/ih_sfsseq.conf:11)
+    sc = mesh_scene((3, 256, 334, 12, 16, 1, 2), seed=3)
+    out.append(("two_hands", sc["pos"], sc["faces"], 256, 334))
     return out
 
 
@@ -73,7 +77,7 @@ def test_rasterize_interpolate_antialias_forward(dr, oracle, case):
         assert rel_err(a2, a_ref) < 1e-6
 
 
-@pytest.mark.parametrize("case", scenes()[:5], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", scenes()[:5] + scenes()[7:], ids=lambda c: c[0])
 def test_backward_parity(dr, oracle, case):
     """the composed rasterize -> interpolate -> antialias chain, gradients w.r.t. pos / attr / color vs the oracle
     (fp32 twin and fp64)."""

@@ -6,10 +6,27 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import mesh_scene, rel_err
+from util import log_parity, mesh_scene, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+
+# The gradient bar is a HARD 1e-4 (per-tensor max|a-b| / max|b| against fp64 values on the fp32 decisions) for every case except the
+# ones named here, each with its measured reason.  In those the fp32 RESTATEMENT OF THE REFERENCE (the oracle's fp32 twin: per-pixel
+# autograd through the homogeneous edge functions, exactly nvdiffrast's formulation) is itself further than 1e-4 from exact
+# arithmetic, because an edge-on triangle amplifies the last bit of its clip positions by 1 / area; the fused step must then be no
+# further from fp64 than twice that twin.  The measured numbers of every case are written to profiles/parity_r03.txt.
+RELAXED = {}
+
+
+def grad_bar(name, e_d, e_a, o_d, o_a):
+    log_parity(f"{name}: fused vs fp64-on-fp32-decisions: gdelta {e_d:.2e} galbedo {e_a:.2e} | fp32 oracle twin vs the same: "
+               f"{o_d:.2e} {o_a:.2e} | bar {'2x twin (' + RELAXED[name] + ')' if name in RELAXED else '1e-4 hard'}")
+    if name in RELAXED:
+        assert o_d > TOL or o_a > TOL, f"{name}: listed as relaxed but the fp32 twin meets 1e-4: remove it from RELAXED"
+        assert e_d < max(TOL, 2 * o_d) and e_a < max(TOL, 2 * o_a), (name, e_d, e_a, o_d, o_a)
+    else:
+        assert e_d < TOL and e_a < TOL, (name, e_d, e_a, o_d, o_a)
 
 
 def oracle_forward_fn(oracle, sc):
@@ -42,7 +59,11 @@ CASES = [("C1", (1, 256, 256, 24, 32), 0), ("C2x3", (3, 512, 334, 24, 32), 1), (
          ("views19", (19, 96, 80, 12, 16), 3), ("views30", (30, 64, 48, 10, 14), 4), ("views41", (41, 64, 48, 10, 14), 5),
          ("ragged", (6, 50, 38, 10, 14), 6),       # H*W = 1900: the 64-pixel segments straddle view boundaries
          ("views53", (53, 48, 40, 10, 14), 7),     # more than 48 views: two view groups (two partial planes for the mesh tail)
-         ("coarse50", (50, 96, 96, 4, 6), 8)]      # every triangle a large-box one, in two view groups (queue + k_face_bwd_large)
+         ("coarse50", (50, 96, 96, 4, 6), 8),      # every triangle a large-box one, in two view groups (queue + k_face_bwd_large)
+         # BASELINE.json configs[4] in small: TWO hands = two connected components with a boundary loop each, subdivided per hand and
+         # concatenated as mesh_sfs_optim.py:76-87 does, W = 334 (conf/ih_sfsseq.conf:11), more than 48 views (two view groups)
+         ("two_hands50", (50, 128, 334, 10, 14, 1, 2), 9),
+         ("two_hands_mano", (3, 512, 334, "mano", 0, 1, 2), 10)]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
@@ -59,7 +80,7 @@ def test_fused_step_vs_oracle(oracle, case):
     v = hs.views()
     pos_gpu = v["pos"].cpu()
 
-    def run_oracle(dtype):
+    def run_oracle(dtype, decisions=None):
         # the oracle is evaluated AT the GPU's clip positions (its own einsum differs from the kernel in the last bit, which
         # would move snapped vertices); they are first checked to agree to 1e-6
         c = lambda t: t.to(dtype)
@@ -67,7 +88,7 @@ def test_fused_step_vs_oracle(oracle, case):
         a = c(sc["albedo"])[None].clone().requires_grad_(True)
         ref = oracle.ham_stage2_losses(c(sc["vertices"]), d, a, c(sc["sh0"]), c(sc["w2c"]), c(sc["proj"]), c(sc["img"]),
                                        c(sc["mask"]), c(sc["valid_mask"]), sc["faces"], (sc["H"], sc["W"]), sc["weights"],
-                                       sc["elm"], pos_value=pos_gpu)
+                                       sc["elm"], pos_value=pos_gpu, decisions=decisions)
         ref["loss"].backward()
         return ref, d.grad, a.grad[0]
 
@@ -77,7 +98,7 @@ def test_fused_step_vs_oracle(oracle, case):
     assert torch.equal(v["rast"].cpu(), ref["rast"]), "rast must be bit-identical to the fp32 oracle"
     assert ld["n_valid"] == ref["n_valid"] and ref["n_valid"] > 100
     with oracle.f32_decisions():                            # fp64 values on the same decisions: the truth for 1e-4
-        ref64, gd64, ga64 = run_oracle(torch.float64)
+        ref64, gd64, ga64 = run_oracle(torch.float64, ref["decisions"])
     assert ref64["n_valid"] == ref["n_valid"]
     # images: tight against the fp32 twin; against fp64 only loosely — fp32 barycentrics of edge-on (near-degenerate)
     # silhouette triangles are ill-conditioned in ANY fp32 implementation of the formula (the oracle twin shows the same)
@@ -91,9 +112,11 @@ def test_fused_step_vs_oracle(oracle, case):
     o_d, o_a = rel_err(gd32, gd64), rel_err(ga32, ga64)
     print(f"{name}: grad rel err vs fp64 oracle: delta {e_d:.2e} albedo {e_a:.2e}; fp32 oracle's own: {o_d:.2e} {o_a:.2e}; "
           f"vs fp32 oracle: {rel_err(gdelta, gd32):.2e} {rel_err(galbedo, ga32):.2e}")
-    # the bar: within 1e-4 of exact arithmetic on the same decisions — or, where fp32 itself cannot reach that (see above),
-    # no further from it than 2x the fp32 restatement of the reference is
-    assert e_d < max(TOL, 2 * o_d) and e_a < max(TOL, 2 * o_a), name
+    log_parity(f"{name}: losses vs fp64: " + " ".join(f"{k} {abs(ld[k] - float(ref64[k])) / max(abs(float(ref64[k])), 1e-6):.1e}"
+                                                       for k in ("sfs", "lap", "albedo", "mask", "edge", "delta"))
+               + f" | tmp_img vs fp32 twin {rel_err(v['tmp_img'], ref['tmp_img']):.1e} vs fp64 {rel_err(v['tmp_img'], ref64['tmp_img']):.1e}"
+               + f" | n_valid {ld['n_valid']:.0f} rast bit-identical")
+    grad_bar(name, e_d, e_a, o_d, o_a)
     # run-to-run spread of the float-atomic accumulation stays far inside the tolerance
     g1 = gdelta.clone()
     hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
@@ -181,13 +204,13 @@ def _step_vs_oracle(oracle, sc, name, osc=None):
     v = hs.views()
     pos_gpu = v["pos"].cpu()
 
-    def run_oracle(dtype):
+    def run_oracle(dtype, decisions=None):
         c = lambda t: t.to(dtype)
         d = c(sc["delta"]).clone().requires_grad_(True)
         a = c(sc["albedo"])[None].clone().requires_grad_(True)
         ref = oracle.ham_stage2_losses(c(sc["vertices"]), d, a, c(sc["sh0"]), c(sc["w2c"]), c(sc["proj"]), c(sc["img"]),
                                        c(osc["mask"]), c(sc["valid_mask"]), sc["faces"], (sc["H"], sc["W"]), osc["weights"],
-                                       sc["elm"], pos_value=pos_gpu)
+                                       sc["elm"], pos_value=pos_gpu, decisions=decisions)
         ref["loss"].backward()
         return ref, d.grad, a.grad[0]
 
@@ -195,14 +218,14 @@ def _step_vs_oracle(oracle, sc, name, osc=None):
     assert torch.equal(v["rast"].cpu(), ref["rast"]), name
     assert osc is not sc or ld["n_valid"] == ref["n_valid"], name
     with oracle.f32_decisions():
-        ref64, gd64, ga64 = run_oracle(torch.float64)
+        ref64, gd64, ga64 = run_oracle(torch.float64, ref["decisions"])
     for k in ("sfs", "lap", "albedo", "mask", "edge", "delta"):
         assert abs(ld[k] - float(ref64[k])) <= TOL * max(abs(float(ref64[k])), 1e-6), (name, k, ld[k], float(ref64[k]))
     assert all(torch.isfinite(t).all() for t in (losses, gdelta, galbedo)), name
     e_d, e_a = rel_err(gdelta, gd64), rel_err(galbedo, ga64)
     o_d, o_a = rel_err(gd32, gd64), rel_err(ga32, ga64)
-    assert e_d < max(TOL, 2 * o_d) and e_a < max(TOL, 2 * o_a), (name, e_d, e_a, o_d, o_a)
     print(f"{name}: grad rel err vs fp64 oracle: delta {e_d:.2e} albedo {e_a:.2e}; fp32 oracle's own: {o_d:.2e} {o_a:.2e}")
+    grad_bar(name, e_d, e_a, o_d, o_a)
     v = dict(v, gdelta=gdelta.clone(), galbedo=galbedo.clone(), gd64=gd64, ga64=ga64, o_d=o_d, o_a=o_a)
     return ld, v
 
@@ -358,7 +381,7 @@ def test_unchanged_loop_body_on_dr(oracle):
 
 @pytest.mark.parametrize("shape", [(3, 512, 512), (2, 1024, 1024), (1, 1024, 1280)], ids=lambda s: "x".join(map(str, s)))
 def test_full_size_step_vs_oracle_and_composed_ops(oracle, shape):
-    """the metric's mesh (V=48693, F=97088) at the metric's 512x512, at configs[3]'s 1024x1024 and at the demo capture's
+    """the metric's mesh (V=49281, F=98432) at the metric's 512x512, at configs[3]'s 1024x1024 and at the demo capture's
     1280x1024 (conf/demo_sfs.conf: w=1280, h=1024): (1) the fused step against the CPU oracle exactly as the small
     cases are checked (bit-identical rast vs the fp32 twin, values vs fp64-on-fp32-decisions); (2) against the reference's loop
     body composed from the generic fmhr_amd.dr / fmhr_amd.utils ops on identical clip positions: every discrete decision
@@ -367,8 +390,8 @@ def test_full_size_step_vs_oracle_and_composed_ops(oracle, shape):
     from fmhr_amd.ham import render_forward, edge_length_mean
     dev = torch.device("cuda:0")
     n, H, W = shape
-    sc = S.make_scene(n, H, W, 21, 37, 3, seed=3)
-    assert sc["V"] == 48693 and sc["F"] == 97088
+    sc = S.make_scene(n, H, W, "mano", 0, 3, seed=3)
+    assert sc["V"] == 49281 and sc["F"] == 98432                                      # train_mlp.py:150-154
     faces = sc["faces"].to(dev)
     fwd = lambda v, a, s, m: render_forward(faces, v, a, s, sc["w2c"].to(dev), sc["proj"].to(dev), m, H, W)
     tg = S.make_targets(sc, fwd, device=dev)
@@ -377,7 +400,7 @@ def test_full_size_step_vs_oracle_and_composed_ops(oracle, shape):
     sc["albedo"] = sc["albedo0"] + 0.05 * torch.rand(sc["V"], 3, generator=gen)       # not constant: |L a| = 0 has no gradient
     sc.update({k: tg[k].cpu() for k in ("img", "mask", "valid_mask")})
     sc["elm"] = float(edge_length_mean(sc["vertices"].to(dev), faces))
-    ld, v = _step_vs_oracle(oracle, sc, "metric_mesh %dx%dx%d" % shape)
+    ld, v = _step_vs_oracle(oracle, sc, "metric_mesh_%dx%dx%d" % shape)
     assert ld["n_valid"] > 0.1 * n * H * W
     if shape[1] != 512:
         return
@@ -401,16 +424,18 @@ def test_full_size_step_vs_oracle_and_composed_ops(oracle, shape):
     e_c = rel_err(out["delta"].grad, v["gd64"])
     print(f"composed ops: gdelta rel err vs fp64 oracle {e_c:.2e} (fp32 oracle {v['o_d']:.2e}, fused "
           f"{rel_err(v['gdelta'], v['gd64']):.2e})")
-    assert e_c < max(TOL, 2 * v["o_d"])
+    log_parity(f"metric_mesh_%dx%dx%d: GENERIC ops (import-swap path) gdelta vs fp64 {e_c:.2e} (fp32 twin {v['o_d']:.2e}), "
+               f"galbedo vs fused {rel_err(v['galbedo'], out['albedo'].grad[0]):.2e}" % shape)
+    assert e_c < max(TOL, 2 * v["o_d"])                     # the generic per-pixel ops ARE the fp32 formulation: bounded by its twin
     assert rel_err(v["gdelta"], out["delta"].grad) < max(TOL, 2 * v["o_d"])
 
 
 def test_full_size_properties():
-    """sub3-class mesh (V=48693, F=97088) at 512x512, 4 views: size-independent properties (the oracle is too slow here)."""
+    """sub3 mesh (V=49281, F=98432) at 512x512, 4 views: size-independent properties (the oracle is too slow here)."""
     from fmhr_amd import synthetic as S
     from fmhr_amd.ham import HamStage2, render_forward, edge_length_mean
     dev = torch.device("cuda:0")
-    sc = S.make_scene(4, 512, 512, 21, 37, 3, seed=0)
+    sc = S.make_scene(4, 512, 512, "mano", 0, 3, seed=0)
     faces = sc["faces"].to(dev)
     fwd = lambda v, a, s, m: render_forward(faces, v, a, s, sc["w2c"].to(dev), sc["proj"].to(dev), m, 512, 512)
     tg = S.make_targets(sc, fwd, device=dev)
@@ -451,3 +476,65 @@ def test_full_size_properties():
     r1 = rast.clone()
     hs.step(*args)
     assert torch.equal(hs.views()["rast"], r1)
+
+
+def test_stale_owner_mark_after_256_steps(oracle):
+    """ADVICE r2 (shade.hip box path): the owner mark of a (view, face) is the low BYTE of the step that wrote it.  A face that owns
+    pixel p at step s and then covers no pixel centre any more, while p stays uncovered, keeps its coverage entry, its mark, the
+    pixel word of p and p's image gradient — and at step s + 256 the mark matches again.  One workspace: step 1 on a zoomed-IN
+    camera (large silhouette), steps 2..257 on the same mesh zoomed OUT (sub-pixel faces, the outer ring of step 1's silhouette
+    uncovered): the gradient of step 257 must equal the one a fresh workspace gives."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (3, 96, 80, 24, 32), 31)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    far = g["proj"].clone()
+    far[:, 0, 0] *= 0.45                                   # zoom out about the principal point: fx, fy scaled (row-vector layout)
+    far[:, 1, 1] *= 0.45
+    mask1 = torch.ones_like(g["mask"])
+    args_near = (g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], mask1, g["valid_mask"])
+    args_far = (g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], far, g["img"], mask1, g["valid_mask"])
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    hs.step(*args_near)
+    cov_near = hs.views()["rast"][..., 3] > 0
+    for _ in range(256):
+        hs.step(*args_far)
+    ld = hs.loss_dict()
+    gd, ga = hs.gdelta.clone(), hs.galbedo.clone()
+    cov_far = hs.views()["rast"][..., 3] > 0
+    assert int((cov_near & ~cov_far).sum()) > 200          # the scenario exists: pixels that lost their coverage
+    fresh = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    fresh.step(*args_far)
+    ld0 = fresh.loss_dict()
+    e_d, e_a = rel_err(gd, fresh.gdelta), rel_err(ga, fresh.galbedo)
+    log_parity(f"stale_owner_mark: step 257 on one workspace vs a fresh workspace: gdelta {e_d:.2e} galbedo {e_a:.2e}")
+    assert abs(ld["total"] - ld0["total"]) <= 1e-6 * abs(ld0["total"])
+    assert e_d < 5e-5 and e_a < 5e-5, (e_d, e_a)          # run-to-run spread of the antialias-backward atomics only
+
+
+def test_fused_step_as_autograd_function(oracle):
+    """north_star: the fused step "exposed as a torch.autograd.Function": loss = ham_step(...); loss.backward() fills delta.grad /
+    albedo.grad ([1,V,3] as the reference keeps it, mesh_sfs_optim.py:176) and torch.optim.Adam steps on them (:308-310)."""
+    from fmhr_amd.ham import HamStage2, ham_step
+    sc = prepare(oracle, (2, 128, 96, 16, 24), 0)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    ref_d, ref_a, ref_l = hs.gdelta.clone(), hs.galbedo.clone(), hs.losses.clone()
+    delta = g["delta"].clone().requires_grad_(True)
+    albedo = g["albedo"][None].clone().requires_grad_(True)
+    optimizer = torch.optim.Adam([{'params': delta, 'lr': 1e-4}, {'params': albedo, 'lr': 5e-3}])
+    loss, losses = ham_step(hs, g["vertices"], delta, albedo, g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    assert loss.requires_grad and not losses.requires_grad and loss.dim() == 0
+    optimizer.zero_grad()
+    (2.0 * loss).backward()
+    assert albedo.grad.shape == (1, sc["V"], 3)
+    assert rel_err(delta.grad, 2.0 * ref_d) < 5e-5 and rel_err(albedo.grad[0], 2.0 * ref_a) < 1e-6
+    assert rel_err(losses[:7], ref_l[:7]) < 1e-6 and float(loss) == float(losses[6])
+    d0 = delta.detach().clone()
+    optimizer.step()
+    assert float((delta.detach() - d0).abs().max()) > 0
+    # a second step overwrites the workspace buffers; the first step's saved gradients must be its own
+    loss2, _ = ham_step(hs, g["vertices"], delta, albedo, g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    assert float(loss2) != float(loss)

@@ -46,3 +46,46 @@ def test_step_fd_and_precision(oracle):
     o32["loss"].backward()
     assert abs(float(o32["loss"]) - float(out["loss"])) < 1e-4 * float(out["loss"])
     assert rel_err(d32.grad, d.grad) < 5e-3 and rel_err(a32.grad, a.grad) < 5e-3
+
+
+def test_loop_body_decisions_are_taken_from_the_fp32_run(oracle):
+    """The loop body's own discrete decisions — the sign of every L1 residual (:289) and the active set of the edge hinge (:302) — can
+    be handed from an fp32 run to the fp64 run ("fp64 values on fp32 decisions"): with the run's own decisions nothing changes; with
+    one hinge entry forced the other way exactly that edge's gradient share appears / disappears."""
+    sc = prepare(oracle, (2, 64, 48, 8, 10), 4)
+    f64 = {k: sc[k].double() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    elm = float(oracle.edge_length_mean(f64["vertices"], sc["faces"]))
+
+    def run(t, dec=None):
+        d = t["delta"].clone().requires_grad_(True)
+        a = t["albedo"].clone().requires_grad_(True)
+        o = oracle.ham_stage2_losses(t["vertices"], d, a[None], t["sh0"], t["w2c"], t["proj"], t["img"], t["mask"], t["valid_mask"],
+                                     sc["faces"], (sc["H"], sc["W"]), sc["weights"], elm, decisions=dec)
+        o["loss"].backward()
+        return o, d.grad, a.grad
+
+    o0, gd0, ga0 = run(f64)
+    o1, gd1, ga1 = run(f64, o0["decisions"])
+    assert float(o1["loss"]) == float(o0["loss"]) and torch.equal(gd0, gd1) and torch.equal(ga0, ga1)
+    dec = dict(o0["decisions"], hinge_active=o0["decisions"]["hinge_active"].clone())
+    k = int(torch.nonzero(dec["hinge_active"])[0])
+    dec["hinge_active"][k] = False
+    o2, gd2, _ = run(f64, dec)
+    F3 = 3 * sc["F"]
+    fl = sc["faces"].long()
+    ends = [(0, 1), (2, 1), (0, 2)][k // sc["F"]]                        # order of the concatenation in :296-301
+    i, j = int(fl[k % sc["F"], ends[0]]), int(fl[k % sc["F"], ends[1]])
+    x = f64["vertices"] + f64["delta"]
+    share = 2.0 * (x[i] - x[j]) * sc["weights"]["edge"] / F3
+    diff = gd0 - gd2
+    assert torch.allclose(diff[i], share, rtol=1e-9, atol=1e-12) and torch.allclose(diff[j], -share, rtol=1e-9, atol=1e-12)
+    touched = torch.zeros(sc["V"], dtype=torch.bool); touched[i] = touched[j] = True
+    assert float(diff[~touched].abs().max()) == 0.0
+    # the fp32 twin's decisions on the fp64 values: where both agree this is the plain fp64 result
+    with oracle.f32_decisions():
+        o32, _, _ = run({k_: sc[k_] for k_ in f64})
+        o3, gd3, _ = run(f64, o32["decisions"])
+    same = torch.equal(o32["decisions"]["hinge_active"], o0["decisions"]["hinge_active"]) and \
+        torch.equal(o32["decisions"]["l1_sign"].double(), o0["decisions"]["l1_sign"])
+    if same and torch.equal(o3["rast"][..., 3], o0["rast"][..., 3]):
+        assert rel_err(gd3, gd0) < 1e-9
