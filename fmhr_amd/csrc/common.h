@@ -43,6 +43,29 @@ bool debug_sync();                                   // abi.cpp: FMHR_DEBUG_SYNC
         }                                                          \
     } while (0)
 
+// ---- wave-level data movement without the LDS crossbar: __shfl_up / __shfl compile to ds_bpermute_b32 (an LDS instruction: it
+// queues behind the kernel's real LDS traffic); the DPP forms below are plain vector-ALU operand modifiers.
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ int dpp_int(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xF, false);   // lanes without a source (or masked rows) read 0
+}
+// inclusive prefix sum over the 64 lanes of a wave: four row_shr steps inside each row of 16, then the row totals via row_bcast
+__device__ __forceinline__ int wave_incl_scan(int x)
+{
+    x += dpp_int<0x111>(x);            // row_shr:1
+    x += dpp_int<0x112>(x);            // row_shr:2
+    x += dpp_int<0x114>(x);            // row_shr:4
+    x += dpp_int<0x118>(x);            // row_shr:8
+    x += dpp_int<0x142, 0xA>(x);       // row_bcast:15 -> rows 1, 3
+    x += dpp_int<0x143, 0xC>(x);       // row_bcast:31 -> rows 2, 3
+    return x;
+}
+// value of the previous lane (lane 0 reads `first`)
+__device__ __forceinline__ int wave_prev_lane(int x, int first)
+{
+    return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xF, 0xF, false);   // wave_shr:1
+}
+
 constexpr int kBlock = 256;
 constexpr int kAaReplicas = 8;   // copies of the antialias-backward vertex accumulators (antialias.hip: k_aa_bwd_items)
 constexpr int kSub = 256;        // sub-pixel units per pixel (8 bits)

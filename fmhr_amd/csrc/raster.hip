@@ -140,7 +140,14 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
               unsigned char* __restrict__ own8)
 {
     FMHR_WTS_BEGIN(raster, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kTrisBlock / 64) + (threadIdx.x >> 6));
+    // the parked triangles as FOUR arrays of 16-B words (a 64-B record per lane put the lanes of a ds_read_b128 lane group on
+    // 4 of the 16 bank quads: SQ_LDS_BANK_CONFLICT 2.4e7 cycles per launch, profiles/r02_v72_issue.txt)
+#ifdef FMHR_X_PARK_AOS
     __shared__ TriPark park[kTrisBlock];
+#else
+    __shared__ float4 pk0[kTrisBlock], pk1[kTrisBlock], pk2[kTrisBlock];
+    __shared__ int4 pk3[kTrisBlock];                                 // f, rbw (float bits), origin, bw
+#endif
     __shared__ unsigned short tasks[kTaskCap];                       // the workgroup's task list: lane (8 bits) << 5 | bit of its mask
     __shared__ int wtot[kTrisBlock / 64];
     __shared__ LargePark lpark[kTrisBlock / 64];
@@ -250,12 +257,16 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     // with a list of its own every other wave ran a second, nearly empty round of the ~110-instruction fragment evaluation (1.56
     // rounds per wave; pooled: ~1.1) and issued its atomics in two instructions that touched some key lines twice
     const int cnt = __popc(cm);
+#ifdef FMHR_X_SHFL_SCAN
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         int t = __shfl_up(incl, d);
         if (lane >= d) incl += t;
     }
+#else
+    const int incl = wave_incl_scan(cnt);                            // DPP: no LDS-crossbar instructions
+#endif
     if (lane == 63) wtot[wv] = incl;
     unsigned long long lbal = __ballot(is_large);                    // lanes holding a large-box triangle
     if (large_q != nullptr && lbal != 0ull) {                        // queue mode: one cursor atomic per wave (same-address atomics
@@ -281,8 +292,13 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         // (8 bits) meets a stale entry only to have its candidates fail the owner test
         if (cov16 != nullptr)
             cov16[(size_t)b * F + f] = make_int2((int)cm, s.pxa | (s.pya << 13) | ((bw - 1) << 26));
+#ifdef FMHR_X_PARK_AOS
         TriPark& t = park[threadIdx.x];
         t.p0 = p0; t.p1 = p1; t.p2 = p2; t.f = f; t.rbw = __builtin_amdgcn_rcpf((float)bw); t.origin = s.pxa | (s.pya << 16); t.bw = bw;
+#else
+        pk0[threadIdx.x] = p0; pk1[threadIdx.x] = p1; pk2[threadIdx.x] = p2;
+        pk3[threadIdx.x] = make_int4(f, __float_as_int(__builtin_amdgcn_rcpf((float)bw)), s.pxa | (s.pya << 16), bw);
+#endif
     }
     __syncthreads();                                                 // every wave of the workgroup gets here (no early return above)
     int wbase = 0, T = 0;
@@ -316,7 +332,16 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             int segl = -1;
             if (t < nt) {
                 const int e = tasks[t], o = e >> 5, bit = e & 31;
+#ifdef FMHR_X_PARK_AOS
                 const TriPark& q = park[o];
+#else
+                TriPark q;
+                {
+                    const int4 m = pk3[o];
+                    q.p0 = pk0[o]; q.p1 = pk1[o]; q.p2 = pk2[o];
+                    q.f = m.x; q.rbw = __int_as_float(m.y); q.origin = m.z; q.bw = m.w;
+                }
+#endif
                 // row / column of the task's pixel in the box: bit < 32, 1 <= bw <= 32, so (bit + 0.5) / bw is at least 1 / 64 away
                 // from an integer and the 1-ulp reciprocal cannot change the truncated quotient (an integer division costs ~25 instructions)
                 float qf = (float)bit + 0.5f;
@@ -333,7 +358,11 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             }
             if (dirty != nullptr) {
                 // consecutive tasks mostly land in the same 64-pixel segment: one flag store per run
+#ifdef FMHR_X_SHFL_SCAN
                 const int prev = __shfl_up(segl, 1);
+#else
+                const int prev = wave_prev_lane(segl, -2);
+#endif
                 if (segl >= 0 && (lane == 0 || prev != segl)) dirty[segbase + segl] = 1;
             }
         }

@@ -399,12 +399,32 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         has_list = has_list || kind[v] == 255;
     }
     int incl = cnt;
+#ifdef FMHR_X_SHFL_SCAN
 #pragma unroll
     for (int d = 1; d < kGroup; d <<= 1) {
         int t = __shfl_up(incl, d, kGroup);
         if (j >= d) incl += t;
     }
     const int excl = incl - cnt, T = __shfl(incl, kGroup - 1, kGroup);
+#else
+    {   // scan over the 8 lanes of a group by DPP row shifts (a group lies inside one row of 16: the guard drops what a shift
+        // pulls in from the neighbouring group), the total from the group's last lane by a quad / half-row broadcast
+        int t;
+        t = dpp_int<0x111>(incl); if (j >= 1) incl += t;
+        t = dpp_int<0x112>(incl); if (j >= 2) incl += t;
+        t = dpp_int<0x114>(incl); if (j >= 4) incl += t;
+    }
+    // lane 7 of the group: row_half_mirror sends lane 7 -> lane 0 of each 8; then quad_perm broadcast... simpler: the group's last
+    // lane holds the total, every lane reads it through one ds_bpermute-free DPP pair (half-mirror, then lane 0 of the half row)
+    const int excl = incl - cnt;
+    int T;
+    {
+        const int mir = dpp_int<0x141>(incl);                        // row_half_mirror: lane j <- lane 7 - j, so lane 0 of the group holds the total
+        const int q = dpp_int<0x00>(mir);                            // quad_perm [0,0,0,0]: lanes 0..3 <- lane 0, lanes 4..7 <- lane 4
+        const int h = dpp_int<0x114>(q);                             // row_shr:4: lanes 4..7 <- lanes 0..3 (of the same group: j >= 4)
+        T = (j < 4) ? q : h;
+    }
+#endif
     const unsigned long long anyk = __ballot(anyv);
     const bool group_any = ((anyk >> (lane & ~(kGroup - 1))) & 0xFFull) != 0ull;
     float A[3][9];                                                 // per corner: g_normal.xyz, g_albedo.xyz, g_vertex.xyz

@@ -10,10 +10,15 @@ Derived columns (per launch):
   lanes        mean active lanes per vector instruction    (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 4: both count quad-cycles)
   valu_us      SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / clock: the time the vector ALUs alone need at one wave64 instruction per
                4 cycles (tools/micro/valu_rate.hip: 4.3 nominal cycles per simple op); compare with the kernel's duration
+  ldsconf_us   SQ_LDS_BANK_CONFLICT (extra LDS-array cycles, summed over the chip) / 256 CUs / clock: the time ONE CU's LDS array
+               spends on bank conflicts (MI355X_MICROARCH.md §LDS); ldsact_us the same for SQ_ACTIVE_INST_LDS (quad-cycles x 4)
+  conf/ldsi    conflict cycles per LDS instruction
+(TA_* / TCP_* counters are not collected: a pass with them hung rocprofv3 on this pool for its whole limit.)
 """
 import csv
 import glob
 import os
+import signal
 import subprocess
 import sys
 from collections import defaultdict
@@ -27,7 +32,6 @@ PASSES = [
     "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_LDS_BANK_CONFLICT",
     "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum",
 ]
-# (a pass with TA_* / TCP_* counters hung rocprofv3 on this pool for its whole 400 s limit: not collected)
 if os.environ.get("PASSES"):
     PASSES = [PASSES[int(i)] for i in os.environ["PASSES"].split(",")]
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -41,10 +45,19 @@ for p, counters in enumerate(PASSES):
     out = os.path.join(ROOT, "gpurun_out", f"{TAG}_issue{p}")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters.split(), "-d", out, "-o", "pmc", "--output-format", "csv", "--",
            "python3", os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-stage1", *BENCH_ARGS]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=150)
-    open(out + ".log", "w").write(r.stdout)
-    if r.returncode != 0:
-        print(f"pass {p} failed (rc {r.returncode}):", r.stdout[-1500:])
+    # own process group: on a timeout the profiler AND the bench child that holds the GPU are killed together
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=int(os.environ.get("PASS_TIMEOUT", "200")))
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        stdout, _ = proc.communicate()
+        open(out + ".log", "w").write(stdout or "")
+        print(f"pass {p} timed out and was killed; no further GPU pass is started", flush=True)
+        sys.exit(3)
+    open(out + ".log", "w").write(stdout)
+    if proc.returncode != 0:
+        print(f"pass {p} failed (rc {proc.returncode}):", stdout[-1500:])
         continue
     f = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
     if not f:
@@ -72,7 +85,7 @@ CLK = 2.4e9
 lines = []
 order = sorted(vals, key=lambda k: -vals[k].get("SQ_INSTS_VALU", 0))
 hdr = ("kernel", "us", "waves", "valu/wave", "salu/wave", "lds/wave", "vmrd/wave", "vmwr/wave", "lanes", "valu_us", "int32%", "int64%", "fma%", "trans%",
-       "rd_wf", "wr_wf", "atom_wf", "l2hit%", "ea_rd", "ea_wr", "ea_atom")
+       "ldsconf_us", "ldsact_us", "conf/ldsi", "l2hit%", "l2req", "ea_atom")
 lines.append(" ".join(h.rjust(9) if i else h.ljust(34) for i, h in enumerate(hdr)))
 for k in order:
     v = vals[k]
@@ -86,8 +99,9 @@ for k in order:
            v.get("SQ_INSTS_VMEM_RD", 0) / w, v.get("SQ_INSTS_VMEM_WR", 0) / w, lanes, iv * 4 / 1024 / CLK * 1e6,
            100 * v.get("SQ_INSTS_VALU_INT32", 0) / max(iv, 1), 100 * v.get("SQ_INSTS_VALU_INT64", 0) / max(iv, 1),
            100 * v.get("SQ_INSTS_VALU_FMA_F32", 0) / max(iv, 1), 100 * v.get("SQ_INSTS_VALU_TRANS_F32", 0) / max(iv, 1),
-           v.get("TA_FLAT_READ_WAVEFRONTS", 0), v.get("TA_FLAT_WRITE_WAVEFRONTS", 0), v.get("TA_FLAT_ATOMIC_WAVEFRONTS", 0),
-           100 * hit / max(hit + miss, 1), v.get("TCC_EA0_RDREQ", 0), v.get("TCC_EA0_WRREQ", 0), v.get("TCC_EA0_ATOMIC_sum", 0))
+           v.get("SQ_LDS_BANK_CONFLICT", 0) / 256 / CLK * 1e6, v.get("SQ_ACTIVE_INST_LDS", 0) * 4 / 256 / CLK * 1e6,
+           v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_INSTS_LDS", 0), 1),
+           100 * hit / max(hit + miss, 1), hit + miss, v.get("TCC_EA0_ATOMIC_sum", 0))
     lines.append(" ".join((("%.4g" % x).rjust(9) if i else x.ljust(34)) for i, x in enumerate(row)))
 lines.append("")
 lines.append("raw counters (mean per dispatch):")
