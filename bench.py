@@ -322,11 +322,11 @@ def main():
     dom_ms = sum(tk.ms(j, dom) for j in range(len(sampled))) / len(sampled)
     step_dev_ms = sum(ev0[j].elapsed_time(ev1[j]) for j in range(len(sampled))) / len(sampled)
     # a full antialias work-item list (some silhouette pairs without a gradient) invalidates the run — on EVERY rank
-    ovf = torch.tensor([1.0 if hs.aa_overflowed() else 0.0], device=dev)
+    ovf = torch.tensor([1.0 if (hs.aa_overflowed() or hs.raster_overflowed()) else 0.0], device=dev)
     if world > 1:
         torch.distributed.all_reduce(ovf)
     if float(ovf) != 0:
-        raise SystemExit(f"bench.py: the antialias work-item list overflowed on {int(float(ovf))} rank(s) (aa_cap={hs.dims.aa_cap})")
+        raise SystemExit(f"bench.py: the antialias work-item list or a rasterizer fragment bin overflowed on {int(float(ovf))} rank(s) (aa_cap={hs.dims.aa_cap})")
     final = dict(zip(("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid"), losses.tolist()))
     aa_items = hs.aa_item_count().to(torch.float32).reshape(1)
     if world > 1:

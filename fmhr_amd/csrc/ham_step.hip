@@ -63,7 +63,7 @@ int face_bwd_blocks(int F);
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
-        g_shaded, cmat, gvert_aa, gvert_aa2, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, total;
+        g_shaded, cmat, gvert_aa, gvert_aa2, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -124,6 +124,13 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.seg_valid = take(off, ((nP + 63) / 64) * 4);   // valid-pixel count of every segment (resolve pass)
     L.cnt_part = take(off, (((nP + 63) / 64 + 1023) / 1024) * 4);   // the same per workgroup of k_active_segments
     L.silw = take(off, ((nP + 63) / 64) * 8);        // per segment: pixels of silhouette faces (resolve pass -> antialias scan)
+    // binned rasterizer (raster.hip): per 64-pixel segment a cursor (one per cache line) and room for bin_cap_entries() 16-B fragment
+    // entries (16 KB per segment: 3.2 GB at the metric, of which a step touches the ~100 MB its fragments fill — sized for the
+    // 288-GB part, not for the footprint)
+    const bool binned = raster_binned_ok(d->F, d->H, d->W);
+    const size_t tiles = binned ? raster_bin_count(d->n, d->H, d->W) : 0;
+    L.bin_cursor = take(off, tiles * 4 * kCursorStride + 16);
+    L.bins = take(off, tiles * (size_t)bin_cap_entries() * 16);
     L.total = off;
     return L;
 }
@@ -168,7 +175,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(own8); FMHR_OFF(stamp); FMHR_OFF(pix16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
     FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(aa_counter); FMHR_OFF(aa_region_cnt); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
-    FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(silw); FMHR_OFF(total);
+    FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(silw); FMHR_OFF(bins); FMHR_OFF(bin_cursor); FMHR_OFF(total);
 #undef FMHR_OFF
     set_error("ham_workspace_offset: unknown buffer '%s'", name);
     return -1;
@@ -209,6 +216,7 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     HIPTRY(hipMemsetAsync(w + L.cov16, 0xFF, (size_t)d->n * d->F * 8, (hipStream_t)stream), "init cov16");
     HIPTRY(hipMemsetAsync(w + L.stamp, 0, 16, (hipStream_t)stream), "init stamp");
     HIPTRY(hipMemsetAsync(w + L.own8, 0, (size_t)d->n * d->F, (hipStream_t)stream), "init own8");
+    HIPTRY(hipMemsetAsync(w + L.bin_cursor, 0, L.bins - L.bin_cursor, (hipStream_t)stream), "init bin cursors");   // self-cleaning afterwards
     return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, d->W, (hipStream_t)stream);
 }
 
@@ -265,6 +273,11 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.aa_init = (float4*)(w + L.aa); fu.seg_valid = (int*)(w + L.seg_valid); fu.silw = (unsigned long long*)(w + L.silw);
         fu.verts = vertices; fu.cmat = (const float4*)(w + L.cmat);
         fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
+        fu.bins = nullptr; fu.bin_cursor = nullptr; fu.bin_flag = nullptr; fu.bin_cap = 0;
+        if (raster_binned_ok(d->F, d->H, d->W)) {
+            fu.bins = (uint4*)(w + L.bins); fu.bin_cursor = (int*)(w + L.bin_cursor); fu.bin_cap = bin_cap_entries();
+            fu.bin_flag = (int*)(w + L.aa_counter) + 2;             // sticky overflow flag next to the antialias list's (read by the host)
+        }
         TRY(rasterize_fwd_impl(nullptr, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
                                rast, w + L.raster_ws, (unsigned char*)(w + L.dirty), covw, &fu, st));
     }

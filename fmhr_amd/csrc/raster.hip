@@ -7,6 +7,7 @@
 // (tiny) bounding box; a triangle with a large box is swept by the whole wave of its lane.
 #include "common.h"
 #include "shade_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace fmhr {
@@ -14,6 +15,7 @@ namespace fmhr {
 // loads through this pointer type go through the scalar cache when the address is wave-uniform (data constant during the kernel)
 typedef const float __attribute__((address_space(4))) const_as4_float;
 
+constexpr bool kBinnedDefault = true;  // the fused step rasterizes through per-tile bins where it can (raster_binned_ok)
 constexpr int kSmallBox = 32;   // boxes up to this many pixel centres are walked by the owning lane (32-bit coverage mask)
 
 struct TriSetup {
@@ -99,6 +101,48 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
     silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
 }
 
+// ---- binned rasterizer: fragments go into per-segment bins instead of a global depth-key buffer -----------------------------------
+// north_star: "LDS-staged per-tile triangle bins and wave64 ballot / prefix-scan fragment compaction".  A bin is one 64-pixel row
+// segment (the tile a wave of the per-pixel kernels owns: everything downstream keeps its layout).  The triangle kernel appends every
+// fragment (face, pixel-in-segment, z/w, u, v: 16 B) to its segment's bin; k_raster_bins — one wave per segment — stages the bin in
+// LDS, takes the depth minimum per pixel in LDS (ds_min_u64 on (monotone(z/w), face, entry index)) and runs the resolve + forward-
+// shading epilogue on the winners straight from the staged entries: the 8-B-per-pixel global key buffer (100 MB at the metric), its
+// 2 M atomicMin line requests, its read-back + reset and the dirty-segment flags are gone, and the winner's (u, v, z/w) are the
+// triangle kernel's own values instead of a second evaluation behind three more vertex gathers.
+// Slots are reserved per WORKGROUP: the fragments of a workgroup's 256 consecutive faces fall into a few dozen segments; an LDS hash
+// table (segment -> count) gives every fragment its rank inside (workgroup, segment) with one ds_cmpst + one ds_add_rtn, then ONE
+// returning global atomic per table entry reserves the run — all of them in one instruction, in flight while the workgroup
+// evaluates its fragments (a returning atomic per wave and round, waited for on the spot, cost 120 -> 280 us).
+struct BinArgs { uint4* bins; int* cursor; int* flag; int cap; int segsX; int segsPerView; };
+constexpr int kHash = 128;                       // LDS table slots per workgroup round (a round has at most 512 fragments)
+constexpr unsigned kBinInvalid = 0xFFFFFFFFu;    // first word of a reserved entry whose fragment was degenerate
+
+// Slow path (a table that ran full, large-box triangles swept by their wave): wave-uniform call; every RUN of consecutive lanes with
+// the same bin reserves its slots with one returning atomic (all runs of the wave in one instruction) and stores to consecutive slots.
+__device__ __forceinline__ void bin_append(bool valid, int bin, const uint4 e, const BinArgs& ba, int lane)
+{
+    const int tl = valid ? bin : -1;
+    const int prev = wave_prev_lane(tl, -2);
+    const bool leader = valid && prev != tl;
+    const unsigned long long lm = __ballot(leader);
+    if (lm == 0ull) return;                                          // wave-uniform: nothing to append
+    const unsigned long long brk = lm | ~__ballot(valid);            // a run ends at the next leader or the next lane without a fragment
+    const unsigned long long upto = (2ull << lane) - 1ull;           // bits 0..lane (lane 63: 2 << 63 wraps to 0 -> all ones)
+    int base = 0;
+    if (leader) {
+        const unsigned long long above = brk & ~upto;
+        const int len = (above != 0ull ? __builtin_ctzll(above) : 64) - lane;
+        base = atomicAdd(ba.cursor + (size_t)tl * kCursorStride, len);
+    }
+    const int start = 63 - __builtin_clzll((lm & upto) | 1ull);      // the run's first lane (meaningless on lanes without a fragment)
+    const int b0 = __shfl(base, start, 64);
+    if (valid) {
+        const int slot = b0 + (lane - start);
+        if (slot < ba.cap) ba.bins[(size_t)tl * ba.cap + slot] = e;
+        else *ba.flag = 1;                                           // reported by the host (HamStage2.loss_dict): the bin capacity was too small
+    }
+}
+
 // one lane per (view, triangle): 3 x 8-B snapped-vertex gathers, integer setup, integer coverage mask of the (<= 32-pixel) box.
 // The fragments are then emitted WAVE-cooperatively: the covering lanes park their triangle (clip positions, box origin) in LDS
 // and expand their coverage bits into a dense per-wave task list; every lane then takes tasks round-robin.  A lane looping over
@@ -130,25 +174,29 @@ struct LargePark {
 // view's combined matrix (the same clip_coord() chains everywhere: bit-identical); the [V,3] vertex array stays in cache, the
 // [n,V,4] position array (37 MB written + gathered per 48 views) does not exist.
 // 64 VGPRs and < 20 KB of LDS per workgroup: 8 waves per SIMD (5 / 6 / 7 / 8 waves: 105 / 100 / 97.5 / 94 us)
-template <bool FV>
-__global__ void __launch_bounds__(kTrisBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// the binned instantiation needs 72 VGPRs: at the 64 of 8 waves per SIMD it spills 24 of them into its task loop (156 vs 88 us)
+#ifndef FMHR_BIN_TRIS_WAVES
+#define FMHR_BIN_TRIS_WAVES 7
+#endif
+template <bool FV, bool BIN>
+__global__ void __launch_bounds__(kTrisBlock) __attribute__((amdgpu_waves_per_eu(BIN ? FMHR_BIN_TRIS_WAVES : 8, 8)))
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
               int2* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
               const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg,
-              unsigned char* __restrict__ own8)
+              unsigned char* __restrict__ own8, const BinArgs ba)
 {
     FMHR_WTS_BEGIN(raster, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kTrisBlock / 64) + (threadIdx.x >> 6));
     // the parked triangles as FOUR arrays of 16-B words (a 64-B record per lane put the lanes of a ds_read_b128 lane group on
     // 4 of the 16 bank quads: SQ_LDS_BANK_CONFLICT 2.4e7 cycles per launch, profiles/r02_v72_issue.txt)
-#ifdef FMHR_X_PARK_AOS
-    __shared__ TriPark park[kTrisBlock];
-#else
     __shared__ float4 pk0[kTrisBlock], pk1[kTrisBlock], pk2[kTrisBlock];
     __shared__ int4 pk3[kTrisBlock];                                 // f, rbw (float bits), origin, bw
-#endif
-    __shared__ unsigned short tasks[kTaskCap];                       // the workgroup's task list: lane (8 bits) << 5 | bit of its mask
+    // the workgroup's task list: bit of its mask | lane (8 bits) << 5 — 16-bit entries, 1024 per round; the binned form keeps the
+    // fragment's table slot and rank with it (32-bit entries, 512 per round: the same 2 KB)
+    __shared__ unsigned tasks32[kTaskCap / 2];
+    unsigned short* const tasks = reinterpret_cast<unsigned short*>(tasks32);
+    __shared__ int hkey[BIN ? kHash : 1], hcnt[BIN ? kHash : 1];    // binned form: segment (inside the view) -> fragments of this workgroup | base slot
     __shared__ int wtot[kTrisBlock / 64];
     __shared__ LargePark lpark[kTrisBlock / 64];
     const int f = blockIdx.x * kTrisBlock + threadIdx.x;
@@ -257,16 +305,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     // with a list of its own every other wave ran a second, nearly empty round of the ~110-instruction fragment evaluation (1.56
     // rounds per wave; pooled: ~1.1) and issued its atomics in two instructions that touched some key lines twice
     const int cnt = __popc(cm);
-#ifdef FMHR_X_SHFL_SCAN
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-#else
     const int incl = wave_incl_scan(cnt);                            // DPP: no LDS-crossbar instructions
-#endif
     if (lane == 63) wtot[wv] = incl;
     unsigned long long lbal = __ballot(is_large);                    // lanes holding a large-box triangle
     if (large_q != nullptr && lbal != 0ull) {                        // queue mode: one cursor atomic per wave (same-address atomics
@@ -285,20 +324,16 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         const int2 q0 = (o0 < 0) ? rej : snapv(o0), q1 = (o1 < 0) ? rej : snapv(o1), q2 = (o2 < 0) ? rej : snapv(o2);
         pin(p0); pin(p1); pin(p2);
         // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
-        if (silh != nullptr) silh[(size_t)b * F + f] = silh_bits(s0, s1, s2, q0, q1, q2);
+        const unsigned char sbv = (silh != nullptr) ? silh_bits(s0, s1, s2, q0, q1, q2) : (unsigned char)0;
+        if (silh != nullptr) silh[(size_t)b * F + f] = sbv;
         // coverage entry (face-parallel backward), 8 B: candidate-pixel mask of the box | origin x, y (13 bits each) and width - 1 (6 bits,
         // 63 = the pixel-list entry of a large-box face, which carries the step stamp instead of a box).  A small-box entry needs no
         // stamp: the backward reads it only under a matching owner mark, an owner's entry was written this step, and a stale mark
         // (8 bits) meets a stale entry only to have its candidates fail the owner test
         if (cov16 != nullptr)
             cov16[(size_t)b * F + f] = make_int2((int)cm, s.pxa | (s.pya << 13) | ((bw - 1) << 26));
-#ifdef FMHR_X_PARK_AOS
-        TriPark& t = park[threadIdx.x];
-        t.p0 = p0; t.p1 = p1; t.p2 = p2; t.f = f; t.rbw = __builtin_amdgcn_rcpf((float)bw); t.origin = s.pxa | (s.pya << 16); t.bw = bw;
-#else
         pk0[threadIdx.x] = p0; pk1[threadIdx.x] = p1; pk2[threadIdx.x] = p2;
-        pk3[threadIdx.x] = make_int4(f, __float_as_int(__builtin_amdgcn_rcpf((float)bw)), s.pxa | (s.pya << 16), bw);
-#endif
+        pk3[threadIdx.x] = make_int4(f, __float_as_int(__builtin_amdgcn_rcpf((float)bw)), s.pxa | (s.pya << 16), bw | ((int)sbv << 8));   // (silhouette bits ride along: binned form)
     }
     __syncthreads();                                                 // every wave of the workgroup gets here (no early return above)
     int wbase = 0, T = 0;
@@ -313,57 +348,139 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     unsigned long long* const keys_view = keys + (size_t)b * P;      // wave-uniform bases: the per-task offsets are 32-bit
     const long long segbase = ((long long)b * P) >> 6;
     const int segrem = (int)(((long long)b * P) & 63);
-    for (int R = 0; R < T; R += kTaskCap) {                          // workgroup-uniform trip count (one round unless boxes are large)
-        if (R > 0) __syncthreads();                                  // the previous round's list has been consumed
-        if (cm != 0u && excl < R + kTaskCap && excl + cnt > R) {
-            unsigned m = cm;
-            int idx = excl - R;
-            while (m != 0u) {
-                const int bit = __builtin_ctz(m);
-                m &= m - 1u;
-                if (idx >= 0 && idx < kTaskCap) tasks[idx] = (unsigned short)((threadIdx.x << 5) | bit);
-                idx++;
+    if (BIN) {
+        // ---- binned form: tasks -> (table slot, rank) -> one reservation per (workgroup, segment) -> entries
+        constexpr int kCap = kTaskCap / 2;                           // 32-bit task entries: bit | lane << 5 | slot << 13 | rank << 21
+        const int segsX = ba.segsX;
+        auto decode = [&](unsigned e, int& o, int& px, int& py) {
+            o = (int)(e >> 5) & 255;
+            const int bit = (int)(e & 31u);
+            const int4 m = pk3[o];
+            float qf = (float)bit + 0.5f;
+            qf = qf * __int_as_float(m.y);
+            const int r = (int)qf, c = bit - r * (m.w & 0xff);
+            px = (m.z & 0xffff) + c; py = (m.z >> 16) + r;
+            return m.x | ((m.w >> 8) << 23);                         // the face | its silhouette bits in this view << 23
+        };
+        for (int R = 0; R < T; R += kCap) {                          // workgroup-uniform trip count (one round on a micro-triangle mesh)
+            if (R > 0) __syncthreads();                              // the previous round's list and table have been consumed
+            if (threadIdx.x < kHash) { hkey[threadIdx.x] = -1; hcnt[threadIdx.x] = 0; }
+            if (cm != 0u && excl < R + kCap && excl + cnt > R) {
+                unsigned m = cm;
+                int idx = excl - R;
+                while (m != 0u) {
+                    const int bit = __builtin_ctz(m);
+                    m &= m - 1u;
+                    if (idx >= 0 && idx < kCap) tasks32[idx] = (unsigned)((threadIdx.x << 5) | bit);
+                    idx++;
+                }
+            }
+            __syncthreads();
+            const int nt = min(kCap, T - R);
+            // phase 1: every fragment's segment -> table slot (open addressing, ds_cmpst) and its rank inside (workgroup, segment)
+            for (int t = threadIdx.x; t < nt; t += kTrisBlock) {
+                const unsigned e = tasks32[t];
+                int o, px, py;
+                decode(e, o, px, py);
+                const int sg = py * segsX + (px >> 6);               // segment inside the view: < 2^20
+                // the segments of 256 consecutive faces are a compact patch: rows (mod 64) x two column segments map it onto the
+                // table without collisions; a slot that is taken by another segment (a patch taller than 64 rows, faces in random
+                // order) sends the fragment down the slow path (255)
+                const int h = ((py & 63) << 1) | ((px >> 6) & 1);
+                const int old = atomicCAS(&hkey[h], -1, sg);
+                const int slot = (old == -1 || old == sg) ? h : 255;
+                unsigned rank = 0u;
+                if (slot != 255) rank = (unsigned)atomicAdd(&hcnt[slot], 1);
+                tasks32[t] = e | ((unsigned)slot << 13) | (rank << 21);
+            }
+            __syncthreads();
+            // phase 2: one returning atomic per table entry, all in one instruction of the first two waves; not waited for yet
+            const bool own = threadIdx.x < kHash && hkey[threadIdx.x] >= 0;
+            int gbase = 0;
+            if (own) gbase = atomicAdd(ba.cursor + ((size_t)b * ba.segsPerView + hkey[threadIdx.x]) * kCursorStride, hcnt[threadIdx.x]);
+            // phase 3: the fragments (the ~110-instruction evaluation hides the reservations' round trip)
+            auto evaluate = [&](int t, unsigned& e, int& bin, uint4& ent) {
+                e = tasks32[t];
+                int o, px, py;
+                const int face = decode(e, o, px, py);
+                bin = b * ba.segsPerView + py * segsX + (px >> 6);
+                Frag fr;
+                const bool okf = fragment(pk0[o], pk1[o], pk2[o], px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr);
+                ent = make_uint4(okf ? ((unsigned)face | ((unsigned)(px & 63) << 26)) : kBinInvalid, __float_as_uint(fr.zw),
+                                 __float_as_uint(fr.u), __float_as_uint(fr.v));
+            };
+            auto store = [&](bool have, unsigned e, int bin, const uint4 ent) {
+                const int slot = (int)(e >> 13) & 255;
+                if (have && slot != 255) {
+                    const int pos = hcnt[slot] + (int)(e >> 21);
+                    if (pos < ba.cap) ba.bins[(size_t)bin * ba.cap + pos] = ent;
+                    else *ba.flag = 1;
+                }
+                const bool slow = have && slot == 255 && ent.x != kBinInvalid;
+                if (__ballot(slow) != 0ull) bin_append(slow, bin, ent, ba, lane);
+            };
+            unsigned e0 = 0u;
+            int bin0 = 0;
+            uint4 ent0 = make_uint4(0u, 0u, 0u, 0u);
+            const bool have0 = (int)threadIdx.x < nt;
+            if (have0) evaluate(threadIdx.x, e0, bin0, ent0);
+            if (own) hcnt[threadIdx.x] = gbase;                      // count -> base slot (waits for the atomic here)
+            __syncthreads();
+            store(have0, e0, bin0, ent0);
+            for (int t0 = kTrisBlock; t0 < nt; t0 += kTrisBlock) {   // further slices of a round: more than 256 fragments per 256 faces
+                const int t = t0 + threadIdx.x;
+                unsigned e1 = 0u;
+                int bin1 = 0;
+                uint4 ent1 = make_uint4(0u, 0u, 0u, 0u);
+                if (t < nt) evaluate(t, e1, bin1, ent1);
+                store(t < nt, e1, bin1, ent1);
             }
         }
-        __syncthreads();
-        const int nt = min(kTaskCap, T - R);
-        for (int t0 = wv * 64; t0 < nt; t0 += kTrisBlock) {             // wave-uniform trip count: the shuffle below needs every lane
-            const int t = t0 + lane;
-            int segl = -1;
-            if (t < nt) {
-                const int e = tasks[t], o = e >> 5, bit = e & 31;
-#ifdef FMHR_X_PARK_AOS
-                const TriPark& q = park[o];
-#else
-                TriPark q;
-                {
-                    const int4 m = pk3[o];
-                    q.p0 = pk0[o]; q.p1 = pk1[o]; q.p2 = pk2[o];
-                    q.f = m.x; q.rbw = __int_as_float(m.y); q.origin = m.z; q.bw = m.w;
-                }
-#endif
-                // row / column of the task's pixel in the box: bit < 32, 1 <= bw <= 32, so (bit + 0.5) / bw is at least 1 / 64 away
-                // from an integer and the 1-ulp reciprocal cannot change the truncated quotient (an integer division costs ~25 instructions)
-                float qf = (float)bit + 0.5f;
-                qf = qf * q.rbw;
-                const int r = (int)qf, c = bit - r * q.bw;
-                const int px = (q.origin & 0xffff) + c, py = (q.origin >> 16) + r;
-                Frag fr;
-                if (fragment(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr)) {
-                    const unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)q.f << 1);
-                    const int pix = py * W + px;                     // < 2^26
-                    atomicMin(&keys_view[pix], key);
-                    segl = (pix + segrem) >> 6;                      // segment index relative to the view's first segment
+    } else {
+        for (int R = 0; R < T; R += kTaskCap) {                          // workgroup-uniform trip count (one round unless boxes are large)
+            if (R > 0) __syncthreads();                                  // the previous round's list has been consumed
+            if (cm != 0u && excl < R + kTaskCap && excl + cnt > R) {
+                unsigned m = cm;
+                int idx = excl - R;
+                while (m != 0u) {
+                    const int bit = __builtin_ctz(m);
+                    m &= m - 1u;
+                    if (idx >= 0 && idx < kTaskCap) tasks[idx] = (unsigned short)((threadIdx.x << 5) | bit);
+                    idx++;
                 }
             }
-            if (dirty != nullptr) {
-                // consecutive tasks mostly land in the same 64-pixel segment: one flag store per run
-#ifdef FMHR_X_SHFL_SCAN
-                const int prev = __shfl_up(segl, 1);
-#else
-                const int prev = wave_prev_lane(segl, -2);
-#endif
-                if (segl >= 0 && (lane == 0 || prev != segl)) dirty[segbase + segl] = 1;
+            __syncthreads();
+            const int nt = min(kTaskCap, T - R);
+            for (int t0 = wv * 64; t0 < nt; t0 += kTrisBlock) {             // wave-uniform trip count: the shuffle below needs every lane
+                const int t = t0 + lane;
+                int segl = -1;
+                if (t < nt) {
+                    const int e = tasks[t], o = e >> 5, bit = e & 31;
+                    TriPark q;
+                    {
+                        const int4 m = pk3[o];
+                        q.p0 = pk0[o]; q.p1 = pk1[o]; q.p2 = pk2[o];
+                        q.f = m.x; q.rbw = __int_as_float(m.y); q.origin = m.z; q.bw = m.w & 0xff;
+                    }
+                    // row / column of the task's pixel in the box: bit < 32, 1 <= bw <= 32, so (bit + 0.5) / bw is at least 1 / 64 away
+                    // from an integer and the 1-ulp reciprocal cannot change the truncated quotient (an integer division costs ~25 instructions)
+                    float qf = (float)bit + 0.5f;
+                    qf = qf * q.rbw;
+                    const int r = (int)qf, c = bit - r * q.bw;
+                    const int px = (q.origin & 0xffff) + c, py = (q.origin >> 16) + r;
+                    Frag fr;
+                    if (fragment(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr)) {
+                        const unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)q.f << 1);
+                        const int pix = py * W + px;                     // < 2^26
+                        atomicMin(&keys_view[pix], key);
+                        segl = (pix + segrem) >> 6;                      // segment index relative to the view's first segment
+                    }
+                }
+                if (dirty != nullptr) {
+                    // consecutive tasks mostly land in the same 64-pixel segment: one flag store per run
+                    const int prev = wave_prev_lane(segl, -2);
+                    if (segl >= 0 && (lane == 0 || prev != segl)) dirty[segbase + segl] = 1;
+                }
             }
         }
     }
@@ -385,12 +502,21 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         {
             const LargePark& q = lpark[wv];
             const int lbw = q.s.pxb - q.s.pxa + 1, lbh = q.s.pyb - q.s.pya + 1, np = lbw * lbh;
-            for (int i = lane; i < np; i += 64) {
+            for (int i0 = 0; i0 < np; i0 += 64) {                    // wave-uniform trip count (bin_append is a wave-level operation)
+                const int i = i0 + lane;
                 int c;
-                const int r = fast_divmod(i, lbw, c);
+                const int r = fast_divmod(min(i, np - 1), lbw, c);
                 const int px = q.s.pxa + c, py = q.s.pya + r;
-                if (covers(q.s, px, py))
+                const bool in = i < np && covers(q.s, px, py);
+                if (BIN) {
+                    Frag fr;
+                    const bool okf = in && fragment(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr);
+                    const uint4 e = make_uint4((unsigned)q.f | (1u << 22) | ((unsigned)(px & 63) << 26),
+                                               __float_as_uint(fr.zw), __float_as_uint(fr.u), __float_as_uint(fr.v));
+                    bin_append(okf, b * ba.segsPerView + py * ba.segsX + (px >> 6), e, ba, lane);
+                } else if (in) {
                     emit_fragment(q.p0, q.p1, q.p2, px, py, q.f, pg.xs, pg.xo, pg.ys, pg.yo, keys_view, W, dirty, (long long)b * P);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -630,6 +756,129 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         FMHR_TS(7);                                                  // ... and once every store has been acknowledged
 #endif
         FMHR_TS_FLUSH();
+    }
+}
+
+// ---- binned rasterizer, second pass: one wave per 64-pixel segment = per bin (the resolve pass's shape: no workgroup barrier, an
+// empty segment costs one scalar load).  The bin is staged in the wave's LDS kBinChunk entries at a time (coalesced 16-B loads, four
+// in flight per lane); every entry posts ds_min_u64 on its pixel's LDS key = (monotone(z/w) << 32 | face << 8 | entry index):
+// nearest fragment, ties to the lowest face index — rule R6, the order of the global atomicMin it replaces — and the pixel's lane
+// reads the winner's entry back from the staged chunk.  No vertex gathers, no clip positions, no second fragment evaluation: the
+// epilogue is the resolve pass's shading + per-pixel word + owner mark + segment words.
+typedef const int __attribute__((address_space(4))) const_as4_int;
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, const BinArgs ba, unsigned long long* __restrict__ covw,
+              int* __restrict__ large_cnt, const RasterFused fu)
+{
+    __shared__ unsigned long long lkey_all[kBlock];
+    __shared__ uint4 chunk_all[(kBlock / 64) * kBinChunk];
+    static_assert(kBinChunk % 64 == 0 && kBinChunk <= 256, "8-bit entry index in the LDS key");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long* const lkey = lkey_all + wv * 64;             // this wave's pixels
+    uint4* const chunk = chunk_all + wv * kBinChunk;
+    const long long gid = (long long)blockIdx.x * kBlock + tid;
+    const long long seg = (long long)blockIdx.x * (kBlock / 64) + wv;
+    if (gid == 0) {                                                  // rearm the list cursors of the kernels after this one (as the resolve pass does)
+        large_cnt[1] = large_cnt[0];
+        large_cnt[0] = 0;
+        if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
+        if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
+    }
+    const long long P = (long long)H * W;
+    if (seg * 64 >= (long long)n * P) return;
+    // the bin's fragment count through the scalar cache (written by the previous kernel's atomics; only this wave resets it)
+    int* const cur = ba.cursor + (size_t)seg * kCursorStride;
+    const int count = *(const_as4_int*)(unsigned long long)cur;
+    if (count == 0) {
+        if (lane == 0) {
+            covw[seg] = 0ull;
+            if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;
+        }
+        return;
+    }
+    const float mk = fu.mask[gid];                                   // independent of the bin: issued with its first loads
+    const int step_tag = fu.stamp[0];
+    const int cnt = min(count, ba.cap);
+    const uint4* __restrict__ bin = ba.bins + (size_t)seg * ba.cap;
+    if (lane == 0) *cur = 0;                                         // self-cleaning
+    lkey[lane] = ~0ull;
+    unsigned long long best = ~0ull;
+    uint4 win = make_uint4(0u, 0u, 0u, 0u);
+    for (int c0 = 0; c0 < cnt; c0 += kBinChunk) {                    // wave-uniform; one round unless > 4 fragments per pixel
+        uint4 e[kBinChunk / 64];
+#pragma unroll
+        for (int k = 0; k < kBinChunk / 64; k++) {
+            const int i = c0 + k * 64 + lane;
+            e[k] = make_uint4(kBinInvalid, 0u, 0u, 0u);
+            if (i < cnt) e[k] = bin[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                             // keys initialised / the previous chunk has been read by every lane
+#pragma unroll
+        for (int k = 0; k < kBinChunk / 64; k++) {
+            const int idx = k * 64 + lane;
+            if (e[k].x != kBinInvalid) {
+                chunk[idx] = e[k];
+                const unsigned long long key = ((unsigned long long)mono_key(__uint_as_float(e[k].y)) << 32) |
+                                               (unsigned long long)(((e[k].x & 0x3FFFFFu) << 8) | (unsigned)idx);
+                atomicMin(&lkey[e[k].x >> 26], key);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned long long k2 = lkey[lane];
+        if (k2 != best) {                                            // the minimum moved: the winner so far is an entry of THIS chunk
+            best = k2;
+            win = chunk[(unsigned)k2 & (unsigned)(kBinChunk - 1)];
+        }
+    }
+    bool covered = false, valid_px = false, sbits_any = false;
+    float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (best != ~0ull) {
+        int rem;
+        const int b = __builtin_amdgcn_readfirstlane(fast_divmod(gid, (int)P, rem));   // W % 64 == 0: a segment lies in one view
+        const int f = (int)(win.x & 0x3FFFFFu);
+        const bool large = ((win.x >> 22) & 1u) != 0u;
+        const float u = __uint_as_float(win.z), v = __uint_as_float(win.w), zw = __uint_as_float(win.y);
+        const bool shade = mk > 0.f;
+        // the face's silhouette bits in this view ride in the entry; a large-box face (swept by its wave, rare) has them in the byte array
+        const int sbits = large ? (int)fu.silh[(size_t)b * F + f] : (int)((win.x >> 23) & 7u);
+        float4 q0, q1, u0, u1, w0, w1;
+        float shc[9];
+        if (shade) {
+            const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+            q0 = fu.attr8[(size_t)i0 * 2]; q1 = fu.attr8[(size_t)i0 * 2 + 1];
+            u0 = fu.attr8[(size_t)i1 * 2]; u1 = fu.attr8[(size_t)i1 * 2 + 1];
+            w0 = fu.attr8[(size_t)i2 * 2]; w1 = fu.attr8[(size_t)i2 * 2 + 1];
+            const_as4_float* sp = (const_as4_float*)(unsigned long long)(fu.sh + (size_t)b * 9);   // the view is wave-uniform
+#pragma unroll
+            for (int k = 0; k < 9; k++) shc[k] = sp[k];
+            pin(q0); pin(q1); pin(u0); pin(u1); pin(w0); pin(w1);
+        }
+        covered = true;
+        if (large) fu.llink[gid] = atomicExch(reinterpret_cast<int*>(&fu.cov16[(size_t)b * F + f]), rem);
+        fu.own8[(size_t)b * F + f] = (unsigned char)step_tag;
+        fu.pix16[gid] = make_float4(u, v, zw, __int_as_float(pix_pack(f, shade, large, sbits)));
+        sbits_any = sbits != 0;
+        const float w2 = 1.0f - u - v;
+        col.w = u + v + w2;
+        if (shade) {
+            PixShade s;
+            shade_eval_attr(u, v, q0, q1, u0, u1, w0, w1, shc, s);
+            col.x = s.rad * s.ar; col.y = s.rad * s.ag; col.z = s.rad * s.ab;
+            valid_px = true;
+        }
+    }
+    const unsigned long long bal = __ballot(covered);
+    if (bal != 0ull) fu.aa_init[gid] = col;                          // zeros on the uncovered lanes (blend targets start from them)
+    const unsigned long long vbal = __ballot(valid_px);
+    const unsigned long long sbal = __ballot(covered && sbits_any);
+    if (lane == 0) {
+        covw[seg] = bal;
+        if (fu.seg_valid != nullptr) fu.seg_valid[seg] = __popcll(vbal) | (sbal != 0ull ? 0x100 : 0);
+        if (fu.silw != nullptr) fu.silw[seg] = sbal;
     }
 }
 
@@ -896,14 +1145,34 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     }
     int2* lq = use_queue ? large_q : nullptr;
     const PixGrid pg = make_pix_grid(H, W);
+    // binned form (fused step, micro-triangle mesh, W % 64 == 0): per-segment fragment bins + k_raster_bins instead of the
+    // global depth keys + k_raster_resolve.  FMHR_RASTER_BINNED=0 / 1 overrides the default (same-library A/B: tools/abn.sh)
+    const char* benv = getenv("FMHR_RASTER_BINNED");               // read per call: the parity test runs both forms in one process
+    const int binned_env = benv ? atoi(benv) : -1;
+    const bool binned = fu.bins != nullptr && fu.verts != nullptr && dirty != nullptr && fu.pix16 != nullptr && fu.aa_init != nullptr &&
+                        raster_binned_ok(F, H, W) && (binned_env < 0 ? kBinnedDefault : binned_env != 0);
+    BinArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    if (binned) {
+        ba.bins = fu.bins; ba.cursor = fu.bin_cursor; ba.flag = fu.bin_flag; ba.cap = fu.bin_cap;
+        ba.segsX = W / 64; ba.segsPerView = (W / 64) * H;
+    }
     if ((long long)n * F > 0) {
         ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
         const dim3 tgrid(cdiv(F, kTrisBlock), n);                    // view = blockIdx.y
-        if (fu.verts != nullptr)
-            k_raster_tris<true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8);
+        if (binned)
+            k_raster_tris<true, true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba);
+        else if (fu.verts != nullptr)
+            k_raster_tris<true, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba);
         else
-            k_raster_tris<false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg, fu.stamp != nullptr ? fu.own8 : nullptr);
+            k_raster_tris<false, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg, fu.stamp != nullptr ? fu.own8 : nullptr, ba);
         FMHR_CHECK_LAUNCH("k_raster_tris");
+    }
+    if (binned) {
+        ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
+        k_raster_bins<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(tri, n, F, H, W, ba, covw, large_cnt, fu);
+        FMHR_CHECK_LAUNCH("k_raster_bins");
+        return FMHR_OK;
     }
     {
         ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);          // empty on a micro-triangle mesh

@@ -399,14 +399,6 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         has_list = has_list || kind[v] == 255;
     }
     int incl = cnt;
-#ifdef FMHR_X_SHFL_SCAN
-#pragma unroll
-    for (int d = 1; d < kGroup; d <<= 1) {
-        int t = __shfl_up(incl, d, kGroup);
-        if (j >= d) incl += t;
-    }
-    const int excl = incl - cnt, T = __shfl(incl, kGroup - 1, kGroup);
-#else
     {   // scan over the 8 lanes of a group by DPP row shifts (a group lies inside one row of 16: the guard drops what a shift
         // pulls in from the neighbouring group), the total from the group's last lane by a quad / half-row broadcast
         int t;
@@ -424,7 +416,6 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         const int h = dpp_int<0x114>(q);                             // row_shr:4: lanes 4..7 <- lanes 0..3 (of the same group: j >= 4)
         T = (j < 4) ? q : h;
     }
-#endif
     const unsigned long long anyk = __ballot(anyv);
     const bool group_any = ((anyk >> (lane & ~(kGroup - 1))) & 0xFFull) != 0ull;
     float A[3][9];                                                 // per corner: g_normal.xyz, g_albedo.xyz, g_vertex.xyz

@@ -2,6 +2,7 @@
 // and the backward (shade.hip): interpolate -> F.normalize -> SH radiance -> albedo product, /root/reference/mesh_sfs_optim.py:268-286.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 namespace fmhr {
 
@@ -135,6 +136,27 @@ struct RasterFused {
     const float* verts; const float4* cmat;                   // non-null: clip positions / snapped vertices are recomputed from the
                                                               // [V,3] vertices and the views' combined matrices (common.h: ClipView),
                                                               // `pos` and `snap` are not read
+    uint4* bins; int* bin_cursor; int* bin_flag; int bin_cap; // non-null: per-tile fragment bins (raster.hip: binned rasterizer)
 };
+
+// ---- binned rasterizer (raster.hip): a bin = one 64-pixel row segment of the flattened [n, H, W] index = the wave that resolves it.
+// Its entries are 16 B per fragment: (face | large-box flag << 22 | pixel-in-segment << 26, z/w bits, u bits, v bits); 0xFFFFFFFF in
+// the first word = a reserved slot whose fragment turned out degenerate.
+inline int bin_cap_entries()                                  // entries per bin (default 1024: 16 fragments per pixel on average)
+{
+    const char* e = getenv("FMHR_BIN_CAP");
+    const int c = e ? atoi(e) : 1024;
+    return c < 64 ? 64 : c;
+}
+constexpr int kBinChunk = 256;                                // entries a wave stages in LDS per round (8-bit entry index in the LDS key)
+#ifndef FMHR_CURSOR_STRIDE
+#define FMHR_CURSOR_STRIDE 16
+#endif
+constexpr int kCursorStride = FMHR_CURSOR_STRIDE;            // ints between two bins' cursors: ONE cursor per 64-B line — atomics on one line are
+                                                              // served one after the other at the memory side (~55 ns each), and with 16 neighbouring
+                                                              // bins in a line every reservation of an image region queued behind the others
+                                                              // (k_raster_tris 277 us with packed cursors, 124 us padded; profiles/r03_binned_ab.txt)
+inline bool raster_binned_ok(int F, int H, int W) { return (W % 64) == 0 && F < (1 << 22) && !raster_use_queue(H, W, F); }
+inline size_t raster_bin_count(int n, int H, int W) { return ((size_t)n * H * W) / 64; }
 
 }  // namespace fmhr

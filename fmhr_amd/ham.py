@@ -203,13 +203,25 @@ class HamStage2:
         """True if the antialias work-item list was full in the last step (one device -> host copy)."""
         if self._aa_flag is None:
             off = self.lib.fmhr_ham_workspace_offset(ctypes.byref(self.dims), b"aa_counter")
-            self._aa_flag = self.ws[off: off + 8].view(torch.int32)
+            self._aa_flag_all = self.ws[off: off + 16].view(torch.int32)
+            self._aa_flag = self._aa_flag_all[:2]
         return int(self._aa_flag[1]) != 0
+
+    def raster_overflowed(self):
+        """True if a fragment bin of the binned rasterizer was full in ANY step since the workspace was initialised (sticky; one device
+        -> host copy): some fragments were dropped — construct the workspace with a larger FMHR_BIN_CAP (entries per 64-pixel
+        segment, default 1024 = 16 fragments per pixel)."""
+        if self._aa_flag is None:
+            self.aa_overflowed()
+        return int(self._aa_flag_all[2]) != 0
 
     def loss_dict(self):
         """The loss vector of the last step as a dict (one device -> host copy).  Also the place where a full antialias work-item
         list is reported: the step never synchronises on its own, so the flag is checked when the caller reads results anyway."""
         vals = self.losses.tolist()
+        if self.raster_overflowed():
+            raise RuntimeError("HamStage2: a fragment bin of the rasterizer overflowed (more than FMHR_BIN_CAP fragments in one 64-pixel "
+                               "segment): fragments were dropped; set FMHR_BIN_CAP higher (default 1024) or FMHR_RASTER_BINNED=0")
         if self.aa_overflowed():
             raise RuntimeError(f"HamStage2: the antialias work-item list overflowed (aa_cap={self.dims.aa_cap}): some silhouette pairs "
                                "got no gradient in the last step; construct HamStage2 with a larger aa_cap")

@@ -538,3 +538,43 @@ def test_fused_step_as_autograd_function(oracle):
     # a second step overwrites the workspace buffers; the first step's saved gradients must be its own
     loss2, _ = ham_step(hs, g["vertices"], delta, albedo, g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
     assert float(loss2) != float(loss)
+
+
+@pytest.mark.parametrize("dims", [(3, 192, 192, 64, 96), (2, 256, 320, "mano", 0, 2), (5, 64, 128, 48, 64)], ids=lambda d: "x".join(map(str, d)))
+def test_binned_rasterizer_equals_the_atomic_key_form(oracle, dims, monkeypatch):
+    """The fused step rasterizes through per-tile LDS bins where it can (micro-triangle mesh, W % 64 == 0, H % 4 == 0: raster.hip
+    k_raster_tile) and through the global atomicMin depth keys + resolve pass elsewhere: on the same inputs both forms must give the
+    SAME per-pixel words, images, losses and gradients (bit-identical images: same fragment values, same depth / tie order)."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, dims, 41)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    args = (g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FMHR_RASTER_BINNED", mode)
+        hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+        for _ in range(3):                                   # the bins are self-cleaning: the third step must equal the first
+            hs.step(*args)
+        v = hs.views()
+        out[mode] = dict(rast=v["rast"].clone(), img=v["tmp_img"].clone(), pm=v["pred_mask"].clone(), gd=hs.gdelta.clone(),
+                         ga=hs.galbedo.clone(), ld=hs.loss_dict())
+    a, b = out["1"], out["0"]
+    assert float((a["rast"][..., 3] > 0).float().mean()) > 0.05
+    assert torch.equal(a["rast"], b["rast"]) and torch.equal(a["img"], b["img"]) and torch.equal(a["pm"], b["pm"])
+    assert a["ld"]["n_valid"] == b["ld"]["n_valid"] and abs(a["ld"]["total"] - b["ld"]["total"]) <= 1e-6 * abs(b["ld"]["total"])
+    assert rel_err(a["gd"], b["gd"]) < 5e-5 and rel_err(a["ga"], b["ga"]) < 1e-6      # antialias-backward atomics order only
+
+
+def test_fragment_bin_overflow_is_reported(oracle, monkeypatch):
+    """a fragment bin that is too small must not pass silently: loss_dict() raises (sticky flag next to the antialias list's)."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (2, 192, 192, 64, 96), 23)          # micro-triangle mesh, W % 64 == 0: the binned form
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    monkeypatch.setenv("FMHR_RASTER_BINNED", "1")
+    monkeypatch.setenv("FMHR_BIN_CAP", "64")                 # one fragment per pixel: every doubly covered segment overflows
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    with pytest.raises(RuntimeError, match="fragment bin"):
+        hs.loss_dict()

@@ -14,7 +14,8 @@ want = sys.argv[1:]                               # optional substrings of kerne
 for f in ("raster.hip", "antialias.hip", "shade.hip", "mesh.hip", "ncc.hip", "stage1.hip"):
     with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math",
-               "-ffp-contract=" + ("off" if f in STRICT else "on"), "-x", "hip", "-S", "--cuda-device-only", os.path.join(SRC, f),
+               "-ffp-contract=" + ("off" if f in STRICT else "on"), *os.environ.get("FMHR_EXTRA_FLAGS", "").split(), "-x", "hip", "-S",
+               "--cuda-device-only", os.path.join(SRC, f),
                "-o", tmp.name]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         s = open(tmp.name).read()
