@@ -69,6 +69,14 @@ def step_alg_bytes(n, P, V, F, nnz):
     return n * (508 * P + 252 * V + 72 * F) + (48 * V + 24 * F) + 4 * (8 * nnz + 24 * V) + (24 * F + 60 * V) + 2 * 7 * 12 * V
 
 
+def traffic_binned(path):
+    """which rasterizer form the committed traffic profile was taken with"""
+    try:
+        return bool(json.load(open(path)).get("_binned", False))
+    except Exception:  # noqa: BLE001
+        return False
+
+
 def step_fused_bound_bytes(n, P, V, F, nnz):
     """the fully fused lower bound (inputs once, rast written + re-read, gradients once) + the per-step constant."""
     return n * (52 * P + 96 * V + 24 * F) + (48 * V + 24 * F) + 4 * (8 * nnz + 24 * V) + (24 * F + 60 * V) + 2 * 7 * 12 * V
@@ -184,8 +192,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage1", action="store_true", help="skip the stage-1 side measurement (N = 1 only; after the timed region)")
     ap.add_argument("--cpu-views", type=int, default=48)   # the whole 48-view batch: 5 x ~2.6 s of CPU work, nothing extrapolated
-    ap.add_argument("--preroll", type=int, default=240, help="upper bound of the untimed pre-roll (stops earlier once the antialias "
-                    "work list is stationary; at least 64 steps; 0 = none)")
+    ap.add_argument("--preroll", type=int, default=320, help="upper bound of the untimed pre-roll (stops earlier once the antialias "
+                    "work list is stationary; at least 128 steps; 0 = none)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -201,34 +209,64 @@ def main():
 
     scene = synthetic.scene_from_config(args.config, args.seed, args.views)
     n_total, H, W, V, F = scene["views"], scene["H"], scene["W"], scene["V"], scene["F"]
-    s0, s1 = fdist.shard_views(n_total, rank, world)
+    # partition: the views of ONE problem over the ranks (metric, C1-C4), or — a sequence capture (C5: 8 frames x 32 views, every
+    # frame an independent (delta, albedo) problem on the shared topology) — frames first, then views (fmhr_amd.dist.shard_frames_views)
+    n_frames = int(scene.get("frames", 1))
+    if n_frames > 1:
+        part = fdist.shard_frames_views(n_frames, n_total, rank, world)
+        fgroups = fdist.frame_groups(n_frames, world) if world > 1 else [None] * n_frames
+        (f0, f1), (s0, s1) = part["frames"], part["views"]
+        view_rank, view_world = part["view_rank"], part["view_world"]
+    else:
+        f0, f1 = 0, 1
+        s0, s1 = fdist.shard_views(n_total, rank, world)
+        fgroups = [torch.distributed.group.WORLD if world > 1 else None]
+        view_rank, view_world = rank, world
     n = s1 - s0
     if n == 0:
         raise SystemExit("more ranks than views")
     faces = scene["faces"].to(dev)
     w2c, proj = scene["w2c"][s0:s1].contiguous().to(dev), scene["proj"][s0:s1].contiguous().to(dev)
     sh = scene["sh0"][s0:s1].contiguous().to(dev)
-    local_scene = dict(scene, views=n, sh_true=scene["sh_true"][s0:s1], sh0=scene["sh0"][s0:s1])
-    tg = synthetic.make_targets(local_scene, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, H, W), device=dev)
     vtmp = scene["vertices"].to(dev).contiguous()
     elm = edge_length_mean(vtmp, faces)
-    hs = HamStage2(faces, V, n, H, W, scene["weights"], elm, n_global=n_total)
-
-    delta = torch.zeros(V, 3, device=dev, requires_grad=True)
-    albedo = scene["albedo0"][None].to(dev).clone().requires_grad_(True)           # [1,V,3] as in the reference (:176)
     lr = scene["lr"]
-    groups = [{'params': delta, 'lr': lr["lr"]}, {'params': albedo, 'lr': lr["albedo_lr"]}]
     from fmhr_amd.optim import Adam          # same update rule as torch.optim.Adam (tests/test_gpu_utils.py::test_adam)
-    opt = Adam(groups)
-    group = torch.distributed.group.WORLD if world > 1 else None
-    reg_range = fdist.shard_views(V, rank, world)     # the view-independent terms are split over the ranks by vertex range
+    reg_range = fdist.shard_views(V, view_rank, view_world)     # the view-independent terms are split over the ranks by vertex range
+
+    class Problem:
+        """one (delta, albedo) optimisation: its targets, its step workspace, its optimiser state"""
+
+        def __init__(self, frame):
+            sc = dict(scene, views=n, sh_true=scene["sh_true"][s0:s1], sh0=scene["sh0"][s0:s1])
+            if frame > 0:                      # another frame of the sequence: its own target geometry (seeded), same cameras / topology
+                g = torch.Generator().manual_seed(1000 + frame)
+                sc["vertices_true"] = scene["vertices"] + 0.0005 * torch.randn(scene["vertices"].shape, generator=g)
+            self.tg = synthetic.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, H, W), device=dev)
+            self.hs = HamStage2(faces, V, n, H, W, scene["weights"], elm, n_global=n_total)
+            self.delta = torch.zeros(V, 3, device=dev, requires_grad=True)
+            self.albedo = scene["albedo0"][None].to(dev).clone().requires_grad_(True)          # [1,V,3] as in the reference (:176)
+            self.opt = Adam([{'params': self.delta, 'lr': lr["lr"]}, {'params': self.albedo, 'lr': lr["albedo_lr"]}])
+            self.group = fgroups[frame]
+
+        def step(self):
+            # the Adam update of (delta, albedo) is applied by the kernel that forms their final gradients (the mesh tail; after the
+            # step's one all-reduce the combine kernel): same rule as opt.step(), no launch of its own
+            tg = self.tg
+            losses, gd, ga = self.hs.step(vtmp, self.delta.detach(), self.albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"],
+                                          tg["valid_mask"], group=self.group, reg_range=reg_range, optimizer=self.opt,
+                                          params=(self.delta, self.albedo))
+            self.delta.grad, self.albedo.grad = gd, ga.view(1, V, 3)
+            return losses
+
+    problems = [Problem(f) for f in range(f0, f1)]
+    hs, tg, delta, albedo, opt, group = (problems[0].hs, problems[0].tg, problems[0].delta, problems[0].albedo, problems[0].opt,
+                                          problems[0].group)
+    nf_local = len(problems)
 
     def step():
-        # the Adam update of (delta, albedo) is applied by the kernel that forms their final gradients (the mesh tail; after the
-        # step's one all-reduce the combine kernel): same rule as opt.step(), no launch of its own
-        losses, gd, ga = hs.step(vtmp, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"],
-                                 group=group, reg_range=reg_range, optimizer=opt, params=(delta, albedo))
-        delta.grad, albedo.grad = gd, ga.view(1, V, 3)
+        for p in problems:                     # the local frames one after the other (one frame: the plain stage-2 iteration)
+            losses = p.step()
         return losses
 
     def step_parts():
@@ -253,19 +291,19 @@ def main():
         torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream()
-    # untimed pre-roll to the stationary workload: at least 64 optimiser steps, then until the antialias work-item count of a
-    # 16-step block is within 2 % of the previous block's (every rank runs the same number of steps: the criterion is evaluated on
-    # the all-reduced count), at most --preroll steps
+    # untimed pre-roll to the stationary workload: at least 128 optimiser steps, then until the antialias work-item count of a
+    # 32-step block is within 0.5 % of the previous block's (every rank runs the same number of steps: the criterion is evaluated
+    # on the all-reduced count), at most --preroll steps
     preroll, aa_hist = 0, []
     while preroll < args.preroll:
-        for _ in range(16):
+        for _ in range(32):
             step()
-        preroll += 16
-        cnt = hs.aa_item_count().to(torch.float32).reshape(1)
+        preroll += 32
+        cnt = sum(p.hs.aa_item_count() for p in problems).to(torch.float32).reshape(1)
         if world > 1:
             torch.distributed.all_reduce(cnt)
         aa_hist.append(float(cnt))
-        if preroll >= 64 and len(aa_hist) >= 2 and abs(aa_hist[-1] - aa_hist[-2]) <= 0.02 * max(aa_hist[-1], 1.0):
+        if preroll >= 128 and len(aa_hist) >= 2 and abs(aa_hist[-1] - aa_hist[-2]) <= 0.005 * max(aa_hist[-1], 1.0):
             break
     for _ in range(args.warmup):
         step()
@@ -281,7 +319,7 @@ def main():
     torch.cuda.synchronize()
     kernels = {name: sum(tm.ms(i, k) for i in range(prof_steps)) / prof_steps for k, name in enumerate(SLOTS)}
     collective = None
-    if world > 1:
+    if group is not None:
         parts = torch.tensor([step_parts() for _ in range(5)][1:], dtype=torch.float64).mean(0).to(dev)     # [kernels, all-reduce, combine]
         allp = [torch.zeros_like(parts) for _ in range(world)]
         torch.distributed.all_gather(allp, parts)
@@ -322,13 +360,13 @@ def main():
     dom_ms = sum(tk.ms(j, dom) for j in range(len(sampled))) / len(sampled)
     step_dev_ms = sum(ev0[j].elapsed_time(ev1[j]) for j in range(len(sampled))) / len(sampled)
     # a full antialias work-item list (some silhouette pairs without a gradient) invalidates the run — on EVERY rank
-    ovf = torch.tensor([1.0 if (hs.aa_overflowed() or hs.raster_overflowed()) else 0.0], device=dev)
+    ovf = torch.tensor([1.0 if any(p.hs.aa_overflowed() or p.hs.raster_overflowed() for p in problems) else 0.0], device=dev)
     if world > 1:
         torch.distributed.all_reduce(ovf)
     if float(ovf) != 0:
         raise SystemExit(f"bench.py: the antialias work-item list or a rasterizer fragment bin overflowed on {int(float(ovf))} rank(s) (aa_cap={hs.dims.aa_cap})")
     final = dict(zip(("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid"), losses.tolist()))
-    aa_items = hs.aa_item_count().to(torch.float32).reshape(1)
+    aa_items = sum(p.hs.aa_item_count() for p in problems).to(torch.float32).reshape(1)
     if world > 1:
         torch.distributed.all_reduce(aa_items)
 
@@ -339,14 +377,14 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
         if not os.path.exists(tpath):
             tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
-        if os.path.exists(tpath) and args.config == "metric" and world == 1 and args.views is None:
+        if os.path.exists(tpath) and args.config == "metric" and world == 1 and args.views is None and hs.binned == traffic_binned(tpath):
             traffic = json.load(open(tpath))
         ms_per_step = elapsed / K * 1e3
         dom_bytes = alg_bytes(SLOTS[dom], n, P, V, F, hs.nnz)
         dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
-        sb = step_alg_bytes(n, P, V, F, hs.nnz)
+        sb = nf_local * step_alg_bytes(n, P, V, F, hs.nnz)
         step_gbs = sb / (step_dev_ms * 1e-3) / 1e9
-        fb = step_fused_bound_bytes(n, P, V, F, hs.nnz)
+        fb = nf_local * step_fused_bound_bytes(n, P, V, F, hs.nnz)
         fused_gbs = fb / (step_dev_ms * 1e-3) / 1e9
         t_lo, t_hi = (traffic["step_total_low"], traffic["step_total_high"]) if traffic else (None, None)
         out = {
@@ -358,8 +396,10 @@ def main():
                                    f"({'MANO sub3 counts' if V % 49281 == 0 else 'MANO base counts' if V % 778 == 0 else 'custom'}"
                                    f"{', two hands' if scene.get('hands', 1) == 2 else ''}), "
                                    f"stage-2 step = render + 6 losses + backward + grad all-reduce + Adam, stationary (pre-rolled {preroll} steps)",
-                       "views": n_total, "views_per_gpu": n, "H": H, "W": W, "V": V, "F": F,
-                       "coverage": round(tg["coverage"], 4), "parallelism": f"views sharded over {world} GPU(s)",
+                       "views": n_total, "views_per_gpu": n, "frames": n_frames, "frames_per_gpu": nf_local, "H": H, "W": W, "V": V, "F": F,
+                       "rasterizer": "binned (per-segment LDS bins)" if hs.binned else "atomic depth keys + resolve",
+                       "coverage": round(tg["coverage"], 4), "parallelism": (f"views sharded over {world} GPU(s)" if n_frames == 1 else
+                                                                        f"{n_frames} frames x {n_total} views: frames first, then views, over {world} GPU(s)"),
                        "preroll_steps": preroll, "aa_items_per_step": int(float(aa_items)), "aa_items_during_preroll": [int(x) for x in aa_hist]},
             "roofline": {"bound": "hbm", "kernel": SLOTS[dom], "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get(SLOTS[dom]),

@@ -46,6 +46,79 @@ def shard_views(n_views, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def shard_frames_views(n_frames, n_views, rank, world):
+    """Partition of a SEQUENCE capture (BASELINE.json configs[4]: 8 frames x 32 views, conf/ih_sfsseq.conf) over `world` ranks,
+    frames first, then views.  Every frame is an independent (delta, albedo) problem on the shared topology, so ranks that hold
+    different frames never exchange anything; only when there are more ranks than frames do the ranks of one frame split its
+    views and all-reduce inside the frame's own subgroup (the single-collective step of HamStage2.step(group=...)).
+
+    Returns dict(frames=(f0, f1), views=(v0, v1), peers=[ranks sharing this rank's frame] or None, view_rank=i, view_world=k):
+      world <= n_frames : frames split contiguously (balanced), every rank renders all views of its frames, peers = None;
+      world  > n_frames : world must be a multiple of n_frames; rank r works on frame r // k (k = world / n_frames) and on the
+                          view share shard_views(n_views, r % k, k); peers = the k ranks of that frame."""
+    if world <= n_frames:
+        f0, f1 = shard_views(n_frames, rank, world)
+        return dict(frames=(f0, f1), views=(0, n_views), peers=None, view_rank=0, view_world=1)
+    if world % n_frames != 0:
+        raise ValueError(f"shard_frames_views: {world} ranks cannot be split evenly over {n_frames} frames")
+    k = world // n_frames
+    f = rank // k
+    v0, v1 = shard_views(n_views, rank % k, k)
+    return dict(frames=(f, f + 1), views=(v0, v1), peers=list(range(f * k, (f + 1) * k)), view_rank=rank % k, view_world=k)
+
+
+def frame_groups(n_frames, world):
+    """The process groups of shard_frames_views for world > n_frames: every rank must create ALL of them, in the same order
+    (torch.distributed.new_group is collective).  Returns a list indexed by frame (None when no exchange is needed)."""
+    if world <= n_frames:
+        return [None] * n_frames
+    k = world // n_frames
+    return [dist.new_group(list(range(f * k, (f + 1) * k))) for f in range(n_frames)]
+
+
+class ShardedStage1:
+    """Stage 1 (mesh_sfs_optim.py:196-240: albedo + SH, vertices frozen) with the views sharded like stage 2: every rank builds the
+    HamStage1 plan of ITS views and keeps their SH rows; an iteration is the rank's fused step, one all-reduce(SUM) of the albedo
+    gradient [V,3] (0.59 MB at V = 49 k) and the replicated Adam update.  F.l1_loss divides by 3 x the valid pixels of the WHOLE
+    batch (:231): the valid-pixel count of every view is known when the plans are built (one all-gather, once), so each rank
+    rescales its share by Pv_local / Pv_global BEFORE the exchange — no second collective."""
+
+    def __init__(self, hs1, view0, n_views_global, group=None):
+        self.hs1, self.group, self.view0, self.n_global = hs1, group, int(view0), int(n_views_global)
+        counts = torch.zeros(self.n_global, dtype=torch.float32, device=hs1.dev)
+        counts[self.view0: self.view0 + hs1.n] = hs1.view_valid.to(torch.float32)
+        if group is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(counts, group=group)
+        self.counts = counts                                      # valid pixels of every view of the capture
+
+    def step(self, albedo, sh_local, idx_global=None):
+        """idx_global: the batch as GLOBAL view indices (None: all views).  Returns (loss, galbedo [V,3] summed over the ranks,
+        gsh [n_local,9] for this rank's SH rows); the caller applies the optimiser (the same update on every rank)."""
+        hs1 = self.hs1
+        if idx_global is None:
+            local, pv_g = None, self.counts.sum()
+        else:
+            ig = idx_global.to(hs1.dev).long()
+            pv_g = self.counts[ig].sum()
+            mine = ig[(ig >= self.view0) & (ig < self.view0 + hs1.n)] - self.view0
+            local = mine
+        if local is not None and local.numel() == 0:
+            hs1.galbedo.zero_(); hs1.gsh.zero_(); hs1.loss_view.zero_()
+            scale = torch.zeros((), device=hs1.dev)
+        else:
+            hs1.step(albedo, sh_local, idx=local)
+            pv_l = hs1.view_valid.to(torch.float32).sum() if local is None else hs1.view_valid[local].to(torch.float32).sum()
+            scale = pv_l / pv_g.clamp_min(1.0)
+        galbedo = hs1.galbedo * scale
+        gsh = hs1.gsh * scale
+        loss = (hs1.loss_view.sum() * scale).reshape(1)
+        if self.group is not None and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            buf = torch.cat([galbedo.reshape(-1), loss])
+            dist.all_reduce(buf, group=self.group)                # the iteration's ONE collective
+            galbedo, loss = buf[:-1].view_as(hs1.galbedo), buf[-1:]
+        return loss[0], galbedo, gsh
+
+
 def combine_bucket(bucket, V):
     """The arithmetic of fmhr_ham_combine on any device (the GPU step uses the kernel; this is the host-side statement the CPU
     rehearsal checks): bucket = [P_delta | P_albedo | R_delta | R_albedo | 8 loss slots] summed over the ranks."""
@@ -65,9 +138,11 @@ class ShardedStep:
     HamStage2.step(group=...) does the same in place on its own bucket with the combine kernel; this class is the host-side
     reference of the protocol (tests/test_dist_gloo.py runs it over gloo with the CPU oracle as the compute)."""
 
-    def __init__(self, V, device, group=None):
+    def __init__(self, V, device, group=None, exchange=True):
+        """exchange=False: this rank holds a whole frame of a sequence capture (shard_frames_views with peers = None): nothing to
+        reduce, whatever the size of the default group."""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.world = dist.get_world_size(group) if (dist.is_initialized() and exchange) else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bucket = torch.zeros(12 * V + 8, dtype=torch.float32, device=device)
         self.V = V

@@ -81,6 +81,12 @@ class HamStage2:
         self.gdelta_rest = self.bucket[2 * V3: 3 * V3].view(self.V, 3)
         self.galbedo_rest = self.bucket[3 * V3: 4 * V3].view(self.V, 3)
         self.losses = self.bucket[4 * V3:]
+        # which rasterizer form fmhr_ham_forward takes for these dims (raster.hip: rasterize_fwd_impl): per-segment fragment bins where
+        # the mesh is a micro-triangle one and W % 64 == 0 (FMHR_RASTER_BINNED=0 / 1 overrides), else global depth keys + resolve pass
+        import os as _os
+        ok = self.W % 64 == 0 and self.F < (1 << 22) and self.H * self.W <= 16 * self.F
+        env = _os.environ.get("FMHR_RASTER_BINNED")
+        self.binned = bool(ok and (env is None or int(env) != 0))
         self._views = None
         self._aa_flag = None
         self._vm_key, self._vm_ref = None, None

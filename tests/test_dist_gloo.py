@@ -105,3 +105,73 @@ def test_two_ranks_match_single_process(oracle):
     one = fdist.ShardedStep(sc["V"], torch.device("cpu")).reduce(*_oracle_step(oracle, sc, 0, 5, 5, True))
     assert float(one[0][7]) == float(ls[7])
     assert rel_err(gd, ref_gd) < 1e-5 and rel_err(ga, ref_ga) < 1e-5
+
+
+def _frames_worker(rank, world, port, q, n_frames):
+    """BASELINE.json configs[4] in small: `n_frames` frames x 4 views of a two-hand mesh on `world` ranks, partitioned frames first,
+    then views (fmhr_amd.dist.shard_frames_views); a frame is an independent problem, only the ranks that share a frame exchange."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    import ham_oracle as oracle
+    from fmhr_amd import dist as fdist
+    from test_gpu_ham import prepare
+    fdist.init_from_env(backend="gloo")
+    part = fdist.shard_frames_views(n_frames, 4, rank, world)
+    groups = fdist.frame_groups(n_frames, world)                  # collective: every rank creates every group
+    out = {}
+    for f in range(*part["frames"]):
+        sc = prepare(oracle, (4, 48, 40, 8, 10, 0, 2), 50 + f)   # frame f: its own two-hand geometry / targets
+        v0, v1 = part["views"]
+        sh = fdist.ShardedStep(sc["V"], torch.device("cpu"), group=groups[f], exchange=part["peers"] is not None)
+        ls, gd, ga = sh.reduce(*_oracle_step(oracle, sc, v0, v1, 4, part["view_rank"] == 0))
+        out[f] = (ls.numpy().copy(), gd.numpy().copy(), ga.numpy().copy())
+    q.put((rank, part["frames"], part["views"], part["peers"], out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("n_frames", [2, 1], ids=["frames2_no_exchange", "frames1_view_split"])
+def test_frames_then_views_partition(oracle, n_frames):
+    """world 2: two frames -> one frame per rank, all views, NO collective; one frame -> the two ranks split its views and all-reduce
+    inside the frame's subgroup.  Either way every frame's result equals the single-process step of that frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fmhr_amd import dist as fdist
+    from test_gpu_ham import prepare
+    from util import rel_err
+    # the partition itself, at the sizes of BASELINE.json configs[4] (8 frames x 32 views)
+    assert [fdist.shard_frames_views(8, 32, r, 8)["frames"] for r in range(8)] == [(r, r + 1) for r in range(8)]
+    assert all(fdist.shard_frames_views(8, 32, r, 8)["peers"] is None for r in range(8))
+    p16 = [fdist.shard_frames_views(8, 32, r, 16) for r in range(16)]
+    assert [p["frames"] for p in p16] == [(r // 2, r // 2 + 1) for r in range(16)] and p16[5]["views"] == (16, 32) and p16[5]["peers"] == [4, 5]
+    assert fdist.shard_frames_views(8, 32, 1, 2)["frames"] == (4, 8)
+    with pytest.raises(ValueError):
+        fdist.shard_frames_views(8, 32, 0, 12)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frames_worker, args=(r, 2, port, q, n_frames)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seen = {}
+    for rank, frames, views, peers, out in res:
+        if n_frames == 2:
+            assert frames == (rank, rank + 1) and views == (0, 4) and peers is None
+        else:
+            assert frames == (0, 1) and views == (2 * rank, 2 * rank + 2) and peers == [0, 1]
+        seen.update({(f, rank): v for f, v in out.items()})
+    for f in range(n_frames):
+        sc = prepare(oracle, (4, 48, 40, 8, 10, 0, 2), 50 + f)
+        ref_l, ref_gd, ref_ga, _ = _reference_step(oracle, sc)
+        for (ff, rank), (ls, gd, ga) in seen.items():
+            if ff != f:
+                continue
+            assert rel_err(torch.from_numpy(ls)[:7], ref_l[:7]) < 1e-5
+            assert rel_err(torch.from_numpy(gd), ref_gd) < 1e-5 and rel_err(torch.from_numpy(ga), ref_ga) < 1e-5

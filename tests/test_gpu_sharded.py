@@ -21,15 +21,15 @@ def _free_port():
     return p
 
 
-def _scene():
+def _scene(dims=(6, 128, 96, 21, 37, 1)):
     sys.path.insert(0, ROOT)
     from fmhr_amd import synthetic as S
     from fmhr_amd.ham import render_forward
     dev = torch.device("cuda:0")
-    sc = S.make_scene(6, 128, 96, 21, 37, 1, seed=3)
+    sc = S.make_scene(*dims, seed=3)
     faces = sc["faces"].to(dev)
     w2c, proj = sc["w2c"].to(dev), sc["proj"].to(dev)
-    tg = S.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, 128, 96), device=dev)
+    tg = S.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, sc["H"], sc["W"]), device=dev)
     torch.manual_seed(0)
     sc["delta"] = (torch.randn(sc["V"], 3) * 2e-4).to(dev)
     return sc, tg, faces, w2c, proj
@@ -39,7 +39,7 @@ def _run(sc, tg, faces, w2c, proj, s0, s1, group, reg_range):
     from fmhr_amd.ham import HamStage2, edge_length_mean
     dev = faces.device
     vt = sc["vertices"].to(dev)
-    hs = HamStage2(faces, sc["V"], s1 - s0, 128, 96, sc["weights"], edge_length_mean(vt, faces), n_global=sc["views"])
+    hs = HamStage2(faces, sc["V"], s1 - s0, sc["H"], sc["W"], sc["weights"], edge_length_mean(vt, faces), n_global=sc["views"])
     sl = slice(s0, s1)
     out = hs.step(vt, sc["delta"], sc["albedo0"].to(dev), sc["sh0"][sl].to(dev).contiguous(), w2c[sl].contiguous(),
                   proj[sl].contiguous(), tg["img"][sl].contiguous(), tg["mask"][sl].contiguous(), tg["valid_mask"][sl].contiguous(),
@@ -47,14 +47,14 @@ def _run(sc, tg, faces, w2c, proj, s0, s1, group, reg_range):
     return [t.clone() for t in out]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, dims=(6, 128, 96, 21, 37, 1)):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from fmhr_amd import dist as fdist
     fdist.init_from_env(backend="gloo")
     torch.cuda.set_device(0)
-    sc, tg, faces, w2c, proj = _scene()
+    sc, tg, faces, w2c, proj = _scene(dims)
     s0, s1 = fdist.shard_views(sc["views"], rank, world)
     # the view-independent terms are split over the ranks by vertex range
     ls, gd, ga = _run(sc, tg, faces, w2c, proj, s0, s1, dist.group.WORLD, fdist.shard_views(sc["V"], rank, world))
@@ -86,3 +86,90 @@ def test_two_ranks_one_gpu_match_single_rank():
     assert float(ls[7]) == float(l1[7]) and float(l1[7]) > 1000
     assert rel_err(ls[:7], l1[:7].cpu()) < 1e-5, (ls, l1)
     assert rel_err(gd, gd1.cpu()) < 5e-5 and rel_err(ga, ga1.cpu()) < 5e-5
+
+
+METRIC12 = (12, 512, 512, "mano", 0, 3)
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_one_gpu_metric_mesh_six_plus_six_views():
+    """the per-GPU share of the 8-GPU metric run (6 views of the V = 49281 mesh at 512 x 512) on two ranks: 6 + 6 views through the
+    kernels (binned rasterizer, face-parallel backward), split backward, ONE all-reduce, combine — against the 12-view single-rank step."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import log_parity, rel_err
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, METRIC12)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ls, gd, ga = (torch.from_numpy(x) for x in q.get(timeout=800))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sc, tg, faces, w2c, proj = _scene(METRIC12)
+    assert sc["V"] == 49281
+    l1, gd1, ga1 = _run(sc, tg, faces, w2c, proj, 0, sc["views"], None, None)
+    e = (rel_err(ls[:7], l1[:7].cpu()), rel_err(gd, gd1.cpu()), rel_err(ga, ga1.cpu()))
+    log_parity("sharded 6 + 6 views of the metric mesh (2 ranks, one GPU, gloo) vs one rank with 12 views: losses %.1e gdelta %.1e galbedo %.1e" % e)
+    assert float(ls[7]) == float(l1[7]) and float(l1[7]) > 100000
+    assert e[0] < 1e-5 and e[1] < 5e-5 and e[2] < 5e-5, e
+
+
+def _stage1_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from fmhr_amd import dist as fdist
+    from fmhr_amd.stage1 import HamStage1
+    fdist.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    sc, tg, faces, w2c, proj = _scene()
+    dev = faces.device
+    s0, s1 = fdist.shard_views(sc["views"], rank, world)
+    sl = slice(s0, s1)
+    hs1 = HamStage1(sc["vertices"].to(dev), faces, w2c[sl].contiguous(), proj[sl].contiguous(), tg["img"][sl].contiguous(),
+                    tg["mask"][sl].contiguous(), (sc["H"], sc["W"]), 50.0)
+    sh1 = fdist.ShardedStage1(hs1, s0, sc["views"], group=dist.group.WORLD)
+    albedo = sc["albedo0"][None].to(dev).contiguous()
+    shc = sc["sh0"].to(dev).contiguous()
+    out = []
+    for idx in (None, torch.tensor([4, 1, 2]), torch.tensor([5, 3])):        # all views; a batch across both ranks; one rank only
+        loss, ga, gs = sh1.step(albedo, shc[sl].contiguous(), idx_global=idx)
+        out.append((float(loss), ga.cpu().numpy().copy(), gs.cpu().numpy().copy()))
+    torch.cuda.synchronize()
+    q.put((rank, (s0, s1), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_stage1_view_sharded_matches_single_rank():
+    """stage 1 sharded by views (fmhr_amd.dist.ShardedStage1): each rank's plan holds its views, ONE all-reduce of the albedo gradient
+    per iteration, the batch-global L1 divisor from the per-view counts exchanged once at construction."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import rel_err
+    from fmhr_amd.stage1 import HamStage1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stage1_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sc, tg, faces, w2c, proj = _scene()
+    dev = faces.device
+    hs1 = HamStage1(sc["vertices"].to(dev), faces, w2c, proj, tg["img"], tg["mask"], (sc["H"], sc["W"]), 50.0)
+    albedo = sc["albedo0"][None].to(dev).contiguous()
+    shc = sc["sh0"].to(dev).contiguous()
+    for k, idx in enumerate((None, torch.tensor([4, 1, 2]), torch.tensor([5, 3]))):
+        lv, ga, gs = hs1.step(albedo, shc, idx=None if idx is None else idx.to(dev))
+        loss = float(lv.sum())
+        for rank, (s0, s1), out in res:
+            l_r, ga_r, gs_r = out[k]
+            assert abs(l_r - loss) <= 1e-5 * abs(loss), (k, rank, l_r, loss)
+            assert rel_err(torch.from_numpy(ga_r), ga.cpu()) < 2e-5
+            assert rel_err(torch.from_numpy(gs_r), gs[s0:s1].cpu()) < 2e-5 or float(gs[s0:s1].abs().max()) == 0.0

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""profiles/traffic_r01.json (read by bench.py for roofline.traffic) from a tools/pmc_summary.py table."""
+"""profiles/traffic_rNN.json (read by bench.py for roofline.traffic) from a tools/pmc_summary.py table:
+    python tools/traffic_json.py profiles/r03_binned_hbm_traffic.txt profiles/traffic_r03.json"""
 import json
 import re
 import sys
 
 SLOT_KERNELS = {
     "geometry": ["k_geometry"],
-    "raster_tris": ["k_raster_tris"], "raster_large": ["k_raster_large"], "raster_resolve": ["k_raster_resolve"],
+    "raster_tris": ["k_raster_tris"], "raster_large": ["k_raster_large"], "raster_resolve": ["k_raster_resolve", "k_raster_bins"],
     "shade_fwd": ["k_active_segments"], "aa_fwd": ["k_aa_fwd_list"], "loss_pix": ["k_loss_pix"],
     "aa_bwd": ["k_aa_bwd_items"], "shade_bwd": ["k_face_bwd"], "regularisers": ["k_mesh_tail_a", "k_mesh_tail_b"],
 }
@@ -27,5 +28,6 @@ for slot, ks in SLOT_KERNELS.items():
     lo += (f + w) * 1024
     hi += (2 * f + w) * 1024
 out["step_total_low"], out["step_total_high"] = int(lo), int(hi)
+out["_binned"] = any("k_raster_bins" in k for k in rows)
 json.dump(out, open(sys.argv[2], "w"), indent=2)
 print(json.dumps(out, indent=2))
