@@ -125,6 +125,16 @@ def save_obj_mesh_with_color(mesh_path, verts, faces, colors):
             f.write('f %d %d %d\n' % (t[0] + 1, t[2] + 1, t[1] + 1))
 
 
+def save_rerender_png(path, img):
+    """mesh_sfs_optim.py:342-343: `cv2.imwrite(path, (rendered * 255).astype(np.int32))` for one [H,W,3] image in the loader's
+    BGR channel order (cv2.imread, get_data.py:77).  cv2 saturates to 8 bits and writes the BGR array as it stands, i.e. the
+    file shows the original colours: PIL gets the RGB view of the same pixels."""
+    from PIL import Image
+    a = np.asarray(img, dtype=np.float64) * 255.0
+    a = np.clip(a.astype(np.int32), 0, 255).astype(np.uint8)             # .astype(np.int32) truncates toward zero, as there
+    Image.fromarray(np.ascontiguousarray(a[:, :, ::-1])).save(path)
+
+
 def load_obj(path):
     vs, fs = [], []
     for line in open(path):

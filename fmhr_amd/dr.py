@@ -90,7 +90,10 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     if len(resolution) != 2 or int(resolution[0]) <= 0 or int(resolution[1]) <= 0:
         raise RuntimeError("rasterize: resolution must be (height, width) > 0")
     rast = _RasterizeFn.apply(pos, tri, int(resolution[0]), int(resolution[1]))
-    return rast, torch.zeros_like(rast)
+    # rast_db (the barycentrics' screen-space derivatives) is discarded at every call site of the reference (`rast_out, _ =`): a
+    # zero tensor of the right shape WITHOUT its 16 B per pixel — one element expanded (a 48-view 512 x 512 call used to allocate
+    # and zero-fill 200 MB here)
+    return rast, torch.zeros((), dtype=rast.dtype, device=rast.device).expand(rast.shape)
 
 
 class _InterpolateFn(torch.autograd.Function):

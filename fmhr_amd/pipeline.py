@@ -115,12 +115,14 @@ def stage1_loss_cached(ops, cache, idx, albedo, sh_coeff, img, sfs_weight):
     return sfs_weight * diff / (3.0 * valid.sum())
 
 
-def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0):
+def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0, scan_id=None):
     """The HAM optimisation end to end on GPU tensors.  conf: dict with the keys of conf/demo_sfs.conf that the loop reads.
-    Returns dict(vertices, delta, albedo, sh_coeffs, history)."""
+    Returns dict(vertices, delta, albedo, sh_coeffs, history).  With `out_dir` the outputs of mesh_sfs_optim.py:319-343 are written
+    under the reference's names: '<scan_id>.pt' (sh_coeff, albedo), '<scan_id>.obj', '<scan_id>_c.obj' (vertex colours) and
+    'rerender/mesh_<view>.png' (the last epoch's rendered batches); scan_id = None keeps the stem 'ham'."""
     from . import optim
     from .ham import HamStage2, edge_length_mean
-    from .data import save_obj, save_obj_mesh_with_color
+    from .data import save_obj, save_obj_mesh_with_color, save_rerender_png
     ops = product_ops()
     dev = vertices.device
     degree, batch = int(conf.get("degree", 3)), int(conf["batch"])
@@ -128,7 +130,10 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     H, W = resolution
     gen = torch.Generator(device="cpu").manual_seed(seed)
     if degree != 3:
-        raise RuntimeError("run_ham: the fused stage-1 path evaluates the order-3 SH basis (degree = 3, conf/demo_sfs.conf:29)")
+        # the fused stage-1 / stage-2 kernels evaluate the order-3 SH basis (conf/demo_sfs.conf:29); the generic ops take any degree
+        # the reference's helpers take (init_sh / stage1_loss above, the import-swap recipe of INTEGRATION.md)
+        raise RuntimeError("run_ham: the fused steps are built for degree = 3; run degree 1 / 2 through the generic ops "
+                           "(pipeline.init_sh + pipeline.stage1_loss on product_ops())")
     # The constant sub-graph of init + stage 1 (:137-148 = :207-218: rasterization, antialiased + normalised normals, validity, start
     # silhouettes) is computed ONCE for all views by HamStage1; the SH least squares of :150-174 then run on it (normal equations
     # accumulated on the GPU, 9 x 9 solves on the host: `init_sh` above — the reference's own per-view host loop — took 2.8 of the
@@ -163,6 +168,7 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     opt = optim.Adam([{'params': delta, 'lr': conf["lr"]}, {'params': albedo, 'lr': conf["albedo_lr"]}])
     steppers = {}
     epoch_sfs = int(conf["epoch_sfs"])
+    rendered_img, perm_last = [], None                                               # :315-317
     for ep in range(epoch_sfs):
         perm = torch.randperm(num, generator=gen).to(dev)
         if ep == epoch_sfs // 2:
@@ -179,16 +185,26 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
                                      masks[idx].contiguous(), init["valid_masks"][idx].contiguous())
             delta.grad, albedo.grad = gd, ga.view(1, -1, 3)
             opt.step()
+            if ep == epoch_sfs - 1 and out_dir is not None:                          # the last epoch's renders are the "rerender" images
+                rendered_img.append(hs.views()["tmp_img"].clone())
+                perm_last = perm.cpu().numpy()
         if log_every and ep % log_every == 0:
             history.append(("sfs", ep, hs.loss_dict()))
     out_vertices = (vertices_tmp + delta).detach()
     result = dict(vertices=out_vertices, delta=delta.detach(), albedo=albedo.detach(), sh_coeffs=sh_coeffs.detach(), history=history,
                   valid_masks=init["valid_masks"])
-    if out_dir is not None:                                                          # :319-335
+    if out_dir is not None:                                                          # :319-343
         os.makedirs(out_dir, exist_ok=True)
-        torch.save({'sh_coeff': sh_coeffs.detach().cpu(), 'albedo': albedo.detach().cpu()}, os.path.join(out_dir, 'ham.pt'))
+        stem = 'ham' if scan_id is None else '%d' % scan_id
+        torch.save({'sh_coeff': sh_coeffs.detach().cpu(), 'albedo': albedo.detach().cpu()}, os.path.join(out_dir, stem + '.pt'))   # :321
         nv, nf = out_vertices.cpu().numpy(), faces.cpu().numpy()
-        save_obj(os.path.join(out_dir, 'ham.obj'), nv, nf)
+        save_obj(os.path.join(out_dir, stem + '.obj'), nv, nf)                                                             # :327
         color = torch.clamp(0.5 * albedo.detach(), 0, 1)[0].cpu().numpy()
-        save_obj_mesh_with_color(os.path.join(out_dir, 'ham_c.obj'), nv, nf, color[:, 2::-1])
+        save_obj_mesh_with_color(os.path.join(out_dir, stem + '_c.obj'), nv, nf, color[:, 2::-1])                          # :334-335
+        os.makedirs(os.path.join(out_dir, 'rerender'), exist_ok=True)                                                     # :337
+        if rendered_img:
+            rendered = torch.cat(rendered_img, 0).cpu().numpy()
+            for i, idx in enumerate(perm_last):                                                                           # :342-343
+                save_rerender_png(os.path.join(out_dir, 'rerender', 'mesh_%02d.png' % idx), rendered[i])
+        result["files"] = sorted(os.listdir(out_dir))
     return result

@@ -65,7 +65,7 @@ def test_run_ham_end_to_end(oracle, tmp_path):
     conf = dict(batch=4, degree=3, epoch_albedo=6, epoch_sfs=8, sfs_weight=50.0, lap_weight=2000.0, albedo_weight=1.0,
                 mask_weight=1000.0, edge_weight=500000.0, delta_weight=50000.0, lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
     out = pipeline.run_ham(sc["vertices"].to(dev), faces, img, gray, tg["mask"], w2c, proj, (128, 96), conf, out_dir=str(tmp_path),
-                           log_every=1)
+                           log_every=1, scan_id=1)
     hist = out["history"]
     s1 = [h[2] for h in hist if h[0] == "albedo"]
     s2 = [h[2]["sfs"] for h in hist if h[0] == "sfs"]
@@ -73,8 +73,17 @@ def test_run_ham_end_to_end(oracle, tmp_path):
     assert s1[-1] < s1[0], s1                       # stage 1 reduces the photometric error
     assert all(np.isfinite(v) for v in s1 + s2)
     assert torch.isfinite(out["vertices"]).all() and float(out["delta"].abs().max()) > 0
-    v, f = load_obj(os.path.join(tmp_path, "ham.obj"))
+    # the reference's output names (mesh_sfs_optim.py:321,327,334,343 with scan_id = 1)
+    v, f = load_obj(os.path.join(tmp_path, "1.obj"))
     assert v.shape == (sc["V"], 3) and f.shape == (sc["F"], 3)
-    ck = torch.load(os.path.join(tmp_path, "ham.pt"))
+    ck = torch.load(os.path.join(tmp_path, "1.pt"))
     assert ck["sh_coeff"].shape == (6, 9) and ck["albedo"].shape == (1, sc["V"], 3)
-    assert os.path.exists(os.path.join(tmp_path, "ham_c.obj"))
+    assert os.path.exists(os.path.join(tmp_path, "1_c.obj"))
+    # rerender PNGs: one per view, named by the view index of the last epoch's permutation; 8-bit, same pixels as the final render
+    from PIL import Image
+    names = sorted(os.listdir(os.path.join(tmp_path, "rerender")))
+    assert names == ["mesh_%02d.png" % i for i in range(6)]
+    png = np.asarray(Image.open(os.path.join(tmp_path, "rerender", "mesh_03.png")))
+    assert png.shape == (128, 96, 3) and png.dtype == np.uint8 and png.max() > 30
+    cov = (tg["mask"][3] > 0).cpu().numpy()
+    assert png[~cov].max() <= 80 and png[cov].mean() > 3 * max(png[~cov].mean(), 0.1)       # the hand is where the mask is

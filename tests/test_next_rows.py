@@ -142,3 +142,97 @@ def test_init_and_stage1_on_the_checker(oracle):
             num = float(f(alb + da, sh + ds) - f(alb - da, sh - ds)) / 2
         ana = float((alb.grad * da).sum() + (sh.grad * ds).sum())
         assert abs(num - ana) <= 1e-3 * abs(ana) + 1e-9, (num, ana)
+
+
+def test_demo_capture_cameras_against_the_captures_own_calibration():
+    """Row N1 on the reference's OWN capture (demo_data/1; committed as tests/golden/demo_ingest.npz by make_demo_fixture.py): the
+    cameras fmhr_amd.data.get_demo_data derives from world_mat @ scale_mat (cv2.decomposeProjectionMatrix replaced by an RQ
+    decomposition) must reproduce the intrinsics / rotations the capture stores next to them (param.npz: int_i, ext_i), the clip
+    projection must be the edit of get_data.py:66-73, and the capture's 3-D hand keypoints must project into the images and onto
+    the hand masks."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "demo_ingest.npz"))
+    W, H = g["res"]
+    X = np.concatenate([g["keypoints"], np.ones((g["keypoints"].shape[0], 1), np.float32)], 1)
+    frac_in_mask = []
+    for i in range(16):
+        w2c, proj, K = g["w2cs"][i].T, g["projs"][i].T, g["ints"][i]          # stored transposed (row-vector convention, :96-97)
+        assert abs(proj[0, 0] * W / 2 - K[0, 0]) < 1e-5 * K[0, 0] and abs(proj[1, 1] * H / 2 - K[1, 1]) < 1e-5 * K[1, 1]
+        assert abs((proj[0, 2] + 1) * W / 2 - K[0, 2]) < 1e-3 and abs((proj[1, 2] + 1) * H / 2 - K[1, 2]) < 1e-3
+        assert proj[2, 3] == np.float32(-0.1) and proj[3, 2] == 1 and proj[2, 2] == 0 and proj[3, 3] == 0
+        assert np.abs(w2c[:3, :3] - g["exts"][i][:3, :3]).max() < 1e-6        # rotation of the stored extrinsics
+        assert abs(np.linalg.det(w2c[:3, :3]) - 1) < 1e-5
+        # translation: the stored extrinsic maps the normalised (scale_mat) space; P = world_mat @ scale_mat folds the scale in
+        s = g["scale0"][0, 0]
+        assert np.allclose(w2c[:3, 3] * s, (g["exts"][i] @ g["scale0"])[:3, 3], atol=1e-5)
+        clip = (proj @ (w2c @ X.T)).T
+        assert (clip[:, 3] > 0.1).all()                                       # in front of every camera, beyond the near plane
+        px, py = (clip[:, 0] / clip[:, 3] + 1) * W / 2, (clip[:, 1] / clip[:, 3] + 1) * H / 2
+        inside = (px >= 0) & (px < W) & (py >= 0) & (py < H)
+        assert inside.mean() >= 0.9
+        if g["mask_sum"][i] / (W * H) > 0.05:
+            m = g["mask_thumb"][i][np.clip((py // 32).astype(int), 0, H // 32 - 1), np.clip((px // 32).astype(int), 0, W // 32 - 1)] > 0
+            frac_in_mask.append((m & inside).mean())
+    assert len(frac_in_mask) >= 10 and np.mean(frac_in_mask) > 0.5 and max(frac_in_mask) > 0.9
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/demo_data/1/camera/param.npz"), reason="the reference capture is only in the build container")
+def test_demo_capture_ingest_runs_and_matches_the_fixture():
+    """get_demo_data on /root/reference/demo_data/1 (16 views, 1280 x 1024 as conf/demo_sfs.conf:11-12), device = cpu: cameras
+    identical to the committed fixture, images / grey images / masks equal to its thumbnails and checksums."""
+    from fmhr_amd.data import get_demo_data
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "demo_ingest.npz"))
+    imgs, grays, masks, w2cs, projs = get_demo_data("/root/reference/demo_data", 1, 16, (1280, 1024), device="cpu")
+    assert imgs.shape == (16, 1024, 1280, 3) and grays.shape == (16, 1024, 1280) and masks.shape == (16, 1024, 1280)
+    assert np.array_equal(w2cs.numpy(), g["w2cs"]) and np.array_equal(projs.numpy(), g["projs"])
+    thumb = lambda t: t.reshape(16, 32, 32, 40, 32, *t.shape[3:]).mean((2, 4)).numpy()
+    assert np.abs(thumb(imgs) - g["img_thumb"]).max() < 1e-6 and np.abs(thumb(masks) - g["mask_thumb"]).max() < 1e-6
+    assert np.allclose(imgs.double().sum((1, 2, 3)).numpy(), g["img_sum"]) and np.allclose(masks.double().sum((1, 2)).numpy(), g["mask_sum"])
+    assert set(np.unique(masks.numpy())) <= {0.0, 1.0} and float(imgs.max()) <= 1.0
+    assert float((imgs.sum(-1) > 0)[masks == 0].float().mean()) < 0.02       # with_mask: the background is blanked (resize halo aside)
+
+
+def test_loop_subdivision_of_the_exact_mano_count_base():
+    """Row N2: three Loop subdivisions of a 778-vertex / 1538-face / 2315-edge disc (MANO's counts: mano/TEMPLATE_RIGHT.obj) give
+    exactly the sizes /root/reference/train_mlp.py:150-154 hard-codes, level by level, and the child-face
+    layout /root/reference/repose.py:14-24 (`subdivide_weight`) relies on: of the four consecutive children tmp[0..3] of a parent,
+    tmp[0][1] is the new vertex of edge (tmp[0][0], tmp[1][1]), tmp[0][2] of (tmp[0][0], tmp[2][2]), tmp[1][2] of (tmp[1][1], tmp[2][2])."""
+    from fmhr_amd.subdivide import subdivide_loop_once
+    from fmhr_amd.synthetic import mano_disc_mesh
+    v, f = mano_disc_mesh()
+    counts = []
+    v, f = v.astype(np.float64), f.astype(np.int64)
+    for level in range(3):
+        V0 = v.shape[0]
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]); e.sort(1)
+        uniq = np.unique(e[:, 0] * V0 + e[:, 1])
+        counts.append((V0, f.shape[0], uniq.shape[0]))
+        v1, f1 = subdivide_loop_once(v, f)
+        f1 = np.asarray(f1)
+        # repose.py:14-24 on the new faces: every new vertex is the midpoint-vertex of exactly the edge the reference averages over
+        edge_of = {V0 + k: (int(u // V0), int(u % V0)) for k, u in enumerate(uniq)}        # odd vertices in unique-edge order
+        for i in range(0, f1.shape[0], 4):
+            t = f1[i:i + 4]
+            for new, a, b in ((t[0][1], t[0][0], t[1][1]), (t[0][2], t[0][0], t[2][2]), (t[1][2], t[1][1], t[2][2])):
+                assert edge_of[int(new)] == (min(int(a), int(b)), max(int(a), int(b)))
+            assert t[0][0] < V0 and t[1][1] < V0 and t[2][2] < V0 and set(t[3]) == {t[0][1], t[0][2], t[1][2]}
+        assert np.array_equal(v1[:V0].shape, v.shape)                                       # even vertices keep their indices
+        v, f = v1, f1
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]); e.sort(1)
+    counts.append((v.shape[0], f.shape[0], np.unique(e[:, 0] * v.shape[0] + e[:, 1]).shape[0]))
+    assert counts == [(778, 1538, 2315), (3093, 6152, 9244), (12337, 24608, 36944), (49281, 98432, 147712)]
+    assert np.isfinite(v).all() and float(np.abs(v).max()) < 0.2                            # a hand-sized smooth surface
+
+
+def test_rerender_png_writer(tmp_path):
+    """mesh_sfs_optim.py:342-343: (rendered * 255).astype(np.int32) written by cv2.imwrite = truncation toward zero, saturation to
+    8 bits, the loader's BGR array stored as it stands (the file shows RGB)."""
+    from PIL import Image
+    from fmhr_amd.data import save_rerender_png
+    img = np.zeros((2, 3, 3))
+    img[0, 0] = [1.0, 0.5, 0.0]           # B, G, R
+    img[0, 1] = [1.2, -0.1, 0.999]        # out of range both ways
+    img[1, 2] = [0.25, 0.25, 0.25]
+    save_rerender_png(tmp_path / "m.png", img)
+    a = np.asarray(Image.open(tmp_path / "m.png"))
+    assert a.shape == (2, 3, 3) and a.dtype == np.uint8
+    assert a[0, 0].tolist() == [0, 127, 255] and a[0, 1].tolist() == [254, 0, 255] and a[1, 2].tolist() == [63, 63, 63]
