@@ -51,6 +51,13 @@ def get_normals(vertices, faces):
     if vertices.dim() != 3 or vertices.shape[2] != 3:
         raise RuntimeError("get_normals: vertices must be [b,n,3]")
     _lib.require_gpu("get_normals", vertices, faces)
+    if vertices.shape[0] > 1 and vertices.stride(0) == 0:
+        # the reference hands over the SAME world-space vertices n times (`vertsw = ....unsqueeze(0).expand(n, -1, -1)`,
+        # mesh_sfs_optim.py:262,265): the normals are view-independent, so they are formed once and the result is expanded — the
+        # values of every view are the ones the batched call would give, autograd sums the n gradient slices back through the expand
+        # (k_normals_faces 0.83 -> 0.02 ms, k_normals_bwd_faces 0.42 -> 0.01 ms per 48-view iteration of the unchanged loop body)
+        one = _NormalsFn.apply(_lib.f32c("get_normals", vertices[0:1]), _faces_i32(faces))
+        return one.expand(vertices.shape[0], -1, -1)
     return _NormalsFn.apply(_lib.f32c("get_normals", vertices), _faces_i32(faces))
 
 

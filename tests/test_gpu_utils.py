@@ -73,6 +73,18 @@ def test_large_mesh_vs_oracle(U, oracle):
     (nd * w.to(dev)).sum().backward()
     assert rel_err(nd, oracle.get_normals(v[None], f)) < 1e-5
     assert rel_err(vd.grad, vg.grad) < TOL
+    # the reference's call shape (mesh_sfs_optim.py:262,265): the same vertices expanded over n views — computed once, expanded;
+    # every view's slice equals the batched result and the gradient is the sum over the views' weights
+    n = 3
+    wn = torch.tensor(rng.standard_normal((n, sc["V"], 3)), dtype=torch.float32)
+    ve = v.to(dev).clone().requires_grad_(True)
+    vertsw = torch.cat([ve, torch.ones_like(ve[:, 0:1])], axis=1).unsqueeze(0).expand(n, -1, -1)
+    ne = U.get_normals(vertsw[:, :, :3], f.to(dev).long())
+    assert ne.shape == (n, sc["V"], 3) and all(torch.equal(ne[k], nd[0].detach()) for k in range(n))
+    (ne * wn.to(dev)).sum().backward()
+    vb = v.to(dev)[None].expand(n, -1, -1).contiguous().clone().requires_grad_(True)      # the batched form, no stride-0 dimension
+    (U.get_normals(vb, f.to(dev)) * wn.to(dev)).sum().backward()
+    assert rel_err(ve.grad, vb.grad.sum(0)) < 1e-5
     # the reference's L.mm(x) loses ~1e-4 (relative) to cancellation in fp32 on a smooth mesh (measured: its own fp32 vs
     # fp64 run differ by 1.2e-4), so the truth for the 1e-4 bar is the fp64 oracle; the kernel sums differences instead
     for x in (v, sc["albedo_true"]):
