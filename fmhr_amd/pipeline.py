@@ -129,40 +129,56 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     num = imgs.shape[0]
     H, W = resolution
     gen = torch.Generator(device="cpu").manual_seed(seed)
-    if degree != 3:
-        # the fused stage-1 / stage-2 kernels evaluate the order-3 SH basis (conf/demo_sfs.conf:29); the generic ops take any degree
-        # the reference's helpers take (init_sh / stage1_loss above, the import-swap recipe of INTEGRATION.md)
-        raise RuntimeError("run_ham: the fused steps are built for degree = 3; run degree 1 / 2 through the generic ops "
-                           "(pipeline.init_sh + pipeline.stage1_loss on product_ops())")
-    # The constant sub-graph of init + stage 1 (:137-148 = :207-218: rasterization, antialiased + normalised normals, validity, start
-    # silhouettes) is computed ONCE for all views by HamStage1; the SH least squares of :150-174 then run on it (normal equations
-    # accumulated on the GPU, 9 x 9 solves on the host: `init_sh` above — the reference's own per-view host loop — took 2.8 of the
-    # 3.0 s of a 48-view run)
-    from . import stage1 as s1
-    hs1 = s1.HamStage1(vertices.detach(), faces, w2cs, projs, imgs, masks, resolution, conf["sfs_weight"], want_pred_masks=True)
-    init = s1.init_sh(hs1, grayimgs)
-    sh_coeffs = init["sh_coeffs"].clone().requires_grad_(True)                       # :168-170
-    albedo = (torch.zeros_like(vertices) + init["albedo_mean"]).unsqueeze(0).contiguous().requires_grad_(True)   # :175-176
+    history = []
     delta = torch.zeros_like(vertices).requires_grad_(True)
     vertices_tmp = vertices.detach().clone()
     elm = edge_length_mean(vertices_tmp, faces)                                      # :184-188
-    history = []
-    # ---- stage 1: albedo + SH (:193-240)
-    # the fused step (fmhr_amd.stage1.HamStage1): the constant sub-graph and the linear interpolate + antialias operator are built
-    # once, an iteration is one C call (two launches), the Adam update of both parameters applied inside it.  `stage1_loss` /
-    # `stage1_loss_cached` above are the op-by-op forms the parity tests compare it with.
-    opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
-    for ep in range(int(conf["epoch_albedo"])):
-        perm = torch.randperm(num, generator=gen).to(dev)
-        for k in range(0, num, batch):
-            idx = perm[k:k + batch]
-            loss_view, _, _ = hs1.step(albedo, sh_coeffs, idx=None if idx.numel() == num else idx, optimizer=opt,
-                                       params=(albedo, sh_coeffs))
-        if log_every and ep % log_every == 0:
-            history.append(("albedo", ep, float(loss_view.sum())))
-    del hs1
+    if degree == 3:
+        # The constant sub-graph of init + stage 1 (:137-148 = :207-218: rasterization, antialiased + normalised normals, validity,
+        # start silhouettes) is computed ONCE for all views by HamStage1; the SH least squares of :150-174 then run on it (normal
+        # equations accumulated on the GPU, 9 x 9 solves on the host: `init_sh` above — the reference's own per-view host loop — took
+        # 2.8 of the 3.0 s of a 48-view run)
+        from . import stage1 as s1
+        hs1 = s1.HamStage1(vertices.detach(), faces, w2cs, projs, imgs, masks, resolution, conf["sfs_weight"], want_pred_masks=True)
+        init = s1.init_sh(hs1, grayimgs)
+        sh_coeffs = init["sh_coeffs"].clone().requires_grad_(True)                   # :168-170
+        albedo = (torch.zeros_like(vertices) + init["albedo_mean"]).unsqueeze(0).contiguous().requires_grad_(True)   # :175-176
+        # ---- stage 1: albedo + SH (:193-240), the fused step (fmhr_amd.stage1.HamStage1): the constant sub-graph and the linear
+        # interpolate + antialias operator are built once, an iteration is one C call (two launches), the Adam update of both
+        # parameters applied inside it.  `stage1_loss` / `stage1_loss_cached` above are the op-by-op forms the parity tests compare it with.
+        opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
+        for ep in range(int(conf["epoch_albedo"])):
+            perm = torch.randperm(num, generator=gen).to(dev)
+            for k in range(0, num, batch):
+                idx = perm[k:k + batch]
+                loss_view, _, _ = hs1.step(albedo, sh_coeffs, idx=None if idx.numel() == num else idx, optimizer=opt,
+                                           params=(albedo, sh_coeffs))
+            if log_every and ep % log_every == 0:
+                history.append(("albedo", ep, float(loss_view.sum())))
+        del hs1
+        sh_fixed = sh_coeffs.detach()
+    else:
+        # degree 1 / 2 (conf key `degree`; the reference's helpers take it, models/utils.py:188-226): the fused stage-1 kernels
+        # evaluate the order-3 basis and would move the higher bands, so init + stage 1 run op by op on the generic ops (cached
+        # constant sub-graph); stage 2 freezes the SH coefficients (:243) and a zero-padded row IS the lower-degree polynomial
+        init = init_sh(ops, vertices.detach(), faces, imgs, grayimgs, masks, w2cs, projs, resolution, degree)
+        sh_coeffs = init["sh_coeffs"].clone().requires_grad_(True)
+        albedo = (torch.zeros_like(vertices) + init["albedo_mean"]).unsqueeze(0).contiguous().requires_grad_(True)
+        cache = Stage1Cache(ops, ops.RasterizeGLContext(), vertices.detach(), faces, w2cs, projs, masks, resolution, degree)
+        opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
+        for ep in range(int(conf["epoch_albedo"])):
+            perm = torch.randperm(num, generator=gen).to(dev)
+            for k in range(0, num, batch):
+                idx = perm[k:k + batch]
+                loss = stage1_loss_cached(ops, cache, idx, albedo, sh_coeffs[idx], imgs[idx], conf["sfs_weight"])
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            if log_every and ep % log_every == 0:
+                history.append(("albedo", ep, float(loss)))
+        del cache
+        sh_fixed = F.pad(sh_coeffs.detach(), (0, 9 - degree ** 2)).contiguous()
     # ---- stage 2: vertex offsets + albedo (:242-317), fused step
-    sh_fixed = sh_coeffs.detach()
     weights = dict(sfs=conf["sfs_weight"], lap=conf["lap_weight"], albedo=conf["albedo_weight"], mask=conf["mask_weight"],
                    edge=conf["edge_weight"], delta=conf["delta_weight"])
     opt = optim.Adam([{'params': delta, 'lr': conf["lr"]}, {'params': albedo, 'lr': conf["albedo_lr"]}])

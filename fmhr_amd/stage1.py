@@ -110,10 +110,12 @@ class HamStage1:
         loss_view.sum() (the views' shares; no extra launch unless somebody asks).  With `optimizer` (fmhr_amd.optim.Adam) and
         params = (albedo, sh_coeffs) the Adam update of both is applied by the step's second kernel (no optimizer.step())."""
         _lib.require_gpu("HamStage1.step", albedo, sh_coeffs)
-        a = albedo.detach().reshape(self.V, 3)
-        s = sh_coeffs.detach()
-        if not (a.is_contiguous() and s.is_contiguous() and a.dtype == torch.float32 and s.dtype == torch.float32):
+        if not (albedo.is_contiguous() and sh_coeffs.is_contiguous() and albedo.dtype == torch.float32 and sh_coeffs.dtype == torch.float32):
             raise RuntimeError("HamStage1.step: albedo / sh_coeffs must be contiguous float32")
+        if albedo.numel() != self.V * 3:
+            raise RuntimeError(f"HamStage1.step: albedo must be [1,{self.V},3] or [{self.V},3]")
+        a = albedo.detach().view(self.V, 3)                          # a view, never a copy: the kernel may update it in place
+        s = sh_coeffs.detach()
         if s.shape != (self.n, 9):
             raise RuntimeError(f"HamStage1.step: sh_coeffs must be [{self.n}, 9]")
         sel = None
@@ -123,10 +125,20 @@ class HamStage1:
             sel = self.view_sel
         adam = (None, None)
         if optimizer is not None:
+            if params is None or len(params) != 2:
+                raise RuntimeError("HamStage1.step: optimizer= needs params=(albedo, sh_coeffs), the tensors the optimiser owns")
+            if params[0].data_ptr() != a.data_ptr() or params[1].data_ptr() != s.data_ptr():
+                raise RuntimeError("HamStage1.step: `params` must be the tensors behind the `albedo` / `sh_coeffs` arguments")
             adam = (optimizer.fused_param(params[0]), optimizer.fused_param(params[1]))
-        call("fmhr_stage1_step", ctypes.byref(self.plan), ptr(a), ptr(s), ptr(sel), self.sfs_weight, ptr(self.galbedo), ptr(self.gsh),
-             ptr(self.loss_view), ctypes.byref(adam[0]) if adam[0] is not None else None,
-             ctypes.byref(adam[1]) if adam[1] is not None else None, ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
+        try:
+            call("fmhr_stage1_step", ctypes.byref(self.plan), ptr(a), ptr(s), ptr(sel), self.sfs_weight, ptr(self.galbedo), ptr(self.gsh),
+                 ptr(self.loss_view), ctypes.byref(adam[0]) if adam[0] is not None else None,
+                 ctypes.byref(adam[1]) if adam[1] is not None else None, ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
+        except RuntimeError:
+            if optimizer is not None:                                # a rejected call applied no update: take the step count back
+                for p_ in params:
+                    optimizer.state[p_]['step'] -= 1
+            raise
         return self.loss_view, self.galbedo, self.gsh
 
 
@@ -145,14 +157,23 @@ def init_sh(hs1, grayimgs, nblk=64):
     acc = part.sum(1).cpu().numpy()                                   # [n, 55]
     iu = np.triu_indices(9)
 
-    def solve(a):
+    def solve(a, view=None):
         G = np.zeros((9, 9))
         G[iu] = a[:45]
         G = G + np.triu(G, 1).T
-        # minimum-norm least-squares solution of the normal equations (= np.linalg.lstsq on the design matrix whenever it has full
-        # column rank; a view with fewer than 9 valid pixels gets the minimum-norm solution of what it has)
+        # The normal equations square the condition number: they reproduce np.linalg.lstsq on the [Pv, 9] design matrix (the
+        # reference, mesh_sfs_optim.py:153-154,165-166) while cond(G) stays far from 1 / eps.  A view whose normals barely span the
+        # basis (a flat patch, a handful of valid pixels) is solved the reference's way instead: its valid pixels are gathered and
+        # handed to lstsq on the design matrix, whose rcond cut-off then acts on the design matrix's own singular values.
+        sv = np.linalg.svd(G, compute_uv=False)
+        if view is not None and (sv[-1] <= 1e-10 * sv[0]):
+            valid = (hs1.masks[view] > 0) & (hs1.rast[view, :, :, 3] > 0)
+            vn = hs1.normals[view][valid].cpu().numpy()
+            if vn.shape[0] > 0:
+                from .utils import get_matrix
+                return np.linalg.lstsq(get_matrix(vn, 3), gray[view][valid].cpu().numpy(), rcond=None)[0]
         return np.linalg.lstsq(G, a[45:54], rcond=None)[0]
-    sh_views = np.stack([solve(acc[b]) for b in range(n)]).astype(np.float32)
+    sh_views = np.stack([solve(acc[b], b) for b in range(n)]).astype(np.float32)
     sh_global = solve(acc.sum(0)).astype(np.float32)
     shg = torch.from_numpy(sh_global).to(dev)
     part2 = torch.empty(n, nblk, 4, dtype=torch.float64, device=dev)

@@ -87,3 +87,25 @@ def test_run_ham_end_to_end(oracle, tmp_path):
     assert png.shape == (128, 96, 3) and png.dtype == np.uint8 and png.max() > 30
     cov = (tg["mask"][3] > 0).cpu().numpy()
     assert png[~cov].max() <= 80 and png[cov].mean() > 3 * max(png[~cov].mean(), 0.1)       # the hand is where the mask is
+
+
+def test_run_ham_with_degree_two(oracle):
+    """conf key `degree` = 2 (the reference's helpers take degrees 1-3, models/utils.py:188-226): init + stage 1 run on the generic
+    ops, stage 2 on the fused step with the frozen coefficient rows zero-padded to order 3."""
+    from fmhr_amd import pipeline, synthetic as S
+    from fmhr_amd.ham import render_forward
+    dev = torch.device("cuda:0")
+    sc = S.make_scene(4, 96, 80, 12, 16, 0, seed=6)
+    faces = sc["faces"].to(dev)
+    w2c, proj = sc["w2c"].to(dev), sc["proj"].to(dev)
+    tg = S.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, 96, 80), device=dev)
+    img = tg["img"]
+    gray = (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).contiguous()
+    conf = dict(batch=2, degree=2, epoch_albedo=4, epoch_sfs=4, sfs_weight=50.0, lap_weight=2000.0, albedo_weight=1.0,
+                mask_weight=1000.0, edge_weight=500000.0, delta_weight=50000.0, lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
+    out = pipeline.run_ham(sc["vertices"].to(dev), faces, img, gray, tg["mask"], w2c, proj, (96, 80), conf, log_every=1)
+    assert out["sh_coeffs"].shape == (4, 4)
+    s1 = [h[2] for h in out["history"] if h[0] == "albedo"]
+    s2 = [h[2]["sfs"] for h in out["history"] if h[0] == "sfs"]
+    assert len(s1) == 4 and len(s2) == 4 and s1[-1] < s1[0] and all(np.isfinite(v) for v in s1 + s2)
+    assert float(out["delta"].abs().max()) > 0

@@ -186,3 +186,41 @@ def test_fused_stage1_edge_cases():
     gray = (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).contiguous()
     init = stage1.init_sh(hs, gray)
     assert float(init["sh_coeffs"][1].abs().max()) == 0.0 and torch.isfinite(init["sh_coeffs"]).all() and torch.isfinite(init["albedo_mean"]).all()
+
+
+def test_sh_initialisation_of_a_rank_deficient_view_follows_the_reference():
+    """a view with fewer valid pixels than SH coefficients (and one whose normals barely span the basis) must get the
+    reference's minimum-norm least-squares solution of the [Pv, 9] DESIGN matrix (mesh_sfs_optim.py:153-154), not that of the squared
+    normal equations; and HamStage1.step(optimizer=...) must refuse parameters that are not the storage behind its arguments."""
+    from fmhr_amd import pipeline, stage1
+    from fmhr_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    sc, faces, w2c, proj, tg = _scene(dev, views=3, seed=11)
+    vt = sc["vertices"].to(dev).contiguous()
+    res = (sc["H"], sc["W"])
+    img = tg["img"]
+    gray = (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).contiguous()
+    mask = tg["mask"].clone()
+    cov = torch.nonzero(mask[1] > 0)
+    keep = cov[cov.shape[0] // 2: cov.shape[0] // 2 + 5]             # view 1: five valid pixels (< 9 unknowns)
+    mask[1] = 0.0
+    mask[1][keep[:, 0], keep[:, 1]] = 1.0
+    ref = pipeline.init_sh(pipeline.product_ops(), vt, faces, img, gray, mask, w2c, proj, res)
+    hs = stage1.HamStage1(vt, faces, w2c, proj, img, mask, res, 50.0, want_pred_masks=True)
+    assert int(hs.view_valid[1]) == 5
+    got = stage1.init_sh(hs, gray)
+    # five neighbouring pixels have nearly the same normal: the minimum-norm coefficients are O(1e4) and move by ~5e-3 with the last
+    # bit of the basis products (float32 products stored in a float64 matrix, as models/utils.py:188-204 forms them, vs float64
+    # products in pipeline.init_sh); the squared normal equations would be off by orders of magnitude
+    assert rel_err(got["sh_coeffs"][1], ref["sh_coeffs"][1]) < 2e-2, (got["sh_coeffs"][1], ref["sh_coeffs"][1])
+    assert rel_err(got["sh_coeffs"][[0, 2]], ref["sh_coeffs"][[0, 2]]) < 1e-4 and rel_err(got["sh_global"], ref["sh_global"]) < 1e-4
+    # the parameter check of the fused update
+    a = sc["albedo0"][None].to(dev).clone().requires_grad_(True)
+    s = got["sh_coeffs"].clone().requires_grad_(True)
+    opt = Adam([{'params': a, 'lr': 5e-3}, {'params': s, 'lr': 5e-3}])
+    with pytest.raises(RuntimeError, match="params"):
+        hs.step(a, s, optimizer=opt)
+    with pytest.raises(RuntimeError, match="params"):
+        hs.step(a.detach().clone(), s, optimizer=opt, params=(a, s))
+    hs.step(a, s, optimizer=opt, params=(a, s))
+    assert opt.state[a]['step'] == 1 and opt.state[s]['step'] == 1

@@ -80,7 +80,8 @@ def test_large_mesh_vs_oracle(U, oracle):
     ve = v.to(dev).clone().requires_grad_(True)
     vertsw = torch.cat([ve, torch.ones_like(ve[:, 0:1])], axis=1).unsqueeze(0).expand(n, -1, -1)
     ne = U.get_normals(vertsw[:, :, :3], f.to(dev).long())
-    assert ne.shape == (n, sc["V"], 3) and all(torch.equal(ne[k], nd[0].detach()) for k in range(n))
+    assert ne.shape == (n, sc["V"], 3) and all(torch.equal(ne[k], ne[0]) for k in range(n))
+    assert rel_err(ne[1], nd[0]) < 1e-6                             # (the face sums are float atomics: last-bit order effects between runs)
     (ne * wn.to(dev)).sum().backward()
     vb = v.to(dev)[None].expand(n, -1, -1).contiguous().clone().requires_grad_(True)      # the batched form, no stride-0 dimension
     (U.get_normals(vb, f.to(dev)) * wn.to(dev)).sum().backward()
