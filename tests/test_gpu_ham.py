@@ -16,7 +16,13 @@ TOL = 1e-4
 # autograd through the homogeneous edge functions, exactly nvdiffrast's formulation) is itself further than 1e-4 from exact
 # arithmetic, because an edge-on triangle amplifies the last bit of its clip positions by 1 / area; the fused step must then be no
 # further from fp64 than twice that twin.  The measured numbers of every case are written to profiles/parity_r03.txt.
-RELAXED = {}
+RELAXED = {
+    # one pixel of an edge-on triangle of the 197 k-face two-hand mesh: rule R5's fp32 barycentrics (nvdiffrast's homogeneous edge
+    # functions) are 2e-3 off there in ANY fp32 evaluation, which is 3.5e-7 of albedo gradient at one vertex = 4.0e-4 of this case's
+    # small maximum (8.8e-4); the fp32 twin shows 4.02e-4, the fused step 4.02e-4, the two agree to 1e-6 (oracle run on the CPU:
+    # sfs term alone 4.02e-4, albedo-Laplacian term 3e-5)
+    "two_hands_sub3_2x512x334": "edge-on triangle: fp32 barycentrics of rule R5, fp32 twin 4.0e-4 too",
+}
 
 
 def grad_bar(name, e_d, e_a, o_d, o_a):
@@ -94,7 +100,19 @@ def test_fused_step_vs_oracle(oracle, case):
 
     ref, gd32, ga32 = run_oracle(torch.float32)             # fp32 twin: decisions must match bit for bit
     assert int(v["aa_counter"][1]) == 0, "antialias queue overflow"
-    assert rel_err(pos_gpu, oracle.clip_positions(sc["vertices"] + sc["delta"], sc["w2c"], sc["proj"])[1]) < 1e-6
+    pos_cpu = oracle.clip_positions(sc["vertices"] + sc["delta"], sc["w2c"], sc["proj"])[1]
+    assert rel_err(pos_gpu, pos_cpu) < 1e-6
+    # ... and what the last-bit difference between the kernel's FMA chain and torch's einsum does to the DECISIONS' inputs: the
+    # snapped vertices (rule R2, 1/256 px) of the two sets of positions differ at a handful of vertices and by one unit at most —
+    # a transform defect that moved a vertex further would fail here, not be absorbed by evaluating the oracle at the GPU's positions
+    def snap(p, n_):
+        p = p.to(torch.float32)
+        rw = 1.0 / p[..., 3]
+        qx = (p[..., 0] * rw) * (n_[1] * 128.0) + (n_[1] * 128.0)
+        qy = (p[..., 1] * rw) * (n_[0] * 128.0) + (n_[0] * 128.0)
+        return torch.stack([torch.round(qx), torch.round(qy)], -1)
+    ds = (snap(pos_gpu, (sc["H"], sc["W"])) - snap(pos_cpu, (sc["H"], sc["W"]))).abs()
+    assert float(ds.max()) <= 1.0 and float((ds > 0).float().mean()) < 2e-3, (float(ds.max()), float((ds > 0).float().mean()))
     assert torch.equal(v["rast"].cpu(), ref["rast"]), "rast must be bit-identical to the fp32 oracle"
     assert ld["n_valid"] == ref["n_valid"] and ref["n_valid"] > 100
     with oracle.f32_decisions():                            # fp64 values on the same decisions: the truth for 1e-4
@@ -578,3 +596,25 @@ def test_fragment_bin_overflow_is_reported(oracle, monkeypatch):
     hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
     with pytest.raises(RuntimeError, match="fragment bin"):
         hs.loss_dict()
+
+
+def test_two_hand_sub3_mesh_at_the_sequence_resolution(oracle):
+    """BASELINE.json configs[4] at size: two hands, each the exact sub3 mesh (V = 2 x 49281, F = 2 x 98432, two boundary loops),
+    334 x 512 (conf/ih_sfsseq.conf:11-12) — the fused step (atomic-key rasterizer: W % 64 != 0; per-pixel antialias scan) against
+    the CPU oracle exactly as the small cases are checked."""
+    from fmhr_amd import synthetic as S
+    from fmhr_amd.ham import render_forward, edge_length_mean
+    dev = torch.device("cuda:0")
+    n, H, W = 2, 512, 334
+    sc = S.make_scene(n, H, W, "mano", 0, 3, seed=5, hands=2)
+    assert sc["V"] == 98562 and sc["F"] == 196864
+    faces = sc["faces"].to(dev)
+    fwd = lambda v, a, s, m: render_forward(faces, v, a, s, sc["w2c"].to(dev), sc["proj"].to(dev), m, H, W)
+    tg = S.make_targets(sc, fwd, device=dev)
+    gen = torch.Generator().manual_seed(12)
+    sc["delta"] = 2e-4 * torch.randn(sc["V"], 3, generator=gen)
+    sc["albedo"] = sc["albedo0"] + 0.05 * torch.rand(sc["V"], 3, generator=gen)
+    sc.update({k: tg[k].cpu() for k in ("img", "mask", "valid_mask")})
+    sc["elm"] = float(edge_length_mean(sc["vertices"].to(dev), faces))
+    ld, v = _step_vs_oracle(oracle, sc, "two_hands_sub3_2x512x334")
+    assert ld["n_valid"] > 0.1 * n * H * W
