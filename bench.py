@@ -310,14 +310,16 @@ def main():
     barrier()
 
     # untimed profiling pass: per-launch-group HIP-event times -> dominant group
-    prof_steps = 3
+    prof_steps = 9
     tm = Timing(prof_steps, stream)
     for i in range(prof_steps):
         tm.attach(i)
         step()
     Timing.detach()
     torch.cuda.synchronize()
-    kernels = {name: sum(tm.ms(i, k) for i in range(prof_steps)) / prof_steps for k, name in enumerate(SLOTS)}
+    # MEDIAN over the instrumented steps: with an event pair around every launch group a step now and then shows one group at
+    # 1.5-2x (k_face_bwd 73 -> 150 us), which a 3-step mean turned into a different "dominant kernel" from run to run
+    kernels = {name: sorted(tm.ms(i, k) for i in range(prof_steps))[prof_steps // 2] for k, name in enumerate(SLOTS)}
     collective = None
     if group is not None:
         parts = torch.tensor([step_parts() for _ in range(5)][1:], dtype=torch.float64).mean(0).to(dev)     # [kernels, all-reduce, combine]
