@@ -130,7 +130,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     const bool binned = raster_binned_ok(d->F, d->H, d->W);
     const size_t tiles = binned ? raster_bin_count(d->n, d->H, d->W) : 0;
     L.bin_cursor = take(off, tiles * 4 * kCursorStride + 16);
-    L.bins = take(off, tiles * (size_t)bin_cap_entries() * 16);
+    L.bins = take(off, tiles * (size_t)bin_cap_entries(d->bin_cap) * 16);
     L.total = off;
     return L;
 }
@@ -141,6 +141,7 @@ static int check_dims(const fmhr_ham_dims* d)
     FMHR_CHECK_ARG(d->n >= 1 && d->V >= 1 && d->F >= 1 && d->H >= 1 && d->W >= 1 && d->aa_cap >= 2048,
                    "ham: bad dims n=%d V=%d F=%d H=%d W=%d aa_cap=%d", d->n, d->V, d->F, d->H, d->W, d->aa_cap);
     FMHR_CHECK_ARG(d->H <= 8192 && d->W <= 8192 && d->F < (1 << 24), "ham: H,W <= 8192 and F < 2^24 required");
+    FMHR_CHECK_ARG(d->bin_cap >= 0 && d->bin_cap <= (1 << 20), "ham: bin_cap must be 0 (default) or 64 .. 2^20, got %d", d->bin_cap);
     FMHR_CHECK_ARG(((long long)d->n * d->H * d->W) % 4 == 0, "ham: n*H*W must be a multiple of 4");
     FMHR_CHECK_ARG(d->n <= 65535 && ((long long)d->n * d->H * d->W) < (1ll << 30), "ham: n <= 65535 and n*H*W < 2^30 required (32-bit channel offsets in k_aa_bwd_items)");
     return FMHR_OK;
@@ -160,6 +161,12 @@ static int check_dims(const fmhr_ham_dims* d)
 }  // namespace fmhr
 
 using namespace fmhr;
+
+extern "C" int fmhr_ham_rasterizer_form(const fmhr_ham_dims* d)
+{
+    if (check_dims(d)) return -1;
+    return (raster_binned_ok(d->F, d->H, d->W) && raster_binned_wanted(true)) ? 1 : 0;
+}
 
 extern "C" size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d)
 {
@@ -275,7 +282,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
         fu.bins = nullptr; fu.bin_cursor = nullptr; fu.bin_flag = nullptr; fu.bin_cap = 0;
         if (raster_binned_ok(d->F, d->H, d->W)) {
-            fu.bins = (uint4*)(w + L.bins); fu.bin_cursor = (int*)(w + L.bin_cursor); fu.bin_cap = bin_cap_entries();
+            fu.bins = (uint4*)(w + L.bins); fu.bin_cursor = (int*)(w + L.bin_cursor); fu.bin_cap = bin_cap_entries(d->bin_cap);
             fu.bin_flag = (int*)(w + L.aa_counter) + 2;             // sticky overflow flag next to the antialias list's (read by the host)
         }
         TRY(rasterize_fwd_impl(nullptr, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,

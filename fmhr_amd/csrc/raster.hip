@@ -1147,10 +1147,8 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     const PixGrid pg = make_pix_grid(H, W);
     // binned form (fused step, micro-triangle mesh, W % 64 == 0): per-segment fragment bins + k_raster_bins instead of the
     // global depth keys + k_raster_resolve.  FMHR_RASTER_BINNED=0 / 1 overrides the default (same-library A/B: tools/abn.sh)
-    const char* benv = getenv("FMHR_RASTER_BINNED");               // read per call: the parity test runs both forms in one process
-    const int binned_env = benv ? atoi(benv) : -1;
     const bool binned = fu.bins != nullptr && fu.verts != nullptr && dirty != nullptr && fu.pix16 != nullptr && fu.aa_init != nullptr &&
-                        raster_binned_ok(F, H, W) && (binned_env < 0 ? kBinnedDefault : binned_env != 0);
+                        raster_binned_ok(F, H, W) && raster_binned_wanted(kBinnedDefault);
     BinArgs ba;
     memset(&ba, 0, sizeof(ba));
     if (binned) {

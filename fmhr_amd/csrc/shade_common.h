@@ -142,11 +142,14 @@ struct RasterFused {
 // ---- binned rasterizer (raster.hip): a bin = one 64-pixel row segment of the flattened [n, H, W] index = the wave that resolves it.
 // Its entries are 16 B per fragment: (face | large-box flag << 22 | pixel-in-segment << 26, z/w bits, u bits, v bits); 0xFFFFFFFF in
 // the first word = a reserved slot whose fragment turned out degenerate.
-inline int bin_cap_entries()                                  // entries per bin (default 1024: 16 fragments per pixel on average)
+inline int bin_cap_entries(int requested)                     // entries per bin: fmhr_ham_dims.bin_cap, 0 = 1024 (16 fragments per pixel on average)
 {
-    const char* e = getenv("FMHR_BIN_CAP");
-    const int c = e ? atoi(e) : 1024;
-    return c < 64 ? 64 : c;
+    return requested <= 0 ? 1024 : (requested < 64 ? 64 : requested);
+}
+inline bool raster_binned_wanted(bool dflt)                   // FMHR_RASTER_BINNED=0 / 1 overrides the default (same-library A/B; read per call)
+{
+    const char* e = getenv("FMHR_RASTER_BINNED");
+    return e ? atoi(e) != 0 : dflt;
 }
 constexpr int kBinChunk = 256;                                // entries a wave stages in LDS per round (8-bit entry index in the LDS key)
 #ifndef FMHR_CURSOR_STRIDE

@@ -27,7 +27,7 @@ class HamStage2:
 
     faces: int32 [F,3] on the GPU.  `n_global` = number of views in the whole batch (== n unless views are sharded)."""
 
-    def __init__(self, faces, V, n, H, W, weights, edge_len_mean, n_global=None, aa_cap=None):
+    def __init__(self, faces, V, n, H, W, weights, edge_len_mean, n_global=None, aa_cap=None, bin_cap=0):
         if not faces.is_cuda or faces.dtype != torch.int32:
             raise RuntimeError("HamStage2: faces must be an int32 GPU tensor")
         self.lib = _lib.load()
@@ -62,7 +62,8 @@ class HamStage2:
         call("fmhr_corner_slots_build", ptr(self.vf_idx), self.F, ptr(self.corner_slot), st)
         # antialias work items: only pairs that blend are listed (∝ silhouette length); 1/4 of the pixels is a generous bound
         cap = int(aa_cap or max(2048 * 256, self.n * self.H * self.W // 4))     # 768 or 1280 regions (one per workgroup of the AA kernels) of >= 409 items
-        self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap)
+        # bin_cap: entries per fragment bin of the binned rasterizer (0 = the default 1024 = 16 fragments per pixel of a 64-pixel segment)
+        self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap, int(bin_cap))
         self.ws_bytes = self.lib.fmhr_ham_workspace_bytes(ctypes.byref(self.dims))
         if self.ws_bytes == 0:
             raise RuntimeError("fmhr_ham_workspace_bytes failed: " + self.lib.fmhr_last_error().decode())
@@ -81,12 +82,9 @@ class HamStage2:
         self.gdelta_rest = self.bucket[2 * V3: 3 * V3].view(self.V, 3)
         self.galbedo_rest = self.bucket[3 * V3: 4 * V3].view(self.V, 3)
         self.losses = self.bucket[4 * V3:]
-        # which rasterizer form fmhr_ham_forward takes for these dims (raster.hip: rasterize_fwd_impl): per-segment fragment bins where
-        # the mesh is a micro-triangle one and W % 64 == 0 (FMHR_RASTER_BINNED=0 / 1 overrides), else global depth keys + resolve pass
-        import os as _os
-        ok = self.W % 64 == 0 and self.F < (1 << 22) and self.H * self.W <= 16 * self.F
-        env = _os.environ.get("FMHR_RASTER_BINNED")
-        self.binned = bool(ok and (env is None or int(env) != 0))
+        # which rasterizer fmhr_ham_forward takes for these dims: per-segment fragment bins resolved in LDS where the mesh is a
+        # micro-triangle one and W % 64 == 0 (FMHR_RASTER_BINNED=0 switches them off), else global depth keys + resolve pass
+        self.binned = self.lib.fmhr_ham_rasterizer_form(ctypes.byref(self.dims)) == 1
         self._views = None
         self._aa_flag = None
         self._vm_key, self._vm_ref = None, None
@@ -215,8 +213,8 @@ class HamStage2:
 
     def raster_overflowed(self):
         """True if a fragment bin of the binned rasterizer was full in ANY step since the workspace was initialised (sticky; one device
-        -> host copy): some fragments were dropped — construct the workspace with a larger FMHR_BIN_CAP (entries per 64-pixel
-        segment, default 1024 = 16 fragments per pixel)."""
+        -> host copy): some fragments were dropped — construct HamStage2 with a larger `bin_cap` (entries per 64-pixel segment,
+        default 1024 = 16 fragments per pixel)."""
         if self._aa_flag is None:
             self.aa_overflowed()
         return int(self._aa_flag_all[2]) != 0
@@ -226,8 +224,8 @@ class HamStage2:
         list is reported: the step never synchronises on its own, so the flag is checked when the caller reads results anyway."""
         vals = self.losses.tolist()
         if self.raster_overflowed():
-            raise RuntimeError("HamStage2: a fragment bin of the rasterizer overflowed (more than FMHR_BIN_CAP fragments in one 64-pixel "
-                               "segment): fragments were dropped; set FMHR_BIN_CAP higher (default 1024) or FMHR_RASTER_BINNED=0")
+            raise RuntimeError(f"HamStage2: a fragment bin of the rasterizer overflowed (more than {self.dims.bin_cap or 1024} fragments "
+                               "in one 64-pixel segment): fragments were dropped; construct HamStage2 with a larger bin_cap")
         if self.aa_overflowed():
             raise RuntimeError(f"HamStage2: the antialias work-item list overflowed (aa_cap={self.dims.aa_cap}): some silhouette pairs "
                                "got no gradient in the last step; construct HamStage2 with a larger aa_cap")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMHR_ABI_VERSION 3
+#define FMHR_ABI_VERSION 4
 #define FMHR_OK 0
 #define FMHR_E_ARG (-1)   /* bad shape / null pointer / workspace too small */
 #define FMHR_E_HIP (-2)   /* HIP runtime error (message has hipGetErrorString) */
@@ -148,6 +148,10 @@ typedef struct fmhr_ham_dims {
     int32_t nnz;                /* adjacency nnz (row_ptr[V]) */
     int32_t aa_cap;             /* capacity of the antialias work-item list (pairs that blend, ∝ silhouette length); on overflow
                                    aa_counter[1] of fmhr_ham_views is set and the excess pairs get no gradient */
+    int32_t bin_cap;            /* ABI 4: entries per fragment bin of the binned rasterizer (one bin per 64-pixel segment, 16 B per
+                                   entry; 0 = the default 1024 = 16 fragments per pixel).  Part of the workspace layout: the SAME
+                                   value must be passed to every call on a workspace.  A full bin sets aa_counter[2] (sticky) and
+                                   drops the excess fragments */
 } fmhr_ham_dims;
 
 typedef struct fmhr_ham_weights {
@@ -175,6 +179,10 @@ typedef struct fmhr_ham_weights {
 #define FMHR_LOSS_NVALID 7
 
 size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
+/* ABI 4: which rasterizer fmhr_ham_forward takes for these dims: 1 = per-segment fragment bins resolved in LDS (micro-triangle mesh:
+ * H*W <= 16 F, W % 64 == 0, F < 2^22; the environment variable FMHR_RASTER_BINNED=0 switches it off for A/B runs), 0 = global
+ * atomicMin depth keys + resolve pass (everything else, and the stand-alone dr.rasterize op: nvdiffrast mesh_sfs_optim.py:267). */
+int fmhr_ham_rasterizer_form(const fmhr_ham_dims* d);
 
 /* Phase A: geometry + rasterize + shade + antialias (forward up to the AA images) and the local valid-pixel count.
  * Phase B: losses + the whole backward.

@@ -26,12 +26,12 @@ def test_header_and_library_agree(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     exported = set(re.findall(r" T (fmhr_[a-z_0-9]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.fmhr_abi_version() == 3
+    assert lib.fmhr_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
     from fmhr_amd._lib import HamDims, HamWeights, HamViews
-    assert ctypes.sizeof(HamDims) == 28 and ctypes.sizeof(HamWeights) == 44 and ctypes.sizeof(HamViews) == 48
+    assert ctypes.sizeof(HamDims) == 32 and ctypes.sizeof(HamWeights) == 44 and ctypes.sizeof(HamViews) == 48
     from fmhr_amd._lib import AdamParam
     assert ctypes.sizeof(AdamParam) == 48
     from fmhr_amd._lib import Stage1Plan
@@ -46,9 +46,9 @@ def test_argument_errors_without_gpu(lib):
     assert lib.fmhr_interpolate_fwd(None, None, None, 2, 3, 3, 1, 8, 8, 4, None, None) == -1
     assert b"attr batch" in lib.fmhr_last_error()
     assert lib.fmhr_laplacian_uniform_fwd(None, None, None, 10, 5, 1.0, None, None, None) == -1
-    bad = HamDims(0, 10, 10, 8, 8, 0, 16)
+    bad = HamDims(0, 10, 10, 8, 8, 0, 16, 0)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(bad)) == 0
-    ok = HamDims(2, 100, 180, 64, 48, 0, 4096)
+    ok = HamDims(2, 100, 180, 64, 48, 0, 4096, 0)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(ok)) > 2 * 64 * 48 * 16
     assert lib.fmhr_rasterize_workspace_bytes(2, 7, 10, 8, 8) == 2 * 64 * 8 + 16 + 2 * 10 * 8 + 2 * 7 * 8
     # fmhr_ham_densify re-shades / recomputes the views the step does not store: it needs the last forward's tri and sh

@@ -591,8 +591,9 @@ def test_fragment_bin_overflow_is_reported(oracle, monkeypatch):
     dev = torch.device("cuda:0")
     g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
     monkeypatch.setenv("FMHR_RASTER_BINNED", "1")
-    monkeypatch.setenv("FMHR_BIN_CAP", "64")                 # one fragment per pixel: every doubly covered segment overflows
-    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    # 64 entries per bin = one fragment per pixel: every doubly covered segment overflows
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"], bin_cap=64)
+    assert hs.binned
     hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
     with pytest.raises(RuntimeError, match="fragment bin"):
         hs.loss_dict()
