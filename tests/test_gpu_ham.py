@@ -619,3 +619,46 @@ def test_two_hand_sub3_mesh_at_the_sequence_resolution(oracle):
     sc["elm"] = float(edge_length_mean(sc["vertices"].to(dev), faces))
     ld, v = _step_vs_oracle(oracle, sc, "two_hands_sub3_2x512x334")
     assert ld["n_valid"] > 0.1 * n * H * W
+
+
+@pytest.mark.parametrize("variant", ["shuffled_faces", "two_large_triangles"])
+def test_binned_rasterizer_rare_paths(oracle, variant, monkeypatch):
+    """The binned rasterizer's slow paths against the atomic-key form AND the oracle: (a) faces in random order — the 256 faces of a
+    workgroup are scattered over the image, their segments collide in the workgroup's direct-mapped LDS table and the fragments go
+    through the per-wave run reservation (`bin_append`); (b) a micro-triangle mesh with two large triangles added — swept by their
+    wave, entries flagged large-box, pixels threaded onto the face's list for the backward."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (4, 192, 192, 64, 96), 2)           # the mesh of the "micro" case, four views (one looks into the wrist)
+    rng = np.random.default_rng(7)
+    f = sc["faces"].clone()
+    if variant == "shuffled_faces":
+        f = f[torch.from_numpy(rng.permutation(f.shape[0]))].contiguous()
+    else:
+        V = sc["V"]
+        ring = lambda r, s: 1 + r * 96 + s                               # blob_mesh vertex numbering: pole 0, then rings x segments
+        # two large triangles that cap the open wrist (rim = the last ring): in front of everything for a camera below the hand
+        big = torch.tensor([[ring(63, 0), ring(63, 32), ring(63, 64)], [ring(63, 0), ring(63, 64), ring(63, 80)]], dtype=torch.int32)
+        assert int(big.max()) < V
+        f = torch.cat([f, big]).contiguous()
+    sc = dict(sc, faces=f, F=f.shape[0])
+    sc["elm"] = float(oracle.edge_length_mean(sc["vertices"], f))
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    args = (g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FMHR_RASTER_BINNED", mode)
+        hs = HamStage2(f.to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+        assert hs.binned == (mode == "1")
+        hs.step(*args)
+        hs.step(*args)
+        v = hs.views()
+        out[mode] = dict(rast=v["rast"].clone(), img=v["tmp_img"].clone(), gd=hs.gdelta.clone(), ga=hs.galbedo.clone(), ld=hs.loss_dict())
+    a, b = out["1"], out["0"]
+    assert torch.equal(a["rast"], b["rast"]) and torch.equal(a["img"], b["img"])
+    assert rel_err(a["gd"], b["gd"]) < 5e-5 and rel_err(a["ga"], b["ga"]) < 1e-6
+    monkeypatch.setenv("FMHR_RASTER_BINNED", "1")
+    _step_vs_oracle(oracle, sc, "binned_" + variant)                     # bit-identical rast vs the fp32 oracle, values vs fp64
+    if variant == "two_large_triangles":
+        ids = a["rast"][..., 3]
+        assert int((ids == sc["F"]).sum() + (ids == sc["F"] - 1).sum()) > 100      # the large triangles own pixels
