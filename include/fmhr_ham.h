@@ -204,7 +204,7 @@ int fmhr_ham_rasterizer_form(const fmhr_ham_dims* d);
  *     caller lays [gdelta | galbedo | gdelta_rest | galbedo_rest | losses] out as ONE bucket of 12V+8 floats, all-reduces it (SUM)
  *     once and calls fmhr_ham_combine. */
 /* Must be called once on a fresh workspace (and after any aborted step): sets up the self-cleaning state (depth keys, dirty
- * flags, antialias-backward vertex accumulator) that every completed forward+backward pair leaves clean again. */
+ * flags, fragment-bin cursors, antialias-backward vertex accumulator) that every completed forward+backward pair leaves clean again. */
 int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);
 int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
                      const float* sh, const float* w2c, const float* proj, const float* mask, const float* valid_mask,
