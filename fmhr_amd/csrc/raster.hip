@@ -760,25 +760,29 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
 }
 
 // ---- binned rasterizer, second pass: one wave per 64-pixel segment = per bin (the resolve pass's shape: no workgroup barrier, an
-// empty segment costs one scalar load).  The bin is staged in the wave's LDS kBinChunk entries at a time (coalesced 16-B loads, four
+// empty segment costs one scalar load).  The bin is staged in the wave's LDS kBinChunk entries at a time (coalesced 16-B loads, two
 // in flight per lane); every entry posts ds_min_u64 on its pixel's LDS key = (monotone(z/w) << 32 | face << 8 | entry index):
 // nearest fragment, ties to the lowest face index — rule R6, the order of the global atomicMin it replaces — and the pixel's lane
 // reads the winner's entry back from the staged chunk.  No vertex gathers, no clip positions, no second fragment evaluation: the
 // epilogue is the resolve pass's shading + per-pixel word + owner mark + segment words.
 typedef const int __attribute__((address_space(4))) const_as4_int;
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef FMHR_BINS_BLOCK
+#define FMHR_BINS_BLOCK 256
+#endif
+constexpr int kBinsBlock = FMHR_BINS_BLOCK;      // threads per workgroup of k_raster_bins (a wave is independent of its workgroup)
+__global__ void __launch_bounds__(kBinsBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, const BinArgs ba, unsigned long long* __restrict__ covw,
               int* __restrict__ large_cnt, const RasterFused fu)
 {
-    __shared__ unsigned long long lkey_all[kBlock];
-    __shared__ uint4 chunk_all[(kBlock / 64) * kBinChunk];
+    __shared__ unsigned long long lkey_all[kBinsBlock];
+    __shared__ uint4 chunk_all[(kBinsBlock / 64) * kBinChunk];
     static_assert(kBinChunk % 64 == 0 && kBinChunk <= 256, "8-bit entry index in the LDS key");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned long long* const lkey = lkey_all + wv * 64;             // this wave's pixels
     uint4* const chunk = chunk_all + wv * kBinChunk;
-    const long long gid = (long long)blockIdx.x * kBlock + tid;
-    const long long seg = (long long)blockIdx.x * (kBlock / 64) + wv;
+    const long long gid = (long long)blockIdx.x * kBinsBlock + tid;
+    const long long seg = (long long)blockIdx.x * (kBinsBlock / 64) + wv;
     if (gid == 0) {                                                  // rearm the list cursors of the kernels after this one (as the resolve pass does)
         large_cnt[1] = large_cnt[0];
         large_cnt[0] = 0;
@@ -1168,7 +1172,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     }
     if (binned) {
         ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-        k_raster_bins<<<cdiv((long long)nP, kBlock), kBlock, 0, st>>>(tri, n, F, H, W, ba, covw, large_cnt, fu);
+        k_raster_bins<<<cdiv((long long)nP, kBinsBlock), kBinsBlock, 0, st>>>(tri, n, F, H, W, ba, covw, large_cnt, fu);
         FMHR_CHECK_LAUNCH("k_raster_bins");
         return FMHR_OK;
     }

@@ -586,11 +586,14 @@ def test_binned_rasterizer_equals_the_atomic_key_form(oracle, dims, monkeypatch)
         for _ in range(3):                                   # the bins are self-cleaning: the third step must equal the first
             hs.step(*args)
         v = hs.views()
-        out[mode] = dict(rast=v["rast"].clone(), img=v["tmp_img"].clone(), pm=v["pred_mask"].clone(), gd=hs.gdelta.clone(),
-                         ga=hs.galbedo.clone(), ld=hs.loss_dict())
+        out[mode] = dict(rast=v["rast"].clone(), img=v["tmp_img"].clone(), pm=v["pred_mask"].clone(), pre=v["tmp_img_pre_aa"].clone(),
+                         gd=hs.gdelta.clone(), ga=hs.galbedo.clone(), ld=hs.loss_dict())
     a, b = out["1"], out["0"]
     assert float((a["rast"][..., 3] > 0).float().mean()) > 0.05
-    assert torch.equal(a["rast"], b["rast"]) and torch.equal(a["img"], b["img"]) and torch.equal(a["pm"], b["pm"])
+    # bit-identical: the rasterizer image and the shaded image before antialias; the antialiased images add their blends with float
+    # atomics (a pixel that receives two blends sums them in either order: one ulp between ANY two runs)
+    assert torch.equal(a["rast"], b["rast"]) and torch.equal(a["pre"], b["pre"])
+    assert float((a["img"] - b["img"]).abs().max()) <= 1e-6 and float((a["pm"] - b["pm"]).abs().max()) <= 1e-6
     assert a["ld"]["n_valid"] == b["ld"]["n_valid"] and abs(a["ld"]["total"] - b["ld"]["total"]) <= 1e-6 * abs(b["ld"]["total"])
     assert rel_err(a["gd"], b["gd"]) < 5e-5 and rel_err(a["ga"], b["ga"]) < 1e-6      # antialias-backward atomics order only
 
@@ -664,9 +667,11 @@ def test_binned_rasterizer_rare_paths(oracle, variant, monkeypatch):
         hs.step(*args)
         hs.step(*args)
         v = hs.views()
-        out[mode] = dict(rast=v["rast"].clone(), img=v["tmp_img"].clone(), gd=hs.gdelta.clone(), ga=hs.galbedo.clone(), ld=hs.loss_dict())
+        out[mode] = dict(rast=v["rast"].clone(), img=v["tmp_img"].clone(), pre=v["tmp_img_pre_aa"].clone(), gd=hs.gdelta.clone(),
+                         ga=hs.galbedo.clone(), ld=hs.loss_dict())
     a, b = out["1"], out["0"]
-    assert torch.equal(a["rast"], b["rast"]) and torch.equal(a["img"], b["img"])
+    assert torch.equal(a["rast"], b["rast"]) and torch.equal(a["pre"], b["pre"])
+    assert float((a["img"] - b["img"]).abs().max()) <= 1e-6               # (float-atomic blend order: see the test above)
     assert rel_err(a["gd"], b["gd"]) < 5e-5 and rel_err(a["ga"], b["ga"]) < 1e-6
     monkeypatch.setenv("FMHR_RASTER_BINNED", "1")
     _step_vs_oracle(oracle, sc, "binned_" + variant)                     # bit-identical rast vs the fp32 oracle, values vs fp64
