@@ -363,7 +363,14 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed)
-    dom_ms = sum(tk.ms(j, dom) for j in range(len(sampled))) / len(sampled)
+    dom_ms_raw = sum(tk.ms(j, dom) for j in range(len(sampled))) / len(sampled)
+    # an event pair with NOTHING between its two records already reads ~4.7 us (the launch groups that are empty on this workload —
+    # raster_clear, raster_large, transform_bwd, normals_bwd — show exactly that in the profiling pass): the dispatch gaps on either
+    # side of a kernel, which rocprofv3's kernel durations do not contain.  It is measured in this run and taken off, so that the
+    # launch duration agrees with the committed rocprofv3 summary
+    empty = sorted(kernels[s_] for s_ in ("raster_clear", "raster_large", "transform_bwd", "normals_bwd") if kernels[s_] < 0.008)
+    ev_overhead = empty[len(empty) // 2] if empty else 0.0
+    dom_ms = max(dom_ms_raw - ev_overhead, 1e-6)
     step_dev_ms = sum(ev0[j].elapsed_time(ev1[j]) for j in range(len(sampled))) / len(sampled)
     # a full antialias work-item list (some silhouette pairs without a gradient) invalidates the run — on EVERY rank
     ovf = torch.tensor([1.0 if any(p.hs.aa_overflowed() or p.hs.raster_overflowed() for p in problems) else 0.0], device=dev)
@@ -413,7 +420,8 @@ def main():
                          "traffic_gbs": ((traffic or {}).get(SLOTS[dom]) or 0) / (dom_ms * 1e-3) / 1e9 or None,
                          "traffic_frac": ((traffic or {}).get(SLOTS[dom]) or 0) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS or None,
                          "traffic_source": (traffic or {}).get("_source"), "alg_bytes_per_launch": dom_bytes,
-                         "avg_launch_ms": dom_ms, "event_samples": len(sampled)},
+                         "avg_launch_ms": dom_ms, "avg_launch_ms_raw_events": dom_ms_raw, "event_pair_overhead_ms": ev_overhead,
+                         "event_samples": len(sampled)},
             "step_roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "device_ms_per_step": step_dev_ms,
                               # physical: measured HBM bytes of the step (PMC profile; FETCH_SIZE x1 .. x2 + WRITE_SIZE) per device time
                               "traffic_low_high": [t_lo, t_hi] if traffic else None,
