@@ -678,3 +678,39 @@ def test_binned_rasterizer_rare_paths(oracle, variant, monkeypatch):
     if variant == "two_large_triangles":
         ids = a["rast"][..., 3]
         assert int((ids == sc["F"]).sum() + (ids == sc["F"] - 1).sum()) > 100      # the large triangles own pixels
+
+
+@pytest.mark.parametrize("dims", [(3, 192, 192, 64, 96), (3, 96, 80, 24, 32)], ids=["binned", "atomic"])
+def test_workspace_state_after_a_long_optimisation(oracle, dims):
+    """Everything the step keeps between calls cleans itself (depth keys / fragment-bin cursors, owner marks, coverage entries,
+    segment words, antialias lists, accumulator replicas): after 700 optimiser steps on ONE workspace — past the 256-step period of
+    the owner marks and their 128-step wipe — a step at the final parameters must equal the same step on a fresh workspace."""
+    from fmhr_amd.ham import HamStage2
+    from fmhr_amd.optim import Adam
+    sc = prepare(oracle, dims, 61)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    assert hs.binned == (dims[1] == 192)
+    delta = g["delta"].clone().requires_grad_(True)
+    albedo = g["albedo"][None].clone().requires_grad_(True)
+    opt = Adam([{'params': delta, 'lr': 1e-4}, {'params': albedo, 'lr': 5e-3}])
+    rest = (g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    first = None
+    for it in range(700):
+        losses, _, _ = hs.step(g["vertices"], delta.detach(), albedo.detach()[0], *rest, optimizer=opt, params=(delta, albedo))
+        if it == 0:
+            first = float(losses[6])
+    ld = hs.loss_dict()                                      # raises on an antialias-list / fragment-bin overflow
+    assert np.isfinite(ld["total"]) and ld["total"] < first  # it optimises
+    d_fin, a_fin = delta.detach().clone(), albedo.detach()[0].clone()
+    hs.step(g["vertices"], d_fin, a_fin, *rest)
+    l_old, gd_old, ga_old = hs.losses.clone(), hs.gdelta.clone(), hs.galbedo.clone()
+    r_old = hs.views()["rast"].clone()
+    fresh = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    fresh.step(g["vertices"], d_fin, a_fin, *rest)
+    assert torch.equal(fresh.views()["rast"], r_old)
+    assert rel_err(l_old[:7], fresh.losses[:7]) < 1e-6 and float(l_old[7]) == float(fresh.losses[7])
+    e = (rel_err(gd_old, fresh.gdelta), rel_err(ga_old, fresh.galbedo))
+    log_parity("step 701 on one workspace vs a fresh workspace (%s rasterizer): gdelta %.1e galbedo %.1e" % ("binned" if hs.binned else "atomic", *e))
+    assert e[0] < 5e-5 and e[1] < 5e-5, e
