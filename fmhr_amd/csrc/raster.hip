@@ -109,10 +109,11 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
 // shading epilogue on the winners straight from the staged entries: the 8-B-per-pixel global key buffer (100 MB at the metric), its
 // 2 M atomicMin line requests, its read-back + reset and the dirty-segment flags are gone, and the winner's (u, v, z/w) are the
 // triangle kernel's own values instead of a second evaluation behind three more vertex gathers.
-// Slots are reserved per WORKGROUP: the fragments of a workgroup's 256 consecutive faces fall into a few dozen segments; an LDS hash
-// table (segment -> count) gives every fragment its rank inside (workgroup, segment) with one ds_cmpst + one ds_add_rtn, then ONE
-// returning global atomic per table entry reserves the run — all of them in one instruction, in flight while the workgroup
-// evaluates its fragments (a returning atomic per wave and round, waited for on the spot, cost 120 -> 280 us).
+// Slots are reserved per WORKGROUP: the fragments of a workgroup's 256 consecutive faces fall into a few dozen segments; a direct-
+// mapped LDS table (segment -> count; rows mod 64 x two column segments) gives every fragment its rank inside (workgroup, segment)
+// with one ds_cmpst + one ds_add_rtn, then ONE returning global atomic per table entry reserves the run — all of them in one
+// instruction, in flight while the workgroup evaluates its fragments (a returning atomic per wave and round, waited for on the spot,
+// cost 124 us; with the cursors packed 16 per cache line 280 us).
 struct BinArgs { uint4* bins; int* cursor; int* flag; int cap; int segsX; int segsPerView; };
 constexpr int kHash = 128;                       // LDS table slots per workgroup round (a round has at most 512 fragments)
 constexpr unsigned kBinInvalid = 0xFFFFFFFFu;    // first word of a reserved entry whose fragment was degenerate
@@ -351,6 +352,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     if (BIN) {
         // ---- binned form: tasks -> (table slot, rank) -> one reservation per (workgroup, segment) -> entries
         constexpr int kCap = kTaskCap / 2;                           // 32-bit task entries: bit | lane << 5 | slot << 13 | rank << 21
+        static_assert(kTrisBlock == 256 && kHash <= kTrisBlock && kCap <= 2048, "8-bit lane, 8-bit slot and 11-bit rank fields of a task");
         const int segsX = ba.segsX;
         auto decode = [&](unsigned e, int& o, int& px, int& py) {
             o = (int)(e >> 5) & 255;
