@@ -69,7 +69,10 @@ CASES = [("C1", (1, 256, 256, 24, 32), 0), ("C2x3", (3, 512, 334, 24, 32), 1), (
          # BASELINE.json configs[4] in small: TWO hands = two connected components with a boundary loop each, subdivided per hand and
          # concatenated as mesh_sfs_optim.py:76-87 does, W = 334 (conf/ih_sfsseq.conf:11), more than 48 views (two view groups)
          ("two_hands50", (50, 128, 334, 10, 14, 1, 2), 9),
-         ("two_hands_mano", (3, 512, 334, "mano", 0, 1, 2), 10)]
+         ("two_hands_mano", (3, 512, 334, "mano", 0, 1, 2), 10),
+         # BASELINE.json configs[0]: ONE view, 256 x 256, the 778-vertex / 1538-face base mesh, silhouette-only loss (every other
+         # weight 0: the gradient reaches the vertices through the antialias of the mask alone)
+         ("silhouette_only_C1", (1, 256, 256, "mano", 0, 0), 13)]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
@@ -77,6 +80,9 @@ def test_fused_step_vs_oracle(oracle, case):
     from fmhr_amd.ham import HamStage2, LOSS_NAMES
     name, dims, seed = case
     sc = prepare(oracle, dims, seed)
+    if name.startswith("silhouette_only"):
+        sc["weights"] = dict(sfs=0.0, lap=0.0, albedo=0.0, mask=1000.0, edge=0.0, delta=0.0)
+        sc["delta"] = sc["delta"] * 10.0                     # move the contour off the start silhouette: a non-zero MSE
     dev = torch.device("cuda:0")
     g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
     hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
