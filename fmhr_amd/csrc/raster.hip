@@ -807,7 +807,11 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, const
     const int step_tag = fu.stamp[0];
     const int cnt = min(count, ba.cap);
     const uint4* __restrict__ bin = ba.bins + (size_t)seg * ba.cap;
-    if (lane == 0) *cur = 0;                                         // self-cleaning
+    // self-cleaning.  NOTE the reset store stays behind the `count == 0` exit above on purpose: the count comes through the scalar cache
+    // (a load from the constant address space: the compiler may move a store across it, and the hardware does not order scalar loads
+    // against vector stores).  A variant that no longer branched on the count before this store read its own zero now and then:
+    // half of the segments came out empty, a different half in every step (round 3, packed non-empty flags experiment)
+    if (lane == 0) *cur = 0;
     lkey[lane] = ~0ull;
     unsigned long long best = ~0ull;
     uint4 win = make_uint4(0u, 0u, 0u, 0u);
