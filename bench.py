@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--preroll", type=int, default=320, help="upper bound of the untimed pre-roll (stops earlier once the antialias "
                     "work list is stationary; at least 128 steps; 0 = none)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--frame-streams", type=int, default=int(os.environ.get("FMHR_FRAME_STREAMS", "2")),
+                    help="HIP streams the local frames of a sequence capture are spread over (independent problems: their kernels may "
+                         "overlap: C5 on one GPU 364 -> 392 it/s with 2, 377 with 4); 1 = one after the other on the current stream")
     args = ap.parse_args()
 
     rank, world, local = fdist.init_from_env()
@@ -211,7 +214,7 @@ def main():
     n_total, H, W, V, F = scene["views"], scene["H"], scene["W"], scene["V"], scene["F"]
     # partition: the views of ONE problem over the ranks (metric, C1-C4), or — a sequence capture (C5: 8 frames x 32 views, every
     # frame an independent (delta, albedo) problem on the shared topology) — frames first, then views (fmhr_amd.dist.shard_frames_views)
-    n_frames = int(scene.get("frames", 1))
+    n_frames = int(os.environ.get("FMHR_DUP_FRAMES", scene.get("frames", 1)))       # FMHR_DUP_FRAMES: experiments only
     if n_frames > 1:
         part = fdist.shard_frames_views(n_frames, n_total, rank, world)
         fgroups = fdist.frame_groups(n_frames, world) if world > 1 else [None] * n_frames
@@ -264,9 +267,23 @@ def main():
                                           problems[0].group)
     nf_local = len(problems)
 
+    n_fs = max(1, min(args.frame_streams, nf_local))
+    fstreams = [torch.cuda.Stream(device=dev) for _ in range(n_fs)] if n_fs > 1 else []
+
     def step():
-        for p in problems:                     # the local frames one after the other (one frame: the plain stage-2 iteration)
-            losses = p.step()
+        if not fstreams:
+            for p in problems:                 # the local frames one after the other (one frame: the plain stage-2 iteration)
+                losses = p.step()
+            return losses
+        # independent frames on side streams, forked from and joined to the current stream
+        cur = torch.cuda.current_stream()
+        for s in fstreams:
+            s.wait_stream(cur)
+        for i, p in enumerate(problems):
+            with torch.cuda.stream(fstreams[i % n_fs]):
+                losses = p.step()
+        for s in fstreams:
+            cur.wait_stream(s)
         return losses
 
     def step_parts():
@@ -412,7 +429,7 @@ def main():
                                    f"({'MANO sub3 counts' if V % 49281 == 0 else 'MANO base counts' if V % 778 == 0 else 'custom'}"
                                    f"{', two hands' if scene.get('hands', 1) == 2 else ''}), "
                                    f"stage-2 step = render + 6 losses + backward + grad all-reduce + Adam, stationary (pre-rolled {preroll} steps)",
-                       "views": n_total, "views_per_gpu": n, "frames": n_frames, "frames_per_gpu": nf_local, "H": H, "W": W, "V": V, "F": F,
+                       "views": n_total, "views_per_gpu": n, "frames": n_frames, "frames_per_gpu": nf_local, "frame_streams": n_fs, "H": H, "W": W, "V": V, "F": F,
                        "rasterizer": "binned (per-segment LDS bins)" if hs.binned else "atomic depth keys + resolve",
                        "coverage": round(tg["coverage"], 4), "parallelism": (f"views sharded over {world} GPU(s)" if n_frames == 1 else
                                                                         f"{n_frames} frames x {n_total} views: frames first, then views, over {world} GPU(s)"),
