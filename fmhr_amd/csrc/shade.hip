@@ -229,6 +229,7 @@ __device__ __forceinline__ float group_sum(float x)
 struct int3a { int x, y, z; };
 
 struct FaceAttr { float3 n2, dn0, dn1, a2, da0, da1, v0, v1, v2; };    // corner-2-relative attributes + the three vertex positions
+static_assert(sizeof(FaceAttr) == 27 * sizeof(float), "k_face_bwd fills the record float by float");
 
 // backward of ONE pixel of a face for all three corners; A[k] += (g_normal.xyz, g_albedo.xyz, g_vertex.xyz) of corner k.
 // c = the view's 9 SH coefficients followed by its clip matrix rows (view_c layout).
@@ -305,7 +306,13 @@ constexpr int kTaskG = 64;                       // candidate pixels a group exp
 #endif
 constexpr int kFbBlock = FMHR_FB_BLOCK;          // threads per workgroup of k_face_bwd
 constexpr int kFacesPerBlock = kFbBlock / kGroup;
-constexpr int kMaxVPL = 6;                       // views per lane: a group of kGroup lanes covers kGroup * VPL views of one face
+// 48 views: 6 views per lane (one 48-view group) ran 75 .. 135 us from PROCESS to process on one box — a wave then gathers from 48
+// views' pixel arrays at once, 4 MB apart each — 4 views per lane (a 32-view and a 16-view group, the launch ordered group by group)
+// 72 .. 88 us: 2 497 [2 397 .. 2 651] -> 2 651 [2 626 .. 2 676] it/s over 8 alternating runs each; 3 (24 + 24): 2 575; 2: 2 553; 5: 2 564
+#ifndef FMHR_MAX_VPL
+#define FMHR_MAX_VPL 4
+#endif
+constexpr int kMaxVPL = FMHR_MAX_VPL;                       // views per lane: a group of kGroup lanes covers kGroup * VPL views of one face
 
 // VPL views per lane: the fixed part of a (face, view group) — vertex ids, attributes, output slots, the DPP sum, the output
 // store, the launch — is paid once per kGroup * VPL views, and the partial planes the mesh tail has to add up shrink with it.
@@ -329,15 +336,6 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     const int tid = threadIdx.x, j = tid & (kGroup - 1), gl = tid / kGroup, lane = tid & 63;
     const int f = blockIdx.x * kFacesPerBlock + gl;
     const int g = blockIdx.y, b0 = g * GV;                         // view of (lane j, slot v) = b0 + v * kGroup + j
-    for (int i = tid; i < GV * 28; i += kFbBlock) {
-        const int vb = i / 28, k = i - vb * 28, bb = b0 + vb;
-        float v = 0.f;
-        // columns (x, y, w, z) of the view's combined matrix rows: the kernel only uses the first three of each row
-        if (bb < n) v = (k < 9) ? sh[(size_t)bb * 9 + k]
-                                : ((k < 25) ? reinterpret_cast<const float*>(cmat)[(size_t)bb * 16 + ((k - 9) & ~3) + (((k - 9) & 3) == 2 ? 3 : (((k - 9) & 3) == 3 ? 2 : ((k - 9) & 3)))] : 0.f);
-        view_c[vb][k] = v;
-    }
-    __syncthreads();                                               // the only workgroup barrier: everything below is per wave
     const bool facelive = f < F;                                   // uniform over a group
     // ---- the coverage entries of this lane's (face, view)s; entries of other steps carry another stamp
     const unsigned cur = (unsigned)stamp[0] & 0xFFFFFFu;           // advanced once per step by the geometry kernel
@@ -351,10 +349,10 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     // everything whose address is known up front is requested together (the kernel's time is #waves / wave slots x the length of
     // a wave's dependent-load chain): the owner marks, the entries, the face's vertex ids, the output slot
     int3a ti = {0, 0, 0};
-    int es = 0;
+    unsigned es = 0u;                                              // (unsigned: as an int its sign extension sat right behind the load, with a wait)
     if (facelive) {
         ti = *reinterpret_cast<const int3a*>(tri + (size_t)f * 3);
-        if (j < 3) es = corner_slot[f * 3 + j];
+        if (j < 3) es = (unsigned)corner_slot[f * 3 + j];
     }
     // kind: 0 nothing, 1..32 box width of a candidate mask, 255 pixel list.  Triangles that own no pixel this step (off screen, no
     // pixel centre, hidden: 2/3 of all) are dropped by the owner mark of the resolve pass; a stale mark only costs candidate checks.
@@ -388,6 +386,32 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             e[v] = cov16[(size_t)b * F + f];
         }
     }
+    // the per-view constants are staged while those requests are in flight (filled first, the fill's own round trip and the
+    // barrier came before the first entry request of every wave)
+    // (one unconditional load per element from a clamped address, all of a thread's loads issued before its first LDS store: as a
+    // plain loop with the source picked by branches every one of its six iterations waited for its own load)
+    {
+        constexpr int IT = (GV * 28 + kFbBlock - 1) / kFbBlock;
+        const float* const cmf = reinterpret_cast<const float*>(cmat);
+        float vals[IT];
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int i = min(tid + it * kFbBlock, GV * 28 - 1);
+            const int vb = i / 28, k = i - vb * 28, bb = min(b0 + vb, n - 1);
+            // columns (x, y, w, z) of the view's combined matrix rows: the kernel only uses the first three of each row
+            const int kk = min(max(k - 9, 0), 15), col = kk & 3;
+            const int pc = (col == 2) ? 3 : ((col == 3) ? 2 : col);
+            const float* src = (k < 9) ? (sh + (size_t)bb * 9 + k) : (cmf + (size_t)bb * 16 + (kk & ~3) + pc);
+            const float v = *src;
+            vals[it] = (b0 + vb < n && k < 25) ? v : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int i = tid + it * kFbBlock;
+            if (i < GV * 28) (&view_c[0][0])[i] = vals[it];
+        }
+    }
+    __syncthreads();                                               // the only workgroup barrier: everything below is per wave
     int kind[VPL], cnt = 0;
     bool anyv = false, has_list = false;
 #pragma unroll
@@ -428,15 +452,14 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         // ---- one memory round trip for the face's attributes (lane 0 of the group) AND the first candidate pixel of every lane:
         //      the attribute loads are issued first, the candidate masks (already here) are expanded into the task list, each lane
         //      requests its first task's pixel word and image gradient, and only then are the attributes parked
-        const bool loader = j == 0 && group_any;
-        float4 q0, q1, u0, u1, w0, w1;
-        float3 vv0, vv1, vv2;
-        if (loader) {
-            q0 = attr8[(size_t)ti.x * 2]; q1 = attr8[(size_t)ti.x * 2 + 1];
-            u0 = attr8[(size_t)ti.y * 2]; u1 = attr8[(size_t)ti.y * 2 + 1];
-            w0 = attr8[(size_t)ti.z * 2]; w1 = attr8[(size_t)ti.z * 2 + 1];
-            vv0 = ld3f(verts + (size_t)ti.x * 3); vv1 = ld3f(verts + (size_t)ti.y * 3); vv2 = ld3f(verts + (size_t)ti.z * 3);
-        }
+        // the face's nine 12- / 16-B pieces are requested by the group's lanes, one or two each: lane j = 2 c + h holds half h of
+        // corner c's packed attributes, lanes 0..2 also a vertex position (all nine in lane 0 were 33 registers of every lane at the
+        // kernel's tightest point: the spill reloads behind them made the wave wait for this round trip before it expanded its tasks)
+        // (unconditional loads — lanes 6 / 7 and groups without an owner repeat a valid piece, a dead face reads vertex 0: under a
+        // condition the merge with a zero default put register copies, and with them a wait, right behind the load)
+        const int cj = j >> 1;
+        const float4 piece = attr8[(size_t)(cj == 0 ? ti.x : (cj == 1 ? ti.y : ti.z)) * 2 + (j & 1)];
+        const float3 vpos = ld3f(verts + (size_t)(j == 0 ? ti.x : (j == 1 ? ti.y : ti.z)) * 3);
 #pragma unroll
         for (int v = 0; v < VPL; v++)
             if (kind[v] != 0) {
@@ -483,16 +506,22 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
             pw = bwd16[gid];
             pgs = g_shaded[gid];
         }
-        if (loader) {
-            pin(q0); pin(q1); pin(u0); pin(u1); pin(w0); pin(w1);
-            FaceAttr fa;
-            fa.n2 = make_float3(w0.x, w0.y, w0.z); fa.a2 = make_float3(w0.w, w1.x, w1.y);
-            fa.dn0 = make_float3(q0.x - fa.n2.x, q0.y - fa.n2.y, q0.z - fa.n2.z);
-            fa.da0 = make_float3(q0.w - fa.a2.x, q1.x - fa.a2.y, q1.y - fa.a2.z);
-            fa.dn1 = make_float3(u0.x - fa.n2.x, u0.y - fa.n2.y, u0.z - fa.n2.z);
-            fa.da1 = make_float3(u0.w - fa.a2.x, u1.x - fa.a2.y, u1.y - fa.a2.z);
-            fa.v0 = vv0; fa.v1 = vv1; fa.v2 = vv2;
-            pk_attr[gl] = fa;
+        {
+            float4 pc = piece;
+            pin(pc);
+            // corner-2-relative attributes: lanes 4 / 5 of the group hold corner 2's halves (same subtractions as before, one per lane)
+            const int srcl = (lane & ~(kGroup - 1)) | 4 | (j & 1);
+            const float4 w = make_float4(__shfl(pc.x, srcl, 64), __shfl(pc.y, srcl, 64), __shfl(pc.z, srcl, 64), __shfl(pc.w, srcl, 64));
+            if (group_any) {
+                float* const fo = reinterpret_cast<float*>(&pk_attr[gl]);   // n2 0, dn0 3, dn1 6, a2 9, da0 12, da1 15, v0 18, v1 21, v2 24
+                if (j < 6) {
+                    const float4 d = (cj == 2) ? pc : make_float4(pc.x - w.x, pc.y - w.y, pc.z - w.z, pc.w - w.w);
+                    const int nb = (cj == 2) ? 0 : 3 + 3 * cj, ab = (cj == 2) ? 9 : 12 + 3 * cj;
+                    if ((j & 1) == 0) { fo[nb] = d.x; fo[nb + 1] = d.y; fo[nb + 2] = d.z; fo[ab] = d.w; }
+                    else { fo[ab + 1] = d.x; fo[ab + 2] = d.y; }
+                }
+                if (j < 3) { fo[18 + 3 * j] = vpos.x; fo[19 + 3 * j] = vpos.y; fo[20 + 3 * j] = vpos.z; }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
