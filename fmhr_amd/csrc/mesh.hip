@@ -262,6 +262,7 @@ k_lap_bwd_gather(const float* __restrict__ rowg, const int32_t* __restrict__ row
 
 // pos[b,v,:] = [v,1] @ (w2c[b] @ proj[b])  — row-vector convention; the reference's two einsums (mesh_sfs_optim.py:258-259)
 // associated the other way: equal to the last bit or two, and the oracle is evaluated at THESE positions
+template <bool HAS_DELTA>
 __device__ __forceinline__ void transform_body(int v, int b, const float* __restrict__ verts, const float* __restrict__ delta,
                                                const float* __restrict__ w2c, const float* __restrict__ proj, int V,
                                                float4* __restrict__ pos, int H, int W, int2* __restrict__ snap,
@@ -269,6 +270,13 @@ __device__ __forceinline__ void transform_body(int v, int b, const float* __rest
 {
     const float* A = w2c + (size_t)b * 16;
     const float* B = proj + (size_t)b * 16;
+    // the vertex (and its delta) is requested FIRST, from a clamped index, so that it travels with the matrix entries: behind the
+    // barrier and a `delta != nullptr` test it was two more dependent round trips of every thread (HAS_DELTA is a template
+    // parameter for that reason: a value merged under a run-time test gets its wait right behind the load)
+    const int vc = min(v, V - 1);
+    float x = verts[(size_t)vc * 3], y = verts[(size_t)vc * 3 + 1], z = verts[(size_t)vc * 3 + 2];
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (HAS_DELTA) { dx = delta[(size_t)vc * 3]; dy = delta[(size_t)vc * 3 + 1]; dz = delta[(size_t)vc * 3 + 2]; }
     // the combined matrix w2c @ proj, one entry per thread through LDS.  The backward recomputes a face's clip positions from
     // the published (x, y, w) columns with clip_coord() as well: the positions it differentiates at are then bit-identical to
     // the ones rasterized (an edge-on triangle amplifies a last-bit difference between the two by 1 / area)
@@ -281,9 +289,8 @@ __device__ __forceinline__ void transform_body(int v, int b, const float* __rest
     if (cmat != nullptr && v < 4)    // row v of w2c @ proj: rows 0..2 = d pos / d vertex_v (the clip-transform backward), row 3 the translation
         cmat[(size_t)b * 4 + v] = make_float4(c[v][0], c[v][1], c[v][2], c[v][3]);
     if (v >= V) return;
-    float x = verts[(size_t)v * 3], y = verts[(size_t)v * 3 + 1], z = verts[(size_t)v * 3 + 2];
-    if (delta != nullptr) {      // fused step: vertex = vertices_tmp + delta (mesh_sfs_optim.py:255), the same single add as the normals part
-        x = x + delta[(size_t)v * 3]; y = y + delta[(size_t)v * 3 + 1]; z = z + delta[(size_t)v * 3 + 2];
+    if (HAS_DELTA) {             // fused step: vertex = vertices_tmp + delta (mesh_sfs_optim.py:255), the same single add as the normals part
+        x = x + dx; y = y + dy; z = z + dz;
     }
     float o[4];
 #pragma unroll
@@ -333,6 +340,7 @@ __device__ __forceinline__ float sum_sub(float x)
     return x;
 }
 
+template <bool HAS_DELTA>
 __device__ __forceinline__ void normals_gather_body(int blk, const float* __restrict__ verts, const int32_t* __restrict__ tri,
                                                     const int32_t* __restrict__ vf_ptr, const int32_t* __restrict__ vf_idx, int V,
                                                     float* __restrict__ nsum, float* __restrict__ normals,
@@ -340,25 +348,54 @@ __device__ __forceinline__ void normals_gather_body(int blk, const float* __rest
                                                     const float* __restrict__ delta, float* __restrict__ vout)
 {
     // fused step: vertex = verts + delta (mesh_sfs_optim.py:255), formed on the fly and stored for the later kernels by the
-    // vertex's first lane (saves the separate add launch); stand-alone op: delta == nullptr
-    auto vertex = [&](int i) {
-        float3 q = ld3(verts + (size_t)i * 3);
-        if (delta != nullptr) { const float3 dl = ld3(delta + (size_t)i * 3); q.x = q.x + dl.x; q.y = q.y + dl.y; q.z = q.z + dl.z; }
-        return q;
-    };
+    // vertex's first lane (saves the separate add launch); stand-alone op: HAS_DELTA = false.
+    // Written in STAGES, every load of a stage requested (unconditionally, from clamped indices) before its first use: (0) the
+    // vertex, its delta, its CSR row bounds and albedo; (1) the lane's first incident corner; (2) that face's other two vertex
+    // ids; (3) their positions and deltas.  As vertex(tri[...]) calls behind a `delta != nullptr` test it was TEN dependent
+    // round trips per lane (vertex -> delta -> row -> corner -> id -> position -> delta -> id -> position -> delta).
     const int v = (blk * kBlock + threadIdx.x) / kSubLanes, sub = threadIdx.x & (kSubLanes - 1);
     const bool live = v < V;
     const int vv = live ? v : 0;
+    auto pos_of = [&](int i, float3& q, float3& dl) {
+        q = ld3(verts + (size_t)i * 3);
+        dl = make_float3(0.f, 0.f, 0.f);
+        if (HAS_DELTA) dl = ld3(delta + (size_t)i * 3);
+    };
+    auto add3 = [&](float3 q, float3 dl) { if (HAS_DELTA) { q.x = q.x + dl.x; q.y = q.y + dl.y; q.z = q.z + dl.z; } return q; };
+    // ---- stage 0
+    float3 p, pd;
+    pos_of(vv, p, pd);
+    const int c0 = vf_ptr[vv], c1 = vf_ptr[vv + 1];
+    float3 al = make_float3(0.f, 0.f, 0.f);
+    if (attr8 != nullptr) al = ld3(albedo + (size_t)vv * 3);        // (uniform)
+    // ---- stage 1
+    const int e0 = c0 + sub;
+    const bool he = live && e0 < c1;
+    const int code0 = vf_idx[max(min(e0, c1 - 1), 0)];
+    // ---- stage 2
+    const int f0 = code0 / 3, k0 = code0 - f0 * 3;
+    const int k1 = (k0 + 1 == 3) ? 0 : k0 + 1, k2 = (k1 + 1 == 3) ? 0 : k1 + 1;
+    const int ia = tri[f0 * 3 + k1], ib = tri[f0 * 3 + k2];
+    // ---- stage 3
+    float3 a, ad, b, bd;
+    pos_of(ia, a, ad);
+    pos_of(ib, b, bd);
+    p = add3(p, pd);
     float3 acc = make_float3(0.f, 0.f, 0.f);
     if (live) {
-        float3 p = vertex(vv);
         if (vout != nullptr && sub == 0) { vout[(size_t)vv * 3] = p.x; vout[(size_t)vv * 3 + 1] = p.y; vout[(size_t)vv * 3 + 2] = p.z; }
-        for (int e = vf_ptr[vv] + sub; e < vf_ptr[vv + 1]; e += kSubLanes) {
+        if (he) {
+            float3 c = cross3(sub3(add3(a, ad), p), sub3(add3(b, bd), p));      // corner k: cross(v[k+1]-v[k], v[k+2]-v[k]) (models/utils.py:517-543)
+            acc.x += c.x; acc.y += c.y; acc.z += c.z;
+        }
+        for (int e = e0 + kSubLanes; e < c1; e += kSubLanes) {              // valence > kSubLanes
             int code = vf_idx[e];
             int f = code / 3, k = code - f * 3;
-            int k1 = (k + 1 == 3) ? 0 : k + 1, k2 = (k1 + 1 == 3) ? 0 : k1 + 1;
-            float3 a = vertex(tri[f * 3 + k1]), b = vertex(tri[f * 3 + k2]);
-            float3 c = cross3(sub3(a, p), sub3(b, p));      // corner k: cross(v[k+1]-v[k], v[k+2]-v[k]) (models/utils.py:517-543)
+            int kk1 = (k + 1 == 3) ? 0 : k + 1, kk2 = (kk1 + 1 == 3) ? 0 : kk1 + 1;
+            float3 a2, a2d, b2, b2d;
+            pos_of(tri[f * 3 + kk1], a2, a2d);
+            pos_of(tri[f * 3 + kk2], b2, b2d);
+            float3 c = cross3(sub3(add3(a2, a2d), p), sub3(add3(b2, b2d), p));
             acc.x += c.x; acc.y += c.y; acc.z += c.z;
         }
     }
@@ -369,8 +406,8 @@ __device__ __forceinline__ void normals_gather_body(int blk, const float* __rest
     float inv = 1.0f / fmaxf(len, 1e-6f);
     normals[(size_t)v * 3] = acc.x * inv; normals[(size_t)v * 3 + 1] = acc.y * inv; normals[(size_t)v * 3 + 2] = acc.z * inv;
     if (attr8 != nullptr) {     // packed per-vertex attributes for the pixel kernels: (normal.xyz, albedo.x | albedo.yz, 0, 0)
-        attr8[(size_t)v * 2] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, albedo[(size_t)v * 3]);
-        attr8[(size_t)v * 2 + 1] = make_float4(albedo[(size_t)v * 3 + 1], albedo[(size_t)v * 3 + 2], 0.f, 0.f);
+        attr8[(size_t)v * 2] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, al.x);
+        attr8[(size_t)v * 2 + 1] = make_float4(al.y, al.z, 0.f, 0.f);
     }
 }
 
@@ -800,6 +837,7 @@ int lap_bwd_impl(const float* lx, const int32_t* row_ptr, const int32_t* col, in
 // ONE launch for the step's geometry: the first rows of the grid form the vertex normals (8 lanes per vertex) and store vertex =
 // tmp + delta, the n rows after them transform the vertices into the n views (clip positions, snapped vertices, combined matrices) —
 // the two parts are independent, so the latency-bound normals walk hides under the bandwidth-bound transform
+template <bool HAS_DELTA>
 __global__ void __launch_bounds__(kBlock)
 k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta, const float* __restrict__ w2c,
            const float* __restrict__ proj, int n, int V, float4* __restrict__ pos, int H, int W, int2* __restrict__ snap,
@@ -811,10 +849,10 @@ k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta,
     if (stamp != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamp[0] = stamp[0] + 1;
     const int rows_normals = (int)gridDim.y - n;                     // dispatched first: their long dependent chains start early
     if ((int)blockIdx.y >= rows_normals)
-        transform_body(blockIdx.x * kBlock + threadIdx.x, (int)blockIdx.y - rows_normals, verts_tmp, delta, w2c, proj, V, pos, H, W, snap,
+        transform_body<HAS_DELTA>(blockIdx.x * kBlock + threadIdx.x, (int)blockIdx.y - rows_normals, verts_tmp, delta, w2c, proj, V, pos, H, W, snap,
                        cmat);
     else
-        normals_gather_body((int)blockIdx.y * gridDim.x + blockIdx.x, verts_tmp, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, attr8,
+        normals_gather_body<HAS_DELTA>((int)blockIdx.y * gridDim.x + blockIdx.x, verts_tmp, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, attr8,
                             delta, vout);
 }
 
@@ -843,8 +881,12 @@ int geometry_impl(const float* verts_tmp, const float* delta, const float* w2c, 
     if (n == 0 || V == 0) return FMHR_OK;
     const int gx = cdiv(V, kBlock);
     const int rows_normals = cdiv(cdiv((long long)V * kSubLanes, kBlock), gx);
-    k_geometry<<<dim3(gx, n + rows_normals), kBlock, 0, st>>>(verts_tmp, delta, w2c, proj, n, V, (float4*)pos, H, W, snap, (float4*)cmat, tri,
-                                                              vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp);
+    if (delta != nullptr)
+        k_geometry<true><<<dim3(gx, n + rows_normals), kBlock, 0, st>>>(verts_tmp, delta, w2c, proj, n, V, (float4*)pos, H, W, snap, (float4*)cmat, tri,
+                                                                    vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp);
+    else
+        k_geometry<false><<<dim3(gx, n + rows_normals), kBlock, 0, st>>>(verts_tmp, delta, w2c, proj, n, V, (float4*)pos, H, W, snap, (float4*)cmat, tri,
+                                                                     vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp);
     FMHR_CHECK_LAUNCH("k_geometry");
     return FMHR_OK;
 }
