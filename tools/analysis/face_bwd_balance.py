@@ -31,3 +31,9 @@ pool = (-(-Tb.reshape(-1, 4, 8).sum(2) // 64)).sum()
 ideal = -(-T.sum() // 64)
 print(f"wave-iterations of the pixel loop: current {cur}, sorted within the workgroup {srt} ({srt / cur:.2f}x), pooled per wave {pool} ({pool / cur:.2f}x), ideal {ideal} ({ideal / cur:.2f}x)")
 print("lane utilisation now: %.2f" % (T[:n32].sum() / (cur * 64)))
+# 4 lanes per face (a wave = 16 consecutive faces): fewer idle lanes per face, but the wave waits for the busiest of 16
+n16 = F // 16 * 16
+it4 = (-(-T[:n16].reshape(-1, 16) // 4)).max(1).sum()
+print(f"4 lanes per face: {it4} wave-iterations over {n16 // 16} waves ({it4 / cur:.2f}x the lane-time of the current form)")
+it16 = (-(-T[:n32].reshape(-1, 4) // 16)).max(1).sum()
+print(f"16 lanes per face: {it16} wave-iterations ({it16 / cur:.2f}x)")
