@@ -365,9 +365,18 @@ def main():
     tk = Timing(len(sampled), stream)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in sampled]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in sampled]
+    # no cyclic garbage collection inside the timed region: with torch loaded a full collection is a ~40 ms host pause, and whether
+    # one falls into the region depended on how many event objects had been created before it (C4 with --steps 60: 1.85 ms per
+    # step by the host clock, 1.15 ms on the device for every single step; --steps 100: 1.17)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
+    dbg = [] if os.environ.get("FMHR_BENCH_DEBUG") else None
     t0 = time.perf_counter()
     for i in range(K):
+        if dbg is not None:
+            dbg.append(time.perf_counter() - t0)
         if i % stride == 0:
             j = i // stride
             tk.attach(j, dom)
@@ -377,8 +386,13 @@ def main():
             Timing.detach()
         else:
             losses = step()
+    if dbg is not None:
+        dbg.append(time.perf_counter() - t0)
     barrier()
     t1 = time.perf_counter()
+    gc.enable()
+    if dbg is not None and rank == 0:
+        print("host time of each step's enqueue (ms since t0):", " ".join("%.2f" % (1e3 * x) for x in dbg), "| barrier at %.2f" % (1e3 * (t1 - t0)), file=sys.stderr)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
