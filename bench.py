@@ -322,6 +322,9 @@ def main():
         aa_hist.append(float(cnt))
         if preroll >= 128 and len(aa_hist) >= 2 and abs(aa_hist[-1] - aa_hist[-2]) <= 0.005 * max(aa_hist[-1], 1.0):
             break
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -368,9 +371,8 @@ def main():
     # no cyclic garbage collection inside the timed region: with torch loaded a full collection is a ~40 ms host pause, and whether
     # one falls into the region depended on how many event objects had been created before it (C4 with --steps 60: 1.85 ms per
     # step by the host clock, 1.15 ms on the device for every single step; --steps 100: 1.17)
-    import gc
-    gc.collect()
-    gc.disable()
+    # (collected and switched off BEFORE the warm-up steps: a collection right before the region leaves the interpreter's working set
+    # cold, and with 20 steps = 7 ms of device time the first step's enqueue latency is a visible share of the host clock)
     barrier()
     dbg = [] if os.environ.get("FMHR_BENCH_DEBUG") else None
     t0 = time.perf_counter()
