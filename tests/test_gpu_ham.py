@@ -513,6 +513,49 @@ def test_full_size_properties():
     assert torch.equal(hs.views()["rast"], r1)
 
 
+def test_full_size_workspace_state_after_600_steps():
+    """The metric workload itself (48 views x 512 x 512, V = 49 281, binned rasterizer, 4 views per lane in the backward): 600
+    optimiser steps on one workspace — two 256-step periods of the owner marks, four of their 128-step wipes, the antialias list grown
+    to its stationary size — then the step at the final parameters must equal the same step on a fresh workspace, no list or bin may
+    have overflowed, and the optimisation must have made progress."""
+    from fmhr_amd import synthetic as S
+    from fmhr_amd.ham import HamStage2, render_forward, edge_length_mean
+    from fmhr_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    sc = S.scene_from_config("metric", 0, None)
+    n, H, W, V = sc["views"], sc["H"], sc["W"], sc["V"]
+    faces = sc["faces"].to(dev)
+    w2c, proj = sc["w2c"].contiguous().to(dev), sc["proj"].contiguous().to(dev)
+    tg = S.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, H, W), device=dev)
+    vt, sh = sc["vertices"].to(dev).contiguous(), sc["sh0"].contiguous().to(dev)
+    elm = edge_length_mean(vt, faces)
+    hs = HamStage2(faces, V, n, H, W, sc["weights"], elm)
+    assert hs.binned
+    delta = torch.zeros(V, 3, device=dev, requires_grad=True)
+    albedo = sc["albedo0"][None].to(dev).clone().requires_grad_(True)
+    opt = Adam([{'params': delta, 'lr': sc["lr"]["lr"]}, {'params': albedo, 'lr': sc["lr"]["albedo_lr"]}])
+    rest = (sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"])
+    first = None
+    for it in range(600):
+        losses, _, _ = hs.step(vt, delta.detach(), albedo.detach()[0], *rest, optimizer=opt, params=(delta, albedo))
+        if it == 0:
+            first = float(losses[6])
+    ld = hs.loss_dict()                                      # raises on an antialias-list / fragment-bin overflow
+    assert np.isfinite(ld["total"]) and ld["total"] < first
+    assert int(hs.aa_item_count()) > 20000                   # the silhouette has roughened: the stationary list
+    d_fin, a_fin = delta.detach().clone(), albedo.detach()[0].clone()
+    hs.step(vt, d_fin, a_fin, *rest)
+    l_old, gd_old, ga_old = hs.losses.clone(), hs.gdelta.clone(), hs.galbedo.clone()
+    r_old = hs.views()["rast"].clone()
+    fresh = HamStage2(faces, V, n, H, W, sc["weights"], elm)
+    fresh.step(vt, d_fin, a_fin, *rest)
+    assert torch.equal(fresh.views()["rast"], r_old)
+    assert rel_err(l_old[:7], fresh.losses[:7]) < 1e-6 and float(l_old[7]) == float(fresh.losses[7])
+    e = (rel_err(gd_old, fresh.gdelta), rel_err(ga_old, fresh.galbedo))
+    log_parity("metric workload, step 601 on one workspace vs a fresh workspace: gdelta %.1e galbedo %.1e, antialias items %d" % (*e, int(hs.aa_item_count())))
+    assert e[0] < 5e-5 and e[1] < 5e-5, e
+
+
 def test_stale_owner_mark_after_256_steps(oracle):
     """ADVICE r2 (shade.hip box path): the owner mark of a (view, face) is the low BYTE of the step that wrote it.  A face that owns
     pixel p at step s and then covers no pixel centre any more, while p stays uncovered, keeps its coverage entry, its mark, the
