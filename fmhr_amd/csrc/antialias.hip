@@ -221,6 +221,53 @@ __device__ __forceinline__ int2 snap_or_reject(const ClipView& cv, int v, float 
     return ok ? make_int2(x, y) : make_int2((int)0x80000000, 0);
 }
 
+// The analysis proper: the nearer triangle's three clip positions, its silhouette bits and which of the pair's two pixels it owns
+// (front0) -> work-item code + alpha.  ONE body for every caller (generic op, fused step, staged fused step): statement-for-statement
+// fp32, no contraction.
+__device__ __forceinline__ int aa_analyse_core(const float4 p0, const float4 p1, const float4 p2, int sb, bool front0, int vi0, int vi1, int vi2,
+                                               int qx, int qy, int d, int H, int W, float& alpha_out, int* edge_va, int* edge_vb)
+{
+    bool s0 = sb & 1, s1 = sb & 2, s2 = sb & 4;
+    float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
+    float w0 = 1.0f / p0.w, w1 = 1.0f / p1.w, w2 = 1.0f / p2.w;
+    float fx = (float)qx + 0.5f; fx = fx - xh;
+    float fy = (float)qy + 0.5f; fy = fy - yh;
+    float m;
+    m = p0.x * w0; m = m * xh; float x0 = m - fx;    m = p0.y * w0; m = m * yh; float y0 = m - fy;
+    m = p1.x * w1; m = m * xh; float x1 = m - fx;    m = p1.y * w1; m = m * yh; float y1 = m - fy;
+    m = p2.x * w2; m = m * xh; float x2 = m - fx;    m = p2.y * w2; m = m * yh; float y2 = m - fy;
+    float l, r;
+    if (d) { float tt; tt = x0; x0 = y0; y0 = tt; tt = x1; x1 = y1; y1 = tt; tt = x2; x2 = y2; y2 = tt; }
+    float dx0 = x2 - x1, dx1 = x0 - x2, dx2 = x1 - x0;
+    float dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;
+    float ds = front0 ? 1.0f : -1.0f;
+    l = x1 * dy0; r = y1 * dx0; float d0 = l - r; d0 = ds * d0;
+    l = x2 * dy1; r = y2 * dx1; float d1 = l - r; d1 = ds * d1;
+    l = x0 * dy2; r = y0 * dx2; float d2 = l - r; d2 = ds * d2;
+    const float NEG = -FLT_MAX;
+    if (same_sign(y1, y2)) { d0 = NEG; dy0 = 1.0f; }
+    if (same_sign(y2, y0)) { d1 = NEG; dy1 = 1.0f; }
+    if (same_sign(y0, y1)) { d2 = NEG; dy2 = 1.0f; }
+    int di = max_idx3(d0, d1, d2, dy0, dy1, dy2);
+    float dc = NEG;
+    if (di == 0 && s0 && fabsf(dy0) >= fabsf(dx0)) dc = d0 / dy0;
+    if (di == 1 && s1 && fabsf(dy1) >= fabsf(dx1)) dc = d1 / dy1;
+    if (di == 2 && s2 && fabsf(dy2) >= fabsf(dx2)) dc = d2 / dy2;
+    const float eps = 0.0625f;
+    if (!(dc > -eps && dc < 1.0f + eps)) return 0;
+    int code = di | (d ? AA_DOWN : 0) | (front0 ? 0 : AA_TRI1) | AA_FOUND;
+    if (dc < 0.0f) { dc = 0.0f; code |= AA_CLAMPED; }
+    if (dc > 1.0f) { dc = 1.0f; code |= AA_CLAMPED; }
+    float al = 0.5f - dc;
+    al = ds * al;
+    alpha_out = al;
+    if (edge_va != nullptr) {                    // the two vertices of the crossing edge (the backward's position gradient goes to them)
+        *edge_va = (di == 0) ? vi1 : ((di == 1) ? vi2 : vi0);
+        *edge_vb = (di == 0) ? vi2 : ((di == 1) ? vi0 : vi1);
+    }
+    return code;
+}
+
 // Analyse the pixel pair ((px,py), (px+1-d, py+d)) of view b.  z0/id0 and z1/id1 are rast.z / rast.w of the two pixels.
 // `silh` (nullable) = this view's per-triangle silhouette bits precomputed by the rasterizer: most seams between
 // micro-triangles are not silhouettes and leave here after one byte load.
@@ -252,46 +299,8 @@ __device__ __forceinline__ int aa_analyse(const ClipView& cv, const int32_t* __r
                                      snap_or_reject(cv, op1, kx, ky), snap_or_reject(cv, op2, kx, ky));
         if (!sb) return 0;
     }
-    bool s0 = sb & 1, s1 = sb & 2, s2 = sb & 4;
     const float4 p0 = cv.get(vi0), p1 = cv.get(vi1), p2 = cv.get(vi2);
-    float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
-    float w0 = 1.0f / p0.w, w1 = 1.0f / p1.w, w2 = 1.0f / p2.w;
-    float fx = (float)qx + 0.5f; fx = fx - xh;
-    float fy = (float)qy + 0.5f; fy = fy - yh;
-    float m;
-    m = p0.x * w0; m = m * xh; float x0 = m - fx;    m = p0.y * w0; m = m * yh; float y0 = m - fy;
-    m = p1.x * w1; m = m * xh; float x1 = m - fx;    m = p1.y * w1; m = m * yh; float y1 = m - fy;
-    m = p2.x * w2; m = m * xh; float x2 = m - fx;    m = p2.y * w2; m = m * yh; float y2 = m - fy;
-    float l, r;
-    if (d) { float tt; tt = x0; x0 = y0; y0 = tt; tt = x1; x1 = y1; y1 = tt; tt = x2; x2 = y2; y2 = tt; }
-    float dx0 = x2 - x1, dx1 = x0 - x2, dx2 = x1 - x0;
-    float dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;
-    float ds = (t == tri0) ? 1.0f : -1.0f;
-    l = x1 * dy0; r = y1 * dx0; float d0 = l - r; d0 = ds * d0;
-    l = x2 * dy1; r = y2 * dx1; float d1 = l - r; d1 = ds * d1;
-    l = x0 * dy2; r = y0 * dx2; float d2 = l - r; d2 = ds * d2;
-    const float NEG = -FLT_MAX;
-    if (same_sign(y1, y2)) { d0 = NEG; dy0 = 1.0f; }
-    if (same_sign(y2, y0)) { d1 = NEG; dy1 = 1.0f; }
-    if (same_sign(y0, y1)) { d2 = NEG; dy2 = 1.0f; }
-    int di = max_idx3(d0, d1, d2, dy0, dy1, dy2);
-    float dc = NEG;
-    if (di == 0 && s0 && fabsf(dy0) >= fabsf(dx0)) dc = d0 / dy0;
-    if (di == 1 && s1 && fabsf(dy1) >= fabsf(dx1)) dc = d1 / dy1;
-    if (di == 2 && s2 && fabsf(dy2) >= fabsf(dx2)) dc = d2 / dy2;
-    const float eps = 0.0625f;
-    if (!(dc > -eps && dc < 1.0f + eps)) return 0;
-    int code = di | (d ? AA_DOWN : 0) | ((t == tri0) ? 0 : AA_TRI1) | AA_FOUND;
-    if (dc < 0.0f) { dc = 0.0f; code |= AA_CLAMPED; }
-    if (dc > 1.0f) { dc = 1.0f; code |= AA_CLAMPED; }
-    float al = 0.5f - dc;
-    al = ds * al;
-    alpha_out = al;
-    if (edge_va != nullptr) {                    // the two vertices of the crossing edge (the backward's position gradient goes to them)
-        *edge_va = (di == 0) ? vi1 : ((di == 1) ? vi2 : vi0);
-        *edge_vb = (di == 0) ? vi2 : ((di == 1) ? vi0 : vi1);
-    }
-    return code;
+    return aa_analyse_core(p0, p1, p2, sb, t == tri0, vi0, vi1, vi2, qx, qy, d, H, W, alpha_out, edge_va, edge_vb);
 }
 
 // append one item per flagged lane with a single queue atomic per wave
@@ -427,6 +436,96 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);           // an uncovered pixel (id 0) has the all-zero colour
     const float4 ca = (id0 != 0.f) ? shade_word(sd.words[gid], tri, sd.attr8, sd.sh + (size_t)b * 9) : zero;
     const float4 cb = (id1 != 0.f) ? shade_word(sd.words[gid1], tri, sd.attr8, sd.sh + (size_t)b * 9) : zero;
+    const float dc[4] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z, cb.w - ca.w};
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (dc[c] != 0.f) atomicAdd(out + tgt * 4 + c, alpha * dc[c]);
+    const int slot = atomicAdd(inum, 1);                             // LDS
+    if (slot < region) sd.dcols[rbase + slot] = make_float4(dc[0], dc[1], dc[2], dc[3]);   // straight to the item's final place
+    if (slot < kItemBuf) {
+        ibuf[slot] = item;
+        abuf[slot] = alpha;
+    } else if (slot < region) {                                      // buffer full (a silhouette-dense workgroup): straight to the region
+        items[rbase + slot] = item;
+        alphas[rbase + slot] = alpha;
+    } else {
+        counter[1] = 1;                                              // region overflow: the pair gets no gradient, flagged
+    }
+}
+
+// aa_fwd_pair in THREE round trips instead of six, for the dense candidate pass of k_aa_fwd_list (a workgroup's ~200 candidates, one
+// per lane: the pass IS one lane's chain — 9.4 of the kernel's 28 us, tools/analysis/wave_timeline.py): (1) both pixels' words, both
+// faces' vertex ids, the view's matrix rows and SH row, all addressed by the candidate itself — the nearer face's silhouette bits
+// ride in its pixel's word (the rasterizer's own value: no byte gather); (2) the nearer face's three vertices -> aa_analyse_core;
+// (3) for the pairs that blend, the twelve attribute words of both pixels' faces -> the two colours.  Same statements as aa_fwd_pair
+// (aa_analyse_core, shade_eval_attr): same items, alphas and colours.
+__device__ __forceinline__ void aa_fwd_pair_staged(int px, int py, int b, int d, float z0, float id0, float z1, float id1,
+                                                   const AaShade& sd, const float* __restrict__ verts, const float4* __restrict__ cmat,
+                                                   const int32_t* __restrict__ tri, int V, int F, int H, int W,
+                                                   float* __restrict__ out, int4* __restrict__ items, float* __restrict__ alphas,
+                                                   int32_t* __restrict__ counter, int4* ibuf, float* abuf, int* inum, int region, size_t rbase)
+{
+    struct I3 { int x, y, z; };
+    const int tri0 = (int)id0 - 1, tri1 = (int)id1 - 1;
+    int t = (tri0 >= 0) ? tri0 : tri1;
+    if (tri0 >= 0 && tri1 >= 0) t = (z0 < z1) ? tri0 : tri1;
+    if (t < 0 || t >= F) return;
+    const bool front0 = t == tri0;
+    int qx = px, qy = py;
+    if (!front0) { qx += 1 - d; qy += d; }
+    const long long gid = ((long long)b * H + py) * W + px, gid1 = gid + (d ? W : 1);
+    // ---- (1)
+    float4 wa = sd.words[gid], wb = sd.words[gid1];                 // (an uncovered pixel's word is stale: masked by its id below)
+    const I3 ra = *reinterpret_cast<const I3*>(tri + (size_t)max(tri0, 0) * 3), rb = *reinterpret_cast<const I3*>(tri + (size_t)max(tri1, 0) * 3);
+    float4 c0 = cmat[(size_t)b * 4], c1 = cmat[(size_t)b * 4 + 1], c2 = cmat[(size_t)b * 4 + 2], c3 = cmat[(size_t)b * 4 + 3];
+    const float* const shv = sd.sh + (size_t)b * 9;
+    const F4U sA = reinterpret_cast<const F4U*>(shv)[0], sB = reinterpret_cast<const F4U*>(shv)[1];
+    const float s8 = shv[8];
+    pin(wa); pin(wb); pin(c0); pin(c1); pin(c2); pin(c3);
+    const int sb = pix_silh(__float_as_int(front0 ? wa.w : wb.w));
+    if (!sb) return;
+    const I3 rt = front0 ? ra : rb;
+    if ((unsigned)rt.x >= (unsigned)V || (unsigned)rt.y >= (unsigned)V || (unsigned)rt.z >= (unsigned)V) return;
+    // ---- (2) the three clip positions exactly as ClipView::get() forms them
+    const F3U x0 = *reinterpret_cast<const F3U*>(verts + (size_t)rt.x * 3), x1 = *reinterpret_cast<const F3U*>(verts + (size_t)rt.y * 3),
+              x2 = *reinterpret_cast<const F3U*>(verts + (size_t)rt.z * 3);
+    auto clip = [&](const F3U& v) {
+        return make_float4(clip_coord(v.x, v.y, v.z, c0.x, c1.x, c2.x, c3.x), clip_coord(v.x, v.y, v.z, c0.y, c1.y, c2.y, c3.y),
+                           clip_coord(v.x, v.y, v.z, c0.z, c1.z, c2.z, c3.z), clip_coord(v.x, v.y, v.z, c0.w, c1.w, c2.w, c3.w));
+    };
+    float alpha = 0.f;
+    int va = 0, vb = 0;
+    const int code = aa_analyse_core(clip(x0), clip(x1), clip(x2), sb, front0, rt.x, rt.y, rt.z, qx, qy, d, H, W, alpha, &va, &vb);
+    if (code == 0) return;
+    // ---- (3) both colours (shade_word with the vertex ids and the SH row already here; an uncovered pixel is the all-zero colour)
+    const int4 item = make_int4(px | (py << 16), b | (code << 16), va, vb);
+    const long long tgt = (alpha > 0.f) ? gid : gid1;
+    float4 qa[6], qb[6];
+    {
+        const int ia[3] = {ra.x, ra.y, ra.z}, ib[3] = {rb.x, rb.y, rb.z};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            qa[2 * k] = sd.attr8[(size_t)ia[k] * 2]; qa[2 * k + 1] = sd.attr8[(size_t)ia[k] * 2 + 1];
+            qb[2 * k] = sd.attr8[(size_t)ib[k] * 2]; qb[2 * k + 1] = sd.attr8[(size_t)ib[k] * 2 + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pin(qa[k]); pin(qb[k]); }
+    }
+    const float shc[9] = {sA.x, sA.y, sA.z, sA.w, sB.x, sB.y, sB.z, sB.w, s8};
+    auto colour = [&](const float4 w, bool covered, const float4 (&q)[6]) {
+        float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!covered) return col;
+        const int pk = __float_as_int(w.w);
+        const float w2 = 1.0f - w.x - w.y;
+        col.w = w.x + w.y + w2;
+        if (pix_mask(pk)) {
+            PixShade ps;
+            shade_eval_attr(w.x, w.y, q[0], q[1], q[2], q[3], q[4], q[5], shc, ps);
+            col.x = ps.rad * ps.ar; col.y = ps.rad * ps.ag; col.z = ps.rad * ps.ab;
+        }
+        return col;
+    };
+    const float4 ca = colour(wa, id0 != 0.f, qa), cb = colour(wb, id1 != 0.f, qb);
     const float dc[4] = {cb.x - ca.x, cb.y - ca.y, cb.z - ca.z, cb.w - ca.w};
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -710,8 +809,13 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
         for (int c = threadIdx.x; c < nc; c += kBlock) {
             const int2 cp = cpos[c];
             const float4 cf = cfrag[c];
-            aa_fwd_pair(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, sd, pos, verts, cmat, tri, opp, silh, V, F, H,
-                        W, out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
+            if (ROW && pos == nullptr)                               // the fused step, no stored clip positions (the per-pixel-scan instantiation
+                                                                     // runs at 96 registers: there the wider stages only add spills, 47.6 -> 51.4 us)
+                aa_fwd_pair_staged(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, sd, verts, cmat, tri, V, F, H, W,
+                                   out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
+            else
+                aa_fwd_pair(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, sd, pos, verts, cmat, tri, opp, silh, V, F, H,
+                            W, out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
         }
     }
 #ifdef FMHR_X_TS

@@ -25,7 +25,7 @@ hs = HamStage2(faces, V, 48, 512, 512, sc["weights"], edge_length_mean(vt, faces
 delta = torch.zeros(V, 3, device=dev, requires_grad=True)
 albedo = sc["albedo0"][None].to(dev).clone().requires_grad_(True)
 opt = Adam([{'params': delta, 'lr': sc["lr"]["lr"]}, {'params': albedo, 'lr': sc["lr"]["albedo_lr"]}])
-for it in range(60):
+for it in range(int(__import__("os").environ.get("FMHR_WTS_STEPS", "60"))):
     hs.step(vt, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"], optimizer=opt, params=(delta, albedo))
 torch.cuda.synchronize()
 
