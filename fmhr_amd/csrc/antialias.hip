@@ -711,13 +711,8 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
             if (tsx[0] == 0ull) tsx[0] = wall_clock64();
 #endif
             const int cnt = __popcll(M);
-            int incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += t;
-            }
-            const int excl = incl - cnt, T = __shfl(incl, 63, 64);
+            const int incl = wave_incl_scan(cnt);                    // DPP (six ds_bpermute round trips before)
+            const int excl = incl - cnt, T = __builtin_amdgcn_readlane(incl, 63);
             for (int R = 0; R < T; R += kPixBuf) {                   // wave-uniform
                 if (cnt != 0 && excl < R + kPixBuf && excl + cnt > R) {
                     unsigned long long m = M;
