@@ -60,7 +60,12 @@ def report(name, fn, nwaves, slots_per_simd):
 
 
 report("tris", hs.lib.fmhr_debug_wts_raster, ((F + 255) // 256) * 48 * 4, 8)
-report("face_bwd", hs.lib.fmhr_debug_wts_shade, ((F + 31) // 32) * 4, 4)
+report("face_bwd", hs.lib.fmhr_debug_wts_shade, ((F + 31) // 32) * 4 * 2, 4)     # both view groups (32 + 16 views)
+tf = np.load("gpurun_out/wts_face_bwd.npy"); nb = ((F + 31) // 32) * 4
+for gi, nm in ((0, "32-view group"), (1, "16-view group")):
+    q = tf[gi * nb:(gi + 1) * nb]; t0f = tf[:, 0].min()
+    st, en = (q[:, 0] - t0f) / 100.0, (q[:, 1] - t0f) / 100.0
+    print(f"   face_bwd {nm}: starts {st.min():.1f} .. {np.median(st):.1f} .. {st.max():.1f} us, ends median {np.median(en):.1f} p99 {np.percentile(en, 99):.1f} max {en.max():.1f} us, life median {np.median(en - st):.2f} p90 {np.percentile(en - st, 90):.2f} sum {((en - st).sum() / 1e3):.1f} ms.wave")
 report("aa_fwd_list", hs.lib.fmhr_debug_wts_aaf, 768 * 4, 3)
 report("aa_bwd_items", hs.lib.fmhr_debug_wts_aab, 768 * 4, 7)
 nvb = (V * 8 + 255) // 256
