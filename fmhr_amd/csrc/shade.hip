@@ -317,13 +317,13 @@ constexpr int kMaxVPL = FMHR_MAX_VPL;                       // views per lane: a
 // VPL views per lane: the fixed part of a (face, view group) — vertex ids, attributes, output slots, the DPP sum, the output
 // store, the launch — is paid once per kGroup * VPL views, and the partial planes the mesh tail has to add up shrink with it.
 template <int VPL>
-__global__ void __launch_bounds__(kFbBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))       // <= 128 VGPRs: 4 waves per SIMD (the few spills sit in the prologue, outside the pixel loop: 77.5 -> 72.5 us)
-k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
+__device__ __forceinline__ void
+face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
            const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
            const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
-           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg)       // skip_lists: queued large-box faces have their own kernel
+           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg, const int g, const int b0)
 {
     FMHR_WTS_BEGIN(shade, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kFbBlock / 64) + (threadIdx.x >> 6));
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
@@ -335,7 +335,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     const long long P = (long long)H * W;
     const int tid = threadIdx.x, j = tid & (kGroup - 1), gl = tid / kGroup, lane = tid & 63;
     const int f = blockIdx.x * kFacesPerBlock + gl;
-    const int g = blockIdx.y, b0 = g * GV;                         // view of (lane j, slot v) = b0 + v * kGroup + j
+    // view of (lane j, slot v) = b0 + v * kGroup + j
     const bool facelive = f < F;                                   // uniform over a group
     // ---- the coverage entries of this lane's (face, view)s; entries of other steps carry another stamp
     const unsigned cur = (unsigned)stamp[0] & 0xFFFFFFu;           // advanced once per step by the geometry kernel
@@ -612,6 +612,26 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     FMHR_WTS_END(shade);
 }
 
+// VA views per lane in every view group but (VB != VA) the last, which holds the remainder in VB per lane: 48 views = a 32-view group
+// (4 per lane) + a 16-view group that runs the 2-per-lane instantiation instead of the 4-per-lane one with half its slots empty
+template <int VA, int VB>
+__global__ void __launch_bounds__(kFbBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))       // <= 128 VGPRs: 4 waves per SIMD
+k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
+           const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
+           const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
+           const int32_t* __restrict__ corner_slot,
+           const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
+           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg)       // skip_lists: queued large-box faces have their own kernel
+{
+    const int g = blockIdx.y;
+    if (VB != VA && g == (int)gridDim.y - 1)                       // (block-uniform)
+        face_bwd_body<VB>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, llink, n, V, F, H, W, part, skip_lists,
+                          pg, g, g * kGroup * VA);
+    else
+        face_bwd_body<VA>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, llink, n, V, F, H, W, part, skip_lists,
+                          pg, g, g * kGroup * VA);
+}
+
 int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char* vmnz, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
@@ -759,17 +779,26 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     const dim3 grid(cdiv(F, kFacesPerBlock), face_bwd_groups(n));
     const int skip_lists = raster_use_queue(H, W, F) ? 1 : 0;      // coarse mesh: the queued large-box faces get their own kernel
     const PixGrid pg = make_pix_grid(H, W);
-#define FMHR_FACE_BWD(VPL)                                                                                                          \
-    k_face_bwd<VPL><<<grid, kFbBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded,     \
+#define FMHR_FACE_BWD(VA, VB)                                                                                                       \
+    k_face_bwd<VA, VB><<<grid, kFbBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded, \
                                              (const int2*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
                                              (float4*)part, skip_lists, pg)
-    switch (face_bwd_vpl(n)) {
-        case 1: FMHR_FACE_BWD(1); break;
-        case 2: FMHR_FACE_BWD(2); break;
-        case 3: FMHR_FACE_BWD(3); break;
-        case 4: FMHR_FACE_BWD(4); break;
-        case 5: FMHR_FACE_BWD(5); break;
-        default: FMHR_FACE_BWD(6); break;
+    static_assert(kMaxVPL <= 4, "the instantiation table below stops at 4 views per lane");
+    {
+        const int va = face_bwd_vpl(n), rem = n - (face_bwd_groups(n) - 1) * kGroup * va;       // views of the last group
+        const int vb = min(va, cdiv(rem, kGroup));
+        switch (va * 8 + vb) {
+            case 1 * 8 + 1: FMHR_FACE_BWD(1, 1); break;
+            case 2 * 8 + 1: FMHR_FACE_BWD(2, 1); break;
+            case 2 * 8 + 2: FMHR_FACE_BWD(2, 2); break;
+            case 3 * 8 + 1: FMHR_FACE_BWD(3, 1); break;
+            case 3 * 8 + 2: FMHR_FACE_BWD(3, 2); break;
+            case 3 * 8 + 3: FMHR_FACE_BWD(3, 3); break;
+            case 4 * 8 + 1: FMHR_FACE_BWD(4, 1); break;
+            case 4 * 8 + 2: FMHR_FACE_BWD(4, 2); break;
+            case 4 * 8 + 3: FMHR_FACE_BWD(4, 3); break;
+            default: FMHR_FACE_BWD(4, 4); break;
+        }
     }
 #undef FMHR_FACE_BWD
     FMHR_CHECK_LAUNCH("k_face_bwd");
