@@ -330,13 +330,18 @@ __global__ void __launch_bounds__(kBlock) k_adam2(const AdamTensor A, const Adam
 // ------------------------------------------------------------------------------------------------ CSR-gather forms (fused step)
 // kSubLanes lanes per vertex walk its incident face corners (vf CSR, entry = 3*face + corner): no float atomics, deterministic
 // summation order.  The face-scatter forms above took ~40 us each on atomics into a 0.6 MB array; these take a few us.
+static_assert(true, "");
 constexpr int kSubLanes = 8;     // lanes per vertex in the CSR-walking kernels (49k lane-per-vertex threads cannot fill 1024 SIMDs)
 
+// sum over the kSubLanes = 8 lanes of a vertex, every lane gets the total: the xor-1 / xor-2 butterflies as DPP quad permutes, the
+// last step by row_half_mirror (lane i <-> 7 - i: after two steps every lane of a quad holds the quad's sum, so the mirror pairs the
+// two quads) — the same three additions per lane as the __shfl_xor form (operands swapped: bit-identical), without its three
+// dependent ds_bpermute round trips through the LDS crossbar per value (k_mesh_tail_a reduces ~30 values: 8 us of LDS time per CU)
 __device__ __forceinline__ float sum_sub(float x)
 {
-    x += __shfl_xor(x, 1);
-    x += __shfl_xor(x, 2);
-    x += __shfl_xor(x, 4);
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));     // row_half_mirror
     return x;
 }
 
