@@ -163,12 +163,19 @@ __device__ __forceinline__ uint32_t mono_key(float f)
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// wave64 sum reduction (all lanes get lane-0-valid result in lane 0)
+// wave64 sum reduction, the total in every lane: the DPP scan of wave_incl_scan (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31) and a
+// readlane of lane 63 — six vector-ALU operand modifiers instead of six dependent ds_bpermute round trips through the LDS crossbar
+// (the sums sit at the very end of their kernels' chains).  The tree differs from the shuffle form's: partial sums of the losses move
+// in the last bit.
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 struct alignas(4) F3U { float x, y, z; };
