@@ -201,6 +201,8 @@ def main():
     args = ap.parse_args()
 
     rank, world, local = fdist.init_from_env()
+    # FMHR_FORCE_SHARDED=1 (rehearsal): one rank runs the view-sharded step — split backward, all-reduce over the real backend, combine
+    sharded = world > 1 or os.environ.get("FMHR_FORCE_SHARDED", "0") == "1"
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -217,13 +219,13 @@ def main():
     n_frames = int(os.environ.get("FMHR_DUP_FRAMES", scene.get("frames", 1)))       # FMHR_DUP_FRAMES: experiments only
     if n_frames > 1:
         part = fdist.shard_frames_views(n_frames, n_total, rank, world)
-        fgroups = fdist.frame_groups(n_frames, world) if world > 1 else [None] * n_frames
+        fgroups = fdist.frame_groups(n_frames, world) if world > 1 else [None] * n_frames          # (one rank holds whole frames: no exchange)
         (f0, f1), (s0, s1) = part["frames"], part["views"]
         view_rank, view_world = part["view_rank"], part["view_world"]
     else:
         f0, f1 = 0, 1
         s0, s1 = fdist.shard_views(n_total, rank, world)
-        fgroups = [torch.distributed.group.WORLD if world > 1 else None]
+        fgroups = [torch.distributed.group.WORLD if sharded else None]
         view_rank, view_world = rank, world
     n = s1 - s0
     if n == 0:
@@ -303,7 +305,7 @@ def main():
         return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
 
     def barrier():
-        if world > 1:
+        if sharded:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -317,7 +319,7 @@ def main():
             step()
         preroll += 32
         cnt = sum(p.hs.aa_item_count() for p in problems).to(torch.float32).reshape(1)
-        if world > 1:
+        if sharded:
             torch.distributed.all_reduce(cnt)
         aa_hist.append(float(cnt))
         if preroll >= 128 and len(aa_hist) >= 2 and abs(aa_hist[-1] - aa_hist[-2]) <= 0.005 * max(aa_hist[-1], 1.0):
@@ -396,7 +398,7 @@ def main():
     if dbg is not None and rank == 0:
         print("host time of each step's enqueue (ms since t0):", " ".join("%.2f" % (1e3 * x) for x in dbg), "| barrier at %.2f" % (1e3 * (t1 - t0)), file=sys.stderr)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed)
     dom_ms_raw = sum(tk.ms(j, dom) for j in range(len(sampled))) / len(sampled)
@@ -410,13 +412,13 @@ def main():
     step_dev_ms = sum(ev0[j].elapsed_time(ev1[j]) for j in range(len(sampled))) / len(sampled)
     # a full antialias work-item list (some silhouette pairs without a gradient) invalidates the run — on EVERY rank
     ovf = torch.tensor([1.0 if any(p.hs.aa_overflowed() or p.hs.raster_overflowed() for p in problems) else 0.0], device=dev)
-    if world > 1:
+    if sharded:
         torch.distributed.all_reduce(ovf)
     if float(ovf) != 0:
         raise SystemExit(f"bench.py: the antialias work-item list or a rasterizer fragment bin overflowed on {int(float(ovf))} rank(s) (aa_cap={hs.dims.aa_cap})")
     final = dict(zip(("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid"), losses.tolist()))
     aa_items = sum(p.hs.aa_item_count() for p in problems).to(torch.float32).reshape(1)
-    if world > 1:
+    if sharded:
         torch.distributed.all_reduce(aa_items)
 
     if rank == 0:
@@ -488,7 +490,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         torch.distributed.destroy_process_group()
 
 

@@ -25,7 +25,10 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if "FMHR_FORCE_DEVICE" in os.environ:            # rehearsal: all ranks on one GPU
         local = int(os.environ["FMHR_FORCE_DEVICE"])
-    if world > 1 and not dist.is_initialized():
+    # FMHR_FORCE_SHARDED=1: rehearsal of the N > 1 code path on ONE rank (RCCL with a world of one on a one-GPU box: the process
+    # group, the in-place all-reduce of the step's bucket on the step's stream and the combine kernel are the real ones)
+    force = os.environ.get("FMHR_FORCE_SHARDED", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:

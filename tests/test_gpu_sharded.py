@@ -21,6 +21,21 @@ def _free_port():
     return p
 
 
+def _get(q, procs, timeout):
+    """q.get that gives up as soon as a worker has died (a worker that raises never puts anything: waiting out the whole timeout in
+    silence looks like a hung GPU to the box's watchdog)"""
+    import queue
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            return q.get(timeout=2)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"worker exited with {dead} before delivering its result"
+            assert time.time() - t0 < timeout, "timed out waiting for the workers"
+
+
 def _scene(dims=(6, 128, 96, 21, 37, 1)):
     sys.path.insert(0, ROOT)
     from fmhr_amd import synthetic as S
@@ -77,7 +92,7 @@ def test_two_ranks_one_gpu_match_single_rank():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ls, gd, ga = (torch.from_numpy(x) for x in q.get(timeout=500))
+    ls, gd, ga = (torch.from_numpy(x) for x in _get(q, procs, 500))
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -103,7 +118,7 @@ def test_two_ranks_one_gpu_metric_mesh_six_plus_six_views():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, METRIC12)) for r in range(2)]
     for p in procs:
         p.start()
-    ls, gd, ga = (torch.from_numpy(x) for x in q.get(timeout=800))
+    ls, gd, ga = (torch.from_numpy(x) for x in _get(q, procs, 800))
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -156,7 +171,7 @@ def test_stage1_view_sharded_matches_single_rank():
     procs = [ctx.Process(target=_stage1_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([_get(q, procs, 500) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -173,3 +188,84 @@ def test_stage1_view_sharded_matches_single_rank():
             assert abs(l_r - loss) <= 1e-5 * abs(loss), (k, rank, l_r, loss)
             assert rel_err(torch.from_numpy(ga_r), ga.cpu()) < 2e-5
             assert rel_err(torch.from_numpy(gs_r), gs[s0:s1].cpu()) < 2e-5 or float(gs[s0:s1].abs().max()) == 0.0
+
+
+def _rccl_worker(port, q):
+    """ONE rank over the real backend: fmhr_amd.dist.init_from_env takes its `nccl` (= RCCL) branch, the sharded step all-reduces its
+    bucket in place through RCCL on the step's stream and combines; ShardedStage1 does the same with the albedo gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", FMHR_FORCE_SHARDED="1")
+    os.environ.pop("FMHR_DIST_BACKEND", None)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from fmhr_amd import dist as fdist
+    from fmhr_amd.ham import HamStage2, edge_length_mean
+    from fmhr_amd.optim import Adam
+    from fmhr_amd.stage1 import HamStage1
+    def say(msg):
+        if os.environ.get("FMHR_TEST_TRACE"):
+            with open(os.environ["FMHR_TEST_TRACE"], "a") as f:
+                f.write(msg + "\n")
+    say("worker up")
+    rank, world, local = fdist.init_from_env()
+    say("process group up")
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+    sc, tg, faces, w2c, proj = _scene()
+    w2c, proj = w2c.contiguous(), proj.contiguous()
+    dev = faces.device
+    vt = sc["vertices"].to(dev)
+    out = {}
+    for name, group in (("sharded", dist.group.WORLD), ("plain", None)):
+        hs = HamStage2(faces, sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], edge_length_mean(vt, faces))
+        delta = sc["delta"].clone().requires_grad_(True)
+        albedo = sc["albedo0"].to(dev).clone().requires_grad_(True)
+        opt = Adam([{'params': delta, 'lr': sc["lr"]["lr"]}, {'params': albedo, 'lr': sc["lr"]["albedo_lr"]}])
+        say(name + ": workspace built")
+        for it in range(12):                        # twelve optimiser steps: the exchange sits between dependent steps every time
+            ls, gd, ga = hs.step(vt, delta.detach(), albedo.detach(), sc["sh0"].to(dev), w2c, proj, tg["img"], tg["mask"], tg["valid_mask"],
+                                 group=group, reg_range=(0, sc["V"]), optimizer=opt, params=(delta, albedo))
+            if it == 0:                             # identical parameters on both sides: the strict comparison
+                out[name + "_first"] = (ls.cpu().numpy(), gd.cpu().numpy(), ga.cpu().numpy())
+        torch.cuda.synchronize()
+        say(name + ": 12 steps done")
+        out[name] = (ls.cpu().numpy(), gd.cpu().numpy(), ga.cpu().numpy(), delta.detach().cpu().numpy(), albedo.detach().cpu().numpy())
+    hs1 = HamStage1(vt, faces, w2c, proj, tg["img"], tg["mask"], (sc["H"], sc["W"]), 50.0)
+    sh1 = fdist.ShardedStage1(hs1, 0, sc["views"], group=dist.group.WORLD)
+    alb1 = sc["albedo0"][None].to(dev).contiguous()
+    shc = sc["sh0"].to(dev).contiguous()
+    loss, ga, _ = sh1.step(alb1, shc)
+    lv, ga_ref, _ = hs1.step(alb1, shc)
+    out["stage1"] = (float(loss), float(lv.sum()), ga.cpu().numpy(), ga_ref.cpu().numpy())
+    say("stage 1 done")
+    dist.barrier()
+    say("barrier done")
+    q.put(out)
+    dist.destroy_process_group()
+    say("destroyed")
+
+
+@pytest.mark.timeout(600)
+def test_rccl_backend_world_of_one_through_the_sharded_step():
+    """RCCL itself (torch.distributed backend "nccl" on ROCm) with the only world size a one-GPU box allows: the sharded step's
+    protocol over the real backend — process group bound to the device, in-place all-reduce of the 12V+8 bucket ordered against the
+    kernels of the step's stream, combine + Adam — must reproduce the plain step over a dozen dependent optimiser steps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import log_parity, rel_err
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = _get(q, [p], 500)
+    p.join(120)
+    assert p.exitcode == 0
+    e1 = [rel_err(torch.from_numpy(x), torch.from_numpy(y)) for x, y in zip(out["sharded_first"], out["plain_first"])]
+    a, b = out["sharded"], out["plain"]
+    e = [rel_err(torch.from_numpy(x), torch.from_numpy(y)) for x, y in zip(a, b)]
+    log_parity("RCCL (world of one) sharded step vs plain step, first step: losses %.1e gdelta %.1e galbedo %.1e | after 12 fused-Adam steps: "
+               "losses %.1e gdelta %.1e galbedo %.1e delta %.1e albedo %.1e" % tuple(e1 + e))
+    assert float(a[0][7]) == float(b[0][7]) and float(b[0][7]) > 1000
+    assert max(e1) < 5e-5, e1
+    # twelve Adam steps apart the two summation orders (P / (3 Pv) + R vs the fused sum) have drifted by what Adam makes of the last bits
+    # (its first updates are ~lr x sign(g)): the parameters agree to 1e-4, the gradients to 2e-3
+    assert e[0] < 1e-4 and max(e[1:3]) < 2e-3 and max(e[3:]) < 1e-4, e
+    l_s, l_p, ga_s, ga_p = out["stage1"]
+    assert abs(l_s - l_p) <= 1e-6 * abs(l_p) and rel_err(torch.from_numpy(ga_s), torch.from_numpy(ga_p)) < 1e-6
