@@ -12,6 +12,7 @@ on ROCm) — SURVEY.md §8e.  The reference has no multi-GPU code; this is the b
   views and the view-independent terms (regularisers) of its VERTEX range — shard_views(V, rank, world) — so the regulariser
   work is split over the ranks too.
 """
+import ctypes
 import os
 
 import torch
@@ -40,6 +41,91 @@ def init_from_env(backend=None):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_ubyte * 128)]     # (c_char fields read back NUL-terminated: the id would be cut short)
+
+
+class StreamAllReduce:
+    """The step's ONE all-reduce issued straight into RCCL on the STEP'S OWN STREAM (ncclAllReduce, in place, fp32 sum).
+
+    torch.distributed's nccl backend runs every collective on a stream of its own: the call records an event on the current stream,
+    makes its stream wait for it, launches, and makes the current stream wait for the result — two cross-stream hand-overs, measured
+    at 14.6 us of device time per call with a world of ONE (profiles/r03_small_views.txt), more than a tenth of the 0.12 ms a rank
+    of the 8-GPU run spends on its six views.  This class owns a second communicator on the same ranks (its unique id travels over
+    the torch group once, at construction) inside the RCCL instance torch itself loaded (torch/lib/librccl.so: one library, two
+    communicators), and enqueues the reduction between the backward's last kernel and the combine kernel like any other launch.
+    HamStage2.step(group=<this object>) uses it; anything that fails at construction raises, and callers fall back to the torch group
+    (make_stream_all_reduce does that collectively)."""
+
+    def __init__(self, group=None):
+        if not (dist.is_initialized() and dist.get_backend(group) == "nccl"):
+            raise RuntimeError("StreamAllReduce needs an initialised torch.distributed group on the nccl (RCCL) backend")
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.lib = ctypes.CDLL(path if os.path.exists(path) else "librccl.so")
+        L = self.lib
+        L.ncclGetErrorString.restype = ctypes.c_char_p
+        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
+        L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                    ctypes.c_void_p]
+        L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        uid = _NcclUniqueId()
+        if self.rank == 0:
+            self._check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        box = [ctypes.string_at(ctypes.byref(uid), 128) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        self.comm = ctypes.c_void_p()
+        self._check(L.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"StreamAllReduce: {what} failed: {self.lib.ncclGetErrorString(rc).decode()}")
+
+    def all_reduce_(self, t, stream=None):
+        """in-place sum of the contiguous float32 GPU tensor `t` over the ranks, enqueued on `stream` (default: the current one)"""
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("StreamAllReduce.all_reduce_: contiguous float32 GPU tensor required")
+        st = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
+        self._check(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), 7, 0, self.comm, st), "ncclAllReduce")   # ncclFloat32, ncclSum
+        return t
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def make_stream_all_reduce(group=None, check_numel=4099):
+    """-> a StreamAllReduce for `group`, or `group` itself (the torch path) when the direct communicator cannot be had: every rank
+    tries, the outcome is agreed on over the torch group (one rank failing sends all of them down the torch path), and the direct path
+    must reproduce torch's all-reduce of a test vector bit for bit before it is trusted.  FMHR_STREAM_ALLREDUCE=0 switches it off."""
+    if os.environ.get("FMHR_STREAM_ALLREDUCE", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        return group
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sar, ok = None, 1.0
+    try:
+        sar = StreamAllReduce(group)
+        g = torch.Generator(device="cpu").manual_seed(1234 + dist.get_rank(group))
+        x = torch.randn(check_numel, generator=g).to(dev)
+        y = x.clone()
+        dist.all_reduce(x, group=group)
+        sar.all_reduce_(y)
+        torch.cuda.synchronize()
+        ok = 1.0 if torch.allclose(x, y, rtol=1e-6, atol=1e-6) else 0.0
+    except Exception:  # noqa: BLE001
+        ok = 0.0
+    flag = torch.tensor([ok], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if float(flag) == 1.0:
+        return sar
+    if sar is not None:
+        sar.close()
+    return group
 
 
 def shard_views(n_views, rank, world):
@@ -87,6 +173,10 @@ class ShardedStage1:
     rescales its share by Pv_local / Pv_global BEFORE the exchange — no second collective."""
 
     def __init__(self, hs1, view0, n_views_global, group=None):
+        """group: a torch.distributed group, or a StreamAllReduce on one (the iteration's all-reduce then runs on the step's stream)"""
+        self.sar = group if hasattr(group, "all_reduce_") else None
+        if self.sar is not None:
+            group = self.sar.group if self.sar.group is not None else dist.group.WORLD
         self.hs1, self.group, self.view0, self.n_global = hs1, group, int(view0), int(n_views_global)
         counts = torch.zeros(self.n_global, dtype=torch.float32, device=hs1.dev)
         counts[self.view0: self.view0 + hs1.n] = hs1.view_valid.to(torch.float32)
@@ -117,7 +207,10 @@ class ShardedStage1:
         loss = (hs1.loss_view.sum() * scale).reshape(1)
         if self.group is not None and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             buf = torch.cat([galbedo.reshape(-1), loss])
-            dist.all_reduce(buf, group=self.group)                # the iteration's ONE collective
+            if self.sar is not None:
+                self.sar.all_reduce_(buf)                         # the iteration's ONE collective, on the current stream
+            else:
+                dist.all_reduce(buf, group=self.group)
             galbedo, loss = buf[:-1].view_as(hs1.galbedo), buf[-1:]
         return loss[0], galbedo, gsh
 

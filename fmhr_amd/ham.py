@@ -127,6 +127,7 @@ class HamStage2:
         """Full forward + backward.  Returns (losses[8] device tensor, gdelta [V,3], galbedo [V,3]) — buffers owned by this
         object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded: the results
         are then the batch-global ones (summed over the ranks), identical on every rank.
+        `group` may also be a fmhr_amd.dist.StreamAllReduce (RCCL on this step's own stream: no cross-stream hand-over).
         `optimizer`, `params`: apply the Adam update of (delta, albedo) inside the step (no separate optimizer.step() launch).
         `reg_range` = (v0, v1): evaluate the view-independent terms for these vertices only (ranks take disjoint ranges covering
         [0, V): fmhr_amd.dist.shard_views(V, rank, world)); `reg_grads=False` switches them off on this rank."""
@@ -144,7 +145,10 @@ class HamStage2:
                       split=group is not None, adam=adam if group is None else (None, None))
         if group is not None:
             # the step's ONE collective (1.18 -> 2.35 MB at V = 49k: still latency-bound on xGMI), then P / (3 Pv) + R
-            torch.distributed.all_reduce(self.bucket, group=group)
+            if hasattr(group, "all_reduce_"):
+                group.all_reduce_(self.bucket, stream_ptr(self.dev))
+            else:
+                torch.distributed.all_reduce(self.bucket, group=group)
             self.combine(adam)
         return self.losses, self.gdelta, self.galbedo
 

@@ -214,7 +214,10 @@ def _rccl_worker(port, q):
     dev = faces.device
     vt = sc["vertices"].to(dev)
     out = {}
-    for name, group in (("sharded", dist.group.WORLD), ("plain", None)):
+    direct = fdist.make_stream_all_reduce(dist.group.WORLD)
+    say("direct communicator: " + type(direct).__name__)
+    out["direct_type"] = type(direct).__name__
+    for name, group in (("sharded", dist.group.WORLD), ("direct", direct), ("plain", None)):
         hs = HamStage2(faces, sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], edge_length_mean(vt, faces))
         delta = sc["delta"].clone().requires_grad_(True)
         albedo = sc["albedo0"].to(dev).clone().requires_grad_(True)
@@ -236,6 +239,8 @@ def _rccl_worker(port, q):
     lv, ga_ref, _ = hs1.step(alb1, shc)
     out["stage1"] = (float(loss), float(lv.sum()), ga.cpu().numpy(), ga_ref.cpu().numpy())
     say("stage 1 done")
+    if hasattr(direct, "close"):
+        direct.close()
     dist.barrier()
     say("barrier done")
     q.put(out)
@@ -267,5 +272,12 @@ def test_rccl_backend_world_of_one_through_the_sharded_step():
     # twelve Adam steps apart the two summation orders (P / (3 Pv) + R vs the fused sum) have drifted by what Adam makes of the last bits
     # (its first updates are ~lr x sign(g)): the parameters agree to 1e-4, the gradients to 2e-3
     assert e[0] < 1e-4 and max(e[1:3]) < 2e-3 and max(e[3:]) < 1e-4, e
+    # the same step with its all-reduce issued straight into RCCL on the step's stream (fmhr_amd.dist.StreamAllReduce)
+    assert out["direct_type"] == "StreamAllReduce", out["direct_type"]
+    ed = [rel_err(torch.from_numpy(x), torch.from_numpy(y)) for x, y in zip(out["direct_first"], out["plain_first"])]
+    ed12 = [rel_err(torch.from_numpy(x), torch.from_numpy(y)) for x, y in zip(out["direct"], out["sharded"])]
+    log_parity("RCCL on the step's own stream (StreamAllReduce, world of one) vs plain step, first step: losses %.1e gdelta %.1e galbedo %.1e | "
+               "vs the torch.distributed path after 12 steps: max %.1e" % (tuple(ed) + (max(ed12),)))
+    assert max(ed) < 5e-5 and ed12[0] < 1e-4 and max(ed12[1:3]) < 2e-3 and max(ed12[3:]) < 1e-4, (ed, ed12)
     l_s, l_p, ga_s, ga_p = out["stage1"]
     assert abs(l_s - l_p) <= 1e-6 * abs(l_p) and rel_err(torch.from_numpy(ga_s), torch.from_numpy(ga_p)) < 1e-6

@@ -1,8 +1,17 @@
-import time, torch, sys
-sys.path.insert(0, '/root/repo')
+"""tools/host_rate.py — how long does the HOST take to enqueue one step?  (plain step; with FMHR_FORCE_SHARDED=1 the view-sharded step
+with its all-reduce over RCCL, world of one: through torch.distributed, or FMHR_STREAM_ALLREDUCE=1 straight into RCCL)"""
+import os, time, torch, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fmhr_amd import synthetic
 from fmhr_amd.ham import HamStage2, edge_length_mean, render_forward
 from fmhr_amd.optim import Adam
+group = None
+if os.environ.get("FMHR_FORCE_SHARDED") == "1":
+    from fmhr_amd import dist as fdist
+    fdist.init_from_env()
+    torch.cuda.set_device(0)
+    group = fdist.make_stream_all_reduce(torch.distributed.group.WORLD)
+    print("group:", type(group).__name__)
 for views in (6, 48):
     sc = synthetic.scene_from_config("metric", 0, views)
     dev = torch.device("cuda:0")
@@ -15,9 +24,13 @@ for views in (6, 48):
     albedo = sc["albedo0"][None].to(dev).clone().requires_grad_(True)
     opt = Adam([{'params': delta, 'lr': 1e-4}, {'params': albedo, 'lr': 1e-3}])
     def step():
-        l, gd, ga = hs.step(vt, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"])
-        delta.grad, albedo.grad = gd, ga.view(1, V, 3)
-        opt.step()
+        if group is None and os.environ.get("HOST_RATE_SEPARATE_ADAM") == "1":
+            l, gd, ga = hs.step(vt, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"])
+            delta.grad, albedo.grad = gd, ga.view(1, V, 3)
+            opt.step()
+        else:
+            hs.step(vt, delta.detach(), albedo.detach()[0], sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"], group=group,
+                    reg_range=(0, V), optimizer=opt, params=(delta, albedo))
     for _ in range(20): step()
     torch.cuda.synchronize()
     K = 300

@@ -73,5 +73,32 @@ if len(sys.argv) > 2 and sys.argv[2] == "step":
                 optimizer=opt if use_opt else None, params=(delta, albedo) if use_opt else None)
     say("8 unsynchronised steps enqueued"); torch.cuda.synchronize(); say("  ... complete: loss %g" % float(hs.losses[6]))
     faulthandler.cancel_dump_traceback_later()
+if len(sys.argv) > 2 and sys.argv[2] == "direct":
+    # a second communicator inside the same RCCL instance, driven through ctypes on the caller's stream (fmhr_amd.dist.StreamAllReduce)
+    import traceback
+    sys.path.insert(0, ROOT)
+    from fmhr_amd import dist as fdist
+    try:
+        sar = fdist.StreamAllReduce(None)
+        say("StreamAllReduce constructed")
+        y = torch.arange(1000, device="cuda", dtype=torch.float32)
+        sar.all_reduce_(y)
+        torch.cuda.synchronize()
+        say("direct all-reduce complete: y[999] = %g" % float(y[999]))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        big = torch.zeros(12 * 49281 + 8, device="cuda")
+        for name, fn in (("direct", lambda: sar.all_reduce_(big)), ("torch", lambda: dist.all_reduce(big))):
+            for _ in range(20):
+                fn(); big.add_(1.0)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(200):
+                fn(); big.add_(1.0)            # a kernel of the same stream on either side of the call
+            e1.record()
+            torch.cuda.synchronize()
+            say("%s: %.2f us per (all-reduce + one elementwise kernel), world of one" % (name, e0.elapsed_time(e1) * 5.0))
+        sar.close()
+    except Exception:  # noqa: BLE001
+        say("direct path FAILED:\n" + traceback.format_exc())
 dist.destroy_process_group()
 say("destroyed; done")
