@@ -67,6 +67,13 @@ def _worker(rank, world, port, q):
     from test_gpu_ham import prepare
     r, w, _ = fdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
+    # the direct RCCL communicator (StreamAllReduce) only exists on the nccl backend: everywhere else the helper hands back the torch group
+    assert fdist.make_stream_all_reduce(dist.group.WORLD) is dist.group.WORLD
+    try:
+        fdist.StreamAllReduce(dist.group.WORLD)
+        raise AssertionError("StreamAllReduce must refuse a gloo group")
+    except RuntimeError:
+        pass
     sc = prepare(oracle, (5, 64, 48, 10, 14), 7)           # 5 views over 2 ranks: ragged 3 + 2 split
     s0, s1 = fdist.shard_views(sc["views"], rank, world)
     sh = fdist.ShardedStep(sc["V"], torch.device("cpu"))
