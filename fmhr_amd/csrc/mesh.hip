@@ -517,10 +517,14 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) { aa1[c] = sum_sub(aa1[c]); aa2[c] = sum_sub(aa2[c]); }
-    if (live && sub == 0) {
-        float rx = hg[0], ry = hg[1], rz = hg[2];         // everything that is NOT the photometric term: hinge, delta, silhouette share
-        gx += aa1[0]; gy += aa1[1]; gz += aa1[2];
-        rx += aa2[0]; ry += aa2[1]; rz += aa2[2];
+    // The vertex's results, one COMPONENT per lane (lanes 0..2; every lane of the vertex holds the 8-lane sums and forms the small
+    // vector quantities itself): six 4-B stores with three lanes active, a vertex's components one 12-B run — as one finishing lane per
+    // vertex they were eighteen stores with one lane in eight active.  The loss terms are still taken from lane 0 alone.
+    if (live && sub < 3) {
+        const int c = sub;
+        float r3[3] = {hg[0] + aa2[0], hg[1] + aa2[1], hg[2] + aa2[2]};   // everything that is NOT the photometric term: hinge, delta, silhouette share
+        const float g3[3] = {gx + aa1[0], gy + aa1[1], gz + aa1[2]};
+        const size_t i = (size_t)v * 3 + c;
         // (2) d/d nsum of the normalised vertex normal (models/utils.py:545, eps 1e-6)
         {
             float3 s = ld3(A.nsum + (size_t)v * 3);
@@ -534,34 +538,33 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
             } else {
                 o = make_float3(n0 * 1e6f, n1 * 1e6f, n2 * 1e6f);
             }
-            A.gs[(size_t)v * 3] = o.x; A.gs[(size_t)v * 3 + 1] = o.y; A.gs[(size_t)v * 3 + 2] = o.z;
+            A.gs[i] = (c == 0) ? o.x : ((c == 1) ? o.y : o.z);
         }
         // (3) row norms -> loss, scaled rows -> backward (part B); an isolated vertex has the row -x (models/utils.py:684)
         if (!mine) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) { A.rowg_v[(size_t)v * 3 + c] = 0.f; A.rowg_a[(size_t)v * 3 + c] = 0.f; }
+            A.rowg_v[i] = 0.f; A.rowg_a[i] = 0.f;
         } else {
             const float inv = (deg > 0) ? 1.0f / (float)deg : 0.0f;
             const float xs[3] = {xv.x, xv.y, xv.z}, as[3] = {xa.x, xa.y, xa.z};
 #pragma unroll
-            for (int c = 0; c < 3; c++) { lv[c] = (deg > 0) ? lv[c] * inv : -xs[c]; la[c] = (deg > 0) ? la[c] * inv : -as[c]; }
+            for (int k = 0; k < 3; k++) { lv[k] = (deg > 0) ? lv[k] * inv : -xs[k]; la[k] = (deg > 0) ? la[k] * inv : -as[k]; }
             float nv = sqrtf(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
             float na = sqrtf(la[0] * la[0] + la[1] * la[1] + la[2] * la[2]);
-            l_lap = nv; l_alb = na;
+            if (sub == 0) { l_lap = nv; l_alb = na; }
             float kv = (nv > 0.f) ? A.lap_w * A.rg / nv : 0.f, ka = (na > 0.f) ? A.alb_w * A.rg / na : 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; c++) { A.rowg_v[(size_t)v * 3 + c] = lv[c] * kv; A.rowg_a[(size_t)v * 3 + c] = la[c] * ka; }
+            A.rowg_v[i] = ((c == 0) ? lv[0] : ((c == 1) ? lv[1] : lv[2])) * kv;
+            A.rowg_a[i] = ((c == 0) ? la[0] : ((c == 1) ? la[1] : la[2])) * ka;
         }
         // (4) delta term (mesh_sfs_optim.py:304)
         if (mine) {
             float3 d = ld3(A.delta + (size_t)v * 3);
-            l_delta = d.x * d.x + d.y * d.y + d.z * d.z;
+            if (sub == 0) l_delta = d.x * d.x + d.y * d.y + d.z * d.z;
             float k = 2.f * A.delta_w * A.rg;
-            rx += k * d.x; ry += k * d.y; rz += k * d.z;
+            r3[0] += k * d.x; r3[1] += k * d.y; r3[2] += k * d.z;
         }
-        A.gacc_v[(size_t)v * 3] = gx; A.gacc_v[(size_t)v * 3 + 1] = gy; A.gacc_v[(size_t)v * 3 + 2] = gz;
-        A.gacc_r[(size_t)v * 3] = rx; A.gacc_r[(size_t)v * 3 + 1] = ry; A.gacc_r[(size_t)v * 3 + 2] = rz;
-        A.gacc_a[(size_t)v * 3] = a0; A.gacc_a[(size_t)v * 3 + 1] = a1; A.gacc_a[(size_t)v * 3 + 2] = a2;
+        A.gacc_v[i] = (c == 0) ? g3[0] : ((c == 1) ? g3[1] : g3[2]);
+        A.gacc_r[i] = (c == 0) ? r3[0] : ((c == 1) ? r3[1] : r3[2]);
+        A.gacc_a[i] = (c == 0) ? a0 : ((c == 1) ? a1 : a2);
     }
     // per-block partials (the finish block of k_mesh_tail_b adds them up: 4 x 1.5k same-address atomics would serialise for ~60 us).
     // ONE reduction for the four sums: four block_sum() calls in a row were eight workgroup barriers at the end of every workgroup
@@ -687,24 +690,35 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_b(const MeshTailArgs A, co
     acc.x = sum_sub(acc.x); acc.y = sum_sub(acc.y); acc.z = sum_sub(acc.z);
     acl.x = sum_sub(acl.x); acl.y = sum_sub(acl.y); acl.z = sum_sub(acl.z);
     aca.x = sum_sub(aca.x); aca.y = sum_sub(aca.y); aca.z = sum_sub(aca.z);
-    if (live && sub == 0) {
-        const float3 g0 = ld3(A.gacc_v + (size_t)v * 3), r0 = ld3(A.gacc_r + (size_t)v * 3), h0 = ld3(A.gacc_a + (size_t)v * 3);
-        const float3 rv = ld3(A.rowg_v + (size_t)v * 3), ra = ld3(A.rowg_a + (size_t)v * 3);
+    // Final combination, one (parameter, component) per lane: lanes 0..2 of a vertex finish delta.x/y/z, lanes 3..5 albedo.x/y/z (every
+    // lane holds the 8-lane sums).  As one finishing lane per vertex this section was ~57 memory instructions of 4-B accesses with one
+    // lane in eight active (five 3-component loads, up to twelve stores, 2 x 3 Adam elements of three loads + three stores each) — the
+    // Adam update alone was 4.6 of the kernel's 14 us (k_mesh_tail_b 9.4 us in the split form, which leaves it to the combine kernel);
+    // now it is ten, and a vertex's three components go out as one 12-B run.  Same statements per component: bit-identical.
+    if (live && sub < 6) {
+        const bool is_alb = sub >= 3;
+        const int c = is_alb ? sub - 3 : sub;
+        const size_t i = (size_t)v * 3 + c;
+        const float* const src_g = is_alb ? A.gacc_a : A.gacc_v;
+        const float* const src_row = is_alb ? A.rowg_a : A.rowg_v;
+        const float g0 = src_g[i], row = src_row[i];
+        const float r0 = is_alb ? 0.f : A.gacc_r[i];
+        const float nb = (c == 0) ? acc.x : ((c == 1) ? acc.y : acc.z);
+        const float lt = is_alb ? ((c == 0) ? aca.x : ((c == 1) ? aca.y : aca.z)) : ((c == 0) ? acl.x : ((c == 1) ? acl.y : acl.z));
         // photometric share (with the batch-global L1 divisor already in it on one rank, left out when view-sharded) | the rest
-        const float pd[3] = {g0.x + acc.x, g0.y + acc.y, g0.z + acc.z}, rd[3] = {r0.x + acl.x - rv.x, r0.y + acl.y - rv.y, r0.z + acl.z - rv.z};
-        const float pa[3] = {h0.x, h0.y, h0.z}, rr[3] = {aca.x - ra.x, aca.y - ra.y, aca.z - ra.z};
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            if (A.gd_rest != nullptr) {
-                A.gdelta[(size_t)v * 3 + c] = pd[c]; A.galbedo[(size_t)v * 3 + c] = pa[c];
-                A.gd_rest[(size_t)v * 3 + c] = rd[c]; A.ga_rest[(size_t)v * 3 + c] = rr[c];
-            } else {
-                const float gd = pd[c] + rd[c], gal = pa[c] + rr[c];
-                A.gdelta[(size_t)v * 3 + c] = gd; A.galbedo[(size_t)v * 3 + c] = gal;
-                // the parameters' final gradients are in registers: apply the optimiser step here (nothing in this kernel reads them)
-                if (A.ad_d.p != nullptr) adam_element(A.ad_d, (long long)v * 3 + c, gd);
-                if (A.ad_a.p != nullptr) adam_element(A.ad_a, (long long)v * 3 + c, gal);
-            }
+        float ph, rest;
+        if (is_alb) { ph = g0; rest = lt - row; }
+        else { ph = g0 + nb; rest = r0 + lt - row; }
+        float* const out_p = is_alb ? A.galbedo : A.gdelta;
+        if (A.gd_rest != nullptr) {
+            float* const out_r = is_alb ? A.ga_rest : A.gd_rest;
+            out_p[i] = ph; out_r[i] = rest;
+        } else {
+            const float g = ph + rest;
+            out_p[i] = g;
+            // the parameters' final gradients are in registers: apply the optimiser step here (nothing in this kernel reads them)
+            if (is_alb) { if (A.ad_a.p != nullptr) adam_element(A.ad_a, (long long)i, g); }
+            else if (A.ad_d.p != nullptr) adam_element(A.ad_d, (long long)i, g);
         }
     }
     FMHR_WTS_END(tailb);
