@@ -388,7 +388,7 @@ __device__ __forceinline__ void normals_gather_body(int blk, const float* __rest
     p = add3(p, pd);
     float3 acc = make_float3(0.f, 0.f, 0.f);
     if (live) {
-        if (vout != nullptr && sub == 0) { vout[(size_t)vv * 3] = p.x; vout[(size_t)vv * 3 + 1] = p.y; vout[(size_t)vv * 3 + 2] = p.z; }
+        if (vout != nullptr && sub < 3) vout[(size_t)vv * 3 + sub] = (sub == 0) ? p.x : ((sub == 1) ? p.y : p.z);
         if (he) {
             float3 c = cross3(sub3(add3(a, ad), p), sub3(add3(b, bd), p));      // corner k: cross(v[k+1]-v[k], v[k+2]-v[k]) (models/utils.py:517-543)
             acc.x += c.x; acc.y += c.y; acc.z += c.z;
@@ -405,14 +405,18 @@ __device__ __forceinline__ void normals_gather_body(int blk, const float* __rest
         }
     }
     acc.x = sum_sub(acc.x); acc.y = sum_sub(acc.y); acc.z = sum_sub(acc.z);
-    if (!live || sub != 0) return;
-    nsum[(size_t)v * 3] = acc.x; nsum[(size_t)v * 3 + 1] = acc.y; nsum[(size_t)v * 3 + 2] = acc.z;
-    float len = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
-    float inv = 1.0f / fmaxf(len, 1e-6f);
-    normals[(size_t)v * 3] = acc.x * inv; normals[(size_t)v * 3 + 1] = acc.y * inv; normals[(size_t)v * 3 + 2] = acc.z * inv;
-    if (attr8 != nullptr) {     // packed per-vertex attributes for the pixel kernels: (normal.xyz, albedo.x | albedo.yz, 0, 0)
-        attr8[(size_t)v * 2] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, al.x);
-        attr8[(size_t)v * 2 + 1] = make_float4(al.y, al.z, 0.f, 0.f);
+    // results: one component per lane (lanes 0..2: the vertex, its normal sum, its normal), the two packed attribute words from lanes 3
+    // and 4 — four store instructions instead of eleven from one finishing lane in eight (every lane holds the sums)
+    if (!live) return;
+    const float len = sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z);
+    const float inv = 1.0f / fmaxf(len, 1e-6f);
+    if (sub < 3) {
+        const size_t i = (size_t)v * 3 + sub;
+        const float ac = (sub == 0) ? acc.x : ((sub == 1) ? acc.y : acc.z);
+        nsum[i] = ac;
+        normals[i] = ac * inv;
+    } else if (attr8 != nullptr && sub < 5) {     // packed per-vertex attributes for the pixel kernels: (normal.xyz, albedo.x | albedo.yz, 0, 0)
+        attr8[(size_t)v * 2 + (sub - 3)] = (sub == 3) ? make_float4(acc.x * inv, acc.y * inv, acc.z * inv, al.x) : make_float4(al.y, al.z, 0.f, 0.f);
     }
 }
 

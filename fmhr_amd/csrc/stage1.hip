@@ -378,13 +378,10 @@ k_s1_bwd(const S1Plan P, const float* __restrict__ R, const float* __restrict__ 
         }
     }
     g0 = s1_sum_sub(g0); g1 = s1_sum_sub(g1); g2 = s1_sum_sub(g2);
-    if (live && sub == 0) {
-        const float g[3] = {g0, g1, g2};
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            galbedo[(size_t)v * 3 + c] = g[c];
-            if (ad_a.p != nullptr) adam_element(ad_a, (long long)v * 3 + c, g[c]);
-        }
+    if (live && sub < 3) {          // one component per lane (every lane holds the sums): a 12-B run per vertex, a third of the instructions
+        const float g = (sub == 0) ? g0 : ((sub == 1) ? g1 : g2);
+        galbedo[(size_t)v * 3 + sub] = g;
+        if (ad_a.p != nullptr) adam_element(ad_a, (long long)v * 3 + sub, g);
     }
 }
 
