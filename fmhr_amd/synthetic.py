@@ -26,6 +26,9 @@ CONFIGS = {
     "C3": (16, 512, 512, "mano", 0, 3),
     "metric": (48, 512, 512, "mano", 0, 3),
     "C4": (48, 1024, 1024, "mano", 0, 3),
+    # experiments only (the view-stride question): the metric workload with eight more rows, so that the views' pixel
+    # arrays lie 4.06 MiB apart instead of exactly 4 MiB
+    "metric_h520": (48, 520, 512, "mano", 0, 3),
     # BASELINE.json configs[4]: two hands (each subdivided on its own, concatenated as mesh_sfs_optim.py:76-87,100-111 does),
     # 32 views x 8 frames of 334 x 512 (conf/ih_sfsseq.conf:11-13); a frame is an independent (delta, albedo) problem on the shared
     # topology (fmhr_amd.dist.shard_frames_views)
