@@ -10,6 +10,7 @@ namespace fmhr {
 struct MeshTailArgs {
     const float4* part; float* gvert_aa; int G;
     float* gvert_aa2;
+    float* vacc;
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     const int32_t* col_mult;
@@ -56,14 +57,14 @@ int loss_pix_impl(const unsigned long long*, const float*, const float*, const f
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
                   const int*, const int32_t*, const float*, const float*, const int*, int, int, int, int, int, float*,
-                  const int2*, const int2*, const int*, const unsigned long long*, hipStream_t);
+                  const int2*, const int2*, const int*, const unsigned long long*, float*, hipStream_t);
 int face_bwd_groups(int n);
 int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
-        g_shaded, cmat, gvert_aa, gvert_aa2, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, total;
+        g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -109,6 +110,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.cmat = take(off, (size_t)d->n * 64);
     L.gvert_aa = take(off, V * 12 * kAaReplicas);
     L.gvert_aa2 = take(off, V * 12 * kAaReplicas);             // view-sharded step: the silhouette share of the antialias position gradient
+    L.vacc = take(off, V * 48);                                  // per vertex 3 float4: sums of the large-box faces' backward (shade.hip), self-cleaning
     L.part = take(off, (size_t)face_bwd_groups(d->n) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
     L.partials = take(off, 2048 * 4 * 3);           // per-workgroup partial sums of the persistent pixel kernels
     L.gnormal = take(off, V * 12);
@@ -181,7 +183,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(own8); FMHR_OFF(stamp); FMHR_OFF(pix16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
-    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(aa_counter); FMHR_OFF(aa_region_cnt); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(part);
+    FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(aa_counter); FMHR_OFF(aa_region_cnt); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(vacc); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(silw); FMHR_OFF(bins); FMHR_OFF(bin_cursor); FMHR_OFF(total);
 #undef FMHR_OFF
     set_error("ham_workspace_offset: unknown buffer '%s'", name);
@@ -214,6 +216,7 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     // self-cleaning accumulator: k_mesh_tail_a zeroes each entry after consuming it
     HIPTRY(hipMemsetAsync(w + L.gvert_aa, 0, (size_t)d->V * 12 * kAaReplicas, (hipStream_t)stream), "init gvert_aa");
     HIPTRY(hipMemsetAsync(w + L.gvert_aa2, 0, (size_t)d->V * 12 * kAaReplicas, (hipStream_t)stream), "init gvert_aa2");
+    HIPTRY(hipMemsetAsync(w + L.vacc, 0, (size_t)d->V * 48, (hipStream_t)stream), "init vacc");
     {
         const float third = 1.0f / 3.0f;           // 3 * (1/3) == 1 exactly in fp32: the kernels' divisor 3 * n_valid becomes 1
         HIPTRY(hipMemcpyAsync(w + L.one_third, &third, 4, hipMemcpyHostToDevice, (hipStream_t)stream), "init one_third");
@@ -362,7 +365,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                           w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot,
                           (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part),
                           (const int2*)(w + L.snap), (const int2*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W) + 16),
-                          (const int*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W)), (const unsigned long long*)(w + L.covw), st));
+                          (const int*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W)), (const unsigned long long*)(w + L.covw),
+                          (float*)(w + L.vacc), st));
     }
     {
         // everything per-vertex after the face-parallel backward, in two kernels (mesh.hip: k_mesh_tail_a / _b)
@@ -370,6 +374,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         MeshTailArgs A;
         A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n);
         A.gvert_aa2 = split ? (float*)(w + L.gvert_aa2) : nullptr; A.col_mult = col_mult;
+        A.vacc = (float*)(w + L.vacc);
         A.gacc_r = (float*)(w + L.gvert_r);
         A.gdelta = gdelta; A.galbedo = galbedo; A.gd_rest = gdelta_rest; A.ga_rest = galbedo_rest;
         TRY(adam_tensor_from(A.ad_d, adam_delta, 3ll * d->V));

@@ -429,6 +429,7 @@ __device__ __forceinline__ void normals_gather_body(int blk, const float* __rest
 struct MeshTailArgs {
     const float4* part; float* gvert_aa; int G;                                       // face-backward corner sums [G, 3F] x 3 float4
     float* gvert_aa2;                                                                 // split mode: the silhouette share of the antialias position gradient
+    float* vacc;                                                                      // [V] x 3 float4: the large-box faces' backward sums per vertex (shade.hip), packed like a corner slot
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     const int32_t* col_mult;                                                          // faces per adjacency entry (fmhr_edge_multiplicity_build)
@@ -472,6 +473,16 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
             else if (slot == 1) { a1 += acc.x; a2 += acc.y; gx += acc.z; gy += acc.w; }
             else gz += acc.x;
         }
+    }
+    // (1b) what the workers of the large-box queue added for this vertex (a handful of vertices per step; zero everywhere else): three
+    //      float4 in the packing of a corner slot, taken by lanes 0..2 and re-zeroed for the next step
+    if (live && sub < 3 && A.vacc != nullptr) {
+        float4* q = reinterpret_cast<float4*>(A.vacc) + (size_t)vv * 3 + sub;
+        const float4 t = *q;
+        if (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f) *q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sub == 0) { n0 += t.x; n1 += t.y; n2 += t.z; a0 += t.w; }
+        else if (sub == 1) { a1 += t.x; a2 += t.y; gx += t.z; gy += t.w; }
+        else gz += t.x;
     }
     // (3) uniform Laplacians of the vertices and of the albedo: differences accumulated per neighbour
     float lv[3] = {0.f, 0.f, 0.f}, la[3] = {0.f, 0.f, 0.f};

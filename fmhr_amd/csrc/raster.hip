@@ -186,7 +186,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
               int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
               int2* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
               const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg,
-              unsigned char* __restrict__ own8, const BinArgs ba)
+              unsigned char* __restrict__ own8, const BinArgs ba, const int defer_large)
 {
     FMHR_WTS_BEGIN(raster, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kTrisBlock / 64) + (threadIdx.x >> 6));
     // the parked triangles as FOUR arrays of 16-B words (a 64-B record per lane put the lanes of a ds_read_b128 lane group on
@@ -309,14 +309,20 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     const int incl = wave_incl_scan(cnt);                            // DPP: no LDS-crossbar instructions
     if (lane == 63) wtot[wv] = incl;
     unsigned long long lbal = __ballot(is_large);                    // lanes holding a large-box triangle
-    if (large_q != nullptr && lbal != 0ull) {                        // queue mode: one cursor atomic per wave (same-address atomics
-        int base = 0;                                                // serialise at ~10 ns each: 1.5 k pushes of a hand in one view)
+    // Large-box (view, face)s go on a queue: one cursor atomic per wave (same-address atomics serialise at ~10 ns each: 1.5 k pushes
+    // of a hand in one view).  A coarse mesh (defer_large) leaves their rasterization to k_raster_large, one workgroup per triangle; on a
+    // micro-triangle mesh the odd large box is swept by its wave below and the queue only feeds the BACKWARD's wave-per-face workers
+    // (shade.hip: face_bwd_large_items)
+    if (large_q != nullptr && lbal != 0ull) {
+        int base = 0;
         const int leader = __builtin_ctzll(lbal);
         if (lane == leader) base = atomicAdd(large_cnt, __popcll(lbal));
         base = __shfl(base, leader, 64);
         if (is_large) large_q[base + __popcll(lbal & ((1ull << lane) - 1ull))] = make_int2(b, f);
-        is_large = false;
-        lbal = 0ull;
+        if (defer_large) {
+            is_large = false;
+            lbal = 0ull;
+        }
     }
     if (cm != 0u) {
         // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
@@ -1153,7 +1159,11 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
             if (e != hipSuccess) return hip_fail(e, "memset large_cnt");
         }
     }
-    int2* lq = use_queue ? large_q : nullptr;
+    // the fused step always queues its large-box (view, face)s (the backward's wave-per-face workers read the queue); the generic op
+    // only when it hands them to k_raster_large
+    const bool fused_step = fused != nullptr && fu.cov16 != nullptr;
+    int2* lq = (use_queue || fused_step) ? large_q : nullptr;
+    const int defer = use_queue ? 1 : 0;
     const PixGrid pg = make_pix_grid(H, W);
     // binned form (fused step, micro-triangle mesh, W % 64 == 0): per-segment fragment bins + k_raster_bins instead of the
     // global depth keys + k_raster_resolve.  FMHR_RASTER_BINNED=0 / 1 overrides the default (same-library A/B: tools/abn.sh)
@@ -1169,11 +1179,11 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
         const dim3 tgrid(cdiv(F, kTrisBlock), n);                    // view = blockIdx.y
         if (binned)
-            k_raster_tris<true, true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba);
+            k_raster_tris<true, true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer);
         else if (fu.verts != nullptr)
-            k_raster_tris<true, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba);
+            k_raster_tris<true, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer);
         else
-            k_raster_tris<false, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg, fu.stamp != nullptr ? fu.own8 : nullptr, ba);
+            k_raster_tris<false, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg, fu.stamp != nullptr ? fu.own8 : nullptr, ba, defer);
         FMHR_CHECK_LAUNCH("k_raster_tris");
     }
     if (binned) {

@@ -323,7 +323,7 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
            const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
            const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
-           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg, const int g, const int b0)
+           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg, const int g, const int b0, const int fb0)
 {
     FMHR_WTS_BEGIN(shade, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kFbBlock / 64) + (threadIdx.x >> 6));
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
@@ -334,7 +334,7 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
     __shared__ unsigned short tasks[kFacesPerBlock][kTaskG];
     const long long P = (long long)H * W;
     const int tid = threadIdx.x, j = tid & (kGroup - 1), gl = tid / kGroup, lane = tid & 63;
-    const int f = blockIdx.x * kFacesPerBlock + gl;
+    const int f = ((int)blockIdx.x - fb0) * kFacesPerBlock + gl;          // (fb0: the row's first face workgroup)
     // view of (lane j, slot v) = b0 + v * kGroup + j
     const bool facelive = f < F;                                   // uniform over a group
     // ---- the coverage entries of this lane's (face, view)s; entries of other steps carry another stamp
@@ -612,90 +612,42 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
     FMHR_WTS_END(shade);
 }
 
-// VA views per lane in every view group but (VB != VA) the last, which holds the remainder in VB per lane: 48 views = a 32-view group
-// (4 per lane) + a 16-view group that runs the 2-per-lane instantiation instead of the 4-per-lane one with half its slots empty
-template <int VA, int VB>
-__global__ void __launch_bounds__(kFbBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))       // <= 128 VGPRs: 4 waves per SIMD
-k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
-           const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
-           const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
-           const int32_t* __restrict__ corner_slot,
-           const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
-           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg)       // skip_lists: queued large-box faces have their own kernel
-{
-    const int g = blockIdx.y;
-    if (VB != VA && g == (int)gridDim.y - 1)                       // (block-uniform)
-        face_bwd_body<VB>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, llink, n, V, F, H, W, part, skip_lists,
-                          pg, g, g * kGroup * VA);
-    else
-        face_bwd_body<VA>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, llink, n, V, F, H, W, part, skip_lists,
-                          pg, g, g * kGroup * VA);
-}
+struct LargeArgs { const int2* snap; const int2* large_q; const int* large_cnt; const unsigned long long* covw; float* vacc; int workers; };
 
-int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char* vmnz, hipStream_t st)
-{
-    if (N == 0) return FMHR_OK;
-    k_valid_mask_segments<<<cdiv(N, kBlock), kBlock, 0, st>>>(valid_mask, N, vmnz);
-    FMHR_CHECK_LAUNCH("k_valid_mask_segments");
-    return FMHR_OK;
-}
-
-int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
-                         int* act_list, int* act_count, const int* seg_valid, float* cnt_part, float* aa_init, hipStream_t st)
-{
-    if (N == 0) return FMHR_OK;
-    long long nSeg = (N + 63) >> 6;
-    k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, seg_valid, cnt_part, N,
-                                                                   (float4*)aa_init);
-    FMHR_CHECK_LAUNCH("k_active_segments");
-    return FMHR_OK;
-}
-
-int active_segments_blocks(long long N) { return cdiv((N + 63) >> 6, kActBlock); }
-
-int densify_impl(const unsigned long long* covw, const unsigned char* act, long long N, const float* pix16, float* rast, float* aa,
-                 hipStream_t st)
-{
-    if (N == 0) return FMHR_OK;
-    k_densify<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, act, N, (const float4*)pix16, (float4*)rast, (float4*)aa);
-    FMHR_CHECK_LAUNCH("k_densify");
-    return FMHR_OK;
-}
-
-int loss_pix_impl(const unsigned long long* covw, const float* aa, const float* img, const float* mask, const float* valid_mask,
-                  long long N, const int* act_list, const int* act_count, const float* n_valid_global, float w_sfs, float w_mask,
-                  float mse_den, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
-{
-    if (N == 0) return FMHR_OK;
-    k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>(covw, (const float4*)aa, img, mask, valid_mask, N, act_list, act_count,
-                                                  n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_shaded, part_l1,
-                                                  part_l2, losses);
-    FMHR_CHECK_LAUNCH("k_loss_pix");
-    return FMHR_OK;
-}
-
-// Backward of the queued large-box (view, face)s of a coarse mesh (raster_use_queue): ONE WAVE per (view, face) scans the face's
-// bounding box, 64 pixels per iteration (independent loads), does the per-pixel backward for the pixels the face owns, sums the
-// 27 corner values over the wave and adds them to the face's corner slots (k_face_bwd wrote them before; float atomics, a few
-// hundred thousand per step).  Inside k_face_bwd one lane walks a ~200-pixel linked list per (view, face): a dependent load per
-// pixel — 187 us for a 778-vertex hand in 8 views of 512 x 334.
-__global__ void __launch_bounds__(kBlock)
-k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const int2* __restrict__ snap,
-                 const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
-                 const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, const float* __restrict__ verts,
-                 const int2* __restrict__ large_q, const int* __restrict__ large_cnt, const unsigned long long* __restrict__ covw,
-                 int n, int V, int F, int H, int W, int GV, float* __restrict__ part, const PixGrid pg)
+// Backward of the queued large-box (view, face)s: ONE WAVE per (view, face) scans the face's bounding box, 64 pixels per iteration
+// (independent loads), does the per-pixel backward for the pixels the face owns and sums the 27 corner values over the wave.
+// Inside k_face_bwd one lane walked a linked list of the face's pixels instead: a dependent load per pixel with its whole wave waiting —
+// 187 us for a 778-vertex hand in 8 views of 512 x 334 (every triangle is a large-box one), and on the metric mesh the reason why the
+// kernel slowed down during an optimisation run: sliver triangles appear (0 large boxes among the owners at step 64, 110 at step 320,
+// 670 at step 960; median 36 -> 56 pixels, up to 240: tools/analysis/face_bwd_over_steps.py) and took it from 73 to 85 .. 137 us.
+//   TO_VACC = false (coarse mesh, thousands of items, a launch of its own after k_face_bwd): float atomics into the face's corner
+//             slots of `part`, which k_face_bwd wrote before;
+//   TO_VACC = true  (micro-triangle mesh, a few hundred items, run by EXTRA WORKGROUPS of the k_face_bwd launch itself, concurrently
+//             with the faces): float atomics into vacc [V] x 3 float4, per VERTEX the packing of one corner slot (normal.xyz albedo.x |
+//             albedo.yz vertex.xy | vertex.z), which k_mesh_tail_a adds to the vertex's corner sums and re-zeroes — the faces' own plain
+//             stores to `part` and these atomics never meet.
+template <bool TO_VACC>
+__device__ __forceinline__ void
+face_bwd_large_items(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const int2* __restrict__ snap,
+                     const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
+                     const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, const float* __restrict__ verts,
+                     const int2* __restrict__ large_q, const int* __restrict__ large_cnt, const unsigned long long* __restrict__ covw,
+                     const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
+                     int n, int V, int F, int H, int W, int GV, float* __restrict__ out, const PixGrid pg, int first, int stride)
 {
     constexpr int kWaves = kBlock / 64;
     __shared__ float view_c[kWaves][28];
     __shared__ FaceAttr pk[kWaves];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int cnt = large_cnt[1];                                  // the resolve pass kept a copy when it rearmed the queue
+    const int cnt = large_cnt[1];                                  // the second rasterizer pass kept a copy when it rearmed the queue
     const long long P = (long long)H * W;
     const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;
-    for (int it = blockIdx.x * kWaves + wv; it < cnt; it += gridDim.x * kWaves) {      // wave-uniform
+    const unsigned char cur = own8 != nullptr ? (unsigned char)stamp[0] : (unsigned char)0;
+    for (int it = first; it < cnt; it += stride) {                 // wave-uniform
         const int2 bf = large_q[it];
         const int b = bf.x, f = bf.y;
+        // the queue holds every large-box (view, face) of the step; only the ones that own a pixel have anything to do
+        if (own8 != nullptr && own8[(size_t)b * F + f] != cur) continue;
         const int3a ti = *reinterpret_cast<const int3a*>(tri + (size_t)f * 3);
         if (lane < 28) {
             const int k = lane;                                    // the view's SH row, then the matrix rows as (x, y, w, z)
@@ -752,7 +704,9 @@ k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ t
             float o[9];
 #pragma unroll
             for (int c = 0; c < 9; c++) o[c] = (lane == 0) ? A[0][c] : ((lane == 1) ? A[1][c] : A[2][c]);
-            float* dst = part + (((size_t)(b / GV) * 3 * F + corner_slot[f * 3 + lane]) * 3) * 4;
+            const int vtx = (lane == 0) ? ti.x : ((lane == 1) ? ti.y : ti.z);
+            float* dst = TO_VACC ? out + (size_t)vtx * 12
+                                 : out + (((size_t)(b / GV) * 3 * F + corner_slot[f * 3 + lane]) * 3) * 4;
 #pragma unroll
             for (int c = 0; c < 9; c++)
                 if (o[c] != 0.f) atomicAdd(dst + c, o[c]);
@@ -760,6 +714,90 @@ k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ t
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();                           // the LDS slots are free for the wave's next item
     }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const int2* __restrict__ snap,
+                 const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
+                 const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, const float* __restrict__ verts,
+                 const int2* __restrict__ large_q, const int* __restrict__ large_cnt, const unsigned long long* __restrict__ covw,
+                 int n, int V, int F, int H, int W, int GV, float* __restrict__ part, const PixGrid pg)
+{
+    constexpr int kWaves = kBlock / 64;
+    face_bwd_large_items<false>(bwd16, tri, snap, attr8, sh, g_shaded, corner_slot, cmat, verts, large_q, large_cnt, covw, nullptr, nullptr,
+                                n, V, F, H, W, GV, part, pg, blockIdx.x * kWaves + (threadIdx.x >> 6), gridDim.x * kWaves);
+}
+
+// VA views per lane in every view group but (VB != VA) the last, which holds the remainder in VB per lane: 48 views = a 32-view group
+// (4 per lane) + a 16-view group that runs the 2-per-lane instantiation instead of the 4-per-lane one with half its slots empty
+template <int VA, int VB>
+__global__ void __launch_bounds__(kFbBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))       // <= 128 VGPRs: 4 waves per SIMD
+k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, const float* __restrict__ pos,
+           const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
+           const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
+           const int32_t* __restrict__ corner_slot,
+           const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
+           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg,       // skip_lists: queued large-box faces are not walked here
+           const LargeArgs la)
+{
+    const int g = blockIdx.y;
+    // the FIRST la.workers workgroups of every grid row are set aside (micro-triangle mesh only); those of row 0 are the workers of the
+    // large-box queue — one wave per queued (view, face), dispatched ahead of the faces and running concurrently with them
+    if ((int)blockIdx.x < la.workers) {
+        static_assert(kFbBlock == kBlock, "the queue workers use k_face_bwd_large's wave layout");
+        if (g == 0)
+            face_bwd_large_items<true>(bwd16, tri, la.snap, attr8, sh, g_shaded, corner_slot, cmat, verts, la.large_q, la.large_cnt, la.covw, own8, stamp,
+                                       n, V, F, H, W, 0, la.vacc, pg, (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6), la.workers * (kBlock / 64));
+        return;
+    }
+    if (VB != VA && g == (int)gridDim.y - 1)                       // (block-uniform)
+        face_bwd_body<VB>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, llink, n, V, F, H, W, part, skip_lists,
+                          pg, g, g * kGroup * VA, la.workers);
+    else
+        face_bwd_body<VA>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, llink, n, V, F, H, W, part, skip_lists,
+                          pg, g, g * kGroup * VA, la.workers);
+}
+
+int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char* vmnz, hipStream_t st)
+{
+    if (N == 0) return FMHR_OK;
+    k_valid_mask_segments<<<cdiv(N, kBlock), kBlock, 0, st>>>(valid_mask, N, vmnz);
+    FMHR_CHECK_LAUNCH("k_valid_mask_segments");
+    return FMHR_OK;
+}
+
+int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
+                         int* act_list, int* act_count, const int* seg_valid, float* cnt_part, float* aa_init, hipStream_t st)
+{
+    if (N == 0) return FMHR_OK;
+    long long nSeg = (N + 63) >> 6;
+    k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, seg_valid, cnt_part, N,
+                                                                   (float4*)aa_init);
+    FMHR_CHECK_LAUNCH("k_active_segments");
+    return FMHR_OK;
+}
+
+int active_segments_blocks(long long N) { return cdiv((N + 63) >> 6, kActBlock); }
+
+int densify_impl(const unsigned long long* covw, const unsigned char* act, long long N, const float* pix16, float* rast, float* aa,
+                 hipStream_t st)
+{
+    if (N == 0) return FMHR_OK;
+    k_densify<<<cdiv(N, kBlock), kBlock, 0, st>>>(covw, act, N, (const float4*)pix16, (float4*)rast, (float4*)aa);
+    FMHR_CHECK_LAUNCH("k_densify");
+    return FMHR_OK;
+}
+
+int loss_pix_impl(const unsigned long long* covw, const float* aa, const float* img, const float* mask, const float* valid_mask,
+                  long long N, const int* act_list, const int* act_count, const float* n_valid_global, float w_sfs, float w_mask,
+                  float mse_den, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
+{
+    if (N == 0) return FMHR_OK;
+    k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>(covw, (const float4*)aa, img, mask, valid_mask, N, act_list, act_count,
+                                                  n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_shaded, part_l1,
+                                                  part_l2, losses);
+    FMHR_CHECK_LAUNCH("k_loss_pix");
+    return FMHR_OK;
 }
 
 // views per lane: one group spans the whole batch when it can (up to kGroup * kMaxVPL = 48 views).  Measured at 48 views, with
@@ -773,16 +811,25 @@ int face_bwd_blocks(int F) { return cdiv(F, kFacesPerBlock); }
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
                   const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
                   const float* verts, const int* llink, int n, int V, int F, int H, int W, float* part,
-                  const int2* snap, const int2* large_q, const int* large_cnt, const unsigned long long* covw, hipStream_t st)
+                  const int2* snap, const int2* large_q, const int* large_cnt, const unsigned long long* covw, float* vacc, hipStream_t st)
 {
     if (n == 0 || F == 0) return FMHR_OK;
-    const dim3 grid(cdiv(F, kFacesPerBlock), face_bwd_groups(n));
-    const int skip_lists = raster_use_queue(H, W, F) ? 1 : 0;      // coarse mesh: the queued large-box faces get their own kernel
+    // large-box (view, face)s: a coarse mesh (every triangle is one) gives them a launch of their own after this one; a micro-triangle
+    // mesh (a few hundred slivers late in an optimisation run) kLargeWorkers extra workgroups of THIS launch, which add their sums to
+    // `vacc` (per vertex) for the mesh tail.  Either way no lane of k_face_bwd walks a pixel list any more.
+    const bool coarse = raster_use_queue(H, W, F);
+    constexpr int kLargeWorkers = 256;                             // x 4 waves: one queued (view, face) per wave and round; an idle one leaves at once
+    LargeArgs la;
+    la.snap = snap; la.large_q = large_q; la.large_cnt = large_cnt; la.covw = covw; la.vacc = vacc;
+    const bool workers = !coarse && vacc != nullptr;
+    la.workers = workers ? kLargeWorkers : 0;
+    const dim3 grid(cdiv(F, kFacesPerBlock) + la.workers, face_bwd_groups(n));
+    const int skip_lists = (coarse || workers) ? 1 : 0;
     const PixGrid pg = make_pix_grid(H, W);
 #define FMHR_FACE_BWD(VA, VB)                                                                                                       \
     k_face_bwd<VA, VB><<<grid, kFbBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded, \
                                              (const int2*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
-                                             (float4*)part, skip_lists, pg)
+                                             (float4*)part, skip_lists, pg, la)
     static_assert(kMaxVPL <= 4, "the instantiation table below stops at 4 views per lane");
     {
         const int va = face_bwd_vpl(n), rem = n - (face_bwd_groups(n) - 1) * kGroup * va;       // views of the last group
@@ -802,7 +849,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     }
 #undef FMHR_FACE_BWD
     FMHR_CHECK_LAUNCH("k_face_bwd");
-    if (skip_lists) {
+    if (coarse) {
         k_face_bwd_large<<<2048, kBlock, 0, st>>>((const float4*)bwd16, tri, snap, (const float4*)attr8, sh, (const float4*)g_shaded, corner_slot,
                                                   (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, kGroup * face_bwd_vpl(n), part, pg);
         FMHR_CHECK_LAUNCH("k_face_bwd_large");
