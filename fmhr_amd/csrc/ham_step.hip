@@ -56,14 +56,14 @@ int geometry_impl(const float*, const float*, const float*, const float*, int, i
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
-                  const int*, const int32_t*, const float*, const float*, const int*, int, int, int, int, int, float*,
+                  const int*, const int32_t*, const float*, const float*, int, int, int, int, int, float*,
                   const int2*, const int2*, const int*, const unsigned long long*, float*, hipStream_t);
 int face_bwd_groups(int n);
 int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, llink, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
+    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
         g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, total;
 };
 
@@ -97,7 +97,6 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.own8 = take(off, (size_t)d->n * d->F);      // per (view, face): low byte of the last step in which it owned a pixel
     L.stamp = take(off, 16);                       // step counter tagging the coverage entries
     L.pix16 = take(off, nP * 16);             // per covered pixel: (u, v, z/w, packed face id | flags | silhouette bits)
-    L.llink = take(off, nP * 4);              // list links of the pixels of large-box faces (written for those pixels only)
     L.rast = take(off, nP * 16);
     L.shaded = take(off, nP * 16);            // inspection only (fmhr_ham_densify re-shades into it): the step keeps no shaded image
     L.aa = take(off, nP * 16);
@@ -278,7 +277,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         RasterFused fu;
         fu.cov16 = (int2*)(w + L.cov16); fu.stamp = (int*)(w + L.stamp); fu.own8 = (unsigned char*)(w + L.own8);
         fu.pix16 = (float4*)(w + L.pix16); fu.mask = mask;
-        fu.silh = (const unsigned char*)(w + L.silh); fu.llink = (int*)(w + L.llink);
+        fu.silh = (const unsigned char*)(w + L.silh);
         fu.attr8 = (const float4*)(w + L.attr8); fu.sh = sh;
         fu.aa_init = (float4*)(w + L.aa); fu.seg_valid = (int*)(w + L.seg_valid); fu.silw = (unsigned long long*)(w + L.silw);
         fu.verts = vertices; fu.cmat = (const float4*)(w + L.cmat);
@@ -363,7 +362,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
         TRY(face_bwd_impl((const float*)(w + L.pix16), tri, nullptr, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
                           w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot,
-                          (const float*)(w + L.cmat), vertices, (const int*)(w + L.llink), d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part),
+                          (const float*)(w + L.cmat), vertices, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part),
                           (const int2*)(w + L.snap), (const int2*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W) + 16),
                           (const int*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W)), (const unsigned long long*)(w + L.covw),
                           (float*)(w + L.vacc), st));

@@ -257,7 +257,8 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             // mesh the odd large box is swept by its wave below and that kernel is not launched at all
             is_large = true;
             write_silh(silh, opp, snapv, s0, s1, s2, b, f, F);
-            // coverage entry of a large-box triangle: head of the pixel list the resolve pass threads (atomicExch on .x)
+            // coverage entry of a large-box triangle: a marker (width field 63) that hides whatever small-box entry an earlier step left
+            // here — the backward finds a large-box face's pixels by scanning its box (shade.hip: face_bwd_large_items)
             if (cov16 != nullptr) cov16[(size_t)b * F + f] = make_int2(-1, (int)((63u << 26) | ((unsigned)stamp[0] & 0x3FFFFFFu)));
         } else {
             // the opposite-vertex ids (antialias rule A3) are requested now and arrive while the coverage mask is computed
@@ -334,7 +335,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         const unsigned char sbv = (silh != nullptr) ? silh_bits(s0, s1, s2, q0, q1, q2) : (unsigned char)0;
         if (silh != nullptr) silh[(size_t)b * F + f] = sbv;
         // coverage entry (face-parallel backward), 8 B: candidate-pixel mask of the box | origin x, y (13 bits each) and width - 1 (6 bits,
-        // 63 = the pixel-list entry of a large-box face, which carries the step stamp instead of a box).  A small-box entry needs no
+        // 63 = the marker entry of a large-box face, which carries the step stamp instead of a box).  A small-box entry needs no
         // stamp: the backward reads it only under a matching owner mark, an owner's entry was written this step, and a stale mark
         // (8 bits) meets a stale entry only to have its candidates fail the owner test
         if (cov16 != nullptr)
@@ -717,8 +718,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                 covered = true;
                 if (fu.pix16 != nullptr) {
                     // everything the later kernels need per pixel in ONE 16-B word (shade_common.h: pix_pack); a large-box face
-                    // has no candidate mask: its pixels are threaded onto a list instead (head = .x of its coverage entry)
-                    if (large) fu.llink[gid] = atomicExch(reinterpret_cast<int*>(&fu.cov16[(size_t)b * F + f]), rem);
+                    // has no candidate mask: the backward finds its pixels by scanning its box (shade.hip: face_bwd_large_items)
                     // "this (view, face) owns pixels in step <stamp>": lets the backward skip the coverage entries of hidden
                     // faces (8-bit stamp; k_raster_tris wipes all marks every 128 steps, so a mark never meets its value again)
                     fu.own8[(size_t)b * F + f] = (unsigned char)step_tag;
@@ -874,7 +874,6 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, const
             pin(q0); pin(q1); pin(u0); pin(u1); pin(w0); pin(w1);
         }
         covered = true;
-        if (large) fu.llink[gid] = atomicExch(reinterpret_cast<int*>(&fu.cov16[(size_t)b * F + f]), rem);
         fu.own8[(size_t)b * F + f] = (unsigned char)step_tag;
         fu.pix16[gid] = make_float4(u, v, zw, __int_as_float(pix_pack(f, shade, large, sbits)));
         sbits_any = sbits != 0;

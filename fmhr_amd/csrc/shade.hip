@@ -1,9 +1,9 @@
 // fmhr_amd/csrc/shade.hip — fused per-pixel / per-vertex kernels of the stage-2 HAM step for gfx950.
 // One pass replaces the reference's interpolate(C=7) -> slices -> F.normalize -> boolean gather -> get_radiance ->
 // multiply -> scatter chain (/root/reference/mesh_sfs_optim.py:268-286), one pass the two loss reductions (:289,:295).
-// The backward is FACE-parallel: one lane per (face, view) walks the face's pixel list (threaded by the rasterizer), does the
-// whole per-pixel backward in registers and stores per-corner sums that the mesh tail adds up per vertex — no float atomics
-// (the scatter form ran at the 0.08 TB/s "64 lanes -> 64 rows" atomic shape: 3.6 ms per step).
+// The backward is FACE-parallel: the lanes of a (face, view group) take the candidate pixels of the face's coverage masks (left by the
+// rasterizer), do the whole per-pixel backward in registers and store per-corner sums that the mesh tail adds up per vertex — no float
+// atomics on that path (the scatter form ran at the 0.08 TB/s "64 lanes -> 64 rows" atomic shape: 3.6 ms per step).
 #include "common.h"
 #include "shade_common.h"
 #include <stdlib.h>
@@ -211,7 +211,7 @@ constexpr int kGroup = 8;  // views summed inside one lane group of the face-par
 // the view's SH row and clip matrix come from an LDS copy.  Finally lanes 0..2 of a group store corner 0..2 as 3 x float4 into
 // the corner's slot of its vertex's CSR row (corner_slot = inverse of vf_idx), where the mesh tail sums a vertex's slots with
 // coalesced loads.  No per-pixel record buffer, no pixel lists for box triangles, no float atomics, deterministic.
-// (Large-box triangles have no mask: their pixels are on a list threaded by the resolve pass, walked by the owning lane.)
+// (Large-box triangles have no mask: the large-box queue's workers scan their boxes, face_bwd_large_items.)
 // The budget of these kernels is the NUMBER of vector-memory requests (a scattered wave-load occupies the texture-address unit
 // for up to 64 cycles) and the number of wave iterations of the ~250-instruction pixel backward.
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x)
@@ -322,8 +322,8 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
            const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
-           const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
-           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg, const int g, const int b0, const int fb0)
+           const float4* __restrict__ cmat, const float* __restrict__ verts, int n, int V, int F,
+           int H, int W, float4* __restrict__ part, const PixGrid pg, const int g, const int b0, const int fb0)
 {
     FMHR_WTS_BEGIN(shade, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kFbBlock / 64) + (threadIdx.x >> 6));
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
@@ -339,12 +339,11 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
     const bool facelive = f < F;                                   // uniform over a group
     // ---- the coverage entries of this lane's (face, view)s; entries of other steps carry another stamp
     const unsigned cur = (unsigned)stamp[0] & 0xFFFFFFu;           // advanced once per step by the geometry kernel
-    // second word of a coverage entry (raster.hip): bits 26..31 = box width - 1, 63 = pixel-list entry of a large-box face, valid if its
-    // low 26 bits hold this step's stamp (a stale list head could chain into links that newer steps rewrote)
+    // second word of a coverage entry (raster.hip): bits 26..31 = box width - 1; 63 = the entry of a large-box face, which has no
+    // candidate mask: its pixels are the business of the large-box queue (face_bwd_large_items), not of this face's lanes
     auto entry_kind = [&](int y) -> int {
         const unsigned fld = (unsigned)y >> 26;
-        if (fld == 63u) return (((unsigned)y & 0x3FFFFFFu) == ((unsigned)stamp[0] & 0x3FFFFFFu)) ? 255 : 0;
-        return (int)fld + 1;
+        return (fld == 63u) ? 0 : (int)fld + 1;
     };
     // everything whose address is known up front is requested together (the kernel's time is #waves / wave slots x the length of
     // a wave's dependent-load chain): the owner marks, the entries, the face's vertex ids, the output slot
@@ -354,10 +353,10 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
         ti = *reinterpret_cast<const int3a*>(tri + (size_t)f * 3);
         if (j < 3) es = (unsigned)corner_slot[f * 3 + j];
     }
-    // kind: 0 nothing, 1..32 box width of a candidate mask, 255 pixel list.  Triangles that own no pixel this step (off screen, no
+    // kind: 0 nothing (also: a large-box face), 1..32 box width of a candidate mask.  Triangles that own no pixel this step (off screen, no
     // pixel centre, hidden: 2/3 of all) are dropped by the owner mark of the resolve pass; a stale mark only costs candidate checks.
-    // The entries are needed once — box + candidate mask go into LDS task lists right away — and again only on two rare paths
-    // (a face with more than kTaskG candidates, pixel lists of large boxes), which LOAD THEM AGAIN: kept alive through the pixel
+    // The entries are needed once — box + candidate mask go into LDS task lists right away — and again only on one rare path
+    // (a face with more than kTaskG candidates), which LOADS THEM AGAIN: kept alive through the pixel
     // loop their 36 registers were the difference between 3 and 4 waves per SIMD.
     auto load_entries = [&](int ff, int2 (&e)[VPL], int (&kind)[VPL]) {
 #pragma unroll
@@ -413,14 +412,13 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
     }
     __syncthreads();                                               // the only workgroup barrier: everything below is per wave
     int kind[VPL], cnt = 0;
-    bool anyv = false, has_list = false;
+    bool anyv = false;
 #pragma unroll
     for (int v = 0; v < VPL; v++) {
         const bool live = facelive && (b0 + v * kGroup + j) < n;
         kind[v] = (live && mark[v] == (unsigned char)cur) ? entry_kind(e[v].y) : 0;
         if (kind[v] >= 1 && kind[v] <= 64) cnt += __popc((unsigned)e[v].x);       // (boxes hold at most 32 pixels: .y is 0)
         anyv = anyv || kind[v] != 0;
-        has_list = has_list || kind[v] == 255;
     }
     int incl = cnt;
     {   // scan over the 8 lanes of a group by DPP row shifts (a group lies inside one row of 16: the guard drops what a shift
@@ -570,31 +568,6 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        // ---- large-box triangles: the owning lane walks the pixel list (head in the entry, links in the owner field)
-        if (!skip_lists && __ballot(has_list) != 0ull) {              // wave-uniform
-        int2 e2[VPL];
-        int kind2[VPL];
-        load_entries(fl, e2, kind2);
-#pragma unroll
-        for (int v = 0; v < VPL; v++) {
-            if (kind2[v] != 255) continue;
-            const int vs = v * kGroup + j;
-            int p = e2[v].x;
-            while (p >= 0) {
-                const long long gid = (long long)(b0 + vs) * P + p;
-                float4 w = bwd16[gid];
-                float4 gs = g_shaded[gid];
-                const int link = llink[gid];
-                pin(w); pin(gs);
-                if (pix_mask(__float_as_int(w.w)) && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) {
-                    int px;
-                    const int py = fast_divmod(p, W, px);
-                    pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
-                }
-                p = link;
-            }
-        }
-        }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++)
@@ -736,9 +709,8 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
            const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
            const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
-           const float4* __restrict__ cmat, const float* __restrict__ verts, const int* __restrict__ llink, int n, int V, int F,
-           int H, int W, float4* __restrict__ part, const int skip_lists, const PixGrid pg,       // skip_lists: queued large-box faces are not walked here
-           const LargeArgs la)
+           const float4* __restrict__ cmat, const float* __restrict__ verts, int n, int V, int F,
+           int H, int W, float4* __restrict__ part, const PixGrid pg, const LargeArgs la)
 {
     const int g = blockIdx.y;
     // the FIRST la.workers workgroups of every grid row are set aside (micro-triangle mesh only); those of row 0 are the workers of the
@@ -751,10 +723,10 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         return;
     }
     if (VB != VA && g == (int)gridDim.y - 1)                       // (block-uniform)
-        face_bwd_body<VB>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, llink, n, V, F, H, W, part, skip_lists,
+        face_bwd_body<VB>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, n, V, F, H, W, part,
                           pg, g, g * kGroup * VA, la.workers);
     else
-        face_bwd_body<VA>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, llink, n, V, F, H, W, part, skip_lists,
+        face_bwd_body<VA>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, n, V, F, H, W, part,
                           pg, g, g * kGroup * VA, la.workers);
 }
 
@@ -810,7 +782,7 @@ int face_bwd_blocks(int F) { return cdiv(F, kFacesPerBlock); }
 
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
                   const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
-                  const float* verts, const int* llink, int n, int V, int F, int H, int W, float* part,
+                  const float* verts, int n, int V, int F, int H, int W, float* part,
                   const int2* snap, const int2* large_q, const int* large_cnt, const unsigned long long* covw, float* vacc, hipStream_t st)
 {
     if (n == 0 || F == 0) return FMHR_OK;
@@ -824,12 +796,11 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     const bool workers = !coarse && vacc != nullptr;
     la.workers = workers ? kLargeWorkers : 0;
     const dim3 grid(cdiv(F, kFacesPerBlock) + la.workers, face_bwd_groups(n));
-    const int skip_lists = (coarse || workers) ? 1 : 0;
     const PixGrid pg = make_pix_grid(H, W);
 #define FMHR_FACE_BWD(VA, VB)                                                                                                       \
     k_face_bwd<VA, VB><<<grid, kFbBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded, \
-                                             (const int2*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, llink, n, V, F, H, W, \
-                                             (float4*)part, skip_lists, pg, la)
+                                             (const int2*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, n, V, F, H, W, \
+                                             (float4*)part, pg, la)
     static_assert(kMaxVPL <= 4, "the instantiation table below stops at 4 views per lane");
     {
         const int va = face_bwd_vpl(n), rem = n - (face_bwd_groups(n) - 1) * kGroup * va;       // views of the last group

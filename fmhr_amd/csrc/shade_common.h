@@ -126,7 +126,7 @@ __device__ __forceinline__ float4 shade_word(const float4 w, const int32_t* __re
 struct RasterFused {
     int2* cov16; int* stamp; unsigned char* own8;             // coverage entries, step counter, owner marks (face-parallel backward)
     float4* pix16; const float* mask;                         // per covered pixel (u, v, z/w, packed id | flags): see pix_pack
-    const unsigned char* silh; int* llink;                    // silhouette bits per (view, face); list links of large-box faces' pixels
+    const unsigned char* silh;                                // silhouette bits per (view, face)
     const float4* attr8; const float* sh;                     // forward shading inputs
     unsigned long long* silw;                                 // per segment: which of its covered pixels belong to a face with a silhouette edge
     float4* aa_init; int* seg_valid;                          // forward shading output (the rgba the antialias pass starts from) +
