@@ -358,11 +358,11 @@ def main():
                       "path": ("ncclAllReduce (RCCL) on the step's own stream" if hasattr(group, "all_reduce_") else
                                "torch.distributed.all_reduce (the backend's own stream)")}
     P = H * W
-    # dominant launch group: the longest one.  Three kernels are within ~20 % of each other (k_raster_tris 83, the second rasterizer
-    # pass 79, k_face_bwd 73-82 us by rocprofv3), and k_face_bwd alone moves between 76 and 114 us from PROCESS to process on one box
-    # (it follows the physical placement of the rows it gathers) while the others repeat within 2 %: groups within 35 %
-    # of the longest count as tied and the tie goes to the earliest in the pipeline, so that the reported kernel is the one the
-    # committed rocprofv3 summary shows as the longest (k_raster_tris) in every run; all candidates are listed in the line
+    # dominant launch group: the longest one.  Three kernels are within ~20 % of each other (k_raster_tris 84-88, the second rasterizer
+    # pass 78, k_face_bwd 70-73 us by rocprofv3; until v89 k_face_bwd moved between 74 and 92 us with the number of sliver triangles the
+    # pre-roll had grown): groups within 35 % of the longest count as tied and the tie goes to the earliest in the
+    # pipeline, so that the reported kernel is the one the committed rocprofv3 summary shows as the longest (k_raster_tris) in every
+    # run; all candidates are listed in the line
     cand = [k for k in range(len(SLOTS)) if alg_bytes(SLOTS[k], n, P, V, F, hs.nnz) > 0]
     tmax = max(kernels[SLOTS[k]] for k in cand)
     dom = min(k for k in cand if kernels[SLOTS[k]] >= 0.65 * tmax)
