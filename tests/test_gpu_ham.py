@@ -687,18 +687,27 @@ def test_two_hand_sub3_mesh_at_the_sequence_resolution(oracle):
     assert ld["n_valid"] > 0.1 * n * H * W
 
 
-@pytest.mark.parametrize("variant", ["shuffled_faces", "two_large_triangles"])
+@pytest.mark.parametrize("variant", ["shuffled_faces", "two_large_triangles", "sliver_faces"])
 def test_binned_rasterizer_rare_paths(oracle, variant, monkeypatch):
     """The binned rasterizer's slow paths against the atomic-key form AND the oracle: (a) faces in random order — the 256 faces of a
     workgroup are scattered over the image, their segments collide in the workgroup's direct-mapped LDS table and the fragments go
     through the per-wave run reservation (`bin_append`); (b) a micro-triangle mesh with two large triangles added — swept by their
-    wave, entries flagged large-box, pixels threaded onto the face's list for the backward."""
+    wave in the forward, queued for the backward's wave-per-face workers (extra workgroups of the k_face_bwd launch, sums through the
+    per-vertex buffer the mesh tail consumes and re-zeroes: the comparison is made after the SECOND step on the workspace); (c) the
+    same mesh with 32 vertices pushed out into spikes — the long thin triangles an optimisation run grows: dozens of
+    large-box (view, face)s that own pixels, several per wave of the triangle kernel."""
     from fmhr_amd.ham import HamStage2
     sc = prepare(oracle, (4, 192, 192, 64, 96), 2)           # the mesh of the "micro" case, four views (one looks into the wrist)
     rng = np.random.default_rng(7)
     f = sc["faces"].clone()
     if variant == "shuffled_faces":
         f = f[torch.from_numpy(rng.permutation(f.shape[0]))].contiguous()
+    elif variant == "sliver_faces":
+        ring = lambda r, s: 1 + r * 96 + s
+        # 32 vertices pushed out along their radius: spikes whose six incident faces are long thin triangles, visible from outside
+        idx = torch.tensor([ring(r, s) for r in (20, 40) for s in range(0, 96, 6)])
+        sc = dict(sc, delta=sc["delta"].clone())
+        sc["delta"][idx] += 0.35 * sc["vertices"][idx]
     else:
         V = sc["V"]
         ring = lambda r, s: 1 + r * 96 + s                               # blob_mesh vertex numbering: pole 0, then rings x segments
@@ -730,6 +739,19 @@ def test_binned_rasterizer_rare_paths(oracle, variant, monkeypatch):
     if variant == "two_large_triangles":
         ids = a["rast"][..., 3]
         assert int((ids == sc["F"]).sum() + (ids == sc["F"] - 1).sum()) > 100      # the large triangles own pixels
+    if variant == "sliver_faces":
+        # the spikes' faces own pixels, and enough of them are large-box ones: count the (view, face)s whose owned pixels span a box above 32
+        ids = a["rast"][..., 3].long()
+        nl = 0
+        for b in range(ids.shape[0]):
+            ys, xs = torch.nonzero(ids[b] > 0, as_tuple=True)
+            fid = ids[b][ys, xs]
+            mnx = torch.full((sc["F"] + 1,), 10**6, device=ids.device).scatter_reduce(0, fid, xs, "amin")
+            mxx = torch.full((sc["F"] + 1,), -1, device=ids.device).scatter_reduce(0, fid, xs, "amax")
+            mny = torch.full((sc["F"] + 1,), 10**6, device=ids.device).scatter_reduce(0, fid, ys, "amin")
+            mxy = torch.full((sc["F"] + 1,), -1, device=ids.device).scatter_reduce(0, fid, ys, "amax")
+            nl += int((((mxx - mnx + 1) * (mxy - mny + 1)) > 32)[mxx >= 0].sum())
+        assert nl >= 40, nl
 
 
 @pytest.mark.parametrize("dims", [(3, 192, 192, 64, 96), (3, 96, 80, 24, 32)], ids=["binned", "atomic"])
