@@ -497,6 +497,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     // by its whole wave, 64 box pixels per iteration (no second launch; coarse meshes took the queue above instead)
     FMHR_WTS_END(raster);
     if (lbal == 0ull) return;                                        // wave-uniform
+#ifdef FMHR_X_NO_LARGE_SWEEP                                         // (measurement builds only: what the in-wave sweep of large boxes costs)
+    return;
+#endif
     float4 lp0 = make_float4(0.f, 0.f, 0.f, 0.f), lp1 = lp0, lp2 = lp0;
     if (is_large) { lp0 = clipv(i0); lp1 = clipv(i1); lp2 = clipv(i2); }
     while (lbal != 0ull) {                                           // wave-uniform trip count
