@@ -314,7 +314,11 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     // of a hand in one view).  A coarse mesh (defer_large) leaves their rasterization to k_raster_large, one workgroup per triangle; on a
     // micro-triangle mesh the odd large box is swept by its wave below and the queue only feeds the BACKWARD's wave-per-face workers
     // (shade.hip: face_bwd_large_items)
+#ifdef FMHR_X_NO_QPUSH                                               // (measurement builds only: what the queue's one cursor costs late in a run)
+    if (large_q != nullptr && lbal != 0ull && defer_large) {
+#else
     if (large_q != nullptr && lbal != 0ull) {
+#endif
         int base = 0;
         const int leader = __builtin_ctzll(lbal);
         if (lane == leader) base = atomicAdd(large_cnt, __popcll(lbal));
