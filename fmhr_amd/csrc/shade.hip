@@ -790,7 +790,10 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     // mesh (a few hundred slivers late in an optimisation run) kLargeWorkers extra workgroups of THIS launch, which add their sums to
     // `vacc` (per vertex) for the mesh tail.  Either way no lane of k_face_bwd walks a pixel list any more.
     const bool coarse = raster_use_queue(H, W, F);
-    constexpr int kLargeWorkers = 256;                             // x 4 waves: one queued (view, face) per wave and round; an idle one leaves at once
+#ifndef FMHR_LARGE_WORKERS
+#define FMHR_LARGE_WORKERS 256
+#endif
+    constexpr int kLargeWorkers = FMHR_LARGE_WORKERS;              // x 4 waves: one queued (view, face) per wave and round; an idle one leaves at once
     LargeArgs la;
     la.snap = snap; la.large_q = large_q; la.large_cnt = large_cnt; la.covw = covw; la.vacc = vacc;
     const bool workers = !coarse && vacc != nullptr;
