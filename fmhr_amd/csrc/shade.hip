@@ -85,6 +85,19 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
         if (threadIdx.x == 0 && cnt_part != nullptr) cnt_part[blockIdx.x] = sv;
     }
     bool a = (seg < nSeg) && segment_is_active(covw, vmnz, nSeg, W, seg, act);
+    // bit 31 of the list entry: the antialias scan has something to find here — a pixel of this segment, of the next one (lane 63's
+    // right neighbour) or of the segments below holds a face with a silhouette edge (bit 8 of the resolve pass's per-segment
+    // word); the nearer pixel of a pair that blends is always such a pixel, so every other active segment is skipped by the scan.
+    // (Requested HERE: behind the cursor atomic below these four loads were a round trip of their own at the end of the kernel.)
+    unsigned flag = 0u;
+    if (a && seg_valid != nullptr) {
+        const long long dn = ((seg << 6) + W) >> 6;
+        int sv = seg_valid[seg];
+        if (seg + 1 < nSeg) sv |= seg_valid[seg + 1];
+        if (dn < nSeg) sv |= seg_valid[dn];
+        if (dn + 1 < nSeg) sv |= seg_valid[dn + 1];
+        flag = (sv & 0x100) ? 0x80000000u : 0u;
+    }
     bool cv = a && covw[seg] == 0ull;                                // active without coverage: needs its zeros
     unsigned long long bal = __ballot(a), cbal = __ballot(cv);
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -99,18 +112,6 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
     if (a) {
         int off = base + __popcll(bal & ((1ull << lane) - 1ull));
         for (int i = 0; i < wv; i++) off += wcnt[i];
-        // bit 31 of the entry: the antialias scan has something to find here — a pixel of this segment, of the next one (lane 63's
-        // right neighbour) or of the segments below holds a face with a silhouette edge (bit 8 of the resolve pass's per-segment
-        // word); the nearer pixel of a pair that blends is always such a pixel, so every other active segment is skipped by the scan
-        unsigned flag = 0u;
-        if (seg_valid != nullptr) {
-            const long long dn = ((seg << 6) + W) >> 6;
-            int sv = seg_valid[seg];
-            if (seg + 1 < nSeg) sv |= seg_valid[seg + 1];
-            if (dn < nSeg) sv |= seg_valid[dn];
-            if (dn + 1 < nSeg) sv |= seg_valid[dn + 1];
-            flag = (sv & 0x100) ? 0x80000000u : 0u;
-        }
         act_list[off] = (int)((unsigned)seg | flag);
     }
     // The forward shading is fused into the rasterizer's resolve pass (raster.hip), which writes the rgba for every pixel of
