@@ -58,7 +58,7 @@ int loss_pix_impl(const unsigned long long*, const float*, const float*, const f
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
                   const int*, const int32_t*, const float*, const float*, int, int, int, int, int, float*,
                   const int2*, const int2*, const int*, const unsigned long long*, float*, hipStream_t);
-int face_bwd_groups(int n);
+int face_bwd_groups(int n, int H, int W);
 int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
@@ -110,7 +110,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.gvert_aa = take(off, V * 12 * kAaReplicas);
     L.gvert_aa2 = take(off, V * 12 * kAaReplicas);             // view-sharded step: the silhouette share of the antialias position gradient
     L.vacc = take(off, V * 48);                                  // per vertex 3 float4: sums of the large-box faces' backward (shade.hip), self-cleaning
-    L.part = take(off, (size_t)face_bwd_groups(d->n) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
+    L.part = take(off, (size_t)face_bwd_groups(d->n, d->H, d->W) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
     L.partials = take(off, 2048 * 4 * 3);           // per-workgroup partial sums of the persistent pixel kernels
     L.gnormal = take(off, V * 12);
     L.gvert = take(off, V * 12);
@@ -371,7 +371,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         // everything per-vertex after the face-parallel backward, in two kernels (mesh.hip: k_mesh_tail_a / _b)
         ProfScope ps(FMHR_SLOT_REGULARISERS, st);
         MeshTailArgs A;
-        A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n);
+        A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n, d->H, d->W);
         A.gvert_aa2 = split ? (float*)(w + L.gvert_aa2) : nullptr; A.col_mult = col_mult;
         A.vacc = (float*)(w + L.vacc);
         A.gacc_r = (float*)(w + L.gvert_r);

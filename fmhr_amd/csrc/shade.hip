@@ -311,7 +311,7 @@ constexpr int kFacesPerBlock = kFbBlock / kGroup;
 // views' pixel arrays at once, 4 MB apart each — 4 views per lane (a 32-view and a 16-view group, the launch ordered group by group)
 // 72 .. 88 us: 2 497 [2 397 .. 2 651] -> 2 651 [2 626 .. 2 676] it/s over 8 alternating runs each; 3 (24 + 24): 2 575; 2: 2 553; 5: 2 564
 #ifndef FMHR_MAX_VPL
-#define FMHR_MAX_VPL 4
+#define FMHR_MAX_VPL 6
 #endif
 constexpr int kMaxVPL = FMHR_MAX_VPL;                       // views per lane: a group of kGroup lanes covers kGroup * VPL views of one face
 
@@ -773,12 +773,22 @@ int loss_pix_impl(const unsigned long long* covw, const float* aa, const float* 
     return FMHR_OK;
 }
 
-// views per lane: one group spans the whole batch when it can (up to kGroup * kMaxVPL = 48 views).  Measured at 48 views, with
-// the clip positions recomputed in-kernel (no LDS parking of positions): 2 / 3 / 4 / 6 views per lane -> 124 / 111 / 110 / 97 us,
-// and one partial plane instead of several for the mesh tail to add up
-static int face_bwd_vpl(int n) { return min(kMaxVPL, cdiv(n, kGroup)); }
+// views per lane: one group spans the whole batch when it can (up to kGroup * kMaxVPL = 48 views): the fixed part of a (face, view
+// group) is paid once and the mesh tail adds ONE plane of corner slots.  Round 3 had settled on 4 per lane (a 32-view and a 16-view
+// group at 48 views) because 6 spilled at the 128 VGPRs of 4 waves per SIMD; with the pixel-list walk gone the 6-per-lane instantiation
+// needs 122 and no spill: four alternating rounds, 4 + 2 per lane 2 817 [2 785 .. 2 836] it/s, k_face_bwd 72.4 us, tails 30.0 us ->
+// 6 per lane 2 868 [2 860 .. 2 875], 69.6 us, 27.9 us (5 per lane over two groups, 40 + 8 views: 2 768).  Batches above 48 views keep the
+// groups of 32 (their remainders run the 1 .. 4-per-lane instantiations).
+static int face_bwd_vpl(int n, int H, int W)
+{
+    const int v = cdiv(n, kGroup);
+    // (one group of 5 or 6 views per lane only up to 512 x 512 pixels per view: at 1024 x 1024 — C4, the views' pixel arrays 16 MB apart —
+    // the same launch is SLOWER than 32 + 16 views, 196 vs 182 us)
+    const bool one_group = v <= kMaxVPL && (long long)H * W <= 512ll * 512ll;
+    return (v <= 4 || one_group) ? v : 4;
+}
 
-int face_bwd_groups(int n) { return cdiv(n, kGroup * face_bwd_vpl(n)); }
+int face_bwd_groups(int n, int H, int W) { return cdiv(n, kGroup * face_bwd_vpl(n, H, W)); }
 int face_bwd_blocks(int F) { return cdiv(F, kFacesPerBlock); }
 
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
@@ -799,15 +809,15 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     la.snap = snap; la.large_q = large_q; la.large_cnt = large_cnt; la.covw = covw; la.vacc = vacc;
     const bool workers = !coarse && vacc != nullptr;
     la.workers = workers ? kLargeWorkers : 0;
-    const dim3 grid(cdiv(F, kFacesPerBlock) + la.workers, face_bwd_groups(n));
+    const dim3 grid(cdiv(F, kFacesPerBlock) + la.workers, face_bwd_groups(n, H, W));
     const PixGrid pg = make_pix_grid(H, W);
 #define FMHR_FACE_BWD(VA, VB)                                                                                                       \
     k_face_bwd<VA, VB><<<grid, kFbBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded, \
                                              (const int2*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, n, V, F, H, W, \
                                              (float4*)part, pg, la)
-    static_assert(kMaxVPL <= 4, "the instantiation table below stops at 4 views per lane");
+    static_assert(kMaxVPL == 6, "the instantiation table below: 1 .. 4 views per lane with any remainder, 5 and 6 as single groups");
     {
-        const int va = face_bwd_vpl(n), rem = n - (face_bwd_groups(n) - 1) * kGroup * va;       // views of the last group
+        const int va = face_bwd_vpl(n, H, W), rem = n - (face_bwd_groups(n, H, W) - 1) * kGroup * va;       // views of the last group
         const int vb = min(va, cdiv(rem, kGroup));
         switch (va * 8 + vb) {
             case 1 * 8 + 1: FMHR_FACE_BWD(1, 1); break;
@@ -819,6 +829,8 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
             case 4 * 8 + 1: FMHR_FACE_BWD(4, 1); break;
             case 4 * 8 + 2: FMHR_FACE_BWD(4, 2); break;
             case 4 * 8 + 3: FMHR_FACE_BWD(4, 3); break;
+            case 5 * 8 + 5: FMHR_FACE_BWD(5, 5); break;
+            case 6 * 8 + 6: FMHR_FACE_BWD(6, 6); break;
             default: FMHR_FACE_BWD(4, 4); break;
         }
     }
@@ -826,7 +838,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     FMHR_CHECK_LAUNCH("k_face_bwd");
     if (coarse) {
         k_face_bwd_large<<<2048, kBlock, 0, st>>>((const float4*)bwd16, tri, snap, (const float4*)attr8, sh, (const float4*)g_shaded, corner_slot,
-                                                  (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, kGroup * face_bwd_vpl(n), part, pg);
+                                                  (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, kGroup * face_bwd_vpl(n, H, W), part, pg);
         FMHR_CHECK_LAUNCH("k_face_bwd_large");
     }
     return FMHR_OK;

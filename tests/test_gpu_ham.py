@@ -60,9 +60,10 @@ def prepare(oracle, dims, seed):
     return sc
 
 
-# "views19/30/41": more views than one lane group holds at 1 view per lane -> 3, 4 and 6 views per lane with ragged last slots
+# "views19/30/37/41": more views than one lane group holds at 1 view per lane -> 3, 4, 5 and 6 views per lane with ragged last slots
 CASES = [("C1", (1, 256, 256, 24, 32), 0), ("C2x3", (3, 512, 334, 24, 32), 1), ("micro", (2, 192, 192, 64, 96), 2),
          ("views19", (19, 96, 80, 12, 16), 3), ("views30", (30, 64, 48, 10, 14), 4), ("views41", (41, 64, 48, 10, 14), 5),
+         ("views37", (37, 64, 48, 10, 14), 15),
          ("ragged", (6, 50, 38, 10, 14), 6),       # H*W = 1900: the 64-pixel segments straddle view boundaries
          ("views53", (53, 48, 40, 10, 14), 7),     # more than 48 views: two view groups (two partial planes for the mesh tail)
          ("coarse50", (50, 96, 96, 4, 6), 8),      # every triangle a large-box one, in two view groups (queue + k_face_bwd_large)
