@@ -13,7 +13,8 @@ c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size
 
 class HamDims(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("V", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32),
-                ("W", ctypes.c_int32), ("nnz", ctypes.c_int32), ("aa_cap", ctypes.c_int32), ("bin_cap", ctypes.c_int32)]
+                ("W", ctypes.c_int32), ("nnz", ctypes.c_int32), ("aa_cap", ctypes.c_int32), ("bin_cap", ctypes.c_int32),
+                ("pitch", ctypes.c_int32)]
 
 
 class HamWeights(ctypes.Structure):
@@ -69,6 +70,7 @@ SIGNATURES = {
                                 P, P, P, P, ctypes.c_longlong, c_float, c_float, c_float, c_float, c_int, P]),
     "fmhr_ham_workspace_bytes": (c_size_t, [ctypes.POINTER(HamDims)]),
     "fmhr_ham_rasterizer_form": (c_int, [ctypes.POINTER(HamDims)]),
+    "fmhr_ham_pitch": (c_int, [ctypes.POINTER(HamDims)]),
     "fmhr_ham_workspace_offset": (ctypes.c_longlong, [ctypes.POINTER(HamDims), ctypes.c_char_p]),
     "fmhr_ham_workspace_views": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, ctypes.POINTER(HamViews)]),
     "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),
@@ -109,7 +111,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.fmhr_abi_version() != 4:
+        if lib.fmhr_abi_version() != 5:
             raise RuntimeError("fmhr_amd: ABI version mismatch")
         _lib = lib
     return _lib

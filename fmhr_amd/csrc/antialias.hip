@@ -419,7 +419,7 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
                                             const AaShade& sd, const float* __restrict__ pos,
                                             const float* __restrict__ verts, const float4* __restrict__ cmat,
                                             const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
-                                            const unsigned char* __restrict__ silh, int V, int F, int H, int W,
+                                            const unsigned char* __restrict__ silh, int V, int F, int H, int W, int Wp,
                                             float* __restrict__ out, int4* __restrict__ items, float* __restrict__ alphas,
                                             int32_t* __restrict__ counter, int4* ibuf, float* abuf, int* inum, int region, size_t rbase)
 {
@@ -431,7 +431,7 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
     // work item of the fused step: (px | py << 16, view | code << 16, edge vertex a, edge vertex b) — the backward starts its vertex
     // loads straight from the item instead of walking pixel word -> face -> tri (two dependent round trips of a latency-bound kernel)
     const int4 item = make_int4(px | (py << 16), b | (code << 16), va, vb);
-    const long long gid = ((long long)b * H + py) * W + px, gid1 = gid + (d ? W : 1);
+    const long long gid = ((long long)b * H + py) * Wp + px, gid1 = gid + (d ? Wp : 1);    // Wp: row pitch of the per-pixel buffers
     const long long tgt = (alpha > 0.f) ? gid : gid1;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);           // an uncovered pixel (id 0) has the all-zero colour
     const float4 ca = (id0 != 0.f) ? shade_word(sd.words[gid], tri, sd.attr8, sd.sh + (size_t)b * 9) : zero;
@@ -449,7 +449,8 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
         items[rbase + slot] = item;
         alphas[rbase + slot] = alpha;
     } else {
-        counter[1] = 1;                                              // region overflow: the pair gets no gradient, flagged
+        counter[1] = 1; counter[3] = 1;                              // region overflow: the pair gets no gradient; [1] is rearmed every
+                                                                     // step, [3] stays set until fmhr_ham_workspace_init (fused step: 4 words)
     }
 }
 
@@ -461,7 +462,7 @@ __device__ __forceinline__ void aa_fwd_pair(int px, int py, int b, int d, float 
 // (aa_analyse_core, shade_eval_attr): same items, alphas and colours.
 __device__ __forceinline__ void aa_fwd_pair_staged(int px, int py, int b, int d, float z0, float id0, float z1, float id1,
                                                    const AaShade& sd, const float* __restrict__ verts, const float4* __restrict__ cmat,
-                                                   const int32_t* __restrict__ tri, int V, int F, int H, int W,
+                                                   const int32_t* __restrict__ tri, int V, int F, int H, int W, int Wp,
                                                    float* __restrict__ out, int4* __restrict__ items, float* __restrict__ alphas,
                                                    int32_t* __restrict__ counter, int4* ibuf, float* abuf, int* inum, int region, size_t rbase)
 {
@@ -473,7 +474,7 @@ __device__ __forceinline__ void aa_fwd_pair_staged(int px, int py, int b, int d,
     const bool front0 = t == tri0;
     int qx = px, qy = py;
     if (!front0) { qx += 1 - d; qy += d; }
-    const long long gid = ((long long)b * H + py) * W + px, gid1 = gid + (d ? W : 1);
+    const long long gid = ((long long)b * H + py) * Wp + px, gid1 = gid + (d ? Wp : 1);    // Wp: row pitch of the per-pixel buffers
     // ---- (1)
     float4 wa = sd.words[gid], wb = sd.words[gid1];                 // (an uncovered pixel's word is stale: masked by its id below)
     const I3 ra = *reinterpret_cast<const I3*>(tri + (size_t)max(tri0, 0) * 3), rb = *reinterpret_cast<const I3*>(tri + (size_t)max(tri1, 0) * 3);
@@ -539,7 +540,8 @@ __device__ __forceinline__ void aa_fwd_pair_staged(int px, int py, int b, int d,
         items[rbase + slot] = item;
         alphas[rbase + slot] = alpha;
     } else {
-        counter[1] = 1;                                              // region overflow: the pair gets no gradient, flagged
+        counter[1] = 1; counter[3] = 1;                              // region overflow: the pair gets no gradient; [1] is rearmed every
+                                                                     // step, [3] stays set until fmhr_ham_workspace_init (fused step: 4 words)
     }
 }
 
@@ -549,11 +551,11 @@ __device__ __attribute__((noinline)) void aa_fwd_pair_overflow(int px, int py, i
                                             const AaShade& sd, const float* __restrict__ pos,
                                             const float* __restrict__ verts, const float4* __restrict__ cmat,
                                             const int32_t* __restrict__ tri, const int32_t* __restrict__ opp,
-                                            const unsigned char* __restrict__ silh, int V, int F, int H, int W,
+                                            const unsigned char* __restrict__ silh, int V, int F, int H, int W, int Wp,
                                             float* __restrict__ out, int4* __restrict__ items, float* __restrict__ alphas,
                                             int32_t* __restrict__ counter, int4* ibuf, float* abuf, int* inum, int region, size_t rbase)
 {
-    aa_fwd_pair(px, py, b, d, z0, id0, z1, id1, sd, pos, verts, cmat, tri, opp, silh, V, F, H, W, out, items, alphas, counter, ibuf, abuf,
+    aa_fwd_pair(px, py, b, d, z0, id0, z1, id1, sd, pos, verts, cmat, tri, opp, silh, V, F, H, W, Wp, out, items, alphas, counter, ibuf, abuf,
                 inum, region, rbase);
 }
 
@@ -566,7 +568,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ROW
 k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __restrict__ pos,
               const float* __restrict__ verts, const float4* __restrict__ cmat, const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, const unsigned char* __restrict__ silh,
               const int* __restrict__ act_list, const int* __restrict__ act_count, const unsigned long long* __restrict__ covw,
-              const unsigned long long* __restrict__ silw, int n, int V, int F, int H, int W, float* __restrict__ out, int4* __restrict__ items,
+              const unsigned long long* __restrict__ silw, int n, int V, int F, int H, int W, int Wp, float* __restrict__ out, int4* __restrict__ items,
               float* __restrict__ alphas, int32_t* __restrict__ counter, int32_t* __restrict__ region_cnt, int cap,
               const float* __restrict__ cnt_part, int nb_cnt, int* __restrict__ n_valid, float* __restrict__ n_valid_f, const SegRows sr)
 {
@@ -592,7 +594,8 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
     }
     __syncthreads();
     const int count = *act_count, lane = threadIdx.x & 63;
-    const long long P = (long long)H * W, N = (long long)n * P, nSeg = (N + 63) >> 6;
+    // W: image width (pair exists <=> px + 1 < W; the analysis' pixel grid); Wp: row pitch of every per-pixel buffer (addressing)
+    const long long P = (long long)H * Wp, N = (long long)n * P, nSeg = (N + 63) >> 6;
     // software-pipelined over the wave's segments, three stages: A(i) requests the segment id and its four coverage words, B(i)
     // turns them into coverage flags and requests the lane's per-pixel words, C(i) decodes and tests the two pairs.  While
     // C(i) runs, the loads of B(i+1) and A(i+2) are in flight: no iteration waits for a dependent chain of three loads.
@@ -605,7 +608,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
             const int ent = act_list[ii];
             if (ent >= 0) return;                                    // no silhouette-face pixel in reach of this segment: nothing to find
             wd.seg = ent & 0x7fffffff;
-            const long long sDn = ((wd.seg << 6) + W) >> 6;
+            const long long sDn = ((wd.seg << 6) + Wp) >> 6;
             wd.w0 = covw[wd.seg]; wd.wR = covw_or0(covw, wd.seg + 1, nSeg); wd.wD0 = covw_or0(covw, sDn, nSeg);
             wd.wD1 = covw_or0(covw, sDn + 1, nSeg);
         }
@@ -616,7 +619,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
         q.b = 0; q.px = 0; q.py = 0;
         q.live = false; q.c0 = q.cD = q.cR63 = q.inR = q.inD = false;
         if (wd.seg < 0) return;
-        const long long gid = (wd.seg << 6) + lane, gidD = gid + W, sD = ((wd.seg << 6) + W) >> 6;
+        const long long gid = (wd.seg << 6) + lane, gidD = gid + Wp, sD = ((wd.seg << 6) + Wp) >> 6;
         q.live = gid < N;
         if (ROW) {                                                   // every lane is live (N is a multiple of 64)
             const unsigned sg = (unsigned)__builtin_amdgcn_readfirstlane((int)wd.seg);
@@ -626,7 +629,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
         } else if (q.live) {
             int rem;
             q.b = fast_divmod(gid, (int)P, rem);
-            q.py = fast_divmod(rem, W, q.px);
+            q.py = fast_divmod(rem, Wp, q.px);
         }
         q.c0 = q.live && ((wd.w0 >> lane) & 1ull);
         q.inR = q.live && q.px + 1 < W; q.inD = q.live && q.py + 1 < H;
@@ -657,7 +660,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
                 cpos[slot] = make_int2(px | (py << 13) | (d << 26), b);
                 cfrag[slot] = make_float4(r0.z, r0.w, r1.z, r1.w);
             } else {
-                aa_fwd_pair_overflow(px, py, b, d, r0.z, r0.w, r1.z, r1.w, sd, pos, verts, cmat, tri, opp, silh, V, F, H, W, out, items, alphas, counter,
+                aa_fwd_pair_overflow(px, py, b, d, r0.z, r0.w, r1.z, r1.w, sd, pos, verts, cmat, tri, opp, silh, V, F, H, W, Wp, out, items, alphas, counter,
                             ibuf, abuf, &inum, region, rbase);
             }
         }
@@ -693,11 +696,13 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
             unsigned long long M = 0ull, c0w = 0ull, cRw = 0ull, cDw = 0ull;
             unsigned sg = 0u;
             bool lastcol = false, lastrow = false;
+            int right_end = 64;                                      // pixels of this segment that have a right neighbour INSIDE the image
             if (ent < 0) {                                           // (>= 0: no silhouette-face pixel in reach, k_active_segments)
                 sg = (unsigned)ent & 0x7fffffffu;
                 const unsigned vb = udiv(sg, sr.per_view), r = sg - vb * sr.segs_per_view;
                 const unsigned row = udiv(r, sr.per_row);
                 lastcol = r - row * spr == spr - 1; lastrow = (int)row == H - 1;
+                right_end = W - 1 - (int)((r - row * spr) << 6);     // bit < right_end <=> px + 1 < W (the pitch may exceed W: pad columns)
                 c0w = covw[sg];
                 unsigned long long s0w = silw[sg], sRw = 0ull, sDw = 0ull;
                 if (!lastcol) { cRw = covw[sg + 1]; sRw = silw[sg + 1]; }
@@ -722,7 +727,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
                         m &= m - 1ull;
                         if (idx >= 0 && idx < kPixBuf) {
                             const bool c0 = (c0w >> bit) & 1ull, cR = (bit < 63) ? ((c0w >> (bit + 1)) & 1ull) : (cRw & 1ull), cD = (cDw >> bit) & 1ull;
-                            const bool inR = bit < 63 || !lastcol, inD = !lastrow;
+                            const bool inR = bit < right_end, inD = !lastrow;
                             pl[idx] = make_int2((int)((sg << 6) | (unsigned)bit),
                                                 (int)c0 | ((int)cR << 1) | ((int)cD << 2) | ((int)inR << 3) | ((int)inD << 4));
                         }
@@ -745,7 +750,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
                         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), rR = r0, rD = r0;
                         if (c0) r0 = rast[gid];
                         if (cR) rR = rast[gid + 1];
-                        if (cD) rD = rast[gid + W];
+                        if (cD) rD = rast[gid + Wp];
                         pin(r0); pin(rR); pin(rD);
 #ifdef FMHR_X_TS
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -806,11 +811,11 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
             const float4 cf = cfrag[c];
             if (ROW && pos == nullptr)                               // the fused step, no stored clip positions (the per-pixel-scan instantiation
                                                                      // runs at 96 registers: there the wider stages only add spills, 47.6 -> 51.4 us)
-                aa_fwd_pair_staged(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, sd, verts, cmat, tri, V, F, H, W,
+                aa_fwd_pair_staged(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, sd, verts, cmat, tri, V, F, H, W, Wp,
                                    out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
             else
                 aa_fwd_pair(cp.x & 8191, (cp.x >> 13) & 8191, cp.y, (cp.x >> 26) & 1, cf.x, cf.y, cf.z, cf.w, sd, pos, verts, cmat, tri, opp, silh, V, F, H,
-                            W, out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
+                            W, Wp, out, items, alphas, counter, ibuf, abuf, &inum, region, rbase);
         }
     }
 #ifdef FMHR_X_TS
@@ -826,7 +831,7 @@ k_aa_fwd_list(const AaShade sd, const float4* __restrict__ rast, const float* __
     for (int i = threadIdx.x; i < nn; i += kBlock) { items[rbase + i] = ibuf[i]; alphas[rbase + i] = abuf[i]; }
     if (threadIdx.x == 0) {
         region_cnt[blockIdx.x] = min(inum, region);
-        if (inum > region) counter[1] = 1;
+        if (inum > region) { counter[1] = 1; counter[3] = 1; }
     }
     FMHR_WTS_END(aaf);
 }
@@ -842,15 +847,17 @@ __device__ __forceinline__ void aa_bwd_item(int px, int py, int b, int code, flo
          float4 gl = make_float4(0.f, 0.f, 0.f, 0.f), bool packed = false, float4 dcol = make_float4(0.f, 0.f, 0.f, 0.f),
          const float* __restrict__ verts = nullptr, bool keep0 = true, bool keep1 = true, float* __restrict__ gvert2 = nullptr,
          int known_va = -1, int known_vb = -1, const float4* pre = nullptr, unsigned* st_off = nullptr, float* st_val = nullptr,
-         float* split2 = nullptr)
+         float* split2 = nullptr, int Wp = 0)
 {
+    // Wp (fused step): row pitch of the per-pixel buffers the offsets below address; 0 = W (the generic op's dense images)
     // pre (fused step): the edge's two clip positions and the view's three matrix rows, loaded by the caller TOGETHER with everything
     // else the item needs: memory operations of a wave complete in order, so a load issued behind the colour atomics below would wait
     // for them (a memory-side float atomic takes microseconds) before the position atomics could even start
     const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
     int d = (code & AA_DOWN) ? 1 : 0, di = code & 3;
-    long long pix0 = ((long long)b * H + py) * W + px;
-    long long pix1 = pix0 + (d ? W : 1);
+    const int Wq = (Wp > 0) ? Wp : W;
+    long long pix0 = ((long long)b * H + py) * Wq + px;
+    long long pix1 = pix0 + (d ? Wq : 1);
     long long tgt = (alpha > 0.f) ? pix0 : pix1;
     float galpha = 0.f, galpha_a = 0.f;       // galpha_a: the alpha channel's share (fused step: the silhouette-MSE term)
     const int C = (CA > 0) ? CA : Cdyn;
@@ -983,7 +990,7 @@ struct LossGrad {
 __global__ void __launch_bounds__(kBlock)
 k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast, const float* __restrict__ pos,
                const float* __restrict__ verts, const int32_t* __restrict__ tri, const LossGrad L, const int4* __restrict__ items,
-               const float* __restrict__ alphas, const int32_t* __restrict__ region_cnt, int cap, int V, int H, int W,
+               const float* __restrict__ alphas, const int32_t* __restrict__ region_cnt, int cap, int V, int H, int W, int Wp,
                float* __restrict__ gcolor, const float4* __restrict__ cmat, float* __restrict__ gvert, float* __restrict__ gvert2)
 {
     FMHR_WTS_BEGIN(aab, (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
@@ -1018,11 +1025,14 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
         const int4 raw = items[rbase + i];                          // (px | py << 16, view | code << 16, edge vertex a, edge vertex b)
         const int4 it = make_int4(raw.x & 0xffff, (int)((unsigned)raw.x >> 16), raw.y & 0xffff, (int)((unsigned)raw.y >> 16));
         const float alpha = alphas[rbase + i];
-        const long long pix0 = ((long long)it.z * H + it.y) * W + it.x;
-        const long long tgt = (alpha > 0.f) ? pix0 : pix0 + ((it.w & AA_DOWN) ? W : 1);
+        // the item's pixels in the step's own buffers (row pitch Wp) and the blend target in the caller's [n,H,W] tensors
+        const int dn = (it.w & AA_DOWN) ? 1 : 0;
+        const long long pix0 = ((long long)it.z * H + it.y) * Wp + it.x;
+        const long long tgt = (alpha > 0.f) ? pix0 : pix0 + (dn ? Wp : 1);
+        const long long ctgt = ((long long)it.z * H + it.y + ((alpha > 0.f) ? 0 : dn)) * W + it.x + ((alpha > 0.f) ? 0 : 1 - dn);
         const float4 a = L.aa[tgt];
-        const F3U im = *reinterpret_cast<const F3U*>(L.img + tgt * 3);
-        const float mk = L.mask[tgt], vm = L.valid_mask[tgt];
+        const F3U im = *reinterpret_cast<const F3U*>(L.img + ctgt * 3);
+        const float mk = L.mask[ctgt], vm = L.valid_mask[ctgt];
         const bool cov = (L.covw[tgt >> 6] >> (tgt & 63)) & 1ull;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mk > 0.f && cov) {
@@ -1040,12 +1050,12 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
             pre[2] = cmat[(size_t)it.z * 4]; pre[3] = cmat[(size_t)it.z * 4 + 1]; pre[4] = cmat[(size_t)it.z * 4 + 2];
             pin(pre[0]); pin(pre[1]); pin(pre[2]); pin(pre[3]); pin(pre[4]);
         }
-        const long long pix1 = pix0 + ((it.w & AA_DOWN) ? W : 1);
+        const long long pix1 = pix0 + (dn ? Wp : 1);
         // d loss / d shaded colour exists for covered pixels only (k_loss_pix stores it for them, the owner face reads it)
         const bool cov0 = (L.covw[pix0 >> 6] >> (pix0 & 63)) & 1ull, cov1 = (L.covw[pix1 >> 6] >> (pix1 & 63)) & 1ull;
         aa_bwd_item<4, 0>(it.x, it.y, it.z, it.w, alpha, nullptr, nullptr, rast, pos, tri, nullptr, nullptr, V, H, W, 4, gcolor, nullptr,
                           nullptr, cmat, gvert, true, g, true, dcol, verts, cov0, cov1, gvert2, raw.z, raw.w, pre, my_off, my_val,
-                          (gvert2 != nullptr) ? split2 : nullptr);
+                          (gvert2 != nullptr) ? split2 : nullptr, Wp);
         }
         __syncthreads();
         for (int e = threadIdx.x; e < nround * kE; e += kBlock) {
@@ -1097,21 +1107,21 @@ static int build_hash(const int32_t* tri, int F, EdgeSlot* tab, unsigned T, hipS
 int aa_fwd_rgba(const float* attr8, const float* sh, float* dcols, const float* rast, const float* pos, const float* verts,
                 const float* cmat, const int32_t* tri, const int32_t* opp,
                 const unsigned char* silh, const int* act_list, const int* act_count, const unsigned long long* covw,
-                const unsigned long long* silw, int n, int V, int F, int H, int W, float* out, int32_t* items, float* alphas, int32_t* counter, int32_t* region_cnt, int cap,
+                const unsigned long long* silw, int n, int V, int F, int H, int W, int Wp, float* out, int32_t* items, float* alphas, int32_t* counter, int32_t* region_cnt, int cap,
                 const float* cnt_part, int nb_cnt, int* n_valid, float* n_valid_f, hipStream_t st)
 {
     AaShade sd;
     sd.words = (const float4*)rast; sd.attr8 = (const float4*)attr8; sd.sh = sh; sd.dcols = (float4*)dcols;
     SegRows sr;
     memset(&sr, 0, sizeof(sr));
-    const bool row = aa_row_aligned(n, H, W);
+    const bool row = aa_row_aligned(n, H, Wp);
     if (row) {
-        sr.segs_per_view = (unsigned)((long long)H * W >> 6); sr.segs_per_row = (unsigned)(W >> 6);
+        sr.segs_per_view = (unsigned)((long long)H * Wp >> 6); sr.segs_per_row = (unsigned)(Wp >> 6);
         sr.per_view = make_udiv(sr.segs_per_view); sr.per_row = make_udiv(sr.segs_per_row);
-        k_aa_fwd_list<true><<<aa_grid(true), kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, silw, n, V, F, H, W,
+        k_aa_fwd_list<true><<<aa_grid(true), kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, silw, n, V, F, H, W, Wp,
                                            out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f, sr);
     } else {
-        k_aa_fwd_list<false><<<aa_grid(false), kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, silw, n, V, F, H, W,
+        k_aa_fwd_list<false><<<aa_grid(false), kBlock, 0, st>>>(sd, (const float4*)rast, pos, verts, (const float4*)cmat, tri, opp, silh, act_list, act_count, covw, silw, n, V, F, H, W, Wp,
                                            out, (int4*)items, alphas, counter, region_cnt, cap, cnt_part, nb_cnt, n_valid, n_valid_f, sr);
     }
     FMHR_CHECK_LAUNCH("k_aa_fwd_list");
@@ -1121,13 +1131,13 @@ int aa_fwd_rgba(const float* attr8, const float* sh, float* dcols, const float* 
 int aa_bwd_rgba(const float* dcols, const float* rast, const float* pos, const float* verts, const int32_t* tri, const float* aa, const float* img,
                 const float* mask, const float* valid_mask, const unsigned long long* covw, const float* n_valid, float w_sfs,
                 float w_mask, float mse_den, const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int n, int V,
-                int H, int W, float* gcolor, const float* cmat, float* gvert, float* gvert2, hipStream_t st)
+                int H, int W, int Wp, float* gcolor, const float* cmat, float* gvert, float* gvert2, hipStream_t st)
 {
     LossGrad L;
     L.aa = (const float4*)aa; L.img = img; L.mask = mask; L.valid_mask = valid_mask; L.covw = covw; L.n_valid = n_valid;
     L.w_sfs = w_sfs; L.w_mask = w_mask; L.mse_den = mse_den;
-    k_aa_bwd_items<<<aa_grid(aa_row_aligned(n, H, W)), kBlock, 0, st>>>(       // the forward's grid: one workgroup per region
-        (const float4*)dcols, (const float4*)rast, pos, verts, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W,
+    k_aa_bwd_items<<<aa_grid(aa_row_aligned(n, H, Wp)), kBlock, 0, st>>>(      // the forward's grid: one workgroup per region
+        (const float4*)dcols, (const float4*)rast, pos, verts, tri, L, (const int4*)items, alphas, region_cnt, cap, V, H, W, Wp,
                                            gcolor, (const float4*)cmat, gvert, gvert2);
     FMHR_CHECK_LAUNCH("k_aa_bwd_items");
     return FMHR_OK;

@@ -217,6 +217,21 @@ inline UDiv make_udiv(unsigned d)
 }
 __device__ __forceinline__ unsigned udiv(unsigned n, const UDiv& u) { return (__umulhi(n, u.m) + n) >> u.l; }
 
+// ---- row pitch (ABI 5).  The fused step's own per-pixel buffers are [n, H, Wp] with Wp = the pitch: by default W rounded up to a
+// multiple of 64, so that every 64-pixel segment (= one wave of every per-pixel kernel, = one fragment bin) lies in ONE row of ONE
+// view whatever W is (W = 334: /root/reference/conf/ih_sfs.conf:14).  The pad columns are never covered (triangle boxes are clipped
+// to W), never a pair of the antialias scan (a pair needs px + 1 < W) and never read from a caller tensor: img / mask / valid_mask
+// stay [n, H, W].  W keeps every GEOMETRIC meaning (pixel grid, snap scale, clipping), Wp only addresses.
+inline int default_row_pitch(int W) { return (W + 63) & ~63; }
+// caller-tensor index of lane `lane` of segment `seg` (wave-uniform) when the pitch differs from W (then Wp % 64 == 0): the segment's
+// global row b * H + py by one scalar magic division; `incol` = the lane is a pixel of the image, not of the pad
+__device__ __forceinline__ long long caller_index(unsigned seg, int lane, int W, const UDiv& segx, bool& incol)
+{
+    const unsigned row = udiv(seg, segx), col0 = (seg - row * segx.d) << 6;
+    incol = (int)col0 + lane < W;
+    return (long long)row * W + (int)col0 + lane;
+}
+
 // one clip coordinate of a vertex under one column (c0..c3) of the combined matrix w2c @ proj: the geometry kernel and the
 // face-parallel backward both go through this explicit chain, so their positions agree bit for bit whatever the compiler contracts
 __device__ __forceinline__ float clip_coord(float x, float y, float z, float c0, float c1, float c2, float c3)

@@ -36,27 +36,27 @@ int ham_combine_impl(float*, int, const fmhr_adam_param*, const fmhr_adam_param*
 size_t raster_core_ws_bytes(int n, int F, int H, int W);
 size_t raster_keys_bytes(int n, int H, int W);
 int raster_sparse_init(void*, unsigned char*, int, int, int, hipStream_t);
-int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, float*,
+int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*, unsigned char*, int, int, int, int, int, int, float*,
                        void*, unsigned char*, unsigned long long*, const RasterFused*, hipStream_t);
-int valid_mask_segments_impl(const float*, long long, unsigned char*, hipStream_t);
+int valid_mask_segments_impl(const float*, int, int, int, int, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, const int*,
                          float*, float*, hipStream_t);
 int reshade_dense_impl(const unsigned long long*, const float*, const int32_t*, const float*, const float*, int, int, int, float*, hipStream_t);
 int active_segments_blocks(long long N);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, const float*, float*, float*, hipStream_t);
 int aa_fwd_rgba(const float*, const float*, float*, const float*, const float*, const float*, const float*, const int32_t*, const int32_t*, const unsigned char*, const int*,
-                const int*, const unsigned long long*, const unsigned long long*, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int,
+                const int*, const unsigned long long*, const unsigned long long*, int, int, int, int, int, int, float*, int32_t*, float*, int32_t*, int32_t*, int,
                 const float*, int, int*, float*, hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
                 const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int, int,
-                int, int, float*, const float*, float*, float*, hipStream_t);
+                int, int, int, float*, const float*, float*, float*, hipStream_t);
 int clip_positions_impl(const float*, const float*, int, int, float*, hipStream_t);
 int geometry_impl(const float*, const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, const int32_t*,
                   const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, int*, hipStream_t);
-int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, const int*, const int*,
+int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, int, int, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
-                  const int*, const int32_t*, const float*, const float*, int, int, int, int, int, float*,
+                  const int*, const int32_t*, const float*, const float*, int, int, int, int, int, int, float*,
                   const int2*, const int2*, const int*, const unsigned long long*, float*, hipStream_t);
 int face_bwd_groups(int n, int H, int W);
 int face_bwd_blocks(int F);
@@ -74,11 +74,15 @@ static size_t take(size_t& off, size_t bytes)
     return at;
 }
 
+// the row pitch of the step's per-pixel buffers (ABI 5): fmhr_ham_dims.pitch, 0 = W rounded up to a multiple of 64
+static int eff_pitch(const fmhr_ham_dims* d) { return d->pitch > 0 ? d->pitch : default_row_pitch(d->W); }
+
 static Layout make_layout(const fmhr_ham_dims* d)
 {
     Layout L;
     size_t off = 0;
-    size_t V = d->V, nP = (size_t)d->n * d->H * d->W, nV = (size_t)d->n * d->V;
+    const int Wp = eff_pitch(d);
+    size_t V = d->V, nP = (size_t)d->n * d->H * Wp, nV = (size_t)d->n * d->V;     // per-pixel buffers: [n, H, Wp]
     L.vertices = take(off, V * 12);
     L.nsum = take(off, V * 12);
     L.normals = take(off, V * 12);
@@ -86,7 +90,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.pos = take(off, nV * 16);
     L.snap = take(off, nV * 8);
     L.silh = take(off, (size_t)d->n * d->F);
-    L.raster_ws = take(off, raster_core_ws_bytes(d->n, d->F, d->H, d->W));
+    L.raster_ws = take(off, raster_core_ws_bytes(d->n, d->F, d->H, Wp));
     L.dirty = take(off, (nP + 63) / 64);
     L.covw = take(off, ((nP + 63) / 64) * 8);
     L.act = take(off, (nP + 63) / 64);
@@ -110,7 +114,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.gvert_aa = take(off, V * 12 * kAaReplicas);
     L.gvert_aa2 = take(off, V * 12 * kAaReplicas);             // view-sharded step: the silhouette share of the antialias position gradient
     L.vacc = take(off, V * 48);                                  // per vertex 3 float4: sums of the large-box faces' backward (shade.hip), self-cleaning
-    L.part = take(off, (size_t)face_bwd_groups(d->n, d->H, d->W) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
+    L.part = take(off, (size_t)face_bwd_groups(d->n, d->H, Wp) * d->F * 3 * 48);   // [view group, corner slot (vf CSR order)] x 3 float4
     L.partials = take(off, 2048 * 4 * 3);           // per-workgroup partial sums of the persistent pixel kernels
     L.gnormal = take(off, V * 12);
     L.gvert = take(off, V * 12);
@@ -128,8 +132,8 @@ static Layout make_layout(const fmhr_ham_dims* d)
     // binned rasterizer (raster.hip): per 64-pixel segment a cursor (one per cache line) and room for bin_cap_entries() 16-B fragment
     // entries (16 KB per segment: 3.2 GB at the metric, of which a step touches the ~100 MB its fragments fill — sized for the
     // 288-GB part, not for the footprint)
-    const bool binned = raster_binned_ok(d->F, d->H, d->W);
-    const size_t tiles = binned ? raster_bin_count(d->n, d->H, d->W) : 0;
+    const bool binned = raster_binned_ok(d->F, d->H, d->W, Wp);
+    const size_t tiles = binned ? raster_bin_count(d->n, d->H, Wp) : 0;
     L.bin_cursor = take(off, tiles * 4 * kCursorStride + 16);
     L.bins = take(off, tiles * (size_t)bin_cap_entries(d->bin_cap) * 16);
     L.total = off;
@@ -143,8 +147,11 @@ static int check_dims(const fmhr_ham_dims* d)
                    "ham: bad dims n=%d V=%d F=%d H=%d W=%d aa_cap=%d", d->n, d->V, d->F, d->H, d->W, d->aa_cap);
     FMHR_CHECK_ARG(d->H <= 8192 && d->W <= 8192 && d->F < (1 << 24), "ham: H,W <= 8192 and F < 2^24 required");
     FMHR_CHECK_ARG(d->bin_cap >= 0 && d->bin_cap <= (1 << 20), "ham: bin_cap must be 0 (default) or 64 .. 2^20, got %d", d->bin_cap);
-    FMHR_CHECK_ARG(((long long)d->n * d->H * d->W) % 4 == 0, "ham: n*H*W must be a multiple of 4");
-    FMHR_CHECK_ARG(d->n <= 65535 && ((long long)d->n * d->H * d->W) < (1ll << 30), "ham: n <= 65535 and n*H*W < 2^30 required (32-bit channel offsets in k_aa_bwd_items)");
+    FMHR_CHECK_ARG(d->pitch == 0 || d->pitch == d->W || (d->pitch > d->W && d->pitch % 64 == 0 && d->pitch <= 8192),
+                   "ham: pitch must be 0 (default: W rounded up to a multiple of 64), W, or a multiple of 64 above W; got %d (W=%d)", d->pitch, d->W);
+    const int Wp = eff_pitch(d);
+    FMHR_CHECK_ARG(((long long)d->n * d->H * Wp) % 4 == 0, "ham: n*H*pitch must be a multiple of 4");
+    FMHR_CHECK_ARG(d->n <= 65535 && ((long long)d->n * d->H * Wp) < (1ll << 30), "ham: n <= 65535 and n*H*pitch < 2^30 required (32-bit channel offsets in k_aa_bwd_items)");
     return FMHR_OK;
 }
 
@@ -166,7 +173,13 @@ using namespace fmhr;
 extern "C" int fmhr_ham_rasterizer_form(const fmhr_ham_dims* d)
 {
     if (check_dims(d)) return -1;
-    return (raster_binned_ok(d->F, d->H, d->W) && raster_binned_wanted(true)) ? 1 : 0;
+    return (raster_binned_ok(d->F, d->H, d->W, eff_pitch(d)) && raster_binned_wanted(true)) ? 1 : 0;
+}
+
+extern "C" int fmhr_ham_pitch(const fmhr_ham_dims* d)
+{
+    if (check_dims(d)) return -1;
+    return eff_pitch(d);
 }
 
 extern "C" size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d)
@@ -226,7 +239,7 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     HIPTRY(hipMemsetAsync(w + L.stamp, 0, 16, (hipStream_t)stream), "init stamp");
     HIPTRY(hipMemsetAsync(w + L.own8, 0, (size_t)d->n * d->F, (hipStream_t)stream), "init own8");
     HIPTRY(hipMemsetAsync(w + L.bin_cursor, 0, L.bins - L.bin_cursor, (hipStream_t)stream), "init bin cursors");   // self-cleaning afterwards
-    return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, d->W, (hipStream_t)stream);
+    return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, eff_pitch(d), (hipStream_t)stream);
 }
 
 extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, const int32_t* tri, const float* sh, void* ws, size_t ws_bytes, void* stream)
@@ -240,8 +253,8 @@ extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, const int32_t* tri, cons
     // kernels computed on the fly (same FMA chains / same shading statements)
     TRY(clip_positions_impl((const float*)(w + L.vertices), (const float*)(w + L.cmat), d->n, d->V, (float*)(w + L.pos), st));
     TRY(reshade_dense_impl((const unsigned long long*)(w + L.covw), (const float*)(w + L.pix16), tri, (const float*)(w + L.attr8), sh, d->n,
-                           d->H, d->W, (float*)(w + L.shaded), st));
-    return densify_impl((const unsigned long long*)(w + L.covw), (const unsigned char*)(w + L.act), (long long)d->n * d->H * d->W,
+                           d->H, eff_pitch(d), (float*)(w + L.shaded), st));
+    return densify_impl((const unsigned long long*)(w + L.covw), (const unsigned char*)(w + L.act), (long long)d->n * d->H * eff_pitch(d),
                         (const float*)(w + L.pix16), (float*)(w + L.rast), (float*)(w + L.aa), st);
 }
 
@@ -260,7 +273,8 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     char* w = (char*)ws;
     float* vertices = (float*)(w + L.vertices);
     float* rast = (float*)(w + L.rast);
-    const long long nP = (long long)d->n * d->H * d->W;
+    const int Wp = eff_pitch(d);                                     // row pitch of every per-pixel buffer of the step; d->W stays the image width
+    const long long nP = (long long)d->n * d->H * Wp;
     unsigned char* act = (unsigned char*)(w + L.act);
     unsigned long long* covw = (unsigned long long*)(w + L.covw);
     {
@@ -283,24 +297,25 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.verts = vertices; fu.cmat = (const float4*)(w + L.cmat);
         fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
         fu.bins = nullptr; fu.bin_cursor = nullptr; fu.bin_flag = nullptr; fu.bin_cap = 0;
-        if (raster_binned_ok(d->F, d->H, d->W)) {
+        fu.segx = make_udiv((unsigned)((Wp + 63) / 64));            // used when Wp != d->W: segment -> row of the caller's [n,H,W] mask
+        if (raster_binned_ok(d->F, d->H, d->W, Wp)) {
             fu.bins = (uint4*)(w + L.bins); fu.bin_cursor = (int*)(w + L.bin_cursor); fu.bin_cap = bin_cap_entries(d->bin_cap);
             fu.bin_flag = (int*)(w + L.aa_counter) + 2;             // sticky overflow flag next to the antialias list's (read by the host)
         }
-        TRY(rasterize_fwd_impl(nullptr, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W,
+        TRY(rasterize_fwd_impl(nullptr, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W, Wp,
                                rast, w + L.raster_ws, (unsigned char*)(w + L.dirty), covw, &fu, st));
     }
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
-        if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, nP, (unsigned char*)(w + L.vmnz), st));
-        TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, d->W, act, (int*)(w + L.act_list),
+        if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, d->n, d->H, d->W, Wp, (unsigned char*)(w + L.vmnz), st));
+        TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, Wp, act, (int*)(w + L.act_list),
                                  (int*)(w + L.act_count), (const int*)(w + L.seg_valid), (float*)(w + L.cnt_part),
                                  (float*)(w + L.aa), st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     TRY(aa_fwd_rgba((const float*)(w + L.attr8), sh, (float*)(w + L.aa_dcol), (const float*)(w + L.pix16), nullptr, vertices, (const float*)(w + L.cmat), tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
                     (const int*)(w + L.act_count), covw, (const unsigned long long*)(w + L.silw), d->n, d->V, d->F,
-                    d->H, d->W, (float*)(w + L.aa), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
+                    d->H, d->W, Wp, (float*)(w + L.aa), (int32_t*)(w + L.aa_items), (float*)(w + L.aa_alphas),
                     (int32_t*)(w + L.aa_counter), (int32_t*)(w + L.aa_region_cnt), d->aa_cap, (const float*)(w + L.cnt_part),
                     active_segments_blocks(nP), n_valid_local, (float*)(w + L.n_valid_f), st));
     return FMHR_OK;
@@ -336,14 +351,15 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     // the count the per-pixel kernels divide the L1 term by: the caller's batch-global one, or "1/3" (divisor 3 * n = 1) when split
     const float* nv_div = split ? (const float*)(w + L.one_third) : n_valid_global;
     float* gvert = (float*)(w + L.gvert);
-    size_t nP = (size_t)d->n * d->H * d->W;
+    const int Wp = eff_pitch(d);
+    size_t nP = (size_t)d->n * d->H * Wp;
     const float rg = wt->reg_grad_scale;
     const size_t nB = 2048;
 
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
         // losses on the antialiased rgba + their per-pixel gradients
-        TRY(loss_pix_impl((const unsigned long long*)(w + L.covw), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP,
+        TRY(loss_pix_impl((const unsigned long long*)(w + L.covw), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP, d->W, Wp,
                           (const int*)(w + L.act_list), (const int*)(w + L.act_count), nv_div,
                           wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_shaded),
                           (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, losses, st));
@@ -354,7 +370,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         TRY(aa_bwd_rgba((const float*)(w + L.aa_dcol), (const float*)(w + L.pix16), nullptr, (const float*)(w + L.vertices), tri, (const float*)(w + L.aa), img, mask, valid_mask,
                         (const unsigned long long*)(w + L.covw), nv_div, wt->sfs, wt->mask, wt->mse_denominator,
                         (const int32_t*)(w + L.aa_items),
-                        (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->n, d->V, d->H, d->W,
+                        (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->n, d->V, d->H, d->W, Wp,
                         (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, split ? (float*)(w + L.gvert_aa2) : nullptr, st));
     }
     {
@@ -362,16 +378,16 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         ProfScope ps(FMHR_SLOT_SHADE_BWD, st);
         TRY(face_bwd_impl((const float*)(w + L.pix16), tri, nullptr, (float*)(w + L.attr8), sh, (float*)(w + L.g_shaded),
                           w + L.cov16, (const unsigned char*)(w + L.own8), (const int*)(w + L.stamp), corner_slot,
-                          (const float*)(w + L.cmat), vertices, d->n, d->V, d->F, d->H, d->W, (float*)(w + L.part),
-                          (const int2*)(w + L.snap), (const int2*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W) + 16),
-                          (const int*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, d->W)), (const unsigned long long*)(w + L.covw),
+                          (const float*)(w + L.cmat), vertices, d->n, d->V, d->F, d->H, d->W, Wp, (float*)(w + L.part),
+                          (const int2*)(w + L.snap), (const int2*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, Wp) + 16),
+                          (const int*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, Wp)), (const unsigned long long*)(w + L.covw),
                           (float*)(w + L.vacc), st));
     }
     {
         // everything per-vertex after the face-parallel backward, in two kernels (mesh.hip: k_mesh_tail_a / _b)
         ProfScope ps(FMHR_SLOT_REGULARISERS, st);
         MeshTailArgs A;
-        A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n, d->H, d->W);
+        A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n, d->H, Wp);
         A.gvert_aa2 = split ? (float*)(w + L.gvert_aa2) : nullptr; A.col_mult = col_mult;
         A.vacc = (float*)(w + L.vacc);
         A.gacc_r = (float*)(w + L.gvert_r);

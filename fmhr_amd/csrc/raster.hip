@@ -183,7 +183,7 @@ template <bool FV, bool BIN>
 __global__ void __launch_bounds__(kTrisBlock) __attribute__((amdgpu_waves_per_eu(BIN ? FMHR_BIN_TRIS_WAVES : 8, 8)))
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
-              int F, int H, int W, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
+              int F, int H, int W, int Wp, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
               int2* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
               const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg,
               unsigned char* __restrict__ own8, const BinArgs ba, const int defer_large)
@@ -356,7 +356,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         T += w;
     }
     const int excl = wbase + incl - cnt;                             // this lane's first task in the workgroup's numbering
-    const long long P = (long long)H * W;
+    const long long P = (long long)H * Wp;                           // Wp: row pitch of the per-pixel buffers (common.h); W clips and scales
     unsigned long long* const keys_view = keys + (size_t)b * P;      // wave-uniform bases: the per-task offsets are 32-bit
     const long long segbase = ((long long)b * P) >> 6;
     const int segrem = (int)(((long long)b * P) & 63);
@@ -484,7 +484,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                     Frag fr;
                     if (fragment(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr)) {
                         const unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)q.f << 1);
-                        const int pix = py * W + px;                     // < 2^26
+                        const int pix = py * Wp + px;                    // < 2^26
                         atomicMin(&keys_view[pix], key);
                         segl = (pix + segrem) >> 6;                      // segment index relative to the view's first segment
                     }
@@ -531,7 +531,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                                                __float_as_uint(fr.zw), __float_as_uint(fr.u), __float_as_uint(fr.v));
                     bin_append(okf, b * ba.segsPerView + py * ba.segsX + (px >> 6), e, ba, lane);
                 } else if (in) {
-                    emit_fragment(q.p0, q.p1, q.p2, px, py, q.f, pg.xs, pg.xo, pg.ys, pg.yo, keys_view, W, dirty, (long long)b * P);
+                    emit_fragment(q.p0, q.p1, q.p2, px, py, q.f, pg.xs, pg.xo, pg.ys, pg.yo, keys_view, Wp, dirty, (long long)b * P);
                 }
             }
         }
@@ -543,7 +543,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
 // one workgroup per queued large-box triangle (grid-stride over the queue; the count lives on the device)
 __global__ void __launch_bounds__(kBlock)
 k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
-               int F, int H, int W, unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt,
+               int F, int H, int W, int Wp, unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt,
                const int2* __restrict__ large_q, unsigned char* __restrict__ dirty, const float* __restrict__ verts,
                const float4* __restrict__ cmat, const PixGrid pg)
 {
@@ -560,10 +560,10 @@ k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, con
         float4 p0 = cv.get(i0), p1 = cv.get(i1), p2 = cv.get(i2);
         pin(p0); pin(p1); pin(p2);
         int bw = s.pxb - s.pxa + 1, bh = s.pyb - s.pya + 1;
-        unsigned long long* kv = keys + (size_t)b * H * W;
+        unsigned long long* kv = keys + (size_t)b * H * Wp;
         for (int i = threadIdx.x; i < bw * bh; i += kBlock) {
             int py = s.pya + i / bw, px = s.pxa + i % bw;
-            if (covers(s, px, py)) emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, W, dirty, (long long)b * H * W);
+            if (covers(s, px, py)) emit_fragment(p0, p1, p2, px, py, f, xs, xo, ys, yo, kv, Wp, dirty, (long long)b * H * Wp);
         }
     }
 }
@@ -590,7 +590,7 @@ __device__ unsigned long long g_ts[8 * 262144];
 constexpr int kResolveBlock = kBlock;
 template <bool UNI, bool FV>
 __global__ void __launch_bounds__(kResolveBlock) __attribute__((amdgpu_waves_per_eu((FV && !UNI) ? 5 : ((UNI && !FV) ? 8 : 7), 8)))
-k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W,
+k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri, int n, int V, int F, int H, int W, int Wp,
                  unsigned long long* __restrict__ keys, float4* __restrict__ rast, unsigned char* __restrict__ dirty,
                  unsigned long long* __restrict__ covw, int* __restrict__ large_cnt, const RasterFused fu, const PixGrid pg)
 {
@@ -601,7 +601,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
     const unsigned blk = blockIdx.x;
     const long long seg_w = (long long)blk * (kResolveBlock / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long gid = (long long)blk * kResolveBlock + threadIdx.x;
-    const long long P = (long long)H * W;
+    const long long P = (long long)H * Wp;
     const bool sparse = dirty != nullptr;
     const long long seg = gid >> 6;
 #ifdef FMHR_X_TS
@@ -648,7 +648,11 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
     {
         const bool live = gid < (long long)n * P;
         unsigned long long key = live ? keys[gid] : ~0ull;
-        const float mk = (live && fu.pix16 != nullptr) ? fu.mask[gid] : 0.f;   // independent of the key: issued with it
+        // the caller's mask is [n,H,W]: with a row pitch the segment's row is one scalar division (a pad lane has no mask)
+        long long cidx = gid;
+        bool incol = true;
+        if (Wp != W) cidx = caller_index((unsigned)seg_w, (int)(threadIdx.x & 63), W, fu.segx, incol);
+        const float mk = (live && incol && fu.pix16 != nullptr) ? fu.mask[cidx] : 0.f;   // independent of the key: issued with it
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f), col = o;
         bool covered = false;
         FMHR_TS(2);
@@ -656,7 +660,7 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
             int rem, px;
             int b = fast_divmod(gid, (int)P, rem);
             if (UNI) b = __builtin_amdgcn_readfirstlane(b);
-            const int py = fast_divmod(rem, W, px);
+            const int py = fast_divmod(rem, Wp, px);
             const int f = (int)((unsigned)(key & 0xffffffffu) >> 1);
             const bool large = (key & 1ull) != 0ull;
             const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
@@ -786,7 +790,7 @@ typedef const int __attribute__((address_space(4))) const_as4_int;
 #endif
 constexpr int kBinsBlock = FMHR_BINS_BLOCK;      // threads per workgroup of k_raster_bins (a wave is independent of its workgroup)
 __global__ void __launch_bounds__(kBinsBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
-k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, const BinArgs ba, unsigned long long* __restrict__ covw,
+k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int Wp, const BinArgs ba, unsigned long long* __restrict__ covw,
               int* __restrict__ large_cnt, const RasterFused fu)
 {
     __shared__ unsigned long long lkey_all[kBinsBlock];
@@ -804,11 +808,17 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, const
         if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
         if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
     }
-    const long long P = (long long)H * W;
+    const long long P = (long long)H * Wp;
     if (seg * 64 >= (long long)n * P) return;
     // the bin's fragment count through the scalar cache (written by the previous kernel's atomics; only this wave resets it)
     int* const cur = ba.cursor + (size_t)seg * kCursorStride;
-    const int count = *(const_as4_int*)(unsigned long long)cur;
+    int count = *(const_as4_int*)(unsigned long long)cur;
+    // EXPLICIT order between this scalar load and the reset store of the same word below: the load comes from the constant address
+    // space (the compiler may move a store across it) and the hardware orders SMEM against VMEM no more than that.  The asm consumes
+    // the loaded register behind an s_waitcnt (the load has returned) and clobbers memory (no store is hoisted above it); the order
+    // no longer hangs on a branch happening to sit in between (round 3: a variant without that branch read its own zero in half of
+    // the segments, a different half in every step).  tests/test_gpu_ham.py::test_bin_cursor_reset_order
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(count) : : "memory");
     if (count == 0) {
         if (lane == 0) {
             covw[seg] = 0ull;
@@ -816,15 +826,15 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, const
         }
         return;
     }
-    const float mk = fu.mask[gid];                                   // independent of the bin: issued with its first loads
+    // the caller's mask is [n,H,W]: with a row pitch the segment's row is one scalar division (a pad lane has no mask)
+    long long cidx = gid;
+    bool incol = true;
+    if (Wp != W) cidx = caller_index((unsigned)seg, lane, W, fu.segx, incol);
+    const float mk = incol ? fu.mask[cidx] : 0.f;                    // independent of the bin: issued with its first loads
     const int step_tag = fu.stamp[0];
     const int cnt = min(count, ba.cap);
     const uint4* __restrict__ bin = ba.bins + (size_t)seg * ba.cap;
-    // self-cleaning.  NOTE the reset store stays behind the `count == 0` exit above on purpose: the count comes through the scalar cache
-    // (a load from the constant address space: the compiler may move a store across it, and the hardware does not order scalar loads
-    // against vector stores).  A variant that no longer branched on the count before this store read its own zero now and then:
-    // half of the segments came out empty, a different half in every step (round 3, packed non-empty flags experiment)
-    if (lane == 0) *cur = 0;
+    if (lane == 0) *cur = 0;                                         // self-cleaning (ordered behind the scalar load of the count: above)
     lkey[lane] = ~0ull;
     unsigned long long best = ~0ull;
     uint4 win = make_uint4(0u, 0u, 0u, 0u);
@@ -861,7 +871,7 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, const
     float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
     if (best != ~0ull) {
         int rem;
-        const int b = __builtin_amdgcn_readfirstlane(fast_divmod(gid, (int)P, rem));   // W % 64 == 0: a segment lies in one view
+        const int b = __builtin_amdgcn_readfirstlane(fast_divmod(gid, (int)P, rem));   // Wp % 64 == 0: a segment lies in one view
         const int f = (int)(win.x & 0x3FFFFFu);
         const bool large = ((win.x >> 22) & 1u) != 0u;
         const float u = __uint_as_float(win.z), v = __uint_as_float(win.w), zw = __uint_as_float(win.y);
@@ -1139,11 +1149,12 @@ int raster_sparse_init(void* ws, unsigned char* dirty, int n, int H, int W, hipS
 // snap [n,V] int2 must already hold the snapped vertices; `fused` may be null.  dirty/covw non-null = sparse mode (the key
 // buffer must have been initialised by raster_sparse_init and is left clean again).
 int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, const int32_t* opp, unsigned char* silh, int n, int V,
-                       int F, int H, int W, float* rast, void* ws, unsigned char* dirty, unsigned long long* covw,
+                       int F, int H, int W, int Wp, float* rast, void* ws, unsigned char* dirty, unsigned long long* covw,
                        const RasterFused* fused, hipStream_t st)
 {
-    size_t nP = (size_t)n * H * W;
-    const size_t kb = raster_keys_bytes(n, H, W);
+    // Wp = row pitch of keys / rast / every fused per-pixel buffer (== W for the stand-alone op; common.h: default_row_pitch)
+    size_t nP = (size_t)n * H * Wp;
+    const size_t kb = raster_keys_bytes(n, H, Wp);
     unsigned long long* keys = (unsigned long long*)ws;
     int* large_cnt = (int*)((char*)ws + kb);
     int2* large_q = (int2*)((char*)ws + kb + 16);
@@ -1174,45 +1185,45 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     // binned form (fused step, micro-triangle mesh, W % 64 == 0): per-segment fragment bins + k_raster_bins instead of the
     // global depth keys + k_raster_resolve.  FMHR_RASTER_BINNED=0 / 1 overrides the default (same-library A/B: tools/abn.sh)
     const bool binned = fu.bins != nullptr && fu.verts != nullptr && dirty != nullptr && fu.pix16 != nullptr && fu.aa_init != nullptr &&
-                        raster_binned_ok(F, H, W) && raster_binned_wanted(kBinnedDefault);
+                        raster_binned_ok(F, H, W, Wp) && raster_binned_wanted(kBinnedDefault);
     BinArgs ba;
     memset(&ba, 0, sizeof(ba));
     if (binned) {
         ba.bins = fu.bins; ba.cursor = fu.bin_cursor; ba.flag = fu.bin_flag; ba.cap = fu.bin_cap;
-        ba.segsX = W / 64; ba.segsPerView = (W / 64) * H;
+        ba.segsX = Wp / 64; ba.segsPerView = (Wp / 64) * H;
     }
     if ((long long)n * F > 0) {
         ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
         const dim3 tgrid(cdiv(F, kTrisBlock), n);                    // view = blockIdx.y
         if (binned)
-            k_raster_tris<true, true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer);
+            k_raster_tris<true, true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer);
         else if (fu.verts != nullptr)
-            k_raster_tris<true, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer);
+            k_raster_tris<true, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer);
         else
-            k_raster_tris<false, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg, fu.stamp != nullptr ? fu.own8 : nullptr, ba, defer);
+            k_raster_tris<false, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg, fu.stamp != nullptr ? fu.own8 : nullptr, ba, defer);
         FMHR_CHECK_LAUNCH("k_raster_tris");
     }
     if (binned) {
         ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-        k_raster_bins<<<cdiv((long long)nP, kBinsBlock), kBinsBlock, 0, st>>>(tri, n, F, H, W, ba, covw, large_cnt, fu);
+        k_raster_bins<<<cdiv((long long)nP, kBinsBlock), kBinsBlock, 0, st>>>(tri, n, F, H, W, Wp, ba, covw, large_cnt, fu);
         FMHR_CHECK_LAUNCH("k_raster_bins");
         return FMHR_OK;
     }
     {
         ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);          // empty on a micro-triangle mesh
         if (use_queue && (long long)n * F > 0) {
-            k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, keys, large_cnt, large_q, dirty, fu.verts, fu.cmat, pg);
+            k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, Wp, keys, large_cnt, large_q, dirty, fu.verts, fu.cmat, pg);
             FMHR_CHECK_LAUNCH("k_raster_large");
         }
     }
     ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
     const dim3 rgrid(cdiv((long long)nP, kResolveBlock));
-    if (fu.verts != nullptr && dirty != nullptr && (((long long)H * W) & 63) == 0)
-        k_raster_resolve<true, true><<<rgrid, kResolveBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
+    if (fu.verts != nullptr && dirty != nullptr && (((long long)H * Wp) & 63) == 0)
+        k_raster_resolve<true, true><<<rgrid, kResolveBlock, 0, st>>>(pos, tri, n, V, F, H, W, Wp, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
     else if (fu.verts != nullptr)
-        k_raster_resolve<false, true><<<rgrid, kResolveBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
+        k_raster_resolve<false, true><<<rgrid, kResolveBlock, 0, st>>>(pos, tri, n, V, F, H, W, Wp, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
     else
-        k_raster_resolve<false, false><<<rgrid, kResolveBlock, 0, st>>>(pos, tri, n, V, F, H, W, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
+        k_raster_resolve<false, false><<<rgrid, kResolveBlock, 0, st>>>(pos, tri, n, V, F, H, W, Wp, keys, (float4*)rast, dirty, covw, large_cnt, fu, pg);
     FMHR_CHECK_LAUNCH("k_raster_resolve");
     return FMHR_OK;
 }
@@ -1229,7 +1240,7 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     int2* snap = (int2*)((char*)ws + raster_core_ws_bytes(n, F, H, W));
     int rc = snap_vertices_impl(pos, n, V, H, W, snap, (hipStream_t)stream);
     if (rc) return rc;
-    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, rast, ws, nullptr, nullptr, nullptr,
+    return rasterize_fwd_impl(pos, snap, tri, nullptr, nullptr, n, V, F, H, W, W, rast, ws, nullptr, nullptr, nullptr,
                               (hipStream_t)stream);
 }
 

@@ -23,11 +23,15 @@ __device__ __forceinline__ unsigned long long covw_at(const unsigned long long* 
 // per-segment "valid_mask has a non-zero" flags: recomputed only when the caller says the mask changed (it is constant over a
 // HAM run: the AA silhouette of the initial mesh, mesh_sfs_optim.py:158)
 __global__ void __launch_bounds__(kBlock)
-k_valid_mask_segments(const float* __restrict__ valid_mask, long long N, unsigned char* __restrict__ vmnz)
+k_valid_mask_segments(const float* __restrict__ valid_mask, long long N, int W, int Wp, const UDiv segx, unsigned char* __restrict__ vmnz)
 {
     long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (gid - (gid & 63) >= N) return;
-    float vm = (gid < N) ? valid_mask[gid] : 0.f;
+    // N counts the step's own pixels [n,H,Wp]; the caller's mask is [n,H,W] (common.h: row pitch)
+    long long cidx = gid;
+    bool incol = true;
+    if (Wp != W) cidx = caller_index((unsigned)__builtin_amdgcn_readfirstlane((int)(gid >> 6)), (int)(threadIdx.x & 63), W, segx, incol);
+    float vm = (gid < N && incol) ? valid_mask[cidx] : 0.f;
     unsigned long long bal = __ballot(vm != 0.f);
     if ((threadIdx.x & 63) == 0) vmnz[gid >> 6] = bal != 0ull ? 1 : 0;
 }
@@ -160,7 +164,7 @@ k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __re
 // the face-parallel backward consumes it.
 __global__ void __launch_bounds__(kBlock)
 k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict__ aa, const float* __restrict__ img,
-           const float* __restrict__ mask, const float* __restrict__ valid_mask, long long N,
+           const float* __restrict__ mask, const float* __restrict__ valid_mask, long long N, int W, int Wp, const UDiv segx,
            const int* __restrict__ act_list, const int* __restrict__ act_count, const float* __restrict__ n_valid_global,
            float w_sfs, float w_mask, float mse_den, float4* __restrict__ g_shaded,
            float* __restrict__ part_l1, float* __restrict__ part_l2, float* __restrict__ losses)
@@ -175,10 +179,15 @@ k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict
         const long long seg = act_list[i] & 0x7fffffff;            // (bit 31 is the antialias scan's flag)
         const long long gid = (seg << 6) + lane;
         if (gid >= N) continue;
+        // img / mask / valid_mask are the caller's [n,H,W] tensors; aa, g_shaded and the coverage words the step's own [n,H,Wp]
+        long long cidx = gid;
+        bool incol = true;
+        if (Wp != W) cidx = caller_index((unsigned)__builtin_amdgcn_readfirstlane((int)seg), lane, W, segx, incol);
+        if (!incol) continue;                                       // a pad column: no pixel, no loss term
         // every request of the iteration up front: aa (16 B), the image pixel (12 B, one request), the two masks
         float4 a = aa[gid];
-        const F3U im = *reinterpret_cast<const F3U*>(img + gid * 3);
-        const float mk = mask[gid], vm = valid_mask[gid];
+        const F3U im = *reinterpret_cast<const F3U*>(img + cidx * 3);
+        const float mk = mask[cidx], vm = valid_mask[cidx];
         const bool cov = (covw[seg] >> lane) & 1ull;          // covered pixel (the segment's coverage word)
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mk > 0.f && cov) {
@@ -326,6 +335,7 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
            const float4* __restrict__ cmat, const float* __restrict__ verts, int n, int V, int F,
            int H, int W, float4* __restrict__ part, const PixGrid pg, const int g, const int b0, const int fb0)
 {
+    // (W here is the ROW PITCH of the per-pixel arrays: this body only addresses with it; the pixel grid comes in pg)
     FMHR_WTS_BEGIN(shade, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kFbBlock / 64) + (threadIdx.x >> 6));
     static_assert(kGroup == 8, "group_sum / the group scans cover 8 lanes");
     constexpr int GV = kGroup * VPL;                               // views per group
@@ -607,14 +617,14 @@ face_bwd_large_items(const float4* __restrict__ bwd16, const int32_t* __restrict
                      const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, const float* __restrict__ verts,
                      const int2* __restrict__ large_q, const int* __restrict__ large_cnt, const unsigned long long* __restrict__ covw,
                      const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
-                     int n, int V, int F, int H, int W, int GV, float* __restrict__ out, const PixGrid pg, int first, int stride)
+                     int n, int V, int F, int H, int W, int Wp, int GV, float* __restrict__ out, const PixGrid pg, int first, int stride)
 {
     constexpr int kWaves = kBlock / 64;
     __shared__ float view_c[kWaves][28];
     __shared__ FaceAttr pk[kWaves];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cnt = large_cnt[1];                                  // the second rasterizer pass kept a copy when it rearmed the queue
-    const long long P = (long long)H * W;
+    const long long P = (long long)H * Wp;                         // W clips the box, Wp (row pitch) addresses
     const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;
     const unsigned char cur = own8 != nullptr ? (unsigned char)stamp[0] : (unsigned char)0;
     for (int it = first; it < cnt; it += stride) {                 // wave-uniform
@@ -658,7 +668,7 @@ face_bwd_large_items(const float4* __restrict__ bwd16, const int32_t* __restrict
             int c;
             const int r = fast_divmod(i, bw, c);
             const int px = pxa + c, py = pya + r;
-            const long long gid = (long long)b * P + (long long)py * W + px;
+            const long long gid = (long long)b * P + (long long)py * Wp + px;
             // a pixel nobody covers in this step keeps the word of an earlier one (possibly this face's): the segment's coverage
             // word tells; a covered pixel's word is this step's, and the owner test settles the rest
             if (!((covw[gid >> 6] >> (gid & 63)) & 1ull)) continue;
@@ -695,11 +705,11 @@ k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ t
                  const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
                  const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, const float* __restrict__ verts,
                  const int2* __restrict__ large_q, const int* __restrict__ large_cnt, const unsigned long long* __restrict__ covw,
-                 int n, int V, int F, int H, int W, int GV, float* __restrict__ part, const PixGrid pg)
+                 int n, int V, int F, int H, int W, int Wp, int GV, float* __restrict__ part, const PixGrid pg)
 {
     constexpr int kWaves = kBlock / 64;
     face_bwd_large_items<false>(bwd16, tri, snap, attr8, sh, g_shaded, corner_slot, cmat, verts, large_q, large_cnt, covw, nullptr, nullptr,
-                                n, V, F, H, W, GV, part, pg, blockIdx.x * kWaves + (threadIdx.x >> 6), gridDim.x * kWaves);
+                                n, V, F, H, W, Wp, GV, part, pg, blockIdx.x * kWaves + (threadIdx.x >> 6), gridDim.x * kWaves);
 }
 
 // VA views per lane in every view group but (VB != VA) the last, which holds the remainder in VB per lane: 48 views = a 32-view group
@@ -711,7 +721,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
            const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
            const float4* __restrict__ cmat, const float* __restrict__ verts, int n, int V, int F,
-           int H, int W, float4* __restrict__ part, const PixGrid pg, const LargeArgs la)
+           int H, int W, int Wp, float4* __restrict__ part, const PixGrid pg, const LargeArgs la)
 {
     const int g = blockIdx.y;
     // the FIRST la.workers workgroups of every grid row are set aside (micro-triangle mesh only); those of row 0 are the workers of the
@@ -720,21 +730,22 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         static_assert(kFbBlock == kBlock, "the queue workers use k_face_bwd_large's wave layout");
         if (g == 0)
             face_bwd_large_items<true>(bwd16, tri, la.snap, attr8, sh, g_shaded, corner_slot, cmat, verts, la.large_q, la.large_cnt, la.covw, own8, stamp,
-                                       n, V, F, H, W, 0, la.vacc, pg, (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6), la.workers * (kBlock / 64));
+                                       n, V, F, H, W, Wp, 0, la.vacc, pg, (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6), la.workers * (kBlock / 64));
         return;
     }
     if (VB != VA && g == (int)gridDim.y - 1)                       // (block-uniform)
-        face_bwd_body<VB>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, n, V, F, H, W, part,
+        face_bwd_body<VB>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, n, V, F, H, Wp, part,
                           pg, g, g * kGroup * VA, la.workers);
     else
-        face_bwd_body<VA>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, n, V, F, H, W, part,
+        face_bwd_body<VA>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, n, V, F, H, Wp, part,
                           pg, g, g * kGroup * VA, la.workers);
 }
 
-int valid_mask_segments_impl(const float* valid_mask, long long N, unsigned char* vmnz, hipStream_t st)
+int valid_mask_segments_impl(const float* valid_mask, int n, int H, int W, int Wp, unsigned char* vmnz, hipStream_t st)
 {
+    const long long N = (long long)n * H * Wp;
     if (N == 0) return FMHR_OK;
-    k_valid_mask_segments<<<cdiv(N, kBlock), kBlock, 0, st>>>(valid_mask, N, vmnz);
+    k_valid_mask_segments<<<cdiv(N, kBlock), kBlock, 0, st>>>(valid_mask, N, W, Wp, make_udiv((unsigned)max(Wp / 64, 1)), vmnz);
     FMHR_CHECK_LAUNCH("k_valid_mask_segments");
     return FMHR_OK;
 }
@@ -762,11 +773,11 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
 }
 
 int loss_pix_impl(const unsigned long long* covw, const float* aa, const float* img, const float* mask, const float* valid_mask,
-                  long long N, const int* act_list, const int* act_count, const float* n_valid_global, float w_sfs, float w_mask,
+                  long long N, int W, int Wp, const int* act_list, const int* act_count, const float* n_valid_global, float w_sfs, float w_mask,
                   float mse_den, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>(covw, (const float4*)aa, img, mask, valid_mask, N, act_list, act_count,
+    k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>(covw, (const float4*)aa, img, mask, valid_mask, N, W, Wp, make_udiv((unsigned)max(Wp / 64, 1)), act_list, act_count,
                                                   n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_shaded, part_l1,
                                                   part_l2, losses);
     FMHR_CHECK_LAUNCH("k_loss_pix");
@@ -793,7 +804,7 @@ int face_bwd_blocks(int F) { return cdiv(F, kFacesPerBlock); }
 
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
                   const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
-                  const float* verts, int n, int V, int F, int H, int W, float* part,
+                  const float* verts, int n, int V, int F, int H, int W, int Wp, float* part,
                   const int2* snap, const int2* large_q, const int* large_cnt, const unsigned long long* covw, float* vacc, hipStream_t st)
 {
     if (n == 0 || F == 0) return FMHR_OK;
@@ -809,15 +820,15 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     la.snap = snap; la.large_q = large_q; la.large_cnt = large_cnt; la.covw = covw; la.vacc = vacc;
     const bool workers = !coarse && vacc != nullptr;
     la.workers = workers ? kLargeWorkers : 0;
-    const dim3 grid(cdiv(F, kFacesPerBlock) + la.workers, face_bwd_groups(n, H, W));
+    const dim3 grid(cdiv(F, kFacesPerBlock) + la.workers, face_bwd_groups(n, H, Wp));
     const PixGrid pg = make_pix_grid(H, W);
 #define FMHR_FACE_BWD(VA, VB)                                                                                                       \
     k_face_bwd<VA, VB><<<grid, kFbBlock, 0, st>>>((const float4*)bwd16, tri, pos, (const float4*)attr8, sh, (const float4*)g_shaded, \
-                                             (const int2*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, n, V, F, H, W, \
+                                             (const int2*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, n, V, F, H, W, Wp, \
                                              (float4*)part, pg, la)
     static_assert(kMaxVPL == 6, "the instantiation table below: 1 .. 4 views per lane with any remainder, 5 and 6 as single groups");
     {
-        const int va = face_bwd_vpl(n, H, W), rem = n - (face_bwd_groups(n, H, W) - 1) * kGroup * va;       // views of the last group
+        const int va = face_bwd_vpl(n, H, Wp), rem = n - (face_bwd_groups(n, H, Wp) - 1) * kGroup * va;     // views of the last group
         const int vb = min(va, cdiv(rem, kGroup));
         switch (va * 8 + vb) {
             case 1 * 8 + 1: FMHR_FACE_BWD(1, 1); break;
@@ -838,7 +849,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     FMHR_CHECK_LAUNCH("k_face_bwd");
     if (coarse) {
         k_face_bwd_large<<<2048, kBlock, 0, st>>>((const float4*)bwd16, tri, snap, (const float4*)attr8, sh, (const float4*)g_shaded, corner_slot,
-                                                  (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, kGroup * face_bwd_vpl(n, H, W), part, pg);
+                                                  (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, Wp, kGroup * face_bwd_vpl(n, H, Wp), part, pg);
         FMHR_CHECK_LAUNCH("k_face_bwd_large");
     }
     return FMHR_OK;

@@ -137,6 +137,8 @@ struct RasterFused {
                                                               // [V,3] vertices and the views' combined matrices (common.h: ClipView),
                                                               // `pos` and `snap` are not read
     uint4* bins; int* bin_cursor; int* bin_flag; int bin_cap; // non-null: per-tile fragment bins (raster.hip: binned rasterizer)
+    UDiv segx;                                                // row pitch != W (ABI 5): division by the segments per row — the caller's
+                                                              // `mask` is [n,H,W], the step's own per-pixel buffers are [n,H,pitch]
 };
 
 // ---- binned rasterizer (raster.hip): a bin = one 64-pixel row segment of the flattened [n, H, W] index = the wave that resolves it.
@@ -163,7 +165,8 @@ constexpr int kCursorStride = FMHR_CURSOR_STRIDE;            // ints between two
                                                               // served one after the other at the memory side (~55 ns each), and with 16 neighbouring
                                                               // bins in a line every reservation of an image region queued behind the others
                                                               // (k_raster_tris 277 us with packed cursors, 124 us padded; profiles/r03_binned_ab.txt)
-inline bool raster_binned_ok(int F, int H, int W) { return (W % 64) == 0 && F < (1 << 22) && !raster_use_queue(H, W, F); }
-inline size_t raster_bin_count(int n, int H, int W) { return ((size_t)n * H * W) / 64; }
+// W: image width (what makes a mesh a micro-triangle one), Wp: row pitch of the step's per-pixel buffers (what a bin is cut from)
+inline bool raster_binned_ok(int F, int H, int W, int Wp) { return (Wp % 64) == 0 && F < (1 << 22) && !raster_use_queue(H, W, F); }
+inline size_t raster_bin_count(int n, int H, int Wp) { return ((size_t)n * H * Wp) / 64; }
 
 }  // namespace fmhr

@@ -47,6 +47,18 @@ class _NcclUniqueId(ctypes.Structure):
     _fields_ = [("internal", ctypes.c_ubyte * 128)]     # (c_char fields read back NUL-terminated: the id would be cut short)
 
 
+class _NcclConfig(ctypes.Structure):
+    """ncclConfig_t up to `splitShare` (the NCCL 2.18 layout; RCCL's parser copies min(size, its own sizeof) bytes over a default-
+    initialised struct and resets whatever is newer than `version`, so the shorter, older form is valid for every later library)."""
+    _fields_ = [("size", ctypes.c_size_t), ("magic", ctypes.c_uint), ("version", ctypes.c_uint), ("blocking", ctypes.c_int),
+                ("cgaClusterSize", ctypes.c_int), ("minCTAs", ctypes.c_int), ("maxCTAs", ctypes.c_int), ("netName", ctypes.c_char_p),
+                ("splitShare", ctypes.c_int)]
+
+
+_NCCL_IN_PROGRESS = 7                                   # ncclInProgress
+_UNDEF_INT = -2147483648                                # NCCL_CONFIG_UNDEF_INT
+
+
 class StreamAllReduce:
     """The step's ONE all-reduce issued straight into RCCL on the STEP'S OWN STREAM (ncclAllReduce, in place, fp32 sum).
 
@@ -56,31 +68,85 @@ class StreamAllReduce:
     of the 8-GPU run spends on its six views.  This class owns a second communicator on the same ranks (its unique id travels over
     the torch group once, at construction) inside the RCCL instance torch itself loaded (torch/lib/librccl.so: one library, two
     communicators), and enqueues the reduction between the backward's last kernel and the combine kernel like any other launch.
-    HamStage2.step(group=<this object>) uses it; anything that fails at construction raises, and callers fall back to the torch group
-    (make_stream_all_reduce does that collectively)."""
+    HamStage2.step(group=<this object>) uses it.
 
-    def __init__(self, group=None):
+    Construction is split into the three phases make_stream_all_reduce negotiates over the torch group, so that NO rank can be left
+    waiting inside RCCL for a peer that never arrives:
+      prepare()      local only: load the library, bind the entry points, rank 0 draws the unique id — may raise, blocks nobody;
+      (the id is broadcast and every rank's "prepared and holds the id" is agreed on with a MIN all-reduce by the caller)
+      connect(t)     ncclCommInitRankConfig with blocking = 0: returns at once; ncclCommGetAsyncError is polled until the communicator
+                     is up or `t` seconds have passed, then ncclCommAbort — bounded, whatever the peers do.
+    StreamAllReduce(group) runs all three for callers that want the object directly (it raises instead of falling back)."""
+
+    def __init__(self, group=None, timeout=30.0, _connect=True):
         if not (dist.is_initialized() and dist.get_backend(group) == "nccl"):
             raise RuntimeError("StreamAllReduce needs an initialised torch.distributed group on the nccl (RCCL) backend")
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.comm, self.lib, self.uid = None, None, None
+        if _connect:
+            self.prepare()
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self.set_id(_broadcast_id(self.id_bytes(), group, dev))
+            self.connect(timeout)
+
+    # -- phase 1: local
+    def prepare(self):
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self.lib = ctypes.CDLL(path if os.path.exists(path) else "librccl.so")
-        L = self.lib
+        self.lib = L = ctypes.CDLL(path if os.path.exists(path) else "librccl.so")
         L.ncclGetErrorString.restype = ctypes.c_char_p
         L.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
-        L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        L.ncclGetVersion.argtypes = [ctypes.POINTER(ctypes.c_int)]
+        L.ncclCommInitRankConfig.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int,
+                                             ctypes.POINTER(_NcclConfig)]
+        L.ncclCommGetAsyncError.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        L.ncclCommAbort.argtypes = [ctypes.c_void_p]
         L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_void_p]
         L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-        uid = _NcclUniqueId()
+        ver = ctypes.c_int(0)
+        self._check(L.ncclGetVersion(ctypes.byref(ver)), "ncclGetVersion")
+        if ver.value < 21800:
+            raise RuntimeError(f"StreamAllReduce: RCCL {ver.value} has no non-blocking communicator initialisation")
+        self.uid = _NcclUniqueId()
         if self.rank == 0:
-            self._check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        box = [ctypes.string_at(ctypes.byref(uid), 128) if self.rank == 0 else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ctypes.memmove(ctypes.byref(uid), box[0], 128)
-        self.comm = ctypes.c_void_p()
-        self._check(L.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+            self._check(L.ncclGetUniqueId(ctypes.byref(self.uid)), "ncclGetUniqueId")
+
+    def id_bytes(self):
+        """the 128 bytes of rank 0's unique id (zeros on the other ranks / before prepare())"""
+        return ctypes.string_at(ctypes.byref(self.uid), 128) if self.uid is not None else bytes(128)
+
+    def set_id(self, raw):
+        ctypes.memmove(ctypes.byref(self.uid), bytes(raw), 128)
+
+    # -- phase 2: the only call that needs the peers — non-blocking, polled against a deadline
+    def connect(self, timeout=30.0):
+        import time
+        L = self.lib
+        cfg = _NcclConfig(ctypes.sizeof(_NcclConfig), 0xcafebeef, 21800, 0, _UNDEF_INT, _UNDEF_INT, _UNDEF_INT, None, _UNDEF_INT)
+        comm = ctypes.c_void_p()
+        rc = L.ncclCommInitRankConfig(ctypes.byref(comm), self.world, self.uid, self.rank, ctypes.byref(cfg))
+        if rc not in (0, _NCCL_IN_PROGRESS):
+            self._check(rc, "ncclCommInitRankConfig")
+        self.comm = comm
+        try:
+            self._wait(time.monotonic() + float(timeout), "ncclCommInitRankConfig")
+        except Exception:
+            self.abort()
+            raise
+
+    def _wait(self, deadline, what):
+        """poll the communicator's asynchronous state until it leaves ncclInProgress; TimeoutError past the deadline"""
+        import time
+        state = ctypes.c_int(_NCCL_IN_PROGRESS)
+        while True:
+            self._check(self.lib.ncclCommGetAsyncError(self.comm, ctypes.byref(state)), "ncclCommGetAsyncError")
+            if state.value != _NCCL_IN_PROGRESS:
+                self._check(state.value, what)
+                return
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"StreamAllReduce: {what} still in progress at its deadline")
+            time.sleep(0.002)
 
     def _check(self, rc, what):
         if rc != 0:
@@ -91,8 +157,18 @@ class StreamAllReduce:
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError("StreamAllReduce.all_reduce_: contiguous float32 GPU tensor required")
         st = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
-        self._check(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), 7, 0, self.comm, st), "ncclAllReduce")   # ncclFloat32, ncclSum
+        rc = self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), 7, 0, self.comm, st)   # ncclFloat32, ncclSum
+        if rc == _NCCL_IN_PROGRESS:                      # a non-blocking communicator may hand the enqueue back unfinished
+            import time
+            self._wait(time.monotonic() + 30.0, "ncclAllReduce")
+        else:
+            self._check(rc, "ncclAllReduce")
         return t
+
+    def abort(self):
+        if getattr(self, "comm", None):
+            self.lib.ncclCommAbort(self.comm)
+            self.comm = None
 
     def close(self):
         if getattr(self, "comm", None):
@@ -100,32 +176,90 @@ class StreamAllReduce:
             self.comm = None
 
 
-def make_stream_all_reduce(group=None, check_numel=4099):
-    """-> a StreamAllReduce for `group`, or `group` itself (the torch path) when the direct communicator cannot be had: every rank
-    tries, the outcome is agreed on over the torch group (one rank failing sends all of them down the torch path), and the direct path
-    must reproduce torch's all-reduce of a test vector bit for bit before it is trusted.  FMHR_STREAM_ALLREDUCE=0 switches it off."""
-    if os.environ.get("FMHR_STREAM_ALLREDUCE", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
-        return group
-    dev = torch.device("cuda", torch.cuda.current_device())
-    sar, ok = None, 1.0
+def _broadcast_id(raw, group, dev):
+    """rank 0's 128 id bytes to every rank of `group` as ONE tensor broadcast (a collective every rank enters, prepared or not)"""
+    t = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return bytes(t.cpu().tolist())
+
+
+def _agree(ok, group, dev):
+    """MIN over the ranks of a local yes / no"""
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return float(flag) == 1.0
+
+
+def negotiate_stream_all_reduce(group, dev, factory, timeout=30.0, check_numel=4099, log=None):
+    """The protocol of make_stream_all_reduce on any backend (`factory(group)` -> an object with prepare / id_bytes / set_id / connect /
+    all_reduce_ / abort / close; the CPU test drives it over gloo with fakes that fail on one rank).  Every collective below is entered
+    by EVERY rank whatever happened to it locally, and the one call that waits for peers inside RCCL (connect) is only entered once all
+    ranks have said they are ready for it, and is bounded by `timeout` on each of them:
+      1. prepare() locally; 2. broadcast of the id; 3. MIN(prepared) — any 0: everybody returns the torch group, nobody connects;
+      4. connect(timeout) — non-blocking init polled against the deadline, aborted on expiry; 5. MIN(connected);
+      6. the direct path must reproduce torch's all-reduce of a test vector; 7. MIN(verified).
+    Returns (object or `group`, reason) — reason is None on success, else the first phase that failed somewhere."""
+    say = log or (lambda m: None)
+    sar, ok = None, True
     try:
-        sar = StreamAllReduce(group)
+        sar = factory(group)
+        sar.prepare()
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        say(f"prepare failed on this rank: {e}")
+    raw = _broadcast_id(sar.id_bytes() if (ok and sar is not None) else bytes(128), group, dev)
+    if ok:
+        try:
+            sar.set_id(raw)
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            say(f"set_id failed on this rank: {e}")
+    if not _agree(ok, group, dev):
+        return group, "prepare"
+    try:
+        sar.connect(timeout)
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        say(f"connect failed on this rank: {e}")
+    if not _agree(ok, group, dev):
+        if ok:
+            sar.abort()                                  # this rank's communicator came up, a peer's did not: give it back
+        return group, "connect"
+    try:
         g = torch.Generator(device="cpu").manual_seed(1234 + dist.get_rank(group))
         x = torch.randn(check_numel, generator=g).to(dev)
         y = x.clone()
         dist.all_reduce(x, group=group)
         sar.all_reduce_(y)
-        torch.cuda.synchronize()
-        ok = 1.0 if torch.allclose(x, y, rtol=1e-6, atol=1e-6) else 0.0
-    except Exception:  # noqa: BLE001
-        ok = 0.0
-    flag = torch.tensor([ok], device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if float(flag) == 1.0:
-        return sar
-    if sar is not None:
-        sar.close()
-    return group
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        ok = bool(torch.allclose(x, y, rtol=1e-6, atol=1e-6))
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        say(f"verification failed on this rank: {e}")
+    if not _agree(ok, group, dev):
+        sar.abort()
+        return group, "verify"
+    return sar, None
+
+
+def make_stream_all_reduce(group=None, check_numel=4099, timeout=None, log=None):
+    """-> a StreamAllReduce for `group`, or `group` itself (the torch path) when the direct communicator cannot be had on EVERY rank:
+    negotiate_stream_all_reduce above — agreed phase by phase over the torch group, the RCCL initialisation non-blocking and bounded
+    (FMHR_STREAM_ALLREDUCE_TIMEOUT seconds, default 30), no rank ever left inside it.  FMHR_STREAM_ALLREDUCE=0 switches it off.
+    `make_stream_all_reduce.last` = (path, reason) of the last call, for the bench line."""
+    make_stream_all_reduce.last = ("torch", "disabled or not the nccl backend")
+    if os.environ.get("FMHR_STREAM_ALLREDUCE", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        return group
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if timeout is None:
+        timeout = float(os.environ.get("FMHR_STREAM_ALLREDUCE_TIMEOUT", "30"))
+    out, why = negotiate_stream_all_reduce(group, dev, lambda g: StreamAllReduce(g, _connect=False), timeout, check_numel, log)
+    make_stream_all_reduce.last = ("rccl-on-step-stream", None) if why is None else ("torch", f"fell back at phase '{why}'")
+    return out
+
+
+make_stream_all_reduce.last = ("torch", "not called")
 
 
 def shard_views(n_views, rank, world):

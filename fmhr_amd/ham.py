@@ -6,6 +6,7 @@ Replaces the loop body of /root/reference/mesh_sfs_optim.py:253-310.  One `HamSt
 L1 divisor left out, the bucket [P | R | losses] is all-reduced once and fmhr_ham_combine applies P / (3 * n_valid_global) + R.
 """
 import ctypes
+import os
 
 import torch
 
@@ -27,7 +28,7 @@ class HamStage2:
 
     faces: int32 [F,3] on the GPU.  `n_global` = number of views in the whole batch (== n unless views are sharded)."""
 
-    def __init__(self, faces, V, n, H, W, weights, edge_len_mean, n_global=None, aa_cap=None, bin_cap=0):
+    def __init__(self, faces, V, n, H, W, weights, edge_len_mean, n_global=None, aa_cap=None, bin_cap=0, pitch=None):
         if not faces.is_cuda or faces.dtype != torch.int32:
             raise RuntimeError("HamStage2: faces must be an int32 GPU tensor")
         self.lib = _lib.load()
@@ -63,7 +64,15 @@ class HamStage2:
         # antialias work items: only pairs that blend are listed (∝ silhouette length); 1/4 of the pixels is a generous bound
         cap = int(aa_cap or max(2048 * 256, self.n * self.H * self.W // 4))     # 768 or 1280 regions (one per workgroup of the AA kernels) of >= 409 items
         # bin_cap: entries per fragment bin of the binned rasterizer (0 = the default 1024 = 16 fragments per pixel of a 64-pixel segment)
-        self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap, int(bin_cap))
+        # pitch (ABI 5): row pitch of the step's own per-pixel buffers; None / 0 = W rounded up to a multiple of 64 (every 64-pixel
+        # segment in one row: binned rasterizer + row-aligned antialias kernels for any W); FMHR_ROW_PITCH=0 in the environment
+        # selects the ABI-4 layout (pitch = W: flat segments) for A/B runs.  The caller's img / mask / valid_mask stay [n,H,W].
+        if pitch is None:
+            pitch = self.W if os.environ.get("FMHR_ROW_PITCH", "1") == "0" else 0
+        self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap, int(bin_cap), int(pitch))
+        self.pitch = self.lib.fmhr_ham_pitch(ctypes.byref(self.dims))
+        if self.pitch < 0:
+            raise RuntimeError("fmhr_ham_pitch failed: " + self.lib.fmhr_last_error().decode())
         self.ws_bytes = self.lib.fmhr_ham_workspace_bytes(ctypes.byref(self.dims))
         if self.ws_bytes == 0:
             raise RuntimeError("fmhr_ham_workspace_bytes failed: " + self.lib.fmhr_last_error().decode())
@@ -83,7 +92,7 @@ class HamStage2:
         self.galbedo_rest = self.bucket[3 * V3: 4 * V3].view(self.V, 3)
         self.losses = self.bucket[4 * V3:]
         # which rasterizer fmhr_ham_forward takes for these dims: per-segment fragment bins resolved in LDS where the mesh is a
-        # micro-triangle one and W % 64 == 0 (FMHR_RASTER_BINNED=0 switches them off), else global depth keys + resolve pass
+        # micro-triangle one and the pitch a multiple of 64 (FMHR_RASTER_BINNED=0 switches them off), else global depth keys + resolve pass
         self.binned = self.lib.fmhr_ham_rasterizer_form(ctypes.byref(self.dims)) == 1
         self._views = None
         self._aa_flag = None
@@ -175,7 +184,7 @@ class HamStage2:
             hv = HamViews()
             call("fmhr_ham_workspace_views", ctypes.byref(self.dims), ptr(self.ws), self.ws_bytes, ctypes.byref(hv))
             base = self.ws.data_ptr()
-            n, V, H, W = self.n, self.V, self.H, self.W
+            n, V, H, W, Wp = self.n, self.V, self.H, self.W, self.pitch
 
             def view(p, shape, dtype=torch.float32):
                 numel = 1
@@ -184,10 +193,12 @@ class HamStage2:
                 off = p - base
                 return self.ws[off: off + numel * 4].view(dtype).view(*shape)
 
-            shaded, aa = view(hv.shaded, (n, H, W, 4)), view(hv.aa, (n, H, W, 4))
-            self._views = dict(pos=view(hv.pos, (n, V, 4)), normals=view(hv.normals, (V, 3)), rast=view(hv.rast, (n, H, W, 4)),
+            # the per-pixel views have rows of `pitch` pixels inside the workspace: sliced to the image's W columns
+            img = lambda p: view(p, (n, H, Wp, 4))[:, :, :W]
+            shaded, aa = img(hv.shaded), img(hv.aa)
+            self._views = dict(pos=view(hv.pos, (n, V, 4)), normals=view(hv.normals, (V, 3)), rast=img(hv.rast),
                                tmp_img_pre_aa=shaded[..., :3], tmp_img=aa[..., :3], pred_mask=aa[..., 3],
-                               aa_counter=view(hv.aa_counter, (2,), torch.int32))
+                               aa_counter=view(hv.aa_counter, (4,), torch.int32))
         return self._views
 
     def raw(self, name, dtype, count):
@@ -207,32 +218,49 @@ class HamStage2:
             self._aa_regions = self.ws[off: off + 2048 * 4].view(torch.int32)
         return self._aa_regions.sum()
 
-    def aa_overflowed(self):
-        """True if the antialias work-item list was full in the last step (one device -> host copy)."""
+    def _flags(self):
         if self._aa_flag is None:
             off = self.lib.fmhr_ham_workspace_offset(ctypes.byref(self.dims), b"aa_counter")
             self._aa_flag_all = self.ws[off: off + 16].view(torch.int32)
             self._aa_flag = self._aa_flag_all[:2]
-        return int(self._aa_flag[1]) != 0
+        return self._aa_flag_all
+
+    def aa_overflowed(self):
+        """True if the antialias work-item list was full in ANY step since the workspace was initialised (sticky, like the
+        fragment-bin flag; one device -> host copy): those steps dropped silhouette pairs from the gradient."""
+        return int(self._flags()[3]) != 0
+
+    def aa_overflowed_last_step(self):
+        """the same for the last step only (the kernel's per-step word, rearmed by every forward)."""
+        return int(self._flags()[1]) != 0
+
+    def overflow_flags(self):
+        """(antialias list, fragment bins) sticky overflow flags with ONE device -> host copy: what an optimisation loop checks once
+        per epoch and at its end (fmhr_amd.pipeline.run_ham)."""
+        f = self._flags().tolist()
+        return f[3] != 0, f[2] != 0
+
+    def check_overflow(self):
+        """raise if a work list of the step overflowed in any step so far (the step itself never synchronises)."""
+        aa, bins = self.overflow_flags()
+        if bins:
+            raise RuntimeError(f"HamStage2: a fragment bin of the rasterizer overflowed (more than {self.dims.bin_cap or 1024} fragments "
+                               "in one 64-pixel segment): fragments were dropped; construct HamStage2 with a larger bin_cap")
+        if aa:
+            raise RuntimeError(f"HamStage2: the antialias work-item list overflowed (aa_cap={self.dims.aa_cap}): some silhouette pairs "
+                               "got no gradient in at least one step; construct HamStage2 with a larger aa_cap")
 
     def raster_overflowed(self):
         """True if a fragment bin of the binned rasterizer was full in ANY step since the workspace was initialised (sticky; one device
         -> host copy): some fragments were dropped — construct HamStage2 with a larger `bin_cap` (entries per 64-pixel segment,
         default 1024 = 16 fragments per pixel)."""
-        if self._aa_flag is None:
-            self.aa_overflowed()
-        return int(self._aa_flag_all[2]) != 0
+        return int(self._flags()[2]) != 0
 
     def loss_dict(self):
         """The loss vector of the last step as a dict (one device -> host copy).  Also the place where a full antialias work-item
         list is reported: the step never synchronises on its own, so the flag is checked when the caller reads results anyway."""
         vals = self.losses.tolist()
-        if self.raster_overflowed():
-            raise RuntimeError(f"HamStage2: a fragment bin of the rasterizer overflowed (more than {self.dims.bin_cap or 1024} fragments "
-                               "in one 64-pixel segment): fragments were dropped; construct HamStage2 with a larger bin_cap")
-        if self.aa_overflowed():
-            raise RuntimeError(f"HamStage2: the antialias work-item list overflowed (aa_cap={self.dims.aa_cap}): some silhouette pairs "
-                               "got no gradient in the last step; construct HamStage2 with a larger aa_cap")
+        self.check_overflow()
         return dict(zip(LOSS_NAMES, vals))
 
 

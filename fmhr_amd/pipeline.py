@@ -115,8 +115,13 @@ def stage1_loss_cached(ops, cache, idx, albedo, sh_coeff, img, sfs_weight):
     return sfs_weight * diff / (3.0 * valid.sum())
 
 
-def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0, scan_id=None):
+def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0, scan_id=None,
+            check_every=1, aa_cap=None, bin_cap=0):
     """The HAM optimisation end to end on GPU tensors.  conf: dict with the keys of conf/demo_sfs.conf that the loop reads.
+    A step never synchronises, so a work list that overflows (antialias pairs, fragment bins: `aa_cap` / `bin_cap` of HamStage2) drops
+    gradient terms without an error of its own: the STICKY overflow flags of every stage-2 workspace are read every `check_every`
+    epochs (one 16-byte copy per workspace), before a workspace is discarded and at the end, and a set flag raises — whatever
+    `log_every` is.
     Returns dict(vertices, delta, albedo, sh_coeffs, history).  With `out_dir` the outputs of mesh_sfs_optim.py:319-343 are written
     under the reference's names: '<scan_id>.pt' (sh_coeff, albedo), '<scan_id>.obj', '<scan_id>_c.obj' (vertex colours) and
     'rerender/mesh_<view>.png' (the last epoch's rendered batches); scan_id = None keeps the stem 'ham'."""
@@ -185,16 +190,21 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     steppers = {}
     epoch_sfs = int(conf["epoch_sfs"])
     rendered_img, perm_last = [], None                                               # :315-317
+    def check_steppers():
+        for hs_ in steppers.values():
+            hs_.check_overflow()
+
     for ep in range(epoch_sfs):
         perm = torch.randperm(num, generator=gen).to(dev)
         if ep == epoch_sfs // 2:
             weights["albedo"] = weights["albedo"] / 10000                            # :250-251
+            check_steppers()                                                         # their flags go with them
             steppers.clear()
         for k in range(0, num, batch):
             idx = perm[k:k + batch]
             n = idx.shape[0]
             if n not in steppers:
-                steppers[n] = HamStage2(faces, vertices.shape[0], n, H, W, weights, elm)
+                steppers[n] = HamStage2(faces, vertices.shape[0], n, H, W, weights, elm, aa_cap=aa_cap, bin_cap=bin_cap)
             hs = steppers[n]
             losses, gd, ga = hs.step(vertices_tmp, delta.detach(), albedo.detach()[0], sh_fixed[idx].contiguous(),
                                      w2cs[idx].contiguous(), projs[idx].contiguous(), imgs[idx].contiguous(),
@@ -206,6 +216,9 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
                 perm_last = perm.cpu().numpy()
         if log_every and ep % log_every == 0:
             history.append(("sfs", ep, hs.loss_dict()))
+        if check_every and (ep + 1) % check_every == 0:
+            check_steppers()
+    check_steppers()
     out_vertices = (vertices_tmp + delta).detach()
     result = dict(vertices=out_vertices, delta=delta.detach(), albedo=albedo.detach(), sh_coeffs=sh_coeffs.detach(), history=history,
                   valid_masks=init["valid_masks"])

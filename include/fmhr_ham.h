@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMHR_ABI_VERSION 4
+#define FMHR_ABI_VERSION 5
 #define FMHR_OK 0
 #define FMHR_E_ARG (-1)   /* bad shape / null pointer / workspace too small */
 #define FMHR_E_HIP (-2)   /* HIP runtime error (message has hipGetErrorString) */
@@ -152,6 +152,15 @@ typedef struct fmhr_ham_dims {
                                    entry; 0 = the default 1024 = 16 fragments per pixel).  Part of the workspace layout: the SAME
                                    value must be passed to every call on a workspace.  A full bin sets aa_counter[2] (sticky) and
                                    drops the excess fragments */
+    int32_t pitch;              /* ABI 5: row pitch, in pixels, of the step's OWN per-pixel buffers (pixel words, antialiased image,
+                                   image gradient, coverage words, fragment bins ...).  0 = the default: W rounded up to a multiple
+                                   of 64, so that every 64-pixel segment — one wave of every per-pixel kernel, one fragment bin — lies
+                                   in ONE row of ONE view whatever W is (W = 334: conf/ih_sfs.conf:14, conf/ih_sfsseq.conf:11) and
+                                   such images run the binned rasterizer and the row-aligned antialias kernels.  Explicit values: W
+                                   (flat segments that straddle rows: the ABI-4 layout, kept for A/B runs) or any multiple of 64
+                                   above W.  Part of the workspace layout like bin_cap.  The CALLER'S tensors are not affected: img
+                                   stays [n,H,W,3], mask / valid_mask [n,H,W]; only the inspection views of fmhr_ham_workspace_views
+                                   have rows of `pitch` pixels (fmhr_ham_pitch) */
 } fmhr_ham_dims;
 
 typedef struct fmhr_ham_weights {
@@ -179,8 +188,11 @@ typedef struct fmhr_ham_weights {
 #define FMHR_LOSS_NVALID 7
 
 size_t fmhr_ham_workspace_bytes(const fmhr_ham_dims* d);
+/* ABI 5: the row pitch in effect for these dims (d->pitch, or W rounded up to a multiple of 64 when that is 0); -1 on bad dims */
+int fmhr_ham_pitch(const fmhr_ham_dims* d);
 /* ABI 4: which rasterizer fmhr_ham_forward takes for these dims: 1 = per-segment fragment bins resolved in LDS (micro-triangle mesh:
- * H*W <= 16 F, W % 64 == 0, F < 2^22; the environment variable FMHR_RASTER_BINNED=0 switches it off for A/B runs), 0 = global
+ * H*W <= 16 F, pitch % 64 == 0 — any W with the default pitch — F < 2^22; the environment variable FMHR_RASTER_BINNED=0 switches it
+ * off for A/B runs), 0 = global
  * atomicMin depth keys + resolve pass (everything else, and the stand-alone dr.rasterize op: nvdiffrast mesh_sfs_optim.py:267). */
 int fmhr_ham_rasterizer_form(const fmhr_ham_dims* d);
 
@@ -189,7 +201,7 @@ int fmhr_ham_rasterizer_form(const fmhr_ham_dims* d);
  *   vertices_tmp, delta, albedo [V,3]; sh [n,9]; w2c, proj [n,4,4] (row-vector convention, get_data.py:96-97);
  *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx, col_mult [nnz]; vf_ptr [V+1]; vf_idx [3F];
  *   corner_slot [3F] (fmhr_corner_slots_build).
- *   n*H*W must be a multiple of 4.
+ *   n*H*pitch must be a multiple of 4 (always true with the default pitch).
  *   valid_mask_changed: pass 1 on the first call on a workspace and whenever valid_mask's CONTENTS may differ from the previous
  *   call (its per-segment non-zero flags are cached in the workspace; the mask is constant over a HAM run, :158).
  *   n_valid_local: device int32[1] written by phase A, which also leaves float(n_valid_local) in the workspace at
@@ -222,16 +234,19 @@ int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const f
  * g = P / (3 * n_valid_global) + R written over P (the first 6V floats are then gdelta | galbedo), the photometric loss slot gets the
  * same divisor, the total slot is formed; n_valid_global = the summed FMHR_LOSS_NVALID slot (0: the photometric term is 0). */
 int fmhr_ham_combine(int V, float* bucket, const fmhr_adam_param* adam_delta, const fmhr_adam_param* adam_albedo, void* stream);
-/* Views of the step's intermediates inside the workspace (for parity tests / rendering): returns device pointers. */
+/* Views of the step's intermediates inside the workspace (for parity tests / rendering): returns device pointers.  The per-pixel
+ * ones have rows of fmhr_ham_pitch(d) pixels: element (b, y, x, c) of `rast` is at ((b*H + y)*pitch + x)*4 + c, x < W; the pad
+ * columns hold zeros after fmhr_ham_densify. */
 typedef struct fmhr_ham_views {
     float* pos;        /* [n,V,4] clip positions: NOT stored by the step (every kernel recomputes them from the vertices and the
                           views' combined matrices) — filled, bit-identical to what the kernels used, by fmhr_ham_densify */
     float* normals;    /* [V,3]     */
-    float* rast;       /* [n,H,W,4] */
-    float* shaded;     /* [n,H,W,4] rgb = shaded image before antialias (tmp_img, :285-286), a = coverage colour (:272); not kept by
+    float* rast;       /* [n,H,pitch,4] */
+    float* shaded;     /* [n,H,pitch,4] rgb = shaded image before antialias (tmp_img, :285-286), a = coverage colour (:272); not kept by
                           the step: filled by fmhr_ham_densify */
-    float* aa;         /* [n,H,W,4] the same after antialias: rgb = tmp_img (:287), a = pred_mask (:274) */
-    int32_t* aa_counter; /* [2] */
+    float* aa;         /* [n,H,pitch,4] the same after antialias: rgb = tmp_img (:287), a = pred_mask (:274) */
+    int32_t* aa_counter; /* [4]: antialias items found (rearmed per step), antialias-list overflow of the LAST step, fragment-bin
+                            overflow (sticky), antialias-list overflow in ANY step since fmhr_ham_workspace_init (sticky) */
 } fmhr_ham_views;
 int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, fmhr_ham_views* out);
 /* byte offset of a named internal buffer inside the workspace (tests / debugging), -1 if unknown */

@@ -84,6 +84,7 @@ void orc_rasterize_fwd_mix(const double* pos, const int32_t* tri, int n, int V, 
     for (size_t i = 0; i < npos; i++) posf[i] = (float)pos[i];
     orc_rasterize_fwd_f32(posf, tri, n, V, F, H, W, rastf);
     const double xs = 2.0 / W, ys = 2.0 / H, xo = 1.0 / W - 1.0, yo = 1.0 / H - 1.0;
+#pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < n; b++)
         for (int py = 0; py < H; py++)
             for (int px = 0; px < W; px++) {
@@ -111,8 +112,15 @@ int orc_antialias_fwd_mix(const double* color, const double* rast, const double*
     for (size_t i = 0; i < npix * 4; i++) rastf[i] = (float)rast[i];
     memcpy(out, color, sizeof(double) * npix * C);
     const double xh = 0.5 * W, yh = 0.5 * H;
-    int cnt = 0;
-    for (int b = 0; b < n; b++)
+    /* per-view item lists, concatenated in view order: see orc_antialias_fwd in raster_oracle_impl.h */
+    int32_t** vit = (int32_t**)calloc((size_t)(n > 0 ? n : 1), sizeof(int32_t*));
+    double** val = (double**)calloc((size_t)(n > 0 ? n : 1), sizeof(double*));
+    int* vcnt = (int*)calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < n; b++) {
+        int cap = 1024, cnt = 0;
+        int32_t* it = (int32_t*)malloc(sizeof(int32_t) * 4 * (size_t)cap);
+        double* al = (double*)malloc(sizeof(double) * (size_t)cap);
         for (int py = 0; py < H; py++)
             for (int px = 0; px < W; px++)
                 for (int d = 0; d < 2; d++) {
@@ -150,12 +158,27 @@ int orc_antialias_fwd_mix(const double* color, const double* rast, const double*
                     const double* c1 = color + pix1 * C;
                     double* o = out + ((alpha > 0.0) ? pix0 : pix1) * C;
                     for (int c = 0; c < C; c++) o[c] += alpha * (c1[c] - c0[c]);
-                    if (cnt < max_items) {
-                        items[cnt * 4 + 0] = px; items[cnt * 4 + 1] = py; items[cnt * 4 + 2] = b; items[cnt * 4 + 3] = code;
-                        alphas[cnt] = alpha;
+                    if (cnt == cap) {
+                        cap *= 2;
+                        it = (int32_t*)realloc(it, sizeof(int32_t) * 4 * (size_t)cap);
+                        al = (double*)realloc(al, sizeof(double) * (size_t)cap);
                     }
+                    it[cnt * 4 + 0] = px; it[cnt * 4 + 1] = py; it[cnt * 4 + 2] = b; it[cnt * 4 + 3] = code;
+                    al[cnt] = alpha;
                     cnt++;
                 }
+        vit[b] = it; val[b] = al; vcnt[b] = cnt;
+    }
+    int cnt = 0;
+    for (int b = 0; b < n; b++) {
+        for (int k = 0; k < vcnt[b]; k++, cnt++)
+            if (cnt < max_items) {
+                memcpy(items + (size_t)cnt * 4, vit[b] + (size_t)k * 4, sizeof(int32_t) * 4);
+                alphas[cnt] = val[b][k];
+            }
+        free(vit[b]); free(val[b]);
+    }
+    free(vit); free(val); free(vcnt);
     free(posf); free(rastf);
     return cnt;
 }

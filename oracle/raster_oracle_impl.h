@@ -92,6 +92,9 @@ void SFX(orc_rasterize_fwd)(const REAL* pos, const int32_t* tri, int n, int V, i
     REAL xo = R_(1) / (REAL)W; xo = xo - R_(1);
     REAL yo = R_(1) / (REAL)H; yo = yo - R_(1);
     memset(rast, 0, sizeof(REAL) * (size_t)n * H * W * 4);
+    /* views are independent (each writes its own image): one OpenMP thread per view at a time — same statements per view, same
+     * results whatever the thread count (bench.py's cpu_baseline runs this on the box's cores; round 3 timed a single-threaded loop) */
+#pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < n; b++) {
         const REAL* vp = pos + (size_t)b * V * 4;
         REAL* ro = rast + (size_t)b * H * W * 4;
@@ -140,6 +143,7 @@ void SFX(orc_rasterize_bwd)(const REAL* pos, const int32_t* tri, const REAL* ras
     const REAL xs = R_(2) / (REAL)W, ys = R_(2) / (REAL)H;
     REAL xo = R_(1) / (REAL)W; xo = xo - R_(1);
     REAL yo = R_(1) / (REAL)H; yo = yo - R_(1);
+#pragma omp parallel for schedule(dynamic, 1)                  /* gpos rows of view b belong to view b: no two threads meet */
     for (int b = 0; b < n; b++)
         for (int py = 0; py < H; py++)
             for (int px = 0; px < W; px++) {
@@ -180,6 +184,7 @@ void SFX(orc_rasterize_bwd)(const REAL* pos, const int32_t* tri, const REAL* ras
 void SFX(orc_interpolate_fwd)(const REAL* attr, const REAL* rast, const int32_t* tri,
                               int n, int an, int V, int F, int H, int W, int C, REAL* out)
 {
+#pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < n; b++) {
         const REAL* A = attr + (an == 1 ? 0 : (size_t)b * V * C);
         for (size_t p = 0; p < (size_t)H * W; p++) {
@@ -200,6 +205,8 @@ void SFX(orc_interpolate_fwd)(const REAL* attr, const REAL* rast, const int32_t*
 void SFX(orc_interpolate_bwd)(const REAL* attr, const REAL* rast, const int32_t* tri, const REAL* dy,
                               int n, int an, int V, int F, int H, int W, int C, REAL* gattr, REAL* grast)
 {
+    /* a broadcast attribute (an == 1) collects the gradient of every view in ONE array: serial then (fixed summation order) */
+#pragma omp parallel for schedule(dynamic, 1) if (an != 1)
     for (int b = 0; b < n; b++) {
         const REAL* A = attr + (an == 1 ? 0 : (size_t)b * V * C);
         REAL* G = gattr + (an == 1 ? 0 : (size_t)b * V * C);
@@ -339,8 +346,16 @@ int SFX(orc_antialias_fwd)(const REAL* color, const REAL* rast, const REAL* pos,
                            int n, int V, int F, int H, int W, int C, REAL* out, int32_t* items, REAL* alphas, int max_items)
 {
     memcpy(out, color, sizeof(REAL) * (size_t)n * H * W * C);
-    int cnt = 0;
-    for (int b = 0; b < n; b++)
+    /* one view per OpenMP thread at a time; every view collects its work items in a list of its own (scan order), and the lists are
+     * concatenated in view order afterwards: the queue is the serial loop's, item for item, whatever the thread count */
+    int32_t** vit = (int32_t**)calloc((size_t)(n > 0 ? n : 1), sizeof(int32_t*));
+    REAL** val = (REAL**)calloc((size_t)(n > 0 ? n : 1), sizeof(REAL*));
+    int* vcnt = (int*)calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < n; b++) {
+        int cap = 1024, cnt = 0;
+        int32_t* it = (int32_t*)malloc(sizeof(int32_t) * 4 * (size_t)cap);
+        REAL* al = (REAL*)malloc(sizeof(REAL) * (size_t)cap);
         for (int py = 0; py < H; py++)
             for (int px = 0; px < W; px++)
                 for (int d = 0; d < 2; d++) {
@@ -356,12 +371,27 @@ int SFX(orc_antialias_fwd)(const REAL* color, const REAL* rast, const REAL* pos,
                     const REAL* c1 = color + pix1 * C;
                     REAL* o = out + ((alpha > R_(0)) ? pix0 : pix1) * C;
                     for (int c = 0; c < C; c++) o[c] += alpha * (c1[c] - c0[c]);
-                    if (cnt < max_items) {
-                        items[cnt * 4 + 0] = px; items[cnt * 4 + 1] = py; items[cnt * 4 + 2] = b; items[cnt * 4 + 3] = code;
-                        alphas[cnt] = alpha;
+                    if (cnt == cap) {
+                        cap *= 2;
+                        it = (int32_t*)realloc(it, sizeof(int32_t) * 4 * (size_t)cap);
+                        al = (REAL*)realloc(al, sizeof(REAL) * (size_t)cap);
                     }
+                    it[cnt * 4 + 0] = px; it[cnt * 4 + 1] = py; it[cnt * 4 + 2] = b; it[cnt * 4 + 3] = code;
+                    al[cnt] = alpha;
                     cnt++;
                 }
+        vit[b] = it; val[b] = al; vcnt[b] = cnt;
+    }
+    int cnt = 0;
+    for (int b = 0; b < n; b++) {
+        for (int k = 0; k < vcnt[b]; k++, cnt++)
+            if (cnt < max_items) {
+                memcpy(items + (size_t)cnt * 4, vit[b] + (size_t)k * 4, sizeof(int32_t) * 4);
+                alphas[cnt] = val[b][k];
+            }
+        free(vit[b]); free(val[b]);
+    }
+    free(vit); free(val); free(vcnt);
     return cnt;
 }
 
@@ -373,7 +403,18 @@ void SFX(orc_antialias_bwd)(const REAL* color, const REAL* rast, const REAL* pos
     (void)F;
     memcpy(gcolor, dy, sizeof(REAL) * (size_t)n * H * W * C);
     REAL xh = R_(0.5) * (REAL)W, yh = R_(0.5) * (REAL)H;
-    for (int k = 0; k < n_items; k++) {
+    /* the forward emits the items view by view: runs of equal view index are independent (a view's pixels and gpos rows are its own),
+     * one run per OpenMP thread at a time, each in list order; an unsorted list (hand-made by a test) is processed serially */
+    int sorted = 1, nruns = 0;
+    for (int k = 1; k < n_items; k++)
+        if (items[k * 4 + 2] < items[(k - 1) * 4 + 2]) sorted = 0;
+    int* run0 = (int*)malloc(sizeof(int) * (size_t)(n_items + 2));
+    for (int k = 0; k < n_items; k++)
+        if (k == 0 || (sorted && items[k * 4 + 2] != items[(k - 1) * 4 + 2])) run0[nruns++] = k;
+    run0[nruns] = n_items;
+#pragma omp parallel for schedule(dynamic, 1) if (sorted && nruns > 1)
+    for (int r = 0; r < nruns; r++)
+    for (int k = run0[r]; k < run0[r + 1]; k++) {
         int px = items[k * 4], py = items[k * 4 + 1], b = items[k * 4 + 2], code = items[k * 4 + 3];
         int d = (code & AA_DOWN) ? 1 : 0, di = AA_DI(code);
         REAL alpha = alphas[k];
@@ -416,6 +457,7 @@ void SFX(orc_antialias_bwd)(const REAL* color, const REAL* rast, const REAL* pos
         qb[0] += g_xb * xh * wb; qb[1] += g_yb * yh * wb;
         qb[3] += -(g_xb * pb[0] * xh + g_yb * pb[1] * yh) * wb * wb;
     }
+    free(run0);
 }
 
 #undef R_

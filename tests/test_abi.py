@@ -26,12 +26,12 @@ def test_header_and_library_agree(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     exported = set(re.findall(r" T (fmhr_[a-z_0-9]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.fmhr_abi_version() == 4
+    assert lib.fmhr_abi_version() == 5
 
 
 def test_struct_layouts_match_header():
     from fmhr_amd._lib import HamDims, HamWeights, HamViews
-    assert ctypes.sizeof(HamDims) == 32 and ctypes.sizeof(HamWeights) == 44 and ctypes.sizeof(HamViews) == 48
+    assert ctypes.sizeof(HamDims) == 36 and ctypes.sizeof(HamWeights) == 44 and ctypes.sizeof(HamViews) == 48
     from fmhr_amd._lib import AdamParam
     assert ctypes.sizeof(AdamParam) == 48
     from fmhr_amd._lib import Stage1Plan
@@ -50,6 +50,18 @@ def test_argument_errors_without_gpu(lib):
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(bad)) == 0
     ok = HamDims(2, 100, 180, 64, 48, 0, 4096, 0)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(ok)) > 2 * 64 * 48 * 16
+    # ABI 5: the row pitch — default W rounded up to a multiple of 64; W itself or a multiple of 64 above it when given
+    assert lib.fmhr_ham_pitch(ctypes.byref(ok)) == 64
+    assert lib.fmhr_ham_pitch(ctypes.byref(HamDims(2, 100, 180, 512, 334, 0, 4096, 0, 0))) == 384
+    assert lib.fmhr_ham_pitch(ctypes.byref(HamDims(2, 100, 180, 512, 334, 0, 4096, 0, 334))) == 334
+    assert lib.fmhr_ham_pitch(ctypes.byref(HamDims(2, 100, 180, 512, 334, 0, 4096, 0, 448))) == 448
+    assert lib.fmhr_ham_pitch(ctypes.byref(HamDims(2, 100, 180, 512, 334, 0, 4096, 0, 400))) == -1
+    assert b"pitch" in lib.fmhr_last_error()
+    flat, padded = HamDims(8, 778, 1538, 512, 334, 0, 4096, 0, 334), HamDims(8, 778, 1538, 512, 334, 0, 4096, 0, 0)
+    assert lib.fmhr_ham_workspace_bytes(ctypes.byref(padded)) > lib.fmhr_ham_workspace_bytes(ctypes.byref(flat)) > 0
+    assert lib.fmhr_ham_rasterizer_form(ctypes.byref(HamDims(2, 49281, 98432, 512, 334, 0, 4096, 0, 0))) == 1     # W = 334, micro-triangle: bins
+    assert lib.fmhr_ham_rasterizer_form(ctypes.byref(HamDims(2, 49281, 98432, 512, 334, 0, 4096, 0, 334))) == 0   # ABI-4 layout: atomic keys
+    assert lib.fmhr_ham_rasterizer_form(ctypes.byref(padded)) == 0                                                 # coarse mesh: the queue
     assert lib.fmhr_rasterize_workspace_bytes(2, 7, 10, 8, 8) == 2 * 64 * 8 + 16 + 2 * 10 * 8 + 2 * 7 * 8
     # fmhr_ham_densify re-shades / recomputes the views the step does not store: it needs the last forward's tri and sh
     lib.fmhr_ham_densify.restype = ctypes.c_int

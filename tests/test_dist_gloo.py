@@ -182,3 +182,101 @@ def test_frames_then_views_partition(oracle, n_frames):
                 continue
             assert rel_err(torch.from_numpy(ls)[:7], ref_l[:7]) < 1e-5
             assert rel_err(torch.from_numpy(gd), ref_gd) < 1e-5 and rel_err(torch.from_numpy(ga), ref_ga) < 1e-5
+
+
+# ---- the negotiation of the direct RCCL communicator (fmhr_amd.dist.negotiate_stream_all_reduce) with fakes over gloo ------------
+class _FakeComm:
+    """stands in for StreamAllReduce: `mode` says what goes wrong on `bad_rank` (prepare raises / connect never completes / the test
+    vector comes out wrong); the good ranks' connect() would wait for the peer like ncclCommInitRank does — the protocol must never
+    put them there when a peer is not coming."""
+    entered_connect = False
+
+    def __init__(self, group, mode, bad_rank):
+        self.group, self.mode, self.bad = group, mode, dist.get_rank(group) == bad_rank
+        self.aborted = False
+
+    def prepare(self):
+        if self.mode == "prepare" and self.bad:
+            raise OSError("librccl.so: cannot open shared object file")
+
+    def id_bytes(self):
+        return bytes(range(128)) if dist.get_rank(self.group) == 0 else bytes(128)
+
+    def set_id(self, raw):
+        assert raw == bytes(range(128)), "the id must reach every rank"
+
+    def connect(self, timeout):
+        import time
+        _FakeComm.entered_connect = True
+        if self.mode == "connect" and self.bad:
+            time.sleep(timeout)                                     # a communicator that never comes up: polled until the deadline
+            raise TimeoutError("ncclCommInitRankConfig still in progress at its deadline")
+        # a good rank: the non-blocking initialisation completes (or, with a missing peer, runs into the same deadline)
+        if self.mode == "connect":
+            time.sleep(timeout)
+            raise TimeoutError("peer never arrived")
+
+    def all_reduce_(self, t, stream=None):
+        dist.all_reduce(t, group=self.group)
+        if self.mode == "verify" and self.bad:
+            t.add_(1.0)
+        return t
+
+    def abort(self):
+        self.aborted = True
+
+    def close(self):
+        pass
+
+
+def _negotiation_worker(rank, world, port, q):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from fmhr_amd import dist as fdist
+    fdist.init_from_env(backend="gloo")
+    cpu = torch.device("cpu")
+    res = {}
+    for mode in ("prepare", "connect", "verify", "ok"):
+        _FakeComm.entered_connect = False
+        made = []
+
+        def factory(g, mode=mode):
+            made.append(_FakeComm(g, mode, bad_rank=1))
+            return made[-1]
+        t0 = time.monotonic()
+        out, why = fdist.negotiate_stream_all_reduce(dist.group.WORLD, cpu, factory, timeout=1.0, check_numel=257)
+        res[mode] = dict(fell_back=out is dist.group.WORLD, why=why, entered_connect=_FakeComm.entered_connect,
+                         seconds=time.monotonic() - t0, aborted=made[0].aborted, is_fake=isinstance(out, _FakeComm))
+        # whatever happened, the torch group still works on every rank (nobody is stuck, nobody left a collective half-entered)
+        x = torch.ones(3)
+        dist.all_reduce(x)
+        assert float(x[0]) == world
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_stream_all_reduce_negotiation_cannot_hang():
+    """ncclCommInitRank is a blocking collective — a rank that failed before it left the others inside it for
+    ever.  Two gloo ranks, rank 1 failing in each phase in turn: (a) prepare fails on one rank -> NO rank enters connect(); (b) connect
+    never completes -> every rank is out after the deadline and falls back; (c) the test vector disagrees on one rank -> all fall back,
+    communicators aborted; (d) all fine -> the direct object on both.  Every case ends with a working torch group on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_negotiation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        r = got[rank]
+        assert r["prepare"]["fell_back"] and r["prepare"]["why"] == "prepare" and not r["prepare"]["entered_connect"], (rank, r["prepare"])
+        assert r["prepare"]["seconds"] < 5.0
+        assert r["connect"]["fell_back"] and r["connect"]["why"] == "connect" and r["connect"]["seconds"] < 10.0, (rank, r["connect"])
+        assert r["verify"]["fell_back"] and r["verify"]["why"] == "verify" and r["verify"]["aborted"], (rank, r["verify"])
+        assert r["ok"]["is_fake"] and r["ok"]["why"] is None and not r["ok"]["aborted"], (rank, r["ok"])

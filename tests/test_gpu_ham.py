@@ -1,6 +1,8 @@
 """GPU parity of the fused stage-2 step (fmhr_ham_forward/backward through fmhr_amd.ham.HamStage2) against the oracle's
 restatement of mesh_sfs_optim.py:253-306 (autograd over the oracle ops), plus the op-by-op `dr` composition (the unchanged
 reference loop body running on fmhr_amd.dr / fmhr_amd.utils)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,7 +17,7 @@ TOL = 1e-4
 # ones named here, each with its measured reason.  In those the fp32 RESTATEMENT OF THE REFERENCE (the oracle's fp32 twin: per-pixel
 # autograd through the homogeneous edge functions, exactly nvdiffrast's formulation) is itself further than 1e-4 from exact
 # arithmetic, because an edge-on triangle amplifies the last bit of its clip positions by 1 / area; the fused step must then be no
-# further from fp64 than twice that twin.  The measured numbers of every case are written to profiles/parity_r03.txt.
+# further from fp64 than twice that twin.  The measured numbers of every case are written to profiles/parity_r04.txt.
 RELAXED = {
     # one pixel of an edge-on triangle of the 197 k-face two-hand mesh: rule R5's fp32 barycentrics (nvdiffrast's homogeneous edge
     # functions) are 2e-3 off there in ANY fp32 evaluation, which is 3.5e-7 of albedo gradient at one vertex = 4.0e-4 of this case's
@@ -76,10 +78,28 @@ CASES = [("C1", (1, 256, 256, 24, 32), 0), ("C2x3", (3, 512, 334, 24, 32), 1), (
          ("silhouette_only_C1", (1, 256, 256, "mano", 0, 0), 13)]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
-def test_fused_step_vs_oracle(oracle, case):
+def expect_layout(hs, flat=False):
+    """ABI 5: the step's per-pixel buffers have a row pitch of W rounded up to 64 unless the ABI-4 layout (pitch = W) is asked for,
+    and the binned rasterizer runs exactly where the mesh is a micro-triangle one (H*W <= 16 F) and the pitch a multiple of 64 —
+    W = 334 (conf/ih_sfs.conf:14, conf/ih_sfsseq.conf:11) included."""
+    assert hs.pitch == (hs.W if flat else (hs.W + 63) // 64 * 64), (hs.pitch, hs.W)
+    micro = hs.H * hs.W <= 16 * hs.F
+    assert hs.binned == (micro and hs.pitch % 64 == 0 and hs.F < (1 << 22)), (hs.binned, hs.H, hs.W, hs.F, hs.pitch)
+
+
+# the ABI-4 layout (pitch = W: segments that straddle rows and views, atomic-key rasterizer, per-pixel antialias scan) stays
+# selectable for A/B runs (FMHR_ROW_PITCH=0 / HamStage2(pitch=W)): these cases keep it under the same oracle bar
+FLAT_CASES = ("C2x3", "ragged", "two_hands50", "views19")
+
+
+@pytest.mark.parametrize("case", CASES + [(c[0] + "_flat",) + c[1:] for c in CASES if c[0] in FLAT_CASES], ids=lambda c: c[0])
+def test_fused_step_vs_oracle(oracle, case, monkeypatch):
     from fmhr_amd.ham import HamStage2, LOSS_NAMES
     name, dims, seed = case
+    flat = name.endswith("_flat")
+    if flat:
+        monkeypatch.setenv("FMHR_ROW_PITCH", "0")
+        name = name[:-5]
     sc = prepare(oracle, dims, seed)
     if name.startswith("silhouette_only"):
         sc["weights"] = dict(sfs=0.0, lap=0.0, albedo=0.0, mask=1000.0, edge=0.0, delta=0.0)
@@ -87,6 +107,7 @@ def test_fused_step_vs_oracle(oracle, case):
     dev = torch.device("cuda:0")
     g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
     hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    expect_layout(hs, flat)
     losses, gdelta, galbedo = hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"],
                                       g["valid_mask"])
     ld = hs.loss_dict()
@@ -137,6 +158,7 @@ def test_fused_step_vs_oracle(oracle, case):
     o_d, o_a = rel_err(gd32, gd64), rel_err(ga32, ga64)
     print(f"{name}: grad rel err vs fp64 oracle: delta {e_d:.2e} albedo {e_a:.2e}; fp32 oracle's own: {o_d:.2e} {o_a:.2e}; "
           f"vs fp32 oracle: {rel_err(gdelta, gd32):.2e} {rel_err(galbedo, ga32):.2e}")
+    name = name + (" [flat ABI-4 layout]" if flat else f" [pitch {hs.pitch}, {'binned' if hs.binned else 'atomic keys'}]")
     log_parity(f"{name}: losses vs fp64: " + " ".join(f"{k} {abs(ld[k] - float(ref64[k])) / max(abs(float(ref64[k])), 1e-6):.1e}"
                                                        for k in ("sfs", "lap", "albedo", "mask", "edge", "delta"))
                + f" | tmp_img vs fp32 twin {rel_err(v['tmp_img'], ref['tmp_img']):.1e} vs fp64 {rel_err(v['tmp_img'], ref64['tmp_img']):.1e}"
@@ -223,6 +245,8 @@ def _step_vs_oracle(oracle, sc, name, osc=None):
     dev = torch.device("cuda:0")
     g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
     hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    if not os.environ.get("FMHR_RASTER_BINNED"):
+        expect_layout(hs, os.environ.get("FMHR_ROW_PITCH") == "0")
     losses, gdelta, galbedo = hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"],
                                       g["valid_mask"])
     ld = hs.loss_dict()
@@ -251,7 +275,7 @@ def _step_vs_oracle(oracle, sc, name, osc=None):
     o_d, o_a = rel_err(gd32, gd64), rel_err(ga32, ga64)
     print(f"{name}: grad rel err vs fp64 oracle: delta {e_d:.2e} albedo {e_a:.2e}; fp32 oracle's own: {o_d:.2e} {o_a:.2e}")
     grad_bar(name, e_d, e_a, o_d, o_a)
-    v = dict(v, gdelta=gdelta.clone(), galbedo=galbedo.clone(), gd64=gd64, ga64=ga64, o_d=o_d, o_a=o_a)
+    v = dict(v, gdelta=gdelta.clone(), galbedo=galbedo.clone(), gd64=gd64, ga64=ga64, o_d=o_d, o_a=o_a, binned=hs.binned, pitch=hs.pitch)
     return ld, v
 
 
@@ -668,7 +692,7 @@ def test_fragment_bin_overflow_is_reported(oracle, monkeypatch):
 
 def test_two_hand_sub3_mesh_at_the_sequence_resolution(oracle):
     """BASELINE.json configs[4] at size: two hands, each the exact sub3 mesh (V = 2 x 49281, F = 2 x 98432, two boundary loops),
-    334 x 512 (conf/ih_sfsseq.conf:11-12) — the fused step (atomic-key rasterizer: W % 64 != 0; per-pixel antialias scan) against
+    334 x 512 (conf/ih_sfsseq.conf:11-12) — the fused step (row pitch 384: binned rasterizer, row-aligned antialias scan) against
     the CPU oracle exactly as the small cases are checked."""
     from fmhr_amd import synthetic as S
     from fmhr_amd.ham import render_forward, edge_length_mean
@@ -685,6 +709,7 @@ def test_two_hand_sub3_mesh_at_the_sequence_resolution(oracle):
     sc.update({k: tg[k].cpu() for k in ("img", "mask", "valid_mask")})
     sc["elm"] = float(edge_length_mean(sc["vertices"].to(dev), faces))
     ld, v = _step_vs_oracle(oracle, sc, "two_hands_sub3_2x512x334")
+    assert v["binned"] and v["pitch"] == 384
     assert ld["n_valid"] > 0.1 * n * H * W
 
 
@@ -755,18 +780,22 @@ def test_binned_rasterizer_rare_paths(oracle, variant, monkeypatch):
         assert nl >= 40, nl
 
 
-@pytest.mark.parametrize("dims", [(3, 192, 192, 64, 96), (3, 96, 80, 24, 32)], ids=["binned", "atomic"])
-def test_workspace_state_after_a_long_optimisation(oracle, dims):
+@pytest.mark.parametrize("dims,flat", [((3, 192, 192, 64, 96), False), ((3, 96, 80, 24, 32), False), ((3, 96, 80, 24, 32), True)],
+                         ids=["binned", "binned_pitch128", "atomic_flat"])
+def test_workspace_state_after_a_long_optimisation(oracle, dims, flat, monkeypatch):
     """Everything the step keeps between calls cleans itself (depth keys / fragment-bin cursors, owner marks, coverage entries,
     segment words, antialias lists, accumulator replicas): after 700 optimiser steps on ONE workspace — past the 256-step period of
     the owner marks and their 128-step wipe — a step at the final parameters must equal the same step on a fresh workspace."""
     from fmhr_amd.ham import HamStage2
     from fmhr_amd.optim import Adam
+    if flat:
+        monkeypatch.setenv("FMHR_ROW_PITCH", "0")             # the ABI-4 layout: pitch = W = 80, atomic depth keys
     sc = prepare(oracle, dims, 61)
     dev = torch.device("cuda:0")
     g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
     hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
-    assert hs.binned == (dims[1] == 192)
+    expect_layout(hs, flat)
+    assert hs.binned == (not flat)
     delta = g["delta"].clone().requires_grad_(True)
     albedo = g["albedo"][None].clone().requires_grad_(True)
     opt = Adam([{'params': delta, 'lr': 1e-4}, {'params': albedo, 'lr': 5e-3}])
@@ -789,3 +818,103 @@ def test_workspace_state_after_a_long_optimisation(oracle, dims):
     e = (rel_err(gd_old, fresh.gdelta), rel_err(ga_old, fresh.galbedo))
     log_parity("step 701 on one workspace vs a fresh workspace (%s rasterizer): gdelta %.1e galbedo %.1e" % ("binned" if hs.binned else "atomic", *e))
     assert e[0] < 5e-5 and e[1] < 5e-5, e
+
+
+# ---- ABI 5: the row pitch ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims", [(3, 256, 334, "mano", 0, 2, 2),      # two hands at W = 334, micro-triangle: bins vs atomic keys
+                                  (2, 512, 334, 24, 32),               # config C2's shape (coarse mesh: the large-triangle queue either way)
+                                  (5, 50, 38, 10, 14),                 # H*W = 1900: flat segments straddle rows AND views
+                                  (4, 72, 120, 16, 24),                # two segments per row, the second one half pad
+                                  (9, 40, 65, 10, 14, 1)],             # one pixel past a segment boundary
+                         ids=lambda d: "x".join(map(str, d)))
+def test_row_pitch_equals_the_flat_layout(oracle, dims):
+    """W % 64 != 0: the default layout (rows padded to a multiple of 64 inside the workspace: row-aligned segments, binned rasterizer
+    on a micro-triangle mesh, mask-scan antialias forward) against the ABI-4 layout (pitch = W) on the same inputs: the rasterizer
+    image and the shaded image bit-identical, the antialiased images / losses / gradients equal up to the order of float atomics — and
+    nothing in the pad columns.  Three steps on each workspace (self-cleaning state behind the pad)."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, dims, 77)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    args = (g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    n, H, W = sc["views"], sc["H"], sc["W"]
+    out = {}
+    for flat in (False, True):
+        hs = HamStage2(sc["faces"].to(dev), sc["V"], n, H, W, sc["weights"], sc["elm"], pitch=W if flat else None)
+        expect_layout(hs, flat)
+        for _ in range(3):
+            hs.step(*args)
+        v = hs.views()
+        out[flat] = dict(rast=v["rast"].clone(), img=v["tmp_img"].clone(), pm=v["pred_mask"].clone(), pre=v["tmp_img_pre_aa"].clone(),
+                         gd=hs.gdelta.clone(), ga=hs.galbedo.clone(), ld=hs.loss_dict(), items=int(hs.aa_item_count()))
+        if not flat:
+            # the pad columns of the workspace images: never covered, never a blend target
+            Wp = hs.pitch
+            off = hs.lib.fmhr_ham_workspace_offset(__import__("ctypes").byref(hs.dims), b"aa")
+            aa_full = hs.ws[off: off + n * H * Wp * 16].view(torch.float32).view(n, H, Wp, 4)
+            off = hs.lib.fmhr_ham_workspace_offset(__import__("ctypes").byref(hs.dims), b"rast")
+            rast_full = hs.ws[off: off + n * H * Wp * 16].view(torch.float32).view(n, H, Wp, 4)
+            assert float(aa_full[:, :, W:].abs().max()) == 0.0 and float(rast_full[:, :, W:].abs().max()) == 0.0
+    a, b = out[False], out[True]
+    assert float((a["rast"][..., 3] > 0).float().mean()) > 0.03
+    assert torch.equal(a["rast"], b["rast"]) and torch.equal(a["pre"], b["pre"])
+    assert a["items"] == b["items"] and a["items"] > 0                     # the same silhouette pairs blend (none across the pad)
+    assert float((a["img"] - b["img"]).abs().max()) <= 1e-6 and float((a["pm"] - b["pm"]).abs().max()) <= 1e-6
+    assert a["ld"]["n_valid"] == b["ld"]["n_valid"]
+    for k in ("sfs", "lap", "albedo", "mask", "edge", "delta", "total"):
+        assert abs(a["ld"][k] - b["ld"][k]) <= 2e-6 * max(abs(b["ld"][k]), 1e-6), (k, a["ld"][k], b["ld"][k])
+    e = (rel_err(a["gd"], b["gd"]), rel_err(a["ga"], b["ga"]))
+    log_parity("row pitch vs flat layout %s: rast / shaded bit-identical, %d antialias items, gdelta %.1e galbedo %.1e" % ("x".join(map(str, dims)), a["items"], *e))
+    assert e[0] < 5e-5 and e[1] < 2e-6, e
+
+
+def test_bad_pitch_is_rejected(oracle):
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (2, 64, 48, 10, 14), 3)
+    dev = torch.device("cuda:0")
+    for bad in (47, 100, 16384):                                           # below W; above W but not a multiple of 64; above 8192
+        with pytest.raises(RuntimeError, match="pitch"):
+            HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"], pitch=bad)
+    assert HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"], pitch=128).pitch == 128
+
+
+def test_bin_cursor_reset_order(oracle):
+    """k_raster_bins reads a bin's fragment count through the scalar cache and resets the same word with a vector store: the order is
+    explicit in the kernel (s_waitcnt + a compiler barrier), and a violation shows as segments that come out empty at random — so
+    every one of eight consecutive steps on one workspace must give the first step's image and valid-pixel count."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (6, 192, 192, 64, 96), 19)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    args = (g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    assert hs.binned
+    hs.step(*args)
+    r1, nv1 = hs.views()["rast"].clone(), float(hs.losses[7])
+    assert float((r1[..., 3] > 0).float().mean()) > 0.05
+    for k in range(7):
+        hs.step(*args)
+        assert float(hs.losses[7]) == nv1, k
+        assert torch.equal(hs.views()["rast"], r1), k
+
+
+def test_aa_overflow_flag_is_sticky(oracle):
+    """the antialias list's overflow word is rearmed every step — an overflow in the MIDDLE of a run was invisible at its
+    end.  aa_counter[3] stays set until the workspace is initialised again: overflow in step 1, none in step 2 (every view looks past
+    the mesh: no pair), and loss_dict() / check_overflow() still raise."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (2, 128, 96, 16, 24), 22)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"], aa_cap=2048)   # 1 - 2 items per region
+    hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    assert hs.aa_overflowed_last_step() and hs.aa_overflowed()
+    away = g["proj"].clone()
+    away[:, :, 0] += 5.0 * away[:, :, 3]                                   # clip x shifted by 5 w: nothing on screen
+    hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], away, g["img"], g["mask"], g["valid_mask"])
+    assert int(hs.aa_item_count()) == 0 and not hs.aa_overflowed_last_step()
+    assert hs.aa_overflowed() and hs.overflow_flags() == (True, False)
+    with pytest.raises(RuntimeError, match="overflowed"):
+        hs.check_overflow()
+    with pytest.raises(RuntimeError, match="overflowed"):
+        hs.loss_dict()

@@ -109,3 +109,29 @@ def test_run_ham_with_degree_two(oracle):
     s2 = [h[2]["sfs"] for h in out["history"] if h[0] == "sfs"]
     assert len(s1) == 4 and len(s2) == 4 and s1[-1] < s1[0] and all(np.isfinite(v) for v in s1 + s2)
     assert float(out["delta"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("which", ["aa_cap", "bin_cap"])
+def test_run_ham_raises_on_a_work_list_overflow(which):
+    """run_ham read the overflow flags only through loss_dict() and only when log_every was set, and the antialias
+    flag only told about the LAST step.  With log_every = 0 and a deliberately small antialias list / fragment bin the run must
+    raise (sticky flags, read every epoch and at the end) instead of returning gradients with dropped terms."""
+    from fmhr_amd import pipeline, synthetic as S
+    from fmhr_amd.ham import render_forward
+    dev = torch.device("cuda:0")
+    sc = S.make_scene(4, 192, 176, 64, 96, 0, seed=8)       # micro-triangle mesh, W % 64 != 0: row pitch 192, binned rasterizer
+    faces = sc["faces"].to(dev)
+    w2c, proj = sc["w2c"].to(dev), sc["proj"].to(dev)
+    tg = S.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, 192, 176), device=dev)
+    img = tg["img"]
+    gray = (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).contiguous()
+    conf = dict(batch=2, degree=3, epoch_albedo=1, epoch_sfs=4, sfs_weight=50.0, lap_weight=2000.0, albedo_weight=1.0,
+                mask_weight=1000.0, edge_weight=500000.0, delta_weight=50000.0, lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
+    args = (sc["vertices"].to(dev), faces, img, gray, tg["mask"], w2c, proj, (192, 176), conf)
+    out = pipeline.run_ham(*args, log_every=0)              # default capacities: runs through
+    assert torch.isfinite(out["vertices"]).all()
+    kw = dict(aa_cap=2048) if which == "aa_cap" else dict(bin_cap=64)
+    with pytest.raises(RuntimeError, match="overflowed"):
+        pipeline.run_ham(*args, log_every=0, **kw)
+    with pytest.raises(RuntimeError, match="overflowed"):   # ... also when only the end-of-run check is left
+        pipeline.run_ham(*args, log_every=0, check_every=0, **kw)
