@@ -120,6 +120,7 @@ def cpu_baseline(scene, views_sample, seed):
         avail = os.cpu_count() or 1
     cores = int(os.environ.get("FMHR_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
+    cores_c = oracle.set_threads(cores)          # the C rasterizer / interpolate / antialias loop over VIEWS with OpenMP: one view per thread
     S = views_sample
     w2c, proj = scene["w2c"][:S].contiguous(), scene["proj"][:S].contiguous()
     sh = scene["sh0"][:S].contiguous()
@@ -146,7 +147,7 @@ def cpu_baseline(scene, views_sample, seed):
     n = scene["views"]
     return dict(value=1.0 / (t * n / S), unit="iterations/s", cores=cores, kind="port",
                 sample=f"{S} of {n} views ({H}x{W}, V={scene['V']}), fwd+bwd, median of 5 = {t:.3f}s, scaled x{n / S:.0f}; "
-                       f"C rasterizer is single-threaded, torch ops use {cores} threads")
+                       f"C rasterize / interpolate / antialias: {cores_c} OpenMP threads over the views, torch ops: {cores} threads")
 
 
 def stage1_side_measurement(scene, faces, w2c, proj, sh, tg, vtmp, H, W, dev, steps=100):
@@ -182,6 +183,43 @@ def stage1_side_measurement(scene, faces, w2c, proj, sh, tg, vtmp, H, W, dev, st
             "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "loss": round(float(lv.sum()), 6), "steps": steps}
 
 
+def run_length_side_measurement(Problem, stream, length):
+    """Not the headline metric: the SAME optimisation from its first step over the reference's demo length (300 epochs x 2 batches
+    of stage 2 = 600 steps, /root/reference/conf/demo_sfs.conf:9,24, mesh_sfs_optim.py:247-252) on a fresh workspace with fresh
+    parameters.  `value` is timed on the stationary (pre-rolled) workload; a real run starts with a short antialias work list and grows
+    sliver triangles as it goes: this is the mean over the whole run and the triangle kernel at its end."""
+    p = Problem(0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    slot = SLOTS.index("raster_tris")
+    marks = sorted({min(32, length), length})
+    probe = {}
+    torch.cuda.synchronize()
+    e0.record(stream)
+    done = 0
+    for m in marks:                                       # the last 8 steps before each mark carry an event pair around k_raster_tris
+        for _ in range(max(0, m - 8 - done)):
+            p.step()
+        k = min(8, m - done - max(0, m - 8 - done))
+        tm = Timing(k, stream)
+        for i in range(k):
+            tm.attach(i, slot)
+            p.step()
+        Timing.detach()
+        probe[m] = (tm, k)
+        done = m
+    e1.record(stream)
+    torch.cuda.synchronize()
+    p.hs.check_overflow()
+    out = {"what": f"steps 1..{length} of the same optimisation from scratch (the reference's demo run: 300 epochs x 2 batches), fresh "
+                   "workspace; HIP events around the whole run (16 of the steps carry an event pair around k_raster_tris)",
+           "steps": length, "ms_per_step_mean": round(e0.elapsed_time(e1) / length, 4),
+           "iterations_per_s_mean": round(length / e0.elapsed_time(e1) * 1e3, 1),
+           "aa_items_at_end": int(p.hs.aa_item_count())}
+    for m, (tm, k) in probe.items():
+        out[f"raster_tris_ms_at_step_{m}"] = round(sum(tm.ms(i, slot) for i in range(k)) / max(k, 1), 4)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +229,9 @@ def main():
     ap.add_argument("--views", type=int, default=None, help="override the view count of the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage1", action="store_true", help="skip the stage-1 side measurement (N = 1 only; after the timed region)")
+    ap.add_argument("--no-run-length", action="store_true", help="skip the reference-length side measurement (N = 1 only)")
+    ap.add_argument("--run-length", type=int, default=600, help="steps of the reference-length side measurement: the demo run is 300 "
+                    "epochs x 2 batches of stage 2 (conf/demo_sfs.conf:9,24; mesh_sfs_optim.py:247-252)")
     ap.add_argument("--cpu-views", type=int, default=48)   # the whole 48-view batch: 5 x ~2.6 s of CPU work, nothing extrapolated
     ap.add_argument("--preroll", type=int, default=320, help="upper bound of the untimed pre-roll (stops earlier once the antialias "
                     "work list is stationary; at least 128 steps; 0 = none)")
@@ -356,7 +397,8 @@ def main():
                                       "combine_adam": [round(float(p[2]), 4) for p in allp]},
                       "bytes": int(hs.bucket.numel() * 4), "note": "all_reduce includes the wait for the slowest rank's kernels",
                       "path": ("ncclAllReduce (RCCL) on the step's own stream" if hasattr(group, "all_reduce_") else
-                               "torch.distributed.all_reduce (the backend's own stream)")}
+                               "torch.distributed.all_reduce (the backend's own stream)"),
+                      "path_negotiation": list(fdist.make_stream_all_reduce.last)}
     P = H * W
     # dominant launch group: the longest one.  Three kernels are within ~20 % of each other (k_raster_tris 84-88, the second rasterizer
     # pass 78, k_face_bwd 70-73 us by rocprofv3; until v89 k_face_bwd moved between 74 and 92 us with the number of sliver triangles the
@@ -408,14 +450,13 @@ def main():
     if sharded:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed)
-    dom_ms_raw = sum(tk.ms(j, dom) for j in range(len(sampled))) / len(sampled)
-    # an event pair with NOTHING between its two records already reads ~4.7 us (the launch groups that are empty on this workload —
-    # raster_clear, raster_large, transform_bwd, normals_bwd — show exactly that in the profiling pass): the dispatch gaps on either
-    # side of a kernel, which rocprofv3's kernel durations do not contain.  It is measured in this run and taken off, so that the
-    # launch duration agrees with the committed rocprofv3 summary
+    # the launch duration of the dominant group = the RAW mean of its HIP-event pairs over the timed region (it agrees with
+    # rocprofv3's kernel duration — 86.2 vs 85.1 us — while the "empty event pair" correction round 3 subtracted put it BELOW the
+    # profiler's figure).  What an empty pair reads (the launch groups that are empty on this workload) is still reported, as
+    # information only
+    dom_ms = dom_ms_raw = sum(tk.ms(j, dom) for j in range(len(sampled))) / len(sampled)
     empty = sorted(kernels[s_] for s_ in ("raster_clear", "raster_large", "transform_bwd", "normals_bwd") if kernels[s_] < 0.008)
     ev_overhead = empty[len(empty) // 2] if empty else 0.0
-    dom_ms = max(dom_ms_raw - ev_overhead, 1e-6)
     step_dev_ms = sum(ev0[j].elapsed_time(ev1[j]) for j in range(len(sampled))) / len(sampled)
     # a full antialias work-item list (some silhouette pairs without a gradient) invalidates the run — on EVERY rank
     ovf = torch.tensor([1.0 if any(p.hs.aa_overflowed() or p.hs.raster_overflowed() for p in problems) else 0.0], device=dev)
@@ -432,9 +473,8 @@ def main():
         # HBM traffic of the launch groups comes from the committed PMC profile of this same command (counters cannot be
         # collected live next to the timed region); null when the workload differs from the profiled one
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
+        tpath = next((os.path.join(ROOT, "profiles", f) for f in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json")
+                      if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
         if os.path.exists(tpath) and args.config == "metric" and world == 1 and args.views is None and hs.binned == traffic_binned(tpath):
             traffic = json.load(open(tpath))
         ms_per_step = elapsed / K * 1e3
@@ -465,7 +505,8 @@ def main():
                          "traffic_gbs": ((traffic or {}).get(SLOTS[dom]) or 0) / (dom_ms * 1e-3) / 1e9 or None,
                          "traffic_frac": ((traffic or {}).get(SLOTS[dom]) or 0) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS or None,
                          "traffic_source": (traffic or {}).get("_source"), "alg_bytes_per_launch": dom_bytes,
-                         "avg_launch_ms": dom_ms, "avg_launch_ms_raw_events": dom_ms_raw, "event_pair_overhead_ms": ev_overhead,
+                         "avg_launch_ms": dom_ms, "avg_launch_ms_source": "raw mean of the HIP-event pairs around the launch group over the timed region",
+                         "empty_event_pair_ms": ev_overhead,
                          "event_samples": len(sampled),
                          "longest_groups_ms": {SLOTS[k]: round(kernels[SLOTS[k]], 4) for k in cand if kernels[SLOTS[k]] >= 0.65 * tmax}},
             "step_roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "device_ms_per_step": step_dev_ms,
@@ -485,6 +526,11 @@ def main():
         }
         if collective is not None:
             out["collective"] = collective
+        if world == 1 and nf_local == 1 and not args.no_run_length:
+            try:
+                out["run_length"] = run_length_side_measurement(Problem, stream, args.run_length)
+            except Exception as e:  # noqa: BLE001
+                out["run_length"] = {"error": f"{type(e).__name__}: {e}"}
         # the two side measurements must never cost the headline line: a failure is reported in their place
         if world == 1 and not args.no_stage1:
             try:

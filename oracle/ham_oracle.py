@@ -55,7 +55,21 @@ def lib():
         _LIB.orc_topology_build.restype = ctypes.c_int
         for s in ("f32", "f64", "mix"):
             getattr(_LIB, "orc_antialias_fwd_" + s).restype = ctypes.c_int
+        set_threads()
     return _LIB
+
+
+def set_threads(n=None):
+    """threads of the C ops' loops over views (OpenMP; results do not depend on the count).  Default: the CPUs this process may run
+    on, at most 16 (a one-GPU job of the pool has a 16-CPU share whatever os.cpu_count() says); FMHR_CPU_THREADS overrides."""
+    if n is None:
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        n = int(os.environ.get("FMHR_CPU_THREADS", min(avail, 16)))
+    lib().orc_set_num_threads(int(n))
+    return int(lib().orc_get_max_threads())
 
 
 def _p(t):

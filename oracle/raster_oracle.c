@@ -9,6 +9,12 @@
 #include <string.h>
 #include <math.h>
 #include <float.h>
+#include <omp.h>
+
+/* threads of the loops over views (this library links the system libgomp; torch carries a libgomp of its own, so
+ * torch.set_num_threads does not reach these loops) */
+void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_get_max_threads(void) { return omp_get_max_threads(); }
 
 /* ---- topology: opp[f*3+k] = vertex opposite to edge k (= edge (v[k+1], v[k+2])) in the neighbouring face, or -1.
  * Edges are keyed by vertex index pairs (as nvdiffrast's edge hash is); an edge shared by more than two faces keeps the

@@ -285,3 +285,30 @@ def test_antialias_is_linear_in_colour_for_a_fixed_geometry(oracle):
         tgt, oth = (p0, p1) if al > 0 else (p1, p0)
         want[tgt] += abs(al) * (x[oth] - x[tgt])
     assert (want - ax).abs().max() < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_view_parallel_loops_do_not_depend_on_the_thread_count(oracle, dtype):
+    """the C ops loop over views with OpenMP (bench.py's cpu_baseline runs them on the box's cores): one view per thread at a time,
+    per-view work-item lists concatenated in view order — forward images, the work queue and every gradient must be bit-identical
+    with 1 and with 4 threads (6 views, so threads hold several views and finish out of order)."""
+    def run():
+        pos, tri, rng = random_scene(5, n=6, H=40, W=36, dtype=dtype, nv=40, nf=70)
+        pos = pos.clone().requires_grad_(True)
+        attr = torch.tensor(rng.standard_normal((6, 40, 3)), dtype=dtype, requires_grad=True)
+        rast, _ = oracle.rasterize(None, pos, tri, (40, 36))
+        col, _ = oracle.interpolate(attr, rast, tri)
+        out, items, alphas = oracle.antialias(col, rast, pos, tri, return_items=True)
+        w = torch.tensor(rng.standard_normal(tuple(out.shape)), dtype=dtype)
+        (out * w).sum().backward()
+        return [rast.detach(), col.detach(), out.detach(), items, alphas, pos.grad.clone(), attr.grad.clone()]
+    try:
+        assert oracle.set_threads(1) == 1
+        a = run()
+        assert oracle.set_threads(4) == 4
+        b = run()
+    finally:
+        oracle.set_threads()
+    assert int(a[3].shape[0]) > 20 and float(a[5].abs().max()) > 0
+    for x, y in zip(a, b):
+        assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))

@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out/abstat
 rm -f $R/gpurun_out/abstat/*.jsonl
 for rep in $(seq 1 ${REPS:-6}); do for v in ${VARIANTS:-old new}; do
   cp $R/build/ab/$v.so $R/fmhr_amd/libfmhr_ham.so
-  python $R/bench.py --no-cpu-baseline --no-stage1 ${BENCH_ARGS:-} > $R/gpurun_out/abstat/_run.log 2>&1 || { tail -5 $R/gpurun_out/abstat/_run.log; exit 1; }
+  python $R/bench.py --no-cpu-baseline --no-stage1 --no-run-length ${BENCH_ARGS:-} > $R/gpurun_out/abstat/_run.log 2>&1 || { tail -5 $R/gpurun_out/abstat/_run.log; exit 1; }
   tail -1 $R/gpurun_out/abstat/_run.log >> $R/gpurun_out/abstat/$v.jsonl
   echo "round $rep $v done"
 done; done

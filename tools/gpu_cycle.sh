@@ -15,7 +15,7 @@ print(d["kernels_ms"])
 PY
 if [ -n "$PROF" ]; then
   cd /tmp && export TMPDIR=/tmp
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$PROF -o $PROF --output-format csv -- python3 $R/bench.py --steps 25 --warmup 3 --no-cpu-baseline --no-stage1 > $R/gpurun_out/p.log 2>&1 || { tail -20 $R/gpurun_out/p.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$PROF -o $PROF --output-format csv -- python3 $R/bench.py --steps 25 --warmup 3 --no-cpu-baseline --no-stage1 --no-run-length > $R/gpurun_out/p.log 2>&1 || { tail -20 $R/gpurun_out/p.log; exit 1; }
   python - <<PY
 import csv, glob
 f = glob.glob("$R/gpurun_out/$PROF/**/*kernel_stats.csv", recursive=True)[0]

@@ -44,7 +44,7 @@ for p, counters in enumerate(PASSES):
         raise SystemExit("the first pass must hold SQ_WAVES / SQ_INSTS_VALU")
     out = os.path.join(ROOT, "gpurun_out", f"{TAG}_issue{p}")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters.split(), "-d", out, "-o", "pmc", "--output-format", "csv", "--",
-           "python3", os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-stage1", *BENCH_ARGS]
+           "python3", os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-stage1", "--no-run-length", *BENCH_ARGS]
     # own process group: on a timeout the profiler AND the bench child that holds the GPU are killed together
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
     try:

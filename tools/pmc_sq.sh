@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 P=0
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_VMEM_RD"; do
   P=$((P+1))
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/${TAG}_sq$P -o pmc --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stage1 > $R/gpurun_out/${TAG}_sq$P.log 2>&1 || { tail -20 $R/gpurun_out/${TAG}_sq$P.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/${TAG}_sq$P -o pmc --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stage1 --no-run-length > $R/gpurun_out/${TAG}_sq$P.log 2>&1 || { tail -20 $R/gpurun_out/${TAG}_sq$P.log; exit 1; }
   echo "pass $P done"
 done
 python3 - <<PY > $R/gpurun_out/${TAG}_sq_counters.txt

@@ -27,7 +27,7 @@ fa, fc = load(sys.argv[1], "FETCH_SIZE")
 wa, wc = load(sys.argv[2], "WRITE_SIZE")
 names = sorted(set(fa) | set(wa), key=lambda k: -(fa.get(k, 0) + wa.get(k, 0)))
 print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (two separate passes: they cannot share one)")
-print("# command: rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stage1")
+print("# command: rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stage1 --no-run-length")
 print("# metric config: 48 views x 512x512, V=49281, F=98432 (pre-rolled to the stationary antialias list).  Values: mean KB per launch.")
 print("# gfx950 caveat: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams (x2 correction = the 'high' total).")
 print(f"{'kernel':44s} {'launches':>8s} {'FETCH_KB':>12s} {'WRITE_KB':>12s}")

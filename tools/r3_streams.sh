@@ -2,7 +2,7 @@
 # frames of a sequence capture on several HIP streams: does the chip have slack that independent problems can fill?
 set -e
 mkdir -p gpurun_out/streams
-B="python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-stage1"
+B="python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-stage1 --no-run-length"
 for k in 1 2; do FMHR_DUP_FRAMES=2 $B --frame-streams $k > gpurun_out/streams/metric_dup2_s$k.json; done
 for k in 1 2 4 8; do $B --config C5 --frame-streams $k > gpurun_out/streams/C5_s$k.json; done
 python - <<'PY'

@@ -9,7 +9,7 @@ timeout -k 10 ${TEST_TIMEOUT:-800} python -m pytest $R/tests ${PYTEST_X--x} -q -
 tail -1 $R/gpurun_out/t.log
 [ "${BENCH:-1}" = "0" ] && exit 0
 timeout -k 10 300 python $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/b20.log 2>&1 || { tail -30 $R/gpurun_out/b20.log; exit 1; }
-timeout -k 10 300 python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-stage1 > $R/gpurun_out/b200.log 2>&1 || { tail -30 $R/gpurun_out/b200.log; exit 1; }
+timeout -k 10 300 python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-stage1 --no-run-length > $R/gpurun_out/b200.log 2>&1 || { tail -30 $R/gpurun_out/b200.log; exit 1; }
 python - <<PY
 import json
 for f in ("b20", "b200"):

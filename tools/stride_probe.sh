@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/stride
 rm -f $R/gpurun_out/stride/*.jsonl
 for rep in $(seq 1 ${REPS:-5}); do for c in metric metric_h520; do
-  python $R/bench.py --config $c --no-cpu-baseline --no-stage1 > $R/gpurun_out/stride/_run.log 2>&1 || { tail -5 $R/gpurun_out/stride/_run.log; exit 1; }
+  python $R/bench.py --config $c --no-cpu-baseline --no-stage1 --no-run-length > $R/gpurun_out/stride/_run.log 2>&1 || { tail -5 $R/gpurun_out/stride/_run.log; exit 1; }
   tail -1 $R/gpurun_out/stride/_run.log >> $R/gpurun_out/stride/$c.jsonl
   echo "round $rep $c done"
 done; done
