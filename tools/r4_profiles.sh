@@ -14,3 +14,6 @@ cp $(find $R/gpurun_out/$TAG -name "*kernel_stats.csv" | head -1) $R/gpurun_out/
 head -14 $R/gpurun_out/${TAG}_kernel_stats.csv | cut -c1-150
 bash $R/tools/pmc_traffic.sh $TAG | tail -16 || exit 1
 [ "${ISSUE:-1}" = "0" ] || python3 $R/tools/pmc_issue.py $TAG | tail -8
+# the raw rocprofv3 directories (per-dispatch CSVs, tens of MB) are scratch: only the summaries above travel back (gpurun merges <= 64 MiB)
+rm -rf $R/gpurun_out/$TAG $R/gpurun_out/${TAG}_FETCH_SIZE $R/gpurun_out/${TAG}_WRITE_SIZE $R/gpurun_out/${TAG}_issue[0-9]
+
