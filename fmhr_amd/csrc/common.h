@@ -141,6 +141,61 @@ __device__ __forceinline__ bool fragment(const float4 p0, const float4 p1, const
     return true;
 }
 
+// rule R5, the depth only: the SAME statements as fragment() for everything z/w and the accept / reject decision depend on (the
+// barycentrics' reciprocal and clamps are left out): the binned rasterizer's triangle kernel evaluates this for every fragment —
+// 60 % of them are hidden behind a nearer one — and the second pass evaluates fragment() in full for the ~2.4 M winners only.
+__device__ __forceinline__ bool fragment_zw(const float4 p0, const float4 p1, const float4 p2, int px, int py,
+                                            float xs, float xo, float ys, float yo, float& zw)
+{
+    float fx = xs * (float)px; fx = fx + xo;
+    float fy = ys * (float)py; fy = fy + yo;
+    float t;
+    t = fx * p0.w; float p0x = p0.x - t;  t = fy * p0.w; float p0y = p0.y - t;
+    t = fx * p1.w; float p1x = p1.x - t;  t = fy * p1.w; float p1y = p1.y - t;
+    t = fx * p2.w; float p2x = p2.x - t;  t = fy * p2.w; float p2y = p2.y - t;
+    float m0, m1;
+    m0 = p1x * p2y; m1 = p1y * p2x; float a0 = m0 - m1;
+    m0 = p2x * p0y; m1 = p2y * p0x; float a1 = m0 - m1;
+    m0 = p0x * p1y; m1 = p0y * p1x; float a2 = m0 - m1;
+    float at = a0 + a1; at = at + a2;
+    if (!(fabsf(at) > 0.0f)) return false;
+    float zn = p0.z * a0; t = p1.z * a1; zn = zn + t; t = p2.z * a2; zn = zn + t;
+    float wn = p0.w * a0; t = p1.w * a1; wn = wn + t; t = p2.w * a2; wn = wn + t;
+    float q = zn / wn;
+    if (!(q == q)) return false;
+    if (q < -1.0f) q = -1.0f;
+    if (q > 1.0f) q = 1.0f;
+    q = q + 0.0f;
+    zw = q;
+    return true;
+}
+
+// ... and the barycentrics only, for a fragment fragment_zw() has accepted (x, y, w of the three clip positions): the statements of
+// fragment() that lead to (u, v), nothing else
+__device__ __forceinline__ void fragment_uv(float p0cx, float p0cy, float p0w, float p1cx, float p1cy, float p1w, float p2cx, float p2cy, float p2w,
+                                            int px, int py, float xs, float xo, float ys, float yo, float& u, float& v)
+{
+    float fx = xs * (float)px; fx = fx + xo;
+    float fy = ys * (float)py; fy = fy + yo;
+    float t;
+    t = fx * p0w; float p0x = p0cx - t;  t = fy * p0w; float p0y = p0cy - t;
+    t = fx * p1w; float p1x = p1cx - t;  t = fy * p1w; float p1y = p1cy - t;
+    t = fx * p2w; float p2x = p2cx - t;  t = fy * p2w; float p2y = p2cy - t;
+    float m0, m1;
+    m0 = p1x * p2y; m1 = p1y * p2x; float a0 = m0 - m1;
+    m0 = p2x * p0y; m1 = p2y * p0x; float a1 = m0 - m1;
+    m0 = p0x * p1y; m1 = p0y * p1x; float a2 = m0 - m1;
+    float at = a0 + a1; at = at + a2;
+    float iw = 1.0f / at;
+    float b0 = a0 * iw;
+    float b1 = a1 * iw;
+    if (b0 < 0.0f) b0 = 0.0f;
+    if (b0 > 1.0f) b0 = 1.0f;
+    if (b1 < 0.0f) b1 = 0.0f;
+    if (b1 > 1.0f) b1 = 1.0f;
+    u = b0; v = b1;
+}
+
 // NDC coordinates of a pixel centre (rule R5): fx = xs * px + xo, fy = ys * py + yo.  Computed ONCE on the host (IEEE fp32, one
 // rounding per operation: bit-identical to the same statements on the device) and handed to the kernels: evaluated per wave the
 // four correctly rounded divisions cost ~45 vector instructions, 6 % of the triangle kernel.

@@ -129,13 +129,13 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.seg_valid = take(off, ((nP + 63) / 64) * 4);   // valid-pixel count of every segment (resolve pass)
     L.cnt_part = take(off, (((nP + 63) / 64 + 1023) / 1024) * 4);   // the same per workgroup of k_active_segments
     L.silw = take(off, ((nP + 63) / 64) * 8);        // per segment: pixels of silhouette faces (resolve pass -> antialias scan)
-    // binned rasterizer (raster.hip): per 64-pixel segment a cursor (one per cache line) and room for bin_cap_entries() 16-B fragment
-    // entries (16 KB per segment: 3.2 GB at the metric, of which a step touches the ~100 MB its fragments fill — sized for the
+    // binned rasterizer (raster.hip): per 64-pixel segment a cursor (one per cache line) and room for bin_cap_entries() 8-B fragment
+    // entries (8 KB per segment: 1.6 GB at the metric, of which a step touches the ~50 MB its fragments fill — sized for the
     // 288-GB part, not for the footprint)
     const bool binned = raster_binned_ok(d->F, d->H, d->W, Wp);
     const size_t tiles = binned ? raster_bin_count(d->n, d->H, Wp) : 0;
     L.bin_cursor = take(off, tiles * 4 * kCursorStride + 16);
-    L.bins = take(off, tiles * (size_t)bin_cap_entries(d->bin_cap) * 16);
+    L.bins = take(off, tiles * (size_t)bin_cap_entries(d->bin_cap) * sizeof(BinEntry));
     L.total = off;
     return L;
 }
@@ -299,7 +299,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.bins = nullptr; fu.bin_cursor = nullptr; fu.bin_flag = nullptr; fu.bin_cap = 0;
         fu.segx = make_udiv((unsigned)((Wp + 63) / 64));            // used when Wp != d->W: segment -> row of the caller's [n,H,W] mask
         if (raster_binned_ok(d->F, d->H, d->W, Wp)) {
-            fu.bins = (uint4*)(w + L.bins); fu.bin_cursor = (int*)(w + L.bin_cursor); fu.bin_cap = bin_cap_entries(d->bin_cap);
+            fu.bins = (BinEntry*)(w + L.bins); fu.bin_cursor = (int*)(w + L.bin_cursor); fu.bin_cap = bin_cap_entries(d->bin_cap);
             fu.bin_flag = (int*)(w + L.aa_counter) + 2;             // sticky overflow flag next to the antialias list's (read by the host)
         }
         TRY(rasterize_fwd_impl(nullptr, (const int2*)(w + L.snap), tri, opp, (unsigned char*)(w + L.silh), d->n, d->V, d->F, d->H, d->W, Wp,

@@ -104,23 +104,25 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
 // ---- binned rasterizer: fragments go into per-segment bins instead of a global depth-key buffer -----------------------------------
 // north_star: "LDS-staged per-tile triangle bins and wave64 ballot / prefix-scan fragment compaction".  A bin is one 64-pixel row
 // segment (the tile a wave of the per-pixel kernels owns: everything downstream keeps its layout).  The triangle kernel appends every
-// fragment (face, pixel-in-segment, z/w, u, v: 16 B) to its segment's bin; k_raster_bins — one wave per segment — stages the bin in
-// LDS, takes the depth minimum per pixel in LDS (ds_min_u64 on (monotone(z/w), face, entry index)) and runs the resolve + forward-
-// shading epilogue on the winners straight from the staged entries: the 8-B-per-pixel global key buffer (100 MB at the metric), its
-// 2 M atomicMin line requests, its read-back + reset and the dirty-segment flags are gone, and the winner's (u, v, z/w) are the
-// triangle kernel's own values instead of a second evaluation behind three more vertex gathers.
+// fragment (face | flags | pixel-in-segment, z/w: 8 B since round 4) to its segment's bin; k_raster_bins — one wave per segment — stages
+// the bin in LDS, takes the depth minimum per pixel in LDS (ds_min_u64 on (monotone(z/w), face, entry index)), evaluates the winners'
+// barycentrics and runs the resolve + forward-shading epilogue: the 8-B-per-pixel global key buffer (100 MB at the metric), its
+// 2 M atomicMin line requests, its read-back + reset and the dirty-segment flags are gone; the depth is evaluated once per fragment
+// (fragment_zw), the barycentrics once per covered pixel (fragment_uv).
 // Slots are reserved per WORKGROUP: the fragments of a workgroup's 256 consecutive faces fall into a few dozen segments; a direct-
 // mapped LDS table (segment -> count; rows mod 64 x two column segments) gives every fragment its rank inside (workgroup, segment)
 // with one ds_cmpst + one ds_add_rtn, then ONE returning global atomic per table entry reserves the run — all of them in one
 // instruction, in flight while the workgroup evaluates its fragments (a returning atomic per wave and round, waited for on the spot,
 // cost 124 us; with the cursors packed 16 per cache line 280 us).
-struct BinArgs { uint4* bins; int* cursor; int* flag; int cap; int segsX; int segsPerView; };
+struct BinArgs { BinEntry* bins; int* cursor; int* flag; int cap; int segsX; int segsPerView; };
+// (face | flags | pixel, z/w[, u, v]) -> an entry
+__device__ __forceinline__ BinEntry make_entry(unsigned head, float zw) { return make_uint2(head, __float_as_uint(zw)); }
 constexpr int kHash = 128;                       // LDS table slots per workgroup round (a round has at most 512 fragments)
 constexpr unsigned kBinInvalid = 0xFFFFFFFFu;    // first word of a reserved entry whose fragment was degenerate
 
 // Slow path (a table that ran full, large-box triangles swept by their wave): wave-uniform call; every RUN of consecutive lanes with
 // the same bin reserves its slots with one returning atomic (all runs of the wave in one instruction) and stores to consecutive slots.
-__device__ __forceinline__ void bin_append(bool valid, int bin, const uint4 e, const BinArgs& ba, int lane)
+__device__ __forceinline__ void bin_append(bool valid, int bin, const BinEntry e, const BinArgs& ba, int lane)
 {
     const int tl = valid ? bin : -1;
     const int prev = wave_prev_lane(tl, -2);
@@ -412,17 +414,18 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             int gbase = 0;
             if (own) gbase = atomicAdd(ba.cursor + ((size_t)b * ba.segsPerView + hkey[threadIdx.x]) * kCursorStride, hcnt[threadIdx.x]);
             // phase 3: the fragments (the ~110-instruction evaluation hides the reservations' round trip)
-            auto evaluate = [&](int t, unsigned& e, int& bin, uint4& ent) {
+            auto evaluate = [&](int t, unsigned& e, int& bin, BinEntry& ent) {
                 e = tasks32[t];
                 int o, px, py;
                 const int face = decode(e, o, px, py);
                 bin = b * ba.segsPerView + py * segsX + (px >> 6);
-                Frag fr;
-                const bool okf = fragment(pk0[o], pk1[o], pk2[o], px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr);
-                ent = make_uint4(okf ? ((unsigned)face | ((unsigned)(px & 63) << 26)) : kBinInvalid, __float_as_uint(fr.zw),
-                                 __float_as_uint(fr.u), __float_as_uint(fr.v));
+                // rule R5, the depth only (common.h: fragment_zw — fragment()'s statements for z/w and for the accept / reject decision;
+                // the barycentrics are evaluated by the second pass, for the winners)
+                float zw = 0.f;
+                const bool okf = fragment_zw(pk0[o], pk1[o], pk2[o], px, py, pg.xs, pg.xo, pg.ys, pg.yo, zw);
+                ent = make_entry(okf ? ((unsigned)face | ((unsigned)(px & 63) << 26)) : kBinInvalid, zw);
             };
-            auto store = [&](bool have, unsigned e, int bin, const uint4 ent) {
+            auto store = [&](bool have, unsigned e, int bin, const BinEntry ent) {
                 const int slot = (int)(e >> 13) & 255;
                 if (have && slot != 255) {
                     const int pos = hcnt[slot] + (int)(e >> 21);
@@ -434,7 +437,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             };
             unsigned e0 = 0u;
             int bin0 = 0;
-            uint4 ent0 = make_uint4(0u, 0u, 0u, 0u);
+            BinEntry ent0 = make_entry(0u, 0.f);
             const bool have0 = (int)threadIdx.x < nt;
             if (have0) evaluate(threadIdx.x, e0, bin0, ent0);
             if (own) hcnt[threadIdx.x] = gbase;                      // count -> base slot (waits for the atomic here)
@@ -444,7 +447,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 const int t = t0 + threadIdx.x;
                 unsigned e1 = 0u;
                 int bin1 = 0;
-                uint4 ent1 = make_uint4(0u, 0u, 0u, 0u);
+                BinEntry ent1 = make_entry(0u, 0.f);
                 if (t < nt) evaluate(t, e1, bin1, ent1);
                 store(t < nt, e1, bin1, ent1);
             }
@@ -525,10 +528,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 const int px = q.s.pxa + c, py = q.s.pya + r;
                 const bool in = i < np && covers(q.s, px, py);
                 if (BIN) {
-                    Frag fr;
-                    const bool okf = in && fragment(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr);
-                    const uint4 e = make_uint4((unsigned)q.f | (1u << 22) | ((unsigned)(px & 63) << 26),
-                                               __float_as_uint(fr.zw), __float_as_uint(fr.u), __float_as_uint(fr.v));
+                    float zw = 0.f;
+                    const bool okf = in && fragment_zw(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, zw);
+                    const BinEntry e = make_entry((unsigned)q.f | (1u << 22) | ((unsigned)(px & 63) << 26), zw);
                     bin_append(okf, b * ba.segsPerView + py * ba.segsX + (px >> 6), e, ba, lane);
                 } else if (in) {
                     emit_fragment(q.p0, q.p1, q.p2, px, py, q.f, pg.xs, pg.xo, pg.ys, pg.yo, keys_view, Wp, dirty, (long long)b * P);
@@ -779,27 +781,30 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
 }
 
 // ---- binned rasterizer, second pass: one wave per 64-pixel segment = per bin (the resolve pass's shape: no workgroup barrier, an
-// empty segment costs one scalar load).  The bin is staged in the wave's LDS kBinChunk entries at a time (coalesced 16-B loads, two
+// empty segment costs one scalar load).  The bin is staged in the wave's LDS kBinChunk entries at a time (coalesced 8-B loads, two
 // in flight per lane); every entry posts ds_min_u64 on its pixel's LDS key = (monotone(z/w) << 32 | face << 8 | entry index):
 // nearest fragment, ties to the lowest face index — rule R6, the order of the global atomicMin it replaces — and the pixel's lane
-// reads the winner's entry back from the staged chunk.  No vertex gathers, no clip positions, no second fragment evaluation: the
-// epilogue is the resolve pass's shading + per-pixel word + owner mark + segment words.
+// reads the winner's entry back from the staged chunk.  The winner's barycentrics are evaluated here (its three vertices ride with
+// the `tri` row); then the resolve pass's epilogue: shading + per-pixel word + owner mark + segment words.
 typedef const int __attribute__((address_space(4))) const_as4_int;
 #ifndef FMHR_BINS_BLOCK
 #define FMHR_BINS_BLOCK 256
 #endif
 constexpr int kBinsBlock = FMHR_BINS_BLOCK;      // threads per workgroup of k_raster_bins (a wave is independent of its workgroup)
-__global__ void __launch_bounds__(kBinsBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef FMHR_BINS_WAVES
+#define FMHR_BINS_WAVES 8
+#endif
+__global__ void __launch_bounds__(kBinsBlock) __attribute__((amdgpu_waves_per_eu(FMHR_BINS_WAVES, 8)))
 k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int Wp, const BinArgs ba, unsigned long long* __restrict__ covw,
-              int* __restrict__ large_cnt, const RasterFused fu)
+              int* __restrict__ large_cnt, const RasterFused fu, const PixGrid pg)
 {
     __shared__ unsigned long long lkey_all[kBinsBlock];
-    __shared__ uint4 chunk_all[(kBinsBlock / 64) * kBinChunk];
+    __shared__ BinEntry chunk_all[(kBinsBlock / 64) * kBinChunk];
     static_assert(kBinChunk % 64 == 0 && kBinChunk <= 256, "8-bit entry index in the LDS key");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned long long* const lkey = lkey_all + wv * 64;             // this wave's pixels
-    uint4* const chunk = chunk_all + wv * kBinChunk;
+    BinEntry* const chunk = chunk_all + wv * kBinChunk;
     const long long gid = (long long)blockIdx.x * kBinsBlock + tid;
     const long long seg = (long long)blockIdx.x * (kBinsBlock / 64) + wv;
     if (gid == 0) {                                                  // rearm the list cursors of the kernels after this one (as the resolve pass does)
@@ -833,17 +838,17 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
     const float mk = incol ? fu.mask[cidx] : 0.f;                    // independent of the bin: issued with its first loads
     const int step_tag = fu.stamp[0];
     const int cnt = min(count, ba.cap);
-    const uint4* __restrict__ bin = ba.bins + (size_t)seg * ba.cap;
+    const BinEntry* __restrict__ bin = ba.bins + (size_t)seg * ba.cap;
     if (lane == 0) *cur = 0;                                         // self-cleaning (ordered behind the scalar load of the count: above)
     lkey[lane] = ~0ull;
     unsigned long long best = ~0ull;
-    uint4 win = make_uint4(0u, 0u, 0u, 0u);
+    BinEntry win = make_entry(0u, 0.f);
     for (int c0 = 0; c0 < cnt; c0 += kBinChunk) {                    // wave-uniform; one round unless > 4 fragments per pixel
-        uint4 e[kBinChunk / 64];
+        BinEntry e[kBinChunk / 64];
 #pragma unroll
         for (int k = 0; k < kBinChunk / 64; k++) {
             const int i = c0 + k * 64 + lane;
-            e[k] = make_uint4(kBinInvalid, 0u, 0u, 0u);
+            e[k] = make_entry(kBinInvalid, 0.f);
             if (i < cnt) e[k] = bin[i];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -874,14 +879,43 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
         const int b = __builtin_amdgcn_readfirstlane(fast_divmod(gid, (int)P, rem));   // Wp % 64 == 0: a segment lies in one view
         const int f = (int)(win.x & 0x3FFFFFu);
         const bool large = ((win.x >> 22) & 1u) != 0u;
-        const float u = __uint_as_float(win.z), v = __uint_as_float(win.w), zw = __uint_as_float(win.y);
         const bool shade = mk > 0.f;
         // the face's silhouette bits in this view ride in the entry; a large-box face (swept by its wave, rare) has them in the byte array
         const int sbits = large ? (int)fu.silh[(size_t)b * F + f] : (int)((win.x >> 23) & 7u);
         float4 q0, q1, u0, u1, w0, w1;
         float shc[9];
+        // The entry carries the depth only: the winner's (u, v) are evaluated HERE, for the ~40 % of the fragments that win their pixel
+        // (round 4: 16-B entries with the triangle kernel's (u, v) -> 8-B entries: k_raster_tris 91.5 -> 86.5 us, this pass 82.8 -> 88.0 us,
+        // 2 823 -> 2 846 it/s over four alternating rounds, half the bins' footprint and entry traffic).  The face's three vertices come
+        // with its `tri` row, the clip positions (x, y, w: the barycentrics need no z) from the shared clip_coord() chains with the view's
+        // matrix in SGPRs, and fragment_uv() is the (u, v) part of rule R5's statement sequence.  The attribute gathers are requested
+        // BEHIND that arithmetic: issued with the vertex loads they kept 24 more registers live across it (94 VGPRs: 5 waves per SIMD,
+        // 104 us; at 6 waves 24 spills: 143 us; requested once the clip positions stand, in front of the barycentrics: 90.6 us).
+        const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+        F3U x0 = *reinterpret_cast<const F3U*>(fu.verts + (size_t)i0 * 3);
+        F3U x1 = *reinterpret_cast<const F3U*>(fu.verts + (size_t)i1 * 3);
+        F3U x2 = *reinterpret_cast<const F3U*>(fu.verts + (size_t)i2 * 3);
+        float cm[16];
+        {
+            const_as4_float* cp = (const_as4_float*)(unsigned long long)(fu.cmat + (size_t)b * 4);
+#pragma unroll
+            for (int k = 0; k < 16; k++) cm[k] = cp[k];
+        }
+        asm volatile("" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z));
+        const float p0x = clip_coord(x0.x, x0.y, x0.z, cm[0], cm[4], cm[8], cm[12]), p0y = clip_coord(x0.x, x0.y, x0.z, cm[1], cm[5], cm[9], cm[13]),
+                    p0w = clip_coord(x0.x, x0.y, x0.z, cm[3], cm[7], cm[11], cm[15]);
+        const float p1x = clip_coord(x1.x, x1.y, x1.z, cm[0], cm[4], cm[8], cm[12]), p1y = clip_coord(x1.x, x1.y, x1.z, cm[1], cm[5], cm[9], cm[13]),
+                    p1w = clip_coord(x1.x, x1.y, x1.z, cm[3], cm[7], cm[11], cm[15]);
+        const float p2x = clip_coord(x2.x, x2.y, x2.z, cm[0], cm[4], cm[8], cm[12]), p2y = clip_coord(x2.x, x2.y, x2.z, cm[1], cm[5], cm[9], cm[13]),
+                    p2w = clip_coord(x2.x, x2.y, x2.z, cm[3], cm[7], cm[11], cm[15]);
+        // the pixel: the segment's row and first column are wave-uniform (one scalar division), the lane is the column inside it
+        const unsigned rowg = udiv((unsigned)seg, fu.segx), col0 = ((unsigned)seg - rowg * fu.segx.d) << 6;
+        const int py = (int)rowg - b * H, px = (int)col0 + lane;
+        float u, v;
+        fragment_uv(p0x, p0y, p0w, p1x, p1y, p1w, p2x, p2y, p2w, px, py, pg.xs, pg.xo, pg.ys, pg.yo, u, v);
+        const float zw = __uint_as_float(win.y);
+        asm volatile("" : "+v"(u), "+v"(v));
         if (shade) {
-            const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
             q0 = fu.attr8[(size_t)i0 * 2]; q1 = fu.attr8[(size_t)i0 * 2 + 1];
             u0 = fu.attr8[(size_t)i1 * 2]; u1 = fu.attr8[(size_t)i1 * 2 + 1];
             w0 = fu.attr8[(size_t)i2 * 2]; w1 = fu.attr8[(size_t)i2 * 2 + 1];
@@ -1205,7 +1239,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     }
     if (binned) {
         ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-        k_raster_bins<<<cdiv((long long)nP, kBinsBlock), kBinsBlock, 0, st>>>(tri, n, F, H, W, Wp, ba, covw, large_cnt, fu);
+        k_raster_bins<<<cdiv((long long)nP, kBinsBlock), kBinsBlock, 0, st>>>(tri, n, F, H, W, Wp, ba, covw, large_cnt, fu, pg);
         FMHR_CHECK_LAUNCH("k_raster_bins");
         return FMHR_OK;
     }

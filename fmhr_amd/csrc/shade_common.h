@@ -122,6 +122,10 @@ __device__ __forceinline__ float4 shade_word(const float4 w, const int32_t* __re
     return col;
 }
 
+// entry of a fragment bin (raster.hip: binned rasterizer): 8 B = (face | large-box flag << 22 | silhouette bits << 23 | pixel-in-segment
+// << 26, z/w bits); the second pass evaluates (u, v) for the winners (round 3 carried them: 16 B)
+typedef uint2 BinEntry;
+
 // what the fused stage-2 step adds to the rasterizer's passes (all null for the stand-alone dr.rasterize path)
 struct RasterFused {
     int2* cov16; int* stamp; unsigned char* own8;             // coverage entries, step counter, owner marks (face-parallel backward)
@@ -136,14 +140,14 @@ struct RasterFused {
     const float* verts; const float4* cmat;                   // non-null: clip positions / snapped vertices are recomputed from the
                                                               // [V,3] vertices and the views' combined matrices (common.h: ClipView),
                                                               // `pos` and `snap` are not read
-    uint4* bins; int* bin_cursor; int* bin_flag; int bin_cap; // non-null: per-tile fragment bins (raster.hip: binned rasterizer)
+    BinEntry* bins; int* bin_cursor; int* bin_flag; int bin_cap; // non-null: per-tile fragment bins (raster.hip: binned rasterizer)
     UDiv segx;                                                // row pitch != W (ABI 5): division by the segments per row — the caller's
                                                               // `mask` is [n,H,W], the step's own per-pixel buffers are [n,H,pitch]
 };
 
 // ---- binned rasterizer (raster.hip): a bin = one 64-pixel row segment of the flattened [n, H, W] index = the wave that resolves it.
-// Its entries are 16 B per fragment: (face | large-box flag << 22 | pixel-in-segment << 26, z/w bits, u bits, v bits); 0xFFFFFFFF in
-// the first word = a reserved slot whose fragment turned out degenerate.
+// Its entries are 8 B per fragment: (face | large-box flag << 22 | silhouette bits << 23 | pixel-in-segment << 26, z/w bits); 0xFFFFFFFF
+// in the first word = a reserved slot whose fragment turned out degenerate.
 inline int bin_cap_entries(int requested)                     // entries per bin: fmhr_ham_dims.bin_cap, 0 = 1024 (16 fragments per pixel on average)
 {
     return requested <= 0 ? 1024 : (requested < 64 ? 64 : requested);
