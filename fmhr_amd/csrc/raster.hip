@@ -173,6 +173,79 @@ struct LargePark {
     int f;
 };
 
+// One large-box triangle rasterized by a whole WAVE, 64 box pixels per iteration (wave-uniform arguments).  Used in place by the wave
+// of the lane that found it, and by the worker waves at the head of the launch for the slivers that were already there last step.
+// `q`: the parked triangle — a reference into LDS for the in-place sweep (read at the use: nothing of it stays in registers over the
+// loop, the triangle kernel sits on its register boundary), a local for the worker waves
+template <bool BIN>
+__device__ __forceinline__ void sweep_large_box(const LargePark& q, const int b, const int lane, const BinArgs& ba, const PixGrid& pg,
+                                                unsigned long long* __restrict__ keys_view, const int Wp, unsigned char* __restrict__ dirty,
+                                                const long long pixbase)
+{
+    const int lbw = q.s.pxb - q.s.pxa + 1, lbh = q.s.pyb - q.s.pya + 1, np = lbw * lbh;
+    for (int i0 = 0; i0 < np; i0 += 64) {                            // wave-uniform trip count (bin_append is a wave-level operation)
+        const int i = i0 + lane;
+        int c;
+        const int r = fast_divmod(min(i, np - 1), lbw, c);
+        const int px = q.s.pxa + c, py = q.s.pya + r;
+        const bool in = i < np && covers(q.s, px, py);
+        if (BIN) {
+            float zw = 0.f;
+            const bool okf = in && fragment_zw(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, zw);
+            const BinEntry e = make_entry((unsigned)q.f | (1u << 22) | ((unsigned)(px & 63) << 26), zw);
+            bin_append(okf, b * ba.segsPerView + py * ba.segsX + (px >> 6), e, ba, lane);
+        } else if (in) {
+            emit_fragment(q.p0, q.p1, q.p2, px, py, q.f, pg.xs, pg.xo, pg.ys, pg.yo, keys_view, Wp, dirty, pixbase);
+        }
+    }
+}
+
+// Forward workers for PERSISTENT slivers (round 4).  An optimisation run grows sliver triangles whose pixel box exceeds the 32-pixel
+// coverage mask (0 at step 32 of the metric run, ~2 000 (view, face)s at step 640, ~3 800 at step 960: DESIGN.md §5.7); each was swept
+// in place by the whole wave of its lane AFTER that wave's main work, its workgroup's LDS and wave slots held meanwhile, the stragglers
+// among them the kernel's tail: k_raster_tris 85 us in the bench's window, 93-97 at step 640, 100-103 at step 960.  A sliver lives for
+// hundreds of steps, so last step's queue of large-box (view, face)s — the one the backward's workers consume — is this step's work
+// list: kSweepWorkers workgroups at the HEAD of the launch take one queued (view, face) per wave, redo its integer setup on THIS step's
+// snapped vertices, and sweep it if its box is still large; the lane that owns the triangle skips the sweep exactly then — it sees the
+// marker entry its predecessor left in cov16 (width field 63, stamped with last step) next to a box that is large again.  Both sides
+// decide from the same two facts (queued last step <=> marker of last step; box large now), so every large box is swept exactly once:
+// by a worker if it persisted, by its own wave if it is new (and a queued face that shrank is an ordinary small box again).  The queue
+// is double-buffered by the step's parity: this step's pushes must not overwrite the list the workers are reading.
+constexpr int kSweepWorkers = 256;              // workgroups (x 4 waves) behind view 0's triangle workgroups: ~3 800 queued (view, face)s at step 960 = 4 per wave (32: 30 per wave, the workers themselves became the tail)
+template <bool FV, bool BIN>
+__device__ __forceinline__ void
+sweep_workers(LargePark* const park, const int first, const int stride, const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
+              int V, int F, int H, int W, int Wp, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
+              const float* __restrict__ verts, const float4* __restrict__ cmat, const int* __restrict__ large_cnt,
+              const int2* __restrict__ prev_q, const PixGrid& pg, const BinArgs& ba)
+{
+    const int lane = threadIdx.x & 63;
+    const int cnt = large_cnt[1];                                    // last step's count (the second rasterizer pass kept it)
+    for (int it = first; it < cnt; it += stride) {                   // wave-uniform
+        const int2 bf = prev_q[it];
+        const int b = __builtin_amdgcn_readfirstlane(bf.x), f = __builtin_amdgcn_readfirstlane(bf.y);
+        if ((unsigned)f >= (unsigned)F) continue;
+        const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
+        if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) continue;
+        const int2* sv = snap + (size_t)b * V;
+        TriSetup ts;
+        if (!setup_triangle(sv[i0], sv[i1], sv[i2], H, W, ts)) continue;
+        if ((ts.pxb - ts.pxa + 1) * (ts.pyb - ts.pya + 1) <= kSmallBox) continue;   // shrank: its own lane handles a small box
+        // parked in the wave's LDS slot like an in-place sweep's triangle: nothing of it is live in registers over the sweep loop
+        if (lane == 0) {
+            const ClipView cv = clip_view(FV ? nullptr : pos, verts, cmat, b, V);
+            park->s = ts; park->p0 = cv.get(i0); park->p1 = cv.get(i1); park->p2 = cv.get(i2); park->f = f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const long long P = (long long)H * Wp;
+        sweep_large_box<BIN>(*park, b, lane, ba, pg, keys + (size_t)b * P, Wp, dirty, (long long)b * P);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                             // every lane has read the slot before the next triangle is parked
+    }
+}
+
 // FV (fused step): no stored clip positions — a lane whose triangle covers a pixel centre transforms its three vertices with the
 // view's combined matrix (the same clip_coord() chains everywhere: bit-identical); the [V,3] vertex array stays in cache, the
 // [n,V,4] position array (37 MB written + gathered per 48 views) does not exist.
@@ -181,15 +254,18 @@ struct LargePark {
 #ifndef FMHR_BIN_TRIS_WAVES
 #define FMHR_BIN_TRIS_WAVES 7
 #endif
-template <bool FV, bool BIN>
-__global__ void __launch_bounds__(kTrisBlock) __attribute__((amdgpu_waves_per_eu(BIN ? FMHR_BIN_TRIS_WAVES : 8, 8)))
+template <bool FV, bool BIN, bool WORKERS = false>
+__global__ void __launch_bounds__(kTrisBlock) __attribute__((amdgpu_waves_per_eu((BIN && !WORKERS) ? FMHR_BIN_TRIS_WAVES : 8, 8)))    // (WORKERS: 63 VGPRs at 8 waves, scalar spills only)
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, int Wp, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
               int2* __restrict__ cov16, const int* __restrict__ stamp, const float* __restrict__ verts,
               const float4* __restrict__ cmat, int* __restrict__ large_cnt, int2* __restrict__ large_q, const PixGrid pg,
-              unsigned char* __restrict__ own8, const BinArgs ba, const int defer_large)
+              unsigned char* __restrict__ own8, const BinArgs ba, const int defer_large, const int sweep_workers_n)
 {
+    // (the large-box queue is double-buffered by the step's parity — two halves of n * F entries: this step's pushes go to one half
+    // while the forward workers read the half last step filled.  The half is picked where it is used: kept from the top of the kernel
+    // the two extra scalar values pushed the kernel past its SGPR budget — 20 spilled SGPRs, and through them 52 spilled VGPRs)
     FMHR_WTS_BEGIN(raster, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kTrisBlock / 64) + (threadIdx.x >> 6));
     // the parked triangles as FOUR arrays of 16-B words (a 64-B record per lane put the lanes of a ds_read_b128 lane group on
     // 4 of the 16 bank quads: SQ_LDS_BANK_CONFLICT 2.4e7 cycles per launch, profiles/r02_v72_issue.txt)
@@ -202,6 +278,18 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     __shared__ int hkey[BIN ? kHash : 1], hcnt[BIN ? kHash : 1];    // binned form: segment (inside the view) -> fragments of this workgroup | base slot
     __shared__ int wtot[kTrisBlock / 64];
     __shared__ LargePark lpark[kTrisBlock / 64];
+    if (WORKERS) {                                                   // (fused step, binned form: a micro-triangle mesh)
+        // the LAST sweep_workers_n workgroups of a row are set aside; those of row 0 — dispatched right behind view 0's triangle
+        // workgroups, ahead of the other n - 1 rows — are the workers.  (Behind, not in front: an offset subtracted from blockIdx.x on
+        // the triangle path costs the compiler the index's range — 64-bit address products, 52 spilled registers)
+        const int wi = (int)blockIdx.x - ((int)gridDim.x - sweep_workers_n);
+        if (wi >= 0) {
+            if (blockIdx.y == 0)
+                sweep_workers<FV, BIN>(lpark + (threadIdx.x >> 6), wi * (kTrisBlock / 64) + (int)(threadIdx.x >> 6), sweep_workers_n * (kTrisBlock / 64), pos, snap, tri, V, F,
+                                       H, W, Wp, keys, dirty, verts, cmat, large_cnt, large_q + ((stamp[0] & 1) ? 0 : (size_t)n * F), pg, ba);
+            return;
+        }
+    }
     const int f = blockIdx.x * kTrisBlock + threadIdx.x;
     const int b = blockIdx.y;                                        // wave-uniform (SGPR)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -218,7 +306,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     }
 #endif
     unsigned cm = 0u;
-    bool is_large = false;
+    bool is_large = false, by_worker = false;
     int i0 = 0, i1 = 0, i2 = 0, o0 = -1, o1 = -1, o2 = -1, bw = 1;
     int2 s0 = make_int2(0, 0), s1 = s0, s2 = s0;
     TriSetup s;
@@ -260,8 +348,15 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             is_large = true;
             write_silh(silh, opp, snapv, s0, s1, s2, b, f, F);
             // coverage entry of a large-box triangle: a marker (width field 63) that hides whatever small-box entry an earlier step left
-            // here — the backward finds a large-box face's pixels by scanning its box (shade.hip: face_bwd_large_items)
-            if (cov16 != nullptr) cov16[(size_t)b * F + f] = make_int2(-1, (int)((63u << 26) | ((unsigned)stamp[0] & 0x3FFFFFFu)));
+            // here — the backward finds a large-box face's pixels by scanning its box (shade.hip: face_bwd_large_items).  The marker the
+            // PREVIOUS step left says whether this (view, face) is on the forward workers' list: then one of them sweeps it (above)
+            if (cov16 != nullptr) {
+                if (WORKERS) {
+                    const int old = cov16[(size_t)b * F + f].y;
+                    by_worker = ((unsigned)old >> 26) == 63u && ((unsigned)old & 0x3FFFFFFu) == (((unsigned)stamp[0] - 1u) & 0x3FFFFFFu);
+                }
+                cov16[(size_t)b * F + f] = make_int2(-1, (int)((63u << 26) | ((unsigned)stamp[0] & 0x3FFFFFFu)));
+            }
         } else {
             // the opposite-vertex ids (antialias rule A3) are requested now and arrive while the coverage mask is computed
             if (silh != nullptr) { o0 = opp[f * 3]; o1 = opp[f * 3 + 1]; o2 = opp[f * 3 + 2]; }
@@ -325,12 +420,16 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         const int leader = __builtin_ctzll(lbal);
         if (lane == leader) base = atomicAdd(large_cnt, __popcll(lbal));
         base = __shfl(base, leader, 64);
-        if (is_large) large_q[base + __popcll(lbal & ((1ull << lane) - 1ull))] = make_int2(b, f);
+        int2* const lq2 = large_q + ((stamp != nullptr && (stamp[0] & 1)) ? (size_t)n * F : 0);      // this step's half of the queue
+        if (is_large) lq2[base + __popcll(lbal & ((1ull << lane) - 1ull))] = make_int2(b, f);
         if (defer_large) {
             is_large = false;
             lbal = 0ull;
         }
     }
+    // a sliver that was queued last step is swept by a worker wave at the head of this launch, not here
+    if (by_worker) is_large = false;
+    lbal = __ballot(is_large);
     if (cm != 0u) {
         // one memory round trip for everything a covering triangle needs: clip positions + the snapped opposite vertices
         float4 p0 = clipv(i0), p1 = clipv(i1), p2 = clipv(i2);
@@ -500,8 +599,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             }
         }
     }
-    // ---- large-box triangles (box > 32 pixels: none on a sub3-class mesh, all of them on a 778-vertex hand): each is rasterized
-    // by its whole wave, 64 box pixels per iteration (no second launch; coarse meshes took the queue above instead)
+    // ---- large-box triangles (box > 32 pixels: none on a sub3-class mesh, all of them on a 778-vertex hand) that are NEW this step (or
+    // any, without the worker workgroups): each is rasterized by its whole wave, 64 box pixels per iteration (no second launch; coarse
+    // meshes took the queue above instead; the ones that were queued last step: sweep_workers)
     FMHR_WTS_END(raster);
     if (lbal == 0ull) return;                                        // wave-uniform
 #ifdef FMHR_X_NO_LARGE_SWEEP                                         // (measurement builds only: what the in-wave sweep of large boxes costs)
@@ -520,6 +620,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         __builtin_amdgcn_wave_barrier();
         {
             const LargePark& q = lpark[wv];
+            // (the loop of sweep_large_box, spelled out: as a call the non-binned instantiations needed 64 VGPRs + 78 spills for 60)
             const int lbw = q.s.pxb - q.s.pxa + 1, lbh = q.s.pyb - q.s.pya + 1, np = lbw * lbh;
             for (int i0 = 0; i0 < np; i0 += 64) {                    // wave-uniform trip count (bin_append is a wave-level operation)
                 const int i = i0 + lane;
@@ -547,8 +648,9 @@ __global__ void __launch_bounds__(kBlock)
 k_raster_large(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri, int n, int V,
                int F, int H, int W, int Wp, unsigned long long* __restrict__ keys, const int* __restrict__ large_cnt,
                const int2* __restrict__ large_q, unsigned char* __restrict__ dirty, const float* __restrict__ verts,
-               const float4* __restrict__ cmat, const PixGrid pg)
+               const float4* __restrict__ cmat, const PixGrid pg, const int* __restrict__ stamp)
 {
+    if (stamp != nullptr && (stamp[0] & 1)) large_q += (size_t)n * F;   // (the queue's half of this step's parity: k_raster_tris)
     const int cnt = *large_cnt;
     const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;
     for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
@@ -1146,9 +1248,9 @@ extern "C" int fmhr_debug_ts(void* out, size_t bytes)
 #endif
 
 namespace fmhr {
-// [keys: n*H*W u64][large-triangle counter: 16 B][large-triangle queue: n*F int2]
+// [keys: n*H*W u64][large-triangle counter: 16 B][large-triangle queue: 2 x n*F int2, the half in use = the step's parity]
 size_t raster_keys_bytes(int n, int H, int W) { return (size_t)n * H * W * 8; }
-size_t raster_core_ws_bytes(int n, int F, int H, int W) { return raster_keys_bytes(n, H, W) + 16 + (size_t)n * F * 8; }
+size_t raster_core_ws_bytes(int n, int F, int H, int W) { return raster_keys_bytes(n, H, W) + 16 + 2 * (size_t)n * F * 8; }   // (two queue halves)
 }  // namespace fmhr
 
 extern "C" size_t fmhr_rasterize_workspace_bytes(int n, int V, int F, int H, int W)
@@ -1228,13 +1330,19 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     }
     if ((long long)n * F > 0) {
         ProfScope ps(FMHR_SLOT_RASTER_TRIS, st);
-        const dim3 tgrid(cdiv(F, kTrisBlock), n);                    // view = blockIdx.y
-        if (binned)
-            k_raster_tris<true, true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer);
+        // forward workers for last step's large-box queue: the fused step on a micro-triangle mesh (FMHR_SWEEP_WORKERS=0 sweeps every
+        // large box in place, as round 3 did: same-library A/B)
+        const char* swe = getenv("FMHR_SWEEP_WORKERS");
+        const int sw = (binned && fused_step && !use_queue && lq != nullptr && fu.stamp != nullptr && !(swe && atoi(swe) == 0)) ? kSweepWorkers : 0;
+        const dim3 tgrid(cdiv(F, kTrisBlock) + sw, n);               // view = blockIdx.y
+        if (binned && sw > 0)
+            k_raster_tris<true, true, true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer, sw);
+        else if (binned)
+            k_raster_tris<true, true><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer, sw);
         else if (fu.verts != nullptr)
-            k_raster_tris<true, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer);
+            k_raster_tris<true, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, fu.verts, fu.cmat, large_cnt, lq, pg, fu.own8, ba, defer, sw);
         else
-            k_raster_tris<false, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg, fu.stamp != nullptr ? fu.own8 : nullptr, ba, defer);
+            k_raster_tris<false, false><<<tgrid, kTrisBlock, 0, st>>>(pos, snap, tri, opp, silh, n, V, F, H, W, Wp, keys, dirty, fu.cov16, fu.stamp, nullptr, nullptr, large_cnt, lq, pg, fu.stamp != nullptr ? fu.own8 : nullptr, ba, defer, 0);
         FMHR_CHECK_LAUNCH("k_raster_tris");
     }
     if (binned) {
@@ -1246,7 +1354,7 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     {
         ProfScope ps(FMHR_SLOT_RASTER_LARGE, st);          // empty on a micro-triangle mesh
         if (use_queue && (long long)n * F > 0) {
-            k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, Wp, keys, large_cnt, large_q, dirty, fu.verts, fu.cmat, pg);
+            k_raster_large<<<1024, kBlock, 0, st>>>(pos, snap, tri, n, V, F, H, W, Wp, keys, large_cnt, large_q, dirty, fu.verts, fu.cmat, pg, fu.stamp);
             FMHR_CHECK_LAUNCH("k_raster_large");
         }
     }

@@ -617,13 +617,15 @@ face_bwd_large_items(const float4* __restrict__ bwd16, const int32_t* __restrict
                      const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, const float* __restrict__ verts,
                      const int2* __restrict__ large_q, const int* __restrict__ large_cnt, const unsigned long long* __restrict__ covw,
                      const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
-                     int n, int V, int F, int H, int W, int Wp, int GV, float* __restrict__ out, const PixGrid pg, int first, int stride)
+                     int n, int V, int F, int H, int W, int Wp, int GV, float* __restrict__ out, const PixGrid pg, int first, int stride,
+                     const int* __restrict__ qstamp)
 {
     constexpr int kWaves = kBlock / 64;
     __shared__ float view_c[kWaves][28];
     __shared__ FaceAttr pk[kWaves];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cnt = large_cnt[1];                                  // the second rasterizer pass kept a copy when it rearmed the queue
+    if (qstamp != nullptr && (qstamp[0] & 1)) large_q += (size_t)n * F;   // the queue's half of this step's parity (raster.hip: k_raster_tris)
     const long long P = (long long)H * Wp;                         // W clips the box, Wp (row pitch) addresses
     const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;
     const unsigned char cur = own8 != nullptr ? (unsigned char)stamp[0] : (unsigned char)0;
@@ -705,11 +707,11 @@ k_face_bwd_large(const float4* __restrict__ bwd16, const int32_t* __restrict__ t
                  const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
                  const int32_t* __restrict__ corner_slot, const float4* __restrict__ cmat, const float* __restrict__ verts,
                  const int2* __restrict__ large_q, const int* __restrict__ large_cnt, const unsigned long long* __restrict__ covw,
-                 int n, int V, int F, int H, int W, int Wp, int GV, float* __restrict__ part, const PixGrid pg)
+                 int n, int V, int F, int H, int W, int Wp, int GV, float* __restrict__ part, const PixGrid pg, const int* __restrict__ stamp)
 {
     constexpr int kWaves = kBlock / 64;
     face_bwd_large_items<false>(bwd16, tri, snap, attr8, sh, g_shaded, corner_slot, cmat, verts, large_q, large_cnt, covw, nullptr, nullptr,
-                                n, V, F, H, W, Wp, GV, part, pg, blockIdx.x * kWaves + (threadIdx.x >> 6), gridDim.x * kWaves);
+                                n, V, F, H, W, Wp, GV, part, pg, blockIdx.x * kWaves + (threadIdx.x >> 6), gridDim.x * kWaves, stamp);
 }
 
 // VA views per lane in every view group but (VB != VA) the last, which holds the remainder in VB per lane: 48 views = a 32-view group
@@ -730,7 +732,7 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
         static_assert(kFbBlock == kBlock, "the queue workers use k_face_bwd_large's wave layout");
         if (g == 0)
             face_bwd_large_items<true>(bwd16, tri, la.snap, attr8, sh, g_shaded, corner_slot, cmat, verts, la.large_q, la.large_cnt, la.covw, own8, stamp,
-                                       n, V, F, H, W, Wp, 0, la.vacc, pg, (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6), la.workers * (kBlock / 64));
+                                       n, V, F, H, W, Wp, 0, la.vacc, pg, (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6), la.workers * (kBlock / 64), stamp);
         return;
     }
     if (VB != VA && g == (int)gridDim.y - 1)                       // (block-uniform)
@@ -849,7 +851,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     FMHR_CHECK_LAUNCH("k_face_bwd");
     if (coarse) {
         k_face_bwd_large<<<2048, kBlock, 0, st>>>((const float4*)bwd16, tri, snap, (const float4*)attr8, sh, (const float4*)g_shaded, corner_slot,
-                                                  (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, Wp, kGroup * face_bwd_vpl(n, H, Wp), part, pg);
+                                                  (const float4*)cmat, verts, large_q, large_cnt, covw, n, V, F, H, W, Wp, kGroup * face_bwd_vpl(n, H, Wp), part, pg, stamp);
         FMHR_CHECK_LAUNCH("k_face_bwd_large");
     }
     return FMHR_OK;

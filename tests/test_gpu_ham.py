@@ -1036,3 +1036,48 @@ def test_demo_capture_cameras_through_the_fused_step(oracle):
         inside.append(float(cov[j][py, px].mean()))
     log_parity("demo capture cameras %s at 1280x1024: coverage %.3f, keypoints inside the rendered silhouette %s" % (cams, cov.mean(), ["%.2f" % x for x in inside]))
     assert min(inside) > 0.6, inside                                      # (the blob is not the hand: finger tips may stick out)
+
+
+def test_sliver_workers_over_consecutive_steps(oracle, monkeypatch):
+    """Round 4: a large-box (sliver) face that was queued LAST step is rasterized by a worker wave at the head of this step's triangle
+    launch instead of by its own wave (raster.hip: sweep_workers); the owning lane decides from the marker its predecessor left in the
+    coverage entry, the worker from the queue + this step's box — both must agree in every transition.  One workspace, six steps:
+    no sliver -> slivers APPEAR (swept in place: nothing was queued) -> PERSIST (worker) -> persist with moved vertices (worker, new
+    boxes) -> VANISH (the worker finds a small box and leaves it to its lane) -> none; every step against a FRESH workspace that sweeps
+    everything in place (FMHR_SWEEP_WORKERS=0): bit-identical rasterizer image and shaded image, gradients up to the float-atomic order."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (4, 192, 192, 64, 96), 2)
+    ring = lambda r, s: 1 + r * 96 + s
+    idx = torch.tensor([ring(r, s) for r in (20, 40) for s in range(0, 96, 6)])
+    spike = sc["delta"].clone()
+    spike[idx] += 0.35 * sc["vertices"][idx]
+    spike2 = sc["delta"].clone()
+    spike2[idx] += 0.30 * sc["vertices"][idx]
+    deltas = [sc["delta"], spike, spike, spike2, sc["delta"], sc["delta"]]
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    faces = sc["faces"].to(dev)
+    args = lambda d: (g["vertices"], d.to(dev).contiguous(), g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    monkeypatch.delenv("FMHR_SWEEP_WORKERS", raising=False)
+    hs = HamStage2(faces, sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    assert hs.binned
+    n, H, Wp = sc["views"], sc["H"], hs.pitch
+    qcnt = hs.raw("raster_ws", torch.uint8, n * H * Wp * 8 + 16)[n * H * Wp * 8:].view(torch.int32)     # [pushed so far, last step's count]
+    queued = []
+    for k, d in enumerate(deltas):
+        monkeypatch.delenv("FMHR_SWEEP_WORKERS", raising=False)
+        hs.step(*args(d))
+        v = hs.views()
+        got = dict(rast=v["rast"].clone(), pre=v["tmp_img_pre_aa"].clone(), gd=hs.gdelta.clone(), ga=hs.galbedo.clone(), ld=hs.loss_dict())
+        queued.append(int(qcnt[1]))
+        monkeypatch.setenv("FMHR_SWEEP_WORKERS", "0")
+        ref = HamStage2(faces, sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+        ref.step(*args(d))
+        rv = ref.views()
+        assert torch.equal(got["rast"], rv["rast"]) and torch.equal(got["pre"], rv["tmp_img_pre_aa"]), k
+        assert got["ld"]["n_valid"] == ref.loss_dict()["n_valid"], k
+        assert rel_err(got["gd"], ref.gdelta) < 5e-5 and rel_err(got["ga"], ref.galbedo) < 2e-6, k
+    # the scenario exists: dozens of large-box (view, face)s while the spikes stand, (next to) none without them
+    assert min(queued[1:4]) >= 40 and max(queued[0], queued[5]) <= 4, queued
+    log_parity("sliver workers over six steps (none / appear / persist / persist moved / vanish / none): queued large-box (view, face)s per step %s, "
+               "every step bit-identical to a fresh in-place workspace" % queued)
