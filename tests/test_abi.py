@@ -62,7 +62,8 @@ def test_argument_errors_without_gpu(lib):
     assert lib.fmhr_ham_rasterizer_form(ctypes.byref(HamDims(2, 49281, 98432, 512, 334, 0, 4096, 0, 0))) == 1     # W = 334, micro-triangle: bins
     assert lib.fmhr_ham_rasterizer_form(ctypes.byref(HamDims(2, 49281, 98432, 512, 334, 0, 4096, 0, 334))) == 0   # ABI-4 layout: atomic keys
     assert lib.fmhr_ham_rasterizer_form(ctypes.byref(padded)) == 0                                                 # coarse mesh: the queue
-    assert lib.fmhr_rasterize_workspace_bytes(2, 7, 10, 8, 8) == 2 * 64 * 8 + 16 + 2 * 10 * 8 + 2 * 7 * 8
+    # depth keys + the large-box counter + the large-box queue (two halves: double-buffered by the step's parity) + the snapped vertices
+    assert lib.fmhr_rasterize_workspace_bytes(2, 7, 10, 8, 8) == 2 * 64 * 8 + 16 + 2 * (2 * 10 * 8) + 2 * 7 * 8
     # fmhr_ham_densify re-shades / recomputes the views the step does not store: it needs the last forward's tri and sh
     lib.fmhr_ham_densify.restype = ctypes.c_int
     lib.fmhr_ham_densify.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]
