@@ -353,7 +353,11 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             if (cov16 != nullptr) {
                 if (WORKERS) {
                     const int old = cov16[(size_t)b * F + f].y;
-                    by_worker = ((unsigned)old >> 26) == 63u && ((unsigned)old & 0x3FFFFFFu) == (((unsigned)stamp[0] - 1u) & 0x3FFFFFFu);
+                    const unsigned prev = ((unsigned)stamp[0] - 1u) & 0x3FFFFFFu;
+                    // (a never-written entry is all ones — the pattern of fmhr_ham_workspace_init — and must not pass for last step's marker
+                    // in the one step in 2^26 whose predecessor's stamp is all ones: then the face is swept here AND by a worker, twice the
+                    // same fragments, harmless)
+                    by_worker = ((unsigned)old >> 26) == 63u && ((unsigned)old & 0x3FFFFFFu) == prev && prev != 0x3FFFFFFu;
                 }
                 cov16[(size_t)b * F + f] = make_int2(-1, (int)((63u << 26) | ((unsigned)stamp[0] & 0x3FFFFFFu)));
             }
