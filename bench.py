@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from fmhr_amd import _lib, dist as fdist, synthetic  # noqa: E402
-from fmhr_amd.ham import HamStage2, edge_length_mean, render_forward  # noqa: E402
+from fmhr_amd.ham import HamStage2, VertexOrder, edge_length_mean, render_forward  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 SLOTS = ["geometry", "raster_clear", "raster_tris", "raster_large", "raster_resolve", "shade_fwd", "aa_fwd", "loss_pix",
@@ -273,6 +273,14 @@ def main():
     n = s1 - s0
     if n == 0:
         raise SystemExit("more ranks than views")
+    # The optimisation runs on the product's renumbering of the VERTICES (fmhr_amd.ham.VertexOrder: first-touch order of the face list;
+    # same triangles in the same face order, `rast` bit-identical, results mapped back with order.to_caller) — exactly what
+    # fmhr_amd.pipeline.run_ham does with a caller's mesh, applied once here to everything the scene holds per vertex.
+    # FMHR_VERTEX_ORDER=0: the subdivision's own numbering (2 880 against 2 930 it/s at the metric config).
+    order = VertexOrder(scene["faces"], V)
+    for k in ("vertices", "vertices_true", "albedo_true", "albedo0"):
+        scene[k] = order.to_internal(scene[k])
+    scene["faces"] = order.faces
     faces = scene["faces"].to(dev)
     w2c, proj = scene["w2c"][s0:s1].contiguous().to(dev), scene["proj"][s0:s1].contiguous().to(dev)
     sh = scene["sh0"][s0:s1].contiguous().to(dev)
@@ -496,6 +504,8 @@ def main():
                                    f"stage-2 step = render + 6 losses + backward + grad all-reduce + Adam, stationary (pre-rolled {preroll} steps)",
                        "views": n_total, "views_per_gpu": n, "frames": n_frames, "frames_per_gpu": nf_local, "frame_streams": n_fs, "H": H, "W": W, "V": V, "F": F,
                        "rasterizer": "binned (per-segment LDS bins)" if hs.binned else "atomic depth keys + resolve",
+                       "vertex_order": ("caller's numbering" if order.identity else
+                                        "first-touch renumbering of the vertices by the product (fmhr_amd.ham.VertexOrder, as run_ham applies it; faces unchanged)"),
                        "coverage": round(tg["coverage"], 4), "parallelism": (f"views sharded over {world} GPU(s)" if n_frames == 1 else
                                                                         f"{n_frames} frames x {n_total} views: frames first, then views, over {world} GPU(s)"),
                        "preroll_steps": preroll, "aa_items_per_step": int(float(aa_items)), "aa_items_during_preroll": [int(x) for x in aa_hist]},

@@ -116,20 +116,27 @@ def stage1_loss_cached(ops, cache, idx, albedo, sh_coeff, img, sfs_weight):
 
 
 def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0, scan_id=None,
-            check_every=1, aa_cap=None, bin_cap=0):
+            check_every=1, aa_cap=None, bin_cap=0, vertex_order=None):
     """The HAM optimisation end to end on GPU tensors.  conf: dict with the keys of conf/demo_sfs.conf that the loop reads.
     A step never synchronises, so a work list that overflows (antialias pairs, fragment bins: `aa_cap` / `bin_cap` of HamStage2) drops
     gradient terms without an error of its own: the STICKY overflow flags of every stage-2 workspace are read every `check_every`
     epochs (one 16-byte copy per workspace), before a workspace is discarded and at the end, and a set flag raises — whatever
     `log_every` is.
+    The optimisation runs on a RENUMBERING of the vertices (fmhr_amd.ham.VertexOrder: first-touch order of the face list, the faces and
+    their corner order untouched — the gathers of every kernel stay within few cache lines) and every per-vertex result is mapped back:
+    what is returned and written has the caller's numbering, i.e. the child-face / appended-midpoint layout of the subdivided mesh that
+    repose.py:14-24 relies on.  `vertex_order=False` (or FMHR_VERTEX_ORDER=0) optimises in the caller's numbering.
     Returns dict(vertices, delta, albedo, sh_coeffs, history).  With `out_dir` the outputs of mesh_sfs_optim.py:319-343 are written
     under the reference's names: '<scan_id>.pt' (sh_coeff, albedo), '<scan_id>.obj', '<scan_id>_c.obj' (vertex colours) and
     'rerender/mesh_<view>.png' (the last epoch's rendered batches); scan_id = None keeps the stem 'ham'."""
     from . import optim
-    from .ham import HamStage2, edge_length_mean
+    from .ham import HamStage2, VertexOrder, edge_length_mean
     from .data import save_obj, save_obj_mesh_with_color, save_rerender_png
     ops = product_ops()
     dev = vertices.device
+    order = VertexOrder(faces, vertices.shape[0], enabled=vertex_order)
+    faces_caller = faces
+    vertices, faces = order.to_internal(vertices), order.faces
     degree, batch = int(conf.get("degree", 3)), int(conf["batch"])
     num = imgs.shape[0]
     H, W = resolution
@@ -219,16 +226,17 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
         if check_every and (ep + 1) % check_every == 0:
             check_steppers()
     check_steppers()
-    out_vertices = (vertices_tmp + delta).detach()
-    result = dict(vertices=out_vertices, delta=delta.detach(), albedo=albedo.detach(), sh_coeffs=sh_coeffs.detach(), history=history,
-                  valid_masks=init["valid_masks"])
+    out_vertices = order.to_caller((vertices_tmp + delta).detach())
+    albedo_out = order.to_caller(albedo.detach(), 1)
+    result = dict(vertices=out_vertices, delta=order.to_caller(delta.detach()), albedo=albedo_out, sh_coeffs=sh_coeffs.detach(),
+                  history=history, valid_masks=init["valid_masks"])
     if out_dir is not None:                                                          # :319-343
         os.makedirs(out_dir, exist_ok=True)
         stem = 'ham' if scan_id is None else '%d' % scan_id
-        torch.save({'sh_coeff': sh_coeffs.detach().cpu(), 'albedo': albedo.detach().cpu()}, os.path.join(out_dir, stem + '.pt'))   # :321
-        nv, nf = out_vertices.cpu().numpy(), faces.cpu().numpy()
+        torch.save({'sh_coeff': sh_coeffs.detach().cpu(), 'albedo': albedo_out.cpu()}, os.path.join(out_dir, stem + '.pt'))   # :321
+        nv, nf = out_vertices.cpu().numpy(), faces_caller.cpu().numpy()
         save_obj(os.path.join(out_dir, stem + '.obj'), nv, nf)                                                             # :327
-        color = torch.clamp(0.5 * albedo.detach(), 0, 1)[0].cpu().numpy()
+        color = torch.clamp(0.5 * albedo_out, 0, 1)[0].cpu().numpy()
         save_obj_mesh_with_color(os.path.join(out_dir, stem + '_c.obj'), nv, nf, color[:, 2::-1])                          # :334-335
         os.makedirs(os.path.join(out_dir, 'rerender'), exist_ok=True)                                                     # :337
         if rendered_img:

@@ -1081,3 +1081,30 @@ def test_sliver_workers_over_consecutive_steps(oracle, monkeypatch):
     assert min(queued[1:4]) >= 40 and max(queued[0], queued[5]) <= 4, queued
     log_parity("sliver workers over six steps (none / appear / persist / persist moved / vanish / none): queued large-box (view, face)s per step %s, "
                "every step bit-identical to a fresh in-place workspace" % queued)
+
+
+def test_vertex_order_gives_the_callers_results(oracle):
+    """fmhr_amd.ham.VertexOrder: the step on the RENUMBERED mesh (first-touch order of the face list; what run_ham and bench.py
+    optimise in) against the oracle on the caller's numbering — `rast` bit-identical (the faces keep their order, a vertex's
+    arithmetic does not know its index), the six losses and the gradients mapped back within the same bars as the plain step."""
+    from fmhr_amd.ham import HamStage2, VertexOrder
+    dev = torch.device("cuda:0")
+    sc = prepare(oracle, (3, 256, 256, "mano", 0, 2), 31)              # two subdivision levels: appended midpoints, a real permutation
+    ld0, v0 = _step_vs_oracle(oracle, sc, "vertex_order_reference")    # the caller's numbering: asserts rast == oracle, grads vs fp64
+    order = VertexOrder(sc["faces"].to(dev), sc["V"], enabled=True)
+    assert not order.identity
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    hs = HamStage2(order.faces, sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+    losses, gd, ga = hs.step(order.to_internal(g["vertices"]), order.to_internal(g["delta"]), order.to_internal(g["albedo"]), g["sh0"],
+                             g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    ld, v = hs.loss_dict(), hs.views()
+    assert torch.equal(v["rast"], v0["rast"])                           # face indices, barycentrics and depths: the same bits
+    assert torch.equal(order.to_caller(v["pos"], 1), v0["pos"])
+    assert ld["n_valid"] == ld0["n_valid"]
+    for k in ("sfs", "lap", "albedo", "mask", "edge", "delta"):
+        assert abs(ld[k] - ld0[k]) <= 2e-6 * max(abs(ld0[k]), 1e-6), (k, ld[k], ld0[k])     # summation order only
+    gd, ga = order.to_caller(gd), order.to_caller(ga)
+    e_d, e_a = rel_err(gd, v0["gd64"]), rel_err(ga, v0["ga64"])
+    print(f"vertex_order: grad rel err vs fp64 oracle (caller's numbering): delta {e_d:.2e} albedo {e_a:.2e}; plain step: "
+          f"{rel_err(v0['gdelta'], v0['gd64']):.2e} {rel_err(v0['galbedo'], v0['ga64']):.2e}")
+    grad_bar("vertex_order", e_d, e_a, v0["o_d"], v0["o_a"])

@@ -135,3 +135,37 @@ def test_run_ham_raises_on_a_work_list_overflow(which):
         pipeline.run_ham(*args, log_every=0, **kw)
     with pytest.raises(RuntimeError, match="overflowed"):   # ... also when only the end-of-run check is left
         pipeline.run_ham(*args, log_every=0, check_every=0, **kw)
+
+
+def test_run_ham_returns_the_callers_vertex_numbering(tmp_path):
+    """run_ham optimises on a renumbering of the vertices (fmhr_amd.ham.VertexOrder) and maps every per-vertex result back: the
+    returned tensors and the written OBJ / .pt are in the caller's numbering (the subdivided mesh's layout repose.py:14-24 relies
+    on), equal to a run in the caller's own numbering up to the float-atomic order."""
+    from fmhr_amd import pipeline, synthetic as S
+    from fmhr_amd.ham import VertexOrder, render_forward
+    from fmhr_amd.data import load_obj
+    dev = torch.device("cuda:0")
+    sc = S.make_scene(4, 128, 96, 21, 37, 1, seed=7)
+    faces = sc["faces"].to(dev)
+    assert not VertexOrder(faces, sc["V"], enabled=True).identity
+    w2c, proj = sc["w2c"].to(dev), sc["proj"].to(dev)
+    tg = S.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, 128, 96), device=dev)
+    img = tg["img"]
+    gray = (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).contiguous()
+    conf = dict(batch=4, degree=3, epoch_albedo=4, epoch_sfs=6, sfs_weight=50.0, lap_weight=2000.0, albedo_weight=1.0,
+                mask_weight=1000.0, edge_weight=500000.0, delta_weight=50000.0, lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
+    outs = {}
+    for on in (True, False):
+        d = os.path.join(tmp_path, "on" if on else "off")
+        outs[on] = pipeline.run_ham(sc["vertices"].to(dev), faces, img, gray, tg["mask"], w2c, proj, (128, 96), conf, out_dir=d,
+                                    scan_id=2, vertex_order=on)
+    a, b = outs[True], outs[False]
+    assert float(b["delta"].abs().max()) > 1e-4
+    assert rel_err(a["delta"], b["delta"]) < 2e-3 and rel_err(a["albedo"], b["albedo"]) < 1e-4 and rel_err(a["vertices"], b["vertices"]) < 1e-5
+    assert rel_err(a["sh_coeffs"], b["sh_coeffs"]) < 1e-4
+    for d in ("on", "off"):
+        v, f = load_obj(os.path.join(tmp_path, d, "2.obj"))
+        assert np.array_equal(f, sc["faces"].numpy())                   # the caller's face table, not the renumbered one
+        assert np.abs(v - outs[d == "on"]["vertices"].cpu().numpy()).max() < 1e-5
+    ck = torch.load(os.path.join(tmp_path, "on", "2.pt"))
+    assert torch.equal(ck["albedo"], a["albedo"].cpu())
