@@ -218,6 +218,20 @@ __device__ __forceinline__ uint32_t mono_key(float f)
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Element `idx` of a table through a 32-BIT byte offset: base (wave-uniform: SGPR pair) + zero-extended idx * sizeof(T) selects the
+// `global_load ... v_off, s[base]` form — one VGPR and one shift per address instead of a sign extension, a 64-bit multiply-add and a
+// VGPR pair.  For per-vertex / per-face tables (V * 32 B, F * 12 B ... < 4 GB by a wide margin); idx must be a valid index (>= 0).
+template <typename T>
+__device__ __forceinline__ const T& at32(const T* base, unsigned idx)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)(idx * (unsigned)sizeof(T)));
+}
+template <typename T>
+__device__ __forceinline__ T& at32(T* base, unsigned idx)
+{
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)(idx * (unsigned)sizeof(T)));
+}
+
 // wave64 sum reduction, the total in every lane: the DPP scan of wave_incl_scan (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31) and a
 // readlane of lane 63 — six vector-ALU operand modifiers instead of six dependent ds_bpermute round trips through the LDS crossbar
 // (the sums sit at the very end of their kernels' chains).  The tree differs from the shuffle form's: partial sums of the losses move
@@ -234,6 +248,7 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 struct alignas(4) F3U { float x, y, z; };
+struct alignas(4) I3U { int x, y, z; };                            // a row of a [*,3] int32 table as ONE 12-byte load
 struct alignas(4) F4U { float x, y, z, w; };     // a 16-B load from a dword-aligned address (global loads need no more)
 
 // keep a loaded 16-B word whole and its load where it was written: without this the compiler splits a float4 load whose

@@ -64,7 +64,7 @@ int face_bwd_blocks(int F);
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
-        g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, total;
+        g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, bin_state, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -134,6 +134,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     // 288-GB part, not for the footprint)
     const bool binned = raster_binned_ok(d->F, d->H, d->W, Wp);
     const size_t tiles = binned ? raster_bin_count(d->n, d->H, Wp) : 0;
+    L.bin_state = take(off, tiles * 4 + 16);                         // per-segment state words, addressed DOWNWARDS from the cursors (raster.hip: seg_state_word)
     L.bin_cursor = take(off, tiles * 4 * kCursorStride + 16);
     L.bins = take(off, tiles * (size_t)bin_cap_entries(d->bin_cap) * sizeof(BinEntry));
     L.total = off;
@@ -196,7 +197,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
     FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(own8); FMHR_OFF(stamp); FMHR_OFF(pix16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
     FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(aa_counter); FMHR_OFF(aa_region_cnt); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(vacc); FMHR_OFF(part);
-    FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(silw); FMHR_OFF(bins); FMHR_OFF(bin_cursor); FMHR_OFF(total);
+    FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(silw); FMHR_OFF(bins); FMHR_OFF(bin_cursor); FMHR_OFF(bin_state); FMHR_OFF(total);
 #undef FMHR_OFF
     set_error("ham_workspace_offset: unknown buffer '%s'", name);
     return -1;
@@ -239,6 +240,10 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     HIPTRY(hipMemsetAsync(w + L.stamp, 0, 16, (hipStream_t)stream), "init stamp");
     HIPTRY(hipMemsetAsync(w + L.own8, 0, (size_t)d->n * d->F, (hipStream_t)stream), "init own8");
     HIPTRY(hipMemsetAsync(w + L.bin_cursor, 0, L.bins - L.bin_cursor, (hipStream_t)stream), "init bin cursors");   // self-cleaning afterwards
+    // every segment's words count as live until the second pass has seen the segment once (bit 1 of every byte: kSegWordsLive, bit 0 clear)
+    HIPTRY(hipMemsetAsync(w + L.bin_state, 0x02, L.bin_cursor - L.bin_state, (hipStream_t)stream), "init bin state");
+    if (raster_binned_ok(d->F, d->H, d->W, eff_pitch(d)))   // the bin-overflow word of the launch pair, two words below the lowest state word
+        HIPTRY(hipMemsetAsync(w + L.bin_cursor - 4 * (raster_bin_count(d->n, d->H, eff_pitch(d)) + 2), 0, 4, (hipStream_t)stream), "init bin overflow word");
     return raster_sparse_init(w + L.raster_ws, (unsigned char*)(w + L.dirty), d->n, d->H, eff_pitch(d), (hipStream_t)stream);
 }
 

@@ -114,7 +114,20 @@ __device__ __forceinline__ void write_silh(unsigned char* __restrict__ silh, con
 // with one ds_cmpst + one ds_add_rtn, then ONE returning global atomic per table entry reserves the run — all of them in one
 // instruction, in flight while the workgroup evaluates its fragments (a returning atomic per wave and round, waited for on the spot,
 // cost 124 us; with the cursors packed 16 per cache line 280 us).
-struct BinArgs { BinEntry* bins; int* cursor; int* flag; int cap; int segsX; int segsPerView; };
+struct BinArgs { BinEntry* bins; int* cursor; int cap; int segsX; int segsPerView; int tiles; };
+// Per-segment STATE word (packed: 16 per line, unlike the cursors), so that the second pass can leave an empty segment — 70 % of them at
+// the metric — on a load that hits: the cursor of a segment no fragment ever reaches is a line of its own that only the second pass
+// reads, once per step, from memory (196 k empty waves: 17 us of that pass; with the state words k_raster_bins 82.8 -> 74.4 us).
+// bit 0: the segment has fragments this step — written (3) by the workgroup whose reservation found the cursor at 0 (the slow path's
+// runs: by every one of them); bit 1: the segment's words (coverage, valid count) may be non-zero from the last step that had
+// fragments — the second pass writes 2 when it resolves a bin, and an empty segment zeroes its words only if bit 1 is set (then
+// writes 0): a segment that stays empty costs one scalar load and no store.
+// The words lie right BELOW the cursors, in reverse order (segment s: cursor[-1 - s]): no pointer of their own to hold — the
+// triangle kernel has no register to spare (see face() there).
+constexpr int kSegHasFragments = 1, kSegWordsLive = 2;
+__device__ __forceinline__ int* seg_state_word(const BinArgs& ba, long long bin) { return ba.cursor - 1 - bin; }
+// ... and below them the bin-overflow word of the launch pair (k_raster_bins adds it to the host-visible sticky flag)
+__device__ __forceinline__ int* bin_overflow_word(const BinArgs& ba) { return ba.cursor - 2 - ba.tiles; }
 // (face | flags | pixel, z/w[, u, v]) -> an entry
 __device__ __forceinline__ BinEntry make_entry(unsigned head, float zw) { return make_uint2(head, __float_as_uint(zw)); }
 constexpr int kHash = 128;                       // LDS table slots per workgroup round (a round has at most 512 fragments)
@@ -136,13 +149,14 @@ __device__ __forceinline__ void bin_append(bool valid, int bin, const BinEntry e
         const unsigned long long above = brk & ~upto;
         const int len = (above != 0ull ? __builtin_ctzll(above) : 64) - lane;
         base = atomicAdd(ba.cursor + (size_t)tl * kCursorStride, len);
+        *seg_state_word(ba, tl) = kSegHasFragments | kSegWordsLive;      // marks the segment for the second pass (this rare path: every run does)
     }
     const int start = 63 - __builtin_clzll((lm & upto) | 1ull);      // the run's first lane (meaningless on lanes without a fragment)
     const int b0 = __shfl(base, start, 64);
     if (valid) {
         const int slot = b0 + (lane - start);
         if (slot < ba.cap) ba.bins[(size_t)tl * ba.cap + slot] = e;
-        else *ba.flag = 1;                                           // reported by the host (HamStage2.loss_dict): the bin capacity was too small
+        else *bin_overflow_word(ba) = 1;                             // reported by the host (HamStage2.loss_dict): the bin capacity was too small
     }
 }
 
@@ -255,7 +269,10 @@ sweep_workers(LargePark* const park, const int first, const int stride, const fl
 #define FMHR_BIN_TRIS_WAVES 7
 #endif
 template <bool FV, bool BIN, bool WORKERS = false>
-__global__ void __launch_bounds__(kTrisBlock) __attribute__((amdgpu_waves_per_eu((BIN && !WORKERS) ? FMHR_BIN_TRIS_WAVES : 8, 8)))    // (WORKERS: 63 VGPRs at 8 waves, scalar spills only)
+#ifndef FMHR_WORKER_TRIS_WAVES
+#define FMHR_WORKER_TRIS_WAVES 8
+#endif
+__global__ void __launch_bounds__(kTrisBlock) __attribute__((amdgpu_waves_per_eu((BIN && !WORKERS) ? FMHR_BIN_TRIS_WAVES : (WORKERS ? FMHR_WORKER_TRIS_WAVES : 8), 8)))    // (WORKERS: 63 VGPRs at 8 waves, scalar spills only)
 k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, const int32_t* __restrict__ tri,
               const int32_t* __restrict__ opp, unsigned char* __restrict__ silh, int n, int V,
               int F, int H, int W, int Wp, unsigned long long* __restrict__ keys, unsigned char* __restrict__ dirty,
@@ -291,6 +308,14 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         }
     }
     const int f = blockIdx.x * kTrisBlock + threadIdx.x;
+    // ... and the same index RECOMPUTED at its late uses (one v_lshl_add from the workgroup id and the thread id, both live anyway)
+    // instead of carried: the allocator's choice of what to spill at the 64-register pin is this value — as a 16-byte scratch store
+    // and six scratch reloads on the hot path (k_raster_tris 83 -> 111 us when one more store tipped it over)
+    auto face = [&]() -> int {
+        int t = (int)threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return (int)(blockIdx.x * kTrisBlock) + t;
+    };
     const int b = blockIdx.y;                                        // wave-uniform (SGPR)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // Owner marks (resolve pass -> face-parallel backward) are the low BYTE of the step that wrote them, and the backward trusts a
@@ -314,7 +339,8 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     const int2* sv = snap + (size_t)b * V;
     bool ok = f < F;
     if (ok) {
-        i0 = tri[f * 3]; i1 = tri[f * 3 + 1]; i2 = tri[f * 3 + 2];
+        const I3U row = at32(reinterpret_cast<const I3U*>(tri), (unsigned)f);
+        i0 = row.x; i1 = row.y; i2 = row.z;
         ok = (unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V;
     }
     // the view's combined matrix (FV): wave-uniform, through the scalar cache into SGPRs
@@ -326,13 +352,13 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
     }
     auto clipv = [&](int v) -> float4 {                              // clip position of vertex v in this view
         if (!FV) return ldg4(pos + ((size_t)b * V + v) * 4);
-        const F3U x = *reinterpret_cast<const F3U*>(verts + (size_t)v * 3);
+        const F3U x = at32(reinterpret_cast<const F3U*>(verts), (unsigned)v);
         return make_float4(clip_coord(x.x, x.y, x.z, cmx[0], cmx[4], cmx[8], cmx[12]), clip_coord(x.x, x.y, x.z, cmx[1], cmx[5], cmx[9], cmx[13]),
                            clip_coord(x.x, x.y, x.z, cmx[2], cmx[6], cmx[10], cmx[14]), clip_coord(x.x, x.y, x.z, cmx[3], cmx[7], cmx[11], cmx[15]));
     };
     // the snapped vertices (R1 + R2 of the rasterizer) stay a stored [n,V] array also in the fused step: snapping in every lane
     // (an IEEE division and a dozen compare / round steps per vertex, for all 4.7 M (view, triangle) pairs) doubled this kernel
-    auto snapv = [&](int v) -> int2 { return sv[v]; };
+    auto snapv = [&](int v) -> int2 { return at32(sv, (unsigned)v); };
     if (ok) {
         s0 = snapv(i0); s1 = snapv(i1); s2 = snapv(i2);
         ok = setup_triangle(s0, s1, s2, H, W, s);
@@ -363,7 +389,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             }
         } else {
             // the opposite-vertex ids (antialias rule A3) are requested now and arrive while the coverage mask is computed
-            if (silh != nullptr) { o0 = opp[f * 3]; o1 = opp[f * 3 + 1]; o2 = opp[f * 3 + 2]; }
+            if (silh != nullptr) { const I3U orow = at32(reinterpret_cast<const I3U*>(opp), (unsigned)f); o0 = orow.x; o1 = orow.y; o2 = orow.z; }
             const int ext = max(max(s.x0, max(s.x1, s.x2)) - min(s.x0, min(s.x1, s.x2)),
                                 max(s.y0, max(s.y1, s.y2)) - min(s.y0, min(s.y1, s.y2)));
             // 32-bit edge arithmetic is exact when the snapped extent is below 2^14 sub-pixel units (64 px): pixel centres lie
@@ -425,7 +451,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         if (lane == leader) base = atomicAdd(large_cnt, __popcll(lbal));
         base = __shfl(base, leader, 64);
         int2* const lq2 = large_q + ((stamp != nullptr && (stamp[0] & 1)) ? (size_t)n * F : 0);      // this step's half of the queue
-        if (is_large) lq2[base + __popcll(lbal & ((1ull << lane) - 1ull))] = make_int2(b, f);
+        if (is_large) lq2[base + __popcll(lbal & ((1ull << lane) - 1ull))] = make_int2(b, face());
         if (defer_large) {
             is_large = false;
             lbal = 0ull;
@@ -442,15 +468,15 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         pin(p0); pin(p1); pin(p2);
         // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
         const unsigned char sbv = (silh != nullptr) ? silh_bits(s0, s1, s2, q0, q1, q2) : (unsigned char)0;
-        if (silh != nullptr) silh[(size_t)b * F + f] = sbv;
+        if (silh != nullptr) at32(silh + (size_t)b * F, (unsigned)face()) = sbv;
         // coverage entry (face-parallel backward), 8 B: candidate-pixel mask of the box | origin x, y (13 bits each) and width - 1 (6 bits,
         // 63 = the marker entry of a large-box face, which carries the step stamp instead of a box).  A small-box entry needs no
         // stamp: the backward reads it only under a matching owner mark, an owner's entry was written this step, and a stale mark
         // (8 bits) meets a stale entry only to have its candidates fail the owner test
         if (cov16 != nullptr)
-            cov16[(size_t)b * F + f] = make_int2((int)cm, s.pxa | (s.pya << 13) | ((bw - 1) << 26));
+            at32(cov16 + (size_t)b * F, (unsigned)face()) = make_int2((int)cm, s.pxa | (s.pya << 13) | ((bw - 1) << 26));
         pk0[threadIdx.x] = p0; pk1[threadIdx.x] = p1; pk2[threadIdx.x] = p2;
-        pk3[threadIdx.x] = make_int4(f, __float_as_int(__builtin_amdgcn_rcpf((float)bw)), s.pxa | (s.pya << 16), bw | ((int)sbv << 8));   // (silhouette bits ride along: binned form)
+        pk3[threadIdx.x] = make_int4(face(), __float_as_int(__builtin_amdgcn_rcpf((float)bw)), s.pxa | (s.pya << 16), bw | ((int)sbv << 8));   // (silhouette bits ride along: binned form)
     }
     __syncthreads();                                                 // every wave of the workgroup gets here (no early return above)
     int wbase = 0, T = 0;
@@ -515,7 +541,10 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             // phase 2: one returning atomic per table entry, all in one instruction of the first two waves; not waited for yet
             const bool own = threadIdx.x < kHash && hkey[threadIdx.x] >= 0;
             int gbase = 0;
-            if (own) gbase = atomicAdd(ba.cursor + ((size_t)b * ba.segsPerView + hkey[threadIdx.x]) * kCursorStride, hcnt[threadIdx.x]);
+            if (own) {
+                const size_t bin = (size_t)b * ba.segsPerView + hkey[threadIdx.x];
+                gbase = atomicAdd(ba.cursor + bin * kCursorStride, hcnt[threadIdx.x]);
+            }
             // phase 3: the fragments (the ~110-instruction evaluation hides the reservations' round trip)
             auto evaluate = [&](int t, unsigned& e, int& bin, BinEntry& ent) {
                 e = tasks32[t];
@@ -533,7 +562,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 if (have && slot != 255) {
                     const int pos = hcnt[slot] + (int)(e >> 21);
                     if (pos < ba.cap) ba.bins[(size_t)bin * ba.cap + pos] = ent;
-                    else *ba.flag = 1;
+                    else *bin_overflow_word(ba) = 1;
                 }
                 const bool slow = have && slot == 255 && ent.x != kBinInvalid;
                 if (__ballot(slow) != 0ull) bin_append(slow, bin, ent, ba, lane);
@@ -543,7 +572,10 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             BinEntry ent0 = make_entry(0u, 0.f);
             const bool have0 = (int)threadIdx.x < nt;
             if (have0) evaluate(threadIdx.x, e0, bin0, ent0);
-            if (own) hcnt[threadIdx.x] = gbase;                      // count -> base slot (waits for the atomic here)
+            if (own) {
+                hcnt[threadIdx.x] = gbase;                           // count -> base slot (waits for the atomic here)
+                if (gbase == 0) *seg_state_word(ba, (long long)b * ba.segsPerView + hkey[threadIdx.x]) = kSegHasFragments | kSegWordsLive;
+            }
             __syncthreads();
             store(have0, e0, bin0, ent0);
             for (int t0 = kTrisBlock; t0 < nt; t0 += kTrisBlock) {   // further slices of a round: more than 256 fragments per 256 faces
@@ -554,6 +586,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 if (t < nt) evaluate(t, e1, bin1, ent1);
                 store(t < nt, e1, bin1, ent1);
             }
+            // EVERY reservation marks its segment for the second pass, not only the bin's first one, and at the END of the round: the
+            // mark then needs nothing but the table (with the fragment's values live, or behind a test of the atomic's result, it cost
+            // the worker instantiation 16 spilled VGPRs); the words are packed — the ~30 marks of a workgroup are a few lines
         }
     } else {
         for (int R = 0; R < T; R += kTaskCap) {                          // workgroup-uniform trip count (one round unless boxes are large)
@@ -618,7 +653,7 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         lbal &= lbal - 1ull;
         if (lane == src) {
             LargePark& q = lpark[wv];
-            q.s = s; q.p0 = lp0; q.p1 = lp1; q.p2 = lp2; q.f = f;
+            q.s = s; q.p0 = lp0; q.p1 = lp1; q.p2 = lp2; q.f = face();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -918,9 +953,24 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
         large_cnt[0] = 0;
         if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
         if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
+        int* const ov = bin_overflow_word(ba);                       // the triangle kernel's overflow word -> the sticky flag the host reads
+        if (*ov != 0) { *ov = 0; if (fu.bin_flag != nullptr) *fu.bin_flag = 1; }
     }
     const long long P = (long long)H * Wp;
     if (seg * 64 >= (long long)n * P) return;
+    // the segment's state word first (packed, hits; BinArgs): an empty segment whose words are already zero leaves here
+    int* const stp = seg_state_word(ba, seg);
+    int state = *(const_as4_int*)(unsigned long long)stp;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(state) : : "memory");   // (the same explicit order as for the count below: this wave stores to the word)
+    if ((state & kSegHasFragments) == 0) {
+        if ((state & kSegWordsLive) != 0 && lane == 0) {
+            covw[seg] = 0ull;
+            if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;
+            *stp = 0;
+        }
+        return;
+    }
+    if (lane == 0) *stp = kSegWordsLive;
     // the bin's fragment count through the scalar cache (written by the previous kernel's atomics; only this wave resets it)
     int* const cur = ba.cursor + (size_t)seg * kCursorStride;
     int count = *(const_as4_int*)(unsigned long long)cur;
@@ -1328,8 +1378,15 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
                         raster_binned_ok(F, H, W, Wp) && raster_binned_wanted(kBinnedDefault);
     BinArgs ba;
     memset(&ba, 0, sizeof(ba));
+    // (a workspace with bins whose step is sent down the atomic-key form — FMHR_RASTER_BINNED=0, same-library A/B — leaves segment words
+    // behind that the state words know nothing of: every word counts as live again)
+    if (!binned && fu.bin_cursor != nullptr && raster_binned_ok(F, H, W, Wp)) {
+        const size_t tiles = raster_bin_count(n, H, Wp);
+        hipError_t e = hipMemsetAsync(fu.bin_cursor - tiles, 0x02, tiles * sizeof(int), st);
+        if (e != hipSuccess) return hip_fail(e, "bin state");
+    }
     if (binned) {
-        ba.bins = fu.bins; ba.cursor = fu.bin_cursor; ba.flag = fu.bin_flag; ba.cap = fu.bin_cap;
+        ba.bins = fu.bins; ba.cursor = fu.bin_cursor; ba.cap = fu.bin_cap; ba.tiles = (int)raster_bin_count(n, H, Wp);
         ba.segsX = Wp / 64; ba.segsPerView = (Wp / 64) * H;
     }
     if ((long long)n * F > 0) {

@@ -1108,3 +1108,50 @@ def test_vertex_order_gives_the_callers_results(oracle):
     print(f"vertex_order: grad rel err vs fp64 oracle (caller's numbering): delta {e_d:.2e} albedo {e_a:.2e}; plain step: "
           f"{rel_err(v0['gdelta'], v0['gd64']):.2e} {rel_err(v0['galbedo'], v0['ga64']):.2e}")
     grad_bar("vertex_order", e_d, e_a, v0["o_d"], v0["o_a"])
+
+
+def test_segment_state_words_follow_moving_coverage(oracle, monkeypatch):
+    """The binned rasterizer's per-segment state words (raster.hip: BinArgs — an empty segment leaves the second pass on one packed
+    load, and zeroes its coverage / valid-count words only when the last step with fragments left them set): one workspace through a
+    sequence in which segments gain, keep and lose their fragments — the mesh on screen, shifted by a third of the image, off screen,
+    back, shifted the other way — every step equal to the same step on a FRESH workspace (`rast`, the antialiased image, the loss
+    vector, the valid-pixel count, both gradients up to the float-atomic order); then the same workspace sent down the atomic-key
+    form for a step (FMHR_RASTER_BINNED=0: segment words written behind the state words' back) and back."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (3, 192, 192, 64, 96), 41)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+
+    def shifted(dx):
+        p = g["proj"].clone()
+        p[:, :, 0] += dx * p[:, :, 3]                                    # clip x shifted by dx * w: the image moves by dx / 2 of its width
+        return p
+
+    def run(hs, proj):
+        losses, gd, ga = hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], proj, g["img"], g["mask"], g["valid_mask"])
+        v = hs.views()
+        return losses.clone(), gd.clone(), ga.clone(), v["rast"].clone(), v["tmp_img"].clone(), v["pred_mask"].clone()
+
+    def same(a, b, what):
+        assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]), what
+        assert float(a[0][7]) == float(b[0][7]), what
+        assert rel_err(a[0][:7], b[0][:7]) < 1e-6 and rel_err(a[1], b[1]) < 1e-5 and rel_err(a[2], b[2]) < 1e-5, what
+
+    def make():
+        return HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+
+    hs = make()
+    assert hs.binned
+    seq = [0.0, 0.66, 5.0, 0.0, -0.66, -0.66, 5.0, 5.0, 0.3]
+    covered = []
+    for k, dx in enumerate(seq):
+        got = run(hs, shifted(dx))
+        same(got, run(make(), shifted(dx)), (k, dx))
+        covered.append(int((got[3][..., 3] > 0).sum()))
+    assert covered[2] == 0 and covered[6] == 0 and covered[0] > 1000 and covered[1] != covered[0]
+    monkeypatch.setenv("FMHR_RASTER_BINNED", "0")                       # one step of the atomic-key form on the SAME workspace ...
+    flat = run(hs, shifted(0.66))
+    monkeypatch.delenv("FMHR_RASTER_BINNED")
+    same(flat, run(make(), shifted(0.66)), "atomic-key form on the binned workspace")
+    for dx in (5.0, -0.66, 0.0):                                        # ... and the bins again: every segment word counts as live
+        same(run(hs, shifted(dx)), run(make(), shifted(dx)), ("after the atomic-key step", dx))
