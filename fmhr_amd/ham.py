@@ -124,6 +124,8 @@ class HamStage2:
         # selects the ABI-4 layout (pitch = W: flat segments) for A/B runs.  The caller's img / mask / valid_mask stay [n,H,W].
         if pitch is None:
             pitch = self.W if os.environ.get("FMHR_ROW_PITCH", "1") == "0" else 0
+        if not bin_cap and os.environ.get("FMHR_BIN_CAP"):             # experiments: the default capacity of every workspace
+            bin_cap = int(os.environ["FMHR_BIN_CAP"])
         self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap, int(bin_cap), int(pitch))
         self.pitch = self.lib.fmhr_ham_pitch(ctypes.byref(self.dims))
         if self.pitch < 0:
