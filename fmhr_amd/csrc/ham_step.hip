@@ -146,7 +146,8 @@ static int check_dims(const fmhr_ham_dims* d)
     FMHR_CHECK_ARG(d != nullptr, "ham: dims is null");
     FMHR_CHECK_ARG(d->n >= 1 && d->V >= 1 && d->F >= 1 && d->H >= 1 && d->W >= 1 && d->aa_cap >= 2048,
                    "ham: bad dims n=%d V=%d F=%d H=%d W=%d aa_cap=%d", d->n, d->V, d->F, d->H, d->W, d->aa_cap);
-    FMHR_CHECK_ARG(d->H <= 8192 && d->W <= 8192 && d->F < (1 << 24), "ham: H,W <= 8192 and F < 2^24 required");
+    FMHR_CHECK_ARG(d->H <= 8192 && d->W <= 8192 && d->F < (1 << 24) && d->V < (1 << 27),
+                   "ham: H,W <= 8192, F < 2^24 and V < 2^27 required (face ids in fp32 / 24 bits; 32-bit byte offsets into the per-vertex tables)");
     FMHR_CHECK_ARG(d->bin_cap >= 0 && d->bin_cap <= (1 << 20), "ham: bin_cap must be 0 (default) or 64 .. 2^20, got %d", d->bin_cap);
     FMHR_CHECK_ARG(d->pitch == 0 || d->pitch == d->W || (d->pitch > d->W && d->pitch % 64 == 0 && d->pitch <= 8192),
                    "ham: pitch must be 0 (default: W rounded up to a multiple of 64), W, or a multiple of 64 above W; got %d (W=%d)", d->pitch, d->W);

@@ -1438,6 +1438,7 @@ extern "C" int fmhr_rasterize_fwd(const float* pos, const int32_t* tri, int n, i
     FMHR_CHECK_ARG(n >= 0 && V >= 0 && F >= 0 && H > 0 && W > 0, "rasterize_fwd: bad dims n=%d V=%d F=%d H=%d W=%d", n, V, F, H, W);
     FMHR_CHECK_ARG(H <= 8192 && W <= 8192, "rasterize_fwd: resolution above 8192 not supported");
     FMHR_CHECK_ARG(F < (1 << 24), "rasterize_fwd: F must be < 2^24 (triangle id is stored as fp32)");
+    FMHR_CHECK_ARG(V < (1 << 27), "rasterize_fwd: V must be < 2^27 (32-bit byte offsets into the per-vertex tables: common.h at32)");
     FMHR_CHECK_ARG(n == 0 || (rast && ws && (pos || V == 0) && (tri || F == 0)), "rasterize_fwd: null pointer");
     FMHR_CHECK_ARG(ws_bytes >= fmhr_rasterize_workspace_bytes(n, V, F, H, W), "rasterize_fwd: workspace too small");
     int2* snap = (int2*)((char*)ws + raster_core_ws_bytes(n, F, H, W));
