@@ -48,6 +48,11 @@ def test_argument_errors_without_gpu(lib):
     assert lib.fmhr_laplacian_uniform_fwd(None, None, None, 10, 5, 1.0, None, None, None) == -1
     bad = HamDims(0, 10, 10, 8, 8, 0, 16, 0)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(bad)) == 0
+    # per-vertex tables are addressed through 32-bit byte offsets (common.h: at32): V < 2^27, said so instead of wrapping
+    assert lib.fmhr_ham_workspace_bytes(ctypes.byref(HamDims(2, 1 << 27, 180, 64, 48, 0, 4096, 0))) == 0
+    assert b"V < 2^27" in lib.fmhr_last_error()
+    assert lib.fmhr_rasterize_fwd(None, None, 1, 1 << 27, 1, 8, 8, None, None, 0, None) == -1
+    assert b"2^27" in lib.fmhr_last_error()
     ok = HamDims(2, 100, 180, 64, 48, 0, 4096, 0)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(ok)) > 2 * 64 * 48 * 16
     # ABI 5: the row pitch — default W rounded up to a multiple of 64; W itself or a multiple of 64 above it when given

@@ -238,7 +238,7 @@ def test_rerender_png_writer(tmp_path):
     assert a[0, 0].tolist() == [0, 127, 255] and a[0, 1].tolist() == [254, 0, 255] and a[1, 2].tolist() == [63, 63, 63]
 
 
-def test_vertex_order_is_a_relabelling_of_the_same_mesh():
+def test_vertex_order_is_a_relabelling_of_the_same_mesh(monkeypatch):
     """fmhr_amd.ham.VertexOrder (the first-touch renumbering run_ham and bench.py optimise in): a permutation of the vertices, the
     faces in their order with their corner order, per-vertex data there and back unchanged, an unused vertex kept (at the end), the
     gathers of 64 consecutive faces within fewer cache lines on a subdivided mesh — and nothing at all with FMHR_VERTEX_ORDER=0 /
@@ -274,5 +274,9 @@ def test_vertex_order_is_a_relabelling_of_the_same_mesh():
     assert again.identity and again.faces is order.faces and again.to_internal(x) is x
     off = VertexOrder(faces, V, enabled=False)
     assert off.identity and torch.equal(off.faces, faces)
+    monkeypatch.setenv("FMHR_VERTEX_ORDER", "0")                       # the environment switch run_ham and bench.py obey
+    assert VertexOrder(faces, V).identity
+    monkeypatch.delenv("FMHR_VERTEX_ORDER")
+    assert not VertexOrder(faces, V).identity
     with pytest.raises(RuntimeError):
         VertexOrder(faces, V - 5)
