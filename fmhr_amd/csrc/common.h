@@ -247,6 +247,33 @@ __device__ __forceinline__ float wave_sum(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// STREAMING accesses (the `nt` cache policy: allocate with the lowest retention priority).  The step's per-pixel arrays are written by
+// one kernel and read once by a later one — 200 MB a piece at the metric, 800 MB at 48 x 1024^2 — and on their way through the 4-MB L2 of
+// an XCD they push out the per-vertex / per-face tables (3.4 MB) every gather of the same kernels goes to.  With the per-pixel stores and
+// the read-once loads of k_raster_bins marked: 74.8 -> 73.4 us at the metric, 387 -> 344 us at 48 x 1024^2 (C4 950 -> 1 009 it/s).
+// Tried and NOT kept (same-box A/B, metric / C4): the per-pixel loads of k_loss_pix (its own 112 -> 97 us at C4, but the antialias and
+// face backward then miss on what it no longer leaves behind: +0.6 % / 0), its gradient store (-0.5 %), the corner-sum stores of
+// k_face_bwd (0 / -1 %), k_face_bwd's per-candidate loads (a pixel's word is read by ~2.5 candidate faces: 68 -> 94 us), the coverage
+// entries of k_raster_tris (+0.2 % / +0.3 %: noise), its fragment entries (scattered 8-B stores want the L2's write combining: bins 72 -> 80 us).
+typedef float v4f_stream __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_stream __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_stream(float4* p, const float4 v)
+{
+    v4f_stream t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f_stream*>(p));
+}
+__device__ __forceinline__ float4 ld_stream(const float4* p)
+{
+    const v4f_stream t = __builtin_nontemporal_load(reinterpret_cast<const v4f_stream*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ uint2 ld_stream(const uint2* p)
+{
+    const v2u_stream t = __builtin_nontemporal_load(reinterpret_cast<const v2u_stream*>(p));
+    return make_uint2(t.x, t.y);
+}
+__device__ __forceinline__ float ld_stream(const float* p) { return __builtin_nontemporal_load(p); }
+
 struct alignas(4) F3U { float x, y, z; };
 struct alignas(4) I3U { int x, y, z; };                            // a row of a [*,3] int32 table as ONE 12-byte load
 struct alignas(4) F4U { float x, y, z, w; };     // a 16-B load from a dword-aligned address (global loads need no more)

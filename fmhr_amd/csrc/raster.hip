@@ -1005,7 +1005,7 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
         for (int k = 0; k < kBinChunk / 64; k++) {
             const int i = c0 + k * 64 + lane;
             e[k] = make_entry(kBinInvalid, 0.f);
-            if (i < cnt) e[k] = bin[i];
+            if (i < cnt) e[k] = ld_stream(&bin[i]);                  // read once
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();                             // keys initialised / the previous chunk has been read by every lane
@@ -1082,7 +1082,7 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
         }
         covered = true;
         fu.own8[(size_t)b * F + f] = (unsigned char)step_tag;
-        fu.pix16[gid] = make_float4(u, v, zw, __int_as_float(pix_pack(f, shade, large, sbits)));
+        st_stream(&fu.pix16[gid], make_float4(u, v, zw, __int_as_float(pix_pack(f, shade, large, sbits))));   // (read by later kernels only: common.h)
         sbits_any = sbits != 0;
         const float w2 = 1.0f - u - v;
         col.w = u + v + w2;
@@ -1094,7 +1094,7 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
         }
     }
     const unsigned long long bal = __ballot(covered);
-    if (bal != 0ull) fu.aa_init[gid] = col;                          // zeros on the uncovered lanes (blend targets start from them)
+    if (bal != 0ull) st_stream(&fu.aa_init[gid], col);               // zeros on the uncovered lanes (blend targets start from them)
     const unsigned long long vbal = __ballot(valid_px);
     const unsigned long long sbal = __ballot(covered && sbits_any);
     if (lane == 0) {
