@@ -118,6 +118,8 @@ def test_run_ham_raises_on_a_work_list_overflow(which):
     raise (sticky flags, read every epoch and at the end) instead of returning gradients with dropped terms."""
     from fmhr_amd import pipeline, synthetic as S
     from fmhr_amd.ham import render_forward
+    if which == "bin_cap" and os.environ.get("FMHR_RASTER_BINNED") == "0":
+        pytest.skip("the atomic-key form has no fragment bins to overflow")
     dev = torch.device("cuda:0")
     sc = S.make_scene(4, 192, 176, 64, 96, 0, seed=8)       # micro-triangle mesh, W % 64 != 0: row pitch 192, binned rasterizer
     faces = sc["faces"].to(dev)
