@@ -251,8 +251,8 @@ __device__ __forceinline__ float wave_sum(float v)
 // one kernel and read once by a later one — 200 MB a piece at the metric, 800 MB at 48 x 1024^2 — and on their way through the 4-MB L2 of
 // an XCD they push out the per-vertex / per-face tables (3.4 MB) every gather of the same kernels goes to.  With the per-pixel stores and
 // the read-once loads of k_raster_bins marked: 74.8 -> 73.4 us at the metric, 387 -> 344 us at 48 x 1024^2 (C4 950 -> 1 009 it/s).
-// Tried and NOT kept (same-box A/B, metric / C4): the per-pixel loads of k_loss_pix (its own 112 -> 97 us at C4, but the antialias and
-// face backward then miss on what it no longer leaves behind: +0.6 % / 0), its gradient store (-0.5 %), the corner-sum stores of
+// Also kept: the per-pixel loads of k_loss_pix (shade.hip: +1 % over five alternating rounds at the metric, +0.6 % at C4).
+// Tried and NOT kept (same-box A/B, metric / C4): k_loss_pix's gradient store (-0.5 %), the corner-sum stores of
 // k_face_bwd (0 / -1 %), k_face_bwd's per-candidate loads (a pixel's word is read by ~2.5 candidate faces: 68 -> 94 us), the coverage
 // entries of k_raster_tris (+0.2 % / +0.3 %: noise), its fragment entries (scattered 8-B stores want the L2's write combining: bins 72 -> 80 us).
 typedef float v4f_stream __attribute__((ext_vector_type(4)));

@@ -185,9 +185,13 @@ k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict
         if (Wp != W) cidx = caller_index((unsigned)__builtin_amdgcn_readfirstlane((int)seg), lane, W, segx, incol);
         if (!incol) continue;                                       // a pad column: no pixel, no loss term
         // every request of the iteration up front: aa (16 B), the image pixel (12 B, one request), the two masks
-        float4 a = aa[gid];
-        const F3U im = *reinterpret_cast<const F3U*>(img + cidx * 3);
-        const float mk = mask[cidx], vm = valid_mask[cidx];
+        // (streaming loads, common.h: this pass reads 160 MB exactly once — through the default policy it leaves the L2 without the
+        // tables the antialias and face backward and the mesh tails gather from; 3 029 -> 3 060 it/s over five alternating rounds, the
+        // tails 26.3 -> 25.0 us; the image pixel as three 4-B requests: a 12-B streaming load does not exist)
+        float4 a = ld_stream(&aa[gid]);
+        F3U im;
+        im.x = ld_stream(img + cidx * 3); im.y = ld_stream(img + cidx * 3 + 1); im.z = ld_stream(img + cidx * 3 + 2);
+        const float mk = ld_stream(mask + cidx), vm = ld_stream(valid_mask + cidx);
         const bool cov = (covw[seg] >> lane) & 1ull;          // covered pixel (the segment's coverage word)
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mk > 0.f && cov) {
