@@ -107,38 +107,86 @@ __device__ __forceinline__ bool edge_in(int ax, int ay, int bx, int by, int cx, 
     return (dy > 0) || (dy == 0 && dx > 0);
 }
 
-// fragment (u, v, z/w) of a triangle at a pixel; false when degenerate.
-__device__ __forceinline__ bool fragment(const float4 p0, const float4 p1, const float4 p2, int px, int py,
-                                         float xs, float xo, float ys, float yo, Frag& o)
+// ---- rule R5.  DECISIONS — accept / reject of a fragment, its depth z/w and with it the depth order — are fp32, one
+// IEEE operation per statement (fragment_zw).  VALUES — the barycentrics (u, v) a winner returns, and their gradient with respect to
+// the clip positions (shade.hip: pixel_backward, raster.hip: k_raster_bwd) — are evaluated in DOUBLE from the same fp32 clip positions
+// and rounded once (round 5): nvdiffrast's pixel-relative edge functions x - fx w cancel ~10 bits at the reference capture's clip-space
+// scale (|x| ~ 2, a pixel 1.5e-3 of it) and a thin triangle divides what is left by its area: evaluated in fp32 — in ANY fp32 order —
+// the position gradient of the thinnest triangles of the capture's own cameras was 8e-4 of the gradient's maximum away from exact
+// arithmetic (profiles/parity_r04.txt; the oracle's fp32 twin showed the same), in double it is 2e-5 (tools/experiments/r05_r5_wide.py).
+// gfx950 issues v_fma_f64 at the rate of the un-packed v_fma_f32 (tools/micro/valu_rate.hip): the ~45 double operations of a winner cost
+// what the fp32 ones did.  The CPU checker's fp32 twin holds the same statements (r5_uv_wide / r5_bwd_wide there): `rast` stays bit-identical.
+struct PixGrid { float xs, xo, ys, yo; double iW, iH; int W, H; };
+
+// pixel-relative homogeneous coordinates p_i - f w_i in double; the pixel centre f = (2 px + 1 - W) / W as an integer times 1 / W
+__device__ __forceinline__ void r5_wide_setup(float p0cx, float p0cy, float p0w, float p1cx, float p1cy, float p1w, float p2cx, float p2cy, float p2w,
+                                              int px, int py, const PixGrid& pg, double (&q)[6], double& fx, double& fy)
 {
-    float fx = xs * (float)px; fx = fx + xo;
-    float fy = ys * (float)py; fy = fy + yo;
-    float t;
-    t = fx * p0.w; float p0x = p0.x - t;  t = fy * p0.w; float p0y = p0.y - t;
-    t = fx * p1.w; float p1x = p1.x - t;  t = fy * p1.w; float p1y = p1.y - t;
-    t = fx * p2.w; float p2x = p2.x - t;  t = fy * p2.w; float p2y = p2.y - t;
-    float m0, m1;
-    m0 = p1x * p2y; m1 = p1y * p2x; float a0 = m0 - m1;
-    m0 = p2x * p0y; m1 = p2y * p0x; float a1 = m0 - m1;
-    m0 = p0x * p1y; m1 = p0y * p1x; float a2 = m0 - m1;
-    float at = a0 + a1; at = at + a2;
-    if (!(fabsf(at) > 0.0f)) return false;
-    float iw = 1.0f / at;
-    float b0 = a0 * iw;
-    float b1 = a1 * iw;
-    float zn = p0.z * a0; t = p1.z * a1; zn = zn + t; t = p2.z * a2; zn = zn + t;
-    float wn = p0.w * a0; t = p1.w * a1; wn = wn + t; t = p2.w * a2; wn = wn + t;
-    float q = zn / wn;
-    if (!(q == q)) return false;
-    if (b0 < 0.0f) b0 = 0.0f;
-    if (b0 > 1.0f) b0 = 1.0f;
-    if (b1 < 0.0f) b1 = 0.0f;
-    if (b1 > 1.0f) b1 = 1.0f;
-    if (q < -1.0f) q = -1.0f;
-    if (q > 1.0f) q = 1.0f;
-    q = q + 0.0f;
-    o.u = b0; o.v = b1; o.zw = q;
-    return true;
+    fx = (double)(2 * px + 1 - pg.W); fx = fx * pg.iW;
+    fy = (double)(2 * py + 1 - pg.H); fy = fy * pg.iH;
+    double t;
+    t = fx * (double)p0w; q[0] = (double)p0cx - t;  t = fy * (double)p0w; q[1] = (double)p0cy - t;
+    t = fx * (double)p1w; q[2] = (double)p1cx - t;  t = fy * (double)p1w; q[3] = (double)p1cy - t;
+    t = fx * (double)p2w; q[4] = (double)p2cx - t;  t = fy * (double)p2w; q[5] = (double)p2cy - t;
+}
+
+// (u, v) of a fragment fragment_zw() has accepted (x, y, w of the three clip positions), clamped to [0, 1]
+__device__ __forceinline__ void fragment_uv(float p0cx, float p0cy, float p0w, float p1cx, float p1cy, float p1w, float p2cx, float p2cy, float p2w,
+                                            int px, int py, const PixGrid& pg, float& u, float& v)
+{
+    double q[6], fx, fy;
+    r5_wide_setup(p0cx, p0cy, p0w, p1cx, p1cy, p1w, p2cx, p2cy, p2w, px, py, pg, q, fx, fy);
+    double m0, m1;
+    m0 = q[2] * q[5]; m1 = q[3] * q[4]; const double a0 = m0 - m1;
+    m0 = q[4] * q[1]; m1 = q[5] * q[0]; const double a1 = m0 - m1;
+    m0 = q[0] * q[3]; m1 = q[1] * q[2]; const double a2 = m0 - m1;
+    double at = a0 + a1; at = at + a2;
+    const double iw = 1.0 / at;                                      // IEEE division (the result is part of `rast`: bit-identical to the checker)
+    const double b0 = a0 * iw;
+    const double b1 = a1 * iw;
+    float uf = (float)b0, vf = (float)b1;
+    if (!(uf >= 0.0f)) uf = 0.0f;                                    // (also a NaN from a zero area in double: the fp32 accept test had passed)
+    if (uf > 1.0f) uf = 1.0f;
+    if (!(vf >= 0.0f)) vf = 0.0f;
+    if (vf > 1.0f) vf = 1.0f;
+    u = uf; v = vf;
+}
+
+// d (u, v) / d clip positions on the UNCLAMPED barycentrics, in double: gu, gv = d loss / d (u, v);
+// qx / qy / qw [k] = d loss / d (x, y, w) of vertex k, rounded to float at the end.  Value-only (nothing discrete hangs on it): the
+// reciprocal of the area is v_rcp_f64 refined by one Newton step instead of the ~15-instruction IEEE division (62 cycles per wave).
+__device__ __forceinline__ void r5_bwd_wide(float p0cx, float p0cy, float p0w, float p1cx, float p1cy, float p1w, float p2cx, float p2cy, float p2w,
+                                            int px, int py, const PixGrid& pg, float gu, float gv, float (&qx)[3], float (&qy)[3], float (&qw)[3])
+{
+    double q[6], fx, fy;
+    r5_wide_setup(p0cx, p0cy, p0w, p1cx, p1cy, p1w, p2cx, p2cy, p2w, px, py, pg, q, fx, fy);
+    const double p0x = q[0], p0y = q[1], p1x = q[2], p1y = q[3], p2x = q[4], p2y = q[5];
+    const double e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
+    const double at = e0 + e1 + e2;
+    double iw = __builtin_amdgcn_rcp(at);                             // 24 bits (measured 4.5e-8); one Newton step: 2e-15 (tools/micro/valu_rate.hip)
+    iw = __builtin_fma(__builtin_fma(-at, iw, 1.0), iw, iw);
+#ifndef FMHR_X_R5_ALL_DOUBLE
+    // The ill-conditioned part ends here: the barycentrics, the reciprocal area and the EDGE DIFFERENCES of the accurate pixel-relative
+    // coordinates are rounded to float once each, the ~30 well-conditioned multiply-adds behind them run in fp32 (same-box A/B at the
+    // metric, k_face_bwd: all-fp32 66.4 us, all of it in double 69.2, this form 68.3; the capture-camera parity case 2.1e-5 either way)
+    const float b0 = (float)(e0 * iw), b1 = (float)(e1 * iw), iwf = (float)iw;
+    const float gb0 = gu * iwf, gb1 = gv * iwf, gbb = gb0 * b0 + gb1 * b1;
+    const float d21y = (float)(p2y - p1y), d02y = (float)(p0y - p2y), d10y = (float)(p1y - p0y);
+    const float d12x = (float)(p1x - p2x), d20x = (float)(p2x - p0x), d01x = (float)(p0x - p1x);
+    const float f0x = (float)p0x, f0y = (float)p0y, f1x = (float)p1x, f1y = (float)p1y, f2x = (float)p2x, f2y = (float)p2y;
+    const float fxf = (float)fx, fyf = (float)fy;
+    qx[0] = gbb * d21y - gb1 * f2y; qx[1] = gbb * d02y + gb0 * f2y; qx[2] = gbb * d10y - gb0 * f1y + gb1 * f0y;
+    qy[0] = gbb * d12x + gb1 * f2x; qy[1] = gbb * d20x - gb0 * f2x; qy[2] = gbb * d01x + gb0 * f1x - gb1 * f0x;
+#pragma unroll
+    for (int k = 0; k < 3; k++) qw[k] = -fxf * qx[k] - fyf * qy[k];
+#else
+    const double gb0 = (double)gu * iw, gb1 = (double)gv * iw, gbb = gb0 * (e0 * iw) + gb1 * (e1 * iw);
+    const double x0 = gbb * (p2y - p1y) - gb1 * p2y, x1 = gbb * (p0y - p2y) + gb0 * p2y, x2 = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
+    const double y0 = gbb * (p1x - p2x) + gb1 * p2x, y1 = gbb * (p2x - p0x) - gb0 * p2x, y2 = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
+    qx[0] = (float)x0; qx[1] = (float)x1; qx[2] = (float)x2;
+    qy[0] = (float)y0; qy[1] = (float)y1; qy[2] = (float)y2;
+    qw[0] = (float)(-fx * x0 - fy * y0); qw[1] = (float)(-fx * x1 - fy * y1); qw[2] = (float)(-fx * x2 - fy * y2);
+#endif
 }
 
 // rule R5, the depth only: the SAME statements as fragment() for everything z/w and the accept / reject decision depend on (the
@@ -170,42 +218,26 @@ __device__ __forceinline__ bool fragment_zw(const float4 p0, const float4 p1, co
     return true;
 }
 
-// ... and the barycentrics only, for a fragment fragment_zw() has accepted (x, y, w of the three clip positions): the statements of
-// fragment() that lead to (u, v), nothing else
-__device__ __forceinline__ void fragment_uv(float p0cx, float p0cy, float p0w, float p1cx, float p1cy, float p1w, float p2cx, float p2cy, float p2w,
-                                            int px, int py, float xs, float xo, float ys, float yo, float& u, float& v)
+// rule R5 in full: the fp32 decisions + depth of fragment_zw(), the barycentrics of fragment_uv()
+__device__ __forceinline__ bool fragment(const float4 p0, const float4 p1, const float4 p2, int px, int py, const PixGrid& pg, Frag& o)
 {
-    float fx = xs * (float)px; fx = fx + xo;
-    float fy = ys * (float)py; fy = fy + yo;
-    float t;
-    t = fx * p0w; float p0x = p0cx - t;  t = fy * p0w; float p0y = p0cy - t;
-    t = fx * p1w; float p1x = p1cx - t;  t = fy * p1w; float p1y = p1cy - t;
-    t = fx * p2w; float p2x = p2cx - t;  t = fy * p2w; float p2y = p2cy - t;
-    float m0, m1;
-    m0 = p1x * p2y; m1 = p1y * p2x; float a0 = m0 - m1;
-    m0 = p2x * p0y; m1 = p2y * p0x; float a1 = m0 - m1;
-    m0 = p0x * p1y; m1 = p0y * p1x; float a2 = m0 - m1;
-    float at = a0 + a1; at = at + a2;
-    float iw = 1.0f / at;
-    float b0 = a0 * iw;
-    float b1 = a1 * iw;
-    if (b0 < 0.0f) b0 = 0.0f;
-    if (b0 > 1.0f) b0 = 1.0f;
-    if (b1 < 0.0f) b1 = 0.0f;
-    if (b1 > 1.0f) b1 = 1.0f;
-    u = b0; v = b1;
+    float zw;
+    if (!fragment_zw(p0, p1, p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, zw)) return false;
+    fragment_uv(p0.x, p0.y, p0.w, p1.x, p1.y, p1.w, p2.x, p2.y, p2.w, px, py, pg, o.u, o.v);
+    o.zw = zw;
+    return true;
 }
 
 // NDC coordinates of a pixel centre (rule R5): fx = xs * px + xo, fy = ys * py + yo.  Computed ONCE on the host (IEEE fp32, one
 // rounding per operation: bit-identical to the same statements on the device) and handed to the kernels: evaluated per wave the
 // four correctly rounded divisions cost ~45 vector instructions, 6 % of the triangle kernel.
-struct PixGrid { float xs, xo, ys, yo; };
 inline PixGrid make_pix_grid(int H, int W)
 {
     PixGrid g;
     volatile float iw = 1.0f / (float)W, ih = 1.0f / (float)H;      // volatile: no host-side re-association / wider intermediates
     g.xs = 2.0f / (float)W; g.ys = 2.0f / (float)H;
     g.xo = iw - 1.0f; g.yo = ih - 1.0f;
+    g.iW = 1.0 / (double)W; g.iH = 1.0 / (double)H; g.W = W; g.H = H;   // rule R5's values (double): the pixel centre is (2 px + 1 - W) * iW
     return g;
 }
 

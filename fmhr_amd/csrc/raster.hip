@@ -66,9 +66,9 @@ __device__ __forceinline__ void emit_fragment(const float4 p0, const float4 p1, 
                                               float xs, float xo, float ys, float yo, unsigned long long* keys_view, int W,
                                               unsigned char* dirty, long long pixbase)
 {
-    Frag fr;
-    if (!fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) return;
-    unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)f << 1) | 1u;   // bit 0: large-box triangle
+    float zw;                                                        // the key needs the depth only: the resolve pass evaluates the winner's (u, v)
+    if (!fragment_zw(p0, p1, p2, px, py, xs, xo, ys, yo, zw)) return;
+    unsigned long long key = ((unsigned long long)mono_key(zw) << 32) | ((unsigned)f << 1) | 1u;   // bit 0: large-box triangle
     const size_t pix = (size_t)py * W + px;
     atomicMin(&keys_view[pix], key);
     if (dirty != nullptr) dirty[(pixbase + (long long)pix) >> 6] = 1;
@@ -622,9 +622,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                     qf = qf * q.rbw;
                     const int r = (int)qf, c = bit - r * q.bw;
                     const int px = (q.origin & 0xffff) + c, py = (q.origin >> 16) + r;
-                    Frag fr;
-                    if (fragment(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, fr)) {
-                        const unsigned long long key = ((unsigned long long)mono_key(fr.zw) << 32) | ((unsigned)q.f << 1);
+                    float zw;
+                    if (fragment_zw(q.p0, q.p1, q.p2, px, py, pg.xs, pg.xo, pg.ys, pg.yo, zw)) {
+                        const unsigned long long key = ((unsigned long long)mono_key(zw) << 32) | ((unsigned)q.f << 1);
                         const int pix = py * Wp + px;                    // < 2^26
                         atomicMin(&keys_view[pix], key);
                         segl = (pix + segrem) >> 6;                      // segment index relative to the view's first segment
@@ -865,9 +865,8 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
                 p2 = make_float4(clip_coord(x2.x, x2.y, x2.z, cm[0], cm[4], cm[8], cm[12]), clip_coord(x2.x, x2.y, x2.z, cm[1], cm[5], cm[9], cm[13]),
                                  clip_coord(x2.x, x2.y, x2.z, cm[2], cm[6], cm[10], cm[14]), clip_coord(x2.x, x2.y, x2.z, cm[3], cm[7], cm[11], cm[15]));
             }
-            const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;
             Frag fr;
-            if (fragment(p0, p1, p2, px, py, xs, xo, ys, yo, fr)) {
+            if (fragment(p0, p1, p2, px, py, pg, fr)) {
                 o = make_float4(fr.u, fr.v, fr.zw, (float)(f + 1));
                 covered = true;
                 if (fu.pix16 != nullptr) {
@@ -1068,7 +1067,7 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
         const unsigned rowg = udiv((unsigned)seg, fu.segx), col0 = ((unsigned)seg - rowg * fu.segx.d) << 6;
         const int py = (int)rowg - b * H, px = (int)col0 + lane;
         float u, v;
-        fragment_uv(p0x, p0y, p0w, p1x, p1y, p1w, p2x, p2y, p2w, px, py, pg.xs, pg.xo, pg.ys, pg.yo, u, v);
+        fragment_uv(p0x, p0y, p0w, p1x, p1y, p1w, p2x, p2y, p2w, px, py, pg, u, v);
         const float zw = __uint_as_float(win.y);
         asm volatile("" : "+v"(u), "+v"(v));
         if (shade) {
@@ -1137,7 +1136,7 @@ int reshade_dense_impl(const unsigned long long* covw, const float* pix16, const
 // issued lane = (pixel, vertex, component), so that a vertex's three components are one cache-line request (k_interp_bwd)
 __global__ void __launch_bounds__(kBlock)
 k_raster_bwd(const float* __restrict__ pos, const int32_t* __restrict__ tri, const float4* __restrict__ rast,
-             const float4* __restrict__ dy, int n, int V, int F, int H, int W, float* __restrict__ gpos)
+             const float4* __restrict__ dy, int n, int V, int F, int H, int W, float* __restrict__ gpos, const PixGrid pg)
 {
     __shared__ float st_val[kBlock * 9];
     __shared__ unsigned st_vtx[kBlock * 3];                          // row (view * V + vertex) of gpos: < 2^32 (checked by the launcher)
@@ -1159,24 +1158,12 @@ k_raster_bwd(const float* __restrict__ pos, const int32_t* __restrict__ tri, con
         int i0 = tri[t * 3], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
         const float* vp = pos + (size_t)b * V * 4;
         const float4 p0 = ldg4(vp + (size_t)i0 * 4), p1 = ldg4(vp + (size_t)i1 * 4), p2 = ldg4(vp + (size_t)i2 * 4);
-        float fx = (2.0f / (float)W) * (float)px + (1.0f / (float)W - 1.0f);
-        float fy = (2.0f / (float)H) * (float)py + (1.0f / (float)H - 1.0f);
-        float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-        float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-        float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-        float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
-        float iw = 1.0f / (a0 + a1 + a2);
-        float b0 = a0 * iw, b1 = a1 * iw;
-        float gb0 = g.x * iw, gb1 = g.y * iw, gbb = gb0 * b0 + gb1 * b1;
-        float g0x = gbb * (p2y - p1y) - gb1 * p2y;
-        float g1x = gbb * (p0y - p2y) + gb0 * p2y;
-        float g2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
-        float g0y = gbb * (p1x - p2x) + gb1 * p2x;
-        float g1y = gbb * (p2x - p0x) - gb0 * p2x;
-        float g2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
-        val[0] = g0x; val[1] = g0y; val[2] = -fx * g0x - fy * g0y;
-        val[3] = g1x; val[4] = g1y; val[5] = -fx * g1x - fy * g1y;
-        val[6] = g2x; val[7] = g2y; val[8] = -fx * g2x - fy * g2y;
+        // rule R5's values: this gradient in double from the fp32 positions (common.h: r5_bwd_wide)
+        float qx[3], qy[3], qw[3];
+        r5_bwd_wide(p0.x, p0.y, p0.w, p1.x, p1.y, p1.w, p2.x, p2.y, p2.w, px, py, pg, g.x, g.y, qx, qy, qw);
+        val[0] = qx[0]; val[1] = qy[0]; val[2] = qw[0];
+        val[3] = qx[1]; val[4] = qy[1]; val[5] = qw[1];
+        val[6] = qx[2]; val[7] = qy[2]; val[8] = qw[2];
         vtx[0] = (unsigned)((long long)b * V + i0); vtx[1] = (unsigned)((long long)b * V + i1); vtx[2] = (unsigned)((long long)b * V + i2);
     }
     wave_add_3x3<4, 3>(gpos, on, val, vtx, st_val + (threadIdx.x & ~63) * 9, st_vtx + (threadIdx.x & ~63) * 3);
@@ -1457,7 +1444,7 @@ extern "C" int fmhr_rasterize_bwd(const float* pos, const int32_t* tri, const fl
     FMHR_CHECK_ARG(pos && tri && rast && dy && gpos, "rasterize_bwd: null pointer");
     FMHR_CHECK_ARG((long long)n * V < (1ll << 32), "rasterize_bwd: n * V must be below 2^32");
     k_raster_bwd<<<cdiv((long long)nP, kBlock), kBlock, 0, (hipStream_t)stream>>>(pos, tri, (const float4*)rast,
-                                                                                  (const float4*)dy, n, V, F, H, W, gpos);
+                                                                                  (const float4*)dy, n, V, F, H, W, gpos, make_pix_grid(H, W));
     FMHR_CHECK_LAUNCH("k_raster_bwd");
     return FMHR_OK;
 }

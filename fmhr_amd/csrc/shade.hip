@@ -249,7 +249,7 @@ static_assert(sizeof(FaceAttr) == 27 * sizeof(float), "k_face_bwd fills the reco
 // c = the view's 9 SH coefficients followed by its clip matrix rows (view_c layout).
 __device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr& fa_lds,
                                                const float* __restrict__ c, float u, float v, const float4 gs, int px, int py,
-                                               float xs, float xo, float ys, float yo)
+                                               const PixGrid& pg)
 {
     const FaceAttr fa = fa_lds;                 // read at the use: the kernel's occupancy is set by its live registers
     const float b0 = u, b1 = v, b2 = 1.0f - u - v;
@@ -281,7 +281,6 @@ __device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr&
     const float gv = gnx * fa.dn1.x + gny * fa.dn1.y + gnz * fa.dn1.z + ga0 * fa.da1.x + ga1 * fa.da1.y + ga2 * fa.da1.z;
     // rasterize backward (Appendix B.1) for the three corners, pushed through the view's clip transform (c[9..]: rows of
     // w2c @ proj, mesh.hip transform_body): the position gradients become view-independent
-    const float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
     // the three clip positions (x, y, w) of this view, recomputed from the face's vertices and the view's combined matrix
     // (c[9..24]: rows of w2c @ proj, columns x, y, w) exactly as the geometry kernel computed them: 27 FMAs instead of three
     // 16-B gathers per (face, view)
@@ -293,23 +292,18 @@ __device__ __forceinline__ void pixel_backward(float (&A)[3][9], const FaceAttr&
 #pragma unroll
             for (int l = 0; l < 3; l++) pp[k * 3 + l] = clip_coord(vv[k].x, vv[k].y, vv[k].z, c[9 + l], c[13 + l], c[17 + l], c[21 + l]);
     }
-    const float p0x = pp[0] - fx * pp[2], p0y = pp[1] - fy * pp[2];
-    const float p1x = pp[3] - fx * pp[5], p1y = pp[4] - fy * pp[5];
-    const float p2x = pp[6] - fx * pp[8], p2y = pp[7] - fy * pp[8];
-    const float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
-    const float iw = frcp(e0 + e1 + e2);
-    const float gb0 = gu * iw, gb1 = gv * iw, gbb = gb0 * (e0 * iw) + gb1 * (e1 * iw);
-    const float qx[3] = {gbb * (p2y - p1y) - gb1 * p2y, gbb * (p0y - p2y) + gb0 * p2y, gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y};
-    const float qy[3] = {gbb * (p1x - p2x) + gb1 * p2x, gbb * (p2x - p0x) - gb0 * p2x, gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x};
+    // rule R5's values (round 5, common.h): the gradient of (u, v) with respect to the clip positions in double — a thin triangle
+    // divides the last bits of the pixel-relative edge functions by its area (capture cameras: 9.9e-4 of the gradient's maximum in fp32)
+    float qx[3], qy[3], qw[3];
+    r5_bwd_wide(pp[0], pp[1], pp[2], pp[3], pp[4], pp[5], pp[6], pp[7], pp[8], px, py, pg, gu, gv, qx, qy, qw);
     const float bk[3] = {b0, b1, b2};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         A[k][0] += bk[k] * gnx; A[k][1] += bk[k] * gny; A[k][2] += bk[k] * gnz;
         A[k][3] += bk[k] * ga0; A[k][4] += bk[k] * ga1; A[k][5] += bk[k] * ga2;
-        const float qw = -fx * qx[k] - fy * qy[k];
-        A[k][6] += qx[k] * c[9] + qy[k] * c[10] + qw * c[11];
-        A[k][7] += qx[k] * c[13] + qy[k] * c[14] + qw * c[15];
-        A[k][8] += qx[k] * c[17] + qy[k] * c[18] + qw * c[19];
+        A[k][6] += qx[k] * c[9] + qy[k] * c[10] + qw[k] * c[11];
+        A[k][7] += qx[k] * c[13] + qy[k] * c[14] + qw[k] * c[15];
+        A[k][8] += qx[k] * c[17] + qy[k] * c[18] + qw[k] * c[19];
     }
 }
 
@@ -460,7 +454,6 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int c = 0; c < 9; c++) A[k][c] = 0.f;
-    const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;        // host constants: four IEEE divisions per wave otherwise
     if (anyk != 0ull) {                                            // wave-uniform
         // ---- one memory round trip for the face's attributes (lane 0 of the group) AND the first candidate pixel of every lane:
         //      the attribute loads are issued first, the candidate masks (already here) are expanded into the task list, each lane
@@ -543,7 +536,7 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
         auto consume = [&](float4 w, float4 gs, int vs, int px, int py) {
             const int pk = __float_as_int(w.w);
             if (pix_face(pk) == f && pix_mask(pk) && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f))
-                pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
+                pixel_backward(A, fa, &view_c[vs][0], w.x, w.y, gs, px, py, pg);
         };
         // a lane's tasks of one round, software-pipelined: the next task's two loads are in flight while the current one is
         // evaluated (a lane has ~5 tasks at 48 views; `have` = the first task (t) is already loaded into w / gs)
@@ -631,7 +624,6 @@ face_bwd_large_items(const float4* __restrict__ bwd16, const int32_t* __restrict
     const int cnt = large_cnt[1];                                  // the second rasterizer pass kept a copy when it rearmed the queue
     if (qstamp != nullptr && (qstamp[0] & 1)) large_q += (size_t)n * F;   // the queue's half of this step's parity (raster.hip: k_raster_tris)
     const long long P = (long long)H * Wp;                         // W clips the box, Wp (row pitch) addresses
-    const float xs = pg.xs, ys = pg.ys, xo = pg.xo, yo = pg.yo;
     const unsigned char cur = own8 != nullptr ? (unsigned char)stamp[0] : (unsigned char)0;
     for (int it = first; it < cnt; it += stride) {                 // wave-uniform
         const int2 bf = large_q[it];
@@ -682,7 +674,7 @@ face_bwd_large_items(const float4* __restrict__ bwd16, const int32_t* __restrict
             const int pkd = __float_as_int(w.w);
             if (pix_face(pkd) == f && pix_mask(pkd)) {
                 const float4 gs = g_shaded[gid];
-                if (!(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) pixel_backward(A, pk[wv], &view_c[wv][0], w.x, w.y, gs, px, py, xs, xo, ys, yo);
+                if (!(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) pixel_backward(A, pk[wv], &view_c[wv][0], w.x, w.y, gs, px, py, pg);
             }
         }
 #pragma unroll

@@ -54,6 +54,77 @@ int orc_topology_build(const int32_t* tri, int F, int V, int32_t* opp)
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Rule R5, VALUES (round 5).  The fp32 twin keeps every DECISION of rule R5 in fp32 (accept / reject of a fragment,
+ * its depth z/w and with it the depth order): those are bit-identical to the HIP kernels.  The barycentrics (u, v) it RETURNS, and
+ * the gradient of (u, v) with respect to the clip positions, are evaluated in double from the same fp32 clip positions and rounded
+ * once: nvdiffrast's pixel-relative edge functions x - fx w cancel ~10 bits at the reference capture's clip-space scale
+ * (|x| ~ 2, a pixel 1.5e-3), and a thin triangle divides what is left by its area — in fp32 the position gradient of the thinnest
+ * triangles was 8e-4 of the gradient's maximum away from exact arithmetic (profiles/parity_r04.txt).  The HIP kernels evaluate the
+ * same statements in double (raster.hip: fragment_uv_wide, shade.hip: pixel_backward), one IEEE operation per statement.
+ * orc_set_r5_wide(0) restores the all-fp32 evaluation (A/B: tools/experiments/r05_r5_wide.py). */
+static int g_r5_wide = 1;
+void orc_set_r5_wide(int on) { g_r5_wide = on ? 1 : 0; }
+int orc_get_r5_wide(void) { return g_r5_wide; }
+
+/* pixel-relative homogeneous coordinates p_i - f w_i in double; the pixel centre f = (2 px + 1 - W) / W as an integer times 1 / W */
+static inline void r5_wide_setup(const float* p0, const float* p1, const float* p2, int px, int py, int H, int W, double* q /* p0x p0y p1x p1y p2x p2y */,
+                                 double* fxo, double* fyo)
+{
+    const double iW = 1.0 / (double)W, iH = 1.0 / (double)H;
+    double fx = (double)(2 * px + 1 - W); fx = fx * iW;
+    double fy = (double)(2 * py + 1 - H); fy = fy * iH;
+    double t;
+    t = fx * (double)p0[3]; q[0] = (double)p0[0] - t;  t = fy * (double)p0[3]; q[1] = (double)p0[1] - t;
+    t = fx * (double)p1[3]; q[2] = (double)p1[0] - t;  t = fy * (double)p1[3]; q[3] = (double)p1[1] - t;
+    t = fx * (double)p2[3]; q[4] = (double)p2[0] - t;  t = fy * (double)p2[3]; q[5] = (double)p2[1] - t;
+    *fxo = fx; *fyo = fy;
+}
+
+/* (u, v) of a fragment rule R5 has accepted, clamped to [0, 1], rounded to float once */
+static inline void r5_uv_wide(const float* p0, const float* p1, const float* p2, int px, int py, int H, int W, float* u, float* v)
+{
+    double q[6], fx, fy;
+    r5_wide_setup(p0, p1, p2, px, py, H, W, q, &fx, &fy);
+    double m0, m1;
+    m0 = q[2] * q[5]; m1 = q[3] * q[4]; double a0 = m0 - m1;
+    m0 = q[4] * q[1]; m1 = q[5] * q[0]; double a1 = m0 - m1;
+    m0 = q[0] * q[3]; m1 = q[1] * q[2]; double a2 = m0 - m1;
+    double at = a0 + a1; at = at + a2;
+    double iw = 1.0 / at;
+    double b0 = a0 * iw;
+    double b1 = a1 * iw;
+    float uf = (float)b0, vf = (float)b1;
+    if (!(uf >= 0.0f)) uf = 0.0f;                                /* (also a NaN from a zero area in double: the fp32 accept test passed) */
+    if (uf > 1.0f) uf = 1.0f;
+    if (!(vf >= 0.0f)) vf = 0.0f;
+    if (vf > 1.0f) vf = 1.0f;
+    *u = uf; *v = vf;
+}
+
+/* d (u, v) / d clip positions in double; g[3 k + 0 / 1 / 2] = gradient w.r.t. x, y, w of vertex k */
+static inline void r5_bwd_wide(const float* p0, const float* p1, const float* p2, int px, int py, int H, int W, double du, double dv, double* g)
+{
+    double q[6], fx, fy;
+    r5_wide_setup(p0, p1, p2, px, py, H, W, q, &fx, &fy);
+    const double p0x = q[0], p0y = q[1], p1x = q[2], p1y = q[3], p2x = q[4], p2y = q[5];
+    double a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+    double at = a0 + a1 + a2;
+    double iw = 1.0 / at;
+    double b0 = a0 * iw, b1 = a1 * iw;
+    double gb0 = du * iw, gb1 = dv * iw, gbb = gb0 * b0 + gb1 * b1;
+    double g0x = gbb * (p2y - p1y) - gb1 * p2y;
+    double g1x = gbb * (p0y - p2y) + gb0 * p2y;
+    double g2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
+    double g0y = gbb * (p1x - p2x) + gb1 * p2x;
+    double g1y = gbb * (p2x - p0x) - gb0 * p2x;
+    double g2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
+    g[0] = g0x; g[1] = g0y; g[2] = -fx * g0x - fy * g0y;
+    g[3] = g1x; g[4] = g1y; g[5] = -fx * g1x - fy * g1y;
+    g[6] = g2x; g[7] = g2y; g[8] = -fx * g2x - fy * g2y;
+}
+
+#define R5_WIDE 1
 #define SFX(name) name##_f32
 #define REAL float
 #define RINT rintf
@@ -66,6 +137,8 @@ int orc_topology_build(const int32_t* tri, int F, int V, int32_t* opp)
 #undef FABS
 #undef MAXREAL
 
+#undef R5_WIDE
+#define R5_WIDE 0
 #define SFX(name) name##_f64
 #define REAL double
 #define RINT rint
@@ -102,7 +175,7 @@ void orc_rasterize_fwd_mix(const double* pos, const int32_t* tri, int n, int V, 
                 const double* vp = pos + (size_t)b * V * 4;
                 double u, v, zw;
                 if (!fragment_f64(vp + (size_t)tri[t * 3] * 4, vp + (size_t)tri[t * 3 + 1] * 4, vp + (size_t)tri[t * 3 + 2] * 4,
-                                  px, py, xs, xo, ys, yo, &u, &v, &zw)) { u = rastf[pix * 4]; v = rastf[pix * 4 + 1]; zw = rastf[pix * 4 + 2]; }
+                                  px, py, H, W, xs, xo, ys, yo, &u, &v, &zw)) { u = rastf[pix * 4]; v = rastf[pix * 4 + 1]; zw = rastf[pix * 4 + 2]; }
                 o[0] = u; o[1] = v; o[2] = zw; o[3] = (double)(t + 1);
             }
     free(posf); free(rastf);

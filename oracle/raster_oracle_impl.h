@@ -9,6 +9,9 @@
  * This header is included twice by raster_oracle.c: REAL=float (decision-exact twin of the HIP kernels — every
  * operation that feeds a discrete decision is written as one IEEE operation per statement and the file is compiled
  * with -ffp-contract=off) and REAL=double (finite-difference target).
+ * Round 5: in the float instantiation (R5_WIDE) the VALUES of rule R5 — (u, v) of a winner and the gradient of (u, v) with respect to
+ * the clip positions — are evaluated in double from the float positions (raster_oracle.c: r5_uv_wide / r5_bwd_wide), exactly as the
+ * HIP kernels do; every decision (coverage, accept / reject, z/w, depth order) stays float.
  */
 
 #define R_(x) ((REAL)(x))
@@ -52,9 +55,10 @@ static inline int SFX(edge_in)(int64_t ax, int64_t ay, int64_t bx, int64_t by, i
 }
 
 /* rule R5: the fragment (u, v, z/w) of triangle (p0,p1,p2) at pixel (px,py); returns 0 if degenerate */
-static inline int SFX(fragment)(const REAL* p0, const REAL* p1, const REAL* p2, int px, int py,
+static inline int SFX(fragment)(const REAL* p0, const REAL* p1, const REAL* p2, int px, int py, int H, int W,
                                 REAL xs, REAL xo, REAL ys, REAL yo, REAL* u, REAL* v, REAL* zw)
 {
+    (void)H; (void)W;
     REAL fx = xs * (REAL)px; fx = fx + xo;
     REAL fy = ys * (REAL)py; fy = fy + yo;
     REAL t;
@@ -82,6 +86,11 @@ static inline int SFX(fragment)(const REAL* p0, const REAL* p1, const REAL* p2, 
     if (q > R_(1)) q = R_(1);
     q = q + R_(0);                                             /* -0 -> +0 so the depth order is total */
     *u = b0; *v = b1; *zw = q;
+#if R5_WIDE
+    /* the fp32 twin: accept / reject and z/w above are the decisions (bit-identical to the HIP kernels); the barycentrics it returns
+     * are evaluated in double from the same fp32 positions and rounded once (raster_oracle.c: r5_uv_wide) */
+    if (g_r5_wide) r5_uv_wide(p0, p1, p2, px, py, H, W, u, v);
+#endif
     return 1;
 }
 
@@ -127,7 +136,7 @@ void SFX(orc_rasterize_fwd)(const REAL* pos, const int32_t* tri, int n, int V, i
                     if (!SFX(edge_in)(x1, y1, x2, y2, cx, cy)) continue;
                     if (!SFX(edge_in)(x2, y2, x0, y0, cx, cy)) continue;
                     REAL u, v, zw;
-                    if (!SFX(fragment)(vp + i0 * 4, vp + i1 * 4, vp + i2 * 4, (int)px, (int)py, xs, xo, ys, yo, &u, &v, &zw)) continue;
+                    if (!SFX(fragment)(vp + i0 * 4, vp + i1 * 4, vp + i2 * 4, (int)px, (int)py, H, W, xs, xo, ys, yo, &u, &v, &zw)) continue;
                     REAL* o = ro + ((size_t)py * W + px) * 4;
                     /* nearest z/w wins; ties keep the lower triangle index (we iterate f ascending) */
                     if (o[3] == R_(0) || zw < o[2]) { o[0] = u; o[1] = v; o[2] = zw; o[3] = (REAL)(f + 1); }
@@ -156,6 +165,19 @@ void SFX(orc_rasterize_bwd)(const REAL* pos, const int32_t* tri, const REAL* ras
                 const REAL* p0 = pos + ((size_t)b * V + i0) * 4;
                 const REAL* p1 = pos + ((size_t)b * V + i1) * 4;
                 const REAL* p2 = pos + ((size_t)b * V + i2) * 4;
+                REAL* q0 = gpos + ((size_t)b * V + i0) * 4;
+                REAL* q1 = gpos + ((size_t)b * V + i1) * 4;
+                REAL* q2 = gpos + ((size_t)b * V + i2) * 4;
+#if R5_WIDE
+                if (g_r5_wide) {                                 /* the fp32 twin: this gradient in double, rounded at the accumulation */
+                    double g[9];
+                    r5_bwd_wide(p0, p1, p2, px, py, H, W, (double)du, (double)dv, g);
+                    q0[0] += (REAL)g[0]; q0[1] += (REAL)g[1]; q0[3] += (REAL)g[2];
+                    q1[0] += (REAL)g[3]; q1[1] += (REAL)g[4]; q1[3] += (REAL)g[5];
+                    q2[0] += (REAL)g[6]; q2[1] += (REAL)g[7]; q2[3] += (REAL)g[8];
+                    continue;
+                }
+#endif
                 REAL fx = xs * (REAL)px + xo, fy = ys * (REAL)py + yo;
                 REAL p0x = p0[0] - fx * p0[3], p0y = p0[1] - fy * p0[3];
                 REAL p1x = p1[0] - fx * p1[3], p1y = p1[1] - fy * p1[3];
@@ -171,9 +193,6 @@ void SFX(orc_rasterize_bwd)(const REAL* pos, const int32_t* tri, const REAL* ras
                 REAL g0y = gbb * (p1x - p2x) + gb1 * p2x;
                 REAL g1y = gbb * (p2x - p0x) - gb0 * p2x;
                 REAL g2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
-                REAL* q0 = gpos + ((size_t)b * V + i0) * 4;
-                REAL* q1 = gpos + ((size_t)b * V + i1) * 4;
-                REAL* q2 = gpos + ((size_t)b * V + i2) * 4;
                 q0[0] += g0x; q0[1] += g0y; q0[3] += -fx * g0x - fy * g0y;
                 q1[0] += g1x; q1[1] += g1y; q1[3] += -fx * g1x - fy * g1y;
                 q2[0] += g2x; q2[1] += g2y; q2[3] += -fx * g2x - fy * g2y;

@@ -89,3 +89,45 @@ def test_loop_body_decisions_are_taken_from_the_fp32_run(oracle):
         torch.equal(o32["decisions"]["l1_sign"].double(), o0["decisions"]["l1_sign"])
     if same and torch.equal(o3["rast"][..., 3], o0["rast"][..., 3]):
         assert rel_err(gd3, gd0) < 1e-9
+
+
+def test_rule_r5_values_in_double_keep_the_decisions_and_meet_the_bar(oracle):
+    """Round 5 (rule R5): the fp32 twin evaluates the VALUES of rule R5 — the barycentrics a winner returns and their
+    gradient with respect to the clip positions — in double from the fp32 clip positions, its DECISIONS (coverage, accept / reject, z/w,
+    depth order) in fp32 as before.  On a micro-triangle scene at a capture-like clip scale: ids and z/w are the same bits under both
+    rules, (u, v) agree with exact arithmetic to half an fp32 ulp instead of ~1e-4, and the twin's gradients — beyond the north_star's
+    1e-4 with the all-fp32 rule — meet it."""
+    lib = oracle.lib()
+    sc = prepare(oracle, (2, 192, 192, 64, 96), 2)
+    # clip-space scale of the reference capture's cameras: |x| ~ 2 where the synthetic scenes have ~0.3 (an off-centre principal point)
+    sc["proj"] = sc["proj"].clone()
+    sc["proj"][:, :, 0] += 0.6 * sc["proj"][:, :, 3]
+    pos32 = oracle.clip_positions(sc["vertices"] + sc["delta"], sc["w2c"], sc["proj"])[1].contiguous()
+
+    def grads(dtype, decisions=None):
+        c = lambda t: t.to(dtype)
+        d = c(sc["delta"]).clone().requires_grad_(True)
+        a = c(sc["albedo"])[None].clone().requires_grad_(True)
+        ref = oracle.ham_stage2_losses(c(sc["vertices"]), d, a, c(sc["sh0"]), c(sc["w2c"]), c(sc["proj"]), c(sc["img"]), c(sc["mask"]),
+                                       c(sc["valid_mask"]), sc["faces"], (sc["H"], sc["W"]), sc["weights"], sc["elm"], pos_value=pos32,
+                                       decisions=decisions)
+        ref["loss"].backward()
+        return ref, d.grad, a.grad[0]
+
+    res = {}
+    try:
+        for wide in (0, 1):
+            lib.orc_set_r5_wide(wide)
+            r32, gd32, ga32 = grads(torch.float32)
+            with oracle.f32_decisions():
+                r64, gd64, ga64 = grads(torch.float64, r32["decisions"])
+            res[wide] = dict(rast=r32["rast"], uv=float((r32["rast"][..., :2].double() - r64["rast"][..., :2]).abs().max()),
+                             e_d=rel_err(gd32, gd64), e_a=rel_err(ga32, ga64))
+    finally:
+        lib.orc_set_r5_wide(1)
+    assert lib.orc_get_r5_wide() == 1                                   # the rule in force
+    assert torch.equal(res[0]["rast"][..., 2:], res[1]["rast"][..., 2:])  # decisions: the same bits
+    assert float((res[1]["rast"][..., 3] > 0).float().mean()) > 0.05
+    assert res[1]["uv"] <= 6e-8 < res[0]["uv"], (res[0]["uv"], res[1]["uv"])
+    assert res[1]["e_d"] < 2e-5 and res[1]["e_a"] < 2e-5, res[1]
+    assert res[0]["e_d"] > 5 * res[1]["e_d"], (res[0]["e_d"], res[1]["e_d"])
