@@ -1160,3 +1160,95 @@ def test_segment_state_words_follow_moving_coverage(oracle, monkeypatch):
     same(flat, run(make(), shifted(0.66)), "atomic-key form on the binned workspace")
     for dx in (5.0, -0.66, 0.0):                                        # ... and the bins again: every segment word counts as live
         same(run(hs, shifted(dx)), run(make(), shifted(dx)), ("after the atomic-key step", dx))
+
+
+def test_two_frames_on_two_streams_equal_their_sequential_results():
+    """BASELINE.json configs[4] / conf/ih_sfsseq.conf:10-12,29 in the form bench.py --config C5 runs it: the frames
+    of a two-hand sequence are independent (delta, albedo) problems on the shared topology, each with its own HamStage2 workspace, and a
+    rank's local frames run CONCURRENTLY on side streams forked from / joined to the current stream every step.  Two frames of the
+    two-hand mesh at W = 334 (row pitch 384, binned rasterizer), six dependent fused-Adam steps each: once one after the other on the
+    current stream, once on two HIP streams — `rast` of the last step bit-identical, losses and parameters equal up to the float-atomic
+    summation order, and frame A's results are not frame B's (the two workspaces do not leak into each other).  The per-launch-group
+    timing hook (thread-local state of the library) is attached during the concurrent steps, as bench.py does."""
+    from fmhr_amd import _lib, synthetic as S
+    from fmhr_amd.ham import HamStage2, edge_length_mean, render_forward
+    from fmhr_amd.optim import Adam
+    dev = torch.device("cuda:0")
+    n, H, W = 4, 256, 334
+    sc = S.make_scene(n, H, W, "mano", 0, 2, seed=5, hands=2)
+    V = sc["V"]
+    faces = sc["faces"].to(dev)
+    w2c, proj, sh = sc["w2c"].to(dev).contiguous(), sc["proj"].to(dev).contiguous(), sc["sh0"].to(dev).contiguous()
+    vt = sc["vertices"].to(dev).contiguous()
+    elm = edge_length_mean(vt, faces)
+    fwd = lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, H, W)
+    targets = []
+    for frame in range(2):                                   # another frame: its own target geometry, same cameras / topology (bench.py: Problem)
+        scf = dict(sc)
+        if frame:
+            scf["vertices_true"] = sc["vertices"] + 0.0005 * torch.randn(sc["vertices"].shape, generator=torch.Generator().manual_seed(1000 + frame))
+        targets.append(S.make_targets(scf, fwd, device=dev))
+
+    class Problem:
+        def __init__(self, frame):
+            self.tg = targets[frame]
+            self.hs = HamStage2(faces, V, n, H, W, sc["weights"], elm)
+            self.delta = torch.zeros(V, 3, device=dev, requires_grad=True)
+            self.albedo = sc["albedo0"][None].to(dev).clone().requires_grad_(True)
+            self.opt = Adam([{'params': self.delta, 'lr': sc["lr"]["lr"]}, {'params': self.albedo, 'lr': sc["lr"]["albedo_lr"]}])
+
+        def step(self):
+            return self.hs.step(vt, self.delta.detach(), self.albedo.detach()[0], sh, w2c, proj, self.tg["img"], self.tg["mask"],
+                                self.tg["valid_mask"], optimizer=self.opt, params=(self.delta, self.albedo))[0]
+
+        def result(self):
+            return dict(losses=self.hs.losses.clone(), delta=self.delta.detach().clone(), albedo=self.albedo.detach().clone(),
+                        rast=self.hs.views()["rast"].clone(), gd=self.hs.gdelta.clone())
+
+    steps = 6
+    seq = [Problem(0), Problem(1)]
+    assert seq[0].hs.pitch == 384 and binned_form(seq[0].hs)
+    for _ in range(steps):
+        for p in seq:
+            p.step()
+    torch.cuda.synchronize()
+    ref = [p.result() for p in seq]
+    for p in seq:
+        p.hs.check_overflow()
+    # the concurrent form: bench.py:360-374
+    con = [Problem(0), Problem(1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    import ctypes
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(26)]
+    for e in evs:
+        e.record()
+    arr = (ctypes.c_void_p * 26)(*[e.cuda_event for e in evs])
+    for it in range(steps):
+        cur = torch.cuda.current_stream()
+        for s in streams:
+            s.wait_stream(cur)
+        if it == steps - 2:
+            _lib.call("fmhr_timing_attach", arr, 26, -1)     # the library's thread-local timing sink while two streams are in flight
+        for i, p in enumerate(con):
+            with torch.cuda.stream(streams[i]):
+                p.step()
+        if it == steps - 2:
+            _lib.call("fmhr_timing_detach")
+        for s in streams:
+            cur.wait_stream(s)
+    torch.cuda.synchronize()
+    got = [p.result() for p in con]
+    for p in con:
+        p.hs.check_overflow()
+    errs = []
+    for f in range(2):
+        assert torch.equal(got[f]["rast"], ref[f]["rast"]), f        # six dependent steps later: the same triangles at the same depths
+        assert float(got[f]["losses"][7]) == float(ref[f]["losses"][7]) and float(ref[f]["losses"][7]) > 1000
+        e = (rel_err(got[f]["losses"][:7], ref[f]["losses"][:7]), rel_err(got[f]["delta"], ref[f]["delta"]),
+             rel_err(got[f]["albedo"], ref[f]["albedo"]), rel_err(got[f]["gd"], ref[f]["gd"]))
+        errs.append(e)
+        assert e[0] < 1e-5 and e[1] < 1e-4 and e[2] < 1e-5 and e[3] < 1e-4, (f, e)
+    # the frames are different problems: nothing of one may show up in the other
+    assert rel_err(got[0]["delta"], got[1]["delta"]) > 1e-2 and not torch.equal(got[0]["rast"], got[1]["rast"])
+    log_parity("two frames of the two-hand mesh (V = %d, %d x %dx%d, pitch 384, binned) on two HIP streams vs one after the other, %d fused-Adam "
+               "steps: rast bit-identical, losses / delta / albedo / gdelta rel %s | %s" % (V, n, H, W, steps, ["%.1e" % x for x in errs[0]], ["%.1e" % x for x in errs[1]]))

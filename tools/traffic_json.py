@@ -14,9 +14,12 @@ SLOT_KERNELS = {
 src = sys.argv[1]
 rows = {}
 for line in open(src):
-    m = re.match(r"^(\S.*?)\s+(\d+)\s+(\d+)\s+(\d+)\s*$", line)
+    # round 5 table: kernel, launches (FETCH pass), launches (WRITE pass), launches per step, FETCH_KB, WRITE_KB; rounds 1-4: kernel,
+    # launches, FETCH_KB, WRITE_KB (one launch per step for every kernel of the step)
+    m = re.match(r"^(\S.*?)\s+(\d+)(?:\s+(\d+)\s+([\d.]+))?\s+(\d+)\s+(\d+)\s*$", line)
     if m:
-        rows[m.group(1)] = (float(m.group(3)), float(m.group(4)))
+        per = max(1.0, round(float(m.group(4)))) if m.group(4) else 1.0
+        rows[m.group(1)] = (float(m.group(5)) * per, float(m.group(6)) * per)
 out = {"_source": f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, metric config, 1 GPU)",
        "_note": "HBM bytes per launch = (FETCH_SIZE * 2 + WRITE_SIZE) * 1024: gfx950 counts 64 B per 128-B request on coalesced streams, "
                 "so this is the upper estimate; the lower one (FETCH_SIZE * 1) is step_total_low"}
