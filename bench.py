@@ -253,6 +253,76 @@ def caller_numbering_side_measurement(scene_c, dev, stream, steps=100, preroll=1
             "ms_per_step": round(ms, 4), "iterations_per_s": round(1e3 / ms, 1)}
 
 
+def run_ham_stage2_side_measurement(scene_c, batch, dev, stream, epochs_timed, preroll_steps=192, label=""):
+    """Not the headline metric: the stage-2 loop THE PRODUCT RUNS (fmhr_amd.pipeline.Stage2Loop, what run_ham drives) — per epoch a fresh
+    permutation of the capture's views (mesh_sfs_optim.py:249), per batch one fused step on perm[k:k+batch] with the capture's tensors
+    resident and the views selected INSIDE the step (ABI 6: no per-batch gathers), fused Adam, overflow flags read every 16 epochs — by
+    HIP events, next to the bare step on fixed tensors of the same batch size by the same clock (within 3 %)."""
+    from fmhr_amd.optim import Adam
+    from fmhr_amd.pipeline import Stage2Loop
+    num, H, W, V = scene_c["views"], scene_c["H"], scene_c["W"], scene_c["V"]
+    order = VertexOrder(scene_c["faces"], V)                       # as run_ham: the optimisation runs on the first-touch renumbering
+    sc = dict(scene_c)
+    for k in ("vertices", "vertices_true", "albedo_true", "albedo0"):
+        sc[k] = order.to_internal(sc[k])
+    sc["faces"] = order.faces
+    faces = sc["faces"].to(dev)
+    w2c, proj, sh = sc["w2c"].to(dev).contiguous(), sc["proj"].to(dev).contiguous(), sc["sh0"].to(dev).contiguous()
+    vt = sc["vertices"].to(dev).contiguous()
+    tg = synthetic.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, H, W), device=dev)
+    elm = edge_length_mean(vt, faces)
+    lr = sc["lr"]
+
+    def fresh():
+        delta = torch.zeros(V, 3, device=dev, requires_grad=True)
+        albedo = sc["albedo0"][None].to(dev).clone().requires_grad_(True)
+        return delta, albedo, Adam([{'params': delta, 'lr': lr["lr"]}, {'params': albedo, 'lr': lr["albedo_lr"]}])
+
+    def timed(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    steps_per_epoch = -(-num // batch)
+    # the loop ...
+    delta, albedo, opt = fresh()
+    loop = Stage2Loop(vt, faces, delta, albedo, sh, tg["img"], tg["mask"], tg["valid_mask"], w2c, proj, (H, W), sc["weights"], elm, opt, batch,
+                      1 << 30, torch.Generator(device="cpu").manual_seed(0))
+    for _ in range(-(-preroll_steps // steps_per_epoch)):
+        loop.run_epoch()
+    # ... and the bare step: the first `batch` views, gathered ONCE, fixed tensors (what `value` times at the metric config)
+    delta_b, albedo_b, opt_b = fresh()
+    n = min(batch, num)
+    hs = HamStage2(faces, V, n, H, W, sc["weights"], elm)
+    fixed = tuple(t[:n].contiguous() for t in (sh, w2c, proj, tg["img"], tg["mask"], tg["valid_mask"]))
+
+    def bare():
+        hs.step(vt, delta_b.detach(), albedo_b.detach()[0], *fixed, optimizer=opt_b, params=(delta_b, albedo_b))
+    for _ in range(preroll_steps):
+        bare()
+    # four alternating blocks of each, by the same clock (the boxes of the pool drift by a per cent or two within a second)
+    blocks, per = 4, max(1, epochs_timed // 4)
+    tl = tb = 0.0
+    for _ in range(blocks):
+        tl += timed(loop.run_epoch, per)
+        tb += timed(bare, per * steps_per_epoch)
+    its = blocks * per * steps_per_epoch
+    loop_ms, bare_ms = tl / its, tb / its
+    loop.check()
+    hs.check_overflow()
+    aa_loop = int(loop.hs.aa_item_count())
+    epochs_timed = blocks * per
+    return {"what": f"{label}: {batch} of {num} views x {H}x{W}, V={V}: ms per ITERATION of the product's stage-2 loop (Stage2Loop = run_ham: fresh "
+                    "permutation per epoch, views selected inside the step, fused Adam) | the bare step on fixed tensors of the same batch, same clock",
+            "loop_ms_per_iteration": round(loop_ms, 4), "bare_step_ms": round(bare_ms, 4), "loop_over_bare": round(loop_ms / bare_ms, 4),
+            "iterations_timed": epochs_timed * steps_per_epoch, "aa_items_last_step": aa_loop}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +335,7 @@ def main():
     ap.add_argument("--no-run-length", action="store_true", help="skip the reference-length side measurement (N = 1 only)")
     ap.add_argument("--run-length", type=int, default=600, help="steps of the reference-length side measurement: the demo run is 300 "
                     "epochs x 2 batches of stage 2 (conf/demo_sfs.conf:9,24; mesh_sfs_optim.py:247-252)")
+    ap.add_argument("--no-run-ham", action="store_true", help="skip the run_ham stage-2 loop side measurement (N = 1 only)")
     ap.add_argument("--cpu-views", type=int, default=48)   # the whole 48-view batch: 5 x ~2.6 s of CPU work, nothing extrapolated
     ap.add_argument("--preroll", type=int, default=320, help="upper bound of the untimed pre-roll (stops earlier once the antialias "
                     "work list is stationary; at least 128 steps; 0 = none)")
@@ -584,6 +655,16 @@ def main():
                                            "first_touch (the timed workload)": {k: v for k, v in caller_numbering_side_measurement(scene, dev, stream).items() if k != "what"}}
             except Exception as e:  # noqa: BLE001
                 out["vertex_numbering"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and nf_local == 1 and not args.no_run_ham and not args.no_run_length:     # (--no-run-length: the lean form the A/B and profile scripts use)
+            try:                                        # the loop the product runs, at the metric batch and at the reference's demo batch
+                rh = {"metric": run_ham_stage2_side_measurement(scene_caller, n_total, dev, stream, 100, label=args.config)}
+                if args.config == "metric":
+                    demo = synthetic.make_scene(16, 1024, 1280, "mano", 0, 3, seed=args.seed, hands=2)
+                    rh["demo_conf"] = run_ham_stage2_side_measurement(demo, 8, dev, stream, 30, preroll_steps=96,
+                                                                      label="conf/demo_sfs.conf:5-7,24 (num 16, batch 8, 1280x1024, two hands)")
+                out["run_ham_stage2"] = rh
+            except Exception as e:  # noqa: BLE001
+                out["run_ham_stage2"] = {"error": f"{type(e).__name__}: {e}"}
         # the two side measurements must never cost the headline line: a failure is reported in their place
         if world == 1 and not args.no_stage1:
             try:

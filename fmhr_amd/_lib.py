@@ -14,7 +14,7 @@ c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size
 class HamDims(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("V", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("W", ctypes.c_int32), ("nnz", ctypes.c_int32), ("aa_cap", ctypes.c_int32), ("bin_cap", ctypes.c_int32),
-                ("pitch", ctypes.c_int32)]
+                ("pitch", ctypes.c_int32), ("n_src", ctypes.c_int32)]
 
 
 class HamWeights(ctypes.Structure):
@@ -73,10 +73,10 @@ SIGNATURES = {
     "fmhr_ham_pitch": (c_int, [ctypes.POINTER(HamDims)]),
     "fmhr_ham_workspace_offset": (ctypes.c_longlong, [ctypes.POINTER(HamDims), ctypes.c_char_p]),
     "fmhr_ham_workspace_views": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, ctypes.POINTER(HamViews)]),
-    "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),
+    "fmhr_ham_forward": (c_int, [ctypes.POINTER(HamDims), P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, c_size_t, P]),
     "fmhr_ham_workspace_init": (c_int, [ctypes.POINTER(HamDims), P, c_size_t, P]),
     "fmhr_ham_densify": (c_int, [ctypes.POINTER(HamDims), P, P, P, c_size_t, P]),
-    "fmhr_ham_backward": (c_int, [ctypes.POINTER(HamDims), ctypes.POINTER(HamWeights), P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+    "fmhr_ham_backward": (c_int, [ctypes.POINTER(HamDims), ctypes.POINTER(HamWeights), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                   P, P, P, P, P, P, P, P, P, ctypes.POINTER(AdamParam), ctypes.POINTER(AdamParam), P, c_size_t, P]),
     "fmhr_ham_combine": (c_int, [c_int, P, ctypes.POINTER(AdamParam), ctypes.POINTER(AdamParam), P]),
     "fmhr_edge_multiplicity_build": (c_int, [P, c_int, c_int, P, P, c_int, P, P]),
@@ -111,7 +111,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.fmhr_abi_version() != 5:
+        if lib.fmhr_abi_version() != 6:
             raise RuntimeError("fmhr_amd: ABI version mismatch")
         _lib = lib
     return _lib

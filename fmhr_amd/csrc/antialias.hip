@@ -985,6 +985,7 @@ FMHR_WTS_DEFINE(aab)
 struct LossGrad {
     const float4* aa; const float* img; const float* mask; const float* valid_mask; const unsigned long long* covw;
     const float* n_valid; float w_sfs, w_mask, mse_den;
+    const int32_t* view_idx;                                       // ABI 6: img / mask / valid_mask hold the capture's views, view b of the step = view_idx[b] of them (null: the same)
 };
 
 __global__ void __launch_bounds__(kBlock)
@@ -1029,7 +1030,8 @@ k_aa_bwd_items(const float4* __restrict__ dcols, const float4* __restrict__ rast
         const int dn = (it.w & AA_DOWN) ? 1 : 0;
         const long long pix0 = ((long long)it.z * H + it.y) * Wp + it.x;
         const long long tgt = (alpha > 0.f) ? pix0 : pix0 + (dn ? Wp : 1);
-        const long long ctgt = ((long long)it.z * H + it.y + ((alpha > 0.f) ? 0 : dn)) * W + it.x + ((alpha > 0.f) ? 0 : 1 - dn);
+        const int cview = (L.view_idx != nullptr) ? L.view_idx[it.z] : it.z;       // the view in the caller's arrays (a 4-B gather from a table of n entries)
+        const long long ctgt = ((long long)cview * H + it.y + ((alpha > 0.f) ? 0 : dn)) * W + it.x + ((alpha > 0.f) ? 0 : 1 - dn);
         const float4 a = L.aa[tgt];
         const F3U im = *reinterpret_cast<const F3U*>(L.img + ctgt * 3);
         const float mk = L.mask[ctgt], vm = L.valid_mask[ctgt];
@@ -1131,9 +1133,10 @@ int aa_fwd_rgba(const float* attr8, const float* sh, float* dcols, const float* 
 int aa_bwd_rgba(const float* dcols, const float* rast, const float* pos, const float* verts, const int32_t* tri, const float* aa, const float* img,
                 const float* mask, const float* valid_mask, const unsigned long long* covw, const float* n_valid, float w_sfs,
                 float w_mask, float mse_den, const int32_t* items, const float* alphas, const int32_t* region_cnt, int cap, int n, int V,
-                int H, int W, int Wp, float* gcolor, const float* cmat, float* gvert, float* gvert2, hipStream_t st)
+                int H, int W, int Wp, float* gcolor, const float* cmat, float* gvert, float* gvert2, const int32_t* view_idx, hipStream_t st)
 {
     LossGrad L;
+    L.view_idx = view_idx;
     L.aa = (const float4*)aa; L.img = img; L.mask = mask; L.valid_mask = valid_mask; L.covw = covw; L.n_valid = n_valid;
     L.w_sfs = w_sfs; L.w_mask = w_mask; L.mse_den = mse_den;
     k_aa_bwd_items<<<aa_grid(aa_row_aligned(n, H, Wp)), kBlock, 0, st>>>(      // the forward's grid: one workgroup per region

@@ -361,6 +361,31 @@ __device__ __forceinline__ long long caller_index(unsigned seg, int lane, int W,
     return (long long)row * W + (int)col0 + lane;
 }
 
+// ---- view selection (ABI 6).  A step may render a SUBSET of the capture's views — the minibatch perm[k:k+batch] of
+// /root/reference/mesh_sfs_optim.py:249,255-260 — while the caller's per-view arrays (img, mask, valid_mask [n_src,H,W(,3)]; sh, w2c, proj)
+// hold the whole capture: view b of the step is view idx[b] of those arrays.  Nothing is gathered: the four kernels that read the big
+// arrays turn their segment into the SOURCE view's row with two scalar magic divisions and one scalar load (a segment lies in one row of
+// one view: H * pitch % 64 == 0 is required), the geometry kernel reads the small per-view rows through idx once and leaves them in the
+// workspace in the step's own order.  idx == nullptr: the arrays hold exactly the step's n views (the ABI-5 meaning).
+typedef const int __attribute__((address_space(4))) const_as4_i32;
+struct ViewSel {
+    const int32_t* idx;       // device int32 [n] or null
+    UDiv segv;                // division by the segments per view (H * pitch / 64)
+    int H;
+    __device__ __forceinline__ int src(unsigned b) const             // wave-uniform b: through the scalar cache (the caller's array is constant during a step)
+    {
+        return *(const_as4_i32*)(unsigned long long)(idx + b);
+    }
+};
+// caller_index through a view selection (sel.idx != nullptr): seg wave-uniform, Wp % 64 == 0
+__device__ __forceinline__ long long caller_index_sel(unsigned seg, int lane, int W, const UDiv& segx, const ViewSel& sel, bool& incol)
+{
+    const unsigned row = udiv(seg, segx), col0 = (seg - row * segx.d) << 6;          // row = b * H + py of the step's numbering
+    const unsigned b = udiv(seg, sel.segv);
+    incol = (int)col0 + lane < W;
+    return ((long long)row + (long long)(sel.src(b) - (int)b) * sel.H) * W + (int)col0 + lane;
+}
+
 // one clip coordinate of a vertex under one column (c0..c3) of the combined matrix w2c @ proj: the geometry kernel and the
 // face-parallel backward both go through this explicit chain, so their positions agree bit for bit whatever the compiler contracts
 __device__ __forceinline__ float clip_coord(float x, float y, float z, float c0, float c1, float c2, float c3)

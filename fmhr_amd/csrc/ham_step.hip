@@ -40,7 +40,7 @@ int rasterize_fwd_impl(const float*, const int2*, const int32_t*, const int32_t*
                        void*, unsigned char*, unsigned long long*, const RasterFused*, hipStream_t);
 int valid_mask_segments_impl(const float*, int, int, int, int, unsigned char*, hipStream_t);
 int active_segments_impl(const unsigned long long*, const unsigned char*, long long, int, unsigned char*, int*, int*, const int*,
-                         float*, float*, hipStream_t);
+                         float*, float*, const ViewSel, hipStream_t);
 int reshade_dense_impl(const unsigned long long*, const float*, const int32_t*, const float*, const float*, int, int, int, float*, hipStream_t);
 int active_segments_blocks(long long N);
 int densify_impl(const unsigned long long*, const unsigned char*, long long, const float*, float*, float*, hipStream_t);
@@ -49,11 +49,11 @@ int aa_fwd_rgba(const float*, const float*, float*, const float*, const float*, 
                 const float*, int, int*, float*, hipStream_t);
 int aa_bwd_rgba(const float*, const float*, const float*, const float*, const int32_t*, const float*, const float*, const float*, const float*,
                 const unsigned long long*, const float*, float, float, float, const int32_t*, const float*, const int32_t*, int, int, int,
-                int, int, int, float*, const float*, float*, float*, hipStream_t);
+                int, int, int, float*, const float*, float*, float*, const int32_t*, hipStream_t);
 int clip_positions_impl(const float*, const float*, int, int, float*, hipStream_t);
 int geometry_impl(const float*, const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, const int32_t*,
-                  const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, int*, hipStream_t);
-int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, int, int, const int*, const int*,
+                  const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, int*, const int32_t*, const float*, float*, hipStream_t);
+int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, int, int, const ViewSel, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
                   const int*, const int32_t*, const float*, const float*, int, int, int, int, int, int, float*,
@@ -63,7 +63,7 @@ int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
+    size_t vertices, nsum, normals, attr8, sh_local, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
         g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, bin_state, total;
 };
 
@@ -87,6 +87,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.nsum = take(off, V * 12);
     L.normals = take(off, V * 12);
     L.attr8 = take(off, V * 32);
+    L.sh_local = take(off, (size_t)d->n * 36);      // the step's n SH rows in the step's own order (ABI 6: the caller's may be the capture's, selected by view_idx)
     L.pos = take(off, nV * 16);
     L.snap = take(off, nV * 8);
     L.silh = take(off, (size_t)d->n * d->F);
@@ -94,7 +95,8 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.dirty = take(off, (nP + 63) / 64);
     L.covw = take(off, ((nP + 63) / 64) * 8);
     L.act = take(off, (nP + 63) / 64);
-    L.vmnz = take(off, (nP + 63) / 64);
+    // valid_mask flags per segment: of the step's n views, or (ABI 6, n_src > 0) of all the capture's views — built once, not per batch
+    L.vmnz = take(off, (((size_t)(d->n_src > d->n ? d->n_src : d->n) * d->H * Wp) + 63) / 64);
     L.act_list = take(off, ((nP + 63) / 64) * 4);
     L.act_count = take(off, 16);
     L.cov16 = take(off, (size_t)d->n * d->F * 8);  // coverage entries [n, F]: candidate-pixel mask | box origin and width (raster.hip)
@@ -152,8 +154,22 @@ static int check_dims(const fmhr_ham_dims* d)
     FMHR_CHECK_ARG(d->pitch == 0 || d->pitch == d->W || (d->pitch > d->W && d->pitch % 64 == 0 && d->pitch <= 8192),
                    "ham: pitch must be 0 (default: W rounded up to a multiple of 64), W, or a multiple of 64 above W; got %d (W=%d)", d->pitch, d->W);
     const int Wp = eff_pitch(d);
+    FMHR_CHECK_ARG(d->n_src >= 0 && d->n_src <= 65535, "ham: n_src must be 0 (the arrays hold the step's views) or the number of views of the capture, got %d", d->n_src);
+    FMHR_CHECK_ARG(d->n_src == 0 || ((long long)d->H * Wp) % 64 == 0,
+                   "ham: a view selection (n_src > 0) needs H * pitch to be a multiple of 64 (every 64-pixel segment inside one view); H=%d pitch=%d", d->H, Wp);
     FMHR_CHECK_ARG(((long long)d->n * d->H * Wp) % 4 == 0, "ham: n*H*pitch must be a multiple of 4");
     FMHR_CHECK_ARG(d->n <= 65535 && ((long long)d->n * d->H * Wp) < (1ll << 30), "ham: n <= 65535 and n*H*pitch < 2^30 required (32-bit channel offsets in k_aa_bwd_items)");
+    return FMHR_OK;
+}
+
+// the view selection of a call (ABI 6): view_idx goes with dims.n_src > 0
+static int view_sel_from(const fmhr_ham_dims* d, const int32_t* view_idx, const char* who, ViewSel& sel)
+{
+    FMHR_CHECK_ARG((view_idx != nullptr) == (d->n_src > 0), "%s: view_idx must be given exactly when dims.n_src > 0 (n_src=%d, view_idx %s)", who,
+                   d->n_src, view_idx ? "given" : "null");
+    sel.idx = view_idx;
+    sel.segv = make_udiv((unsigned)(((long long)d->H * eff_pitch(d) + 63) / 64));
+    sel.H = d->H;
     return FMHR_OK;
 }
 
@@ -195,7 +211,7 @@ extern "C" long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const cha
     if (check_dims(d) || name == nullptr) return -1;
     Layout L = make_layout(d);
 #define FMHR_OFF(x) if (!strcmp(name, #x)) return (long long)L.x
-    FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
+    FMHR_OFF(vertices); FMHR_OFF(nsum); FMHR_OFF(normals); FMHR_OFF(sh_local); FMHR_OFF(pos); FMHR_OFF(snap); FMHR_OFF(silh); FMHR_OFF(raster_ws);
     FMHR_OFF(dirty); FMHR_OFF(covw); FMHR_OFF(act); FMHR_OFF(cov16); FMHR_OFF(own8); FMHR_OFF(stamp); FMHR_OFF(pix16); FMHR_OFF(rast); FMHR_OFF(shaded); FMHR_OFF(aa);
     FMHR_OFF(aa_items); FMHR_OFF(aa_alphas); FMHR_OFF(aa_counter); FMHR_OFF(aa_region_cnt); FMHR_OFF(g_shaded); FMHR_OFF(cmat); FMHR_OFF(gvert_aa); FMHR_OFF(vacc); FMHR_OFF(part);
     FMHR_OFF(gnormal); FMHR_OFF(gvert); FMHR_OFF(n_valid_f); FMHR_OFF(silw); FMHR_OFF(bins); FMHR_OFF(bin_cursor); FMHR_OFF(bin_state); FMHR_OFF(total);
@@ -252,13 +268,14 @@ extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, const int32_t* tri, cons
 {
     TRY(check_dims(d));
     Layout L = make_layout(d);
-    FMHR_CHECK_ARG(ws && ws_bytes >= L.total && tri && sh, "ham_densify: workspace too small or null pointer");
+    FMHR_CHECK_ARG(ws && ws_bytes >= L.total && tri, "ham_densify: workspace too small or null pointer");
     char* w = (char*)ws;
     hipStream_t st = (hipStream_t)stream;
     // the step stores neither clip positions nor a shaded image: both views are produced here, bit-identical to what the
     // kernels computed on the fly (same FMA chains / same shading statements)
     TRY(clip_positions_impl((const float*)(w + L.vertices), (const float*)(w + L.cmat), d->n, d->V, (float*)(w + L.pos), st));
-    TRY(reshade_dense_impl((const unsigned long long*)(w + L.covw), (const float*)(w + L.pix16), tri, (const float*)(w + L.attr8), sh, d->n,
+    (void)sh;                                                        // (ABI 6: the step's SH rows are in the workspace, in the step's order)
+    TRY(reshade_dense_impl((const unsigned long long*)(w + L.covw), (const float*)(w + L.pix16), tri, (const float*)(w + L.attr8), (const float*)(w + L.sh_local), d->n,
                            d->H, eff_pitch(d), (float*)(w + L.shaded), st));
     return densify_impl((const unsigned long long*)(w + L.covw), (const unsigned char*)(w + L.act), (long long)d->n * d->H * eff_pitch(d),
                         (const float*)(w + L.pix16), (float*)(w + L.rast), (float*)(w + L.aa), st);
@@ -266,11 +283,13 @@ extern "C" int fmhr_ham_densify(const fmhr_ham_dims* d, const int32_t* tri, cons
 
 extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
                                 const float* sh, const float* w2c, const float* proj, const float* mask,
-                                const float* valid_mask, const int32_t* tri, const int32_t* opp, const int32_t* vf_ptr,
+                                const float* valid_mask, const int32_t* view_idx, const int32_t* tri, const int32_t* opp, const int32_t* vf_ptr,
                                 const int32_t* vf_idx, int valid_mask_changed, int32_t* n_valid_local, void* ws,
                                 size_t ws_bytes, void* stream)
 {
     TRY(check_dims(d));
+    ViewSel sel;
+    TRY(view_sel_from(d, view_idx, "ham_forward", sel));
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_forward: workspace too small (%zu < %zu)", ws_bytes, L.total);
     FMHR_CHECK_ARG(vertices_tmp && delta && albedo && sh && w2c && proj && mask && valid_mask && tri && opp && vf_ptr && vf_idx &&
@@ -289,7 +308,8 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         // on the fly by both parts and stored for everything after them
         TRY(geometry_impl(vertices_tmp, delta, w2c, proj, d->n, d->V, nullptr, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), tri,
                           vf_ptr, vf_idx, (float*)(w + L.nsum), (float*)(w + L.normals), albedo, (float*)(w + L.attr8), vertices,
-                          (int*)(w + L.stamp), st));
+                          (int*)(w + L.stamp), view_idx, sh, (float*)(w + L.sh_local), st));
+        sh = (const float*)(w + L.sh_local);                         // from here on: the step's n rows, in the step's order
     }
     {
         // rasterize; the resolve pass also shades the covered pixels, leaves the per-pixel backward word, marks the owning
@@ -304,6 +324,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.rearm2 = (int*)(w + L.act_count); fu.rearm_aa = (int*)(w + L.aa_counter);
         fu.bins = nullptr; fu.bin_cursor = nullptr; fu.bin_flag = nullptr; fu.bin_cap = 0;
         fu.segx = make_udiv((unsigned)((Wp + 63) / 64));            // used when Wp != d->W: segment -> row of the caller's [n,H,W] mask
+        fu.sel = sel;
         if (raster_binned_ok(d->F, d->H, d->W, Wp)) {
             fu.bins = (BinEntry*)(w + L.bins); fu.bin_cursor = (int*)(w + L.bin_cursor); fu.bin_cap = bin_cap_entries(d->bin_cap);
             fu.bin_flag = (int*)(w + L.aa_counter) + 2;             // sticky overflow flag next to the antialias list's (read by the host)
@@ -313,10 +334,11 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
     }
     {
         ProfScope ps(FMHR_SLOT_SHADE_FWD, st);
-        if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, d->n, d->H, d->W, Wp, (unsigned char*)(w + L.vmnz), st));
+        // (with a view selection the flags are those of ALL the capture's views, addressed through it: built once for every batch)
+        if (valid_mask_changed) TRY(valid_mask_segments_impl(valid_mask, d->n_src > 0 ? d->n_src : d->n, d->H, d->W, Wp, (unsigned char*)(w + L.vmnz), st));
         TRY(active_segments_impl(covw, (const unsigned char*)(w + L.vmnz), nP, Wp, act, (int*)(w + L.act_list),
                                  (int*)(w + L.act_count), (const int*)(w + L.seg_valid), (float*)(w + L.cnt_part),
-                                 (float*)(w + L.aa), st));
+                                 (float*)(w + L.aa), sel, st));
     }
     ProfScope ps_aa(FMHR_SLOT_AA_FWD, st);
     TRY(aa_fwd_rgba((const float*)(w + L.attr8), sh, (float*)(w + L.aa_dcol), (const float*)(w + L.pix16), nullptr, vertices, (const float*)(w + L.cmat), tri, opp, (const unsigned char*)(w + L.silh), (const int*)(w + L.act_list),
@@ -329,7 +351,7 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
 
 extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* wt, const float* vertices_tmp,
                                  const float* delta, const float* albedo, const float* sh, const float* w2c, const float* proj,
-                                 const float* img, const float* mask, const float* valid_mask, const int32_t* tri,
+                                 const float* img, const float* mask, const float* valid_mask, const int32_t* view_idx, const int32_t* tri,
                                  const int32_t* opp, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* col_mult,
                                  const int32_t* vf_ptr, const int32_t* vf_idx, const int32_t* corner_slot,
                                  const float* n_valid_global, float* losses, float* gdelta,
@@ -338,6 +360,8 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
 {
     (void)vertices_tmp; (void)opp;
     TRY(check_dims(d));
+    ViewSel sel;
+    TRY(view_sel_from(d, view_idx, "ham_backward", sel));
     Layout L = make_layout(d);
     FMHR_CHECK_ARG(ws && ws_bytes >= L.total, "ham_backward: workspace too small (%zu < %zu)", ws_bytes, L.total);
     FMHR_CHECK_ARG(wt && delta && albedo && sh && w2c && proj && img && mask && valid_mask && tri && row_ptr && col_idx && col_mult &&
@@ -361,11 +385,12 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     size_t nP = (size_t)d->n * d->H * Wp;
     const float rg = wt->reg_grad_scale;
     const size_t nB = 2048;
+    sh = (const float*)(w + L.sh_local);                             // the forward left the step's n SH rows here, in the step's order (ABI 6)
 
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);
         // losses on the antialiased rgba + their per-pixel gradients
-        TRY(loss_pix_impl((const unsigned long long*)(w + L.covw), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP, d->W, Wp,
+        TRY(loss_pix_impl((const unsigned long long*)(w + L.covw), (float*)(w + L.aa), img, mask, valid_mask, (long long)nP, d->W, Wp, sel,
                           (const int*)(w + L.act_list), (const int*)(w + L.act_count), nv_div,
                           wt->sfs, wt->mask, wt->mse_denominator, (float*)(w + L.g_shaded),
                           (float*)(w + L.partials) + nB, (float*)(w + L.partials) + 2 * nB, losses, st));
@@ -377,7 +402,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                         (const unsigned long long*)(w + L.covw), nv_div, wt->sfs, wt->mask, wt->mse_denominator,
                         (const int32_t*)(w + L.aa_items),
                         (const float*)(w + L.aa_alphas), (const int32_t*)(w + L.aa_region_cnt), d->aa_cap, d->n, d->V, d->H, d->W, Wp,
-                        (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, split ? (float*)(w + L.gvert_aa2) : nullptr, st));
+                        (float*)(w + L.g_shaded), (const float*)(w + L.cmat), gvert_aa, split ? (float*)(w + L.gvert_aa2) : nullptr, view_idx, st));
     }
     {
         // shade + interpolate + rasterize + clip-transform backward, face-parallel (shade.hip: k_face_bwd)

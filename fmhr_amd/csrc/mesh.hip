@@ -266,10 +266,15 @@ template <bool HAS_DELTA>
 __device__ __forceinline__ void transform_body(int v, int b, const float* __restrict__ verts, const float* __restrict__ delta,
                                                const float* __restrict__ w2c, const float* __restrict__ proj, int V,
                                                float4* __restrict__ pos, int H, int W, int2* __restrict__ snap,
-                                               float4* __restrict__ cmat)
+                                               float4* __restrict__ cmat, const int32_t* __restrict__ view_idx,
+                                               const float* __restrict__ sh, float* __restrict__ sh_local)
 {
-    const float* A = w2c + (size_t)b * 16;
-    const float* B = proj + (size_t)b * 16;
+    // ABI 6: view b of the step is view view_idx[b] of the caller's per-view arrays (the loop's minibatch, mesh_sfs_optim.py:255-260);
+    // this kernel is the only reader of the small ones: the combined matrix lands in cmat[b], the SH row in sh_local[b]
+    const int sb = (view_idx != nullptr) ? view_idx[b] : b;
+    const float* A = w2c + (size_t)sb * 16;
+    const float* B = proj + (size_t)sb * 16;
+    if (sh_local != nullptr && blockIdx.x == 0 && threadIdx.x >= 32 && threadIdx.x < 41) sh_local[(size_t)b * 9 + (threadIdx.x - 32)] = sh[(size_t)sb * 9 + (threadIdx.x - 32)];
     // the vertex (and its delta) is requested FIRST, from a clamped index, so that it travels with the matrix entries: behind the
     // barrier and a `delta != nullptr` test it was two more dependent round trips of every thread (HAS_DELTA is a template
     // parameter for that reason: a value merged under a run-time test gets its wait right behind the load)
@@ -877,14 +882,15 @@ k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta,
            const float* __restrict__ proj, int n, int V, float4* __restrict__ pos, int H, int W, int2* __restrict__ snap,
            float4* __restrict__ cmat, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
            const int32_t* __restrict__ vf_idx, float* __restrict__ nsum, float* __restrict__ normals,
-           const float* __restrict__ albedo, float4* __restrict__ attr8, float* __restrict__ vout, int* __restrict__ stamp)
+           const float* __restrict__ albedo, float4* __restrict__ attr8, float* __restrict__ vout, int* __restrict__ stamp,
+           const int32_t* __restrict__ view_idx, const float* __restrict__ sh, float* __restrict__ sh_local)
 {
     // the step counter that tags this step's coverage entries and owner marks (raster.hip, shade.hip): advanced by the step's first kernel
     if (stamp != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamp[0] = stamp[0] + 1;
     const int rows_normals = (int)gridDim.y - n;                     // dispatched first: their long dependent chains start early
     if ((int)blockIdx.y >= rows_normals)
         transform_body<HAS_DELTA>(blockIdx.x * kBlock + threadIdx.x, (int)blockIdx.y - rows_normals, verts_tmp, delta, w2c, proj, V, pos, H, W, snap,
-                       cmat);
+                       cmat, view_idx, sh, sh_local);
     else
         normals_gather_body<HAS_DELTA>((int)blockIdx.y * gridDim.x + blockIdx.x, verts_tmp, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, attr8,
                             delta, vout);
@@ -910,17 +916,18 @@ int clip_positions_impl(const float* verts, const float* cmat, int n, int V, flo
 
 int geometry_impl(const float* verts_tmp, const float* delta, const float* w2c, const float* proj, int n, int V, float* pos, int H, int W,
                   int2* snap, float* cmat, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, float* nsum,
-                  float* normals, const float* albedo, float* attr8, float* vout, int* stamp, hipStream_t st)
+                  float* normals, const float* albedo, float* attr8, float* vout, int* stamp, const int32_t* view_idx, const float* sh,
+                  float* sh_local, hipStream_t st)
 {
     if (n == 0 || V == 0) return FMHR_OK;
     const int gx = cdiv(V, kBlock);
     const int rows_normals = cdiv(cdiv((long long)V * kSubLanes, kBlock), gx);
     if (delta != nullptr)
         k_geometry<true><<<dim3(gx, n + rows_normals), kBlock, 0, st>>>(verts_tmp, delta, w2c, proj, n, V, (float4*)pos, H, W, snap, (float4*)cmat, tri,
-                                                                    vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp);
+                                                                    vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp, view_idx, sh, sh_local);
     else
         k_geometry<false><<<dim3(gx, n + rows_normals), kBlock, 0, st>>>(verts_tmp, delta, w2c, proj, n, V, (float4*)pos, H, W, snap, (float4*)cmat, tri,
-                                                                     vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp);
+                                                                     vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp, view_idx, sh, sh_local);
     FMHR_CHECK_LAUNCH("k_geometry");
     return FMHR_OK;
 }

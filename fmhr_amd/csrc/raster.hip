@@ -794,7 +794,8 @@ k_raster_resolve(const float* __restrict__ pos, const int32_t* __restrict__ tri,
         // the caller's mask is [n,H,W]: with a row pitch the segment's row is one scalar division (a pad lane has no mask)
         long long cidx = gid;
         bool incol = true;
-        if (Wp != W) cidx = caller_index((unsigned)seg_w, (int)(threadIdx.x & 63), W, fu.segx, incol);
+        if (fu.sel.idx != nullptr) cidx = caller_index_sel((unsigned)seg_w, (int)(threadIdx.x & 63), W, fu.segx, fu.sel, incol);   // (a minibatch of the capture's views: ABI 6)
+        else if (Wp != W) cidx = caller_index((unsigned)seg_w, (int)(threadIdx.x & 63), W, fu.segx, incol);
         const float mk = (live && incol && fu.pix16 != nullptr) ? fu.mask[cidx] : 0.f;   // independent of the key: issued with it
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f), col = o;
         bool covered = false;
@@ -960,7 +961,14 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
     // the segment's state word first (packed, hits; BinArgs): an empty segment whose words are already zero leaves here
     int* const stp = seg_state_word(ba, seg);
     int state = *(const_as4_int*)(unsigned long long)stp;
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(state) : : "memory");   // (the same explicit order as for the count below: this wave stores to the word)
+    // (ABI 6) the segment's view in the caller's arrays, requested WITH the state word: behind the waits below it was one more scalar
+    // round trip in front of the mask load of every non-empty segment
+    int src_delta = 0;
+    if (fu.sel.idx != nullptr) {
+        const unsigned bsel = udiv((unsigned)seg, fu.sel.segv);
+        src_delta = fu.sel.src(bsel) - (int)bsel;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(state), "+s"(src_delta) : : "memory");   // (the same explicit order as for the count below: this wave stores to the word)
     if ((state & kSegHasFragments) == 0) {
         if ((state & kSegWordsLive) != 0 && lane == 0) {
             covw[seg] = 0ull;
@@ -989,7 +997,11 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
     // the caller's mask is [n,H,W]: with a row pitch the segment's row is one scalar division (a pad lane has no mask)
     long long cidx = gid;
     bool incol = true;
-    if (Wp != W) cidx = caller_index((unsigned)seg, lane, W, fu.segx, incol);
+    if (fu.sel.idx != nullptr) {                                     // (a minibatch of the capture's views: ABI 6; common.h: caller_index_sel)
+        const unsigned row = udiv((unsigned)seg, fu.segx), col0 = ((unsigned)seg - row * fu.segx.d) << 6;
+        incol = (int)col0 + lane < W;
+        cidx = ((long long)row + (long long)src_delta * fu.sel.H) * W + (int)col0 + lane;
+    } else if (Wp != W) cidx = caller_index((unsigned)seg, lane, W, fu.segx, incol);
     const float mk = incol ? fu.mask[cidx] : 0.f;                    // independent of the bin: issued with its first loads
     const int step_tag = fu.stamp[0];
     const int cnt = min(count, ba.cap);

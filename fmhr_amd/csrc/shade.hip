@@ -38,15 +38,21 @@ k_valid_mask_segments(const float* __restrict__ valid_mask, long long N, int W, 
 
 // active = own coverage | 4-neighbour coverage | valid_mask flag (seven independent word loads)
 __device__ __forceinline__ bool segment_is_active(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz,
-                                                  long long nSeg, int W, long long seg, unsigned char* __restrict__ act)
+                                                  long long nSeg, int W, long long seg, unsigned char* __restrict__ act, const ViewSel& sel)
 {
+    // the valid_mask flags are kept per SOURCE view when the step's views are a selection of the capture's (ABI 6): lane = segment here
+    long long vseg = seg;
+    if (sel.idx != nullptr) {
+        const unsigned b = udiv((unsigned)seg, sel.segv);
+        vseg = seg + (long long)(sel.idx[b] - (int)b) * sel.segv.d;
+    }
     long long s0 = seg << 6, up = s0 - W, dn = s0 + W;
     long long wu = up >> 6, wd = dn >> 6;               // arithmetic shift = floor, also for negative `up`
     int su = (int)(up & 63), sd = (int)(dn & 63);
     unsigned long long c0 = covw[seg], cl = covw_at(covw, seg - 1, nSeg), cr = covw_at(covw, seg + 1, nSeg);
     unsigned long long u0 = covw_at(covw, wu, nSeg), u1 = covw_at(covw, wu + 1, nSeg);
     unsigned long long d0 = covw_at(covw, wd, nSeg), d1 = covw_at(covw, wd + 1, nSeg);
-    unsigned long long any = (unsigned long long)vmnz[seg] | c0 | (cl >> 63) | (cr & 1ull);
+    unsigned long long any = (unsigned long long)vmnz[vseg] | c0 | (cl >> 63) | (cr & 1ull);
     any |= (u0 >> su) | (su ? (u1 << (64 - su)) : 0ull);   // covered pixels among [s0-W, s0-W+63]
     any |= (d0 >> sd) | (sd ? (d1 << (64 - sd)) : 0ull);   // and among [s0+W, s0+W+63]
     act[seg] = any != 0ull ? 1 : 0;
@@ -74,7 +80,7 @@ constexpr int kActBlock = 1024;   // few, fat workgroups: the list cursors are s
 __global__ void __launch_bounds__(kActBlock)
 k_active_segments(const unsigned long long* __restrict__ covw, const unsigned char* __restrict__ vmnz, long long nSeg, int W,
                   unsigned char* __restrict__ act, int* __restrict__ act_list, int* __restrict__ act_count,
-                  const int* __restrict__ seg_valid, float* __restrict__ cnt_part, long long N, float4* __restrict__ aa_init)
+                  const int* __restrict__ seg_valid, float* __restrict__ cnt_part, long long N, float4* __restrict__ aa_init, const ViewSel sel)
 {
     // act_count[0] = number of active segments (act_list): the cursor advances with ONE atomic per workgroup
     constexpr int kWaves = kActBlock / 64;
@@ -88,7 +94,7 @@ k_active_segments(const unsigned long long* __restrict__ covw, const unsigned ch
         float sv = block1024_sum(v, sm16);
         if (threadIdx.x == 0 && cnt_part != nullptr) cnt_part[blockIdx.x] = sv;
     }
-    bool a = (seg < nSeg) && segment_is_active(covw, vmnz, nSeg, W, seg, act);
+    bool a = (seg < nSeg) && segment_is_active(covw, vmnz, nSeg, W, seg, act, sel);
     // bit 31 of the list entry: the antialias scan has something to find here — a pixel of this segment, of the next one (lane 63's
     // right neighbour) or of the segments below holds a face with a silhouette edge (bit 8 of the resolve pass's per-segment
     // word); the nearer pixel of a pair that blends is always such a pixel, so every other active segment is skipped by the scan.
@@ -164,7 +170,7 @@ k_densify(const unsigned long long* __restrict__ covw, const unsigned char* __re
 // the face-parallel backward consumes it.
 __global__ void __launch_bounds__(kBlock)
 k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict__ aa, const float* __restrict__ img,
-           const float* __restrict__ mask, const float* __restrict__ valid_mask, long long N, int W, int Wp, const UDiv segx,
+           const float* __restrict__ mask, const float* __restrict__ valid_mask, long long N, int W, int Wp, const UDiv segx, const ViewSel sel,
            const int* __restrict__ act_list, const int* __restrict__ act_count, const float* __restrict__ n_valid_global,
            float w_sfs, float w_mask, float mse_den, float4* __restrict__ g_shaded,
            float* __restrict__ part_l1, float* __restrict__ part_l2, float* __restrict__ losses)
@@ -182,7 +188,8 @@ k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict
         // img / mask / valid_mask are the caller's [n,H,W] tensors; aa, g_shaded and the coverage words the step's own [n,H,Wp]
         long long cidx = gid;
         bool incol = true;
-        if (Wp != W) cidx = caller_index((unsigned)__builtin_amdgcn_readfirstlane((int)seg), lane, W, segx, incol);
+        if (sel.idx != nullptr) cidx = caller_index_sel((unsigned)__builtin_amdgcn_readfirstlane((int)seg), lane, W, segx, sel, incol);   // (ABI 6: a minibatch of the capture's views)
+        else if (Wp != W) cidx = caller_index((unsigned)__builtin_amdgcn_readfirstlane((int)seg), lane, W, segx, incol);
         if (!incol) continue;                                       // a pad column: no pixel, no loss term
         // every request of the iteration up front: aa (16 B), the image pixel (12 B, one request), the two masks
         // (streaming loads, common.h: this pass reads 160 MB exactly once — through the default policy it leaves the L2 without the
@@ -749,12 +756,12 @@ int valid_mask_segments_impl(const float* valid_mask, int n, int H, int W, int W
 }
 
 int active_segments_impl(const unsigned long long* covw, const unsigned char* vmnz, long long N, int W, unsigned char* act,
-                         int* act_list, int* act_count, const int* seg_valid, float* cnt_part, float* aa_init, hipStream_t st)
+                         int* act_list, int* act_count, const int* seg_valid, float* cnt_part, float* aa_init, const ViewSel sel, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
     long long nSeg = (N + 63) >> 6;
     k_active_segments<<<cdiv(nSeg, kActBlock), kActBlock, 0, st>>>(covw, vmnz, nSeg, W, act, act_list, act_count, seg_valid, cnt_part, N,
-                                                                   (float4*)aa_init);
+                                                                   (float4*)aa_init, sel);
     FMHR_CHECK_LAUNCH("k_active_segments");
     return FMHR_OK;
 }
@@ -771,11 +778,11 @@ int densify_impl(const unsigned long long* covw, const unsigned char* act, long 
 }
 
 int loss_pix_impl(const unsigned long long* covw, const float* aa, const float* img, const float* mask, const float* valid_mask,
-                  long long N, int W, int Wp, const int* act_list, const int* act_count, const float* n_valid_global, float w_sfs, float w_mask,
+                  long long N, int W, int Wp, const ViewSel sel, const int* act_list, const int* act_count, const float* n_valid_global, float w_sfs, float w_mask,
                   float mse_den, float* g_shaded, float* part_l1, float* part_l2, float* losses, hipStream_t st)
 {
     if (N == 0) return FMHR_OK;
-    k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>(covw, (const float4*)aa, img, mask, valid_mask, N, W, Wp, make_udiv((unsigned)max(Wp / 64, 1)), act_list, act_count,
+    k_loss_pix<<<kPersistBlocks, kBlock, 0, st>>>(covw, (const float4*)aa, img, mask, valid_mask, N, W, Wp, make_udiv((unsigned)max(Wp / 64, 1)), sel, act_list, act_count,
                                                   n_valid_global, w_sfs, w_mask, mse_den, (float4*)g_shaded, part_l1,
                                                   part_l2, losses);
     FMHR_CHECK_LAUNCH("k_loss_pix");

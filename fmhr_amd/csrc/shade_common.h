@@ -143,6 +143,7 @@ struct RasterFused {
     BinEntry* bins; int* bin_cursor; int* bin_flag; int bin_cap; // non-null: per-tile fragment bins (raster.hip: binned rasterizer)
     UDiv segx;                                                // row pitch != W (ABI 5): division by the segments per row — the caller's
                                                               // `mask` is [n,H,W], the step's own per-pixel buffers are [n,H,pitch]
+    ViewSel sel;                                              // ABI 6: the step's views are a subset of the caller's (common.h); sel.idx null = not
 };
 
 // ---- binned rasterizer (raster.hip): a bin = one 64-pixel row segment of the flattened [n, H, W] index = the wave that resolves it.

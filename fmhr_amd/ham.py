@@ -81,9 +81,13 @@ class VertexOrder:
 class HamStage2:
     """Owns the per-mesh tables (edge/opposite-vertex table, adjacency CSR) and the step workspace for `n` local views.
 
-    faces: int32 [F,3] on the GPU.  `n_global` = number of views in the whole batch (== n unless views are sharded)."""
+    faces: int32 [F,3] on the GPU.  `n_global` = number of views in the whole batch (== n unless views are sharded).
+    `n_src` (ABI 6): the object steps MINIBATCHES of n views out of a capture of n_src — the per-view arguments of step() / forward() /
+    backward() (sh, w2c, proj, img, mask, valid_mask) are then the capture's resident [n_src, ...] tensors and `view_idx` (int32 [n] on
+    the GPU, e.g. perm[k:k+batch] of mesh_sfs_optim.py:249,255-260) says which views the step renders; the kernels index through it,
+    nothing is gathered, and the per-segment valid_mask table is built once for all n_src views."""
 
-    def __init__(self, faces, V, n, H, W, weights, edge_len_mean, n_global=None, aa_cap=None, bin_cap=0, pitch=None):
+    def __init__(self, faces, V, n, H, W, weights, edge_len_mean, n_global=None, aa_cap=None, bin_cap=0, pitch=None, n_src=None):
         if not faces.is_cuda or faces.dtype != torch.int32:
             raise RuntimeError("HamStage2: faces must be an int32 GPU tensor")
         self.lib = _lib.load()
@@ -126,7 +130,8 @@ class HamStage2:
             pitch = self.W if os.environ.get("FMHR_ROW_PITCH", "1") == "0" else 0
         if not bin_cap and os.environ.get("FMHR_BIN_CAP"):             # experiments: the default capacity of every workspace
             bin_cap = int(os.environ["FMHR_BIN_CAP"])
-        self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap, int(bin_cap), int(pitch))
+        self.n_src = int(n_src or 0)
+        self.dims = HamDims(self.n, self.V, self.F, self.H, self.W, self.nnz, cap, int(bin_cap), int(pitch), self.n_src)
         self.pitch = self.lib.fmhr_ham_pitch(ctypes.byref(self.dims))
         if self.pitch < 0:
             raise RuntimeError("fmhr_ham_pitch failed: " + self.lib.fmhr_last_error().decode())
@@ -157,25 +162,38 @@ class HamStage2:
         self._last_sh = None
 
     # -- the two phases -------------------------------------------------------------------------------------------------
-    def forward(self, vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask):
+    def _view_idx(self, view_idx):
+        if (view_idx is not None) != (self.n_src > 0):
+            raise RuntimeError("HamStage2: view_idx goes with n_src (a minibatch of a resident capture): construct with n_src=<views of the "
+                               "capture> and pass view_idx to every step, or neither")
+        if view_idx is None:
+            return None
+        if view_idx.dtype != torch.int32 or not view_idx.is_cuda or tuple(view_idx.shape) != (self.n,) or not view_idx.is_contiguous():
+            raise RuntimeError(f"HamStage2: view_idx must be a contiguous int32 GPU tensor of shape ({self.n},), got {tuple(view_idx.shape)} "
+                               f"{view_idx.dtype} {view_idx.device}")
+        return view_idx
+
+    def forward(self, vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask, view_idx=None):
+        view_idx = self._view_idx(view_idx)
         key = (valid_mask.data_ptr(), valid_mask._version)
         changed = 1 if key != self._vm_key else 0            # the tensor is kept alive below, so its address is not reused
         self._vm_key, self._vm_ref = key, valid_mask
         self._last_sh = sh                                   # views() re-shades the dense `shaded` image with it
         call("fmhr_ham_forward", ctypes.byref(self.dims), ptr(vertices_tmp), ptr(delta), ptr(albedo), ptr(sh), ptr(w2c),
-             ptr(proj), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp), ptr(self.vf_ptr), ptr(self.vf_idx),
+             ptr(proj), ptr(mask), ptr(valid_mask), ptr(view_idx), ptr(self.faces), ptr(self.opp), ptr(self.vf_ptr), ptr(self.vf_idx),
              changed, ptr(self.n_valid_local), ptr(self.ws), self.ws_bytes, stream_ptr(self.dev))
 
     def backward(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=True, reg_range=None, split=False,
-                 adam=(None, None)):
+                 adam=(None, None), view_idx=None):
         """split=True: the view-sharded form — gdelta / galbedo get the photometric share without the L1 divisor, gdelta_rest /
         galbedo_rest the rest (include/fmhr_ham.h); the caller all-reduces self.bucket and calls combine()."""
         w = self.weights
+        view_idx = self._view_idx(view_idx)
         v0, v1 = (0, self.V) if reg_range is None else reg_range
         wt = HamWeights(w["sfs"], w["lap"], w["albedo"], w["mask"], w["edge"], w["delta"], self.edge_len_mean,
                         float(self.n_global * self.H * self.W), 1.0 if reg_grads else 0.0, int(v0), int(v1))
         call("fmhr_ham_backward", ctypes.byref(self.dims), ctypes.byref(wt), ptr(vertices_tmp), ptr(delta), ptr(albedo),
-             ptr(sh), ptr(w2c), ptr(proj), ptr(img), ptr(mask), ptr(valid_mask), ptr(self.faces), ptr(self.opp),
+             ptr(sh), ptr(w2c), ptr(proj), ptr(img), ptr(mask), ptr(valid_mask), ptr(view_idx), ptr(self.faces), ptr(self.opp),
              ptr(self.row_ptr), ptr(self.col_idx), ptr(self.col_mult), ptr(self.vf_ptr), ptr(self.vf_idx), ptr(self.corner_slot),
              ptr(self.n_valid_global),
              ptr(self.losses), ptr(self.gdelta),
@@ -189,14 +207,16 @@ class HamStage2:
              ctypes.byref(adam[1]) if adam[1] is not None else None, stream_ptr(self.dev))
 
     def step(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, group=None, reg_grads=True, reg_range=None,
-             optimizer=None, params=None):
+             optimizer=None, params=None, view_idx=None):
         """Full forward + backward.  Returns (losses[8] device tensor, gdelta [V,3], galbedo [V,3]) — buffers owned by this
         object and overwritten by the next step.  `group`: torch.distributed process group when views are sharded: the results
         are then the batch-global ones (summed over the ranks), identical on every rank.
         `group` may also be a fmhr_amd.dist.StreamAllReduce (RCCL on this step's own stream: no cross-stream hand-over).
         `optimizer`, `params`: apply the Adam update of (delta, albedo) inside the step (no separate optimizer.step() launch).
         `reg_range` = (v0, v1): evaluate the view-independent terms for these vertices only (ranks take disjoint ranges covering
-        [0, V): fmhr_amd.dist.shard_views(V, rank, world)); `reg_grads=False` switches them off on this rank."""
+        [0, V): fmhr_amd.dist.shard_views(V, rank, world)); `reg_grads=False` switches them off on this rank.
+        `view_idx` (object built with n_src): int32 [n] GPU tensor — the step renders views view_idx[b] of the capture-resident
+        sh / w2c / proj / img / mask / valid_mask [n_src, ...] (the loop's `perm[k:k+batch]`, mesh_sfs_optim.py:255-260, without the gathers)."""
         self._check(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask)
         adam = (None, None)
         if optimizer is not None:
@@ -206,9 +226,9 @@ class HamStage2:
             if p_delta.data_ptr() != delta.data_ptr() or p_albedo.data_ptr() != albedo.data_ptr():
                 raise RuntimeError("HamStage2.step: `params` must be the tensors behind the `delta` / `albedo` arguments")
             adam = (optimizer.fused_param(p_delta), optimizer.fused_param(p_albedo))
-        self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask)
+        self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask, view_idx=view_idx)
         self.backward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=reg_grads, reg_range=reg_range,
-                      split=group is not None, adam=adam if group is None else (None, None))
+                      split=group is not None, adam=adam if group is None else (None, None), view_idx=view_idx)
         if group is not None:
             # the step's ONE collective (1.18 -> 2.35 MB at V = 49k: still latency-bound on xGMI), then P / (3 Pv) + R
             if hasattr(group, "all_reduce_"):
@@ -219,7 +239,7 @@ class HamStage2:
         return self.losses, self.gdelta, self.galbedo
 
     def _check(self, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask):
-        n, V, H, W = self.n, self.V, self.H, self.W
+        n, V, H, W = self.n_src or self.n, self.V, self.H, self.W        # (n_src: the per-view arguments are the capture's)
         exp = dict(vertices_tmp=(V, 3), delta=(V, 3), albedo=(V, 3), sh=(n, 9), w2c=(n, 4, 4), proj=(n, 4, 4),
                    img=(n, H, W, 3), mask=(n, H, W), valid_mask=(n, H, W))
         got = dict(vertices_tmp=vertices_tmp, delta=delta, albedo=albedo, sh=sh, w2c=w2c, proj=proj, img=img, mask=mask,

@@ -115,13 +115,118 @@ def stage1_loss_cached(ops, cache, idx, albedo, sh_coeff, img, sfs_weight):
     return sfs_weight * diff / (3.0 * valid.sum())
 
 
+class Stage2Loop:
+    """The stage-2 loop of mesh_sfs_optim.py:242-317 as the product runs it: per epoch a fresh permutation of the capture's views (:249),
+    per batch ONE fused step on `perm[k:k+batch]` — the capture's images, masks, start silhouettes, cameras and SH rows stay where they
+    are and the step indexes them through the batch's view indices (HamStage2(n_src=num), ABI 6: no per-batch gathers, the per-segment
+    valid_mask table built once), the Adam update of (delta, albedo) applied by the kernel that forms their gradients.  The loop never
+    synchronises: the sticky overflow flags of every workspace are read every `check_every` epochs (one 16-byte copy each), before a
+    workspace is dropped, and at the end.  run_ham drives it; bench.py times it (`run_ham_stage2`)."""
+
+    def __init__(self, vertices_tmp, faces, delta, albedo, sh_fixed, imgs, masks, valid_masks, w2cs, projs, resolution, weights, elm,
+                 optimizer, batch, epoch_sfs, gen, aa_cap=None, bin_cap=0, check_every=16):
+        from .ham import HamStage2
+        self.HamStage2 = HamStage2
+        self.vertices_tmp, self.faces, self.delta, self.albedo = vertices_tmp, faces, delta, albedo
+        self.args = tuple(t.contiguous() for t in (sh_fixed, w2cs, projs, imgs, masks, valid_masks))
+        self.H, self.W = resolution
+        self.weights, self.elm, self.opt = dict(weights), elm, optimizer
+        self.num, self.batch, self.epoch_sfs, self.gen = imgs.shape[0], int(batch), int(epoch_sfs), gen
+        self.aa_cap, self.bin_cap, self.check_every = aa_cap, bin_cap, check_every
+        self.steppers, self.epoch, self.hs, self.perm, self._pending = {}, 0, None, None, []
+        self.dev = vertices_tmp.device
+        self._perms, self._perm_at = None, 0
+
+    def _next_perm(self):
+        """the epoch's permutation (:249) as an int32 device row.  Drawn from the generator exactly as one torch.randperm per epoch
+        would be, but kPermChunk epochs at a time, into ONE pinned staging buffer allocated once, and copied with one non-blocking
+        transfer on the step's stream (stream order protects the rows the queued steps still read).  What it replaces, measured at the
+        metric config: a pageable host-to-device copy per epoch — the reference's `.cuda()` — stalls the launch
+        queue for ~25 us = 9 % of a 48-view step; a freshly pinned buffer per chunk (hipHostMalloc) ~1 ms per 64 epochs = 5 %."""
+        kPermChunk = 64
+        if self._perms is None:
+            self._pin = torch.empty((kPermChunk, self.num), dtype=torch.int32)
+            if self.dev.type == "cuda":
+                self._pin = self._pin.pin_memory()
+            self._perms = torch.empty((kPermChunk, self.num), dtype=torch.int32, device=self.dev)
+            self._perm_at, self._copied = kPermChunk, None
+        if self._perm_at == kPermChunk:
+            if self._copied is not None:
+                self._copied.synchronize()                                              # the previous chunk's transfer has read the staging buffer (64 epochs ago)
+            for i in range(kPermChunk):
+                self._pin[i].copy_(torch.randperm(self.num, generator=self.gen))
+            self._perms.copy_(self._pin, non_blocking=True)
+            if self.dev.type == "cuda":
+                self._copied = torch.cuda.Event()
+                self._copied.record()
+            self._perm_at = 0
+        self._perm_at += 1
+        return self._perms[self._perm_at - 1]
+
+    def check(self):
+        """synchronous: raise if a work list of any live workspace overflowed in any step so far (one device -> host copy each)"""
+        self._pending = []
+        for hs_ in self.steppers.values():
+            hs_.check_overflow()
+
+    def poll(self):
+        """the periodic check WITHOUT a synchronisation: inspect the copies of the sticky flags issued at the previous poll —
+        their transfers completed epochs ago — and issue this poll's (16 bytes per workspace into pinned memory, non-blocking, on the
+        step's stream).  An overflow is reported one polling interval late at most; check() before a workspace is dropped and at the end
+        of the run is synchronous and exact."""
+        for hs_, pin, ev in getattr(self, "_pending", []):
+            ev.synchronize()
+            f = pin.tolist()
+            if f[2] != 0 or f[3] != 0:
+                hs_.check_overflow()                                                    # raises with the message that names the list
+        self._pending = []
+        if self.dev.type != "cuda":
+            return self.check()
+        for hs_ in self.steppers.values():
+            if getattr(hs_, "_flag_pin", None) is None:
+                hs_._flag_pin = torch.zeros(4, dtype=torch.int32).pin_memory()
+            hs_._flag_pin.copy_(hs_._flags(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((hs_, hs_._flag_pin, ev))
+
+    def run_epoch(self, after_step=None):
+        """one epoch: ceil(num / batch) fused steps on a fresh permutation (the last batch ragged when batch does not divide num)"""
+        ep = self.epoch
+        perm = self._next_perm()
+        if ep == self.epoch_sfs // 2:
+            self.weights["albedo"] = self.weights["albedo"] / 10000                   # :250-251
+            self.check()                                                                # their flags go with them
+            self.steppers.clear()
+        V = self.vertices_tmp.shape[0]
+        sh, w2cs, projs, imgs, masks, valid_masks = self.args
+        for k in range(0, self.num, self.batch):
+            idx = perm[k:k + self.batch]                                                # a view of the permutation: no copy
+            n = idx.shape[0]
+            hs = self.steppers.get(n)
+            if hs is None:
+                hs = self.steppers[n] = self.HamStage2(self.faces, V, n, self.H, self.W, self.weights, self.elm, aa_cap=self.aa_cap,
+                                                       bin_cap=self.bin_cap, n_src=self.num)
+            hs.step(self.vertices_tmp, self.delta.detach(), self.albedo.detach()[0], sh, w2cs, projs, imgs, masks, valid_masks,
+                    view_idx=idx, optimizer=self.opt, params=(self.delta, self.albedo))
+            self.hs = hs
+            if after_step is not None:
+                after_step(hs, idx)
+        self.perm = perm
+        self.epoch = ep + 1
+        if self.check_every and self.epoch % self.check_every == 0:
+            self.poll()
+
+
 def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0, scan_id=None,
-            check_every=1, aa_cap=None, bin_cap=0, vertex_order=None):
+            check_every=16, aa_cap=None, bin_cap=0, vertex_order=None):
     """The HAM optimisation end to end on GPU tensors.  conf: dict with the keys of conf/demo_sfs.conf that the loop reads.
     A step never synchronises, so a work list that overflows (antialias pairs, fragment bins: `aa_cap` / `bin_cap` of HamStage2) drops
     gradient terms without an error of its own: the STICKY overflow flags of every stage-2 workspace are read every `check_every`
-    epochs (one 16-byte copy per workspace), before a workspace is discarded and at the end, and a set flag raises — whatever
-    `log_every` is.
+    epochs (one 16-byte copy per workspace — a device-to-host copy drains the launch queue, so not every epoch: the demo's epoch is two
+    steps, 0.7 ms of GPU work), before a workspace is discarded and at the end, and a set flag raises — whatever `log_every` is.
+    Stage 2 steps MINIBATCHES of the resident capture (Stage2Loop: HamStage2(n_src=num) + view_idx = perm[k:k+batch], ABI 6): the six
+    per-batch gathers of mesh_sfs_optim.py:255-260 do not exist, the Adam update rides in the step.
     The optimisation runs on a RENUMBERING of the vertices (fmhr_amd.ham.VertexOrder: first-touch order of the face list, the faces and
     their corner order untouched — the gathers of every kernel stay within few cache lines) and every per-vertex result is mapped back:
     what is returned and written has the caller's numbering, i.e. the child-face / appended-midpoint layout of the subdivided mesh that
@@ -190,42 +295,22 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
                 history.append(("albedo", ep, float(loss)))
         del cache
         sh_fixed = F.pad(sh_coeffs.detach(), (0, 9 - degree ** 2)).contiguous()
-    # ---- stage 2: vertex offsets + albedo (:242-317), fused step
+    # ---- stage 2: vertex offsets + albedo (:242-317): the fused step on minibatches of the resident capture (Stage2Loop above)
     weights = dict(sfs=conf["sfs_weight"], lap=conf["lap_weight"], albedo=conf["albedo_weight"], mask=conf["mask_weight"],
                    edge=conf["edge_weight"], delta=conf["delta_weight"])
     opt = optim.Adam([{'params': delta, 'lr': conf["lr"]}, {'params': albedo, 'lr': conf["albedo_lr"]}])
-    steppers = {}
     epoch_sfs = int(conf["epoch_sfs"])
+    loop = Stage2Loop(vertices_tmp, faces, delta, albedo, sh_fixed, imgs, masks, init["valid_masks"], w2cs, projs, (H, W), weights, elm, opt,
+                      batch, epoch_sfs, gen, aa_cap=aa_cap, bin_cap=bin_cap, check_every=check_every)
     rendered_img, perm_last = [], None                                               # :315-317
-    def check_steppers():
-        for hs_ in steppers.values():
-            hs_.check_overflow()
-
+    keep = (lambda hs_, idx_: rendered_img.append(hs_.views()["tmp_img"].clone())) if out_dir is not None else None
     for ep in range(epoch_sfs):
-        perm = torch.randperm(num, generator=gen).to(dev)
-        if ep == epoch_sfs // 2:
-            weights["albedo"] = weights["albedo"] / 10000                            # :250-251
-            check_steppers()                                                         # their flags go with them
-            steppers.clear()
-        for k in range(0, num, batch):
-            idx = perm[k:k + batch]
-            n = idx.shape[0]
-            if n not in steppers:
-                steppers[n] = HamStage2(faces, vertices.shape[0], n, H, W, weights, elm, aa_cap=aa_cap, bin_cap=bin_cap)
-            hs = steppers[n]
-            losses, gd, ga = hs.step(vertices_tmp, delta.detach(), albedo.detach()[0], sh_fixed[idx].contiguous(),
-                                     w2cs[idx].contiguous(), projs[idx].contiguous(), imgs[idx].contiguous(),
-                                     masks[idx].contiguous(), init["valid_masks"][idx].contiguous())
-            delta.grad, albedo.grad = gd, ga.view(1, -1, 3)
-            opt.step()
-            if ep == epoch_sfs - 1 and out_dir is not None:                          # the last epoch's renders are the "rerender" images
-                rendered_img.append(hs.views()["tmp_img"].clone())
-                perm_last = perm.cpu().numpy()
+        loop.run_epoch(after_step=keep if ep == epoch_sfs - 1 else None)             # the last epoch's renders are the "rerender" images
         if log_every and ep % log_every == 0:
-            history.append(("sfs", ep, hs.loss_dict()))
-        if check_every and (ep + 1) % check_every == 0:
-            check_steppers()
-    check_steppers()
+            history.append(("sfs", ep, loop.hs.loss_dict()))
+    if out_dir is not None and loop.perm is not None:
+        perm_last = loop.perm.cpu().numpy()
+    loop.check()
     out_vertices = order.to_caller((vertices_tmp + delta).detach())
     albedo_out = order.to_caller(albedo.detach(), 1)
     result = dict(vertices=out_vertices, delta=order.to_caller(delta.detach()), albedo=albedo_out, sh_coeffs=sh_coeffs.detach(),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMHR_ABI_VERSION 5
+#define FMHR_ABI_VERSION 6
 #define FMHR_OK 0
 #define FMHR_E_ARG (-1)   /* bad shape / null pointer / workspace too small */
 #define FMHR_E_HIP (-2)   /* HIP runtime error (message has hipGetErrorString) */
@@ -161,6 +161,12 @@ typedef struct fmhr_ham_dims {
                                    above W.  Part of the workspace layout like bin_cap.  The CALLER'S tensors are not affected: img
                                    stays [n,H,W,3], mask / valid_mask [n,H,W]; only the inspection views of fmhr_ham_workspace_views
                                    have rows of `pitch` pixels (fmhr_ham_pitch) */
+    int32_t n_src;              /* ABI 6: views of the CAPTURE the caller's per-view arrays hold (sh, w2c, proj, img, mask, valid_mask:
+                                   [n_src, ...]) when a step renders a SUBSET of them, chosen per step by `view_idx` of fmhr_ham_forward /
+                                   fmhr_ham_backward — the minibatch of mesh_sfs_optim.py:249,255-260 (`perm[k:k+batch]`) without the six
+                                   gathers.  0 = the arrays hold exactly the n views of the step (view_idx must then be NULL).  Part of
+                                   the workspace layout (the per-segment valid_mask flags are kept per SOURCE view: built once, not
+                                   once per batch); n_src > 0 needs H * pitch % 64 == 0 (always true with the default pitch) */
 } fmhr_ham_dims;
 
 typedef struct fmhr_ham_weights {
@@ -201,6 +207,11 @@ int fmhr_ham_rasterizer_form(const fmhr_ham_dims* d);
  *   vertices_tmp, delta, albedo [V,3]; sh [n,9]; w2c, proj [n,4,4] (row-vector convention, get_data.py:96-97);
  *   img [n,H,W,3]; mask, valid_mask [n,H,W]; tri [F,3]; opp [F,3]; row_ptr [V+1]; col_idx, col_mult [nnz]; vf_ptr [V+1]; vf_idx [3F];
  *   corner_slot [3F] (fmhr_corner_slots_build).
+ *   view_idx (ABI 6): NULL, or — with dims.n_src > 0 — device int32 [n], all in [0, n_src): view b of the step is view view_idx[b] of
+ *   the caller's arrays, which are then [n_src, ...] (the whole capture, resident): sh, w2c, proj, img, mask, valid_mask.  The kernels
+ *   index through it (one scalar load per wave); nothing is gathered or copied.  The SAME array must be passed to the forward and the
+ *   backward of a step and stay unchanged until both have run (stream order).  Replaces the loop's per-batch gathers
+ *   `w2cs[perm[k:k+batch]]` ... `sh_coeffs[perm[k:k+batch]]` (mesh_sfs_optim.py:255-260).
  *   n*H*pitch must be a multiple of 4 (always true with the default pitch).
  *   valid_mask_changed: pass 1 on the first call on a workspace and whenever valid_mask's CONTENTS may differ from the previous
  *   call (its per-segment non-zero flags are cached in the workspace; the mask is constant over a HAM run, :158).
@@ -220,11 +231,11 @@ int fmhr_ham_rasterizer_form(const fmhr_ham_dims* d);
 int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, void* stream);
 int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tmp, const float* delta, const float* albedo,
                      const float* sh, const float* w2c, const float* proj, const float* mask, const float* valid_mask,
-                     const int32_t* tri, const int32_t* opp, const int32_t* vf_ptr, const int32_t* vf_idx,
+                     const int32_t* view_idx, const int32_t* tri, const int32_t* opp, const int32_t* vf_ptr, const int32_t* vf_idx,
                      int valid_mask_changed, int32_t* n_valid_local, void* ws, size_t ws_bytes, void* stream);
 int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights* w, const float* vertices_tmp, const float* delta,
                       const float* albedo, const float* sh, const float* w2c, const float* proj, const float* img,
-                      const float* mask, const float* valid_mask, const int32_t* tri, const int32_t* opp,
+                      const float* mask, const float* valid_mask, const int32_t* view_idx, const int32_t* tri, const int32_t* opp,
                       const int32_t* row_ptr, const int32_t* col_idx, const int32_t* col_mult, const int32_t* vf_ptr,
                       const int32_t* vf_idx, const int32_t* corner_slot, const float* n_valid_global,
                       float* losses, float* gdelta, float* galbedo, float* gdelta_rest, float* galbedo_rest,
@@ -253,8 +264,9 @@ int fmhr_ham_workspace_views(const fmhr_ham_dims* d, void* ws, size_t ws_bytes, 
 long long fmhr_ham_workspace_offset(const fmhr_ham_dims* d, const char* name);
 /* The step only writes shaded / aa inside "active" 64-pixel segments (covered pixels, their 4-neighbours, non-zero valid_mask)
  * and stores neither the dr.rasterize image, nor the clip positions, nor the shaded image before antialias; this fills the zeros,
- * rebuilds `rast` from the per-pixel words, computes `pos` and re-shades `shaded` (tri / sh: the arrays the last forward was given),
- * so the views above can be inspected as dense arrays.  Call it after the step whose state you want. */
+ * rebuilds `rast` from the per-pixel words, computes `pos` and re-shades `shaded` (tri: the array the last forward was given; sh: ignored
+ * since ABI 6 — the forward keeps the step's n SH rows in the workspace, may be NULL), so the views above can be inspected as dense arrays.
+ * Call it after the step whose state you want. */
 int fmhr_ham_densify(const fmhr_ham_dims* d, const int32_t* tri, const float* sh, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ fused stage-1 step

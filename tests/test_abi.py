@@ -26,12 +26,12 @@ def test_header_and_library_agree(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     exported = set(re.findall(r" T (fmhr_[a-z_0-9]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.fmhr_abi_version() == 5
+    assert lib.fmhr_abi_version() == 6
 
 
 def test_struct_layouts_match_header():
     from fmhr_amd._lib import HamDims, HamWeights, HamViews
-    assert ctypes.sizeof(HamDims) == 36 and ctypes.sizeof(HamWeights) == 44 and ctypes.sizeof(HamViews) == 48
+    assert ctypes.sizeof(HamDims) == 40 and ctypes.sizeof(HamWeights) == 44 and ctypes.sizeof(HamViews) == 48
     from fmhr_amd._lib import AdamParam
     assert ctypes.sizeof(AdamParam) == 48
     from fmhr_amd._lib import Stage1Plan
@@ -62,6 +62,11 @@ def test_argument_errors_without_gpu(lib):
     assert lib.fmhr_ham_pitch(ctypes.byref(HamDims(2, 100, 180, 512, 334, 0, 4096, 0, 448))) == 448
     assert lib.fmhr_ham_pitch(ctypes.byref(HamDims(2, 100, 180, 512, 334, 0, 4096, 0, 400))) == -1
     assert b"pitch" in lib.fmhr_last_error()
+    # ABI 6: a view selection (n_src > 0: the step's views are a subset of the capture's) needs every segment inside one view
+    assert lib.fmhr_ham_workspace_bytes(ctypes.byref(HamDims(2, 100, 180, 64, 48, 0, 4096, 0, 0, 5))) > 0
+    assert lib.fmhr_ham_workspace_bytes(ctypes.byref(HamDims(2, 100, 180, 50, 38, 0, 4096, 0, 38, 5))) == 0
+    assert b"multiple of 64" in lib.fmhr_last_error()
+    assert lib.fmhr_ham_workspace_bytes(ctypes.byref(HamDims(2, 100, 180, 64, 48, 0, 4096, 0, 0, -1))) == 0
     flat, padded = HamDims(8, 778, 1538, 512, 334, 0, 4096, 0, 334), HamDims(8, 778, 1538, 512, 334, 0, 4096, 0, 0)
     assert lib.fmhr_ham_workspace_bytes(ctypes.byref(padded)) > lib.fmhr_ham_workspace_bytes(ctypes.byref(flat)) > 0
     assert lib.fmhr_ham_rasterizer_form(ctypes.byref(HamDims(2, 49281, 98432, 512, 334, 0, 4096, 0, 0))) == 1     # W = 334, micro-triangle: bins

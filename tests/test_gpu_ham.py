@@ -1167,7 +1167,7 @@ def test_two_frames_on_two_streams_equal_their_sequential_results():
     of a two-hand sequence are independent (delta, albedo) problems on the shared topology, each with its own HamStage2 workspace, and a
     rank's local frames run CONCURRENTLY on side streams forked from / joined to the current stream every step.  Two frames of the
     two-hand mesh at W = 334 (row pitch 384, binned rasterizer), six dependent fused-Adam steps each: once one after the other on the
-    current stream, once on two HIP streams — `rast` of the last step bit-identical, losses and parameters equal up to the float-atomic
+    current stream, once on two HIP streams — the last step's face ids equal and (u, v, z/w) to 1e-5, losses and parameters equal up to the float-atomic
     summation order, and frame A's results are not frame B's (the two workspaces do not leak into each other).  The per-launch-group
     timing hook (thread-local state of the library) is attached during the concurrent steps, as bench.py does."""
     from fmhr_amd import _lib, synthetic as S
@@ -1242,13 +1242,83 @@ def test_two_frames_on_two_streams_equal_their_sequential_results():
         p.hs.check_overflow()
     errs = []
     for f in range(2):
-        assert torch.equal(got[f]["rast"], ref[f]["rast"]), f        # six dependent steps later: the same triangles at the same depths
+        # six dependent steps later: the same triangles in the same pixels.  Not bit for bit: the float-atomic order of the antialias
+        # backward moves a gradient in its last bits from run to run — two SEQUENTIAL runs of frame 1 differ the same way in one run of
+        # three (tools/experiments/r05_two_stream_debug.py: one vertex one ulp apart after six Adam steps, (u, v) of the 16 pixels of its
+        # faces in the last bits, every face id equal) — so: ids equal but for a handful of pixels at most, values to 1e-5
+        ids_a, ids_b = got[f]["rast"][..., 3], ref[f]["rast"][..., 3]
+        assert int((ids_a != ids_b).sum()) <= 8, (f, int((ids_a != ids_b).sum()))
+        same = (ids_a == ids_b).unsqueeze(-1)
+        assert float(((got[f]["rast"] - ref[f]["rast"]).abs() * same)[..., :3].max()) < 1e-5, f
         assert float(got[f]["losses"][7]) == float(ref[f]["losses"][7]) and float(ref[f]["losses"][7]) > 1000
         e = (rel_err(got[f]["losses"][:7], ref[f]["losses"][:7]), rel_err(got[f]["delta"], ref[f]["delta"]),
              rel_err(got[f]["albedo"], ref[f]["albedo"]), rel_err(got[f]["gd"], ref[f]["gd"]))
         errs.append(e)
         assert e[0] < 1e-5 and e[1] < 1e-4 and e[2] < 1e-5 and e[3] < 1e-4, (f, e)
     # the frames are different problems: nothing of one may show up in the other
-    assert rel_err(got[0]["delta"], got[1]["delta"]) > 1e-2 and not torch.equal(got[0]["rast"], got[1]["rast"])
+    assert rel_err(got[0]["delta"], got[1]["delta"]) > 1e-2 and float((got[0]["rast"] - got[1]["rast"]).abs().max()) > 1e-3
     log_parity("two frames of the two-hand mesh (V = %d, %d x %dx%d, pitch 384, binned) on two HIP streams vs one after the other, %d fused-Adam "
-               "steps: rast bit-identical, losses / delta / albedo / gdelta rel %s | %s" % (V, n, H, W, steps, ["%.1e" % x for x in errs[0]], ["%.1e" % x for x in errs[1]]))
+               "steps: face ids equal, losses / delta / albedo / gdelta rel %s | %s" % (V, n, H, W, steps, ["%.1e" % x for x in errs[0]], ["%.1e" % x for x in errs[1]]))
+
+
+@pytest.mark.parametrize("case", [("micro_sel", (7, 192, 176, 64, 96), 51, [5, 0, 3]),          # W = 176: row pitch 192, binned rasterizer
+                                  ("coarse_sel", (6, 128, 334, 10, 14), 52, [4, 1, 5, 2]),      # W = 334: pitch 384, atomic keys + resolve pass, large-box queue
+                                  ("flat512_sel", (5, 64, 128, 24, 32), 53, [2, 4])],           # pitch == W (a multiple of 64): the cidx == gid fast path is left
+                         ids=lambda c: c[0])
+def test_view_selection_equals_the_gathered_batch(oracle, case):
+    """ABI 6: the loop's minibatch — `perm[k:k+batch]` of mesh_sfs_optim.py:249,255-260 — INSIDE the step.  The
+    capture's per-view tensors (sh, w2c, proj, img, mask, valid_mask: all `num` views) stay resident, a device int32 array says which views
+    the step renders, and the kernels index through it.  A permuted subset through HamStage2(n_src=num).step(view_idx=...) against (a) the
+    oracle on the GATHERED inputs under the same bars as every other case and (b) the same step on gathered tensors: `rast` bit-identical,
+    losses and gradients equal up to the float-atomic order.  Then a SECOND batch on the same workspace (other views, same object):
+    the per-segment valid_mask table was built once for all source views and must serve it."""
+    from fmhr_amd.ham import HamStage2
+    name, dims, seed, pick = case
+    sc = prepare(oracle, dims, seed)
+    num = sc["views"]
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    hs = HamStage2(sc["faces"].to(dev), sc["V"], len(pick), sc["H"], sc["W"], sc["weights"], sc["elm"], n_src=num)
+    for picked in (pick, [v for v in range(num) if v not in pick][:len(pick)][::-1] or pick):
+        if len(picked) != len(pick):
+            continue
+        idx = torch.tensor(picked, dtype=torch.int32, device=dev)
+        sub = dict(sc, views=len(picked))
+        for k in ("sh0", "w2c", "proj", "img", "mask", "valid_mask"):
+            sub[k] = sc[k][picked].contiguous()
+        ld_ref, v = _step_vs_oracle(oracle, sub, f"{name}{picked}")            # the gathered batch: GPU vs oracle, hard 1e-4
+        losses, gd, ga = hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"],
+                                 view_idx=idx)
+        ld = hs.loss_dict()
+        vs = hs.views()
+        assert torch.equal(vs["rast"], v["rast"]), picked
+        assert torch.equal(vs["tmp_img_pre_aa"], v["tmp_img_pre_aa"]), picked   # the SH rows went through the selection too
+        assert ld["n_valid"] == ld_ref["n_valid"]
+        for k in ("sfs", "lap", "albedo", "mask", "edge", "delta", "total"):
+            assert abs(ld[k] - ld_ref[k]) <= 2e-6 * max(abs(ld_ref[k]), 1e-6), (picked, k, ld[k], ld_ref[k])
+        e = (rel_err(gd, v["gdelta"]), rel_err(ga, v["galbedo"]), rel_err(gd, v["gd64"]), rel_err(ga, v["ga64"]))
+        log_parity(f"{name}: views {picked} of {num} selected inside the step vs the gathered batch: rast bit-identical, gdelta {e[0]:.1e} galbedo {e[1]:.1e}"
+                   f" | vs fp64 on the gathered inputs: {e[2]:.1e} {e[3]:.1e}")
+        assert e[0] < 2e-5 and e[1] < 2e-5 and e[2] < TOL and e[3] < TOL, (picked, e)
+
+
+def test_view_selection_argument_errors(oracle):
+    """view_idx goes with n_src, both ways; a selection needs every 64-pixel segment inside one view (H * pitch % 64 == 0)"""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (3, 64, 64, 10, 14), 54)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    args = (g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    idx = torch.tensor([2, 0], dtype=torch.int32, device=dev)
+    plain = HamStage2(sc["faces"].to(dev), sc["V"], 3, 64, 64, sc["weights"], sc["elm"])
+    with pytest.raises(RuntimeError, match="view_idx"):
+        plain.step(*args, view_idx=idx)
+    sel = HamStage2(sc["faces"].to(dev), sc["V"], 2, 64, 64, sc["weights"], sc["elm"], n_src=3)
+    with pytest.raises(RuntimeError, match="view_idx"):
+        sel.step(*args)
+    with pytest.raises(RuntimeError, match="int32"):
+        sel.step(*args, view_idx=idx.long())
+    with pytest.raises(RuntimeError, match="multiple of 64"):                    # 50 x 38 pixels at pitch = W: segments straddle views
+        HamStage2(sc["faces"].to(dev), sc["V"], 2, 50, 38, sc["weights"], sc["elm"], n_src=3, pitch=38)
+    sel.step(*args, view_idx=idx)                                                 # ... and the well-formed call runs
+    assert sel.loss_dict()["n_valid"] > 0
