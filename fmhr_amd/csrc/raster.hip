@@ -586,9 +586,10 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 if (t < nt) evaluate(t, e1, bin1, ent1);
                 store(t < nt, e1, bin1, ent1);
             }
-            // EVERY reservation marks its segment for the second pass, not only the bin's first one, and at the END of the round: the
-            // mark then needs nothing but the table (with the fragment's values live, or behind a test of the atomic's result, it cost
-            // the worker instantiation 16 spilled VGPRs); the words are packed — the ~30 marks of a workgroup are a few lines
+            // (the segment's mark for the second pass is the `gbase == 0` store above: the reservation that found the cursor at 0 is the
+            // bin's first of this step — the second pass resets the cursor only on marked segments, so exactly one reservation per
+            // segment and step sees 0, and one mark is enough; marking at the end of the round from every reservation cost the worker
+            // instantiation 16 spilled VGPRs)
         }
     } else {
         for (int R = 0; R < T; R += kTaskCap) {                          // workgroup-uniform trip count (one round unless boxes are large)

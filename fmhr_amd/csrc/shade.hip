@@ -191,7 +191,7 @@ k_loss_pix(const unsigned long long* __restrict__ covw, const float4* __restrict
         if (sel.idx != nullptr) cidx = caller_index_sel((unsigned)__builtin_amdgcn_readfirstlane((int)seg), lane, W, segx, sel, incol);   // (ABI 6: a minibatch of the capture's views)
         else if (Wp != W) cidx = caller_index((unsigned)__builtin_amdgcn_readfirstlane((int)seg), lane, W, segx, incol);
         if (!incol) continue;                                       // a pad column: no pixel, no loss term
-        // every request of the iteration up front: aa (16 B), the image pixel (12 B, one request), the two masks
+        // every request of the iteration up front: aa (16 B), the image pixel (three 4-B streaming loads: see below), the two masks
         // (streaming loads, common.h: this pass reads 160 MB exactly once — through the default policy it leaves the L2 without the
         // tables the antialias and face backward and the mesh tails gather from; 3 029 -> 3 060 it/s over five alternating rounds, the
         // tails 26.3 -> 25.0 us; the image pixel as three 4-B requests: a 12-B streaming load does not exist)

@@ -135,18 +135,24 @@ class StreamAllReduce:
             self.abort()
             raise
 
-    def _wait(self, deadline, what):
-        """poll the communicator's asynchronous state until it leaves ncclInProgress; TimeoutError past the deadline"""
+    def _wait(self, deadline, what, spin=0.0):
+        """poll the communicator's asynchronous state until it leaves ncclInProgress; TimeoutError past the deadline.
+        `spin` seconds of busy polling come first (the STEP's all-reduce: on a non-blocking communicator RCCL's helper thread hands the
+        enqueue back as ncclInProgress as a matter of course, and a 2 ms sleep there would be ten steps of the 8-GPU run — ADVICE r4);
+        after them, and from the start for connect(), the poll sleeps between looks."""
         import time
         state = ctypes.c_int(_NCCL_IN_PROGRESS)
+        spin_until = time.monotonic() + spin
         while True:
             self._check(self.lib.ncclCommGetAsyncError(self.comm, ctypes.byref(state)), "ncclCommGetAsyncError")
             if state.value != _NCCL_IN_PROGRESS:
                 self._check(state.value, what)
                 return
-            if time.monotonic() > deadline:
+            now = time.monotonic()
+            if now > deadline:
                 raise TimeoutError(f"StreamAllReduce: {what} still in progress at its deadline")
-            time.sleep(0.002)
+            if now >= spin_until:
+                time.sleep(0.002 if spin == 0.0 else 0.0002)
 
     def _check(self, rc, what):
         if rc != 0:
@@ -160,7 +166,7 @@ class StreamAllReduce:
         rc = self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), 7, 0, self.comm, st)   # ncclFloat32, ncclSum
         if rc == _NCCL_IN_PROGRESS:                      # a non-blocking communicator may hand the enqueue back unfinished
             import time
-            self._wait(time.monotonic() + 30.0, "ncclAllReduce")
+            self._wait(time.monotonic() + 30.0, "ncclAllReduce", spin=0.005)          # busy-poll: the enqueue completes within microseconds
         else:
             self._check(rc, "ncclAllReduce")
         return t
@@ -171,9 +177,35 @@ class StreamAllReduce:
             self.comm = None
 
     def close(self):
+        """orderly end of a communicator every rank still holds: ncclCommFinalize (non-blocking communicators must be finalised
+        before they are destroyed), polled against a short deadline, then ncclCommDestroy; anything else — abort"""
         if getattr(self, "comm", None):
-            self.lib.ncclCommDestroy(self.comm)
-            self.comm = None
+            import time
+            try:
+                fin = getattr(self.lib, "ncclCommFinalize", None)
+                if fin is not None:
+                    fin.argtypes = [ctypes.c_void_p]
+                    rc = fin(self.comm)
+                    if rc not in (0, _NCCL_IN_PROGRESS):
+                        self._check(rc, "ncclCommFinalize")
+                    self._wait(time.monotonic() + 5.0, "ncclCommFinalize")
+                self.lib.ncclCommDestroy(self.comm)
+                self.comm = None
+            except Exception:  # noqa: BLE001
+                self.abort()
+
+
+def _sync_bounded(dev, deadline):
+    """wait for the current stream of `dev` WITH a deadline (torch.cuda.synchronize() has none): an event polled with query()"""
+    import time
+    if dev.type != "cuda":
+        return
+    ev = torch.cuda.Event()
+    ev.record()
+    while not ev.query():
+        if time.monotonic() > deadline:
+            raise TimeoutError("the direct all-reduce of the test vector did not complete before the deadline")
+        time.sleep(0.001)
 
 
 def _broadcast_id(raw, group, dev):
@@ -231,12 +263,16 @@ def negotiate_stream_all_reduce(group, dev, factory, timeout=30.0, check_numel=4
         y = x.clone()
         dist.all_reduce(x, group=group)
         sar.all_reduce_(y)
-        if dev.type == "cuda":
-            torch.cuda.synchronize()
+        # bounded: a rank whose direct all-reduce never completes (a peer failed inside it) must still reach the MIN below — it aborts
+        # its communicator there, which also releases the enqueued collective (torch.cuda.synchronize() has no deadline)
+        import time
+        _sync_bounded(dev, time.monotonic() + float(timeout))
         ok = bool(torch.allclose(x, y, rtol=1e-6, atol=1e-6))
     except Exception as e:  # noqa: BLE001
         ok = False
         say(f"verification failed on this rank: {e}")
+    if not ok:
+        sar.abort()                                      # BEFORE the agreement: it frees this rank's stream if the collective is stuck
     if not _agree(ok, group, dev):
         sar.abort()
         return group, "verify"

@@ -64,3 +64,26 @@ def sort_items(items, alphas):
     key = ((it[:, 2] * 100000 + it[:, 1]) * 100000 + it[:, 0]) * 2 + ((it[:, 3] >> 2) & 1)
     o = torch.argsort(key)
     return it[o], al[o]
+
+
+def load_demo_capture(device="cpu"):
+    """The reference's own capture (/root/reference/demo_data/1) from the committed fixtures (tests/golden/make_demo_fixture.py,
+    make_capture_fixture.py; arrays only): imgs [16,1024,1280,3] (BGR / 255, background zeroed by the mask), grayimgs, masks, w2cs,
+    projs exactly as /root/reference/get_data.py:49-118 hands them to the loop, the capture's 42 three-D keypoints, and the two MANO
+    template meshes (778 / 1 538)."""
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cam, cap = np.load(os.path.join(gdir, "demo_ingest.npz")), np.load(os.path.join(gdir, "demo_capture.npz"))
+    W, H = int(cap["res"][0]), int(cap["res"][1])
+    n = cap["boxes"].shape[0]
+    img8 = np.zeros((n, H, W, 3), np.uint8)
+    mask = np.zeros((n, H, W), np.float32)
+    for i, (y0, y1, x0, x1) in enumerate(cap["boxes"]):
+        img8[i, y0:y1, x0:x1] = cap["img%02d" % i]
+        mask[i, y0:y1, x0:x1] = cap["mask%02d" % i]
+    gray8 = np.round(0.114 * img8[..., 0].astype(np.float64) + 0.587 * img8[..., 1] + 0.299 * img8[..., 2]).astype(np.uint8)   # COLOR_BGR2GRAY, get_data.py:83
+    t = lambda a: torch.from_numpy(a).to(device)
+    return dict(imgs=t(img8.astype(np.float32) / np.float32(255.)), grayimgs=t(gray8.astype(np.float32) / np.float32(255.)), masks=t(mask),
+                w2cs=t(cam["w2cs"].copy()), projs=t(cam["projs"].copy()), keypoints=cam["keypoints"].astype(np.float64), res=(H, W),
+                templates={s: (cap["template_%s_v" % s].astype(np.float64), cap["template_%s_f" % s].astype(np.int64)) for s in ("right", "left")},
+                img_sum=cam["img_sum"], mask_sum=cam["mask_sum"], gray_sum=cam["gray_sum"])
