@@ -323,6 +323,31 @@ def run_ham_stage2_side_measurement(scene_c, batch, dev, stream, epochs_timed, p
             "iterations_timed": epochs_timed * steps_per_epoch, "aa_items_last_step": aa_loop}
 
 
+def import_swap_side_measurement(scene_c, dev, views=None, iters=5):
+    """Not the headline metric: the import-swap experience of INTEGRATION.md — the stage-2 loop body of mesh_sfs_optim.py:253-308 on the
+    generic fmhr_amd.dr / fmhr_amd.utils ops with torch autograd, op by op (tests/test_gpu_ham.py::_loop_body_on_dr is the restated body
+    the parity test runs), ms per iteration on this workload by the host clock (the path synchronises: torch.where, .item())."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_ham import _loop_body_on_dr
+    n, H, W = views or scene_c["views"], scene_c["H"], scene_c["W"]
+    faces = scene_c["faces"].to(dev)
+    w2c, proj = scene_c["w2c"][:n].contiguous().to(dev), scene_c["proj"][:n].contiguous().to(dev)
+    sc = dict(scene_c, views=n, sh_true=scene_c["sh_true"][:n], sh0=scene_c["sh0"][:n], w2c=scene_c["w2c"][:n], proj=scene_c["proj"][:n])
+    tg = synthetic.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, H, W), device=dev)
+    g = dict(vertices=sc["vertices"].to(dev), delta=torch.zeros_like(sc["vertices"]).to(dev), albedo=sc["albedo0"].to(dev), sh0=sc["sh0"].to(dev),
+             w2c=w2c, proj=proj, img=tg["img"], mask=tg["mask"], valid_mask=tg["valid_mask"])
+    elm = edge_length_mean(g["vertices"], faces)
+    for _ in range(2):
+        _loop_body_on_dr(g, faces, n, H, W, sc["weights"], elm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        _loop_body_on_dr(g, faces, n, H, W, sc["weights"], elm)
+    torch.cuda.synchronize()
+    return {"what": f"mesh_sfs_optim.py:253-308 op by op on fmhr_amd.dr + fmhr_amd.utils with torch autograd (the two-line import swap), {n} views x {H}x{W}",
+            "import_swap_ms": round(1e3 * (time.perf_counter() - t0) / iters, 2), "iterations": iters}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -665,6 +690,11 @@ def main():
                 out["run_ham_stage2"] = rh
             except Exception as e:  # noqa: BLE001
                 out["run_ham_stage2"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and nf_local == 1 and not args.no_run_ham and not args.no_run_length:
+            try:
+                out["import_swap"] = import_swap_side_measurement(scene_caller, dev)
+            except Exception as e:  # noqa: BLE001
+                out["import_swap"] = {"error": f"{type(e).__name__}: {e}"}
         # the two side measurements must never cost the headline line: a failure is reported in their place
         if world == 1 and not args.no_stage1:
             try:

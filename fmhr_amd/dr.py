@@ -22,6 +22,16 @@ class RasterizeGLContext:
         self._topo_key = None
         self._tri_ref = None     # keeps the keyed tensor alive so its address cannot be reused by another tensor
         self._opp = None
+        self._scratch = {}       # reusable scratch by (name, device): the rasterizer's key / queue workspace
+
+    def scratch(self, name, nbytes, device):
+        """a uint8 scratch buffer of at least `nbytes`, owned by the context and reused by every call that asks for `name` (round 5: a
+        48-view 512 x 512 rasterize allocated 138 MB of depth keys + queue per call; what a call leaves in it is dead when it returns)"""
+        key = (name, device)
+        buf = self._scratch.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self._scratch[key] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        return buf
 
     def opp_table(self, tri, V):
         """edge -> opposite-vertex table for antialias, rebuilt only when the triangle tensor changes."""
@@ -56,12 +66,12 @@ def _check_tri(name, tri, device):
 
 class _RasterizeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pos, tri, H, W):
+    def forward(ctx, pos, tri, H, W, glctx):
         n, V, _ = pos.shape
         F = tri.shape[0]
         rast = torch.empty(n, H, W, 4, dtype=torch.float32, device=pos.device)
         nb = _lib.load().fmhr_rasterize_workspace_bytes(n, V, F, H, W)
-        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=pos.device)
+        ws = (glctx if isinstance(glctx, RasterizeGLContext) else _ctx()).scratch("rasterize", nb, pos.device)
         call("fmhr_rasterize_fwd", ptr(pos), ptr(tri), n, V, F, H, W, ptr(rast), ptr(ws), nb, stream_ptr(pos.device))
         ctx.save_for_backward(pos, tri, rast)
         return rast
@@ -75,7 +85,7 @@ class _RasterizeFn(torch.autograd.Function):
         gpos = torch.zeros_like(pos)
         call("fmhr_rasterize_bwd", ptr(pos), ptr(tri), ptr(rast), ptr(dy), n, V, tri.shape[0], H, W, ptr(gpos),
              stream_ptr(pos.device))
-        return gpos, None, None, None
+        return gpos, None, None, None, None
 
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
@@ -89,7 +99,7 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     tri = _check_tri("rasterize", tri, pos.device)
     if len(resolution) != 2 or int(resolution[0]) <= 0 or int(resolution[1]) <= 0:
         raise RuntimeError("rasterize: resolution must be (height, width) > 0")
-    rast = _RasterizeFn.apply(pos, tri, int(resolution[0]), int(resolution[1]))
+    rast = _RasterizeFn.apply(pos, tri, int(resolution[0]), int(resolution[1]), glctx)
     # rast_db (the barycentrics' screen-space derivatives) is discarded at every call site of the reference (`rast_out, _ =`): a
     # zero tensor of the right shape WITHOUT its 16 B per pixel — one element expanded (a 48-view 512 x 512 call used to allocate
     # and zero-fill 200 MB here)
@@ -143,12 +153,21 @@ class _AntialiasFn(torch.autograd.Function):
         V = pos.shape[1]
         dev = color.device
         out = torch.empty_like(color)
-        cap = max(n * H * W, 1)
-        items = torch.empty(cap, 4, dtype=torch.int32, device=dev)
-        alphas = torch.empty(cap, dtype=torch.float32, device=dev)
-        counter = torch.zeros(4, dtype=torch.int32, device=dev)
-        call("fmhr_antialias_fwd", ptr(color), ptr(rast), ptr(pos), ptr(tri), ptr(opp), n, V, tri.shape[0], H, W, C, ptr(out),
-             ptr(items), ptr(alphas), ptr(counter), cap, stream_ptr(dev))
+        # the work items are the pixel pairs that BLEND (one per silhouette crossing): a list of n*H*W / 8 entries (20 B each) holds any
+        # silhouette a mesh can draw; the kernel flags an overflow instead of writing past it, and the call is repeated once with the
+        # full bound (every horizontal + vertical pair) in that case.  (Round 4 allocated n*H*W entries — 252 MB at 48 x 512 x 512 — for
+        # ~50 k items on EVERY call; the backward needs the list, so it cannot live in the context: two antialias calls per iteration
+        # are alive at once)
+        cap = max(n * H * W // 8, 4096)
+        while True:
+            items = torch.empty(cap, 4, dtype=torch.int32, device=dev)
+            alphas = torch.empty(cap, dtype=torch.float32, device=dev)
+            counter = torch.zeros(4, dtype=torch.int32, device=dev)
+            call("fmhr_antialias_fwd", ptr(color), ptr(rast), ptr(pos), ptr(tri), ptr(opp), n, V, tri.shape[0], H, W, C, ptr(out),
+                 ptr(items), ptr(alphas), ptr(counter), cap, stream_ptr(dev))
+            if cap >= 2 * n * H * W or int(counter[1]) == 0:        # (the flag is read back: this op-by-op path synchronises per call anyway — its callers' torch.where does)
+                break
+            cap = 2 * n * H * W
         ctx.save_for_backward(color, rast, pos, tri, items, alphas, counter)
         ctx.cap = cap
         return out
