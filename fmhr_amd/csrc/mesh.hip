@@ -886,7 +886,10 @@ k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta,
            const int32_t* __restrict__ view_idx, const float* __restrict__ sh, float* __restrict__ sh_local)
 {
     // the step counter that tags this step's coverage entries and owner marks (raster.hip, shade.hip): advanced by the step's first kernel
-    if (stamp != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamp[0] = stamp[0] + 1;
+    if (stamp != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        stamp[0] = stamp[0] + 1;
+        stamp[2] = 0;                                                // cursor of the step's list of segments with fragments (raster.hip: k_bins_compact)
+    }
     const int rows_normals = (int)gridDim.y - n;                     // dispatched first: their long dependent chains start early
     if ((int)blockIdx.y >= rows_normals)
         transform_body<HAS_DELTA>(blockIdx.x * kBlock + threadIdx.x, (int)blockIdx.y - rows_normals, verts_tmp, delta, w2c, proj, V, pos, H, W, snap,

@@ -936,64 +936,109 @@ constexpr int kBinsBlock = FMHR_BINS_BLOCK;      // threads per workgroup of k_r
 #ifndef FMHR_BINS_WAVES
 #define FMHR_BINS_WAVES 8
 #endif
-__global__ void __launch_bounds__(kBinsBlock) __attribute__((amdgpu_waves_per_eu(FMHR_BINS_WAVES, 8)))
-k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int Wp, const BinArgs ba, unsigned long long* __restrict__ covw,
-              int* __restrict__ large_cnt, const RasterFused fu, const PixGrid pg)
+// ---- round 5: the second pass over a COMPACTED list of the segments that hold fragments.  With one wave launched per segment 70 % of the
+// waves of the metric step (85 % at 48 x 1024 x 1024) find an empty segment and leave — 137 k (670 k) launches that each take a wave slot for a
+// scalar round trip; k_bins_compact (one lane per segment over the packed state words: 0.8 / 3 MB) lists the segments whose state word the
+// triangle kernel marked, does the empty segments' housekeeping (words that were live last step are zeroed) and the second pass runs as
+// 8 192 persistent waves over that list (LIST = true) where the launch is large (rasterize_fwd_impl); else one wave per segment as before.
+constexpr int kCompactBlock = 1024;
+__global__ void __launch_bounds__(kCompactBlock)
+k_bins_compact(const BinArgs ba, long long nSeg, unsigned long long* __restrict__ covw, int* __restrict__ seg_valid, int2* __restrict__ list,
+               int* __restrict__ list_cnt)
 {
-    __shared__ unsigned long long lkey_all[kBinsBlock];
-    __shared__ BinEntry chunk_all[(kBinsBlock / 64) * kBinChunk];
-    static_assert(kBinChunk % 64 == 0 && kBinChunk <= 256, "8-bit entry index in the LDS key");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long* const lkey = lkey_all + wv * 64;             // this wave's pixels
-    BinEntry* const chunk = chunk_all + wv * kBinChunk;
-    const long long gid = (long long)blockIdx.x * kBinsBlock + tid;
-    const long long seg = (long long)blockIdx.x * (kBinsBlock / 64) + wv;
-    if (gid == 0) {                                                  // rearm the list cursors of the kernels after this one (as the resolve pass does)
-        large_cnt[1] = large_cnt[0];
-        large_cnt[0] = 0;
-        if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
-        if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
-        int* const ov = bin_overflow_word(ba);                       // the triangle kernel's overflow word -> the sticky flag the host reads
-        if (*ov != 0) { *ov = 0; if (fu.bin_flag != nullptr) *fu.bin_flag = 1; }
-    }
-    const long long P = (long long)H * Wp;
-    if (seg * 64 >= (long long)n * P) return;
-    // the segment's state word first (packed, hits; BinArgs): an empty segment whose words are already zero leaves here
-    int* const stp = seg_state_word(ba, seg);
-    int state = *(const_as4_int*)(unsigned long long)stp;
-    // (ABI 6) the segment's view in the caller's arrays, requested WITH the state word: behind the waits below it was one more scalar
-    // round trip in front of the mask load of every non-empty segment
-    int src_delta = 0;
-    if (fu.sel.idx != nullptr) {
-        const unsigned bsel = udiv((unsigned)seg, fu.sel.segv);
-        src_delta = fu.sel.src(bsel) - (int)bsel;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(state), "+s"(src_delta) : : "memory");   // (the same explicit order as for the count below: this wave stores to the word)
-    if ((state & kSegHasFragments) == 0) {
-        if ((state & kSegWordsLive) != 0 && lane == 0) {
+    constexpr int kWaves = kCompactBlock / 64;
+    __shared__ int wcnt[kWaves];
+    __shared__ int base;
+    const long long seg = (long long)blockIdx.x * kCompactBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool has = false;
+    int count = 0;
+    if (seg < nSeg) {
+        int* const stp = seg_state_word(ba, seg);
+        const int state = *stp;
+        has = (state & kSegHasFragments) != 0;
+        if (has) {
+            // the bin's fragment count, fetched and reset HERE, one lane per segment (60 k cold cursor lines in parallel instead of one
+            // scalar round trip at the head of every second-pass wave): the list entry carries it
+            int* const cur = ba.cursor + (size_t)seg * kCursorStride;
+            count = *cur;
+            *cur = 0;                                                // self-cleaning
+            *stp = kSegWordsLive;
+        } else if ((state & kSegWordsLive) != 0) {                  // had fragments last step, none now: its words go back to zero
             covw[seg] = 0ull;
-            if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;
+            if (seg_valid != nullptr) seg_valid[seg] = 0;
             *stp = 0;
         }
-        return;
     }
-    if (lane == 0) *stp = kSegWordsLive;
-    // the bin's fragment count through the scalar cache (written by the previous kernel's atomics; only this wave resets it)
-    int* const cur = ba.cursor + (size_t)seg * kCursorStride;
-    int count = *(const_as4_int*)(unsigned long long)cur;
-    // EXPLICIT order between this scalar load and the reset store of the same word below: the load comes from the constant address
-    // space (the compiler may move a store across it) and the hardware orders SMEM against VMEM no more than that.  The asm consumes
-    // the loaded register behind an s_waitcnt (the load has returned) and clobbers memory (no store is hoisted above it); the order
-    // no longer hangs on a branch happening to sit in between (round 3: a variant without that branch read its own zero in half of
-    // the segments, a different half in every step).  tests/test_gpu_ham.py::test_bin_cursor_reset_order
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(count) : : "memory");
-    if (count == 0) {
-        if (lane == 0) {
-            covw[seg] = 0ull;
-            if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;
+    const unsigned long long bal = __ballot(has);
+    if (lane == 0) wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int na = 0;
+        for (int i = 0; i < kWaves; i++) na += wcnt[i];
+        base = na ? atomicAdd(list_cnt, na) : 0;                    // one cursor atomic per 1 024 segments
+    }
+    __syncthreads();
+    if (has) {
+        int off = base + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int i = 0; i < wv; i++) off += wcnt[i];
+        list[off] = make_int2((int)seg, count);
+    }
+}
+
+// one segment of the second pass (wave-uniform `seg`); lkey / chunk: the wave's LDS stage.  LIST: the segment comes off the compacted list
+// with its fragment count (k_bins_compact has fetched and reset the cursor and marked the words live): no state word, no cursor here
+template <bool LIST>
+__device__ __forceinline__ void bins_segment(const long long seg, const int count_in, const int lane, unsigned long long* const lkey, BinEntry* const chunk,
+                                             const int32_t* __restrict__ tri, const int n, const int F, const int H, const int W, const int Wp,
+                                             const BinArgs& ba, unsigned long long* __restrict__ covw, const RasterFused& fu, const PixGrid& pg)
+{
+    const long long P = (long long)H * Wp;
+    const long long gid = seg * 64 + lane;
+    if (seg * 64 >= (long long)n * P) return;
+    int src_delta = 0, count = count_in;
+    if (LIST) {
+        if (fu.sel.idx != nullptr) {                                 // (ABI 6) the segment's view in the caller's arrays
+            const unsigned bsel = udiv((unsigned)seg, fu.sel.segv);
+            src_delta = fu.sel.src(bsel) - (int)bsel;
         }
-        return;
+    } else {
+        // the segment's state word first (packed, hits; BinArgs): an empty segment whose words are already zero leaves here
+        int* const stp = seg_state_word(ba, seg);
+        int state = *(const_as4_int*)(unsigned long long)stp;
+        // (ABI 6) the segment's view in the caller's arrays, requested WITH the state word: behind the waits below it was one more scalar
+        // round trip in front of the mask load of every non-empty segment
+        if (fu.sel.idx != nullptr) {
+            const unsigned bsel = udiv((unsigned)seg, fu.sel.segv);
+            src_delta = fu.sel.src(bsel) - (int)bsel;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(state), "+s"(src_delta) : : "memory");   // (the same explicit order as for the count below: this wave stores to the word)
+        if ((state & kSegHasFragments) == 0) {                           // (LIST: cannot happen — the list holds marked segments only)
+            if ((state & kSegWordsLive) != 0 && lane == 0) {
+                covw[seg] = 0ull;
+                if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;
+                *stp = 0;
+            }
+            return;
+        }
+        if (lane == 0) *stp = kSegWordsLive;
+        // the bin's fragment count through the scalar cache (written by the previous kernel's atomics; only this wave resets it)
+        int* const cur = ba.cursor + (size_t)seg * kCursorStride;
+        count = *(const_as4_int*)(unsigned long long)cur;
+        // EXPLICIT order between this scalar load and the reset store of the same word below: the load comes from the constant address
+        // space (the compiler may move a store across it) and the hardware orders SMEM against VMEM no more than that.  The asm consumes
+        // the loaded register behind an s_waitcnt (the load has returned) and clobbers memory (no store is hoisted above it); the order
+        // no longer hangs on a branch happening to sit in between (round 3: a variant without that branch read its own zero in half of
+        // the segments, a different half in every step).  tests/test_gpu_ham.py::test_bin_cursor_reset_order
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(count) : : "memory");
+        if (count == 0) {
+            if (lane == 0) {
+                covw[seg] = 0ull;
+                if (fu.seg_valid != nullptr) fu.seg_valid[seg] = 0;
+            }
+            return;
+        }
+        if (lane == 0) *cur = 0;                                     // self-cleaning (ordered behind the scalar load of the count: above)
     }
     // the caller's mask is [n,H,W]: with a row pitch the segment's row is one scalar division (a pad lane has no mask)
     long long cidx = gid;
@@ -1007,7 +1052,6 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
     const int step_tag = fu.stamp[0];
     const int cnt = min(count, ba.cap);
     const BinEntry* __restrict__ bin = ba.bins + (size_t)seg * ba.cap;
-    if (lane == 0) *cur = 0;                                         // self-cleaning (ordered behind the scalar load of the count: above)
     lkey[lane] = ~0ull;
     unsigned long long best = ~0ull;
     BinEntry win = make_entry(0u, 0.f);
@@ -1113,6 +1157,44 @@ k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int W
         covw[seg] = bal;
         if (fu.seg_valid != nullptr) fu.seg_valid[seg] = __popcll(vbal) | (sbal != 0ull ? 0x100 : 0);
         if (fu.silw != nullptr) fu.silw[seg] = sbal;
+    }
+}
+
+#ifndef FMHR_BINS_LIST_WAVES
+#define FMHR_BINS_LIST_WAVES 8
+#endif
+template <bool LIST>
+__global__ void __launch_bounds__(kBinsBlock) __attribute__((amdgpu_waves_per_eu(LIST ? FMHR_BINS_LIST_WAVES : FMHR_BINS_WAVES, 8)))
+k_raster_bins(const int32_t* __restrict__ tri, int n, int F, int H, int W, int Wp, const BinArgs ba, unsigned long long* __restrict__ covw,
+              int* __restrict__ large_cnt, const RasterFused fu, const PixGrid pg)
+{
+    __shared__ unsigned long long lkey_all[kBinsBlock];
+    __shared__ BinEntry chunk_all[(kBinsBlock / 64) * kBinChunk];
+    static_assert(kBinChunk % 64 == 0 && kBinChunk <= 256, "8-bit entry index in the LDS key");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long* const lkey = lkey_all + wv * 64;             // this wave's pixels
+    BinEntry* const chunk = chunk_all + wv * kBinChunk;
+    if (blockIdx.x == 0 && tid == 0) {                               // rearm the list cursors of the kernels after this one (as the resolve pass does)
+        large_cnt[1] = large_cnt[0];
+        large_cnt[0] = 0;
+        if (fu.rearm2 != nullptr) { fu.rearm2[0] = 0; fu.rearm2[1] = 0; }
+        if (fu.rearm_aa != nullptr) { fu.rearm_aa[0] = 0; fu.rearm_aa[1] = 0; }
+        int* const ov = bin_overflow_word(ba);                       // the triangle kernel's overflow word -> the sticky flag the host reads
+        if (*ov != 0) { *ov = 0; if (fu.bin_flag != nullptr) *fu.bin_flag = 1; }
+    }
+    if (!LIST) {                                                     // one wave per segment
+        bins_segment<false>((long long)blockIdx.x * (kBinsBlock / 64) + wv, 0, lane, lkey, chunk, tri, n, F, H, W, Wp, ba, covw, fu, pg);
+        return;
+    }
+    // persistent waves over the step's list of segments with fragments (k_bins_compact)
+    const int list_n = *(const_as4_int*)(unsigned long long)fu.bin_list_cnt;
+    for (int li = (int)(blockIdx.x * (kBinsBlock / 64)) + wv; li < list_n; li += (int)gridDim.x * (kBinsBlock / 64)) {
+        const_as4_int* const ent = (const_as4_int*)(unsigned long long)(fu.bin_list + li);      // (segment, fragment count): one 8-B scalar load
+        const int eseg = ent[0], ecnt = ent[1];
+        bins_segment<true>((long long)eseg, ecnt, lane, lkey, chunk, tri, n, F, H, W, Wp, ba, covw, fu, pg);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // the wave's LDS stage is reused by its next segment
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1408,7 +1490,20 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
     }
     if (binned) {
         ProfScope ps(FMHR_SLOT_RASTER_RESOLVE, st);
-        k_raster_bins<<<cdiv((long long)nP, kBinsBlock), kBinsBlock, 0, st>>>(tri, n, F, H, W, Wp, ba, covw, large_cnt, fu, pg);
+        // the compacted list pays where the empty segments dominate the launch: same-box A/B (k_raster_bins + k_bins_compact vs
+        // k_raster_bins<false>): 48 x 1024 x 1024 (786 k segments, 85 % empty) 312 -> 244 us, C4 1 040 -> 1 120 it/s; the metric (197 k
+        // segments, 70 % empty) 69 -> 78 + 6 us — 8 192 persistent waves with ~7 segments each end on their slowest wave, while one wave
+        // per segment is scheduled dynamically by the hardware.  FMHR_BINS_LIST=0 / 1 forces either form (same-library A/B)
+        const char* ble = getenv("FMHR_BINS_LIST");
+        const bool use_list = fu.bin_list != nullptr && fu.bin_list_cnt != nullptr && (ble ? atoi(ble) != 0 : ba.tiles >= 400000);
+        if (use_list) {
+            const long long nSeg = (long long)ba.tiles;
+            k_bins_compact<<<cdiv(nSeg, kCompactBlock), kCompactBlock, 0, st>>>(ba, nSeg, covw, fu.seg_valid, (int2*)fu.bin_list, fu.bin_list_cnt);
+            FMHR_CHECK_LAUNCH("k_bins_compact");
+            k_raster_bins<true><<<2048, kBinsBlock, 0, st>>>(tri, n, F, H, W, Wp, ba, covw, large_cnt, fu, pg);
+        } else {
+            k_raster_bins<false><<<cdiv((long long)nP, kBinsBlock), kBinsBlock, 0, st>>>(tri, n, F, H, W, Wp, ba, covw, large_cnt, fu, pg);
+        }
         FMHR_CHECK_LAUNCH("k_raster_bins");
         return FMHR_OK;
     }

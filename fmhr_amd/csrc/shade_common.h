@@ -141,6 +141,7 @@ struct RasterFused {
                                                               // [V,3] vertices and the views' combined matrices (common.h: ClipView),
                                                               // `pos` and `snap` are not read
     BinEntry* bins; int* bin_cursor; int* bin_flag; int bin_cap; // non-null: per-tile fragment bins (raster.hip: binned rasterizer)
+    int2* bin_list; int* bin_list_cnt;                         // round 5: the step's compacted list of segments that hold fragments + its cursor
     UDiv segx;                                                // row pitch != W (ABI 5): division by the segments per row — the caller's
                                                               // `mask` is [n,H,W], the step's own per-pixel buffers are [n,H,pitch]
     ViewSel sel;                                              // ABI 6: the step's views are a subset of the caller's (common.h); sel.idx null = not
