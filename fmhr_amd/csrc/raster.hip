@@ -468,13 +468,17 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         pin(p0); pin(p1); pin(p2);
         // only a triangle that covers a pixel centre can own a pixel, and only an owner's bits are ever read
         const unsigned char sbv = (silh != nullptr) ? silh_bits(s0, s1, s2, q0, q1, q2) : (unsigned char)0;
+#ifndef FMHR_X_NO_SILH_STORE                                          // (measurement builds only: the store classes of this kernel, tools/r5_tris_writes.sh)
         if (silh != nullptr) at32(silh + (size_t)b * F, (unsigned)face()) = sbv;
+#endif
         // coverage entry (face-parallel backward), 8 B: candidate-pixel mask of the box | origin x, y (13 bits each) and width - 1 (6 bits,
         // 63 = the marker entry of a large-box face, which carries the step stamp instead of a box).  A small-box entry needs no
         // stamp: the backward reads it only under a matching owner mark, an owner's entry was written this step, and a stale mark
         // (8 bits) meets a stale entry only to have its candidates fail the owner test
+#ifndef FMHR_X_NO_COV16_STORE
         if (cov16 != nullptr)
             at32(cov16 + (size_t)b * F, (unsigned)face()) = make_int2((int)cm, s.pxa | (s.pya << 13) | ((bw - 1) << 26));
+#endif
         pk0[threadIdx.x] = p0; pk1[threadIdx.x] = p1; pk2[threadIdx.x] = p2;
         pk3[threadIdx.x] = make_int4(face(), __float_as_int(__builtin_amdgcn_rcpf((float)bw)), s.pxa | (s.pya << 16), bw | ((int)sbv << 8));   // (silhouette bits ride along: binned form)
     }
@@ -561,8 +565,10 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
                 const int slot = (int)(e >> 13) & 255;
                 if (have && slot != 255) {
                     const int pos = hcnt[slot] + (int)(e >> 21);
+#ifndef FMHR_X_NO_ENTRY_STORE
                     if (pos < ba.cap) ba.bins[(size_t)bin * ba.cap + pos] = ent;
                     else *bin_overflow_word(ba) = 1;
+#endif
                 }
                 const bool slow = have && slot == 255 && ent.x != kBinInvalid;
                 if (__ballot(slow) != 0ull) bin_append(slow, bin, ent, ba, lane);
