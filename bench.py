@@ -397,7 +397,7 @@ def main():
         s0, s1 = fdist.shard_views(n_total, rank, world)
         # the step's one all-reduce goes straight into RCCL on the step's own stream where that communicator can be had (two cross-stream
         # hand-overs of torch's nccl backend = 14.6 us per call saved); otherwise the torch group itself
-        fgroups = [fdist.make_stream_all_reduce(torch.distributed.group.WORLD) if sharded else None]
+        fgroups = [fdist.make_stream_all_reduce(torch.distributed.group.WORLD, numel=12 * V + 8) if sharded else None]
         view_rank, view_world = rank, world
     n = s1 - s0
     if n == 0:
@@ -534,7 +534,8 @@ def main():
         collective = {"per_rank_ms": {"kernels": [round(float(p[0]), 4) for p in allp], "all_reduce": [round(float(p[1]), 4) for p in allp],
                                       "combine_adam": [round(float(p[2]), 4) for p in allp]},
                       "bytes": int(hs.bucket.numel() * 4), "note": "all_reduce includes the wait for the slowest rank's kernels",
-                      "path": ("ncclAllReduce (RCCL) on the step's own stream" if hasattr(group, "all_reduce_") else
+                      "path": ("one-shot peer-to-peer all-reduce over the direct links (fmhr_peer_all_reduce) on the step's own stream" if type(group).__name__ == "PeerAllReduce" else
+                               "ncclAllReduce (RCCL) on the step's own stream" if hasattr(group, "all_reduce_") else
                                "torch.distributed.all_reduce (the backend's own stream)"),
                       "path_negotiation": list(fdist.make_stream_all_reduce.last)}
     P = H * W

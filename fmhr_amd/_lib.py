@@ -92,6 +92,13 @@ SIGNATURES = {
     "fmhr_stage1_transpose": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "fmhr_sh_normal_equations": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "fmhr_sh_albedo_sums": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "fmhr_peer_handle_bytes": (c_size_t, []),
+    "fmhr_peer_create": (c_int, [c_int, c_int, ctypes.c_longlong, ctypes.POINTER(c_void_p)]),
+    "fmhr_peer_export": (c_int, [P, P]),
+    "fmhr_peer_import": (c_int, [P, c_int, P]),
+    "fmhr_peer_all_reduce": (c_int, [P, P, ctypes.c_longlong, P]),
+    "fmhr_peer_status": (c_int, [P, ctypes.POINTER(c_int)]),
+    "fmhr_peer_destroy": (c_int, [P]),
     "fmhr_stage1_step_workspace_bytes": (c_size_t, [ctypes.POINTER(Stage1Plan)]),
     "fmhr_stage1_step": (c_int, [ctypes.POINTER(Stage1Plan), P, P, P, c_float, P, P, P, ctypes.POINTER(AdamParam),
                                  ctypes.POINTER(AdamParam), P, c_size_t, P]),

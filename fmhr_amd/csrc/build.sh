@@ -4,7 +4,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libfmhr_ham.so
-SRCS="abi.cpp raster.hip antialias.hip mesh.hip shade.hip ncc.hip ham_step.hip stage1.hip"
+SRCS="abi.cpp raster.hip antialias.hip mesh.hip shade.hip ncc.hip ham_step.hip stage1.hip peer.hip"
 NEW=0
 for f in $SRCS common.h shade_common.h adam.h ../../include/fmhr_ham.h build.sh; do
   if [ ! -f "$OUT" ] || [ "$f" -nt "$OUT" ]; then NEW=1; fi

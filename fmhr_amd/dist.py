@@ -279,8 +279,126 @@ def negotiate_stream_all_reduce(group, dev, factory, timeout=30.0, check_numel=4
     return sar, None
 
 
-def make_stream_all_reduce(group=None, check_numel=4099, timeout=None, log=None):
-    """-> a StreamAllReduce for `group`, or `group` itself (the torch path) when the direct communicator cannot be had on EVERY rank:
+class PeerAllReduce:
+    """The step's ONE exchange as a one-shot peer-to-peer all-reduce over the direct xGMI links (fmhr_amd/csrc/peer.hip:
+    fmhr_peer_*): every rank exports a block of uncached device memory by IPC handle, maps the peers' blocks, and one launch per rank on
+    the STEP'S OWN STREAM stages the bucket, reduces the rank's shard straight out of the peers' memory and gathers the reduced shards —
+    two flag exchanges instead of the 2 (G - 1) dependent hops of a ring; every wait inside the kernel is bounded.  Same calling surface
+    as StreamAllReduce (`all_reduce_(tensor, stream)`, `close()`), so HamStage2.step(group=<this object>) uses it as it stands.  The
+    tensor must be the `numel` float32 elements the object was negotiated for (the step's bucket: 12 V + 8).
+    Set up by negotiate_peer_all_reduce — phase by phase over the torch group, like the RCCL communicator."""
+
+    def __init__(self, group, numel):
+        from . import _lib
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.numel = int(numel)
+        self._lib = _lib
+        self.state = ctypes.c_void_p()
+        self.hbytes = int(_lib.load().fmhr_peer_handle_bytes())
+
+    def create(self):
+        self._lib.call("fmhr_peer_create", self.rank, self.world, self.numel, ctypes.byref(self.state))
+
+    def handle(self):
+        buf = ctypes.create_string_buffer(self.hbytes)
+        self._lib.call("fmhr_peer_export", self.state, buf)
+        return bytes(buf.raw)
+
+    def import_peers(self, handles):
+        for p, h in enumerate(handles):
+            if p != self.rank:
+                self._lib.call("fmhr_peer_import", self.state, p, ctypes.create_string_buffer(bytes(h), self.hbytes))
+
+    def all_reduce_(self, t, stream=None):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != self.numel:
+            raise RuntimeError(f"PeerAllReduce.all_reduce_: the contiguous float32 GPU tensor of {self.numel} elements it was set up for is required")
+        st = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
+        st = st.value if isinstance(st, ctypes.c_void_p) else st
+        self._lib.call("fmhr_peer_all_reduce", self.state, ctypes.c_void_p(t.data_ptr()), self.numel, ctypes.c_void_p(st))
+        return t
+
+    def gave_up(self):
+        """True if a wait inside any all-reduce so far ran into its bound (synchronises): the object must not be used again"""
+        flag = ctypes.c_int(0)
+        self._lib.call("fmhr_peer_status", self.state, ctypes.byref(flag))
+        return flag.value != 0
+
+    def abort(self):
+        self.close()
+
+    def close(self):
+        if self.state:
+            self._lib.load().fmhr_peer_destroy(self.state)
+            self.state = ctypes.c_void_p()
+
+
+def negotiate_peer_all_reduce(group, dev, numel, factory=None, timeout=30.0, log=None):
+    """PeerAllReduce for `group` or None, agreed phase by phase — every collective below is a torch collective every rank enters whatever
+    happened to it locally, and nothing in between waits for a peer on the host:
+      1. create() locally (allocate + export);  2. all_gather of the 64-byte handles;  3. MIN(created);
+      4. import the peers' blocks (local calls);  5. MIN(imported);
+      6. the one-shot all-reduce of a test vector must reproduce torch's — its completion is awaited with a DEADLINE (the kernel's own
+         waits are bounded too);  7. MIN(verified).
+    Returns (object or None, reason)."""
+    say = log or (lambda m: None)
+    world = dist.get_world_size(group)
+    par, ok = None, True
+    try:
+        par = (factory or PeerAllReduce)(group, numel)
+        par.create()
+        mine = par.handle()
+    except Exception as e:  # noqa: BLE001
+        ok, mine = False, bytes(64)
+        say(f"peer all-reduce: create failed on this rank: {e}")
+    hb = len(mine)
+    hdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")        # (gloo gathers host tensors only)
+    t = torch.tensor(list(mine), dtype=torch.uint8, device=hdev)
+    allh = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allh, t, group=group)
+    if not _agree(ok, group, dev):
+        if par is not None and ok:
+            par.close()
+        return None, "peer-create"
+    try:
+        par.import_peers([bytes(h.cpu().tolist())[:hb] for h in allh])
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        say(f"peer all-reduce: import failed on this rank: {e}")
+    if not _agree(ok, group, dev):
+        par.close()
+        return None, "peer-import"
+    try:
+        import time
+        g = torch.Generator(device="cpu").manual_seed(4321 + dist.get_rank(group))
+        x = torch.randn(numel, generator=g).to(dev)
+        y = x.clone()
+        dist.all_reduce(x, group=group)
+        par.all_reduce_(y)
+        _sync_bounded(dev, time.monotonic() + float(timeout))
+        ok = (not par.gave_up()) and bool(torch.allclose(x, y, rtol=1e-5, atol=1e-5))
+        # ... and three more with fresh data each: the flags carry the call count, and a rank that served a peer's block of the
+        # PREVIOUS call out of a cache would show here
+        for k in range(3):
+            x = torch.randn(numel, generator=g).to(dev)
+            y = x.clone()
+            dist.all_reduce(x, group=group)
+            par.all_reduce_(y)
+            _sync_bounded(dev, time.monotonic() + float(timeout))
+            ok = ok and (not par.gave_up()) and bool(torch.allclose(x, y, rtol=1e-5, atol=1e-5))
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        say(f"peer all-reduce: verification failed on this rank: {e}")
+    if not _agree(ok, group, dev):
+        par.close()
+        return None, "peer-verify"
+    return par, None
+
+
+def make_stream_all_reduce(group=None, check_numel=4099, timeout=None, log=None, numel=None):
+    """-> the fastest exchange every rank of `group` could set up for the step's bucket of `numel` floats: a PeerAllReduce (one-shot
+    peer-to-peer over the direct links; needs `numel`; FMHR_PEER_ALLREDUCE=0 switches it off), else a StreamAllReduce (RCCL on the step's
+    stream), else `group` itself (the torch path).  The RCCL communicator cannot be had on EVERY rank:
     negotiate_stream_all_reduce above — agreed phase by phase over the torch group, the RCCL initialisation non-blocking and bounded
     (FMHR_STREAM_ALLREDUCE_TIMEOUT seconds, default 30), no rank ever left inside it.  FMHR_STREAM_ALLREDUCE=0 switches it off.
     `make_stream_all_reduce.last` = (path, reason) of the last call, for the bench line."""
@@ -290,8 +408,15 @@ def make_stream_all_reduce(group=None, check_numel=4099, timeout=None, log=None)
     dev = torch.device("cuda", torch.cuda.current_device())
     if timeout is None:
         timeout = float(os.environ.get("FMHR_STREAM_ALLREDUCE_TIMEOUT", "30"))
+    peer_why = "no bucket size given"
+    if numel is not None and os.environ.get("FMHR_PEER_ALLREDUCE", "1") != "0":
+        par, peer_why = negotiate_peer_all_reduce(group, dev, int(numel), timeout=timeout, log=log)
+        if par is not None:
+            make_stream_all_reduce.last = ("peer-to-peer one-shot on the step's stream", None)
+            return par
     out, why = negotiate_stream_all_reduce(group, dev, lambda g: StreamAllReduce(g, _connect=False), timeout, check_numel, log)
-    make_stream_all_reduce.last = ("rccl-on-step-stream", None) if why is None else ("torch", f"fell back at phase '{why}'")
+    make_stream_all_reduce.last = (("rccl-on-step-stream", f"peer-to-peer not used: {peer_why}") if why is None else
+                                   ("torch", f"fell back at phase '{why}' (peer-to-peer: {peer_why})"))
     return out
 
 

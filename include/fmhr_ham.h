@@ -321,6 +321,29 @@ int fmhr_sh_normal_equations(const float* normals, const float* rast, const floa
 int fmhr_sh_albedo_sums(const float* normals, const float* rast, const float* mask, const float* img, const float* sh, int n,
                         int H, int W, int nblk, double* part, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ one-shot peer-to-peer all-reduce
+ * the view-sharded step's ONE exchange (the 12V+8 bucket of fmhr_ham_backward / fmhr_ham_combine) as one launch per rank
+ * over the direct xGMI links instead of a ring: every rank exports a block of uncached device memory (staging copy of its bucket, its
+ * reduced shard, arrival flags) by hipIpcGetMemHandle, maps the peers' blocks, and fmhr_peer_all_reduce stages, reduces its shard from
+ * all ranks' staging blocks (fixed rank order: bit-identical results on every rank) and gathers the peers' reduced shards — two flag
+ * exchanges, every wait bounded (a dead peer ends in an error the host reads, not in a hung GPU).  One process per GPU; the handles (64
+ * bytes each) travel over the caller's own channel (fmhr_amd/dist.py: one all_gather of torch.distributed).  Replaces ncclAllReduce of
+ * the bucket where every rank could set it up (negotiated, RCCL is the fallback).
+ *   fmhr_peer_create      allocate + initialise this rank's block for a bucket of n_floats floats (a multiple of 4); world <= 16
+ *   fmhr_peer_export      this rank's 64-byte IPC handle (fmhr_peer_handle_bytes)
+ *   fmhr_peer_import      map peer `peer`'s block from its handle (every peer but oneself, once)
+ *   fmhr_peer_all_reduce  in-place SUM of `bucket` (this rank's device memory, 16-byte aligned) over the ranks, enqueued on `stream`;
+ *                         every rank must call it the same number of times (the flags carry the call count)
+ *   fmhr_peer_status      *gave_up = 1 if a wait of any call so far ran into its bound (synchronises; the state is unusable afterwards)
+ *   fmhr_peer_destroy     unmap, free */
+size_t fmhr_peer_handle_bytes(void);
+int fmhr_peer_create(int rank, int world, long long n_floats, void** state_out);
+int fmhr_peer_export(void* state, void* handle_out);
+int fmhr_peer_import(void* state, int peer, const void* handle);
+int fmhr_peer_all_reduce(void* state, float* bucket, long long n_floats, void* stream);
+int fmhr_peer_status(void* state, int* gave_up);
+int fmhr_peer_destroy(void* state);
+
 /* ------------------------------------------------------------------------------------------------ per-kernel timing (optional)
  * Attach an array of 2*FMHR_SLOT_COUNT hipEvent_t (created by the caller with timing enabled) to the CALLING THREAD: while
  * attached, fmhr_ham_forward/backward record events[2*slot] / events[2*slot+1] around launch group `slot` on the step's

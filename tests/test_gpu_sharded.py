@@ -103,6 +103,78 @@ def test_two_ranks_one_gpu_match_single_rank():
     assert rel_err(gd, gd1.cpu()) < 5e-5 and rel_err(ga, ga1.cpu()) < 5e-5
 
 
+def _peer_worker(rank, world, port, q, dims=(6, 128, 96, 21, 37, 1)):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from fmhr_amd import dist as fdist
+    fdist.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    sc, tg, faces, w2c, proj = _scene(dims)
+    why_log = []
+    par, why = fdist.negotiate_peer_all_reduce(dist.group.WORLD, dev, 12 * sc["V"] + 8, timeout=20.0, log=why_log.append)
+    out = dict(why=why, log=why_log, type=type(par).__name__)
+    if par is not None:
+        s0, s1 = fdist.shard_views(sc["views"], rank, world)
+        rr = fdist.shard_views(sc["V"], rank, world)
+        ls, gd, ga = _run(sc, tg, faces, w2c, proj, s0, s1, par, rr)
+        torch.cuda.synchronize()
+        out["first"] = (ls.cpu().numpy(), gd.cpu().numpy(), ga.cpu().numpy())
+        # a dozen more exchanges on the same object (the flags carry the call count), every one checked against torch's all-reduce
+        g = torch.Generator().manual_seed(7 + rank)
+        worst = 0.0
+        for k in range(12):
+            x = torch.randn(12 * sc["V"] + 8, generator=g).to(dev)
+            y = x.clone()
+            dist.all_reduce(x)
+            par.all_reduce_(y)
+            torch.cuda.synchronize()
+            worst = max(worst, float((x - y).abs().max() / x.abs().max()))
+        out["worst"] = worst
+        out["gave_up"] = par.gave_up()
+        # every rank holds the same bits (each element is summed by exactly one rank, in rank order)
+        chk = y.double().sum().reshape(1).cpu()
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        out["same_bits"] = bool(all(torch.equal(b, both[0]) for b in both))
+        par.close()
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_one_gpu_through_the_one_shot_peer_all_reduce():
+    """the step's exchange as a ONE-SHOT peer-to-peer all-reduce (fmhr_amd/csrc/peer.hip) rehearsed the
+    only way a one-GPU box allows — two processes on one GPU, each other's exported block mapped through IPC handles (the same calls map a
+    peer GPU's memory over xGMI): negotiated phase by phase over the torch group, the sharded step through it against the single-rank step,
+    twelve more exchanges against torch's all-reduce, no wait ran into its bound, both ranks hold the same bits."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import log_parity, rel_err
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = _get(q, procs, 500)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out["why"] is None and out["type"] == "PeerAllReduce", (out["why"], out["log"])
+    ls, gd, ga = (torch.from_numpy(x) for x in out["first"])
+    sc, tg, faces, w2c, proj = _scene()
+    l1, gd1, ga1 = _run(sc, tg, faces, w2c, proj, 0, sc["views"], None, None)
+    e = (rel_err(ls[:7], l1[:7].cpu()), rel_err(gd, gd1.cpu()), rel_err(ga, ga1.cpu()))
+    log_parity("one-shot peer-to-peer all-reduce (2 processes on one GPU, IPC-mapped blocks): sharded 3 + 3 views vs one rank: losses %.1e gdelta %.1e "
+               "galbedo %.1e | 12 exchanges vs torch's all-reduce: worst %.1e, same bits on both ranks: %s" % (e + (out["worst"], out["same_bits"])))
+    assert float(ls[7]) == float(l1[7]) and float(l1[7]) > 1000
+    assert e[0] < 1e-5 and e[1] < 5e-5 and e[2] < 5e-5, e
+    assert out["worst"] < 1e-6 and not out["gave_up"] and out["same_bits"]
+
+
 METRIC12 = (12, 512, 512, "mano", 0, 3)
 
 
@@ -217,7 +289,12 @@ def _rccl_worker(port, q):
     direct = fdist.make_stream_all_reduce(dist.group.WORLD)
     say("direct communicator: " + type(direct).__name__)
     out["direct_type"] = type(direct).__name__
-    for name, group in (("sharded", dist.group.WORLD), ("direct", direct), ("plain", None)):
+    # ... and with the bucket size given: the one-shot peer-to-peer all-reduce is negotiated first (a world of one: no peer to map,
+    # the whole launch — staging, grid barriers, shard reduction, gather — still runs)
+    peer = fdist.make_stream_all_reduce(dist.group.WORLD, numel=12 * sc["V"] + 8)
+    say("with the bucket size: " + type(peer).__name__ + " " + str(fdist.make_stream_all_reduce.last))
+    out["peer_type"] = type(peer).__name__
+    for name, group in (("sharded", dist.group.WORLD), ("direct", direct), ("peer", peer), ("plain", None)):
         hs = HamStage2(faces, sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], edge_length_mean(vt, faces))
         delta = sc["delta"].clone().requires_grad_(True)
         albedo = sc["albedo0"].to(dev).clone().requires_grad_(True)
@@ -241,6 +318,9 @@ def _rccl_worker(port, q):
     say("stage 1 done")
     if hasattr(direct, "close"):
         direct.close()
+    if hasattr(peer, "close"):
+        out["peer_gave_up"] = peer.gave_up() if hasattr(peer, "gave_up") else None
+        peer.close()
     dist.barrier()
     say("barrier done")
     q.put(out)
@@ -281,5 +361,12 @@ def test_rccl_backend_world_of_one_through_the_sharded_step():
     log_parity("RCCL on the step's own stream (StreamAllReduce, world of one) vs plain step, first step: losses %.1e gdelta %.1e galbedo %.1e | "
                "vs the torch.distributed path after 12 steps: max %.1e" % (tuple(ed) + (max(ed12),)))
     assert max(ed) < 5e-5 and ed12[0] < 1e-4 and max(ed12[1:3]) < 2e-3 and max(ed12[3:]) < 5e-4, (ed, ed12)
+    # the same step through the one-shot peer-to-peer all-reduce (fmhr_amd.dist.PeerAllReduce)
+    assert out["peer_type"] == "PeerAllReduce" and out["peer_gave_up"] is False, (out["peer_type"], out.get("peer_gave_up"))
+    ep = [rel_err(torch.from_numpy(x), torch.from_numpy(y)) for x, y in zip(out["peer_first"], out["plain_first"])]
+    ep12 = [rel_err(torch.from_numpy(x), torch.from_numpy(y)) for x, y in zip(out["peer"], out["sharded"])]
+    log_parity("one-shot peer-to-peer all-reduce (world of one) vs plain step, first step: losses %.1e gdelta %.1e galbedo %.1e | vs the "
+               "torch.distributed path after 12 steps: max %.1e" % (tuple(ep) + (max(ep12),)))
+    assert max(ep) < 5e-5 and ep12[0] < 1e-4 and max(ep12[1:3]) < 2e-3 and max(ep12[3:]) < 5e-4, (ep, ep12)
     l_s, l_p, ga_s, ga_p = out["stage1"]
     assert abs(l_s - l_p) <= 1e-6 * abs(l_p) and rel_err(torch.from_numpy(ga_s), torch.from_numpy(ga_p)) < 1e-6
