@@ -280,3 +280,92 @@ def test_stream_all_reduce_negotiation_cannot_hang():
         assert r["connect"]["fell_back"] and r["connect"]["why"] == "connect" and r["connect"]["seconds"] < 10.0, (rank, r["connect"])
         assert r["verify"]["fell_back"] and r["verify"]["why"] == "verify" and r["verify"]["aborted"], (rank, r["verify"])
         assert r["ok"]["is_fake"] and r["ok"]["why"] is None and not r["ok"]["aborted"], (rank, r["ok"])
+
+
+# ---- the negotiation of the one-shot peer-to-peer all-reduce (fmhr_amd.dist.negotiate_peer_all_reduce) with fakes over gloo ---------
+class _FakePeer:
+    """stands in for PeerAllReduce: `mode` says what goes wrong on `bad_rank` — create raises (no uncached allocation / no IPC export),
+    import raises (a handle that cannot be mapped), the reduction gives up inside the kernel (a wait ran into its bound), the result is
+    wrong on one rank (a peer's block served out of a cache)"""
+
+    def __init__(self, group, numel, mode, bad_rank):
+        self.group, self.numel, self.mode, self.bad = group, numel, mode, dist.get_rank(group) == bad_rank
+        self.closed, self.imported, self.calls = False, None, 0
+
+    def create(self):
+        if self.mode == "peer-create" and self.bad:
+            raise RuntimeError("fmhr_peer_create failed (-2): hipExtMallocWithFlags(uncached): out of memory")
+
+    def handle(self):
+        return bytes([dist.get_rank(self.group) + 1] * 64)
+
+    def import_peers(self, handles):
+        assert [h[0] for h in handles] == [r + 1 for r in range(dist.get_world_size(self.group))], "every rank's handle must reach every rank"
+        self.imported = len(handles)
+        if self.mode == "peer-import" and self.bad:
+            raise RuntimeError("fmhr_peer_import failed (-2): hipIpcOpenMemHandle: invalid argument")
+
+    def all_reduce_(self, t, stream=None):
+        dist.all_reduce(t, group=self.group)
+        self.calls += 1
+        if self.mode == "peer-verify" and self.bad and self.calls == 3:      # the THIRD exchange: a stale block would first show after the first
+            t.add_(1.0)
+        return t
+
+    def gave_up(self):
+        return self.mode == "gave-up" and self.bad
+
+    def close(self):
+        self.closed = True
+
+    abort = close
+
+
+def _peer_negotiation_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from fmhr_amd import dist as fdist
+    fdist.init_from_env(backend="gloo")
+    cpu = torch.device("cpu")
+    res = {}
+    for mode in ("peer-create", "peer-import", "peer-verify", "gave-up", "ok"):
+        made = []
+
+        def factory(g, numel, mode=mode):
+            made.append(_FakePeer(g, numel, mode, bad_rank=1))
+            return made[-1]
+        out, why = fdist.negotiate_peer_all_reduce(dist.group.WORLD, cpu, 260, factory=factory, timeout=2.0)
+        res[mode] = dict(none=out is None, why=why, closed=made[0].closed, imported=made[0].imported, calls=made[0].calls, is_fake=isinstance(out, _FakePeer))
+        x = torch.ones(3)
+        dist.all_reduce(x)                                          # the torch group still works on every rank
+        assert float(x[0]) == world
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_peer_all_reduce_negotiation_falls_back_together():
+    """The one-shot peer-to-peer all-reduce is set up phase by phase over the torch group (create + export, all_gather of the handles,
+    import, four verified exchanges): whatever fails on ONE rank — the allocation, the mapping of a peer's block, a wait inside the kernel
+    that ran into its bound, a wrong result in a later exchange — EVERY rank ends without the object (the caller goes on to RCCL), its
+    block freed, the torch group intact; all fine: the object on both."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_negotiation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        r = got[rank]
+        assert r["peer-create"]["none"] and r["peer-create"]["why"] == "peer-create" and r["peer-create"]["imported"] is None, (rank, r["peer-create"])
+        assert r["peer-import"]["none"] and r["peer-import"]["why"] == "peer-import" and r["peer-import"]["closed"] and r["peer-import"]["calls"] == 0
+        assert r["peer-verify"]["none"] and r["peer-verify"]["why"] == "peer-verify" and r["peer-verify"]["closed"] and r["peer-verify"]["calls"] == 4
+        assert r["gave-up"]["none"] and r["gave-up"]["why"] == "peer-verify" and r["gave-up"]["closed"]
+        assert r["ok"]["is_fake"] and r["ok"]["why"] is None and not r["ok"]["closed"] and r["ok"]["imported"] == 2, (rank, r["ok"])
+    # rank 0 (the good one) closed its block when rank 1's create failed
+    assert got[0]["peer-create"]["closed"]
