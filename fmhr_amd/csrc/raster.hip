@@ -363,6 +363,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         s0 = snapv(i0); s1 = snapv(i1); s2 = snapv(i2);
         ok = setup_triangle(s0, s1, s2, H, W, s);
     }
+#ifdef FMHR_X_TRIS_STOP                                              // (measurement builds only, DESIGN.md 5.11: 1 = nothing after the integer setup,
+    if (FMHR_X_TRIS_STOP == 1) ok = false;                           //  2 = nothing after the coverage masks, 3 = no fragment rounds)
+#endif
     if (ok) {
         bw = s.pxb - s.pxa + 1;
         const int bh = s.pyb - s.pya + 1;
@@ -429,6 +432,10 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
             }
         }
     }
+#ifdef FMHR_X_TRIS_STOP
+    if (FMHR_X_TRIS_STOP == 1) { cm = 0u; is_large = false; }
+    if (FMHR_X_TRIS_STOP == 2) { cm = 0u; }
+#endif
     // ---- task numbering over the WORKGROUP: wave-wide exclusive scan of the per-lane fragment counts + the waves' totals.  The
     // four waves share one task list and take dense 64-task slices of it: a wave of a sub3-class mesh has 64 +- 15 fragments, so
     // with a list of its own every other wave ran a second, nearly empty round of the ~110-instruction fragment evaluation (1.56
@@ -490,6 +497,9 @@ k_raster_tris(const float* __restrict__ pos, const int2* __restrict__ snap, cons
         if (i < wv) wbase += w;
         T += w;
     }
+#ifdef FMHR_X_TRIS_STOP
+    if (FMHR_X_TRIS_STOP == 3) T = 0;
+#endif
     const int excl = wbase + incl - cnt;                             // this lane's first task in the workgroup's numbering
     const long long P = (long long)H * Wp;                           // Wp: row pitch of the per-pixel buffers (common.h); W clips and scales
     unsigned long long* const keys_view = keys + (size_t)b * P;      // wave-uniform bases: the per-task offsets are 32-bit
