@@ -1516,7 +1516,9 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
             const long long nSeg = (long long)ba.tiles;
             k_bins_compact<<<cdiv(nSeg, kCompactBlock), kCompactBlock, 0, st>>>(ba, nSeg, covw, fu.seg_valid, (int2*)fu.bin_list, fu.bin_list_cnt);
             FMHR_CHECK_LAUNCH("k_bins_compact");
-            k_raster_bins<true><<<2048, kBinsBlock, 0, st>>>(tri, n, F, H, W, Wp, ba, covw, large_cnt, fu, pg);
+            // (FMHR_BINS_LIST=2: one wave per LIST ENTRY, as many waves as segments — a wave past the list's end leaves after one scalar load)
+            const unsigned lgrid = (ble && atoi(ble) == 2) ? (unsigned)cdiv((long long)nP, kBinsBlock) : 2048u;
+            k_raster_bins<true><<<lgrid, kBinsBlock, 0, st>>>(tri, n, F, H, W, Wp, ba, covw, large_cnt, fu, pg);
         } else {
             k_raster_bins<false><<<cdiv((long long)nP, kBinsBlock), kBinsBlock, 0, st>>>(tri, n, F, H, W, Wp, ba, covw, large_cnt, fu, pg);
         }
