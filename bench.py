@@ -256,7 +256,7 @@ def caller_numbering_side_measurement(scene_c, dev, stream, steps=100, preroll=1
 def run_ham_stage2_side_measurement(scene_c, batch, dev, stream, epochs_timed, preroll_steps=192, label=""):
     """Not the headline metric: the stage-2 loop THE PRODUCT RUNS (fmhr_amd.pipeline.Stage2Loop, what run_ham drives) — per epoch a fresh
     permutation of the capture's views (mesh_sfs_optim.py:249), per batch one fused step on perm[k:k+batch] with the capture's tensors
-    resident and the views selected INSIDE the step (ABI 6: no per-batch gathers), fused Adam, overflow flags read every 16 epochs — by
+    resident and the views selected INSIDE the step (ABI 6: no per-batch gathers), fused Adam, overflow flags polled every 64 epochs — by
     HIP events, next to the bare step on fixed tensors of the same batch size by the same clock (within 3 %)."""
     from fmhr_amd.optim import Adam
     from fmhr_amd.pipeline import Stage2Loop

@@ -124,7 +124,7 @@ class Stage2Loop:
     workspace is dropped, and at the end.  run_ham drives it; bench.py times it (`run_ham_stage2`)."""
 
     def __init__(self, vertices_tmp, faces, delta, albedo, sh_fixed, imgs, masks, valid_masks, w2cs, projs, resolution, weights, elm,
-                 optimizer, batch, epoch_sfs, gen, aa_cap=None, bin_cap=0, check_every=16):
+                 optimizer, batch, epoch_sfs, gen, aa_cap=None, bin_cap=0, check_every=64):
         from .ham import HamStage2
         self.HamStage2 = HamStage2
         self.vertices_tmp, self.faces, self.delta, self.albedo = vertices_tmp, faces, delta, albedo
@@ -174,7 +174,9 @@ class Stage2Loop:
         """the periodic check WITHOUT a synchronisation: inspect the copies of the sticky flags issued at the previous poll —
         their transfers completed epochs ago — and issue this poll's (16 bytes per workspace into pinned memory, non-blocking, on the
         step's stream).  An overflow is reported one polling interval late at most; check() before a workspace is dropped and at the end
-        of the run is synchronous and exact."""
+        of the run is synchronous and exact.  Cadence: a device-to-host copy, however small, ends in a system-scope release — the L2s
+        are written back — and costs the steps around it ~58 us at the metric config (tools/experiments/r05_loop_cost.py: +3.3 % at
+        every 16 epochs, +2.2 % without any poll); every 64 epochs — the cadence of the permutation refill — it is below 0.3 %."""
         for hs_, pin, ev in getattr(self, "_pending", []):
             ev.synchronize()
             f = pin.tolist()
@@ -220,7 +222,7 @@ class Stage2Loop:
 
 
 def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0, scan_id=None,
-            check_every=16, aa_cap=None, bin_cap=0, vertex_order=None):
+            check_every=64, aa_cap=None, bin_cap=0, vertex_order=None):
     """The HAM optimisation end to end on GPU tensors.  conf: dict with the keys of conf/demo_sfs.conf that the loop reads.
     A step never synchronises, so a work list that overflows (antialias pairs, fragment bins: `aa_cap` / `bin_cap` of HamStage2) drops
     gradient terms without an error of its own: the STICKY overflow flags of every stage-2 workspace are read every `check_every`
