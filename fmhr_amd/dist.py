@@ -403,11 +403,21 @@ def make_stream_all_reduce(group=None, check_numel=4099, timeout=None, log=None,
     (FMHR_STREAM_ALLREDUCE_TIMEOUT seconds, default 30), no rank ever left inside it.  FMHR_STREAM_ALLREDUCE=0 switches it off.
     `make_stream_all_reduce.last` = (path, reason) of the last call, for the bench line."""
     make_stream_all_reduce.last = ("torch", "disabled or not the nccl backend")
-    if os.environ.get("FMHR_STREAM_ALLREDUCE", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+    if os.environ.get("FMHR_STREAM_ALLREDUCE", "1") == "0" or not dist.is_initialized():
         return group
-    dev = torch.device("cuda", torch.cuda.current_device())
     if timeout is None:
         timeout = float(os.environ.get("FMHR_STREAM_ALLREDUCE_TIMEOUT", "30"))
+    if dist.get_backend(group) != "nccl":
+        # a rehearsal on one GPU (ranks over gloo, FMHR_FORCE_DEVICE): the peer-to-peer exchange needs no RCCL — hipIpc handles work between
+        # processes on one device — so it can be rehearsed there when asked for EXPLICITLY (FMHR_PEER_ALLREDUCE=1); the fallback is the group
+        if numel is not None and os.environ.get("FMHR_PEER_ALLREDUCE") == "1" and torch.cuda.is_available():
+            par, peer_why = negotiate_peer_all_reduce(group, torch.device("cuda", torch.cuda.current_device()), int(numel), timeout=timeout, log=log)
+            if par is not None:
+                make_stream_all_reduce.last = ("peer-to-peer one-shot on the step's stream", "rehearsal: ranks over " + dist.get_backend(group))
+                return par
+            make_stream_all_reduce.last = ("torch", f"not the nccl backend (peer-to-peer: {peer_why})")
+        return group
+    dev = torch.device("cuda", torch.cuda.current_device())
     peer_why = "no bucket size given"
     if numel is not None and os.environ.get("FMHR_PEER_ALLREDUCE", "1") != "0":
         par, peer_why = negotiate_peer_all_reduce(group, dev, int(numel), timeout=timeout, log=log)
