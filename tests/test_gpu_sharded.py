@@ -146,17 +146,19 @@ def _peer_worker(rank, world, port, q, dims=(6, 128, 96, 21, 37, 1)):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_one_gpu_through_the_one_shot_peer_all_reduce():
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_on_one_gpu_through_the_one_shot_peer_all_reduce(world):
     """the step's exchange as a ONE-SHOT peer-to-peer all-reduce (fmhr_amd/csrc/peer.hip) rehearsed the
     only way a one-GPU box allows — two processes on one GPU, each other's exported block mapped through IPC handles (the same calls map a
     peer GPU's memory over xGMI): negotiated phase by phase over the torch group, the sharded step through it against the single-rank step,
-    twelve more exchanges against torch's all-reduce, no wait ran into its bound, both ranks hold the same bits."""
+    twelve more exchanges against torch's all-reduce, no wait ran into its bound, every rank holds the same bits.  Three ranks: two
+    peers per rank, and shards of the bucket (12 V + 8 floats) and of the vertex range that do not divide evenly."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import log_parity, rel_err
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = _get(q, procs, 500)
@@ -168,8 +170,9 @@ def test_two_ranks_one_gpu_through_the_one_shot_peer_all_reduce():
     sc, tg, faces, w2c, proj = _scene()
     l1, gd1, ga1 = _run(sc, tg, faces, w2c, proj, 0, sc["views"], None, None)
     e = (rel_err(ls[:7], l1[:7].cpu()), rel_err(gd, gd1.cpu()), rel_err(ga, ga1.cpu()))
-    log_parity("one-shot peer-to-peer all-reduce (2 processes on one GPU, IPC-mapped blocks): sharded 3 + 3 views vs one rank: losses %.1e gdelta %.1e "
-               "galbedo %.1e | 12 exchanges vs torch's all-reduce: worst %.1e, same bits on both ranks: %s" % (e + (out["worst"], out["same_bits"])))
+    log_parity("one-shot peer-to-peer all-reduce (%d processes on one GPU, IPC-mapped blocks): 6 views sharded %s vs one rank: losses %.1e gdelta %.1e "
+               "galbedo %.1e | 12 exchanges vs torch's all-reduce: worst %.1e, same bits on every rank: %s"
+               % ((world, " + ".join(["%d" % (6 // world)] * world)) + e + (out["worst"], out["same_bits"])))
     assert float(ls[7]) == float(l1[7]) and float(l1[7]) > 1000
     assert e[0] < 1e-5 and e[1] < 5e-5 and e[2] < 5e-5, e
     assert out["worst"] < 1e-6 and not out["gave_up"] and out["same_bits"]
