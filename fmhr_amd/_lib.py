@@ -97,6 +97,7 @@ SIGNATURES = {
     "fmhr_peer_export": (c_int, [P, P]),
     "fmhr_peer_import": (c_int, [P, c_int, P]),
     "fmhr_peer_all_reduce": (c_int, [P, P, ctypes.c_longlong, P]),
+    "fmhr_peer_staging": (c_int, [P, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_longlong)]),
     "fmhr_peer_status": (c_int, [P, ctypes.POINTER(c_int)]),
     "fmhr_peer_destroy": (c_int, [P]),
     "fmhr_stage1_step_workspace_bytes": (c_size_t, [ctypes.POINTER(Stage1Plan)]),

@@ -38,6 +38,8 @@ struct PeerArgs {
     int rank, world;
     long long n2;                                 // 16-byte words in the bucket
     unsigned epoch;
+    unsigned bar0;                                // the grid-barrier counter before this call's first barrier (the host keeps the count)
+    int in_place;                                 // the bucket IS this rank's staging area (fmhr_peer_staging): nothing to stage
     unsigned* bar;                                // local: grid-barrier counter (monotone), abort word
 };
 
@@ -127,11 +129,16 @@ __global__ void __launch_bounds__(kBlock) k_peer_all_reduce(const PeerArgs A, fl
 {
     const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x, nth = (long long)gridDim.x * kBlock;
     float4* const b4 = reinterpret_cast<float4*>(bucket);
-    const unsigned bar0 = (A.epoch - 1u) * 2u * gridDim.x;            // the barrier counter before this call's first barrier
-    // A: stage (a thread's loads are all in flight before its first store: the loops below are latency-, not bandwidth-bound)
+    unsigned bar_at = A.bar0;
+    // A: stage (a thread's loads are all in flight before its first store: the loops below are latency-, not bandwidth-bound).
+    // In place — the step's last kernels wrote the bucket straight into the exported block — there is nothing to copy and nothing of
+    // THIS launch to wait for: the kernels in front of it on the stream have completed, and the flag stores are system-scope releases
     const PeerBlock mine = A.blk[A.rank];
-    copy_words(mine.stage, b4, A.n2, tid, nth);
-    if (!grid_barrier(A.bar, bar0 + gridDim.x)) return;
+    if (!A.in_place) {
+        copy_words(mine.stage, b4, A.n2, tid, nth);
+        bar_at += gridDim.x;
+        if (!grid_barrier(A.bar, bar_at)) return;
+    }
     if (blockIdx.x == 0) signal_peers(A, 0);
     // B
     if (!wait_peers(A, 0)) return;
@@ -151,7 +158,8 @@ __global__ void __launch_bounds__(kBlock) k_peer_all_reduce(const PeerArgs A, fl
         }
         mine.out[i - s0] = acc;
     }
-    if (!grid_barrier(A.bar, bar0 + 2u * gridDim.x)) return;
+    bar_at += gridDim.x;
+    if (!grid_barrier(A.bar, bar_at)) return;
     if (blockIdx.x == 0) signal_peers(A, 1);
     // D
     if (!wait_peers(A, 1)) return;
@@ -174,6 +182,7 @@ struct PeerState {
     PeerBlock* table;                             // [world] device copy of the mapped blocks' pointers, refreshed when a peer is imported
     bool table_dirty;
     unsigned epoch;
+    unsigned bar_count;                           // arrivals at the grid-barrier counter the launches so far account for
 };
 
 }  // namespace fmhr
@@ -258,8 +267,20 @@ extern "C" int fmhr_peer_all_reduce(void* state, float* bucket, long long n_floa
     A.blk = S->table;
     A.rank = S->rank; A.world = S->world; A.n2 = S->n2; A.bar = S->bar;
     A.epoch = ++S->epoch;
+    A.in_place = (char*)bucket == S->base ? 1 : 0;
+    A.bar0 = S->bar_count;
+    S->bar_count += (A.in_place ? 1u : 2u) * (unsigned)kPeerBlocks;
     k_peer_all_reduce<<<kPeerBlocks, kBlock, 0, (hipStream_t)stream>>>(A, bucket);
     FMHR_CHECK_LAUNCH("k_peer_all_reduce");
+    return FMHR_OK;
+}
+
+extern "C" int fmhr_peer_staging(void* state, void** ptr_out, long long* n_floats_out)
+{
+    PeerState* S = (PeerState*)state;
+    FMHR_CHECK_ARG(S != nullptr && ptr_out != nullptr && n_floats_out != nullptr, "peer_staging: null");
+    *ptr_out = S->base;
+    *n_floats_out = 4 * S->n2;
     return FMHR_OK;
 }
 

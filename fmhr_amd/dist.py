@@ -14,6 +14,7 @@ on ROCm) — SURVEY.md §8e.  The reference has no multi-GPU code; this is the b
 """
 import ctypes
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -317,6 +318,22 @@ class PeerAllReduce:
         st = st.value if isinstance(st, ctypes.c_void_p) else st
         self._lib.call("fmhr_peer_all_reduce", self.state, ctypes.c_void_p(t.data_ptr()), self.numel, ctypes.c_void_p(st))
         return t
+
+    def staging(self, owner):
+        """The staging area of this rank's exported block as a float32 tensor of `numel` elements, for ONE owner (the first to ask; None
+        for anyone else): a step that writes its bucket there and passes it to all_reduce_ has nothing to stage — the launch drops its
+        copy pass and one of its two grid barriers (fmhr_peer_staging).  The memory is uncached device memory owned by this object: the
+        tensor must not outlive it (close() is for the end of the run)."""
+        if getattr(self, "_stage_owner", None) is None:
+            ptr, n = ctypes.c_void_p(), ctypes.c_longlong(0)
+            self._lib.call("fmhr_peer_staging", self.state, ctypes.byref(ptr), ctypes.byref(n))
+
+            class _Block:                                                # (torch maps device memory it does not own through this protocol)
+                __cuda_array_interface__ = dict(shape=(int(n.value),), typestr="<f4", data=(int(ptr.value), False), version=2)
+            self._stage_keep = _Block()
+            self._stage = torch.as_tensor(self._stage_keep, device=torch.device("cuda", torch.cuda.current_device()))
+            self._stage_owner = weakref.ref(owner)
+        return self._stage if self._stage_owner() is owner else None
 
     def gave_up(self):
         """True if a wait inside any all-reduce so far ran into its bound (synchronises): the object must not be used again"""

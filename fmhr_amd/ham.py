@@ -146,13 +146,7 @@ class HamStage2:
         self.n_valid_global = self.raw("n_valid_f", torch.float32, 1)
         # one contiguous bucket [gdelta | galbedo | gdelta_rest | galbedo_rest | losses]: one rank uses the first two and the loss
         # slots; a view-sharded step fills all of it (photometric share | the rest), all-reduces it in place ONCE and combines
-        self.bucket = torch.zeros(12 * self.V + 8, dtype=torch.float32, device=self.dev)
-        V3 = 3 * self.V
-        self.gdelta = self.bucket[:V3].view(self.V, 3)
-        self.galbedo = self.bucket[V3: 2 * V3].view(self.V, 3)
-        self.gdelta_rest = self.bucket[2 * V3: 3 * V3].view(self.V, 3)
-        self.galbedo_rest = self.bucket[3 * V3: 4 * V3].view(self.V, 3)
-        self.losses = self.bucket[4 * V3:]
+        self._bind_bucket(torch.zeros(12 * self.V + 8, dtype=torch.float32, device=self.dev))
         # which rasterizer fmhr_ham_forward takes for these dims: per-segment fragment bins resolved in LDS where the mesh is a
         # micro-triangle one and the pitch a multiple of 64 (FMHR_RASTER_BINNED=0 switches them off), else global depth keys + resolve pass
         self.binned = self.lib.fmhr_ham_rasterizer_form(ctypes.byref(self.dims)) == 1
@@ -160,6 +154,16 @@ class HamStage2:
         self._aa_flag = None
         self._vm_key, self._vm_ref = None, None
         self._last_sh = None
+
+    def _bind_bucket(self, bucket):
+        """the step's output buffer [gdelta | galbedo | gdelta_rest | galbedo_rest | 8 loss slots]; every step writes all of it"""
+        V3 = 3 * self.V
+        self.bucket = bucket
+        self.gdelta = bucket[:V3].view(self.V, 3)
+        self.galbedo = bucket[V3: 2 * V3].view(self.V, 3)
+        self.gdelta_rest = bucket[2 * V3: 3 * V3].view(self.V, 3)
+        self.galbedo_rest = bucket[3 * V3: 4 * V3].view(self.V, 3)
+        self.losses = bucket[4 * V3:]
 
     # -- the two phases -------------------------------------------------------------------------------------------------
     def _view_idx(self, view_idx):
@@ -226,6 +230,13 @@ class HamStage2:
             if p_delta.data_ptr() != delta.data_ptr() or p_albedo.data_ptr() != albedo.data_ptr():
                 raise RuntimeError("HamStage2.step: `params` must be the tensors behind the `delta` / `albedo` arguments")
             adam = (optimizer.fused_param(p_delta), optimizer.fused_param(p_albedo))
+        if group is not None and hasattr(group, "staging") and getattr(self, "_staged_for", None) is not group:
+            # a one-shot peer-to-peer exchange (fmhr_amd.dist.PeerAllReduce): the backward writes the bucket straight into the block the
+            # peers read — no staging copy inside the exchange.  One owner per exchange object; anyone else's bucket is staged by the launch
+            self._staged_for = group
+            st = group.staging(self) if os.environ.get("FMHR_PEER_IN_PLACE", "1") != "0" else None
+            if st is not None and st.numel() == self.bucket.numel():
+                self._bind_bucket(st)
         self.forward(vertices_tmp, delta, albedo, sh, w2c, proj, mask, valid_mask, view_idx=view_idx)
         self.backward(vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_mask, reg_grads=reg_grads, reg_range=reg_range,
                       split=group is not None, adam=adam if group is None else (None, None), view_idx=view_idx)

@@ -334,6 +334,9 @@ int fmhr_sh_albedo_sums(const float* normals, const float* rast, const float* ma
  *   fmhr_peer_import      map peer `peer`'s block from its handle (every peer but oneself, once)
  *   fmhr_peer_all_reduce  in-place SUM of `bucket` (this rank's device memory, 16-byte aligned) over the ranks, enqueued on `stream`;
  *                         every rank must call it the same number of times (the flags carry the call count)
+ *   fmhr_peer_staging     the staging area of this rank's block as a bucket: a caller that lets fmhr_ham_backward write its bucket THERE
+ *                         (uncached device memory, n_floats floats) and passes that pointer to fmhr_peer_all_reduce saves the staging
+ *                         copy and one grid barrier of every exchange; any other 16-byte aligned bucket is staged by the launch
  *   fmhr_peer_status      *gave_up = 1 if a wait of any call so far ran into its bound (synchronises; the state is unusable afterwards)
  *   fmhr_peer_destroy     unmap, free */
 size_t fmhr_peer_handle_bytes(void);
@@ -341,6 +344,7 @@ int fmhr_peer_create(int rank, int world, long long n_floats, void** state_out);
 int fmhr_peer_export(void* state, void* handle_out);
 int fmhr_peer_import(void* state, int peer, const void* handle);
 int fmhr_peer_all_reduce(void* state, float* bucket, long long n_floats, void* stream);
+int fmhr_peer_staging(void* state, void** ptr_out, long long* n_floats_out);
 int fmhr_peer_status(void* state, int* gave_up);
 int fmhr_peer_destroy(void* state);
 
