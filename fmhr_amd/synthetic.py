@@ -33,6 +33,9 @@ CONFIGS = {
     # 32 views x 8 frames of 334 x 512 (conf/ih_sfsseq.conf:11-13); a frame is an independent (delta, albedo) problem on the shared
     # topology (fmhr_amd.dist.shard_frames_views)
     "C5": (32, 512, 334, "mano", 0, 3, 2, 8),
+    # one BATCH of the reference's own demo run (conf/demo_sfs.conf:5-7,24: 8 of 16 views, 1280 x 1024, two hands): what a stage-2 step
+    # of `python mesh_sfs_optim.py --conf conf/demo_sfs.conf` renders
+    "demo": (8, 1024, 1280, "mano", 0, 3, 2),
 }
 
 
