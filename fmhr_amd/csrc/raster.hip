@@ -1065,7 +1065,11 @@ __device__ __forceinline__ void bins_segment(const long long seg, const int coun
         cidx = ((long long)row + (long long)src_delta * fu.sel.H) * W + (int)col0 + lane;
     } else if (Wp != W) cidx = caller_index((unsigned)seg, lane, W, fu.segx, incol);
     const float mk = incol ? fu.mask[cidx] : 0.f;                    // independent of the bin: issued with its first loads
-    const int step_tag = fu.stamp[0];
+    // the step tag and, in the same 16-B word, the high-water mark of the fragments one segment has held since the workspace was initialised
+    // (stamp[3]): what `bin_cap` has to cover — HamStage2.bin_depth_max() reads it.  ONE load; the mark is compared at the end of the segment,
+    // and the atomic runs only when it moves (as a second load with its own wait up here the mark cost this pass 1.7 us)
+    const int4 stamp4 = *reinterpret_cast<const int4*>(fu.stamp);
+    const int step_tag = stamp4.x;
     const int cnt = min(count, ba.cap);
     const BinEntry* __restrict__ bin = ba.bins + (size_t)seg * ba.cap;
     lkey[lane] = ~0ull;
@@ -1173,6 +1177,9 @@ __device__ __forceinline__ void bins_segment(const long long seg, const int coun
         covw[seg] = bal;
         if (fu.seg_valid != nullptr) fu.seg_valid[seg] = __popcll(vbal) | (sbal != 0ull ? 0x100 : 0);
         if (fu.silw != nullptr) fu.silw[seg] = sbal;
+#ifndef FMHR_X_NO_DEPTH_MARK                                         // (measurement builds only: same-box A/B of the mark's cost)
+        if (count > stamp4.w) atomicMax(fu.stamp + 3, count);
+#endif
     }
 }
 

@@ -313,6 +313,12 @@ class HamStage2:
             self._aa_flag = self._aa_flag_all[:2]
         return self._aa_flag_all
 
+    def bin_depth_max(self):
+        """The most fragments ONE 64-pixel segment has held in any step since the workspace was initialised (binned rasterizer; 0 with the
+        atomic-key form) — what `bin_cap` (default 1024 = 8 KB per segment) has to cover.  Synchronises (one 4-byte copy): call it where the
+        run synchronises anyway; run_ham reports it at the end."""
+        return int(self.raw("stamp", torch.int32, 4)[3])
+
     def aa_overflowed(self):
         """True if the antialias work-item list was full in ANY step since the workspace was initialised (sticky, like the
         fragment-bin flag; one device -> host copy): those steps dropped silhouette pairs from the gradient."""
@@ -333,7 +339,8 @@ class HamStage2:
         aa, bins = self.overflow_flags()
         if bins:
             raise RuntimeError(f"HamStage2: a fragment bin of the rasterizer overflowed (more than {self.dims.bin_cap or 1024} fragments "
-                               "in one 64-pixel segment): fragments were dropped; construct HamStage2 with a larger bin_cap")
+                               f"in one 64-pixel segment; the fullest segment so far held {self.bin_depth_max()}): fragments were dropped; "
+                               "construct HamStage2 with a larger bin_cap")
         if aa:
             raise RuntimeError(f"HamStage2: the antialias work-item list overflowed (aa_cap={self.dims.aa_cap}): some silhouette pairs "
                                "got no gradient in at least one step; construct HamStage2 with a larger aa_cap")

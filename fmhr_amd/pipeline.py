@@ -234,7 +234,7 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     their corner order untouched — the gathers of every kernel stay within few cache lines) and every per-vertex result is mapped back:
     what is returned and written has the caller's numbering, i.e. the child-face / appended-midpoint layout of the subdivided mesh that
     repose.py:14-24 relies on.  `vertex_order=False` (or FMHR_VERTEX_ORDER=0) optimises in the caller's numbering.
-    Returns dict(vertices, delta, albedo, sh_coeffs, history).  With `out_dir` the outputs of mesh_sfs_optim.py:319-343 are written
+    Returns dict(vertices, delta, albedo, sh_coeffs, history, valid_masks, bin_depth_max).  With `out_dir` the outputs of mesh_sfs_optim.py:319-343 are written
     under the reference's names: '<scan_id>.pt' (sh_coeff, albedo), '<scan_id>.obj', '<scan_id>_c.obj' (vertex colours) and
     'rerender/mesh_<view>.png' (the last epoch's rendered batches); scan_id = None keeps the stem 'ham'."""
     from . import optim
@@ -317,7 +317,9 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     out_vertices = order.to_caller((vertices_tmp + delta).detach())
     albedo_out = order.to_caller(albedo.detach(), 1)
     result = dict(vertices=out_vertices, delta=order.to_caller(delta.detach()), albedo=albedo_out, sh_coeffs=sh_coeffs.detach(),
-                  history=history, valid_masks=init["valid_masks"])
+                  history=history, valid_masks=init["valid_masks"],
+                  # the fullest fragment bin of the run (0: atomic-key rasterizer) — what `bin_cap` has to cover (HamStage2.bin_depth_max)
+                  bin_depth_max=max([hs_.bin_depth_max() for hs_ in loop.steppers.values()] or [0]))
     if out_dir is not None:                                                          # :319-343
         os.makedirs(out_dir, exist_ok=True)
         stem = 'ham' if scan_id is None else '%d' % scan_id

@@ -722,6 +722,19 @@ def test_fragment_bin_overflow_is_reported(oracle, monkeypatch):
     hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
     with pytest.raises(RuntimeError, match="fragment bin"):
         hs.loss_dict()
+    # the high-water mark says what the capacity has to be: a workspace with that capacity holds the same step without overflow, and
+    # its own mark is the same number (the count of a segment does not depend on the capacity)
+    need = hs.bin_depth_max()
+    assert need > 64
+    hs2 = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"], bin_cap=need)
+    hs2.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    hs2.loss_dict()
+    assert hs2.bin_depth_max() == need
+    if need > 65:
+        hs3 = HamStage2(sc["faces"].to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"], bin_cap=need - 1)
+        hs3.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+        with pytest.raises(RuntimeError, match="fragment bin"):
+            hs3.loss_dict()
 
 
 def test_two_hand_sub3_mesh_at_the_sequence_resolution(oracle):

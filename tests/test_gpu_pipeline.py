@@ -275,5 +275,7 @@ def test_run_ham_on_the_reference_capture(tmp_path):
     assert sorted(os.listdir(os.path.join(tmp_path, "rerender"))) == ["mesh_%02d.png" % i for i in range(16)]
     log_parity("the reference's capture end to end (demo_data/1: 16 real views at 1280x1024, MANO templates %s placed on the keypoints, IoU %.2f, "
                "sub3 = 98 562 vertices): stage 1 L1 %.4f -> %.4f in 4 epochs; stage 2 (8 of 16 views per step) sfs %.3f -> %.3f, mask %.3f -> %.3f, "
-               "total %.2f -> %.2f in 8 epochs; no overflow; outputs 1.pt / 1.obj / 1_c.obj / rerender/mesh_00..15.png"
-               % (sides, iou, s1[0], s1[-1], s2[0]["sfs"], s2[-1]["sfs"], s2[0]["mask"], s2[-1]["mask"], s2[0]["total"], s2[-1]["total"]))
+               "total %.2f -> %.2f in 8 epochs; no overflow (fullest fragment bin %d of 1024); outputs 1.pt / 1.obj / 1_c.obj / rerender/mesh_00..15.png"
+               % (sides, iou, s1[0], s1[-1], s2[0]["sfs"], s2[-1]["sfs"], s2[0]["mask"], s2[-1]["mask"], s2[0]["total"], s2[-1]["total"],
+                  out["bin_depth_max"]))
+    assert 0 < out["bin_depth_max"] <= 1024
