@@ -397,7 +397,10 @@ k_aa_fwd(const float* __restrict__ colorA, const float* __restrict__ colorB, con
 // the mask scan of k_aa_fwd_list): 768 workgroups at 3 waves per SIMD — the kernel needs ~137 VGPRs; at 1280 / 5 (96 VGPRs) it spilled
 // 37-59 registers into its latency-bound phases: 35 vs 23.5 us; 1024 / 4: 27 us; 512 / 2: 26 us.  The per-pixel scan of the other
 // case is the faster the more waves share its load latency: 1280 / 5 (36 us; 1024 / 4: 37, 768 / 3: 42).
-constexpr int kAaGridRow = 768, kAaGridAny = 1280;
+#ifndef FMHR_AA_GRID_ROW
+#define FMHR_AA_GRID_ROW 768
+#endif
+constexpr int kAaGridRow = FMHR_AA_GRID_ROW, kAaGridAny = 1280;
 static bool aa_row_aligned(int n, int H, int W) { return (W & 63) == 0 && ((long long)n * H * W) < (1ll << 36); }   // segment ids below 2^30
 static int aa_grid(bool row) { return row ? kAaGridRow : kAaGridAny; }
                                               // of k_aa_fwd_list at its 5 waves per SIMD (96 VGPRs; 2048 workgroups ran as 1.6 rounds: 40.5 -> 32.7 us)

@@ -144,7 +144,10 @@ __device__ __forceinline__ bool seg_active(const unsigned char* __restrict__ act
     return __builtin_amdgcn_readfirstlane((int)act[gid >> 6]) != 0;
 }
 
-constexpr int kPersistBlocks = 2048;      // persistent per-pixel kernels: 8 workgroups per CU, waves loop over act_list
+#ifndef FMHR_PERSIST_BLOCKS
+#define FMHR_PERSIST_BLOCKS 2048
+#endif
+constexpr int kPersistBlocks = FMHR_PERSIST_BLOCKS;      // persistent per-pixel kernels: 8 workgroups per CU, waves loop over act_list
 
 // test/inspection helper: make the sparse buffers dense (zeros wherever the step did not write)
 __global__ void __launch_bounds__(kBlock)
