@@ -174,13 +174,57 @@ def stage1_side_measurement(scene, faces, w2c, proj, sh, tg, vtmp, H, W, dev, st
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
+    # ... and the loop run_ham drives around it when a batch is PART of the capture (mesh_sfs_optim.py:195-204: a fresh permutation per
+    # epoch, batches of it): half the views per step — the batch masks of 64 epochs drawn and transferred at once
+    # (fmhr_amd.pipeline.PermChunks), handed to the step in the C ABI's own form — against the same selection with fixed masks, and
+    # against the reference's form (torch.randperm(num).cuda() per epoch, index tensors per step), by the same clock
+    from fmhr_amd.pipeline import PermChunks
+    n_all = int(w2c.shape[0])
+    loop = None
+    if n_all >= 2:
+        half = n_all // 2
+        gen = torch.Generator().manual_seed(0)
+        pc = PermChunks(n_all, half, gen, dev)
+        fixed = pc.next()[1].clone()
+
+        def epoch_masks():
+            m = pc.next()[1]
+            for j in range(2):
+                hs1.step(albedo, shc, sel=m[j], optimizer=opt, params=(albedo, shc))
+
+        def epoch_fixed():
+            for j in range(2):
+                hs1.step(albedo, shc, sel=fixed[j], optimizer=opt, params=(albedo, shc))
+
+        def epoch_reference_form():
+            perm = torch.randperm(n_all, generator=gen).to(dev)
+            for k in (0, half):
+                hs1.step(albedo, shc, idx=perm[k:k + half], optimizer=opt, params=(albedo, shc))
+        res = {}
+        for _ in range(2):                                           # two alternating rounds
+            for name, fn in (("fixed_masks", epoch_fixed), ("loop", epoch_masks), ("reference_form", epoch_reference_form)):
+                for _ in range(8):
+                    fn()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(48):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                res.setdefault(name, []).append(e0.elapsed_time(e1) / 96)
+        loop = {"what": f"half-batch steps ({half} of {n_all} views): ms per step with fixed masks | run_ham's loop (PermChunks: a fresh permutation "
+                        "per epoch, masks of 64 epochs per transfer) | the reference's form (randperm().cuda() per epoch + index tensors per step)",
+                **{k: round(min(v), 4) for k, v in res.items()},
+                "loop_over_fixed": round(min(res["loop"]) / min(res["fixed_masks"]), 4),
+                "reference_form_over_fixed": round(min(res["reference_form"]) / min(res["fixed_masks"]), 4)}
     V = albedo.shape[1]
     # forward: row_ptr + entries + normal + target + R per row; backward: transposed entries + one R gather per entry + Adam state
     nbytes = hs1.rows * (4 + 12 + 12 + 12) + hs1.entries * 8 + hs1.entries * (8 + 12) + V * 3 * 4 * 7
     return {"what": "fused stage-1 (albedo + SH) step, mesh_sfs_optim.py:205-236, same views / mesh", "ms_per_step": round(ms, 4),
             "iterations_per_s": round(1e3 / ms, 1), "plan_ms_once": round(plan_ms, 1), "rows": hs1.rows, "entries": hs1.entries,
             "antialias_items": hs1.n_items, "table_bytes_per_step": nbytes, "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
-            "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "loss": round(float(lv.sum()), 6), "steps": steps}
+            "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "loss": round(float(lv.sum()), 6), "steps": steps,
+            "run_ham_stage1": loop}
 
 
 def run_length_side_measurement(Problem, stream, length):

@@ -115,6 +115,46 @@ def stage1_loss_cached(ops, cache, idx, albedo, sh_coeff, img, sfs_weight):
     return sfs_weight * diff / (3.0 * valid.sum())
 
 
+class PermChunks:
+    """The loops' per-epoch permutations (mesh_sfs_optim.py:195,249: `perm = torch.randperm(num).cuda()`) without a host-to-device copy
+    per epoch: uniform permutations drawn from the run's generator kChunk epochs at a time (one vectorised draw: argsort of i.i.d.
+    uniforms), into ONE pinned staging buffer allocated once, and copied with one non-blocking transfer on the step's stream (stream
+    order protects the rows the queued steps still read).  What it replaces, measured at the metric config: a
+    pageable host-to-device copy per epoch — the reference's `.cuda()` — stalls the launch queue for ~25 us = 9 % of a 48-view stage-2
+    step; a freshly pinned buffer per chunk (hipHostMalloc) ~1 ms per 64 epochs = 5 %; 64 torch.randperm calls + 64 row copies ~1 ms of
+    host time per refill.  next() -> (perm [num] int32, masks [ceil(num / batch), num] int32): row j of `masks` is 1 on the views of the
+    epoch's j-th batch `perm[j*batch:(j+1)*batch]` — the selection form HamStage1.step(sel=...) takes (no per-step index kernels)."""
+    kChunk = 64
+
+    def __init__(self, num, batch, gen, dev):
+        self.num, self.batch, self.gen, self.dev = int(num), int(batch), gen, dev
+        self.nb = (self.num + self.batch - 1) // self.batch
+        words = self.num + self.nb * self.num
+        self._pin = torch.empty((self.kChunk, words), dtype=torch.int32)
+        if dev.type == "cuda":
+            self._pin = self._pin.pin_memory()
+        self._dev = torch.empty((self.kChunk, words), dtype=torch.int32, device=dev)
+        self._at, self._copied = self.kChunk, None
+
+    def next(self):
+        if self._at == self.kChunk:
+            if self._copied is not None:
+                self._copied.synchronize()                                              # the previous chunk's transfer has read the staging buffer (64 epochs ago)
+            perms = torch.rand(self.kChunk, self.num, generator=self.gen).argsort(dim=1)
+            batch_of_view = perms.argsort(dim=1) // self.batch                          # [chunk, num]: which batch of its epoch a view is in
+            masks = (batch_of_view[:, None, :] == torch.arange(self.nb)[None, :, None]).to(torch.int32)
+            self._pin[:, :self.num].copy_(perms)
+            self._pin[:, self.num:].copy_(masks.reshape(self.kChunk, -1))
+            self._dev.copy_(self._pin, non_blocking=True)
+            if self.dev.type == "cuda":
+                self._copied = torch.cuda.Event()
+                self._copied.record()
+            self._at = 0
+        row = self._dev[self._at]
+        self._at += 1
+        return row[:self.num], row[self.num:].view(self.nb, self.num)
+
+
 class Stage2Loop:
     """The stage-2 loop of mesh_sfs_optim.py:242-317 as the product runs it: per epoch a fresh permutation of the capture's views (:249),
     per batch ONE fused step on `perm[k:k+batch]` — the capture's images, masks, start silhouettes, cameras and SH rows stay where they
@@ -135,34 +175,13 @@ class Stage2Loop:
         self.aa_cap, self.bin_cap, self.check_every = aa_cap, bin_cap, check_every
         self.steppers, self.epoch, self.hs, self.perm, self._pending = {}, 0, None, None, []
         self.dev = vertices_tmp.device
-        self._perms, self._perm_at = None, 0
+        self._perms = None
 
     def _next_perm(self):
-        """the epoch's permutation (:249) as an int32 device row: uniform permutations drawn from the run's generator kPermChunk epochs
-        at a time (one vectorised draw), into ONE pinned staging buffer allocated once, and copied with one non-blocking
-        transfer on the step's stream (stream order protects the rows the queued steps still read).  What it replaces, measured at the
-        metric config: a pageable host-to-device copy per epoch — the reference's `.cuda()` — stalls the launch
-        queue for ~25 us = 9 % of a 48-view step; a freshly pinned buffer per chunk (hipHostMalloc) ~1 ms per 64 epochs = 5 %."""
-        kPermChunk = 64
+        """the epoch's permutation (:249) as an int32 device row (PermChunks below)"""
         if self._perms is None:
-            self._pin = torch.empty((kPermChunk, self.num), dtype=torch.int32)
-            if self.dev.type == "cuda":
-                self._pin = self._pin.pin_memory()
-            self._perms = torch.empty((kPermChunk, self.num), dtype=torch.int32, device=self.dev)
-            self._perm_at, self._copied = kPermChunk, None
-        if self._perm_at == kPermChunk:
-            if self._copied is not None:
-                self._copied.synchronize()                                              # the previous chunk's transfer has read the staging buffer (64 epochs ago)
-            # kPermChunk uniform permutations in ONE call (argsort of i.i.d. uniforms; 64 torch.randperm calls + 64 row copies were ~1 ms of
-            # host time per refill — exposed whenever the launch queue happens to be short)
-            self._pin.copy_(torch.rand(kPermChunk, self.num, generator=self.gen).argsort(dim=1))
-            self._perms.copy_(self._pin, non_blocking=True)
-            if self.dev.type == "cuda":
-                self._copied = torch.cuda.Event()
-                self._copied.record()
-            self._perm_at = 0
-        self._perm_at += 1
-        return self._perms[self._perm_at - 1]
+            self._perms = PermChunks(self.num, self.batch, self.gen, self.dev)
+        return self._perms.next()[0]
 
     def check(self):
         """synchronous: raise if a work list of any live workspace overflowed in any step so far (one device -> host copy each)"""
@@ -267,11 +286,11 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
         # interpolate + antialias operator are built once, an iteration is one C call (two launches), the Adam update of both
         # parameters applied inside it.  `stage1_loss` / `stage1_loss_cached` above are the op-by-op forms the parity tests compare it with.
         opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
+        perms1 = PermChunks(num, batch, gen, dev)                                      # (no per-epoch copy, no per-step index kernels)
         for ep in range(int(conf["epoch_albedo"])):
-            perm = torch.randperm(num, generator=gen).to(dev)
-            for k in range(0, num, batch):
-                idx = perm[k:k + batch]
-                loss_view, _, _ = hs1.step(albedo, sh_coeffs, idx=None if idx.numel() == num else idx, optimizer=opt,
+            _, batch_masks = perms1.next()                                              # :195
+            for j in range(batch_masks.shape[0]):
+                loss_view, _, _ = hs1.step(albedo, sh_coeffs, sel=None if batch >= num else batch_masks[j], optimizer=opt,
                                            params=(albedo, sh_coeffs))
             if log_every and ep % log_every == 0:
                 history.append(("albedo", ep, float(loss_view.sum())))

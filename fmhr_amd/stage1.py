@@ -104,8 +104,9 @@ class HamStage1:
         self.view_sel = torch.ones(num, dtype=torch.int32, device=dev)
         self.rast, self.normals, self.masks, self.imgs = rast, normals, masks, imgs      # the constant sub-graph (also read by init_sh)
 
-    def step(self, albedo, sh_coeffs, idx=None, optimizer=None, params=None):
-        """One iteration on the views `idx` (None: all).  albedo [1,V,3] or [V,3], sh_coeffs [num,9].  Returns (loss_view [num],
+    def step(self, albedo, sh_coeffs, idx=None, optimizer=None, params=None, sel=None):
+        """One iteration on the views `idx` (None: all) — or on the views whose entry of `sel` (int32 [num] GPU tensor, the C ABI's own
+        form: no index kernels in front of the step) is non-zero.  albedo [1,V,3] or [V,3], sh_coeffs [num,9].  Returns (loss_view [num],
         galbedo [V,3], gsh [num,9]) — device tensors, overwritten by the next call; the loss of mesh_sfs_optim.py:233 is
         loss_view.sum() (the views' shares; no extra launch unless somebody asks).  With `optimizer` (fmhr_amd.optim.Adam) and
         params = (albedo, sh_coeffs) the Adam update of both is applied by the step's second kernel (no optimizer.step())."""
@@ -118,8 +119,12 @@ class HamStage1:
         s = sh_coeffs.detach()
         if s.shape != (self.n, 9):
             raise RuntimeError(f"HamStage1.step: sh_coeffs must be [{self.n}, 9]")
-        sel = None
-        if idx is not None:
+        if sel is not None:
+            if idx is not None:
+                raise RuntimeError("HamStage1.step: idx and sel are two forms of one selection: pass one")
+            if sel.dtype != torch.int32 or not sel.is_cuda or tuple(sel.shape) != (self.n,) or not sel.is_contiguous():
+                raise RuntimeError(f"HamStage1.step: sel must be a contiguous int32 GPU tensor of shape ({self.n},)")
+        elif idx is not None:
             self.view_sel.zero_()
             self.view_sel[idx.long()] = 1
             sel = self.view_sel

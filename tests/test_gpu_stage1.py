@@ -60,6 +60,16 @@ def test_fused_stage1_step_matches_the_op_by_op_loop_body():
     ga_first = ga.clone()
     l2, ga2, gs2 = hs.step(albedo, sh, idx=idx)
     assert torch.equal(ga2, ga_first) and float(l2.sum()) == float(loss)
+    # the selection as the C ABI takes it — an int32 mask over the views, the form run_ham's loop passes (fmhr_amd.pipeline.PermChunks:
+    # the masks of 64 epochs' batches in one transfer, no index kernels in front of a step): the same bits
+    sel = torch.zeros(sc["views"], dtype=torch.int32, device=dev)
+    sel[idx] = 1
+    l3, ga3, gs3 = hs.step(albedo, sh, sel=sel)
+    assert torch.equal(ga3, ga_first) and torch.equal(gs3, gs2) and float(l3.sum()) == float(loss)
+    with pytest.raises(RuntimeError, match="two forms"):
+        hs.step(albedo, sh, idx=idx, sel=sel)
+    with pytest.raises(RuntimeError, match="int32"):
+        hs.step(albedo, sh, sel=sel.long())
 
 
 def test_fused_stage1_step_vs_cpu_checker(oracle):

@@ -280,3 +280,27 @@ def test_vertex_order_is_a_relabelling_of_the_same_mesh(monkeypatch):
     assert not VertexOrder(faces, V).identity
     with pytest.raises(RuntimeError):
         VertexOrder(faces, V - 5)
+
+
+def test_permutation_chunks_are_permutations_and_their_batch_masks():
+    """fmhr_amd.pipeline.PermChunks (the loops' `perm = torch.randperm(num)` per epoch, mesh_sfs_optim.py:195,249, drawn 64 epochs at a
+    time): every row a permutation, row j of an epoch's masks exactly the views of `perm[j*batch:(j+1)*batch]` (a ragged last batch
+    included), across a refill, reproducible from the generator's seed"""
+    import torch
+    from fmhr_amd.pipeline import PermChunks
+    for num, batch in ((7, 3), (16, 8), (5, 5), (4, 9)):
+        runs = []
+        for rep in range(2):
+            pc = PermChunks(num, batch, torch.Generator().manual_seed(11), torch.device("cpu"))
+            rows = []
+            for ep in range(PermChunks.kChunk + 3):
+                perm, masks = pc.next()
+                assert perm.dtype == torch.int32 and sorted(perm.tolist()) == list(range(num))
+                nb = (num + batch - 1) // batch
+                assert tuple(masks.shape) == (nb, num) and int(masks.sum()) == num
+                for j in range(nb):
+                    assert sorted(torch.nonzero(masks[j]).flatten().tolist()) == sorted(perm[j * batch:(j + 1) * batch].tolist())
+                rows.append(perm.clone())
+            runs.append(torch.stack(rows))
+        assert torch.equal(runs[0], runs[1])
+        assert len({tuple(r.tolist()) for r in runs[0]}) > (1 if num > 1 else 0)
