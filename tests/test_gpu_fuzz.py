@@ -122,3 +122,34 @@ def test_hostile_cameras_through_the_fused_step(oracle, case):
     sc = hostile_cameras(oracle, dims, seed)
     ld, v = _step_vs_oracle(oracle, sc, "hostile cameras %s seed %d" % (dims, seed))
     assert all(np.isfinite(x) for x in ld.values())
+
+
+@pytest.mark.parametrize("dims", [(3, 64, 64, 24, 32), (3, 96, 80, 12, 16), (2, 64, 192, 40, 56)], ids=lambda d: "%dx%dx%d" % d[:3])
+def test_one_workspace_follows_a_different_hostile_scene_every_step(oracle, dims):
+    """everything the step keeps BETWEEN steps (segment state words, bin cursors, owner marks, coverage entries, the sliver workers' queue,
+    the antialias lists) under the worst a caller can do to it: a new shape of the mesh, new cameras (views going empty and coming back,
+    triangles switching between the small-box and the large-box path), new targets — every step on the SAME workspace; `rast` bit-identical
+    to the fp32 checker at the step's own positions, losses and gradients against its fp32 evaluation (a stale entry shows as O(1)).
+    (tools/experiments/r05_fuzz_stateful.py is the same loop over 40 scenes x 8 steps.)"""
+    from fmhr_amd.ham import HamStage2
+    from util import rel_err
+    dev = torch.device("cuda:0")
+    hs, faces = None, None
+    for t in range(6):
+        sc = hostile_cameras(oracle, dims, 7000 + t)
+        if hs is None:
+            faces = sc["faces"]
+            hs = HamStage2(faces.to(dev), sc["V"], sc["views"], sc["H"], sc["W"], sc["weights"], sc["elm"])
+        assert torch.equal(sc["faces"], faces)                          # one topology; the vertices, cameras and targets change
+        g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+        _, gd, ga = hs.step(g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+        ld, v = hs.loss_dict(), hs.views()
+        d = sc["delta"].clone().requires_grad_(True)
+        a = sc["albedo"][None].clone().requires_grad_(True)
+        ref = oracle.ham_stage2_losses(sc["vertices"], d, a, sc["sh0"], sc["w2c"], sc["proj"], sc["img"], sc["mask"], sc["valid_mask"], faces,
+                                       (sc["H"], sc["W"]), sc["weights"], hs.edge_len_mean, pos_value=v["pos"].cpu())
+        ref["loss"].backward()
+        assert torch.equal(v["rast"].cpu(), ref["rast"]), (dims, t)
+        for k in ("sfs", "lap", "albedo", "mask", "edge", "delta"):
+            assert abs(ld[k] - float(ref[k])) <= 1e-3 * max(abs(float(ref[k])), 1e-6), (dims, t, k, ld[k], float(ref[k]))
+        assert rel_err(gd, d.grad) < 1e-3 and rel_err(ga, a.grad[0]) < 1e-3, (dims, t)
