@@ -40,27 +40,28 @@ class VertexOrder:
     Laplacians); `rast` is bit-identical."""
 
     def __init__(self, faces, V, enabled=None):
-        import numpy as np
         if enabled is None:
             enabled = os.environ.get("FMHR_VERTEX_ORDER", "1") != "0"
         self.V = int(V)
-        self.device = faces.device
-        fa = faces.detach().cpu().numpy().astype(np.int64)
-        if fa.size and (fa.min() < 0 or fa.max() >= self.V):
+        self.device = dev = faces.device
+        # (on the faces' own device: as NumPy on the host — unique + argsort over 3 F indices and three transfers — this was 20-30 ms
+        # of a 260-ms demo run; tools/experiments/r05_run_ham_cold.py)
+        flat = faces.detach().reshape(-1).to(torch.int64)
+        if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= self.V):
             raise RuntimeError("VertexOrder: face table refers to a vertex outside [0, V)")
-        if enabled and fa.size:
-            used, first = np.unique(fa.reshape(-1), return_index=True)
-            seen = used[np.argsort(first, kind="stable")]               # the vertices in first-touch order of the face list
-            rest = np.setdiff1d(np.arange(self.V, dtype=np.int64), used, assume_unique=True)   # in no face: behind them, in their own order
-            old_of_new = np.concatenate([seen, rest])
+        ar = torch.arange(self.V, dtype=torch.int64, device=dev)
+        if enabled and flat.numel():
+            # where the face list first touches each vertex; a vertex in no face keeps 3 F and sorts behind the others, in its own order
+            first = torch.full((self.V,), flat.numel(), dtype=torch.int64, device=dev)
+            first.scatter_reduce_(0, flat, torch.arange(flat.numel(), dtype=torch.int64, device=dev), reduce="amin", include_self=True)
+            old_of_new = torch.argsort(first, stable=True)
         else:
-            old_of_new = np.arange(self.V, dtype=np.int64)
-        new_of_old = np.empty(self.V, np.int64)
-        new_of_old[old_of_new] = np.arange(self.V, dtype=np.int64)
-        self.identity = bool((old_of_new == np.arange(self.V)).all())
-        self.old_of_new = torch.from_numpy(old_of_new).to(self.device)
-        self.new_of_old = torch.from_numpy(new_of_old).to(self.device)
-        self.faces = (faces if self.identity else torch.from_numpy(new_of_old[fa]).to(device=self.device, dtype=faces.dtype)).contiguous()
+            old_of_new = ar
+        new_of_old = torch.empty_like(old_of_new)
+        new_of_old[old_of_new] = ar
+        self.identity = bool((old_of_new == ar).all())
+        self.old_of_new, self.new_of_old = old_of_new, new_of_old
+        self.faces = (faces if self.identity else new_of_old[faces.detach().to(torch.int64)].to(faces.dtype)).contiguous()
 
     def _index(self, x, idx, dim):
         if self.identity:
