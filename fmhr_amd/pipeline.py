@@ -218,8 +218,8 @@ class Stage2Loop:
         perm = self._next_perm()
         if ep == self.epoch_sfs // 2:
             self.weights["albedo"] = self.weights["albedo"] / 10000                   # :250-251
-            self.check()                                                                # their flags go with them
-            self.steppers.clear()
+            for hs_ in self.steppers.values():                                          # the weights are arguments of every backward call: the
+                hs_.weights = dict(self.weights)                                        # workspaces and their mesh tables stay (rebuilding them: 8 ms each)
         V = self.vertices_tmp.shape[0]
         sh, w2cs, projs, imgs, masks, valid_masks = self.args
         for k in range(0, self.num, self.batch):

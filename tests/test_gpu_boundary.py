@@ -156,3 +156,41 @@ def test_stage2_fused_step_matches_the_reference_statements(fx):
     assert e[0] < 1e-4 and e[1] < 1e-4 and e[2] < 1e-4 and e[3] < 1e-4, e
     # four Adam steps from zero moments are ~lr x sign(g) each: a component whose gradient is rounding noise may differ by O(lr)
     assert e[4] < 1e-3 and e[5] < 1e-4, e                                                 # (measured 6.5e-5 / 2.3e-7)
+
+
+def test_stage2_loop_of_the_product_matches_the_reference_statements(fx):
+    """the same fixture through the loop run_ham DRIVES (fmhr_amd.pipeline.Stage2Loop: the capture resident, the batch's views selected
+    inside the step — ABI 6 —, the fused Adam, the albedo-weight switch of :250-251 applied to the live workspaces), fed the fixture's
+    permutations instead of its own draws: the last batch's six loss terms and the parameters after the two epochs"""
+    from fmhr_amd import optim, pipeline
+    g, conf = fx
+    dev = torch.device("cuda:0")
+    x = _inputs(g, dev)
+    H, W = g["in_img"].shape[1:3]
+    V, batch = x["vertices"].shape[0], int(conf["batch"])
+    weights = dict(sfs=conf["sfs_weight"], lap=conf["lap_weight"], albedo=conf["albedo_weight"], mask=conf["mask_weight"],
+                   edge=conf["edge_weight"], delta=conf["delta_weight"])
+    sh = torch.from_numpy(g["s1_sh_coeffs"]).to(dev).float().contiguous()
+    albedo = torch.from_numpy(g["s1_albedo"]).to(dev).float().contiguous().requires_grad_(True)
+    valid_masks = torch.from_numpy(g["init_valid_masks"]).to(dev).contiguous()
+    delta = torch.zeros(V, 3, device=dev, requires_grad=True)
+    opt = optim.Adam([{'params': delta, 'lr': conf["lr"]}, {'params': albedo, 'lr': conf["albedo_lr"]}])
+    perms = iter(torch.from_numpy(g["s2_perms"]).to(torch.int32).to(dev))
+
+    class FixturePerms(pipeline.Stage2Loop):
+        def _next_perm(self):
+            return next(perms)
+    loop = FixturePerms(x["vertices"], x["faces"], delta, albedo, sh, x["img"].contiguous(), x["mask"].contiguous(), valid_masks, x["w2c"].contiguous(),
+                        x["proj"].contiguous(), (H, W), weights, float(g["init_edge_length_mean"]), opt, batch, int(conf["epoch_sfs"]),
+                        torch.Generator().manual_seed(0))
+    for _ in range(g["s2_perms"].shape[0]):
+        loop.run_epoch()
+    loop.check()
+    assert len(loop.steppers) == 2                                      # a batch of 3 views and the ragged last one: both workspaces lived through the switch
+    ref_last = dict(zip(("sfs", "lap", "albedo", "mask", "edge", "delta", "total"), g["s2_last_losses"]))
+    ld = loop.hs.loss_dict()
+    e_last = max(abs(ld[k] - v) / max(abs(v), 1e-6) for k, v in ref_last.items())
+    e = (e_last, rel_err(delta.detach(), g["s2_delta"]), rel_err(albedo.detach(), g["s2_albedo"]))
+    log_parity("stage 2 (:242-317) through the product's own loop (Stage2Loop, views selected inside the step, fused Adam, albedo-weight switch on the "
+               "live workspaces), the fixture's permutations: the last batch's six losses %.1e, final delta %.1e albedo %.1e" % e)
+    assert e[0] < 1e-4 and e[1] < 1e-3 and e[2] < 1e-4, e
