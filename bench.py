@@ -369,10 +369,9 @@ def run_ham_stage2_side_measurement(scene_c, batch, dev, stream, epochs_timed, p
 
 def import_swap_side_measurement(scene_c, dev, views=None, iters=5):
     """Not the headline metric: the import-swap experience of INTEGRATION.md — the stage-2 loop body of mesh_sfs_optim.py:253-308 on the
-    generic fmhr_amd.dr / fmhr_amd.utils ops with torch autograd, op by op (tests/test_gpu_ham.py::_loop_body_on_dr is the restated body
-    the parity test runs), ms per iteration on this workload by the host clock (the path synchronises: torch.where, .item())."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_gpu_ham import _loop_body_on_dr
+    generic fmhr_amd.dr / fmhr_amd.utils ops with torch autograd, op by op (fmhr_amd/examples/loop_body.py is the restated body the
+    parity test runs), ms per iteration on this workload by the host clock (the path synchronises: torch.where, .item())."""
+    from fmhr_amd.examples.loop_body import loop_body_on_dr as _loop_body_on_dr
     n, H, W = views or scene_c["views"], scene_c["H"], scene_c["W"]
     faces = scene_c["faces"].to(dev)
     w2c, proj = scene_c["w2c"][:n].contiguous().to(dev), scene_c["proj"][:n].contiguous().to(dev)

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "oracle") not in sys.path:           # the checker (ham_oracle, checker_scenes): test infrastructure
+    sys.path.insert(1, os.path.join(ROOT, "oracle"))
 
 
 def pytest_configure(config):

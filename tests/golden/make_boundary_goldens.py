@@ -45,7 +45,7 @@ FIRST, LAST = 120, 317                           # mesh_sfs_optim.py: `glctx = d
 def capture(dims=(4, 96, 80, 12, 16), seed=2):
     """the seeded synthetic capture (the scene tests/test_gpu_boundary.py used since round 3)"""
     from util import mesh_scene
-    from test_gpu_ham import oracle_forward_fn
+    from checker_scenes import oracle_forward_fn
     from fmhr_amd import synthetic as S
     sc = mesh_scene(dims, seed=seed)
     with torch.no_grad():

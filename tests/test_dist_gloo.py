@@ -64,7 +64,7 @@ def _worker(rank, world, port, q):
     torch.set_num_threads(2)
     import ham_oracle as oracle
     from fmhr_amd import dist as fdist
-    from test_gpu_ham import prepare
+    from checker_scenes import prepare
     r, w, _ = fdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
     # the direct RCCL communicator (StreamAllReduce) only exists on the nccl backend: everywhere else the helper hands back the torch group
@@ -88,7 +88,7 @@ def _worker(rank, world, port, q):
 def test_two_ranks_match_single_process(oracle):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from fmhr_amd import dist as fdist
-    from test_gpu_ham import prepare
+    from checker_scenes import prepare
     from util import rel_err
     assert [fdist.shard_views(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
     assert [fdist.shard_views(48, r, 8) for r in range(8)] == [(6 * r, 6 * r + 6) for r in range(8)]
@@ -124,7 +124,7 @@ def _frames_worker(rank, world, port, q, n_frames):
     torch.set_num_threads(2)
     import ham_oracle as oracle
     from fmhr_amd import dist as fdist
-    from test_gpu_ham import prepare
+    from checker_scenes import prepare
     fdist.init_from_env(backend="gloo")
     part = fdist.shard_frames_views(n_frames, 4, rank, world)
     groups = fdist.frame_groups(n_frames, world)                  # collective: every rank creates every group
@@ -147,7 +147,7 @@ def test_frames_then_views_partition(oracle, n_frames):
     inside the frame's subgroup.  Either way every frame's result equals the single-process step of that frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from fmhr_amd import dist as fdist
-    from test_gpu_ham import prepare
+    from checker_scenes import prepare
     from util import rel_err
     # the partition itself, at the sizes of BASELINE.json configs[4] (8 frames x 32 views)
     assert [fdist.shard_frames_views(8, 32, r, 8)["frames"] for r in range(8)] == [(r, r + 1) for r in range(8)]

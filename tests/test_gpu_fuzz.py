@@ -78,7 +78,7 @@ def hostile_cameras(oracle, dims, seed):
     every triangle sub-pixel), mirrored (every winding flipped), and pushed INTO the mesh (w <= 0 for about a third of the vertices:
     their triangles are dropped, rule R1).  Targets are rendered by the checker with the same cameras."""
     from fmhr_amd import synthetic as S
-    from test_gpu_ham import oracle_forward_fn
+    from checker_scenes import oracle_forward_fn
     sc = mesh_scene(dims, seed=seed)
     rng = np.random.default_rng(500 + seed)
     proj = sc["proj"].clone()

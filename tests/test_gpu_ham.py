@@ -9,6 +9,9 @@ import torch
 import torch.nn.functional as F
 
 from util import log_parity, mesh_scene, rel_err
+from checker_scenes import oracle_forward_fn, prepare              # noqa: F401  (re-exported: other test modules import them from here)
+import checker_scenes
+from fmhr_amd.examples.loop_body import loop_body_on_dr as _loop_body_on_dr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -35,55 +38,6 @@ def grad_bar(name, e_d, e_a, o_d, o_a, t_d=None, t_a=None):
         assert e_d < max(TOL, 2 * o_d) and e_a < max(TOL, 2 * o_a), (name, e_d, e_a, o_d, o_a)
     else:
         assert e_d < TOL and e_a < TOL, (name, e_d, e_a, o_d, o_a)
-
-
-def gpu_loop_decisions(ref32, tmp_img_gpu, img, mask, name=""):
-    """The loop body's own discrete decisions as the GPU took them.  The rasterizer's decisions are bit-identical between
-    the kernels and the fp32 twin (asserted: rast, antialias items), so the fp64 reference can take them from the twin; the SIGN of an
-    L1 residual (mesh_sfs_optim.py:289) is decided on image VALUES, which agree to 1e-6 only — a residual within that of zero may
-    come out with the other sign on the GPU (one pixel-channel in 2.6 M on the demo-capture scene: +-w_sfs / (3 Pv) x radiance at the
-    three corners of one face = 2.5 % of that case's largest albedo gradient).  "fp64 values on the GPU's decisions" therefore takes
-    the signs from the GPU's own antialiased image — after checking that they differ from the twin's ONLY where both residuals are
-    within fp32 rounding of zero, and only in a handful of places: anything else is a defect, not a marginal decision."""
-    idx = torch.where((mask > 0) & (ref32["rast"][..., 3] > 0))
-    r_gpu = torch.as_tensor(tmp_img_gpu).detach().cpu().to(torch.float32)[idx] - img[idx]
-    r_ref = ref32["tmp_img"].detach().to(torch.float32)[idx] - img[idx]
-    s_gpu, s_ref = torch.sign(r_gpu), ref32["decisions"]["l1_sign"].to(torch.float32)
-    assert s_gpu.shape == s_ref.shape
-    flip = s_gpu != s_ref
-    nflip = int(flip.sum())
-    if nflip:
-        tol = 4e-6 * max(1.0, float(img.abs().max()))
-        assert nflip <= 8 and float(r_gpu[flip].abs().max()) <= tol and float(r_ref[flip].abs().max()) <= tol, \
-            (name, nflip, float(r_gpu[flip].abs().max()), float(r_ref[flip].abs().max()))
-        log_parity(f"{name}: {nflip} L1 residual sign(s) within fp32 rounding of zero decided the other way by the GPU "
-                   f"(|d| <= {float(torch.maximum(r_gpu[flip].abs(), r_ref[flip].abs()).max()):.1e}): the fp64 reference takes the GPU's")
-    return dict(ref32["decisions"], l1_sign=s_gpu)
-
-
-def oracle_forward_fn(oracle, sc):
-    def fwd(vertices, albedo, sh, mask):
-        z = torch.zeros_like(vertices)
-        img = torch.zeros(sc["views"], sc["H"], sc["W"], 3)
-        out = oracle.ham_stage2_losses(vertices, z, albedo[None], sh, sc["w2c"], sc["proj"], img, mask, mask, sc["faces"],
-                                       (sc["H"], sc["W"]), dict(sfs=0, lap=0, albedo=0, mask=0, edge=0, delta=0), 0.0)
-        return dict(tmp_img=out["tmp_img"], pred_mask=out["pred_mask"], rast=out["rast"])
-    return fwd
-
-
-def prepare(oracle, dims, seed):
-    from fmhr_amd import synthetic as S
-    sc = mesh_scene(dims, seed=seed)
-    with torch.no_grad():
-        tg = S.make_targets(sc, oracle_forward_fn(oracle, sc))
-    rng = np.random.default_rng(seed + 100)
-    sc["delta"] = torch.tensor(rng.standard_normal((sc["V"], 3)) * 2e-4, dtype=torch.float32)
-    sc["albedo"] = (sc["albedo0"] + torch.tensor(rng.uniform(-0.1, 0.1, (sc["V"], 3)), dtype=torch.float32))
-    # make the photometric mask differ from coverage somewhere (exercise mask>0 gating)
-    tg["mask"][:, : sc["H"] // 5] = 0
-    sc.update(tg)
-    sc["elm"] = float(oracle.edge_length_mean(sc["vertices"], sc["faces"]))
-    return sc
 
 
 # "views19/30/37/41": more views than one lane group holds at 1 view per lane -> 3, 4, 5 and 6 views per lane with ragged last slots
@@ -378,56 +332,6 @@ def test_fused_step_edge_cases(oracle):
     sc = dict(sc, mask=torch.zeros_like(sc["mask"]))
     ld, v = _step_vs_oracle(oracle, sc, "no valid pixel", osc)
     assert ld["n_valid"] == 0 and ld["sfs"] == 0.0
-
-
-def _loop_body_on_dr(g, faces, n, H, W, weights, elm, pos_value=None, reg_dtype=torch.float32, lap_fn=None):
-    """the reference's own loop body (mesh_sfs_optim.py:253-306) on fmhr_amd.dr / fmhr_amd.utils GPU ops.  `pos_value`
-    substitutes the VALUE of the clip positions (straight-through: the gradient still flows through the einsums), so two
-    implementations can be compared on identical discrete decisions.  `reg_dtype=float64` evaluates the mesh regularisers
-    (torch ops only) in double on the fp32-rounded vertices: on a sub3-class mesh the uniform Laplacian cancels 3 digits
-    (|Lx| ~ 1e-4 |x|), so two fp32 evaluations of it differ by more than 1e-4 and neither can referee the other."""
-    from fmhr_amd import dr, utils
-    delta = g["delta"].clone().requires_grad_(True)
-    albedo = g["albedo"][None].clone().requires_grad_(True)
-    glctx = dr.RasterizeGLContext()
-    vertices = g["vertices"] + delta
-    vertsw = torch.cat([vertices, torch.ones_like(vertices[:, 0:1])], axis=1).unsqueeze(0).expand(n, -1, -1)
-    rot_verts = torch.einsum('ijk,ikl->ijl', vertsw, g["w2c"])
-    proj_verts = torch.einsum('ijk,ikl->ijl', rot_verts, g["proj"])
-    if pos_value is not None:
-        proj_verts = pos_value.detach() + (proj_verts - proj_verts.detach())
-    normals = utils.get_normals(vertsw[:, :, :3], faces.long())
-    rast_out, _ = dr.rasterize(glctx, proj_verts, faces, resolution=(H, W))
-    feat = torch.cat([normals, albedo.expand(n, -1, -1), torch.ones_like(vertsw[:, :, :1])], dim=2)
-    feat, _ = dr.interpolate(feat, rast_out, faces)
-    pred_normals = F.normalize(feat[:, :, :, :3].contiguous(), p=2, dim=3)
-    rast_albedo = feat[:, :, :, 3:6].contiguous()
-    pred_mask = dr.antialias(feat[:, :, :, 6:7].contiguous(), rast_out, proj_verts, faces).squeeze(-1)
-    valid_idx = torch.where((g["mask"] > 0) & (rast_out[:, :, :, 3] > 0))
-    radiance = utils.get_radiance(g["sh0"][valid_idx[0]], pred_normals[valid_idx], 3).unsqueeze(-1)
-    pred_img = radiance * rast_albedo[valid_idx]
-    tmp_img = torch.zeros_like(g["img"])
-    tmp_img[valid_idx] = pred_img
-    tmp_img = dr.antialias(tmp_img, rast_out, proj_verts, faces)
-    terms = {}
-    terms["sfs"] = weights["sfs"] * F.l1_loss(tmp_img[valid_idx], g["img"][valid_idx])
-    rv, ra, rd = vertices.to(reg_dtype), albedo.squeeze(0).to(reg_dtype), delta.to(reg_dtype)
-    fl = faces.long()
-    if lap_fn is None:
-        lap_fn = utils.laplacian_smoothing
-    else:                                             # the checker's torch Laplacian builds its operator on the CPU
-        rv, ra, rd, fl = rv.cpu(), ra.cpu(), rd.cpu(), fl.cpu()
-    terms["lap"] = (weights["lap"] * lap_fn(rv, fl, method="uniform")).to(delta.device)
-    terms["albedo"] = (weights["albedo"] * lap_fn(ra, fl, method="uniform")).to(delta.device)
-    terms["mask"] = weights["mask"] * F.mse_loss(pred_mask, g["valid_mask"])
-    a, b, c = rv[fl[:, 0]], rv[fl[:, 1]], rv[fl[:, 2]]
-    edge_length = torch.cat([((a - b) ** 2).sum(1), ((c - b) ** 2).sum(1), ((a - c) ** 2).sum(1)])
-    terms["edge"] = (torch.clip(edge_length - float(elm), 0, 1).mean() * weights["edge"]).to(delta.device)
-    terms["delta"] = ((rd ** 2).sum(1).mean() * weights["delta"]).to(delta.device)
-    loss = terms["sfs"] + terms["lap"] + terms["albedo"] + terms["mask"] + terms["delta"] + terms["edge"]
-    loss.backward()
-    return dict(loss=loss.detach(), terms={k: float(v) for k, v in terms.items()}, delta=delta, albedo=albedo,
-                rast=rast_out.detach(), pos=proj_verts.detach(), tmp_img=tmp_img.detach(), n_valid=valid_idx[0].numel())
 
 
 def test_unchanged_loop_body_on_dr(oracle):

@@ -106,7 +106,7 @@ def test_obj_writers(tmp_path):
 
 def _tiny_capture(oracle, dtype=torch.float32, seed=2):
     sc = mesh_scene((3, 72, 64, 10, 14), seed=seed)
-    from test_gpu_ham import oracle_forward_fn
+    from checker_scenes import oracle_forward_fn
     from fmhr_amd import synthetic as S
     with torch.no_grad():
         tg = S.make_targets(sc, oracle_forward_fn(oracle, sc))

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from util import mesh_scene, rel_err
-from test_gpu_ham import prepare
+from checker_scenes import prepare
 
 
 def test_step_fd_and_precision(oracle):

@@ -2,6 +2,8 @@
 import numpy as np
 import torch
 
+from checker_scenes import mesh_scene                     # noqa: F401  (oracle/checker_scenes.py: shared with __graft_entry__.smoke())
+
 
 def rel_err(a, b):
     """per-tensor max|a-b| / max|b| (SURVEY.md §7 'Tolerance definition')."""
@@ -42,19 +44,6 @@ def random_scene(seed, n=2, H=24, W=20, dtype=torch.float32, nv=14, nf=18):
             faces.append(t)
     tri = torch.tensor(np.stack(faces), dtype=torch.int32)
     return pos, tri, rng
-
-
-def mesh_scene(name_or_dims, seed=0, views=None):
-    """synthetic HAM scene (fmhr_amd.synthetic) as CPU tensors + clip positions for its start mesh."""
-    from fmhr_amd import synthetic as S
-    if isinstance(name_or_dims, str):
-        sc = S.scene_from_config(name_or_dims, seed, views)
-    else:                                            # (views, H, W, rings, segs[, subdiv[, hands]])
-        d = tuple(name_or_dims)
-        sc = S.make_scene(*d[:6], seed=seed, hands=d[6] if len(d) > 6 else 1)
-    v4 = torch.cat([sc["vertices"], torch.ones(sc["V"], 1)], 1)
-    sc["pos"] = torch.einsum('nvk,nkl->nvl', torch.einsum('vk,nkl->nvl', v4, sc["w2c"]), sc["proj"]).contiguous()
-    return sc
 
 
 def sort_items(items, alphas):

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from fmhr_amd import synthetic
 from fmhr_amd.ham import render_forward, edge_length_mean
-from test_gpu_ham import _loop_body_on_dr
+from fmhr_amd.examples.loop_body import loop_body_on_dr as _loop_body_on_dr
 views = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 sc = synthetic.scene_from_config("metric", 0, views)
 dev = torch.device("cuda:0")
