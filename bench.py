@@ -108,8 +108,9 @@ class Timing:
         return evs[2 * slot].elapsed_time(evs[2 * slot + 1])
 
 
-def cpu_baseline(scene, views_sample, seed):
-    """Time the CPU oracle (restatement of the reference loop body on CPU torch + the C rasterizer) on a bounded sample."""
+def cpu_baseline(scene, views_sample, seed, views_per_step=None):
+    """Time the CPU oracle (restatement of the reference loop body on CPU torch + the C rasterizer) on a bounded sample.
+    views_per_step: the views ONE step of the timed workload renders (loop mode: the minibatch; default: all the scene's views)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ham_oracle as oracle
     oracle.lib()
@@ -144,7 +145,7 @@ def cpu_baseline(scene, views_sample, seed):
         out["loss"].backward()
         times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
-    n = scene["views"]
+    n = views_per_step or scene["views"]
     return dict(value=1.0 / (t * n / S), unit="iterations/s", cores=cores, kind="port",
                 sample=f"{S} of {n} views ({H}x{W}, V={scene['V']}), fwd+bwd, median of 5 = {t:.3f}s, scaled x{n / S:.0f}; "
                        f"C rasterize / interpolate / antialias: {cores_c} OpenMP threads over the views, torch ops: {cores} threads")
@@ -443,6 +444,13 @@ def main():
         fgroups = [fdist.make_stream_all_reduce(torch.distributed.group.WORLD, numel=12 * V + 8) if sharded else None]
         view_rank, view_world = rank, world
     n = s1 - s0
+    # LOOP MODE (--config demo): a step is one MINIBATCH of the resident capture, drawn by the product's own loop (fmhr_amd.pipeline.Stage2Loop:
+    # a fresh permutation per epoch, views selected inside the step — ABI 6 — and, on N ranks, the batch sharded over them): every rank
+    # holds the whole capture, `n` is this rank's share of a batch
+    loop_batch = synthetic.LOOP_BATCH.get(args.config) if (n_frames == 1 and args.views is None) else None
+    if loop_batch:
+        s0, s1 = 0, n_total
+        n = fdist.shard_batch(loop_batch, V, rank, world)["n_local"]
     if n == 0:
         raise SystemExit("more ranks than views")
     # The optimisation runs on the product's renumbering of the VERTICES (fmhr_amd.ham.VertexOrder: first-touch order of the face list;
@@ -488,7 +496,30 @@ def main():
             self.delta.grad, self.albedo.grad = gd, ga.view(1, V, 3)
             return losses
 
-    problems = [Problem(f) for f in range(f0, f1)]
+    class LoopProblem:
+        """LOOP MODE: the same optimisation stepped by the product's loop on minibatches of the resident capture (fmhr_amd.pipeline.Stage2Loop)"""
+
+        def __init__(self, frame):
+            from fmhr_amd.pipeline import Stage2Loop
+            self.tg = tgt = synthetic.make_targets(scene, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, H, W), device=dev)
+            self.delta = torch.zeros(V, 3, device=dev, requires_grad=True)
+            self.albedo = scene["albedo0"][None].to(dev).clone().requires_grad_(True)
+            self.opt = Adam([{'params': self.delta, 'lr': lr["lr"]}, {'params': self.albedo, 'lr': lr["albedo_lr"]}])
+            self.group = fgroups[frame]
+            self.loop = Stage2Loop(vtmp, faces, self.delta, self.albedo, sh, tgt["img"], tgt["mask"], tgt["valid_mask"], w2c, proj, (H, W),
+                                   scene["weights"], elm, self.opt, loop_batch, 1 << 30, torch.Generator(device="cpu").manual_seed(args.seed),
+                                   check_every=64, group=torch.distributed.group.WORLD if sharded else None, exchange=self.group)
+            self.loop.step_next()                                # the first step builds the workspace of this rank's batch share
+
+        @property
+        def hs(self):
+            return self.loop.hs
+
+        def step(self):
+            self.loop.step_next()
+            return self.loop.hs.losses
+
+    problems = [(LoopProblem if loop_batch else Problem)(f) for f in range(f0, f1)]
     hs, tg, delta, albedo, opt, group = (problems[0].hs, problems[0].tg, problems[0].delta, problems[0].albedo, problems[0].opt,
                                           problems[0].group)
     nf_local = len(problems)
@@ -517,9 +548,15 @@ def main():
         profiling pass only (N > 1)."""
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         a = (vtmp, delta.detach(), albedo.detach()[0], sh, w2c, proj)
+        vi, rr = None, reg_range
+        if loop_batch:                                           # LOOP MODE: this rank's share of the running epoch's first batch
+            lp = problems[0].loop
+            part = fdist.shard_batch(loop_batch, V, rank, world)
+            perm = lp._cur if lp._cur is not None else lp.perm
+            vi, rr = perm[part["views"][0]: part["views"][1]], part["reg_range"]
         ev[0].record(stream)
-        hs.forward(*a, tg["mask"], tg["valid_mask"])
-        hs.backward(*a, tg["img"], tg["mask"], tg["valid_mask"], reg_range=reg_range, split=True)
+        hs.forward(*a, tg["mask"], tg["valid_mask"], view_idx=vi)
+        hs.backward(*a, tg["img"], tg["mask"], tg["valid_mask"], reg_range=rr, split=True, view_idx=vi)
         ev[1].record(stream)
         if hasattr(group, "all_reduce_"):
             group.all_reduce_(hs.bucket)
@@ -649,6 +686,18 @@ def main():
         torch.distributed.all_reduce(ovf)
     if float(ovf) != 0:
         raise SystemExit(f"bench.py: the antialias work-item list or a rasterizer fragment bin overflowed on {int(float(ovf))} rank(s) (aa_cap={hs.dims.aa_cap})")
+    # ... and so does a dead or diverged exchange (it would read as a FASTER number): after the timed region the
+    # replicated parameters of every problem are fingerprinted across the ranks that share it and the exchange's own failure state is read
+    # (fmhr_amd.dist.ExchangeMonitor) — ExchangeError on every rank, exit code != 0, no JSON line
+    exchange_ok = None
+    if sharded:
+        for p_ in problems:
+            tg_ = p_.group
+            if tg_ is None:
+                continue                                         # (a rank that holds whole frames exchanges nothing)
+            torch_group = tg_.group if hasattr(tg_, "all_reduce_") else tg_
+            mon = fdist.ExchangeMonitor(torch_group if torch_group is not None else torch.distributed.group.WORLD, tg_ if hasattr(tg_, "gave_up") else None, dev)
+            exchange_ok = mon.verify([p_.delta, p_.albedo], "bench.py: (delta, albedo) after the timed region")
     final = dict(zip(("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid"), losses.tolist()))
     aa_items = sum(p.hs.aa_item_count() for p in problems).to(torch.float32).reshape(1)
     if sharded:
@@ -675,10 +724,12 @@ def main():
             "value": K / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n_total} views x {H}x{W}, synthetic hand mesh V={V} F={F} "
+            "config": {"workload": f"{args.config}: {(str(loop_batch) + ' of ') if loop_batch else ''}{n_total} views x {H}x{W}, synthetic hand mesh V={V} F={F} "
                                    f"({'MANO sub3 counts' if V % 49281 == 0 else 'MANO base counts' if V % 778 == 0 else 'custom'}"
                                    f"{', two hands' if scene.get('hands', 1) == 2 else ''}), "
-                                   f"stage-2 step = render + 6 losses + backward + grad all-reduce + Adam, stationary (pre-rolled {preroll} steps)",
+                                   f"stage-2 step = render + 6 losses + backward + grad all-reduce + Adam, stationary (pre-rolled {preroll} steps)"
+                                   + (f"; LOOP MODE: each step is a minibatch of {loop_batch} views drawn by the product's loop (fresh permutation per epoch, views selected inside the step, the batch sharded over the ranks)" if loop_batch else ""),
+                       "batch": loop_batch or n_total,
                        "views": n_total, "views_per_gpu": n, "frames": n_frames, "frames_per_gpu": nf_local, "frame_streams": n_fs, "H": H, "W": W, "V": V, "F": F,
                        "rasterizer": "binned (per-segment LDS bins)" if hs.binned else "atomic depth keys + resolve",
                        "vertex_order": ("caller's numbering" if order.identity else
@@ -714,7 +765,12 @@ def main():
             "losses": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in final.items()},
         }
         if collective is not None:
+            # the cross-rank check after the timed region: every rank holds the same bits of (delta, albedo), no exchange gave up
+            collective["exchange_ok"] = bool(exchange_ok and exchange_ok["ok"])
+            collective["exchange_check"] = exchange_ok
             out["collective"] = collective
+        if loop_batch:                                          # LOOP MODE times the product's loop itself: the side measurements of the fixed-batch
+            args.no_run_length = True                            # workload (run length, numbering, run_ham's loop against the bare step, import swap) do not apply
         if world == 1 and nf_local == 1 and not args.no_run_length:
             try:
                 out["run_length"] = run_length_side_measurement(Problem, stream, args.run_length)
@@ -749,7 +805,7 @@ def main():
                 out["stage1"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(scene, max(1, min(args.cpu_views, n_total)), args.seed)
+                out["cpu_baseline"] = cpu_baseline(scene, max(1, min(args.cpu_views, loop_batch or n_total)), args.seed, views_per_step=loop_batch)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))

@@ -52,7 +52,7 @@ int aa_bwd_rgba(const float*, const float*, const float*, const float*, const in
                 int, int, int, float*, const float*, float*, float*, const int32_t*, hipStream_t);
 int clip_positions_impl(const float*, const float*, int, int, float*, hipStream_t);
 int geometry_impl(const float*, const float*, const float*, const float*, int, int, float*, int, int, int2*, float*, const int32_t*,
-                  const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, int*, const int32_t*, const float*, float*, hipStream_t);
+                  const int32_t*, const int32_t*, float*, float*, const float*, float*, float*, int*, const int32_t*, const float*, float*, int, int32_t*, hipStream_t);
 int loss_pix_impl(const unsigned long long*, const float*, const float*, const float*, const float*, long long, int, int, const ViewSel, const int*, const int*,
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
@@ -63,7 +63,7 @@ int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
-    size_t vertices, nsum, normals, attr8, sh_local, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
+    size_t vertices, nsum, normals, attr8, sh_local, view_idx_ws, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
         g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, bin_state, bin_list, total;
 };
 
@@ -88,6 +88,7 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.normals = take(off, V * 12);
     L.attr8 = take(off, V * 32);
     L.sh_local = take(off, (size_t)d->n * 36);      // the step's n SH rows in the step's own order (ABI 6: the caller's may be the capture's, selected by view_idx)
+    L.view_idx_ws = take(off, (size_t)d->n * 4);    // the step's view selection, clamped to the capture's views by the geometry kernel: what every later kernel reads
     L.pos = take(off, nV * 16);
     L.snap = take(off, nV * 8);
     L.silh = take(off, (size_t)d->n * d->F);
@@ -309,8 +310,9 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         // on the fly by both parts and stored for everything after them
         TRY(geometry_impl(vertices_tmp, delta, w2c, proj, d->n, d->V, nullptr, d->H, d->W, (int2*)(w + L.snap), (float*)(w + L.cmat), tri,
                           vf_ptr, vf_idx, (float*)(w + L.nsum), (float*)(w + L.normals), albedo, (float*)(w + L.attr8), vertices,
-                          (int*)(w + L.stamp), view_idx, sh, (float*)(w + L.sh_local), st));
+                          (int*)(w + L.stamp), view_idx, sh, (float*)(w + L.sh_local), d->n_src, (int32_t*)(w + L.view_idx_ws), st));
         sh = (const float*)(w + L.sh_local);                         // from here on: the step's n rows, in the step's order
+        if (view_idx != nullptr) sel.idx = (const int32_t*)(w + L.view_idx_ws);     // ... and the selection the geometry kernel clamped to [0, n_src)
     }
     {
         // rasterize; the resolve pass also shades the covered pixels, leaves the per-pixel backward word, marks the owning
@@ -388,6 +390,10 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
     const float rg = wt->reg_grad_scale;
     const size_t nB = 2048;
     sh = (const float*)(w + L.sh_local);                             // the forward left the step's n SH rows here, in the step's order (ABI 6)
+    if (view_idx != nullptr) {                                       // ... and the view selection it rendered, clamped to the capture's views: the backward
+        view_idx = (const int32_t*)(w + L.view_idx_ws);              // differentiates exactly what the forward rendered, whatever the caller passes here
+        sel.idx = view_idx;
+    }
 
     {
         ProfScope ps(FMHR_SLOT_LOSS_PIX, st);

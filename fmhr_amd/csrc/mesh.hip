@@ -267,11 +267,23 @@ __device__ __forceinline__ void transform_body(int v, int b, const float* __rest
                                                const float* __restrict__ w2c, const float* __restrict__ proj, int V,
                                                float4* __restrict__ pos, int H, int W, int2* __restrict__ snap,
                                                float4* __restrict__ cmat, const int32_t* __restrict__ view_idx,
-                                               const float* __restrict__ sh, float* __restrict__ sh_local)
+                                               const float* __restrict__ sh, float* __restrict__ sh_local, int n_src, int32_t* __restrict__ view_idx_ws,
+                                               int* __restrict__ stamp)
 {
     // ABI 6: view b of the step is view view_idx[b] of the caller's per-view arrays (the loop's minibatch, mesh_sfs_optim.py:255-260);
     // this kernel is the only reader of the small ones: the combined matrix lands in cmat[b], the SH row in sh_local[b]
-    const int sb = (view_idx != nullptr) ? view_idx[b] : b;
+    // The index is the caller's data: it is CLAMPED to the capture's views here, the clamped value is what every later kernel of the step
+    // reads (view_idx_ws: the four pixel kernels index img / mask / valid_mask through it), and an index that needed clamping sets the
+    // sticky word stamp[1] the host reads with the overflow flags — a bad index is a reported error, never an out-of-bounds read
+    int sb = b;
+    if (view_idx != nullptr) {
+        const int raw = view_idx[b];
+        sb = min(max(raw, 0), n_src - 1);
+        if (blockIdx.x == 0 && threadIdx.x == 41) {
+            view_idx_ws[b] = sb;
+            if (raw != sb) stamp[1] = 1;
+        }
+    }
     const float* A = w2c + (size_t)sb * 16;
     const float* B = proj + (size_t)sb * 16;
     if (sh_local != nullptr && blockIdx.x == 0 && threadIdx.x >= 32 && threadIdx.x < 41) sh_local[(size_t)b * 9 + (threadIdx.x - 32)] = sh[(size_t)sb * 9 + (threadIdx.x - 32)];
@@ -883,7 +895,7 @@ k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta,
            float4* __restrict__ cmat, const int32_t* __restrict__ tri, const int32_t* __restrict__ vf_ptr,
            const int32_t* __restrict__ vf_idx, float* __restrict__ nsum, float* __restrict__ normals,
            const float* __restrict__ albedo, float4* __restrict__ attr8, float* __restrict__ vout, int* __restrict__ stamp,
-           const int32_t* __restrict__ view_idx, const float* __restrict__ sh, float* __restrict__ sh_local)
+           const int32_t* __restrict__ view_idx, const float* __restrict__ sh, float* __restrict__ sh_local, int n_src, int32_t* __restrict__ view_idx_ws)
 {
     // the step counter that tags this step's coverage entries and owner marks (raster.hip, shade.hip): advanced by the step's first kernel
     if (stamp != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -893,7 +905,7 @@ k_geometry(const float* __restrict__ verts_tmp, const float* __restrict__ delta,
     const int rows_normals = (int)gridDim.y - n;                     // dispatched first: their long dependent chains start early
     if ((int)blockIdx.y >= rows_normals)
         transform_body<HAS_DELTA>(blockIdx.x * kBlock + threadIdx.x, (int)blockIdx.y - rows_normals, verts_tmp, delta, w2c, proj, V, pos, H, W, snap,
-                       cmat, view_idx, sh, sh_local);
+                       cmat, view_idx, sh, sh_local, n_src, view_idx_ws, stamp);
     else
         normals_gather_body<HAS_DELTA>((int)blockIdx.y * gridDim.x + blockIdx.x, verts_tmp, tri, vf_ptr, vf_idx, V, nsum, normals, albedo, attr8,
                             delta, vout);
@@ -920,17 +932,18 @@ int clip_positions_impl(const float* verts, const float* cmat, int n, int V, flo
 int geometry_impl(const float* verts_tmp, const float* delta, const float* w2c, const float* proj, int n, int V, float* pos, int H, int W,
                   int2* snap, float* cmat, const int32_t* tri, const int32_t* vf_ptr, const int32_t* vf_idx, float* nsum,
                   float* normals, const float* albedo, float* attr8, float* vout, int* stamp, const int32_t* view_idx, const float* sh,
-                  float* sh_local, hipStream_t st)
+                  float* sh_local, int n_src, int32_t* view_idx_ws, hipStream_t st)
 {
+    FMHR_CHECK_ARG(view_idx == nullptr || (n_src >= 1 && view_idx_ws != nullptr && stamp != nullptr), "geometry: a view selection needs n_src >= 1 and its workspace copy");
     if (n == 0 || V == 0) return FMHR_OK;
     const int gx = cdiv(V, kBlock);
     const int rows_normals = cdiv(cdiv((long long)V * kSubLanes, kBlock), gx);
     if (delta != nullptr)
         k_geometry<true><<<dim3(gx, n + rows_normals), kBlock, 0, st>>>(verts_tmp, delta, w2c, proj, n, V, (float4*)pos, H, W, snap, (float4*)cmat, tri,
-                                                                    vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp, view_idx, sh, sh_local);
+                                                                    vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp, view_idx, sh, sh_local, n_src, view_idx_ws);
     else
         k_geometry<false><<<dim3(gx, n + rows_normals), kBlock, 0, st>>>(verts_tmp, delta, w2c, proj, n, V, (float4*)pos, H, W, snap, (float4*)cmat, tri,
-                                                                     vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp, view_idx, sh, sh_local);
+                                                                     vf_ptr, vf_idx, nsum, normals, albedo, (float4*)attr8, vout, stamp, view_idx, sh, sh_local, n_src, view_idx_ws);
     FMHR_CHECK_LAUNCH("k_geometry");
     return FMHR_OK;
 }

@@ -14,10 +14,12 @@
 // the flags are written with system-scope release stores and read with system-scope acquire loads, every thread fences (acquire, system
 // scope: the L1 is invalidated) behind the wait before it touches a peer's data, which then moves in plain 16-byte accesses (the first
 // form read it with 8-byte system-scope atomic loads: 33 us for the 2.35 MB bucket with NO peer at all; this one: see DESIGN.md §6).  Flags carry the call's epoch (monotone:
-// nothing is ever reset); every spin is BOUNDED — a wave that waits longer than kSpinLimit polls sets the block's abort word, every
-// other wait sees it and the whole grid drains: a rank whose peer died leaves the kernel with an error the host reads
-// (fmhr_peer_status), it does not hang the GPU.  Host protocol, negotiation and fallback to RCCL: fmhr_amd/dist.py (PeerAllReduce).
+// nothing is ever reset); every spin is BOUNDED BY WALL CLOCK — a wave that waits longer than 5 s (FMHR_PEER_WAIT_MS) sets the block's abort
+// word, every other wait sees it and the whole grid drains with the bucket's loss slots set to NaN: a rank whose peer died or fell more than
+// that behind leaves the kernel with an error the host reads (fmhr_peer_status; fmhr_amd.dist.ExchangeMonitor polls it) and with results
+// nobody can mistake for reduced ones; it does not hang the GPU.  Host protocol, negotiation and fallback to RCCL: fmhr_amd/dist.py (PeerAllReduce).
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace fmhr {
@@ -25,7 +27,10 @@ namespace fmhr {
 constexpr int kPeerMax = 16;
 constexpr int kPeerBlocks = 128;                  // resident by construction (256 CUs): the grid barrier below needs every block running; the
                                                   // copies are as fast from 128 workgroups as from 1 024 (3 us), a barrier costs per workgroup
-constexpr unsigned kSpinLimit = 1u << 22;         // polls (a few seconds) before a wait gives up
+constexpr long long kWaitTicksDefault = 5ll * 100000000ll;   // a wait gives up after 5 s of WALL CLOCK (s_memrealtime: 100 MHz, constant) — the rank
+                                                  // skew the exchange tolerates; FMHR_PEER_WAIT_MS at fmhr_peer_create overrides it.  (Until round 5
+                                                  // the bound was a poll count, "a few seconds" only for an undisturbed wave: ADVICE r5)
+constexpr unsigned kClockEvery = 64;              // polls between two looks at the clock
 
 struct PeerBlock {                                // what the kernel needs of one rank's exported block
     float4* stage;                                // [n / 4] the rank's bucket as 16-byte words
@@ -41,7 +46,15 @@ struct PeerArgs {
     unsigned bar0;                                // the grid-barrier counter before this call's first barrier (the host keeps the count)
     int in_place;                                 // the bucket IS this rank's staging area (fmhr_peer_staging): nothing to stage
     unsigned* bar;                                // local: grid-barrier counter (monotone), abort word
+    long long wait_ticks;                         // s_memrealtime ticks (10 ns) a wait may last
 };
+
+// true once a poll loop that started at `t0` has used up its wall-clock budget (looked at every kClockEvery-th poll)
+__device__ __forceinline__ bool out_of_time(unsigned& spins, long long t0, long long budget)
+{
+    if ((++spins % kClockEvery) != 0u) return false;
+    return (long long)wall_clock64() - t0 > budget;
+}
 
 // every thread, behind a wait on the peers' flags and the workgroup barrier that ends it: nothing of a peer's block may come out of
 // this CU's L1 (the waiting lanes' acquire loads invalidate it as well; this makes it every wave's own)
@@ -56,7 +69,7 @@ __device__ __forceinline__ void acquire_system() { __builtin_amdgcn_fence(__ATOM
 //   * ONE system-scope acquire per workgroup behind the wait, by the threads that polled (the L1 it invalidates is the CU's, shared by
 //     the workgroup's waves), then the workgroup barrier.
 // all blocks of the grid have arrived `target / gridDim.x` times; false: aborted.  The polls are RELAXED loads
-__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target)
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, long long budget)
 {
     __shared__ int ok;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // this wave's stores (staging / reduced shard) have completed
@@ -65,12 +78,16 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                // system scope, once per workgroup
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
+        const long long t0 = (long long)wall_clock64();
         int good = 1;
         while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            if (++spins > kSpinLimit || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { good = 0; break; }
+            if (out_of_time(spins, t0, budget) || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { good = 0; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         if (!good) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the other workgroups' arrivals were relaxed increments behind their release fences: this acquire orders what they wrote before the
+        // flag store that follows the barrier (signal_peers: a system-scope release) — ADVICE r5
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         ok = good;
     }
     __syncthreads();
@@ -85,8 +102,9 @@ __device__ __forceinline__ bool wait_peers(const PeerArgs& A, int which)
         if (threadIdx.x < (unsigned)A.world && (int)threadIdx.x != A.rank) {
             const unsigned* f = A.blk[A.rank].flags + which * kPeerMax + threadIdx.x;
             unsigned spins = 0;
+            const long long t0 = (long long)wall_clock64();
             while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - A.epoch) < 0) {
-                if (++spins > kSpinLimit || __hip_atomic_load(A.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (out_of_time(spins, t0, A.wait_ticks) || __hip_atomic_load(A.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                     __hip_atomic_store(A.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -125,6 +143,14 @@ __device__ __forceinline__ void copy_words(float4* __restrict__ dst, const float
     for (; i < n; i += nth) dst[i] = src[i];
 }
 
+// A wait gave up (the abort word is set and stays set: every later call leaves at its first wait): the bucket holds this rank's share
+// only.  So that NOTHING downstream can take it for the reduced one, its last 8 floats — the step's loss slots, the valid-pixel count among
+// them — become NaN: fmhr_ham_combine then turns every gradient, the losses and (fused Adam) the parameters into NaN on this rank.
+__device__ __forceinline__ void poison(float* bucket, long long n2)
+{
+    if (threadIdx.x < 8) bucket[4 * n2 - 8 + threadIdx.x] = __builtin_nanf("");
+}
+
 __global__ void __launch_bounds__(kBlock) k_peer_all_reduce(const PeerArgs A, float* __restrict__ bucket)
 {
     const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x, nth = (long long)gridDim.x * kBlock;
@@ -137,11 +163,11 @@ __global__ void __launch_bounds__(kBlock) k_peer_all_reduce(const PeerArgs A, fl
     if (!A.in_place) {
         copy_words(mine.stage, b4, A.n2, tid, nth);
         bar_at += gridDim.x;
-        if (!grid_barrier(A.bar, bar_at)) return;
+        if (!grid_barrier(A.bar, bar_at, A.wait_ticks)) { poison(bucket, A.n2); return; }
     }
     if (blockIdx.x == 0) signal_peers(A, 0);
     // B
-    if (!wait_peers(A, 0)) return;
+    if (!wait_peers(A, 0)) { poison(bucket, A.n2); return; }
     // C: my shard, every rank's contribution in rank order (the same sum, bit for bit, whoever computes it)
     long long s0, s1;
     shard_of(A.n2, A.world, A.rank, s0, s1);
@@ -159,10 +185,10 @@ __global__ void __launch_bounds__(kBlock) k_peer_all_reduce(const PeerArgs A, fl
         mine.out[i - s0] = acc;
     }
     bar_at += gridDim.x;
-    if (!grid_barrier(A.bar, bar_at)) return;
+    if (!grid_barrier(A.bar, bar_at, A.wait_ticks)) { poison(bucket, A.n2); return; }
     if (blockIdx.x == 0) signal_peers(A, 1);
     // D
-    if (!wait_peers(A, 1)) return;
+    if (!wait_peers(A, 1)) { poison(bucket, A.n2); return; }
     // E: gather every rank's reduced shard
     for (int p = 0; p < A.world; p++) {
         long long a, b;
@@ -183,6 +209,7 @@ struct PeerState {
     bool table_dirty;
     unsigned epoch;
     unsigned bar_count;                           // arrivals at the grid-barrier counter the launches so far account for
+    long long wait_ticks;
 };
 
 }  // namespace fmhr
@@ -200,6 +227,8 @@ extern "C" int fmhr_peer_create(int rank, int world, long long n_floats, void** 
     memset(S, 0, sizeof(*S));
     S->rank = rank; S->world = world; S->n2 = n_floats / 4;
     S->shard_max2 = (S->n2 + world - 1) / world;
+    S->wait_ticks = kWaitTicksDefault;
+    if (const char* ms = getenv("FMHR_PEER_WAIT_MS")) { const long long v = atoll(ms); if (v > 0) S->wait_ticks = v * 100000ll; }
     S->off_out = ((size_t)S->n2 * 16 + 255) & ~(size_t)255;
     S->off_flags = (S->off_out + (size_t)S->shard_max2 * 16 + 255) & ~(size_t)255;
     S->bytes = S->off_flags + 4096;
@@ -269,6 +298,7 @@ extern "C" int fmhr_peer_all_reduce(void* state, float* bucket, long long n_floa
     A.epoch = ++S->epoch;
     A.in_place = (char*)bucket == S->base ? 1 : 0;
     A.bar0 = S->bar_count;
+    A.wait_ticks = S->wait_ticks;
     S->bar_count += (A.in_place ? 1u : 2u) * (unsigned)kPeerBlocks;
     k_peer_all_reduce<<<kPeerBlocks, kBlock, 0, (hipStream_t)stream>>>(A, bucket);
     FMHR_CHECK_LAUNCH("k_peer_all_reduce");

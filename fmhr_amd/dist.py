@@ -172,6 +172,15 @@ class StreamAllReduce:
             self._check(rc, "ncclAllReduce")
         return t
 
+    def gave_up(self):
+        """True if the communicator reports an asynchronous error (ncclCommGetAsyncError: a peer died, a transport failed) — what
+        ExchangeMonitor polls; ncclInProgress (an enqueue still being handed over) is not an error"""
+        if not getattr(self, "comm", None):
+            return True
+        state = ctypes.c_int(0)
+        rc = self.lib.ncclCommGetAsyncError(self.comm, ctypes.byref(state))
+        return rc != 0 or state.value not in (0, _NCCL_IN_PROGRESS)
+
     def abort(self):
         if getattr(self, "comm", None):
             self.lib.ncclCommAbort(self.comm)
@@ -374,8 +383,8 @@ def negotiate_peer_all_reduce(group, dev, numel, factory=None, timeout=30.0, log
     allh = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(allh, t, group=group)
     if not _agree(ok, group, dev):
-        if par is not None and ok:
-            par.close()
+        if par is not None:
+            par.close()                                  # whatever this rank got as far as allocating (close() is idempotent) — ADVICE r5
         return None, "peer-create"
     try:
         par.import_peers([bytes(h.cpu().tolist())[:hb] for h in allh])
@@ -413,9 +422,13 @@ def negotiate_peer_all_reduce(group, dev, numel, factory=None, timeout=30.0, log
 
 
 def make_stream_all_reduce(group=None, check_numel=4099, timeout=None, log=None, numel=None):
-    """-> the fastest exchange every rank of `group` could set up for the step's bucket of `numel` floats: a PeerAllReduce (one-shot
-    peer-to-peer over the direct links; needs `numel`; FMHR_PEER_ALLREDUCE=0 switches it off), else a StreamAllReduce (RCCL on the step's
-    stream), else `group` itself (the torch path).  The RCCL communicator cannot be had on EVERY rank:
+    """-> the exchange every rank of `group` could set up for the step's bucket of `numel` floats: a StreamAllReduce (RCCL on the step's
+    stream) — the DEFAULT on the nccl backend —, else `group` itself (the torch path); with FMHR_PEER_ALLREDUCE=1 a PeerAllReduce (one-shot
+    peer-to-peer over the direct links; needs `numel`) is negotiated first.  The peer-to-peer kernel is OPT-IN since round 6: it has
+    only ever run between processes on ONE GPU, where the "remote" blocks sit behind the same L2; whether IPC-mapped uncached memory of
+    another device is visible inside a running kernel the way it assumes cannot be rehearsed on a one-GPU box, so the path a first multi-GPU
+    run takes by default is the library's.  Whichever path is taken, fmhr_amd.dist.ExchangeMonitor checks it while the loop runs.
+    The RCCL communicator cannot be had on EVERY rank:
     negotiate_stream_all_reduce above — agreed phase by phase over the torch group, the RCCL initialisation non-blocking and bounded
     (FMHR_STREAM_ALLREDUCE_TIMEOUT seconds, default 30), no rank ever left inside it.  FMHR_STREAM_ALLREDUCE=0 switches it off.
     `make_stream_all_reduce.last` = (path, reason) of the last call, for the bench line."""
@@ -435,8 +448,8 @@ def make_stream_all_reduce(group=None, check_numel=4099, timeout=None, log=None,
             make_stream_all_reduce.last = ("torch", f"not the nccl backend (peer-to-peer: {peer_why})")
         return group
     dev = torch.device("cuda", torch.cuda.current_device())
-    peer_why = "no bucket size given"
-    if numel is not None and os.environ.get("FMHR_PEER_ALLREDUCE", "1") != "0":
+    peer_why = "opt-in (FMHR_PEER_ALLREDUCE=1): never run across two devices"
+    if numel is not None and os.environ.get("FMHR_PEER_ALLREDUCE", "0") == "1":
         par, peer_why = negotiate_peer_all_reduce(group, dev, int(numel), timeout=timeout, log=log)
         if par is not None:
             make_stream_all_reduce.last = ("peer-to-peer one-shot on the step's stream", None)
@@ -455,6 +468,73 @@ def shard_views(n_views, rank, world):
     base, rem = divmod(n_views, world)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_batch(n_batch, V, rank, world):
+    """ONE minibatch of the loop (`perm[k:k+batch]`, mesh_sfs_optim.py:255-260: n_batch views, the last batch of an epoch may be ragged)
+    over the ranks: the rank's contiguous share of the batch's views, and its share of the view-independent terms.  A batch with fewer
+    views than ranks leaves ranks WITHOUT a view: they render nothing and enter the step's exchange with a zero share (the exchange is a
+    collective: every rank takes part in every step); the regularisers are split by vertex range over the ranks that do have views.
+    Returns dict(views=(s0, s1) within the batch, n_local, active = ranks with views, reg_range=(v0, v1))."""
+    s0, s1 = shard_views(n_batch, rank, world)
+    active = min(world, n_batch)
+    return dict(views=(s0, s1), n_local=s1 - s0, active=active, reg_range=shard_views(V, rank, active) if rank < active else (0, 0))
+
+
+class ExchangeError(RuntimeError):
+    """the ranks no longer hold the same parameters, or the step's exchange reported a failure"""
+
+
+class ExchangeMonitor:
+    """What makes a dead exchange impossible to miss.  The replicated parameters of a view-sharded run stay
+    identical ONLY because every rank applies the same update to the same all-reduced gradient; an exchange that silently returns a rank's
+    own share (a peer-to-peer wait that ran into its bound, a communicator in an error state) would let the ranks drift apart — and read
+    as a FASTER run.  `verify(tensors)`: a checksum of the BITS of the replicated tensors (sum of their int32 images, in int64) must be the
+    same on every rank — MAX and MIN over the ranks through the TORCH group, which is independent of the step's own exchange path — and no
+    rank's exchange may report a failure (PeerAllReduce.gave_up(): the kernel's sticky abort word; StreamAllReduce.gave_up(): RCCL's
+    asynchronous error).  One small collective + one synchronisation: the loops call it every `check_every` epochs and at their end,
+    bench.py after its timed region.  It raises ExchangeError ON EVERY RANK (the verdict itself is all-reduced)."""
+
+    def __init__(self, group, exchange=None, dev=None):
+        self.group, self.exchange = group, exchange
+        self.dev = dev if dev is not None else torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.checks, self.last = 0, None
+
+    def _active(self):
+        return self.group is not None and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    @staticmethod
+    def fingerprint(tensors):
+        return torch.stack([t.detach().contiguous().view(-1).view(torch.int32).to(torch.int64).sum() for t in tensors])
+
+    def verify(self, tensors, what="parameters"):
+        """-> dict(ok, checks); raises ExchangeError on every rank when any rank disagrees or reports a failed exchange"""
+        bad_local = 0
+        ex = self.exchange
+        if ex is not None and hasattr(ex, "gave_up"):
+            try:
+                bad_local = 1 if ex.gave_up() else 0
+            except Exception:  # noqa: BLE001
+                bad_local = 1
+        fp = self.fingerprint(tensors).to(self.dev)
+        nan = torch.stack([(~torch.isfinite(t.detach())).any().to(torch.int64) for t in tensors]).to(self.dev)
+        v = torch.cat([fp, -fp, nan, torch.tensor([bad_local], dtype=torch.int64, device=self.dev)])
+        if self._active():
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+        k = len(tensors)
+        v = v.tolist()
+        same = all(v[i] == -v[k + i] for i in range(k))
+        self.checks += 1
+        self.last = dict(ok=same and v[-1] == 0 and not any(v[2 * k: 3 * k]), same_bits=same, exchange_failed=bool(v[-1]), non_finite=bool(any(v[2 * k: 3 * k])),
+                         checks=self.checks)
+        if not self.last["ok"]:
+            rank = dist.get_rank(self.group) if self._active() else 0
+            raise ExchangeError(f"rank {rank}: the view-sharded run is broken ({what}): "
+                                + ("the step's exchange reported a failure on some rank (a bounded wait gave up / RCCL asynchronous error); " if v[-1] else "")
+                                + ("the ranks hold DIFFERENT bits; " if not same else "")
+                                + ("non-finite values; " if any(v[2 * k: 3 * k]) else "")
+                                + f"check {self.checks} — results since the previous check are invalid")
+        return self.last
 
 
 def shard_frames_views(n_frames, n_views, rank, world):
@@ -506,6 +586,33 @@ class ShardedStage1:
             dist.all_reduce(counts, group=group)
         self.counts = counts                                      # valid pixels of every view of the capture
 
+    def step_sel(self, albedo, sh_local, sel_global):
+        """The same iteration with the batch given as a 0 / 1 mask over the capture's views (int32 [n_views_global] on the GPU — a row of
+        fmhr_amd.pipeline.PermChunks' masks): no index kernels, no host synchronisation; a rank none of whose views is in the batch runs
+        the step on an all-zero selection (zero gradient, zero loss share) and enters the all-reduce like everybody else.
+        Returns (loss, galbedo [V,3] summed over the ranks, gsh [n_local,9])."""
+        hs1 = self.hs1
+        local = sel_global[self.view0: self.view0 + hs1.n]
+        w = sel_global.to(torch.float32)
+        pv_g = (self.counts * w).sum()
+        pv_l = (hs1.view_valid.to(torch.float32) * w[self.view0: self.view0 + hs1.n]).sum()
+        hs1.step(albedo, sh_local, sel=local)
+        return self._exchange(pv_l / pv_g.clamp_min(1.0))
+
+    def _exchange(self, scale):
+        hs1 = self.hs1
+        galbedo = hs1.galbedo * scale
+        gsh = hs1.gsh * scale
+        loss = (hs1.loss_view.sum() * scale).reshape(1)
+        if self.group is not None and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            buf = torch.cat([galbedo.reshape(-1), loss])
+            if self.sar is not None:
+                self.sar.all_reduce_(buf)                         # the iteration's ONE collective, on the current stream
+            else:
+                dist.all_reduce(buf, group=self.group)
+            galbedo, loss = buf[:-1].view_as(hs1.galbedo), buf[-1:]
+        return loss[0], galbedo, gsh
+
     def step(self, albedo, sh_local, idx_global=None):
         """idx_global: the batch as GLOBAL view indices (None: all views).  Returns (loss, galbedo [V,3] summed over the ranks,
         gsh [n_local,9] for this rank's SH rows); the caller applies the optimiser (the same update on every rank)."""
@@ -524,17 +631,7 @@ class ShardedStage1:
             hs1.step(albedo, sh_local, idx=local)
             pv_l = hs1.view_valid.to(torch.float32).sum() if local is None else hs1.view_valid[local].to(torch.float32).sum()
             scale = pv_l / pv_g.clamp_min(1.0)
-        galbedo = hs1.galbedo * scale
-        gsh = hs1.gsh * scale
-        loss = (hs1.loss_view.sum() * scale).reshape(1)
-        if self.group is not None and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            buf = torch.cat([galbedo.reshape(-1), loss])
-            if self.sar is not None:
-                self.sar.all_reduce_(buf)                         # the iteration's ONE collective, on the current stream
-            else:
-                dist.all_reduce(buf, group=self.group)
-            galbedo, loss = buf[:-1].view_as(hs1.galbedo), buf[-1:]
-        return loss[0], galbedo, gsh
+        return self._exchange(scale)
 
 
 def combine_bucket(bucket, V):

@@ -338,6 +338,9 @@ class HamStage2:
     def check_overflow(self):
         """raise if a work list of the step overflowed in any step so far (the step itself never synchronises)."""
         aa, bins = self.overflow_flags()
+        if self.n_src and int(self.raw("stamp", torch.int32, 4)[1]) != 0:
+            raise RuntimeError(f"HamStage2: a step was given a view index outside [0, {self.n_src}) (view_idx selects views of the resident capture): "
+                               "the kernels clamped it — that step rendered the wrong view")
         if bins:
             raise RuntimeError(f"HamStage2: a fragment bin of the rasterizer overflowed (more than {self.dims.bin_cap or 1024} fragments "
                                f"in one 64-pixel segment; the fullest segment so far held {self.bin_depth_max()}): fragments were dropped; "

@@ -155,6 +155,27 @@ class PermChunks:
         return row[:self.num], row[self.num:].view(self.nb, self.num)
 
 
+class FixedPerms:
+    """PermChunks' interface over GIVEN permutations ([epochs, num] integers: e.g. the sequence a reference run drew with torch.randperm,
+    mesh_sfs_optim.py:195,249) — run_ham(perms=...) replays them instead of drawing its own."""
+
+    def __init__(self, perms, batch, dev):
+        perms = torch.as_tensor(perms).to(torch.int64).cpu()
+        num = perms.shape[1]
+        if not bool((perms.sort(dim=1).values == torch.arange(num)[None]).all()):
+            raise RuntimeError("FixedPerms: every row must be a permutation of range(num)")
+        nb = (num + int(batch) - 1) // int(batch)
+        batch_of_view = perms.argsort(dim=1) // int(batch)
+        masks = (batch_of_view[:, None, :] == torch.arange(nb)[None, :, None]).to(torch.int32)
+        self._perms, self._masks, self._at = perms.to(torch.int32).to(dev), masks.to(dev), 0
+
+    def next(self):
+        if self._at >= self._perms.shape[0]:
+            raise RuntimeError(f"FixedPerms: the run asks for epoch {self._at + 1}, {self._perms.shape[0]} permutations were given")
+        self._at += 1
+        return self._perms[self._at - 1], self._masks[self._at - 1]
+
+
 class Stage2Loop:
     """The stage-2 loop of mesh_sfs_optim.py:242-317 as the product runs it: per epoch a fresh permutation of the capture's views (:249),
     per batch ONE fused step on `perm[k:k+batch]` — the capture's images, masks, start silhouettes, cameras and SH rows stay where they
@@ -164,7 +185,12 @@ class Stage2Loop:
     workspace is dropped, and at the end.  run_ham drives it; bench.py times it (`run_ham_stage2`)."""
 
     def __init__(self, vertices_tmp, faces, delta, albedo, sh_fixed, imgs, masks, valid_masks, w2cs, projs, resolution, weights, elm,
-                 optimizer, batch, epoch_sfs, gen, aa_cap=None, bin_cap=0, check_every=64):
+                 optimizer, batch, epoch_sfs, gen, aa_cap=None, bin_cap=0, check_every=64, group=None, exchange=None, perms=None):
+        """perms: explicit permutations [epochs, num] instead of draws from `gen` (FixedPerms).
+        group: torch.distributed process group over whose ranks every batch's views are sharded (None: one rank).  Every rank holds the
+        whole capture and the same `gen` seed — the permutations are drawn identically everywhere — and steps views
+        shard_batch(len(batch), rank, world) of perm[k:k+batch] with n_global = len(batch); `exchange`: what carries the step's ONE
+        all-reduce (fmhr_amd.dist.make_stream_all_reduce's result; None: negotiated here)."""
         from .ham import HamStage2
         self.HamStage2 = HamStage2
         self.vertices_tmp, self.faces, self.delta, self.albedo = vertices_tmp, faces, delta, albedo
@@ -174,8 +200,16 @@ class Stage2Loop:
         self.num, self.batch, self.epoch_sfs, self.gen = imgs.shape[0], int(batch), int(epoch_sfs), gen
         self.aa_cap, self.bin_cap, self.check_every = aa_cap, bin_cap, check_every
         self.steppers, self.epoch, self.hs, self.perm, self._pending = {}, 0, None, None, []
+        self._k, self._cur = None, None
         self.dev = vertices_tmp.device
-        self._perms = None
+        self._perms = FixedPerms(perms, self.batch, self.dev) if perms is not None else None
+        self.group, self.rank, self.world, self.exchange, self.monitor, self._zero = group, 0, 1, None, None, None
+        if group is not None:
+            import torch.distributed as tdist
+            from . import dist as fdist
+            self.rank, self.world = tdist.get_rank(group), tdist.get_world_size(group)
+            self.exchange = exchange if exchange is not None else fdist.make_stream_all_reduce(group, numel=12 * vertices_tmp.shape[0] + 8)
+            self.monitor = fdist.ExchangeMonitor(group, self.exchange if hasattr(self.exchange, "gave_up") else None, self.dev)
 
     def _next_perm(self):
         """the epoch's permutation (:249) as an int32 device row (PermChunks below)"""
@@ -184,10 +218,21 @@ class Stage2Loop:
         return self._perms.next()[0]
 
     def check(self):
-        """synchronous: raise if a work list of any live workspace overflowed in any step so far (one device -> host copy each)"""
+        """synchronous: raise if a work list of any live workspace overflowed in any step so far (one device -> host copy each) or — a
+        view-sharded run — if the ranks no longer hold identical parameters / the exchange reported a failure (ExchangeMonitor)"""
         self._pending = []
-        for hs_ in self.steppers.values():
-            hs_.check_overflow()
+        bad = None
+        try:
+            for hs_ in self.steppers.values():
+                hs_.check_overflow()
+        except RuntimeError as e:
+            if self.monitor is None:
+                raise
+            bad = e                                                                 # (sharded: the collective below is entered by EVERY rank first)
+        if self.monitor is not None:
+            self.monitor.verify([self.delta, self.albedo], "stage-2 parameters (delta, albedo) after epoch %d" % self.epoch)
+        if bad is not None:
+            raise bad
 
     def poll(self):
         """the periodic check WITHOUT a synchronisation: inspect the copies of the sticky flags issued at the previous poll —
@@ -196,6 +241,8 @@ class Stage2Loop:
         of the run is synchronous and exact.  Cadence: a device-to-host copy, however small, ends in a system-scope release — the L2s
         are written back — and costs the steps around it ~58 us at the metric config (tools/experiments/r05_loop_cost.py: +3.3 % at
         every 16 epochs, +2.2 % without any poll); every 64 epochs — the cadence of the permutation refill — it is below 0.3 %."""
+        if self.monitor is not None:                                                # a view-sharded run synchronises here: one small collective per
+            return self.check()                                                     # `check_every` epochs (>= 128 steps) is what keeps a dead exchange from going unnoticed
         for hs_, pin, ev in getattr(self, "_pending", []):
             ev.synchronize()
             f = pin.tolist()
@@ -212,37 +259,111 @@ class Stage2Loop:
             ev.record()
             self._pending.append((hs_, hs_._flag_pin, ev))
 
-    def run_epoch(self, after_step=None):
-        """one epoch: ceil(num / batch) fused steps on a fresh permutation (the last batch ragged when batch does not divide num)"""
-        ep = self.epoch
-        perm = self._next_perm()
-        if ep == self.epoch_sfs // 2:
-            self.weights["albedo"] = self.weights["albedo"] / 10000                   # :250-251
-            for hs_ in self.steppers.values():                                          # the weights are arguments of every backward call: the
-                hs_.weights = dict(self.weights)                                        # workspaces and their mesh tables stay (rebuilding them: 8 ms each)
+    def _zero_share(self):
+        """this rank has no view in the batch (fewer views than ranks — a ragged last batch): it still enters the step's exchange, with a
+        zero share, and applies the same combine + Adam update as every other rank"""
+        import ctypes
+        from ._lib import call, ptr, stream_ptr
+        V = self.vertices_tmp.shape[0]
+        if self._zero is None:
+            self._zero = _ZeroShare(V, self.dev)
+        z = self._zero
+        z.bucket.zero_()
+        if hasattr(self.exchange, "all_reduce_"):
+            self.exchange.all_reduce_(z.bucket, stream_ptr(self.dev))
+        else:
+            torch.distributed.all_reduce(z.bucket, group=self.exchange)
+        ad, aa = self.opt.fused_param(self.delta), self.opt.fused_param(self.albedo)
+        call("fmhr_ham_combine", V, ptr(z.bucket), ctypes.byref(ad), ctypes.byref(aa), stream_ptr(self.dev))
+        return z
+
+    def step_batch(self, perm, k, after_step=None):
+        """ONE fused step on the batch perm[k:k+batch] (this rank's share of it)"""
         V = self.vertices_tmp.shape[0]
         sh, w2cs, projs, imgs, masks, valid_masks = self.args
-        for k in range(0, self.num, self.batch):
-            idx = perm[k:k + self.batch]                                                # a view of the permutation: no copy
-            n = idx.shape[0]
-            hs = self.steppers.get(n)
-            if hs is None:
-                hs = self.steppers[n] = self.HamStage2(self.faces, V, n, self.H, self.W, self.weights, self.elm, aa_cap=self.aa_cap,
-                                                       bin_cap=self.bin_cap, n_src=self.num)
-            hs.step(self.vertices_tmp, self.delta.detach(), self.albedo.detach()[0], sh, w2cs, projs, imgs, masks, valid_masks,
-                    view_idx=idx, optimizer=self.opt, params=(self.delta, self.albedo))
-            self.hs = hs
-            if after_step is not None:
-                after_step(hs, idx)
-        self.perm = perm
-        self.epoch = ep + 1
+        nb = min(self.batch, self.num - k)
+        s0, s1, reg = 0, nb, None
+        if self.group is not None:
+            from .dist import shard_batch
+            part = shard_batch(nb, V, self.rank, self.world)
+            (s0, s1), reg = part["views"], part["reg_range"]
+        n = s1 - s0
+        if n == 0:
+            self.hs = self._zero_share()
+            return
+        idx = perm[k + s0: k + s1]                                                  # a view of the permutation: no copy
+        hs = self.steppers.get(n)
+        if hs is None:
+            hs = self.steppers[n] = self.HamStage2(self.faces, V, n, self.H, self.W, self.weights, self.elm, aa_cap=self.aa_cap,
+                                                   bin_cap=self.bin_cap, n_src=self.num)
+        hs.n_global = nb                                                            # the MSE divisor is the BATCH's n * H * W (:295), ragged or sharded
+        hs.step(self.vertices_tmp, self.delta.detach(), self.albedo.detach()[0], sh, w2cs, projs, imgs, masks, valid_masks,
+                view_idx=idx, optimizer=self.opt, params=(self.delta, self.albedo), group=self.exchange, reg_range=reg)
+        self.hs = hs
+        if after_step is not None:
+            after_step(hs, idx)
+
+    def step_next(self, after_step=None):
+        """the loop's next fused step: the next batch of the running epoch, or — at an epoch boundary — a fresh permutation first (:249; the
+        albedo-weight switch of :250-251 at epoch_sfs // 2).  Returns True when the step ended an epoch (the overflow / exchange checks run
+        there every `check_every` epochs).  run_epoch() = step_next() until it returns True; bench.py times step_next() itself."""
+        if self._k is None:
+            self._cur = self._next_perm()
+            if self.epoch == self.epoch_sfs // 2:
+                self.weights["albedo"] = self.weights["albedo"] / 10000               # :250-251
+                for hs_ in self.steppers.values():                                      # the weights are arguments of every backward call: the
+                    hs_.weights = dict(self.weights)                                    # workspaces and their mesh tables stay (rebuilding them: 8 ms each)
+            self._k = 0
+        self.step_batch(self._cur, self._k, after_step)
+        self._k += self.batch
+        if self._k < self.num:
+            return False
+        self.perm, self._k = self._cur, None
+        self.epoch += 1
         if self.check_every and self.epoch % self.check_every == 0:
             self.poll()
+        return True
+
+    def run_epoch(self, after_step=None):
+        """one epoch: ceil(num / batch) fused steps on a fresh permutation (the last batch ragged when batch does not divide num)"""
+        if self._k is not None:
+            raise RuntimeError("Stage2Loop.run_epoch: an epoch is under way (step_next)")
+        while not self.step_next(after_step):
+            pass
+
+
+class _ZeroShare:
+    """the bucket [P | R | losses] of a rank without a view in the batch: all zero going into the exchange, the batch-global gradients and
+    loss vector coming out of it (fmhr_ham_combine)"""
+
+    def __init__(self, V, dev):
+        self.V = V
+        self.bucket = torch.zeros(12 * V + 8, dtype=torch.float32, device=dev)
+        self.losses = self.bucket[12 * V:]
+
+    def loss_dict(self):
+        from .ham import LOSS_NAMES
+        return dict(zip(LOSS_NAMES, self.losses.tolist()))
 
 
 def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, conf, out_dir=None, log_every=0, seed=0, scan_id=None,
-            check_every=64, aa_cap=None, bin_cap=0, vertex_order=None):
+            check_every=64, aa_cap=None, bin_cap=0, vertex_order=None, group=None, exchange=None, perms=None):
     """The HAM optimisation end to end on GPU tensors.  conf: dict with the keys of conf/demo_sfs.conf that the loop reads.
+    `group` (a torch.distributed process group, e.g. dist.group.WORLD under torchrun; None: one rank): the run is VIEW-SHARDED over its
+    ranks (north_star: "views shard one-per-GPU ... all-reduce ... each optimizer step").  Every rank calls run_ham with the
+    SAME arguments — the whole capture and the same seed, so that all ranks draw the same permutations (mesh_sfs_optim.py:195,249) — and
+      * init + stage 1: rank r builds the constant sub-graph of views shard_views(num, r, world) only; the global SH least squares and the
+        mean albedo come from all-reduced float64 sums, the start silhouettes are gathered once; an iteration is the rank's fused step on
+        the batch's views it holds, ONE all-reduce of the albedo gradient and the replicated Adam update (fmhr_amd.dist.ShardedStage1);
+      * stage 2: of every batch perm[k:k+batch] rank r steps views shard_batch(len(batch), r, world) with the MSE divisor of the whole
+        batch, the regularisers split by vertex range; ONE exchange of [P | R | losses] per step, then combine + Adam on every rank; a rank
+        that has no view of a ragged batch enters the exchange with a zero share (Stage2Loop);
+      * every `check_every` epochs and at the end the ranks' parameters are fingerprinted against each other and the exchange's failure
+        state is read (fmhr_amd.dist.ExchangeMonitor): a dead or diverged exchange raises ExchangeError on every rank;
+      * every rank returns the same result; only rank 0 writes files.
+    `exchange`: the object that carries the stage-2 all-reduce (default: fmhr_amd.dist.make_stream_all_reduce(group, 12 V + 8)).
+    `perms`: dict(stage1=[epoch_albedo, num], stage2=[epoch_sfs, num]) of explicit permutations replayed instead of the run's own draws
+    (either key optional) — e.g. the sequence a reference run drew.
     A step never synchronises, so a work list that overflows (antialias pairs, fragment bins: `aa_cap` / `bin_cap` of HamStage2) drops
     gradient terms without an error of its own: the STICKY overflow flags of every stage-2 workspace are read every `check_every`
     epochs (one 16-byte copy per workspace — a device-to-host copy drains the launch queue, so not every epoch: the demo's epoch is two
@@ -272,7 +393,50 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     delta = torch.zeros_like(vertices).requires_grad_(True)
     vertices_tmp = vertices.detach().clone()
     elm = edge_length_mean(vertices_tmp, faces)                                      # :184-188
-    if degree == 3:
+    rank, world = 0, 1
+    if group is not None:
+        import torch.distributed as tdist
+        from . import dist as fdist
+        rank, world = tdist.get_rank(group), tdist.get_world_size(group)
+        if degree != 3:
+            raise RuntimeError("run_ham: the view-sharded run uses the fused stage-1 step (degree 3, as every conf of the reference)")
+        if world > num:
+            raise RuntimeError(f"run_ham: {world} ranks for a capture of {num} views: stage 1 shards the capture's views, one at least per rank")
+        if exchange is None:
+            exchange = fdist.make_stream_all_reduce(group, numel=12 * vertices.shape[0] + 8)
+    if degree == 3 and group is not None and world > 1:
+        # ---- view-sharded init + stage 1: this rank's views of the capture
+        from . import stage1 as s1
+        v0, v1 = fdist.shard_views(num, rank, world)
+        hs1 = s1.HamStage1(vertices.detach(), faces, w2cs[v0:v1].contiguous(), projs[v0:v1].contiguous(), imgs[v0:v1].contiguous(),
+                           masks[v0:v1].contiguous(), resolution, conf["sfs_weight"], want_pred_masks=True)
+        init = s1.init_sh(hs1, grayimgs[v0:v1].contiguous(), group=group, view0=v0, n_views_global=num)
+        sh_local = init["sh_coeffs"].clone().requires_grad_(True)                    # this rank's rows of :168-170
+        albedo = (torch.zeros_like(vertices) + init["albedo_mean"]).unsqueeze(0).contiguous().requires_grad_(True)
+        opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_local, 'lr': conf["sh_lr"]}])
+        # (the one-shot peer-to-peer exchange is built for the stage-2 bucket: stage 1's 3 V + 1 floats go through RCCL / the torch group)
+        sh1 = fdist.ShardedStage1(hs1, v0, num, group=exchange if isinstance(exchange, fdist.StreamAllReduce) else group)
+        monitor = fdist.ExchangeMonitor(group, exchange if isinstance(exchange, fdist.StreamAllReduce) else None, dev)
+        perms1 = FixedPerms(perms["stage1"], batch, dev) if (perms or {}).get("stage1") is not None else PermChunks(num, batch, gen, dev)
+        ones = torch.ones(num, dtype=torch.int32, device=dev)
+        for ep in range(int(conf["epoch_albedo"])):
+            _, batch_masks = perms1.next()                                              # :195 — the same draw on every rank
+            for j in range(batch_masks.shape[0]):
+                loss, galbedo, gsh = sh1.step_sel(albedo, sh_local, ones if batch >= num else batch_masks[j])
+                albedo.grad, sh_local.grad = galbedo.view_as(albedo), gsh
+                opt.step()
+            if log_every and ep % log_every == 0:
+                history.append(("albedo", ep, float(loss)))
+            if check_every and (ep + 1) % check_every == 0:
+                monitor.verify([albedo], "stage-1 albedo after epoch %d" % (ep + 1))
+        monitor.verify([albedo], "stage-1 albedo at the end of stage 1")
+        sh_coeffs = torch.zeros(num, 9, dtype=torch.float32, device=dev)               # every rank needs every view's row: stage 2 picks any view
+        sh_coeffs[v0:v1] = sh_local.detach()
+        tdist.all_reduce(sh_coeffs, group=group)
+        albedo = albedo.detach().clone().requires_grad_(True)
+        del hs1, sh1
+        sh_fixed = sh_coeffs.detach()
+    elif degree == 3:
         # The constant sub-graph of init + stage 1 (:137-148 = :207-218: rasterization, antialiased + normalised normals, validity,
         # start silhouettes) is computed ONCE for all views by HamStage1; the SH least squares of :150-174 then run on it (normal
         # equations accumulated on the GPU, 9 x 9 solves on the host: `init_sh` above — the reference's own per-view host loop — took
@@ -286,7 +450,7 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
         # interpolate + antialias operator are built once, an iteration is one C call (two launches), the Adam update of both
         # parameters applied inside it.  `stage1_loss` / `stage1_loss_cached` above are the op-by-op forms the parity tests compare it with.
         opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
-        perms1 = PermChunks(num, batch, gen, dev)                                      # (no per-epoch copy, no per-step index kernels)
+        perms1 = FixedPerms(perms["stage1"], batch, dev) if (perms or {}).get("stage1") is not None else PermChunks(num, batch, gen, dev)   # (no per-epoch copy, no per-step index kernels)
         for ep in range(int(conf["epoch_albedo"])):
             _, batch_masks = perms1.next()                                              # :195
             for j in range(batch_masks.shape[0]):
@@ -323,9 +487,14 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     opt = optim.Adam([{'params': delta, 'lr': conf["lr"]}, {'params': albedo, 'lr': conf["albedo_lr"]}])
     epoch_sfs = int(conf["epoch_sfs"])
     loop = Stage2Loop(vertices_tmp, faces, delta, albedo, sh_fixed, imgs, masks, init["valid_masks"], w2cs, projs, (H, W), weights, elm, opt,
-                      batch, epoch_sfs, gen, aa_cap=aa_cap, bin_cap=bin_cap, check_every=check_every)
-    rendered_img, perm_last = [], None                                               # :315-317
-    keep = (lambda hs_, idx_: rendered_img.append(hs_.views()["tmp_img"].clone())) if out_dir is not None else None
+                      batch, epoch_sfs, gen, aa_cap=aa_cap, bin_cap=bin_cap, check_every=check_every, group=group if world > 1 else None,
+                      exchange=exchange if world > 1 else None, perms=(perms or {}).get("stage2"))
+    rendered_img, rendered_idx, perm_last = [], [], None                             # :315-317
+    keep = None
+    if out_dir is not None:
+        def keep(hs_, idx_):
+            rendered_img.append(hs_.views()["tmp_img"].clone())
+            rendered_idx.append(idx_.clone())
     for ep in range(epoch_sfs):
         loop.run_epoch(after_step=keep if ep == epoch_sfs - 1 else None)             # the last epoch's renders are the "rerender" images
         if log_every and ep % log_every == 0:
@@ -333,13 +502,23 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     if out_dir is not None and loop.perm is not None:
         perm_last = loop.perm.cpu().numpy()
     loop.check()
+    if out_dir is not None and world > 1:
+        # the last epoch's renders live on the ranks that stepped their views: summed into one [num,H,W,3] array (every view is rendered
+        # by exactly one rank of exactly one batch), once
+        full = torch.zeros(num, H, W, 3, dtype=torch.float32, device=dev)
+        if rendered_img:
+            full[torch.cat(rendered_idx).long()] = torch.cat(rendered_img, 0)
+        tdist.all_reduce(full, group=group)
+        rendered_img = [full[torch.from_numpy(perm_last).to(dev).long()]]
     out_vertices = order.to_caller((vertices_tmp + delta).detach())
     albedo_out = order.to_caller(albedo.detach(), 1)
     result = dict(vertices=out_vertices, delta=order.to_caller(delta.detach()), albedo=albedo_out, sh_coeffs=sh_coeffs.detach(),
                   history=history, valid_masks=init["valid_masks"],
                   # the fullest fragment bin of the run (0: atomic-key rasterizer) — what `bin_cap` has to cover (HamStage2.bin_depth_max)
                   bin_depth_max=max([hs_.bin_depth_max() for hs_ in loop.steppers.values()] or [0]))
-    if out_dir is not None:                                                          # :319-343
+    if world > 1:
+        result["exchange"] = dict(loop.monitor.last or {}, path=type(loop.exchange).__name__, ranks=world)
+    if out_dir is not None and rank == 0:                                            # :319-343
         os.makedirs(out_dir, exist_ok=True)
         stem = 'ham' if scan_id is None else '%d' % scan_id
         torch.save({'sh_coeff': sh_coeffs.detach().cpu(), 'albedo': albedo_out.cpu()}, os.path.join(out_dir, stem + '.pt'))   # :321

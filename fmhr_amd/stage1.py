@@ -147,8 +147,12 @@ class HamStage1:
         return self.loss_view, self.galbedo, self.gsh
 
 
-def init_sh(hs1, grayimgs, nblk=64):
-    """The SH least-squares initialisation of mesh_sfs_optim.py:124-174 on the constant sub-graph a HamStage1 already holds (the same
+def init_sh(hs1, grayimgs, nblk=64, group=None, view0=0, n_views_global=None):
+    """(view-sharded: `hs1` holds this rank's views [view0, view0 + hs1.n) of a capture of `n_views_global`, `grayimgs` their gray
+    images, `group` the torch.distributed group of the ranks: the per-view solves stay local, the GLOBAL least squares of
+    mesh_sfs_optim.py:165-166 and the mean albedo of :172-174 are solved from the all-reduced float64 sums — 55 + 4 numbers —, and the
+    start silhouettes, which stage 2 reads for arbitrary views of every batch, are gathered to [n_views_global, H, W] on every rank.)
+    The SH least-squares initialisation of mesh_sfs_optim.py:124-174 on the constant sub-graph a HamStage1 already holds (the same
     rasterization / antialiased normals / validity): per-view and global coefficients, the mean albedo.  The reference solves
     [Pv, 9] float64 least-squares problems with np.linalg.lstsq on the host, one view at a time; here the GPU accumulates the normal
     equations (fmhr_sh_normal_equations: 55 float64 sums per view) and only the 9 x 9 solves run on the host.
@@ -178,11 +182,26 @@ def init_sh(hs1, grayimgs, nblk=64):
                 from .utils import get_matrix
                 return np.linalg.lstsq(get_matrix(vn, 3), gray[view][valid].cpu().numpy(), rcond=None)[0]
         return np.linalg.lstsq(G, a[45:54], rcond=None)[0]
+    sharded = group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1
     sh_views = np.stack([solve(acc[b], b) for b in range(n)]).astype(np.float32)
-    sh_global = solve(acc.sum(0)).astype(np.float32)
+    acc_all = acc.sum(0)
+    if sharded:
+        t = torch.from_numpy(acc_all).to(dev)
+        torch.distributed.all_reduce(t, group=group)
+        acc_all = t.cpu().numpy()
+    sh_global = solve(acc_all).astype(np.float32)
     shg = torch.from_numpy(sh_global).to(dev)
     part2 = torch.empty(n, nblk, 4, dtype=torch.float64, device=dev)
     call("fmhr_sh_albedo_sums", ptr(hs1.normals), ptr(hs1.rast), ptr(hs1.masks), ptr(hs1.imgs), ptr(shg), n, H, W, nblk, ptr(part2), st)
-    tot = part2.sum((0, 1)).cpu().numpy()
+    tot = part2.sum((0, 1))
+    if sharded:
+        torch.distributed.all_reduce(tot, group=group)
+    tot = tot.cpu().numpy()
+    valid_masks = hs1.pred_masks
+    if sharded and valid_masks is not None:
+        full = torch.zeros(int(n_views_global), H, W, dtype=torch.float32, device=dev)
+        full[view0: view0 + n] = valid_masks
+        torch.distributed.all_reduce(full, group=group)
+        valid_masks = full
     albedo_mean = torch.from_numpy((tot[:3] / max(tot[3], 1.0)).astype(np.float32)).to(dev)
-    return dict(sh_coeffs=torch.from_numpy(sh_views).to(dev), sh_global=shg, albedo_mean=albedo_mean, valid_masks=hs1.pred_masks)
+    return dict(sh_coeffs=torch.from_numpy(sh_views).to(dev), sh_global=shg, albedo_mean=albedo_mean, valid_masks=valid_masks)

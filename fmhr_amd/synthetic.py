@@ -33,10 +33,15 @@ CONFIGS = {
     # 32 views x 8 frames of 334 x 512 (conf/ih_sfsseq.conf:11-13); a frame is an independent (delta, albedo) problem on the shared
     # topology (fmhr_amd.dist.shard_frames_views)
     "C5": (32, 512, 334, "mano", 0, 3, 2, 8),
-    # one BATCH of the reference's own demo run (conf/demo_sfs.conf:5-7,24: 8 of 16 views, 1280 x 1024, two hands): what a stage-2 step
-    # of `python mesh_sfs_optim.py --conf conf/demo_sfs.conf` renders
-    "demo": (8, 1024, 1280, "mano", 0, 3, 2),
+    # the reference's own demo run (conf/demo_sfs.conf:5-7,24: a capture of 16 views, 1280 x 1024, two hands, minibatches of 8): bench.py
+    # drives it through the product's loop (LOOP_BATCH below: fmhr_amd.pipeline.Stage2Loop — a fresh permutation per epoch, the batch's views
+    # selected inside the step and, on N ranks, sharded: `--config demo --gpus 8` is one view per GPU and step)
+    "demo": (16, 1024, 1280, "mano", 0, 3, 2),
+    # ONE fixed batch of it (8 views, no permutation): the bare step at that size
+    "demo_batch": (8, 1024, 1280, "mano", 0, 3, 2),
 }
+# configs whose step is a MINIBATCH of the capture drawn by the loop (mesh_sfs_optim.py:247-260): name -> batch
+LOOP_BATCH = {"demo": 8}
 
 
 TH_MAX = 0.86 * math.pi

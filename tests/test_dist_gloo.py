@@ -369,3 +369,103 @@ def test_peer_all_reduce_negotiation_falls_back_together():
         assert r["ok"]["is_fake"] and r["ok"]["why"] is None and not r["ok"]["closed"] and r["ok"]["imported"] == 2, (rank, r["ok"])
     # rank 0 (the good one) closed its block when rank 1's create failed
     assert got[0]["peer-create"]["closed"]
+
+
+# ---- the loop's minibatches over the ranks (fmhr_amd.dist.shard_batch) and the exchange monitor ---------------------------------------
+def _sub_scene(sc, idx):
+    """the views `idx` of a scene, as a scene"""
+    sub = dict(sc)
+    for k in ("sh0", "w2c", "proj", "img", "mask", "valid_mask"):
+        sub[k] = sc[k][idx].contiguous()
+    sub["views"] = len(idx)
+    return sub
+
+
+def _loop_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    torch.set_num_threads(2)
+    import ham_oracle as oracle
+    from checker_scenes import prepare
+    from fmhr_amd import dist as fdist
+    fdist.init_from_env(backend="gloo")
+    sc = prepare(oracle, (4, 64, 48, 10, 14), 11)
+    perm, batch = [2, 0, 3, 1], 3                               # an epoch of the loop: a batch of 3 views, then the ragged last one
+    out = []
+    for k in range(0, 4, batch):
+        views = perm[k:k + batch]
+        part = fdist.shard_batch(len(views), sc["V"], rank, world)
+        s0, s1 = part["views"]
+        sh = fdist.ShardedStep(sc["V"], torch.device("cpu"))
+        if part["n_local"] == 0:                                # no view of this batch: a ZERO share — but the exchange is entered all the same
+            z = torch.zeros(sc["V"], 3)
+            share = (torch.zeros(8), z, z, z, z)
+        else:
+            # (the oracle evaluates the regularisers whole: the first rank with views takes them; the kernels split them by part["reg_range"])
+            share = _oracle_step(oracle, _sub_scene(sc, views[s0:s1]), 0, s1 - s0, len(views), rank == 0)
+        ls, gd, ga = sh.reduce(*share)
+        out.append((part["n_local"], part["reg_range"], ls.numpy().copy(), gd.numpy().copy(), ga.numpy().copy()))
+    # the monitor: identical tensors pass; a rank that holds other bits, or whose exchange reports a failure, raises ON EVERY RANK
+    mon = fdist.ExchangeMonitor(dist.group.WORLD, None, torch.device("cpu"))
+    same = torch.arange(12, dtype=torch.float32).view(4, 3)
+    verdicts = [mon.verify([same, same * 2])["ok"]]
+    for case in ("bits", "gave_up", "nan"):
+        t = same.clone()
+        if case == "bits" and rank == 1:
+            t[2, 1] = torch.nextafter(t[2, 1], torch.tensor(100.0))          # ONE bit of one element on one rank
+        if case == "nan" and rank == 1:
+            t[0, 0] = float("nan")
+
+        class Ex:
+            def gave_up(self, case=case):
+                return case == "gave_up" and rank == 0
+        m = fdist.ExchangeMonitor(dist.group.WORLD, Ex(), torch.device("cpu"))
+        try:
+            m.verify([t])
+            verdicts.append("no error")
+        except fdist.ExchangeError as e:
+            verdicts.append(("raised", m.last["same_bits"], m.last["exchange_failed"], m.last["non_finite"]))
+    q.put((rank, out, verdicts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_loop_batches_over_two_ranks_with_a_zero_view_rank(oracle):
+    """the product's loop on N ranks.  An epoch of 4 views in batches of 3 on 2 ranks: the batch of 3 splits 2 + 1, the
+    ragged last batch of ONE view leaves rank 1 without a view — it enters the exchange with a zero share; the MSE divisor is the BATCH's
+    n * H * W on every rank.  Both batches must equal the single-process step on the batch's views.  And the exchange monitor: one
+    differing bit on one rank, a failed exchange on one rank, a NaN on one rank each raise on BOTH."""
+    from checker_scenes import prepare
+    from fmhr_amd import dist as fdist
+    from util import rel_err
+    assert fdist.shard_batch(1, 99, 0, 2) == dict(views=(0, 1), n_local=1, active=1, reg_range=(0, 99))
+    assert fdist.shard_batch(1, 99, 1, 2) == dict(views=(1, 1), n_local=0, active=1, reg_range=(0, 0))
+    assert [fdist.shard_batch(8, 16, r, 8)["views"] for r in range(8)] == [(r, r + 1) for r in range(8)]        # the demo conf on 8 GPUs: one view each
+    assert [fdist.shard_batch(2, 16, r, 8)["n_local"] for r in range(8)] == [1, 1, 0, 0, 0, 0, 0, 0]
+    assert [fdist.shard_batch(2, 16, r, 8)["reg_range"] for r in range(3)] == [(0, 8), (8, 16), (0, 0)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (o, v)) for r, o, v in (q.get(timeout=240) for _ in range(2)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sc = prepare(oracle, (4, 64, 48, 10, 14), 11)
+    assert [o[0] for o in got[0][0]] == [2, 1] and [o[0] for o in got[1][0]] == [1, 0]
+    for b, views in enumerate(([2, 0, 3], [1])):
+        ref_l, ref_gd, ref_ga, _ = _reference_step(oracle, _sub_scene(sc, views))
+        for rank in (0, 1):
+            _, _, ls, gd, ga = got[rank][0][b]
+            assert rel_err(torch.from_numpy(ls)[:7], ref_l[:7]) < 1e-5, (b, rank)
+            assert rel_err(torch.from_numpy(gd), ref_gd) < 1e-5 and rel_err(torch.from_numpy(ga), ref_ga) < 1e-5, (b, rank)
+    for rank in (0, 1):
+        v = got[rank][1]
+        assert v[0] is True
+        assert v[1] == ("raised", False, False, False), v
+        assert v[2] == ("raised", True, True, False), v
+        assert v[3][0] == "raised" and v[3][3] is True, v

@@ -16,11 +16,11 @@ def rel_err(a, b):
 
 
 def log_parity(line):
-    """append one line of MEASURED parity numbers to the round's parity log (the GPU run writes gpurun_out/parity_r05.txt, which is
+    """append one line of MEASURED parity numbers to the round's parity log (the GPU run writes gpurun_out/parity_r06.txt, which is
     copied to profiles/): `pytest -q` swallows prints, the judge reads the tracked file."""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.environ.get("FMHR_PARITY_LOG", os.path.join(root, "gpurun_out", "parity_r05.txt"))
+    path = os.environ.get("FMHR_PARITY_LOG", os.path.join(root, "gpurun_out", "parity_r06.txt"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "a") as f:
