@@ -40,6 +40,11 @@ def grad_bar(name, e_d, e_a, o_d, o_a, t_d=None, t_a=None):
         assert e_d < TOL and e_a < TOL, (name, e_d, e_a, o_d, o_a)
 
 
+def gpu_loop_decisions(ref32, tmp_img_gpu, img, mask, name=""):
+    """oracle/checker_scenes.gpu_loop_decisions, logging into the round's parity file"""
+    return checker_scenes.gpu_loop_decisions(ref32, tmp_img_gpu, img, mask, name, log=log_parity)
+
+
 # "views19/30/37/41": more views than one lane group holds at 1 view per lane -> 3, 4, 5 and 6 views per lane with ragged last slots
 CASES = [("C1", (1, 256, 256, 24, 32), 0), ("C2x3", (3, 512, 334, 24, 32), 1), ("micro", (2, 192, 192, 64, 96), 2),
          ("views19", (19, 96, 80, 12, 16), 3), ("views30", (30, 64, 48, 10, 14), 4), ("views41", (41, 64, 48, 10, 14), 5),
