@@ -738,7 +738,7 @@ def main():
                                                                         f"{n_frames} frames x {n_total} views: frames first, then views, over {world} GPU(s)"),
                        "preroll_steps": preroll, "aa_items_per_step": int(float(aa_items)), "aa_items_during_preroll": [int(x) for x in aa_hist],
                        # the fullest 64-pixel segment of any step so far (fragments) against the bins' capacity (workspace span: 8 B x capacity per segment)
-                       "bin_depth_max": max(p.hs.bin_depth_max() for p in problems), "bin_cap": int(hs.dims.bin_cap) or 1024},
+                       "bin_depth_max": max(p.hs.bin_depth_max() for p in problems), "bin_cap": int(hs.dims.bin_cap) or 512, "workspace_bytes": int(hs.ws_bytes)},
             "roofline": {"bound": "hbm", "kernel": SLOTS[dom], "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get(SLOTS[dom]),
                          # the same launch priced by its MEASURED HBM bytes (upper estimate of the PMC profile): how busy HBM really was

@@ -150,9 +150,12 @@ struct RasterFused {
 // ---- binned rasterizer (raster.hip): a bin = one 64-pixel row segment of the flattened [n, H, W] index = the wave that resolves it.
 // Its entries are 8 B per fragment: (face | large-box flag << 22 | silhouette bits << 23 | pixel-in-segment << 26, z/w bits); 0xFFFFFFFF
 // in the first word = a reserved slot whose fragment turned out degenerate.
-inline int bin_cap_entries(int requested)                     // entries per bin: fmhr_ham_dims.bin_cap, 0 = 1024 (16 fragments per pixel on average)
+constexpr int kBinCapDefault = 512;                           // 8 fragments per pixel of a 64-pixel segment on average.  The fullest segment measured: 336-448 at the
+                                                              // metric over a 600-step run, 366 at the demo conf's 1280 x 1024 (bench.py: bin_depth_max); until
+                                                              // round 5 the default was 1024 = 1.6 GB of reserved span at the metric for that depth
+inline int bin_cap_entries(int requested)                     // entries per bin: fmhr_ham_dims.bin_cap, 0 = kBinCapDefault
 {
-    return requested <= 0 ? 1024 : (requested < 64 ? 64 : requested);
+    return requested <= 0 ? kBinCapDefault : (requested < 64 ? 64 : requested);
 }
 inline bool raster_binned_wanted(bool dflt)                   // FMHR_RASTER_BINNED=0 / 1 overrides the default (same-library A/B; read per call)
 {

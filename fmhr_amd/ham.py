@@ -14,6 +14,17 @@ from . import _lib
 from ._lib import HamDims, HamViews, HamWeights, call, ptr, stream_ptr
 
 LOSS_NAMES = ("sfs", "lap", "albedo", "mask", "edge", "delta", "total", "n_valid")
+BIN_CAP_DEFAULT = 512                  # fmhr_amd/csrc/shade_common.h: kBinCapDefault
+
+
+class WorkListOverflow(RuntimeError):
+    """a work list of the step was full in some step (the steps themselves never synchronise: the sticky flags are read where the caller
+    synchronises anyway).  which = "bins" (fragment bins of the rasterizer: `needed` = the fullest segment's depth — run_ham rebuilds the
+    workspaces with room for it and repeats stage 2) or "aa" (the antialias work-item list)."""
+
+    def __init__(self, msg, which, needed=None):
+        super().__init__(msg)
+        self.which, self.needed = which, needed
 
 
 def edge_length_mean(vertices, faces):
@@ -123,7 +134,7 @@ class HamStage2:
         call("fmhr_corner_slots_build", ptr(self.vf_idx), self.F, ptr(self.corner_slot), st)
         # antialias work items: only pairs that blend are listed (∝ silhouette length); 1/4 of the pixels is a generous bound
         cap = int(aa_cap or max(2048 * 256, self.n * self.H * self.W // 4))     # 768 or 1280 regions (one per workgroup of the AA kernels) of >= 409 items
-        # bin_cap: entries per fragment bin of the binned rasterizer (0 = the default 1024 = 16 fragments per pixel of a 64-pixel segment)
+        # bin_cap: entries per fragment bin of the binned rasterizer (0 = the default 512 = 8 fragments per pixel of a 64-pixel segment; run_ham grows it on overflow)
         # pitch (ABI 5): row pitch of the step's own per-pixel buffers; None / 0 = W rounded up to a multiple of 64 (every 64-pixel
         # segment in one row: binned rasterizer + row-aligned antialias kernels for any W); FMHR_ROW_PITCH=0 in the environment
         # selects the ABI-4 layout (pitch = W: flat segments) for A/B runs.  The caller's img / mask / valid_mask stay [n,H,W].
@@ -316,7 +327,7 @@ class HamStage2:
 
     def bin_depth_max(self):
         """The most fragments ONE 64-pixel segment has held in any step since the workspace was initialised (binned rasterizer; 0 with the
-        atomic-key form) — what `bin_cap` (default 1024 = 8 KB per segment) has to cover.  Synchronises (one 4-byte copy): call it where the
+        atomic-key form) — what `bin_cap` (default 512 = 4 KB per segment) has to cover.  Synchronises (one 4-byte copy): call it where the
         run synchronises anyway; run_ham reports it at the end."""
         return int(self.raw("stamp", torch.int32, 4)[3])
 
@@ -342,17 +353,18 @@ class HamStage2:
             raise RuntimeError(f"HamStage2: a step was given a view index outside [0, {self.n_src}) (view_idx selects views of the resident capture): "
                                "the kernels clamped it — that step rendered the wrong view")
         if bins:
-            raise RuntimeError(f"HamStage2: a fragment bin of the rasterizer overflowed (more than {self.dims.bin_cap or 1024} fragments "
-                               f"in one 64-pixel segment; the fullest segment so far held {self.bin_depth_max()}): fragments were dropped; "
-                               "construct HamStage2 with a larger bin_cap")
+            need = self.bin_depth_max()
+            raise WorkListOverflow(f"HamStage2: a fragment bin of the rasterizer overflowed (more than {self.dims.bin_cap or BIN_CAP_DEFAULT} fragments "
+                                   f"in one 64-pixel segment; the fullest segment so far held {need}): fragments were dropped; "
+                                   "construct HamStage2 with a larger bin_cap", "bins", need)
         if aa:
-            raise RuntimeError(f"HamStage2: the antialias work-item list overflowed (aa_cap={self.dims.aa_cap}): some silhouette pairs "
-                               "got no gradient in at least one step; construct HamStage2 with a larger aa_cap")
+            raise WorkListOverflow(f"HamStage2: the antialias work-item list overflowed (aa_cap={self.dims.aa_cap}): some silhouette pairs "
+                                   "got no gradient in at least one step; construct HamStage2 with a larger aa_cap", "aa")
 
     def raster_overflowed(self):
         """True if a fragment bin of the binned rasterizer was full in ANY step since the workspace was initialised (sticky; one device
         -> host copy): some fragments were dropped — construct HamStage2 with a larger `bin_cap` (entries per 64-pixel segment,
-        default 1024 = 16 fragments per pixel)."""
+        default 512 = 8 fragments per pixel)."""
         return int(self._flags()[2]) != 0
 
     def loss_dict(self):

@@ -219,20 +219,35 @@ class Stage2Loop:
 
     def check(self):
         """synchronous: raise if a work list of any live workspace overflowed in any step so far (one device -> host copy each) or — a
-        view-sharded run — if the ranks no longer hold identical parameters / the exchange reported a failure (ExchangeMonitor)"""
+        view-sharded run — if the ranks no longer hold identical parameters / the exchange reported a failure (ExchangeMonitor).  On N ranks
+        the overflow verdict is COLLECTIVE (MAX over the ranks of the flags and of the fullest bin): every rank raises the same
+        WorkListOverflow, so that run_ham's grow-and-repeat is taken by all of them together and no rank is left in the next collective."""
+        from .ham import BIN_CAP_DEFAULT, WorkListOverflow
         self._pending = []
-        bad = None
-        try:
+        if self.monitor is None:
             for hs_ in self.steppers.values():
                 hs_.check_overflow()
-        except RuntimeError as e:
-            if self.monitor is None:
-                raise
-            bad = e                                                                 # (sharded: the collective below is entered by EVERY rank first)
-        if self.monitor is not None:
-            self.monitor.verify([self.delta, self.albedo], "stage-2 parameters (delta, albedo) after epoch %d" % self.epoch)
-        if bad is not None:
-            raise bad
+            return
+        flags = [0, 0, 0, 0]                                                         # antialias list, fragment bins, fullest bin, a clamped view index
+        for hs_ in self.steppers.values():
+            try:
+                hs_.check_overflow()
+            except WorkListOverflow as e:
+                flags[0 if e.which == "aa" else 1] = 1
+                flags[2] = max(flags[2], int(e.needed or 0))
+            except RuntimeError:
+                flags[3] = 1
+        v = torch.tensor(flags, dtype=torch.int64, device=self.dev)
+        torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        aa, bins, need, bad_idx = v.tolist()
+        self.monitor.verify([self.delta, self.albedo], "stage-2 parameters (delta, albedo) after epoch %d" % self.epoch)
+        if bad_idx:
+            raise RuntimeError("Stage2Loop: a step on some rank was given a view index outside the capture")
+        if bins:
+            raise WorkListOverflow(f"Stage2Loop: a fragment bin of the rasterizer overflowed on some rank (capacity {self.bin_cap or BIN_CAP_DEFAULT}, the fullest "
+                                   f"segment held {need}): fragments were dropped", "bins", need)
+        if aa:
+            raise WorkListOverflow("Stage2Loop: the antialias work-item list overflowed on some rank: construct with a larger aa_cap", "aa")
 
     def poll(self):
         """the periodic check WITHOUT a synchronisation: inspect the copies of the sticky flags issued at the previous poll —
@@ -484,24 +499,47 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     # ---- stage 2: vertex offsets + albedo (:242-317): the fused step on minibatches of the resident capture (Stage2Loop above)
     weights = dict(sfs=conf["sfs_weight"], lap=conf["lap_weight"], albedo=conf["albedo_weight"], mask=conf["mask_weight"],
                    edge=conf["edge_weight"], delta=conf["delta_weight"])
-    opt = optim.Adam([{'params': delta, 'lr': conf["lr"]}, {'params': albedo, 'lr': conf["albedo_lr"]}])
     epoch_sfs = int(conf["epoch_sfs"])
-    loop = Stage2Loop(vertices_tmp, faces, delta, albedo, sh_fixed, imgs, masks, init["valid_masks"], w2cs, projs, (H, W), weights, elm, opt,
-                      batch, epoch_sfs, gen, aa_cap=aa_cap, bin_cap=bin_cap, check_every=check_every, group=group if world > 1 else None,
-                      exchange=exchange if world > 1 else None, perms=(perms or {}).get("stage2"))
-    rendered_img, rendered_idx, perm_last = [], [], None                             # :315-317
-    keep = None
-    if out_dir is not None:
-        def keep(hs_, idx_):
-            rendered_img.append(hs_.views()["tmp_img"].clone())
-            rendered_idx.append(idx_.clone())
-    for ep in range(epoch_sfs):
-        loop.run_epoch(after_step=keep if ep == epoch_sfs - 1 else None)             # the last epoch's renders are the "rerender" images
-        if log_every and ep % log_every == 0:
-            history.append(("sfs", ep, loop.hs.loss_dict()))
+    # A fragment bin that overflows drops fragments (the sticky flag says so where the loop synchronises): with the default capacity — 512
+    # entries per 64-pixel segment, the fullest one measured holds 336-448 — stage 2 is then REPEATED from its start state with room for the
+    # depth the run needed (x 1.25, at least 2 x): at most one stage-2 run is lost (0.2 s for the demo's 600 steps), and the reserved span
+    # follows the measured depth instead of being sized for the worst case.  An explicit `bin_cap` is the caller's
+    # decision: its overflow raises.
+    from .ham import WorkListOverflow
+    start = dict(albedo=albedo.detach().clone(), gen=gen.get_state(), history=len(history))
+    cap, grown = bin_cap, []
+    while True:
+        opt = optim.Adam([{'params': delta, 'lr': conf["lr"]}, {'params': albedo, 'lr': conf["albedo_lr"]}])
+        loop = Stage2Loop(vertices_tmp, faces, delta, albedo, sh_fixed, imgs, masks, init["valid_masks"], w2cs, projs, (H, W), weights, elm, opt,
+                          batch, epoch_sfs, gen, aa_cap=aa_cap, bin_cap=cap, check_every=check_every, group=group if world > 1 else None,
+                          exchange=exchange if world > 1 else None, perms=(perms or {}).get("stage2"))
+        rendered_img, rendered_idx, perm_last = [], [], None                         # :315-317
+        keep = None
+        if out_dir is not None:
+            def keep(hs_, idx_):
+                rendered_img.append(hs_.views()["tmp_img"].clone())
+                rendered_idx.append(idx_.clone())
+        try:
+            for ep in range(epoch_sfs):
+                loop.run_epoch(after_step=keep if ep == epoch_sfs - 1 else None)     # the last epoch's renders are the "rerender" images
+                if log_every and ep % log_every == 0:
+                    history.append(("sfs", ep, loop.hs.loss_dict()))
+            loop.check()
+            break
+        except WorkListOverflow as e:
+            if e.which != "bins" or bin_cap or len(grown) >= 3:
+                raise
+            from .ham import BIN_CAP_DEFAULT
+            cap = max(2 * (cap or BIN_CAP_DEFAULT), (int(1.25 * (e.needed or 0)) + 63) // 64 * 64)
+            grown.append(cap)
+            with torch.no_grad():                                                    # back to the start of stage 2: parameters, draws, log
+                delta.zero_()
+                albedo.copy_(start["albedo"])
+            gen.set_state(start["gen"])
+            del history[start["history"]:]
+            del loop
     if out_dir is not None and loop.perm is not None:
         perm_last = loop.perm.cpu().numpy()
-    loop.check()
     if out_dir is not None and world > 1:
         # the last epoch's renders live on the ranks that stepped their views: summed into one [num,H,W,3] array (every view is rendered
         # by exactly one rank of exactly one batch), once
@@ -515,7 +553,9 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
     result = dict(vertices=out_vertices, delta=order.to_caller(delta.detach()), albedo=albedo_out, sh_coeffs=sh_coeffs.detach(),
                   history=history, valid_masks=init["valid_masks"],
                   # the fullest fragment bin of the run (0: atomic-key rasterizer) — what `bin_cap` has to cover (HamStage2.bin_depth_max)
-                  bin_depth_max=max([hs_.bin_depth_max() for hs_ in loop.steppers.values()] or [0]))
+                  bin_depth_max=max([hs_.bin_depth_max() for hs_ in loop.steppers.values()] or [0]),
+                  # the capacities stage 2 was repeated with after a fragment-bin overflow ([]: the default sufficed)
+                  bin_cap_grown=grown)
     if world > 1:
         result["exchange"] = dict(loop.monitor.last or {}, path=type(loop.exchange).__name__, ranks=world)
     if out_dir is not None and rank == 0:                                            # :319-343

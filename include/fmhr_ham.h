@@ -149,7 +149,7 @@ typedef struct fmhr_ham_dims {
     int32_t aa_cap;             /* capacity of the antialias work-item list (pairs that blend, ∝ silhouette length); on overflow
                                    aa_counter[1] of fmhr_ham_views is set and the excess pairs get no gradient */
     int32_t bin_cap;            /* ABI 4: entries per fragment bin of the binned rasterizer (one bin per 64-pixel segment, 8 B per
-                                   entry; 0 = the default 1024 = 16 fragments per pixel).  Part of the workspace layout: the SAME
+                                   entry; 0 = the default 512 = 8 fragments per pixel; the host loop grows it on overflow).  Part of the workspace layout: the SAME
                                    value must be passed to every call on a workspace.  A full bin sets aa_counter[2] (sticky) and
                                    drops the excess fragments */
     int32_t pitch;              /* ABI 5: row pitch, in pixels, of the step's OWN per-pixel buffers (pixel words, antialiased image,

@@ -139,6 +139,37 @@ def test_run_ham_raises_on_a_work_list_overflow(which):
         pipeline.run_ham(*args, log_every=0, check_every=0, **kw)
 
 
+def test_run_ham_grows_the_fragment_bins_and_repeats_stage_2(monkeypatch):
+    """the bins' capacity follows the measured depth.  The default capacity (here forced down to 64 entries through
+    FMHR_BIN_CAP, the default every workspace takes) overflows; run_ham — given NO explicit bin_cap — rebuilds the workspaces with room for
+    the depth the run needed and repeats stage 2 from its start state (parameters, permutation draws, log): the result equals the run whose
+    bins never overflowed."""
+    from fmhr_amd import pipeline, synthetic as S
+    from fmhr_amd.ham import render_forward
+    from util import rel_err
+    if os.environ.get("FMHR_RASTER_BINNED") == "0":
+        pytest.skip("the atomic-key form has no fragment bins to overflow")
+    dev = torch.device("cuda:0")
+    sc = S.make_scene(4, 192, 176, 64, 96, 0, seed=8)
+    faces = sc["faces"].to(dev)
+    w2c, proj = sc["w2c"].to(dev), sc["proj"].to(dev)
+    tg = S.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, 192, 176), device=dev)
+    img = tg["img"]
+    gray = (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).contiguous()
+    conf = dict(batch=2, degree=3, epoch_albedo=1, epoch_sfs=4, sfs_weight=50.0, lap_weight=2000.0, albedo_weight=1.0,
+                mask_weight=1000.0, edge_weight=500000.0, delta_weight=50000.0, lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
+    args = (sc["vertices"].to(dev), faces, img, gray, tg["mask"], w2c, proj, (192, 176), conf)
+    ref = pipeline.run_ham(*args, log_every=1, seed=3)
+    assert ref["bin_cap_grown"] == [] and 64 < ref["bin_depth_max"] <= 512
+    monkeypatch.setenv("FMHR_BIN_CAP", "64")
+    out = pipeline.run_ham(*args, log_every=1, seed=3)
+    assert len(out["bin_cap_grown"]) == 1 and out["bin_cap_grown"][0] >= ref["bin_depth_max"], out["bin_cap_grown"]
+    assert len(out["history"]) == len(ref["history"])
+    assert rel_err(out["delta"], ref["delta"]) < 1e-3 and rel_err(out["albedo"], ref["albedo"]) < 1e-4
+    with pytest.raises(RuntimeError, match="overflowed"):   # an explicit capacity is the caller's decision: its overflow raises
+        pipeline.run_ham(*args, log_every=0, bin_cap=64)
+
+
 def test_run_ham_returns_the_callers_vertex_numbering(tmp_path):
     """run_ham optimises on a renumbering of the vertices (fmhr_amd.ham.VertexOrder) and maps every per-vertex result back: the
     returned tensors and the written OBJ / .pt are in the caller's numbering (the subdivided mesh's layout repose.py:14-24 relies
