@@ -471,6 +471,8 @@ def main():
     from fmhr_amd.optim import Adam          # same update rule as torch.optim.Adam (tests/test_gpu_utils.py::test_adam)
     reg_range = fdist.shard_views(V, view_rank, view_world)     # the view-independent terms are split over the ranks by vertex range
 
+    bench_bin_cap = [0]                  # entries per fragment bin of the workspaces below (0: the library's default, 512); grown after the pre-roll if it overflowed
+
     class Problem:
         """one (delta, albedo) optimisation: its targets, its step workspace, its optimiser state"""
 
@@ -480,7 +482,7 @@ def main():
                 g = torch.Generator().manual_seed(1000 + frame)
                 sc["vertices_true"] = scene["vertices"] + 0.0005 * torch.randn(scene["vertices"].shape, generator=g)
             self.tg = synthetic.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, H, W), device=dev)
-            self.hs = HamStage2(faces, V, n, H, W, scene["weights"], elm, n_global=n_total)
+            self.hs = HamStage2(faces, V, n, H, W, scene["weights"], elm, n_global=n_total, bin_cap=bench_bin_cap[0])
             self.delta = torch.zeros(V, 3, device=dev, requires_grad=True)
             self.albedo = scene["albedo0"][None].to(dev).clone().requires_grad_(True)          # [1,V,3] as in the reference (:176)
             self.opt = Adam([{'params': self.delta, 'lr': lr["lr"]}, {'params': self.albedo, 'lr': lr["albedo_lr"]}])
@@ -508,7 +510,7 @@ def main():
             self.group = fgroups[frame]
             self.loop = Stage2Loop(vtmp, faces, self.delta, self.albedo, sh, tgt["img"], tgt["mask"], tgt["valid_mask"], w2c, proj, (H, W),
                                    scene["weights"], elm, self.opt, loop_batch, 1 << 30, torch.Generator(device="cpu").manual_seed(args.seed),
-                                   check_every=64, group=torch.distributed.group.WORLD if sharded else None, exchange=self.group)
+                                   check_every=64, group=torch.distributed.group.WORLD if sharded else None, exchange=self.group, bin_cap=bench_bin_cap[0])
             self.loop.step_next()                                # the first step builds the workspace of this rank's batch share
 
         @property
@@ -523,6 +525,7 @@ def main():
     hs, tg, delta, albedo, opt, group = (problems[0].hs, problems[0].tg, problems[0].delta, problems[0].albedo, problems[0].opt,
                                           problems[0].group)
     nf_local = len(problems)
+    bin_cap_grown = []
 
     n_fs = max(1, min(args.frame_streams, nf_local))
     fstreams = [torch.cuda.Stream(device=dev) for _ in range(n_fs)] if n_fs > 1 else []
@@ -577,17 +580,33 @@ def main():
     # untimed pre-roll to the stationary workload: at least 128 optimiser steps, then until the antialias work-item count of a
     # 32-step block is within 0.5 % of the previous block's (every rank runs the same number of steps: the criterion is evaluated
     # on the all-reduced count), at most --preroll steps
-    preroll, aa_hist = 0, []
-    while preroll < args.preroll:
-        for _ in range(32):
-            step()
-        preroll += 32
-        cnt = sum(p.hs.aa_item_count() for p in problems).to(torch.float32).reshape(1)
+    while True:
+        preroll, aa_hist = 0, []
+        while preroll < args.preroll:
+            for _ in range(32):
+                step()
+            preroll += 32
+            cnt = sum(p.hs.aa_item_count() for p in problems).to(torch.float32).reshape(1)
+            if sharded:
+                torch.distributed.all_reduce(cnt)
+            aa_hist.append(float(cnt))
+            if preroll >= 128 and len(aa_hist) >= 2 and abs(aa_hist[-1] - aa_hist[-2]) <= 0.005 * max(aa_hist[-1], 1.0):
+                break
+        # the product's policy for the fragment bins (fmhr_amd.pipeline.run_ham): the default capacity follows the measured depth — if the
+        # pre-roll overflowed it on ANY rank, every rank rebuilds its workspaces with room for the fullest bin (x 1.25, at least 2 x) and
+        # pre-rolls again from fresh parameters; the timed region then runs on workspaces that hold the workload
+        need = torch.tensor([max([p.hs.bin_depth_max() if p.hs.raster_overflowed() else 0 for p in problems] + [0])], dtype=torch.int64, device=dev)
         if sharded:
-            torch.distributed.all_reduce(cnt)
-        aa_hist.append(float(cnt))
-        if preroll >= 128 and len(aa_hist) >= 2 and abs(aa_hist[-1] - aa_hist[-2]) <= 0.005 * max(aa_hist[-1], 1.0):
+            torch.distributed.all_reduce(need, op=torch.distributed.ReduceOp.MAX)
+        if int(need) == 0 or len(bin_cap_grown) >= 3:
             break
+        bench_bin_cap[0] = max(2 * (bench_bin_cap[0] or 512), (int(1.25 * int(need)) + 63) // 64 * 64)
+        bin_cap_grown.append(bench_bin_cap[0])
+        del problems, hs, tg, delta, albedo, opt
+        torch.cuda.empty_cache()
+        problems = [(LoopProblem if loop_batch else Problem)(f) for f in range(f0, f1)]
+        hs, tg, delta, albedo, opt, group = (problems[0].hs, problems[0].tg, problems[0].delta, problems[0].albedo, problems[0].opt,
+                                              problems[0].group)
     import gc
     gc.collect()
     gc.disable()
@@ -738,7 +757,7 @@ def main():
                                                                         f"{n_frames} frames x {n_total} views: frames first, then views, over {world} GPU(s)"),
                        "preroll_steps": preroll, "aa_items_per_step": int(float(aa_items)), "aa_items_during_preroll": [int(x) for x in aa_hist],
                        # the fullest 64-pixel segment of any step so far (fragments) against the bins' capacity (workspace span: 8 B x capacity per segment)
-                       "bin_depth_max": max(p.hs.bin_depth_max() for p in problems), "bin_cap": int(hs.dims.bin_cap) or 512, "workspace_bytes": int(hs.ws_bytes)},
+                       "bin_depth_max": max(p.hs.bin_depth_max() for p in problems), "bin_cap": int(hs.dims.bin_cap) or 512, "bin_cap_grown": bin_cap_grown, "workspace_bytes": int(hs.ws_bytes)},
             "roofline": {"bound": "hbm", "kernel": SLOTS[dom], "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": (traffic or {}).get(SLOTS[dom]),
                          # the same launch priced by its MEASURED HBM bytes (upper estimate of the PMC profile): how busy HBM really was

@@ -51,15 +51,35 @@ def _scene(dims=(6, 128, 96, 21, 37, 1)):
 
 
 def _run(sc, tg, faces, w2c, proj, s0, s1, group, reg_range):
-    from fmhr_amd.ham import HamStage2, edge_length_mean
+    from fmhr_amd.ham import HamStage2, WorkListOverflow, edge_length_mean
     dev = faces.device
     vt = sc["vertices"].to(dev)
-    hs = HamStage2(faces, sc["V"], s1 - s0, sc["H"], sc["W"], sc["weights"], edge_length_mean(vt, faces), n_global=sc["views"])
     sl = slice(s0, s1)
-    out = hs.step(vt, sc["delta"], sc["albedo0"].to(dev), sc["sh0"][sl].to(dev).contiguous(), w2c[sl].contiguous(),
-                  proj[sl].contiguous(), tg["img"][sl].contiguous(), tg["mask"][sl].contiguous(), tg["valid_mask"][sl].contiguous(),
-                  group=group, reg_range=reg_range)
-    return [t.clone() for t in out]
+    cap = 0
+    for attempt in range(3):
+        hs = HamStage2(faces, sc["V"], s1 - s0, sc["H"], sc["W"], sc["weights"], edge_length_mean(vt, faces), n_global=sc["views"], bin_cap=cap)
+        out = hs.step(vt, sc["delta"], sc["albedo0"].to(dev), sc["sh0"][sl].to(dev).contiguous(), w2c[sl].contiguous(),
+                      proj[sl].contiguous(), tg["img"][sl].contiguous(), tg["mask"][sl].contiguous(), tg["valid_mask"][sl].contiguous(),
+                      group=group, reg_range=reg_range)
+        out = [t.clone() for t in out]
+        # the caller of the bare step polls the sticky overflow flags (the step never synchronises): a fragment bin deeper than the default
+        # 512 entries — a grazing view of the metric mesh — means "build the workspace with room for it and step again", as run_ham does.
+        # (Sharded: every rank steps the same number of times — the verdict is agreed over the group — or the exchange would not pair up.)
+        need = 0
+        try:
+            hs.check_overflow()
+        except WorkListOverflow as e:
+            assert e.which == "bins"
+            need = int(e.needed)
+        if group is not None:
+            import torch.distributed as dist
+            t = torch.tensor([need], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=getattr(group, "group", group) if not isinstance(group, dist.ProcessGroup) else group)
+            need = int(t)
+        if need == 0:
+            return out
+        cap = (need + 63) // 64 * 64
+    raise AssertionError("the fragment bins overflowed three times")
 
 
 def _worker(rank, world, port, q, dims=(6, 128, 96, 21, 37, 1)):

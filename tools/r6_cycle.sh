@@ -7,7 +7,7 @@ O=$R/gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 if [ -z "$SKIP_TESTS" ]; then
   rm -f $O/parity_r06.txt
-  timeout -k 10 ${TEST_TIMEOUT:-700} python -m pytest $R/tests -x -q -m gpu ${TESTS:-} > $O/t.log 2>&1 || { tail -40 $O/t.log; exit 1; }
+  timeout -k 10 ${TEST_TIMEOUT:-700} python -m pytest ${TESTS:-$R/tests} -x -q -m gpu > $O/t.log 2>&1 || { tail -40 $O/t.log; exit 1; }
   tail -1 $O/t.log
 fi
 if [ -z "$SKIP_BENCH" ]; then
