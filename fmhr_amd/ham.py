@@ -412,11 +412,23 @@ def ham_step(hs, vertices_tmp, delta, albedo, sh, w2c, proj, img, mask, valid_ma
 
 
 def render_forward(faces, vertices, albedo, sh, w2c, proj, mask, H, W):
-    """Stage-2 forward only (for target generation / re-rendering): returns dict(tmp_img, pred_mask, rast) clones."""
+    """Stage-2 forward only (for target generation / re-rendering): returns dict(tmp_img, pred_mask, rast) clones.  The sticky overflow
+    flags are read before the result is handed out (this call synchronises anyway): a fragment bin deeper than the default capacity means
+    a workspace with room for it and a second render — never an image with dropped fragments."""
     n, V = w2c.shape[0], vertices.shape[0]
-    hs = HamStage2(faces, V, n, H, W, dict(sfs=0, lap=0, albedo=0, mask=0, edge=0, delta=0), 0.0)
-    zero = torch.zeros_like(vertices)
-    hs.forward(vertices.contiguous(), zero, albedo.contiguous(), sh.contiguous(), w2c.contiguous(), proj.contiguous(),
-               mask.contiguous(), torch.zeros_like(mask))
-    v = hs.views()
-    return dict(tmp_img=v["tmp_img"].clone(), pred_mask=v["pred_mask"].clone(), rast=v["rast"].clone())
+    cap = 0
+    for _ in range(4):
+        hs = HamStage2(faces, V, n, H, W, dict(sfs=0, lap=0, albedo=0, mask=0, edge=0, delta=0), 0.0, bin_cap=cap)
+        zero = torch.zeros_like(vertices)
+        hs.forward(vertices.contiguous(), zero, albedo.contiguous(), sh.contiguous(), w2c.contiguous(), proj.contiguous(),
+                   mask.contiguous(), torch.zeros_like(mask))
+        try:
+            hs.check_overflow()
+        except WorkListOverflow as e:
+            if e.which != "bins":
+                raise
+            cap = max(2 * (cap or BIN_CAP_DEFAULT), (int(1.25 * e.needed) + 63) // 64 * 64)
+            continue
+        v = hs.views()
+        return dict(tmp_img=v["tmp_img"].clone(), pred_mask=v["pred_mask"].clone(), rast=v["rast"].clone())
+    raise RuntimeError("render_forward: the fragment bins overflowed at every capacity tried")
