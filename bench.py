@@ -470,6 +470,9 @@ def main():
     lr = scene["lr"]
     from fmhr_amd.optim import Adam          # same update rule as torch.optim.Adam (tests/test_gpu_utils.py::test_adam)
     reg_range = fdist.shard_views(V, view_rank, view_world)     # the view-independent terms are split over the ranks by vertex range
+    if os.environ.get("FMHR_BENCH_REG_SHARE"):                  # experiments (tools/r6_tail_share.sh): the regulariser share of a rank of a K-rank run
+        k_ = int(os.environ["FMHR_BENCH_REG_SHARE"])            # on ONE rank: K = 0 none at all, K = 8 an eighth of the vertices, K = 1 all
+        reg_range = (0, 0) if k_ == 0 else fdist.shard_views(V, 0, k_)
 
     bench_bin_cap = [0]                  # entries per fragment bin of the workspaces below (0: the library's default, 512); grown after the pre-roll if it overflowed
 

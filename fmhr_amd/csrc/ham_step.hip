@@ -64,7 +64,7 @@ int face_bwd_blocks(int F);
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, sh_local, view_idx_ws, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
-        g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, bin_state, bin_list, face_rec, total;
+        g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, bin_state, bin_list, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -141,11 +141,6 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.bin_state = take(off, tiles * 4 + 16);                         // per-segment state words, addressed DOWNWARDS from the cursors (raster.hip: seg_state_word)
     L.bin_cursor = take(off, tiles * 4 * kCursorStride + 16);
     L.bins = take(off, tiles * (size_t)bin_cap_entries(d->bin_cap) * sizeof(BinEntry));
-#ifdef FMHR_X_FACE_REC
-    L.face_rec = take(off, (size_t)d->F * kFaceRecWords * 16);
-#else
-    L.face_rec = 0;
-#endif
     L.total = off;
     return L;
 }
@@ -333,7 +328,6 @@ extern "C" int fmhr_ham_forward(const fmhr_ham_dims* d, const float* vertices_tm
         fu.bins = nullptr; fu.bin_cursor = nullptr; fu.bin_flag = nullptr; fu.bin_cap = 0; fu.bin_list = nullptr; fu.bin_list_cnt = nullptr;
         fu.segx = make_udiv((unsigned)((Wp + 63) / 64));            // used when Wp != d->W: segment -> row of the caller's [n,H,W] mask
         fu.sel = sel;
-        fu.face_rec = (float4*)(w + L.face_rec);
         if (raster_binned_ok(d->F, d->H, d->W, Wp)) {
             fu.bins = (BinEntry*)(w + L.bins); fu.bin_cursor = (int*)(w + L.bin_cursor); fu.bin_cap = bin_cap_entries(d->bin_cap);
             fu.bin_flag = (int*)(w + L.aa_counter) + 2;             // sticky overflow flag next to the antialias list's (read by the host)

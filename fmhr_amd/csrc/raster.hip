@@ -1004,28 +1004,6 @@ k_bins_compact(const BinArgs ba, long long nSeg, unsigned long long* __restrict_
 
 // one segment of the second pass (wave-uniform `seg`); lkey / chunk: the wave's LDS stage.  LIST: the segment comes off the compacted list
 // with its fragment count (k_bins_compact has fetched and reset the cursor and marked the words live): no state word, no cursor here
-// experiment FMHR_X_FACE_REC: the per-face record of the second pass (DESIGN.md "what comes next" (1)) — one thread per
-// 16-B word: 8 threads per face (the eighth idle), consecutive lanes write consecutive words
-__global__ void __launch_bounds__(kBlock)
-k_face_records(const int32_t* __restrict__ tri, const float* __restrict__ verts, const float4* __restrict__ attr8, int F, float4* __restrict__ rec)
-{
-    const int t = blockIdx.x * kBlock + threadIdx.x, f = t >> 3, slot = t & 7;
-    if (f >= F || slot == 7) return;
-    float4 o;
-    if (slot == 6) {
-        const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
-        o = make_float4(verts[(size_t)i0 * 3 + 2], verts[(size_t)i1 * 3 + 2], verts[(size_t)i2 * 3 + 2], 0.f);
-    } else {
-        const int i = tri[f * 3 + (slot >> 1)];
-        if ((slot & 1) == 0) o = attr8[(size_t)i * 2];
-        else {
-            const float4 a = attr8[(size_t)i * 2 + 1];
-            o = make_float4(a.x, a.y, verts[(size_t)i * 3], verts[(size_t)i * 3 + 1]);
-        }
-    }
-    rec[(size_t)f * kFaceRecWords + slot] = o;
-}
-
 template <bool LIST>
 __device__ __forceinline__ void bins_segment(const long long seg, const int count_in, const int lane, unsigned long long* const lkey, BinEntry* const chunk,
                                              const int32_t* __restrict__ tri, const int n, const int F, const int H, const int W, const int Wp,
@@ -1145,22 +1123,10 @@ __device__ __forceinline__ void bins_segment(const long long seg, const int coun
         // matrix in SGPRs, and fragment_uv() is the (u, v) part of rule R5's statement sequence.  The attribute gathers are requested
         // BEHIND that arithmetic: issued with the vertex loads they kept 24 more registers live across it (94 VGPRs: 5 waves per SIMD,
         // 104 us; at 6 waves 24 spills: 143 us; requested once the clip positions stand, in front of the barycentrics: 90.6 us).
-#ifdef FMHR_X_FACE_REC
-        // ONE level of gathers behind the winner: the face's record (its corners' positions, normals, albedo: 7 x 16 B, one or two lines)
-        const float4* const fr = fu.face_rec + (size_t)f * kFaceRecWords;
-        const float4 rB0 = fr[1], rB1 = fr[3], rB2 = fr[5], rC = fr[6];
-        if (shade) { q0 = fr[0]; u0 = fr[2]; w0 = fr[4]; }
-        F3U x0, x1, x2;
-        x0.x = rB0.z; x0.y = rB0.w; x0.z = rC.x;
-        x1.x = rB1.z; x1.y = rB1.w; x1.z = rC.y;
-        x2.x = rB2.z; x2.y = rB2.w; x2.z = rC.z;
-        q1 = make_float4(rB0.x, rB0.y, 0.f, 0.f); u1 = make_float4(rB1.x, rB1.y, 0.f, 0.f); w1 = make_float4(rB2.x, rB2.y, 0.f, 0.f);
-#else
         const int i0 = tri[f * 3], i1 = tri[f * 3 + 1], i2 = tri[f * 3 + 2];
         F3U x0 = *reinterpret_cast<const F3U*>(fu.verts + (size_t)i0 * 3);
         F3U x1 = *reinterpret_cast<const F3U*>(fu.verts + (size_t)i1 * 3);
         F3U x2 = *reinterpret_cast<const F3U*>(fu.verts + (size_t)i2 * 3);
-#endif
         float cm[16];
         {
             const_as4_float* cp = (const_as4_float*)(unsigned long long)(fu.cmat + (size_t)b * 4);
@@ -1182,11 +1148,9 @@ __device__ __forceinline__ void bins_segment(const long long seg, const int coun
         const float zw = __uint_as_float(win.y);
         asm volatile("" : "+v"(u), "+v"(v));
         if (shade) {
-#ifndef FMHR_X_FACE_REC
             q0 = fu.attr8[(size_t)i0 * 2]; q1 = fu.attr8[(size_t)i0 * 2 + 1];
             u0 = fu.attr8[(size_t)i1 * 2]; u1 = fu.attr8[(size_t)i1 * 2 + 1];
             w0 = fu.attr8[(size_t)i2 * 2]; w1 = fu.attr8[(size_t)i2 * 2 + 1];
-#endif
             const_as4_float* sp = (const_as4_float*)(unsigned long long)(fu.sh + (size_t)b * 9);   // the view is wave-uniform
 #pragma unroll
             for (int k = 0; k < 9; k++) shc[k] = sp[k];
@@ -1555,10 +1519,6 @@ int rasterize_fwd_impl(const float* pos, const int2* snap, const int32_t* tri, c
         // per segment is scheduled dynamically by the hardware.  FMHR_BINS_LIST=0 / 1 forces either form (same-library A/B)
         const char* ble = getenv("FMHR_BINS_LIST");
         const bool use_list = fu.bin_list != nullptr && fu.bin_list_cnt != nullptr && (ble ? atoi(ble) != 0 : ba.tiles >= 400000);
-#ifdef FMHR_X_FACE_REC
-        k_face_records<<<cdiv((long long)F * 8, kBlock), kBlock, 0, st>>>(tri, fu.verts, fu.attr8, F, fu.face_rec);
-        FMHR_CHECK_LAUNCH("k_face_records");
-#endif
         if (use_list) {
             const long long nSeg = (long long)ba.tiles;
             k_bins_compact<<<cdiv(nSeg, kCompactBlock), kCompactBlock, 0, st>>>(ba, nSeg, covw, fu.seg_valid, (int2*)fu.bin_list, fu.bin_list_cnt);

@@ -145,10 +145,7 @@ struct RasterFused {
     UDiv segx;                                                // row pitch != W (ABI 5): division by the segments per row — the caller's
                                                               // `mask` is [n,H,W], the step's own per-pixel buffers are [n,H,pitch]
     ViewSel sel;                                              // ABI 6: the step's views are a subset of the caller's (common.h); sel.idx null = not
-    float4* face_rec;                                         // experiment FMHR_X_FACE_REC (round 6): per face 7 x 16 B = its three corners' (normal, albedo,
-                                                              // position) — ONE gather behind a winning fragment instead of tri -> vertices -> attributes
 };
-constexpr int kFaceRecWords = 7;                              // float4 per face record: [2k] = attr8[2 i_k], [2k+1] = (albedo.y, albedo.z, x, y) of corner k, [6] = (z0, z1, z2, 0)
 
 // ---- binned rasterizer (raster.hip): a bin = one 64-pixel row segment of the flattened [n, H, W] index = the wave that resolves it.
 // Its entries are 8 B per fragment: (face | large-box flag << 22 | silhouette bits << 23 | pixel-in-segment << 26, z/w bits); 0xFFFFFFFF

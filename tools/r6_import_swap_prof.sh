@@ -15,13 +15,17 @@ import csv, sys
 rows = list(csv.DictReader(open("$f")))
 ITERS = 7.0                                    # tools/opbyop_rate.py: 2 warm-up + 5 timed iterations, 48 views x 512 x 512
 def cls(n):
-    return "fmhr" if "fmhr::" in n else "torch" if ("at::native" in n or "at_cuda" in n or "rocprim" in n or "hipcub" in n or "Cijk" in n or "elementwise" in n) else "other"
+    # torch's own: ATen kernels (incl. the anonymous-namespace indexing backward), rocPRIM sorts / scans behind index_put, Tensile GEMMs (einsum);
+    # "runtime": the HIP runtime's copy / fill kernels (torch.zeros, .cuda(), clones)
+    if "fmhr::" in n: return "fmhr"
+    if "__amd_rocclr" in n: return "runtime"
+    return "torch" if ("at::native" in n or "at_cuda" in n or "rocprim" in n or "hipcub" in n or "Cijk" in n or "elementwise" in n or "indexing_backward" in n or "anonymous namespace" in n) else "other"
 tot = {}
 for r in rows:
     tot[cls(r["Name"])] = tot.get(cls(r["Name"]), 0.0) + float(r["TotalDurationNs"])
 w = csv.writer(sys.stdout)
 w.writerow(["class_or_kernel", "calls_per_iteration", "avg_us", "ms_per_iteration"])
-for k in ("fmhr", "torch", "other"):
+for k in ("fmhr", "torch", "runtime", "other"):
     w.writerow(["(all %s kernels)" % k, "", "", round(tot.get(k, 0.0) / ITERS / 1e6, 3)])
 w.writerow(["(all kernels)", "", "", round(sum(tot.values()) / ITERS / 1e6, 3)])
 for r in rows[:60]:
