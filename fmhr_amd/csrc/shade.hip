@@ -341,7 +341,7 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
            const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
            const int32_t* __restrict__ corner_slot,
            const float4* __restrict__ cmat, const float* __restrict__ verts, int n, int V, int F,
-           int H, int W, float4* __restrict__ part, const PixGrid pg, const int g, const int b0, const int fb0)
+           int H, int W, float4* __restrict__ part, const PixGrid pg, const int g, const int b0, const int fb0, int* __restrict__ slot_stamp)
 {
     // (W here is the ROW PITCH of the per-pixel arrays: this body only addresses with it; the pixel grid comes in pg)
     FMHR_WTS_BEGIN(shade, ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (kFbBlock / 64) + (threadIdx.x >> 6));
@@ -596,14 +596,22 @@ face_bwd_body(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
 #pragma unroll
         for (int c = 0; c < 9; c++) o[c] = (j == 0) ? A[0][c] : ((j == 1) ? A[1][c] : A[2][c]);
         float4* dst = part + ((size_t)g * 3 * F + es) * 3;
-        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-        dst[1] = make_float4(o[4], o[5], o[6], o[7]);
-        dst[2] = make_float4(o[8], 0.f, 0.f, 0.f);
+        // FEW views (slot_stamp != null: one view group of at most kGroup views, round 6): a face that owns no pixel in any of them — two
+        // thirds of the faces with one view — writes NOTHING; an owner stamps its three corner slots with the step counter and the mesh tail
+        // reads only stamped slots.  The 3 F scattered 48-byte slot stores were HALF of this kernel at one view of the two-hand mesh (46 ->
+        // 23 us without them, tools/r6_nostore_ab.sh), and the tail read them all back.
+        if (slot_stamp == nullptr || group_any) {
+            dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+            dst[2] = make_float4(o[8], 0.f, 0.f, 0.f);
+            if (slot_stamp != nullptr) slot_stamp[es] = stamp[0];
+        }
     }
     FMHR_WTS_END(shade);
 }
 
-struct LargeArgs { const int2* snap; const int2* large_q; const int* large_cnt; const unsigned long long* covw; float* vacc; int workers; };
+struct LargeArgs { const int2* snap; const int2* large_q; const int* large_cnt; const unsigned long long* covw; float* vacc; int workers;
+                   int* slot_stamp; };   // (slot_stamp: not the workers' — the few-views form of the faces' own stores, carried here to the kernel)
 
 // Backward of the queued large-box (view, face)s: ONE WAVE per (view, face) scans the face's bounding box, 64 pixels per iteration
 // (independent loads), does the per-pixel backward for the pixels the face owns and sums the 27 corner values over the wave.
@@ -743,10 +751,10 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
     }
     if (VB != VA && g == (int)gridDim.y - 1)                       // (block-uniform)
         face_bwd_body<VB>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, n, V, F, H, Wp, part,
-                          pg, g, g * kGroup * VA, la.workers);
+                          pg, g, g * kGroup * VA, la.workers, la.slot_stamp);
     else
         face_bwd_body<VA>(bwd16, tri, pos, attr8, sh, g_shaded, cov16, own8, stamp, corner_slot, cmat, verts, n, V, F, H, Wp, part,
-                          pg, g, g * kGroup * VA, la.workers);
+                          pg, g, g * kGroup * VA, la.workers, la.slot_stamp);
 }
 
 int valid_mask_segments_impl(const float* valid_mask, int n, int H, int W, int Wp, unsigned char* vmnz, hipStream_t st)
@@ -808,12 +816,19 @@ static int face_bwd_vpl(int n, int H, int W)
 }
 
 int face_bwd_groups(int n, int H, int W) { return cdiv(n, kGroup * face_bwd_vpl(n, H, W)); }
+// FEW views: one view group of at most kGroup views on a micro-triangle mesh (the share of a rank of an 8-GPU run; small batches) — the
+// faces' corner slots are written by owners only and carry a stamp (k_face_bwd / k_mesh_tail_a).  FMHR_SLOT_SKIP=0 / 1 forces either form.
+bool face_bwd_slot_skip(int n, int H, int W, int F)
+{
+    const char* e = getenv("FMHR_SLOT_SKIP");
+    return n <= kGroup && !raster_use_queue(H, W, F) && (e ? atoi(e) != 0 : true);
+}
 int face_bwd_blocks(int F) { return cdiv(F, kFacesPerBlock); }
 
 int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, const float* attr8, const float* sh, const float* g_shaded,
                   const void* cov16, const unsigned char* own8, const int* stamp, const int32_t* corner_slot, const float* cmat,
                   const float* verts, int n, int V, int F, int H, int W, int Wp, float* part,
-                  const int2* snap, const int2* large_q, const int* large_cnt, const unsigned long long* covw, float* vacc, hipStream_t st)
+                  const int2* snap, const int2* large_q, const int* large_cnt, const unsigned long long* covw, float* vacc, int* slot_stamp, hipStream_t st)
 {
     if (n == 0 || F == 0) return FMHR_OK;
     // large-box (view, face)s: a coarse mesh (every triangle is one) gives them a launch of their own after this one; a micro-triangle
@@ -828,6 +843,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
     la.snap = snap; la.large_q = large_q; la.large_cnt = large_cnt; la.covw = covw; la.vacc = vacc;
     const bool workers = !coarse && vacc != nullptr;
     la.workers = workers ? kLargeWorkers : 0;
+    la.slot_stamp = (slot_stamp != nullptr && face_bwd_slot_skip(n, H, W, F)) ? slot_stamp : nullptr;
     const dim3 grid(cdiv(F, kFacesPerBlock) + la.workers, face_bwd_groups(n, H, Wp));
     const PixGrid pg = make_pix_grid(H, W);
 #define FMHR_FACE_BWD(VA, VB)                                                                                                       \
