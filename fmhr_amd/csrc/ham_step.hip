@@ -433,7 +433,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n, d->H, Wp);
         A.gvert_aa2 = split ? (float*)(w + L.gvert_aa2) : nullptr; A.col_mult = col_mult;
         A.vacc = (float*)(w + L.vacc);
-        A.slot_stamp = face_bwd_slot_skip(d->n, d->H, Wp, d->F) ? (const int*)(w + L.slot_stamp) : nullptr;
+        A.slot_stamp = face_bwd_slot_skip(d->n, d->H, d->W, d->F) ? (const int*)(w + L.slot_stamp) : nullptr;
         A.stamp = (const int*)(w + L.stamp);
         A.gacc_r = (float*)(w + L.gvert_r);
         A.gdelta = gdelta; A.galbedo = galbedo; A.gd_rest = gdelta_rest; A.ga_rest = galbedo_rest;
