@@ -11,7 +11,6 @@ struct MeshTailArgs {
     const float4* part; float* gvert_aa; int G;
     float* gvert_aa2;
     float* vacc;
-    const int* slot_stamp; const int* stamp;
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     const int32_t* col_mult;
@@ -58,15 +57,14 @@ int loss_pix_impl(const unsigned long long*, const float*, const float*, const f
                   const float*, float, float, float, float*, float*, float*, float*, hipStream_t);
 int face_bwd_impl(const float*, const int32_t*, const float*, const float*, const float*, const float*, const void*, const unsigned char*,
                   const int*, const int32_t*, const float*, const float*, int, int, int, int, int, int, float*,
-                  const int2*, const int2*, const int*, const unsigned long long*, float*, int*, hipStream_t);
+                  const int2*, const int2*, const int*, const unsigned long long*, float*, hipStream_t);
 int face_bwd_groups(int n, int H, int W);
-bool face_bwd_slot_skip(int n, int H, int W, int F);
 int face_bwd_blocks(int F);
 
 // workspace carving: every block 256-B aligned
 struct Layout {
     size_t vertices, nsum, normals, attr8, sh_local, view_idx_ws, pos, snap, silh, raster_ws, dirty, covw, act, vmnz, act_list, act_count, cov16, own8, stamp, pix16, rast, shaded, aa, aa_items, aa_alphas, aa_dcol, aa_counter, aa_region_cnt,
-        g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, bin_state, bin_list, slot_stamp, total;
+        g_shaded, cmat, gvert_aa, gvert_aa2, vacc, part, partials, gnormal, gvert, gvert_r, gtmp, lx_v, lx_a, rowg, tail_part, n_valid_f, one_third, seg_valid, cnt_part, silw, bins, bin_cursor, bin_state, bin_list, total;
 };
 
 static size_t take(size_t& off, size_t bytes)
@@ -143,7 +141,6 @@ static Layout make_layout(const fmhr_ham_dims* d)
     L.bin_state = take(off, tiles * 4 + 16);                         // per-segment state words, addressed DOWNWARDS from the cursors (raster.hip: seg_state_word)
     L.bin_cursor = take(off, tiles * 4 * kCursorStride + 16);
     L.bins = take(off, tiles * (size_t)bin_cap_entries(d->bin_cap) * sizeof(BinEntry));
-    L.slot_stamp = take(off, (size_t)d->F * 3 * 4);                  // few views (round 6): the step counter of the last step in which a corner slot was written (shade.hip)
     L.total = off;
     return L;
 }
@@ -260,7 +257,6 @@ extern "C" int fmhr_ham_workspace_init(const fmhr_ham_dims* d, void* ws, size_t 
     // coverage entries are recognised by the step stamp: start with no entry valid, counter at 0
     HIPTRY(hipMemsetAsync(w + L.cov16, 0xFF, (size_t)d->n * d->F * 8, (hipStream_t)stream), "init cov16");
     HIPTRY(hipMemsetAsync(w + L.stamp, 0, 16, (hipStream_t)stream), "init stamp");
-    HIPTRY(hipMemsetAsync(w + L.slot_stamp, 0, (size_t)d->F * 3 * 4, (hipStream_t)stream), "init slot stamps");   // (the counter's first value is 1)
     HIPTRY(hipMemsetAsync(w + L.own8, 0, (size_t)d->n * d->F, (hipStream_t)stream), "init own8");
     HIPTRY(hipMemsetAsync(w + L.bin_cursor, 0, L.bins - L.bin_cursor, (hipStream_t)stream), "init bin cursors");   // self-cleaning afterwards
     // every segment's words count as live until the second pass has seen the segment once (bit 1 of every byte: kSegWordsLive, bit 0 clear)
@@ -424,7 +420,7 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
                           (const float*)(w + L.cmat), vertices, d->n, d->V, d->F, d->H, d->W, Wp, (float*)(w + L.part),
                           (const int2*)(w + L.snap), (const int2*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, Wp) + 16),
                           (const int*)(w + L.raster_ws + raster_keys_bytes(d->n, d->H, Wp)), (const unsigned long long*)(w + L.covw),
-                          (float*)(w + L.vacc), (int*)(w + L.slot_stamp), st));
+                          (float*)(w + L.vacc), st));
     }
     {
         // everything per-vertex after the face-parallel backward, in two kernels (mesh.hip: k_mesh_tail_a / _b)
@@ -433,8 +429,6 @@ extern "C" int fmhr_ham_backward(const fmhr_ham_dims* d, const fmhr_ham_weights*
         A.part = (const float4*)(w + L.part); A.gvert_aa = gvert_aa; A.G = face_bwd_groups(d->n, d->H, Wp);
         A.gvert_aa2 = split ? (float*)(w + L.gvert_aa2) : nullptr; A.col_mult = col_mult;
         A.vacc = (float*)(w + L.vacc);
-        A.slot_stamp = face_bwd_slot_skip(d->n, d->H, d->W, d->F) ? (const int*)(w + L.slot_stamp) : nullptr;
-        A.stamp = (const int*)(w + L.stamp);
         A.gacc_r = (float*)(w + L.gvert_r);
         A.gdelta = gdelta; A.galbedo = galbedo; A.gd_rest = gdelta_rest; A.ga_rest = galbedo_rest;
         TRY(adam_tensor_from(A.ad_d, adam_delta, 3ll * d->V));

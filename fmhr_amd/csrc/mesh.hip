@@ -447,7 +447,6 @@ struct MeshTailArgs {
     const float4* part; float* gvert_aa; int G;                                       // face-backward corner sums [G, 3F] x 3 float4
     float* gvert_aa2;                                                                 // split mode: the silhouette share of the antialias position gradient
     float* vacc;                                                                      // [V] x 3 float4: the large-box faces' backward sums per vertex (shade.hip), packed like a corner slot
-    const int* slot_stamp; const int* stamp;                                          // few views (round 6): only corner slots stamped with THIS step's counter hold sums (null: all do)
     const float* verts; const float* delta; const float* albedo; const float* nsum;
     const int32_t* tri; const int32_t* vf_ptr; const int32_t* vf_idx; const int32_t* row_ptr; const int32_t* col;
     const int32_t* col_mult;                                                          // faces per adjacency entry (fmhr_edge_multiplicity_build)
@@ -479,10 +478,7 @@ __global__ void __launch_bounds__(kBlock) k_mesh_tail_a(const MeshTailArgs A)
     if (live) {
         const int c0 = A.vf_ptr[vv], nq = (A.vf_ptr[vv + 1] - c0) * 3;
         const size_t plane = (size_t)A.F * 9;
-        const int cur = (A.slot_stamp != nullptr) ? A.stamp[0] : 0;
         for (int j = sub; j < nq; j += kSubLanes) {
-            // few views: a slot nobody stamped in this step belongs to a face that owned no pixel — nothing was written, nothing is read
-            if (A.slot_stamp != nullptr && A.slot_stamp[c0 + j / 3] != cur) continue;
             const float4* q = A.part + (size_t)c0 * 3 + j;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int g = 0; g < A.G; g++) {
