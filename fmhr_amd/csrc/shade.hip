@@ -749,187 +749,6 @@ k_face_bwd(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri, co
                           pg, g, g * kGroup * VA, la.workers);
 }
 
-// ---- the face-parallel backward for FEW views (round 6): n <= kGroup, one view group.
-// k_face_bwd gives every face a group of 8 lanes, one per view: with the 1 .. 6 views a rank of an 8-GPU run renders (VERDICT r5 item 2:
-// the per-rank share) most of those lanes have no view, and the launch is 8 F lanes = 24.6 k waves for the two-hand mesh — k_face_bwd<1,1>
-// took 43.6 us for ONE view of it (F = 196 864; 20.7 us at F = 98 432 with six views: a cost per FACE, profiles/r06_v104_*).  Here a LANE
-// is a face in the set-up (owner marks, coverage entries, vertex ids, attributes: 64 faces per wave, F / 64 waves), the candidate pixels
-// of the wave's 64 faces x n views are numbered into ONE task list in LDS (wave prefix scan), and the lanes take CONTIGUOUS runs of it:
-// a run stays inside one or two faces, so the per-pixel backward accumulates in registers and is added to the face's LDS accumulator
-// (ds_add_f32) only where the face changes; at the end the lane that owns a face stores its three corner slots exactly as k_face_bwd does.
-// Same per-pixel statements (pixel_backward), same outputs (`part`, G = 1), same large-box workers at the head of the launch.
-constexpr int kFewTasks = 1024;                  // task-list entries per wave and round (a wave has ~110 n candidates on the metric mesh)
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))      // 68 KB of LDS per workgroup: two workgroups per CU — the launch is F / 64 waves, 1 - 1.5 rounds of that
-k_face_bwd_few(const float4* __restrict__ bwd16, const int32_t* __restrict__ tri,
-               const float4* __restrict__ attr8, const float* __restrict__ sh, const float4* __restrict__ g_shaded,
-               const int2* __restrict__ cov16, const unsigned char* __restrict__ own8, const int* __restrict__ stamp,
-               const int32_t* __restrict__ corner_slot,
-               const float4* __restrict__ cmat, const float* __restrict__ verts, int n, int V, int F,
-               int H, int W, int Wp, float4* __restrict__ part, const PixGrid pg, const LargeArgs la)
-{
-    if ((int)blockIdx.x < la.workers) {                            // the workers of the large-box queue, as in k_face_bwd
-        face_bwd_large_items<true>(bwd16, tri, la.snap, attr8, sh, g_shaded, corner_slot, cmat, verts, la.large_q, la.large_cnt, la.covw, own8, stamp,
-                                   n, V, F, H, W, Wp, 0, la.vacc, pg, (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6), la.workers * (kBlock / 64), stamp);
-        return;
-    }
-    constexpr int kWaves = kBlock / 64;
-    __shared__ float view_c[kGroup][28];                           // per view: 9 SH coefficients, the clip-matrix rows as (x, y, w, z)
-    __shared__ FaceAttr fattr[kBlock];                             // per face of the workgroup (27 floats: an odd stride, conflict-free per lane)
-    __shared__ float facc[kBlock][27];                             // per face: the 3 x 9 corner sums
-    __shared__ int pk_box[kBlock][kGroup];                         // packed box of (face, view)
-    __shared__ unsigned short tasks[kWaves][kFewTasks];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int f = ((int)blockIdx.x - la.workers) * kBlock + tid;
-    const bool facelive = f < F;
-    const long long P = (long long)H * Wp;
-    const unsigned cur = (unsigned)stamp[0] & 0xFFFFFFu;
-    // ---- everything whose address is known up front: vertex ids, output slots, owner marks and coverage entries of the n views
-    int3a ti = {0, 0, 0};
-    int es[3] = {0, 0, 0};
-    unsigned msk[kGroup];
-    int box[kGroup];
-    unsigned char mark[kGroup];
-#pragma unroll
-    for (int b = 0; b < kGroup; b++) { msk[b] = 0u; box[b] = -1; mark[b] = 0; }
-    if (facelive) {
-        ti = *reinterpret_cast<const int3a*>(tri + (size_t)f * 3);
-#pragma unroll
-        for (int k = 0; k < 3; k++) es[k] = corner_slot[f * 3 + k];
-#pragma unroll
-        for (int b = 0; b < kGroup; b++)
-            if (b < n) {
-                mark[b] = own8[(size_t)b * F + f];
-                const int2 e = cov16[(size_t)b * F + f];
-                msk[b] = (unsigned)e.x; box[b] = e.y;
-            }
-    }
-    {   // the views' constants (one element per thread: kGroup * 28 = 224 <= kBlock), staged while those requests are in flight
-        const float* const cmf = reinterpret_cast<const float*>(cmat);
-        const int i = min(tid, kGroup * 28 - 1);
-        const int vb = i / 28, k = i - vb * 28, bb = min(vb, n - 1);
-        const int kk = min(max(k - 9, 0), 15), col = kk & 3;
-        const int pc = (col == 2) ? 3 : ((col == 3) ? 2 : col);
-        const float* src = (k < 9) ? (sh + (size_t)bb * 9 + k) : (cmf + (size_t)bb * 16 + (kk & ~3) + pc);
-        const float v = *src;
-        if (tid < kGroup * 28) (&view_c[0][0])[tid] = (vb < n && k < 25) ? v : 0.f;
-    }
-#pragma unroll
-    for (int c = 0; c < 27; c++) facc[tid][c] = 0.f;
-    __syncthreads();                                               // the only workgroup barrier: everything below is per wave
-    // candidates of this face: a (face, view) counts when it owned a pixel in THIS step and is a box triangle (a large-box face — field 63 —
-    // has no candidate mask: its pixels are the queue workers' business)
-    int cnt = 0;
-#pragma unroll
-    for (int b = 0; b < kGroup; b++) {
-        const bool own = facelive && b < n && mark[b] == (unsigned char)cur && ((unsigned)box[b] >> 26) != 63u;
-        if (!own) msk[b] = 0u;
-        cnt += __popc(msk[b]);
-        pk_box[tid][b] = box[b];
-    }
-    const int incl = wave_incl_scan(cnt), excl = incl - cnt;
-    const int T = __builtin_amdgcn_readlane(incl, 63);             // the wave's candidate pixels
-    if (T != 0) {                                                  // wave-uniform
-        if (cnt != 0) {                                            // the face's attributes -> its LDS record (the statements of face_bwd_large_items)
-            const float4 q0 = attr8[(size_t)ti.x * 2], q1 = attr8[(size_t)ti.x * 2 + 1], u0 = attr8[(size_t)ti.y * 2], u1 = attr8[(size_t)ti.y * 2 + 1],
-                         w0 = attr8[(size_t)ti.z * 2], w1 = attr8[(size_t)ti.z * 2 + 1];
-            FaceAttr fa;
-            fa.n2 = make_float3(w0.x, w0.y, w0.z); fa.a2 = make_float3(w0.w, w1.x, w1.y);
-            fa.dn0 = make_float3(q0.x - fa.n2.x, q0.y - fa.n2.y, q0.z - fa.n2.z);
-            fa.da0 = make_float3(q0.w - fa.a2.x, q1.x - fa.a2.y, q1.y - fa.a2.z);
-            fa.dn1 = make_float3(u0.x - fa.n2.x, u0.y - fa.n2.y, u0.z - fa.n2.z);
-            fa.da1 = make_float3(u0.w - fa.a2.x, u1.x - fa.a2.y, u1.y - fa.a2.z);
-            fa.v0 = ld3f(verts + (size_t)ti.x * 3); fa.v1 = ld3f(verts + (size_t)ti.y * 3); fa.v2 = ld3f(verts + (size_t)ti.z * 3);
-            fattr[tid] = fa;
-        }
-        const int fbase = f - lane;                                // the wave's first face
-        for (int R = 0; R < T; R += kFewTasks) {                   // wave-uniform; one round unless the wave has > kFewTasks candidates
-            // task = face-in-wave << 8 | view << 5 | candidate bit; numbered in (face, view, bit) order
-            if (cnt != 0 && excl < R + kFewTasks && excl + cnt > R) {
-                int idx = excl - R;
-#pragma unroll
-                for (int b = 0; b < kGroup; b++) {
-                    unsigned m = msk[b];
-                    while (m != 0u) {
-                        const int bit = __builtin_ctz(m);
-                        m &= m - 1u;
-                        if (idx >= 0 && idx < kFewTasks) tasks[wv][idx] = (unsigned short)((lane << 8) | (b << 5) | bit);
-                        idx++;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int nt = min(kFewTasks, T - R), per = (nt + 63) >> 6;
-            const int t0 = lane * per, t1 = min(t0 + per, nt);     // this lane's contiguous run
-            auto locate = [&](int t, int& fl, int& b, int& px, int& py) {
-                const int en = tasks[wv][t], bit = en & 31;
-                fl = en >> 8; b = (en >> 5) & 7;
-                const int bx = pk_box[(wv << 6) + fl][b];
-                const int bwd = ((bx >> 26) & 63) + 1;
-                const int r = (int)(((float)bit + 0.5f) * frcp((float)bwd)), c = bit - r * bwd;
-                px = (bx & 0x1fff) + c; py = ((bx >> 13) & 0x1fff) + r;
-                return (long long)b * P + (long long)py * Wp + px;
-            };
-            float A[3][9];
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-#pragma unroll
-                for (int c = 0; c < 9; c++) A[k][c] = 0.f;
-            auto flush = [&](int fl) {                             // the run's sums of face fl -> its accumulator (zeros are not sent)
-                float* const dst = &facc[(wv << 6) + fl][0];
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-#pragma unroll
-                    for (int c = 0; c < 9; c++) {
-                        if (A[k][c] != 0.f) __hip_atomic_fetch_add(dst + k * 9 + c, A[k][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        A[k][c] = 0.f;
-                    }
-            };
-            int fl = 0, b = 0, px = 0, py = 0, flcur = -1;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f), gs = w;
-            if (t0 < t1) {
-                const long long gid = locate(t0, fl, b, px, py);
-                w = bwd16[gid];
-                gs = g_shaded[gid];
-            }
-            for (int t = t0; t < t1; t++) {                        // software-pipelined: the next task's two loads fly while this one is evaluated
-                int fl2 = 0, b2 = 0, px2 = 0, py2 = 0;
-                float4 w2 = w, gs2 = gs;
-                if (t + 1 < t1) {
-                    const long long gid2 = locate(t + 1, fl2, b2, px2, py2);
-                    w2 = bwd16[gid2];
-                    gs2 = g_shaded[gid2];
-                }
-                pin(w); pin(gs);
-                const int pk = __float_as_int(w.w);
-                if (pix_face(pk) == fbase + fl && pix_mask(pk) && !(gs.x == 0.f && gs.y == 0.f && gs.z == 0.f)) {
-                    if (fl != flcur) {
-                        if (flcur >= 0) flush(flcur);
-                        flcur = fl;
-                    }
-                    pixel_backward(A, fattr[(wv << 6) + fl], &view_c[b][0], w.x, w.y, gs, px, py, pg);
-                }
-                w = w2; gs = gs2; fl = fl2; b = b2; px = px2; py = py2;
-            }
-            if (flcur >= 0) flush(flcur);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();                       // the task list is reused by the next round / the sums are complete
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-    if (facelive) {                                                // the face's three corner slots (zeros for a face that owns nothing: the tail sums every slot)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float* const o = &facc[tid][k * 9];
-            float4* dst = part + (size_t)es[k] * 3;
-            dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-            dst[1] = make_float4(o[4], o[5], o[6], o[7]);
-            dst[2] = make_float4(o[8], 0.f, 0.f, 0.f);
-        }
-    }
-}
-
 int valid_mask_segments_impl(const float* valid_mask, int n, int H, int W, int Wp, unsigned char* vmnz, hipStream_t st)
 {
     const long long N = (long long)n * H * Wp;
@@ -1016,15 +835,7 @@ int face_bwd_impl(const float* bwd16, const int32_t* tri, const float* pos, cons
                                              (const int2*)cov16, own8, stamp, corner_slot, (const float4*)cmat, verts, n, V, F, H, W, Wp, \
                                              (float4*)part, pg, la)
     static_assert(kMaxVPL == 6, "the instantiation table below: 1 .. 4 views per lane with any remainder, 5 and 6 as single groups");
-    // FEW views (one group of at most kGroup: the share of a rank of an 8-GPU run, the small configurations): lane = face (k_face_bwd_few);
-    // FMHR_FACE_BWD_FEW=0 / 1 forces either form (same-library A/B)
-    const char* few_env = getenv("FMHR_FACE_BWD_FEW");
-    const bool few = n <= kGroup && !coarse && (few_env ? atoi(few_env) != 0 : true);
-    if (few) {
-        const dim3 fgrid(cdiv(F, kBlock) + la.workers);
-        k_face_bwd_few<<<fgrid, kBlock, 0, st>>>((const float4*)bwd16, tri, (const float4*)attr8, sh, (const float4*)g_shaded, (const int2*)cov16, own8, stamp,
-                                                corner_slot, (const float4*)cmat, verts, n, V, F, H, W, Wp, (float4*)part, pg, la);
-    } else {
+    {
         const int va = face_bwd_vpl(n, H, Wp), rem = n - (face_bwd_groups(n, H, Wp) - 1) * kGroup * va;     // views of the last group
         const int vb = min(va, cdiv(rem, kGroup));
         switch (va * 8 + vb) {
