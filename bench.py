@@ -729,7 +729,7 @@ def main():
         # HBM traffic of the launch groups comes from the committed PMC profile of this same command (counters cannot be
         # collected live next to the timed region); null when the workload differs from the profiled one
         traffic = None
-        tpath = next((os.path.join(ROOT, "profiles", f) for f in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json")
+        tpath = next((os.path.join(ROOT, "profiles", f) for f in ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json")
                       if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
         if os.path.exists(tpath) and args.config == "metric" and world == 1 and args.views is None and hs.binned == traffic_binned(tpath):
             traffic = json.load(open(tpath))
