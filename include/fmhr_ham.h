@@ -209,8 +209,11 @@ int fmhr_ham_rasterizer_form(const fmhr_ham_dims* d);
  *   corner_slot [3F] (fmhr_corner_slots_build).
  *   view_idx (ABI 6): NULL, or — with dims.n_src > 0 — device int32 [n], all in [0, n_src): view b of the step is view view_idx[b] of
  *   the caller's arrays, which are then [n_src, ...] (the whole capture, resident): sh, w2c, proj, img, mask, valid_mask.  The kernels
- *   index through it (one scalar load per wave); nothing is gathered or copied.  The SAME array must be passed to the forward and the
- *   backward of a step and stay unchanged until both have run (stream order).  Replaces the loop's per-batch gathers
+ *   index through it (one scalar load per wave); nothing is gathered or copied.  The forward CLAMPS every entry to [0, n_src) and keeps the
+ *   clamped selection in the workspace: that copy is what every later kernel of the step — the backward included — reads, so an index out
+ *   of range is never an out-of-bounds access; it sets a sticky word (int32 at fmhr_ham_workspace_offset(d, "stamp") + 4) that the host
+ *   reads with the overflow flags (HamStage2.check_overflow raises).  The backward differentiates the selection the forward rendered;
+ *   its own view_idx argument only has to be non-NULL.  Replaces the loop's per-batch gathers
  *   `w2cs[perm[k:k+batch]]` ... `sh_coeffs[perm[k:k+batch]]` (mesh_sfs_optim.py:255-260).
  *   n*H*pitch must be a multiple of 4 (always true with the default pitch).
  *   valid_mask_changed: pass 1 on the first call on a workspace and whenever valid_mask's CONTENTS may differ from the previous

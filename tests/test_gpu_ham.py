@@ -1244,3 +1244,28 @@ def test_view_selection_argument_errors(oracle):
         HamStage2(sc["faces"].to(dev), sc["V"], 2, 50, 38, sc["weights"], sc["elm"], n_src=3, pitch=38)
     sel.step(*args, view_idx=idx)                                                 # ... and the well-formed call runs
     assert sel.loss_dict()["n_valid"] > 0
+
+
+def test_view_index_out_of_range_is_clamped_and_reported(oracle):
+    """view_idx is dereferenced on the device.  An index outside [0, n_src) must never read out of bounds: the geometry kernel
+    clamps it (the step then renders the clamped view — exactly, for every later kernel reads the clamped copy) and sets a sticky word;
+    check_overflow() / loss_dict() raise.  A well-formed selection on the same workspace afterwards still reports the earlier fault."""
+    from fmhr_amd.ham import HamStage2
+    sc = prepare(oracle, (3, 64, 64, 10, 14), 55)
+    dev = torch.device("cuda:0")
+    g = {k: sc[k].to(dev).contiguous() for k in ("vertices", "delta", "albedo", "sh0", "w2c", "proj", "img", "mask", "valid_mask")}
+    args = (g["vertices"], g["delta"], g["albedo"], g["sh0"], g["w2c"], g["proj"], g["img"], g["mask"], g["valid_mask"])
+    good = HamStage2(sc["faces"].to(dev), sc["V"], 2, 64, 64, sc["weights"], sc["elm"], n_src=3)
+    good.step(*args, view_idx=torch.tensor([2, 0], dtype=torch.int32, device=dev))
+    ref = (good.losses.clone(), good.gdelta.clone(), good.galbedo.clone())
+    good.check_overflow()
+    bad = HamStage2(sc["faces"].to(dev), sc["V"], 2, 64, 64, sc["weights"], sc["elm"], n_src=3)
+    bad.step(*args, view_idx=torch.tensor([7, -4], dtype=torch.int32, device=dev))          # clamped to views 2 and 0
+    torch.cuda.synchronize()
+    assert float(bad.losses[7]) == float(ref[0][7]) and rel_err(bad.losses[:7], ref[0][:7]) < 1e-6      # (float atomics: not the same bits)
+    assert rel_err(bad.gdelta, ref[1]) < 1e-5 and rel_err(bad.galbedo, ref[2]) < 1e-5
+    with pytest.raises(RuntimeError, match="view index outside"):
+        bad.check_overflow()
+    bad.step(*args, view_idx=torch.tensor([2, 0], dtype=torch.int32, device=dev))
+    with pytest.raises(RuntimeError, match="view index outside"):                              # sticky
+        bad.loss_dict()
