@@ -22,12 +22,14 @@ class RasterizeGLContext:
         self._topo_key = None
         self._tri_ref = None     # keeps the keyed tensor alive so its address cannot be reused by another tensor
         self._opp = None
-        self._scratch = {}       # reusable scratch by (name, device): the rasterizer's key / queue workspace
+        self._scratch = {}       # reusable scratch by (name, device, stream): the rasterizer's key / queue workspace
 
     def scratch(self, name, nbytes, device):
-        """a uint8 scratch buffer of at least `nbytes`, owned by the context and reused by every call that asks for `name` (round 5: a
-        48-view 512 x 512 rasterize allocated 138 MB of depth keys + queue per call; what a call leaves in it is dead when it returns)"""
-        key = (name, device)
+        """a uint8 scratch buffer of at least `nbytes`, owned by the context and reused by every call that asks for `name` ON THE SAME
+        STREAM (round 5: a 48-view 512 x 512 rasterize allocated 138 MB of depth keys + queue per call; what a call leaves in it is dead
+        when it returns).  Keyed by the current stream as well: two calls on different streams that share a context — the
+        default context is global — get different buffers instead of racing on one; stream order protects a buffer within its stream."""
+        key = (name, device, torch.cuda.current_stream(device).cuda_stream)
         buf = self._scratch.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = self._scratch[key] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
