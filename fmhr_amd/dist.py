@@ -488,17 +488,24 @@ class ExchangeError(RuntimeError):
 class ExchangeMonitor:
     """What makes a dead exchange impossible to miss.  The replicated parameters of a view-sharded run stay
     identical ONLY because every rank applies the same update to the same all-reduced gradient; an exchange that silently returns a rank's
-    own share (a peer-to-peer wait that ran into its bound, a communicator in an error state) would let the ranks drift apart — and read
-    as a FASTER run.  `verify(tensors)`: a checksum of the BITS of the replicated tensors (sum of their int32 images, in int64) must be the
-    same on every rank — MAX and MIN over the ranks through the TORCH group, which is independent of the step's own exchange path — and no
-    rank's exchange may report a failure (PeerAllReduce.gave_up(): the kernel's sticky abort word; StreamAllReduce.gave_up(): RCCL's
-    asynchronous error).  One small collective + one synchronisation: the loops call it every `check_every` epochs and at their end,
-    bench.py after its timed region.  It raises ExchangeError ON EVERY RANK (the verdict itself is all-reduced)."""
+    own share (a peer-to-peer wait that ran into its bound, a communicator in an error state) would let the ranks optimise apart — and read
+    as a FASTER run.  `verify(tensors)`:
+      1. a checksum of the BITS of the replicated tensors (sum of their int32 images, in int64), MAX and MIN over the ranks through the
+         TORCH group — independent of the step's own exchange path —, a NaN flag, and the exchange's own failure state
+         (PeerAllReduce.gave_up(): the kernel's sticky abort word; StreamAllReduce.gave_up(): RCCL's asynchronous error);
+      2. only when the bits differ: the largest element-wise spread over the ranks (all-reduce MAX and MIN of the tensors themselves)
+         relative to the largest magnitude.  A reduction that is not bit-reproducible ACROSS ranks (an all-reduce algorithm in which every
+         rank sums in its own order) shows as a spread of a few ulps; ranks that stopped exchanging are apart by O(lr x steps).
+    The verdict — taken from all-reduced quantities, so every rank reaches the same one — is `ok` unless an exchange failed, a value is not
+    finite, or the spread exceeds `tol` (default 1e-3 of the largest magnitude); then ExchangeError is raised ON EVERY RANK.  With
+    `resync=[...]` and differing-but-close bits, rank 0's tensors are broadcast so that rounding differences cannot accumulate.
+    One or three small collectives + one synchronisation: the loops call it every `check_every` epochs and at their end, bench.py after its
+    timed region."""
 
-    def __init__(self, group, exchange=None, dev=None):
-        self.group, self.exchange = group, exchange
+    def __init__(self, group, exchange=None, dev=None, tol=1e-3):
+        self.group, self.exchange, self.tol = group, exchange, float(tol)
         self.dev = dev if dev is not None else torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        self.checks, self.last = 0, None
+        self.checks, self.last, self.resyncs = 0, None, 0
 
     def _active(self):
         return self.group is not None and dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -507,8 +514,8 @@ class ExchangeMonitor:
     def fingerprint(tensors):
         return torch.stack([t.detach().contiguous().view(-1).view(torch.int32).to(torch.int64).sum() for t in tensors])
 
-    def verify(self, tensors, what="parameters"):
-        """-> dict(ok, checks); raises ExchangeError on every rank when any rank disagrees or reports a failed exchange"""
+    def verify(self, tensors, what="parameters", resync=None):
+        """-> dict(ok, same_bits, spread_rel, exchange_failed, non_finite, checks); raises ExchangeError on every rank when not ok"""
         bad_local = 0
         ex = self.exchange
         if ex is not None and hasattr(ex, "gave_up"):
@@ -516,24 +523,39 @@ class ExchangeMonitor:
                 bad_local = 1 if ex.gave_up() else 0
             except Exception:  # noqa: BLE001
                 bad_local = 1
+        k = len(tensors)
         fp = self.fingerprint(tensors).to(self.dev)
         nan = torch.stack([(~torch.isfinite(t.detach())).any().to(torch.int64) for t in tensors]).to(self.dev)
         v = torch.cat([fp, -fp, nan, torch.tensor([bad_local], dtype=torch.int64, device=self.dev)])
         if self._active():
             dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
-        k = len(tensors)
         v = v.tolist()
         same = all(v[i] == -v[k + i] for i in range(k))
+        non_finite, failed = bool(any(v[2 * k: 3 * k])), bool(v[-1])
+        spread = 0.0
+        if not same and not non_finite and self._active():           # (every rank knows `same`: all of them enter these collectives)
+            for t in tensors:
+                hi, lo = t.detach().clone(), t.detach().clone()
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+                spread = max(spread, float((hi - lo).abs().max() / torch.maximum(hi.abs().max(), lo.abs().max()).clamp_min(1e-30)))
         self.checks += 1
-        self.last = dict(ok=same and v[-1] == 0 and not any(v[2 * k: 3 * k]), same_bits=same, exchange_failed=bool(v[-1]), non_finite=bool(any(v[2 * k: 3 * k])),
-                         checks=self.checks)
-        if not self.last["ok"]:
+        ok = (not failed) and (not non_finite) and (same or spread <= self.tol)
+        self.last = dict(ok=ok, same_bits=same, spread_rel=spread, exchange_failed=failed, non_finite=non_finite, checks=self.checks,
+                         resyncs=self.resyncs)
+        if not ok:
             rank = dist.get_rank(self.group) if self._active() else 0
             raise ExchangeError(f"rank {rank}: the view-sharded run is broken ({what}): "
-                                + ("the step's exchange reported a failure on some rank (a bounded wait gave up / RCCL asynchronous error); " if v[-1] else "")
-                                + ("the ranks hold DIFFERENT bits; " if not same else "")
-                                + ("non-finite values; " if any(v[2 * k: 3 * k]) else "")
+                                + ("the step's exchange reported a failure on some rank (a bounded wait gave up / RCCL asynchronous error); " if failed else "")
+                                + (f"the ranks hold DIFFERENT values (largest spread {spread:.2e} of the largest magnitude); " if not same else "")
+                                + ("non-finite values; " if non_finite else "")
                                 + f"check {self.checks} — results since the previous check are invalid")
+        if not same and resync and self._active():                   # close but not the same bits: rank 0's values for everybody
+            src = dist.get_global_rank(self.group, 0) if self.group is not dist.group.WORLD else 0
+            for t in resync:
+                dist.broadcast(t.detach(), src=src, group=self.group)
+            self.resyncs += 1
+            self.last["resyncs"] = self.resyncs
         return self.last
 
 

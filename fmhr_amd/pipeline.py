@@ -240,7 +240,9 @@ class Stage2Loop:
         v = torch.tensor(flags, dtype=torch.int64, device=self.dev)
         torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX, group=self.group)
         aa, bins, need, bad_idx = v.tolist()
-        self.monitor.verify([self.delta, self.albedo], "stage-2 parameters (delta, albedo) after epoch %d" % self.epoch)
+        state = [st_[k_] for p_ in (self.delta, self.albedo) for st_ in [self.opt.state.get(p_)] if st_ for k_ in ("exp_avg", "exp_avg_sq")]
+        self.monitor.verify([self.delta, self.albedo], "stage-2 parameters (delta, albedo) after epoch %d" % self.epoch,
+                            resync=[self.delta, self.albedo] + state)
         if bad_idx:
             raise RuntimeError("Stage2Loop: a step on some rank was given a view index outside the capture")
         if bins:

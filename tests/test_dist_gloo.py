@@ -410,10 +410,12 @@ def _loop_worker(rank, world, port, q):
     mon = fdist.ExchangeMonitor(dist.group.WORLD, None, torch.device("cpu"))
     same = torch.arange(12, dtype=torch.float32).view(4, 3)
     verdicts = [mon.verify([same, same * 2])["ok"]]
-    for case in ("bits", "gave_up", "nan"):
+    for case in ("bits", "gave_up", "nan", "apart"):
         t = same.clone()
         if case == "bits" and rank == 1:
             t[2, 1] = torch.nextafter(t[2, 1], torch.tensor(100.0))          # ONE bit of one element on one rank
+        if case == "apart" and rank == 1:
+            t[2, 1] = t[2, 1] * 1.05                                          # ranks that stopped exchanging: apart by per cents
         if case == "nan" and rank == 1:
             t[0, 0] = float("nan")
 
@@ -422,8 +424,8 @@ def _loop_worker(rank, world, port, q):
                 return case == "gave_up" and rank == 0
         m = fdist.ExchangeMonitor(dist.group.WORLD, Ex(), torch.device("cpu"))
         try:
-            m.verify([t])
-            verdicts.append("no error")
+            m.verify([t], resync=[t])
+            verdicts.append(("ok", m.last["same_bits"], m.last["spread_rel"], m.last["resyncs"], float(t[2, 1])))
         except fdist.ExchangeError as e:
             verdicts.append(("raised", m.last["same_bits"], m.last["exchange_failed"], m.last["non_finite"]))
     q.put((rank, out, verdicts))
@@ -435,8 +437,10 @@ def _loop_worker(rank, world, port, q):
 def test_loop_batches_over_two_ranks_with_a_zero_view_rank(oracle):
     """the product's loop on N ranks.  An epoch of 4 views in batches of 3 on 2 ranks: the batch of 3 splits 2 + 1, the
     ragged last batch of ONE view leaves rank 1 without a view — it enters the exchange with a zero share; the MSE divisor is the BATCH's
-    n * H * W on every rank.  Both batches must equal the single-process step on the batch's views.  And the exchange monitor: one
-    differing bit on one rank, a failed exchange on one rank, a NaN on one rank each raise on BOTH."""
+    n * H * W on every rank.  Both batches must equal the single-process step on the batch's views.  And the exchange monitor: ONE differing
+    bit on one rank is reported (same_bits False, a spread of an ulp) and repaired (rank 0's values broadcast) without an error — a
+    reduction need not be bit-reproducible across ranks —; a failed exchange on one rank, a NaN on one rank, values apart by per cents each
+    raise on BOTH."""
     from checker_scenes import prepare
     from fmhr_amd import dist as fdist
     from util import rel_err
@@ -466,6 +470,7 @@ def test_loop_batches_over_two_ranks_with_a_zero_view_rank(oracle):
     for rank in (0, 1):
         v = got[rank][1]
         assert v[0] is True
-        assert v[1] == ("raised", False, False, False), v
+        assert v[1][0] == "ok" and v[1][1] is False and 0 < v[1][2] < 1e-6 and v[1][3] == 1 and v[1][4] == 7.0, v      # (7.0: rank 0's value on both)
         assert v[2] == ("raised", True, True, False), v
         assert v[3][0] == "raised" and v[3][3] is True, v
+        assert v[4] == ("raised", False, False, False), v
