@@ -513,7 +513,8 @@ def main():
             self.group = fgroups[frame]
             self.loop = Stage2Loop(vtmp, faces, self.delta, self.albedo, sh, tgt["img"], tgt["mask"], tgt["valid_mask"], w2c, proj, (H, W),
                                    scene["weights"], elm, self.opt, loop_batch, 1 << 30, torch.Generator(device="cpu").manual_seed(args.seed),
-                                   check_every=64, group=torch.distributed.group.WORLD if sharded else None, exchange=self.group, bin_cap=bench_bin_cap[0])
+                                   check_every=0,      # (no polls inside the timed region: the flags and the exchange are checked after it)
+                                   group=torch.distributed.group.WORLD if sharded else None, exchange=self.group, bin_cap=bench_bin_cap[0])
             self.loop.step_next()                                # the first step builds the workspace of this rank's batch share
 
         @property

@@ -525,7 +525,10 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
             for ep in range(epoch_sfs):
                 loop.run_epoch(after_step=keep if ep == epoch_sfs - 1 else None)     # the last epoch's renders are the "rerender" images
                 if log_every and ep % log_every == 0:
-                    history.append(("sfs", ep, loop.hs.loss_dict()))
+                    # (on N ranks the losses are read WITHOUT the local overflow check of loss_dict(): a rank that raised alone would leave
+                    # the others in the next exchange — the flags are judged collectively by loop.check() / poll())
+                    from .ham import LOSS_NAMES
+                    history.append(("sfs", ep, dict(zip(LOSS_NAMES, loop.hs.losses.tolist())) if world > 1 else loop.hs.loss_dict()))
             loop.check()
             break
         except WorkListOverflow as e:
