@@ -410,24 +410,31 @@ def _loop_worker(rank, world, port, q):
     mon = fdist.ExchangeMonitor(dist.group.WORLD, None, torch.device("cpu"))
     same = torch.arange(12, dtype=torch.float32).view(4, 3)
     verdicts = [mon.verify([same, same * 2])["ok"]]
-    for case in ("bits", "gave_up", "nan", "apart"):
+    for case in ("bits", "gave_up", "nan", "apart", "dead"):
         t = same.clone()
         if case == "bits" and rank == 1:
             t[2, 1] = torch.nextafter(t[2, 1], torch.tensor(100.0))          # ONE bit of one element on one rank
         if case == "apart" and rank == 1:
-            t[2, 1] = t[2, 1] * 1.05                                          # ranks that stopped exchanging: apart by per cents
+            t = t * 1.5 + 3.0                                                 # ranks that stopped exchanging: other values altogether
         if case == "nan" and rank == 1:
             t[0, 0] = float("nan")
 
         class Ex:
+            numel = 64
+
             def gave_up(self, case=case):
                 return case == "gave_up" and rank == 0
+
+            def all_reduce_(self, t, stream=None, case=case):                # the probe goes through this: "dead" hands the local data back
+                if case != "dead":
+                    dist.all_reduce(t)
+                return t
         m = fdist.ExchangeMonitor(dist.group.WORLD, Ex(), torch.device("cpu"))
         try:
             m.verify([t], resync=[t])
-            verdicts.append(("ok", m.last["same_bits"], m.last["spread_rel"], m.last["resyncs"], float(t[2, 1])))
+            verdicts.append(("ok", m.last["same_bits"], m.last["spread_max"], m.last["resyncs"], float(t[2, 1])))
         except fdist.ExchangeError as e:
-            verdicts.append(("raised", m.last["same_bits"], m.last["exchange_failed"], m.last["non_finite"]))
+            verdicts.append(("raised", m.last["same_bits"], m.last["exchange_failed"], m.last["non_finite"], m.last["probe_ok"]))
     q.put((rank, out, verdicts))
     dist.barrier()
     dist.destroy_process_group()
@@ -439,8 +446,8 @@ def test_loop_batches_over_two_ranks_with_a_zero_view_rank(oracle):
     ragged last batch of ONE view leaves rank 1 without a view — it enters the exchange with a zero share; the MSE divisor is the BATCH's
     n * H * W on every rank.  Both batches must equal the single-process step on the batch's views.  And the exchange monitor: ONE differing
     bit on one rank is reported (same_bits False, a spread of an ulp) and repaired (rank 0's values broadcast) without an error — a
-    reduction need not be bit-reproducible across ranks —; a failed exchange on one rank, a NaN on one rank, values apart by per cents each
-    raise on BOTH."""
+    reduction need not be bit-reproducible across ranks —; a failed exchange on one rank, a NaN on one rank, altogether different values,
+    and an exchange object that hands every rank its own data back (the PROBE through the exchange path) each raise on BOTH."""
     from checker_scenes import prepare
     from fmhr_amd import dist as fdist
     from util import rel_err
@@ -471,6 +478,7 @@ def test_loop_batches_over_two_ranks_with_a_zero_view_rank(oracle):
         v = got[rank][1]
         assert v[0] is True
         assert v[1][0] == "ok" and v[1][1] is False and 0 < v[1][2] < 1e-6 and v[1][3] == 1 and v[1][4] == 7.0, v      # (7.0: rank 0's value on both)
-        assert v[2] == ("raised", True, True, False), v
+        assert v[2] == ("raised", True, True, False, True), v
         assert v[3][0] == "raised" and v[3][3] is True, v
-        assert v[4] == ("raised", False, False, False), v
+        assert v[4] == ("raised", False, False, False, True), v              # apart: the exchange works, the parameters do not agree
+        assert v[5] == ("raised", True, False, False, False), v              # dead: identical parameters (so far), but the exchange does not reduce
