@@ -10,6 +10,10 @@ if [ -z "$SKIP_TESTS" ]; then
   timeout -k 10 ${TEST_TIMEOUT:-700} python -m pytest ${TESTS:-$R/tests} -x -q -m gpu > $O/t.log 2>&1 || { tail -40 $O/t.log; exit 1; }
   tail -1 $O/t.log
 fi
+if [ -z "$SKIP_SMOKE" ]; then
+  timeout -k 10 200 python $R/__graft_entry__.py smoke > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 1; }
+  tail -1 $O/smoke.log
+fi
 if [ -z "$SKIP_BENCH" ]; then
   timeout -k 10 300 python $R/bench.py ${BENCH_ARGS:-} > $O/b.log 2>&1 || { tail -30 $O/b.log; exit 1; }
   timeout -k 10 300 python $R/bench.py --config demo --steps 60 --warmup 10 --no-stage1 ${DEMO_ARGS:-} > $O/b_demo.log 2>&1 || { tail -30 $O/b_demo.log; exit 1; }
