@@ -643,5 +643,5 @@ def test_run_ham_on_the_reference_capture_sharded_over_two_ranks(tmp_path):
                "rank: SH rows %.1e, the logged six losses of every epoch %.1e, share of rerendered pixels that differ by more than 8 / 255: %.1e; parameters in L2: albedo %.1e delta %.1e; "
                "components apart by more than 1e-3 / 1e-2 of the maximum: albedo %.2e delta %.2e of all (max-norm albedo %.1e delta %.1e: L1 sign flips, see the test)"
                % (e[0], e[3], worst, n2[0], n2[1], apart[0], apart[1], e[1], e[2]))
-    assert e[0] < 1e-4 and e[3] < 2e-3 and worst < 1e-5, (e, worst, nbad)
-    assert n2[0] < 1e-3 and n2[1] < 0.1 and apart[0] < 1e-3 and apart[1] < 0.05, (n2, apart)
+    assert e[0] < 1e-4 and e[3] < 5e-3 and worst < 1e-5, (e, worst, nbad)          # (measured 5e-4 .. 6e-4; 1 .. 3 pixels of 21 M)
+    assert n2[0] < 2e-3 and n2[1] < 0.1 and apart[0] < 5e-3 and apart[1] < 0.05, (n2, apart)   # (measured 1.4e-4, 6e-3, 5e-4, 1.3e-3)
