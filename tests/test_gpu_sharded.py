@@ -410,7 +410,7 @@ def _fixture():
     return g, conf
 
 
-def _run_ham_on_fixture(group=None, exchange=None, check_every=1):
+def _run_ham_on_fixture(group=None, exchange=None, check_every=1, batch=None):
     """run_ham on the inputs of tests/golden/boundary_loop.npz (4 views of 3 + 1 per epoch, two epochs per stage), replaying the
     fixture's permutations (the sequence the reference's statements drew when the fixture was made)"""
     from fmhr_amd import pipeline
@@ -419,11 +419,13 @@ def _run_ham_on_fixture(group=None, exchange=None, check_every=1):
     t = lambda k: torch.from_numpy(g["in_" + k]).to(dev)
     res = tuple(g["in_img"].shape[1:3])
     perms = dict(stage1=torch.from_numpy(g["s1_perms"]), stage2=torch.from_numpy(g["s2_perms"]))
+    if batch is not None:
+        conf = dict(conf, batch=batch)
     return pipeline.run_ham(t("vertices"), t("faces"), t("img"), t("gray"), t("mask"), t("w2c"), t("proj"), res, conf, seed=0, perms=perms,
                             check_every=check_every, log_every=1, group=group, exchange=exchange)
 
 
-def _run_ham_worker(rank, world, port, q, peer):
+def _run_ham_worker(rank, world, port, q, peer, batch=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     if peer:
         os.environ["FMHR_PEER_ALLREDUCE"] = "1"                 # the one-shot peer-to-peer exchange is opt-in; on one GPU it can be rehearsed over gloo
@@ -432,7 +434,7 @@ def _run_ham_worker(rank, world, port, q, peer):
     from fmhr_amd import dist as fdist
     fdist.init_from_env(backend="gloo")
     torch.cuda.set_device(0)
-    out = _run_ham_on_fixture(group=dist.group.WORLD)
+    out = _run_ham_on_fixture(group=dist.group.WORLD, batch=batch)
     torch.cuda.synchronize()
     q.put((rank, dict(delta=out["delta"].cpu().numpy(), albedo=out["albedo"].cpu().numpy(), sh=out["sh_coeffs"].cpu().numpy(),
                       valid_masks=out["valid_masks"].cpu().numpy(), exchange=out["exchange"],
@@ -442,8 +444,9 @@ def _run_ham_worker(rank, world, port, q, peer):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("peer,world", [(False, 2), (True, 2), (False, 3)], ids=["torch_group", "peer_to_peer", "three_ranks"])
-def test_run_ham_on_two_ranks_equals_the_single_rank_run(peer, world):
+@pytest.mark.parametrize("peer,world,batch", [(False, 2, None), (True, 2, None), (False, 3, None), (False, 3, 2)],
+                         ids=["torch_group", "peer_to_peer", "three_ranks", "a_rank_that_never_has_a_view"])
+def test_run_ham_on_two_ranks_equals_the_single_rank_run(peer, world, batch):
     """VERDICT r5 item 1 ('done' test): the product's own loop — init, stage 1, stage 2 of run_ham — view-sharded over two ranks on ONE GPU
     on the boundary fixture's capture and permutations: batches of 3 of 4 views split 2 + 1, the ragged last batch of one view leaves rank 1
     WITHOUT a view (zero share into the exchange), the stage-2 minibatch is selected inside the step (view_idx) AND sharded (group) in one
@@ -454,7 +457,8 @@ def test_run_ham_on_two_ranks_equals_the_single_rank_run(peer, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_ham_worker, args=(r, world, port, q, peer)) for r in range(world)]
+    # (batch = 2 on three ranks: every stage-2 batch is 1 + 1 + 0 views — rank 2 never renders, it only exchanges zero shares and updates)
+    procs = [ctx.Process(target=_run_ham_worker, args=(r, world, port, q, peer, batch)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(_get(q, procs, 800) for _ in range(world))
@@ -466,7 +470,7 @@ def test_run_ham_on_two_ranks_equals_the_single_rank_run(peer, world):
         assert all(np.array_equal(a[k], got[r][k]) for k in ("delta", "albedo", "sh", "valid_masks")), "the ranks hold different results"
     assert a["exchange"]["ok"] and a["exchange"]["same_bits"] and a["exchange"]["ranks"] == world and a["exchange"]["checks"] >= 2, a["exchange"]
     assert a["exchange"]["path"] == ("PeerAllReduce" if peer else "ProcessGroup"), a["exchange"]
-    one = _run_ham_on_fixture()
+    one = _run_ham_on_fixture(batch=batch)
     e = (rel_err(torch.from_numpy(a["sh"]), one["sh_coeffs"].cpu()), rel_err(torch.from_numpy(a["valid_masks"]), one["valid_masks"].cpu()),
          rel_err(torch.from_numpy(a["albedo"]), one["albedo"].cpu()), rel_err(torch.from_numpy(a["delta"]), one["delta"].cpu()),
          max(abs(a["last"][k] - v) / max(abs(v), 1e-6) for k, v in one["history"][-1][2].items() if k != "n_valid"))
@@ -480,7 +484,7 @@ def test_run_ham_on_two_ranks_equals_the_single_rank_run(peer, world):
     assert e[0] < 1e-5 and e[1] == 0.0 and e[2] < 1e-4 and e[4] < 1e-4, e
     # four Adam steps from zero moments are ~lr x sign(g) each: a component whose gradient is rounding noise may differ by O(lr)
     assert e[3] < 1e-3, e
-    assert ef[0] < 2e-3 and ef[1] < 2e-3, ef
+    assert batch is not None or (ef[0] < 2e-3 and ef[1] < 2e-3), ef        # (the fixture's own end state was made with batches of 3)
 
 
 def _skip_worker(rank, world, port, q):
