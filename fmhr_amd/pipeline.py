@@ -415,20 +415,25 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
         import torch.distributed as tdist
         from . import dist as fdist
         rank, world = tdist.get_rank(group), tdist.get_world_size(group)
-        if degree != 3:
-            raise RuntimeError("run_ham: the view-sharded run uses the fused stage-1 step (degree 3, as every conf of the reference)")
         if world > num:
             raise RuntimeError(f"run_ham: {world} ranks for a capture of {num} views: stage 1 shards the capture's views, one at least per rank")
         if exchange is None:
             exchange = fdist.make_stream_all_reduce(group, numel=12 * vertices.shape[0] + 8)
-    if degree == 3 and group is not None and world > 1:
+    d2 = degree * degree
+    fused_s1 = os.environ.get("FMHR_STAGE1_OPBYOP", "0") != "1"                      # (the op-by-op stage 1 on the generic ops stays selectable: A/B, tests)
+    # degree 1 / 2 (conf key `degree`; models/utils.py:188-226): the same fused stage-1 kernels on coefficient rows zero-padded to order 3,
+    # with the gradient of the bands the degree does not have masked out before the (then separate) Adam update — a zero coefficient with a
+    # zero gradient stays zero under Adam, so the padded rows ARE the lower-degree polynomial throughout (round 6; until then: op by op)
+    band = torch.zeros(9, dtype=torch.float32, device=dev)
+    band[:d2] = 1.0
+    if fused_s1 and group is not None and world > 1:
         # ---- view-sharded init + stage 1: this rank's views of the capture
         from . import stage1 as s1
         v0, v1 = fdist.shard_views(num, rank, world)
         hs1 = s1.HamStage1(vertices.detach(), faces, w2cs[v0:v1].contiguous(), projs[v0:v1].contiguous(), imgs[v0:v1].contiguous(),
                            masks[v0:v1].contiguous(), resolution, conf["sfs_weight"], want_pred_masks=True)
-        init = s1.init_sh(hs1, grayimgs[v0:v1].contiguous(), group=group, view0=v0, n_views_global=num)
-        sh_local = init["sh_coeffs"].clone().requires_grad_(True)                    # this rank's rows of :168-170
+        init = s1.init_sh(hs1, grayimgs[v0:v1].contiguous(), group=group, view0=v0, n_views_global=num, degree=degree)
+        sh_local = F.pad(init["sh_coeffs"], (0, 9 - d2)).contiguous().requires_grad_(True)   # this rank's rows of :168-170 (order-3 form)
         albedo = (torch.zeros_like(vertices) + init["albedo_mean"]).unsqueeze(0).contiguous().requires_grad_(True)
         opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_local, 'lr': conf["sh_lr"]}])
         # (the one-shot peer-to-peer exchange is built for the stage-2 bucket: stage 1's 3 V + 1 floats go through RCCL / the torch group)
@@ -440,47 +445,54 @@ def run_ham(vertices, faces, imgs, grayimgs, masks, w2cs, projs, resolution, con
             _, batch_masks = perms1.next()                                              # :195 — the same draw on every rank
             for j in range(batch_masks.shape[0]):
                 loss, galbedo, gsh = sh1.step_sel(albedo, sh_local, ones if batch >= num else batch_masks[j])
-                albedo.grad, sh_local.grad = galbedo.view_as(albedo), gsh
+                albedo.grad, sh_local.grad = galbedo.view_as(albedo), gsh if degree == 3 else gsh * band
                 opt.step()
             if log_every and ep % log_every == 0:
                 history.append(("albedo", ep, float(loss)))
             if check_every and (ep + 1) % check_every == 0:
                 monitor.verify([albedo], "stage-1 albedo after epoch %d" % (ep + 1))
         monitor.verify([albedo], "stage-1 albedo at the end of stage 1")
-        sh_coeffs = torch.zeros(num, 9, dtype=torch.float32, device=dev)               # every rank needs every view's row: stage 2 picks any view
-        sh_coeffs[v0:v1] = sh_local.detach()
-        tdist.all_reduce(sh_coeffs, group=group)
+        sh9 = torch.zeros(num, 9, dtype=torch.float32, device=dev)                     # every rank needs every view's row: stage 2 picks any view
+        sh9[v0:v1] = sh_local.detach()
+        tdist.all_reduce(sh9, group=group)
         albedo = albedo.detach().clone().requires_grad_(True)
         del hs1, sh1
-        sh_fixed = sh_coeffs.detach()
-    elif degree == 3:
+        sh_fixed = sh9.contiguous()
+        sh_coeffs = sh9[:, :d2].contiguous()
+    elif fused_s1:
         # The constant sub-graph of init + stage 1 (:137-148 = :207-218: rasterization, antialiased + normalised normals, validity,
         # start silhouettes) is computed ONCE for all views by HamStage1; the SH least squares of :150-174 then run on it (normal
         # equations accumulated on the GPU, 9 x 9 solves on the host: `init_sh` above — the reference's own per-view host loop — took
         # 2.8 of the 3.0 s of a 48-view run)
         from . import stage1 as s1
         hs1 = s1.HamStage1(vertices.detach(), faces, w2cs, projs, imgs, masks, resolution, conf["sfs_weight"], want_pred_masks=True)
-        init = s1.init_sh(hs1, grayimgs)
-        sh_coeffs = init["sh_coeffs"].clone().requires_grad_(True)                   # :168-170
+        init = s1.init_sh(hs1, grayimgs, degree=degree)
+        sh9 = F.pad(init["sh_coeffs"], (0, 9 - d2)).contiguous().requires_grad_(True)   # :168-170 (the rows in their order-3 form)
         albedo = (torch.zeros_like(vertices) + init["albedo_mean"]).unsqueeze(0).contiguous().requires_grad_(True)   # :175-176
         # ---- stage 1: albedo + SH (:193-240), the fused step (fmhr_amd.stage1.HamStage1): the constant sub-graph and the linear
         # interpolate + antialias operator are built once, an iteration is one C call (two launches), the Adam update of both
         # parameters applied inside it.  `stage1_loss` / `stage1_loss_cached` above are the op-by-op forms the parity tests compare it with.
-        opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh_coeffs, 'lr': conf["sh_lr"]}])
+        opt = optim.Adam([{'params': albedo, 'lr': conf["albedo_lr"]}, {'params': sh9, 'lr': conf["sh_lr"]}])
         perms1 = FixedPerms(perms["stage1"], batch, dev) if (perms or {}).get("stage1") is not None else PermChunks(num, batch, gen, dev)   # (no per-epoch copy, no per-step index kernels)
         for ep in range(int(conf["epoch_albedo"])):
             _, batch_masks = perms1.next()                                              # :195
             for j in range(batch_masks.shape[0]):
-                loss_view, _, _ = hs1.step(albedo, sh_coeffs, sel=None if batch >= num else batch_masks[j], optimizer=opt,
-                                           params=(albedo, sh_coeffs))
+                sel = None if batch >= num else batch_masks[j]
+                if degree == 3:
+                    loss_view, _, _ = hs1.step(albedo, sh9, sel=sel, optimizer=opt, params=(albedo, sh9))
+                else:                                                                   # the step's gradients, the absent bands masked, then Adam
+                    loss_view, galbedo, gsh = hs1.step(albedo, sh9, sel=sel)
+                    albedo.grad, sh9.grad = galbedo.view_as(albedo), gsh * band
+                    opt.step()
             if log_every and ep % log_every == 0:
                 history.append(("albedo", ep, float(loss_view.sum())))
         del hs1
-        sh_fixed = sh_coeffs.detach()
+        sh_fixed = sh9.detach()
+        sh_coeffs = sh9.detach()[:, :d2].contiguous()
     else:
-        # degree 1 / 2 (conf key `degree`; the reference's helpers take it, models/utils.py:188-226): the fused stage-1 kernels
-        # evaluate the order-3 basis and would move the higher bands, so init + stage 1 run op by op on the generic ops (cached
-        # constant sub-graph); stage 2 freezes the SH coefficients (:243) and a zero-padded row IS the lower-degree polynomial
+        # FMHR_STAGE1_OPBYOP=1 (comparison runs; until round 5 the path of degrees 1 / 2): init + stage 1 op by op on the generic ops with
+        # degree-d get_matrix / get_radiance and torch autograd (cached constant sub-graph); stage 2 freezes the SH coefficients (:243) and a
+        # zero-padded row IS the lower-degree polynomial
         init = init_sh(ops, vertices.detach(), faces, imgs, grayimgs, masks, w2cs, projs, resolution, degree)
         sh_coeffs = init["sh_coeffs"].clone().requires_grad_(True)
         albedo = (torch.zeros_like(vertices) + init["albedo_mean"]).unsqueeze(0).contiguous().requires_grad_(True)

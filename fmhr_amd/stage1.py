@@ -147,11 +147,14 @@ class HamStage1:
         return self.loss_view, self.galbedo, self.gsh
 
 
-def init_sh(hs1, grayimgs, nblk=64, group=None, view0=0, n_views_global=None):
+def init_sh(hs1, grayimgs, nblk=64, group=None, view0=0, n_views_global=None, degree=3):
     """(view-sharded: `hs1` holds this rank's views [view0, view0 + hs1.n) of a capture of `n_views_global`, `grayimgs` their gray
     images, `group` the torch.distributed group of the ranks: the per-view solves stay local, the GLOBAL least squares of
     mesh_sfs_optim.py:165-166 and the mean albedo of :172-174 are solved from the all-reduced float64 sums — 55 + 4 numbers —, and the
     start silhouettes, which stage 2 reads for arbitrary views of every batch, are gathered to [n_views_global, H, W] on every rank.)
+    `degree` 1 / 2 (conf key `degree`, models/utils.py:188-226): the design matrix of degree d is the first d^2 columns of the order-3 one
+    (fmhr_amd.utils.get_matrix), so the degree-d least squares IS the leading d^2 x d^2 block of the accumulated normal equations; the
+    returned rows have d^2 entries (`sh_coeffs`, `sh_global`), zero-padded to 9 where a kernel wants the order-3 form.
     The SH least-squares initialisation of mesh_sfs_optim.py:124-174 on the constant sub-graph a HamStage1 already holds (the same
     rasterization / antialiased normals / validity): per-view and global coefficients, the mean albedo.  The reference solves
     [Pv, 9] float64 least-squares problems with np.linalg.lstsq on the host, one view at a time; here the GPU accumulates the normal
@@ -165,11 +168,14 @@ def init_sh(hs1, grayimgs, nblk=64, group=None, view0=0, n_views_global=None):
     call("fmhr_sh_normal_equations", ptr(hs1.normals), ptr(hs1.rast), ptr(hs1.masks), ptr(gray), n, H, W, nblk, ptr(part), st)
     acc = part.sum(1).cpu().numpy()                                   # [n, 55]
     iu = np.triu_indices(9)
+    if degree not in (1, 2, 3):
+        raise RuntimeError("init_sh: degree must be 1, 2 or 3")
+    d2 = degree * degree
 
     def solve(a, view=None):
         G = np.zeros((9, 9))
         G[iu] = a[:45]
-        G = G + np.triu(G, 1).T
+        G = (G + np.triu(G, 1).T)[:d2, :d2]
         # The normal equations square the condition number: they reproduce np.linalg.lstsq on the [Pv, 9] design matrix (the
         # reference, mesh_sfs_optim.py:153-154,165-166) while cond(G) stays far from 1 / eps.  A view whose normals barely span the
         # basis (a flat patch, a handful of valid pixels) is solved the reference's way instead: its valid pixels are gathered and
@@ -180,8 +186,8 @@ def init_sh(hs1, grayimgs, nblk=64, group=None, view0=0, n_views_global=None):
             vn = hs1.normals[view][valid].cpu().numpy()
             if vn.shape[0] > 0:
                 from .utils import get_matrix
-                return np.linalg.lstsq(get_matrix(vn, 3), gray[view][valid].cpu().numpy(), rcond=None)[0]
-        return np.linalg.lstsq(G, a[45:54], rcond=None)[0]
+                return np.linalg.lstsq(get_matrix(vn, degree), gray[view][valid].cpu().numpy(), rcond=None)[0]
+        return np.linalg.lstsq(G, a[45:45 + d2], rcond=None)[0]
     sharded = group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1
     sh_views = np.stack([solve(acc[b], b) for b in range(n)]).astype(np.float32)
     acc_all = acc.sum(0)
@@ -191,8 +197,9 @@ def init_sh(hs1, grayimgs, nblk=64, group=None, view0=0, n_views_global=None):
         acc_all = t.cpu().numpy()
     sh_global = solve(acc_all).astype(np.float32)
     shg = torch.from_numpy(sh_global).to(dev)
+    shg9 = F.pad(shg, (0, 9 - d2)).contiguous()                       # the kernels evaluate the order-3 polynomial: higher bands zero
     part2 = torch.empty(n, nblk, 4, dtype=torch.float64, device=dev)
-    call("fmhr_sh_albedo_sums", ptr(hs1.normals), ptr(hs1.rast), ptr(hs1.masks), ptr(hs1.imgs), ptr(shg), n, H, W, nblk, ptr(part2), st)
+    call("fmhr_sh_albedo_sums", ptr(hs1.normals), ptr(hs1.rast), ptr(hs1.masks), ptr(hs1.imgs), ptr(shg9), n, H, W, nblk, ptr(part2), st)
     tot = part2.sum((0, 1))
     if sharded:
         torch.distributed.all_reduce(tot, group=group)

