@@ -304,3 +304,32 @@ def test_permutation_chunks_are_permutations_and_their_batch_masks():
             runs.append(torch.stack(rows))
         assert torch.equal(runs[0], runs[1])
         assert len({tuple(r.tolist()) for r in runs[0]}) > (1 if num > 1 else 0)
+
+
+def test_permutation_sources_are_deterministic_and_well_formed():
+    """The view-sharded loop relies on every rank drawing the SAME permutations from the same seed (fmhr_amd.pipeline.PermChunks) and on
+    replayed ones (FixedPerms) being handed out unchanged, with batch masks that partition the views (mesh_sfs_optim.py:195,249,255-260)."""
+    from fmhr_amd.pipeline import FixedPerms, PermChunks
+    cpu = torch.device("cpu")
+    a = PermChunks(16, 8, torch.Generator().manual_seed(5), cpu)
+    b = PermChunks(16, 8, torch.Generator().manual_seed(5), cpu)
+    seen = []
+    for _ in range(70):                                              # across a refill of the 64-epoch chunk
+        (pa, ma), (pb, mb) = a.next(), b.next()
+        assert torch.equal(pa, pb) and torch.equal(ma, mb)
+        assert sorted(pa.tolist()) == list(range(16)) and ma.shape == (2, 16)
+        assert torch.equal(ma.sum(0), torch.ones(16, dtype=torch.int32))               # every view in exactly one batch
+        assert sorted(torch.nonzero(ma[0]).flatten().tolist()) == sorted(pa[:8].tolist())
+        seen.append(tuple(pa.tolist()))
+    assert len(set(seen)) > 60                                       # fresh draws, not one permutation repeated
+    c = PermChunks(16, 8, torch.Generator().manual_seed(6), cpu)
+    assert not torch.equal(c.next()[0], torch.tensor(seen[0], dtype=torch.int32))
+    given = [[2, 0, 1, 3, 4], [4, 3, 2, 1, 0]]
+    f = FixedPerms(given, 2, cpu)
+    p0, m0 = f.next()
+    assert p0.tolist() == given[0] and m0.shape == (3, 5) and m0[2].tolist() == [0, 0, 0, 0, 1]   # ragged last batch: view 4 alone
+    assert f.next()[0].tolist() == given[1]
+    with pytest.raises(RuntimeError, match="2 permutations were given"):
+        f.next()
+    with pytest.raises(RuntimeError, match="permutation of range"):
+        FixedPerms([[0, 0, 1]], 2, cpu)
